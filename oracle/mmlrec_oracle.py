@@ -1,0 +1,646 @@
+"""CPU oracle for the MMLRec hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-numpy (float32) restatement of the reference's training step for the five hot-path models:
+multi-field embedding gather -> concat -> expert/gate/tower MLPs -> sigmoid heads -> summed BCE ->
+hand-derived backward (dense [V,E] table gradients) -> dense optimizer.  Every function cites the
+reference file:line (relative to the alipay/MMLRec tree) it restates.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+shipped package never does (it fails loudly when the HIP library is missing instead).
+
+Parity status: PINNED -- tests/test_oracle_golden.py checks this file against fixtures in
+tests/golden/*.npz that were produced by importing and running the unmodified reference
+(tests/golden/make_golden.py).  The reference's own tree holds no tests or golden vectors
+(SURVEY.md section 4), and its arithmetic lives in PyTorch ATen (un-vendored; README pins "PyTorch 1.11.0",
+the fixtures were produced with torch 2.10.0 CPU), so those fixtures are the only pin there is.
+"""
+from __future__ import annotations
+
+import json
+from collections import OrderedDict
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# model description
+# ----------------------------------------------------------------------------------------------
+class Spec:
+    """Static description of one model instance: feature schema + config (model/utils.py:328-431)."""
+
+    def __init__(self, cfg, sparse_names, vocab, dense_names=()):
+        self.cfg = cfg
+        self.mc = cfg["model_config"]
+        self.dc = cfg["data_config"]
+        self.sparse_names = list(sparse_names)
+        self.vocab = [int(v) for v in vocab]
+        self.dense_names = list(dense_names)
+        self.emb = int(self.mc.get("emb", 8))
+        self.F = len(self.sparse_names)
+        self.Nd = len(self.dense_names)
+        self.K0 = self.F * self.emb + self.Nd  # compute_input_dim, basemodel.py:489-508
+        self.model_name = self.mc.get("model_name", "sharedbottom").lower()
+        self.task_name = self.mc.get("task_name", "mtl")
+        self.num_domains = int(self.dc.get("num_domains", 1))
+        # basemodel.py:93-102
+        if self.task_name == "msl":
+            self.T = self.num_domains
+        elif self.task_name == "mtmsl":
+            self.T = len(self.dc["label_columns"])
+        else:
+            self.T = len(self.mc.get("task_names", ["ctr", "ctcvr"]))
+        if self.mc.get("dnn_use_bn", False) or self.mc.get("dnn_dropout", 0) != 0:
+            raise NotImplementedError("oracle covers the hot-path configs only (no BN / dropout)")
+        if self.mc.get("dnn_activation", "relu") != "relu":
+            raise NotImplementedError("oracle covers relu towers only")
+
+    @staticmethod
+    def from_golden(g):
+        cfg = json.loads(str(g["cfg"]))
+        return Spec(cfg, [str(s) for s in g["sparse_names"]], g["vocab"], [str(s) for s in g["dense_names"]])
+
+
+# ----------------------------------------------------------------------------------------------
+# K1: multi-field gather + concat
+# ----------------------------------------------------------------------------------------------
+def gather_dnn_input(spec, params, X):
+    """input_from_feature_columns (model/basemodel.py:461-487) + combined_dnn_input (model/utils.py:434-446).
+
+    idx = X[:, f].long() truncates toward zero (basemodel.py:476); out[b, f*E:(f+1)*E] = table_f[idx];
+    dense columns follow the sparse block unchanged.  Bit-exact copy semantics.
+    """
+    X = np.asarray(X, dtype=F32)
+    B = X.shape[0]
+    E = spec.emb
+    out = np.empty((B, spec.K0), dtype=F32)
+    idx_all = np.trunc(X[:, :spec.F]).astype(np.int64)
+    for f, name in enumerate(spec.sparse_names):
+        tab = params[f"embedding_dict.{name}.weight"]
+        idx = idx_all[:, f]
+        if idx.min() < 0 or idx.max() >= tab.shape[0]:
+            raise IndexError(f"index out of range in field {name}")  # nn.Embedding raises IndexError on CPU
+        out[:, f * E:(f + 1) * E] = tab[idx]
+    if spec.Nd:
+        out[:, spec.F * E:] = X[:, spec.F:spec.F + spec.Nd]
+    return out, idx_all
+
+
+def scatter_table_grads(spec, d_dnn_input, idx_all, params):
+    """embedding_dense_backward triggered by sparse=False (model/basemodel.py:122, model/utils.py:476):
+    gradW_f = zeros[V_f,E]; gradW_f[idx] += g[:, f*E:(f+1)*E] with duplicates accumulating in batch order."""
+    E = spec.emb
+    grads = {}
+    for f, name in enumerate(spec.sparse_names):
+        key = f"embedding_dict.{name}.weight"
+        g = np.zeros_like(params[key], dtype=F32)
+        np.add.at(g, idx_all[:, f], d_dnn_input[:, f * E:(f + 1) * E])
+        grads[key] = g
+    return grads
+
+
+# ----------------------------------------------------------------------------------------------
+# dense building blocks (forward returns what backward needs)
+# ----------------------------------------------------------------------------------------------
+def linear_fwd(x, W, b=None):
+    """nn.Linear: y = x @ W^T + b with W [out,in] (model/utils.py:130, :151)."""
+    y = x @ W.T
+    if b is not None:
+        y = y + b
+    return y.astype(F32, copy=False)
+
+
+def linear_bwd(x, W, dy, has_bias=True):
+    dx = (dy @ W).astype(F32, copy=False)
+    dW = (dy.T @ x).astype(F32, copy=False)
+    db = dy.sum(0).astype(F32) if has_bias else None
+    return dx, dW, db
+
+
+def relu(x):
+    return np.maximum(x, F32(0))
+
+
+def sigmoid(x):
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def softmax_rows(z):
+    m = z.max(1, keepdims=True)
+    e = np.exp(z - m, dtype=F32)
+    return (e / e.sum(1, keepdims=True)).astype(F32)
+
+
+def dnn_fwd(params, prefix, x):
+    """DNN.forward (model/utils.py:146-161): [Linear -> ReLU]* (BN off, dropout 0 in the hot-path configs).
+    Returns output and the list of per-layer (input, output) for backward."""
+    acts = []
+    l = 0
+    h = x
+    while f"{prefix}.linears.{l}.weight" in params:
+        W = params[f"{prefix}.linears.{l}.weight"]
+        b = params[f"{prefix}.linears.{l}.bias"]
+        y = relu(linear_fwd(h, W, b))
+        acts.append((h, y))
+        h = y
+        l += 1
+    if l == 0:
+        raise KeyError(prefix)
+    return h, acts
+
+
+def dnn_bwd(params, prefix, acts, dy, grads):
+    """Backward of dnn_fwd; accumulates into grads[key]; returns d(input)."""
+    for l in range(len(acts) - 1, -1, -1):
+        x, y = acts[l]
+        dz = dy * (y > 0)
+        W = params[f"{prefix}.linears.{l}.weight"]
+        dx, dW, db = linear_bwd(x, W, dz)
+        _acc(grads, f"{prefix}.linears.{l}.weight", dW)
+        _acc(grads, f"{prefix}.linears.{l}.bias", db)
+        dy = dx
+    return dy
+
+
+def _acc(grads, key, val):
+    if key in grads:
+        grads[key] = (grads[key] + val).astype(F32)
+    else:
+        grads[key] = np.asarray(val, dtype=F32)
+
+
+def gate_mix_fwd(logits, experts):
+    """softmax over experts then bmm([B,1,Ne],[B,Ne,H]) (model/mmoe.py:86-88, model/ple.py:139-140)."""
+    p = softmax_rows(logits)
+    mix = np.einsum("be,beh->bh", p, experts).astype(F32)
+    return p, mix
+
+
+def gate_mix_bwd(p, experts, dmix):
+    dexperts = (p[:, :, None] * dmix[:, None, :]).astype(F32)
+    dp = np.einsum("bh,beh->be", dmix, experts).astype(F32)
+    dlogits = (p * (dp - (p * dp).sum(1, keepdims=True))).astype(F32)
+    return dlogits, dexperts
+
+
+# ----------------------------------------------------------------------------------------------
+# heads + loss
+# ----------------------------------------------------------------------------------------------
+def head_fwd(params, t, h, w_key):
+    """Linear(H->1, bias=False) then PredictionLayer: sigmoid(x + bias) (model/utils.py:242-248)."""
+    logit = linear_fwd(h, params[w_key]) + params[f"out.{t}.bias"]
+    return sigmoid(logit[:, 0])
+
+
+def bce_sum(p, y):
+    """F.binary_cross_entropy(reduction='sum') (model/basemodel.py:294-296): log terms clamped at -100."""
+    lp = np.maximum(np.log(p, dtype=F32), F32(-100))
+    l1p = np.maximum(np.log1p(-p, dtype=F32), F32(-100))
+    return float((-(y * lp + (F32(1) - y) * l1p)).astype(np.float64).sum())
+
+
+def bce_sigmoid_bwd(p, y):
+    """d loss / d logit: BCE backward (p-y)/max(p(1-p),1e-12) times sigmoid' p(1-p)."""
+    pq = p * (F32(1) - p)
+    return ((p - y) / np.maximum(pq, F32(1e-12)) * pq).astype(F32)
+
+
+def apply_mask(spec, y_pred, mask):
+    """output * domain_mask[:, i] (msl) or [:, i % D] (mtmsl) (model/mmoe.py:101-106)."""
+    if mask is None or spec.task_name not in ("msl", "mtmsl"):
+        return y_pred
+    out = y_pred.copy()
+    for i in range(spec.T):
+        j = i if spec.task_name == "msl" else i % spec.num_domains
+        out[:, i] = out[:, i] * mask[:, j]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# model forwards / backwards.  Each forward returns (probabilities [B,T], cache); each backward takes
+# dlogit [B,T] and returns (grads of dense params, d dnn_input).
+# ----------------------------------------------------------------------------------------------
+def _towers_fwd(spec, params, streams):
+    """tower DNN + final layer + PredictionLayer per task (model/mmoe.py:91-108, sharedbottom.py:58-76)."""
+    T = spec.T
+    has_tower = "tower_dnn.0.linears.0.weight" in params
+    ps, cache = [], []
+    for t in range(T):
+        if has_tower:
+            h, acts = dnn_fwd(params, f"tower_dnn.{t}", streams[t])
+        else:
+            h, acts = streams[t], []
+        ps.append(head_fwd(params, t, h, f"tower_dnn_final_layer.{t}.weight"))
+        cache.append((h, acts))
+    return np.stack(ps, 1).astype(F32), cache
+
+
+def _towers_bwd(spec, params, cache, dlogit, grads):
+    dstreams = []
+    for t in range(spec.T):
+        h, acts = cache[t]
+        dz = dlogit[:, t:t + 1]
+        W = params[f"tower_dnn_final_layer.{t}.weight"]
+        _acc(grads, f"out.{t}.bias", dz.sum(0))
+        dh, dW, _ = linear_bwd(h, W, dz, has_bias=False)
+        _acc(grads, f"tower_dnn_final_layer.{t}.weight", dW)
+        if acts:
+            dh = dnn_bwd(params, f"tower_dnn.{t}", acts, dh, grads)
+        dstreams.append(dh)
+    return dstreams
+
+
+def sharedbottom_fwd(spec, params, x):
+    """SharedBottom.forward (model/sharedbottom.py:52-86)."""
+    bottom, acts = dnn_fwd(params, "bottom_dnn", x)
+    p, tc = _towers_fwd(spec, params, [bottom] * spec.T)
+    layers = {"shared_bottom_outputs": bottom}
+    if tc[0][1]:
+        layers["tower_outputs"] = np.stack([c[0] for c in tc], 1)
+    return p, dict(acts=acts, towers=tc, layers=layers)
+
+
+def sharedbottom_bwd(spec, params, cache, dlogit):
+    grads = {}
+    ds = _towers_bwd(spec, params, cache["towers"], dlogit, grads)
+    dbottom = sum(ds).astype(F32)
+    dx = dnn_bwd(params, "bottom_dnn", cache["acts"], dbottom, grads)
+    return grads, dx
+
+
+def mmoe_fwd(spec, params, x):
+    """MMOE.forward (model/mmoe.py:65-119)."""
+    Ne = int(spec.mc.get("num_experts", 4))
+    eo, eacts = [], []
+    for e in range(Ne):
+        h, a = dnn_fwd(params, f"expert_dnn.{e}", x)
+        eo.append(h)
+        eacts.append(a)
+    experts = np.stack(eo, 1)  # [B,Ne,H]
+    has_gate_dnn = "gate_dnn.0.linears.0.weight" in params
+    gates, mixes = [], []
+    for t in range(spec.T):
+        if has_gate_dnn:
+            g, gacts = dnn_fwd(params, f"gate_dnn.{t}", x)
+        else:
+            g, gacts = x, []
+        logits = linear_fwd(g, params[f"gate_dnn_final_layer.{t}.weight"])
+        p, mix = gate_mix_fwd(logits, experts)
+        gates.append((g, gacts, p))
+        mixes.append(mix)
+    probs, tc = _towers_fwd(spec, params, mixes)
+    layers = {"expert_outputs": experts, "mmoe_outputs": np.stack(mixes, 1),
+              "gate_outputs": np.stack([g[2] for g in gates], 1)}
+    if tc[0][1]:
+        layers["tower_outputs"] = np.stack([c[0] for c in tc], 1)
+    return probs, dict(x=x, experts=experts, eacts=eacts, gates=gates, towers=tc, layers=layers)
+
+
+def mmoe_bwd(spec, params, cache, dlogit):
+    grads = {}
+    Ne = cache["experts"].shape[1]
+    dmix = _towers_bwd(spec, params, cache["towers"], dlogit, grads)
+    dexperts = np.zeros_like(cache["experts"])
+    dx = np.zeros_like(cache["x"])
+    for t in range(spec.T):
+        g, gacts, p = cache["gates"][t]
+        dlogits, de = gate_mix_bwd(p, cache["experts"], dmix[t])
+        dexperts += de
+        W = params[f"gate_dnn_final_layer.{t}.weight"]
+        dg, dW, _ = linear_bwd(g, W, dlogits, has_bias=False)
+        _acc(grads, f"gate_dnn_final_layer.{t}.weight", dW)
+        if gacts:
+            dx += dnn_bwd(params, f"gate_dnn.{t}", gacts, dg, grads)
+        else:
+            dx += dg
+    for e in range(Ne):
+        dx += dnn_bwd(params, f"expert_dnn.{e}", cache["eacts"][e], dexperts[:, e], grads)
+    return grads, dx.astype(F32)
+
+
+def ple_fwd(spec, params, x):
+    """PLE.forward / cgc_net (model/ple.py:107-198).  Quirks kept: `specific_expert_num` shared
+    experts are constructed but only `shared_expert_num` are used (ple.py:47 vs :120-121); the last level's
+    shared gate output is never consumed."""
+    T = spec.T
+    S = int(spec.mc.get("specific_expert_num", 3))
+    Sh = int(spec.mc.get("shared_expert_num", 1))
+    L = int(spec.mc.get("num_levels", 1))
+    has_gate_dnn = "specific_gate_dnn.0.0.0.linears.0.weight" in params
+    inputs = [x] * (T + 1)
+    levels = []
+    outs_per_level = []
+    for lv in range(L):
+        spec_out, spec_acts = [], []
+        for i in range(T):
+            for j in range(S):
+                h, a = dnn_fwd(params, f"specific_experts.{lv}.{i}.{j}", inputs[i])
+                spec_out.append(h)
+                spec_acts.append(a)
+        sh_out, sh_acts = [], []
+        for k in range(Sh):
+            h, a = dnn_fwd(params, f"shared_experts.{lv}.0.{k}", inputs[-1])
+            sh_out.append(h)
+            sh_acts.append(a)
+        gates = []
+        outs = []
+        for i in range(T + 1):
+            if i < T:
+                ex = np.stack(spec_out[i * S:(i + 1) * S] + sh_out, 1)
+                gpre = f"specific_gate_dnn.{lv}.{i}.0"
+                fkey = f"specific_gate_dnn_final_layer.{lv}.{i}.weight"
+            else:
+                ex = np.stack(spec_out + sh_out, 1)
+                gpre = f"shared_gate_dnn.{lv}"
+                fkey = f"shared_gate_dnn_final_layer.{lv}.weight"
+            if has_gate_dnn:
+                g, gacts = dnn_fwd(params, gpre, inputs[i])
+            else:
+                g, gacts = inputs[i], []
+            p, mix = gate_mix_fwd(linear_fwd(g, params[fkey]), ex)
+            gates.append((g, gacts, p, ex, gpre, fkey))
+            outs.append(mix)
+        levels.append(dict(inputs=inputs, spec_acts=spec_acts, sh_acts=sh_acts, gates=gates))
+        outs_per_level.append(np.stack(outs, 1))
+        inputs = outs
+    probs, tc = _towers_fwd(spec, params, inputs[:T])
+    layers = {f"ple_output_{i}": o for i, o in enumerate(outs_per_level)}
+    if tc[0][1]:
+        layers["tower_outputs"] = np.stack([c[0] for c in tc], 1)
+    return probs, dict(levels=levels, towers=tc, layers=layers, T=T, S=S, Sh=Sh)
+
+
+def ple_bwd(spec, params, cache, dlogit):
+    grads = {}
+    T, S, Sh = cache["T"], cache["S"], cache["Sh"]
+    dstreams = _towers_bwd(spec, params, cache["towers"], dlogit, grads) + [None]
+    for lv in range(len(cache["levels"]) - 1, -1, -1):
+        L = cache["levels"][lv]
+        inputs = L["inputs"]
+        dinputs = [np.zeros_like(inputs[0]) for _ in range(T + 1)]
+        dspec = [None] * (T * S)
+        dsh = [None] * Sh
+
+        def add(lst, i, v):
+            lst[i] = v if lst[i] is None else (lst[i] + v).astype(F32)
+
+        for i in range(T + 1):
+            if dstreams[i] is None:  # last level's shared gate: output unused (ple.py:146-152)
+                continue
+            g, gacts, p, ex, gpre, fkey = L["gates"][i]
+            dlogits, de = gate_mix_bwd(p, ex, dstreams[i])
+            if i < T:
+                for j in range(S):
+                    add(dspec, i * S + j, de[:, j])
+                for k in range(Sh):
+                    add(dsh, k, de[:, S + k])
+            else:
+                for j in range(T * S):
+                    add(dspec, j, de[:, j])
+                for k in range(Sh):
+                    add(dsh, k, de[:, T * S + k])
+            dg, dW, _ = linear_bwd(g, params[fkey], dlogits, has_bias=False)
+            _acc(grads, fkey, dW)
+            if gacts:
+                dinputs[i] += dnn_bwd(params, gpre, gacts, dg, grads)
+            else:
+                dinputs[i] += dg
+        for i in range(T):
+            for j in range(S):
+                if dspec[i * S + j] is not None:
+                    dinputs[i] += dnn_bwd(params, f"specific_experts.{lv}.{i}.{j}", L["spec_acts"][i * S + j],
+                                          dspec[i * S + j], grads)
+        for k in range(Sh):
+            if dsh[k] is not None:
+                dinputs[T] += dnn_bwd(params, f"shared_experts.{lv}.0.{k}", L["sh_acts"][k], dsh[k], grads)
+        dstreams = dinputs
+    dx = sum(dstreams).astype(F32)  # level-0 inputs are all dnn_input (ple.py:161)
+    return grads, dx
+
+
+def _star_w(params, frozen, pfx, li, d, T):
+    """SharedSpecificLinear (model/utils.py:163-223): only the LAST domain's specific weight is a registered
+    parameter; domains d < T-1 use frozen tensors."""
+    if d == T - 1:
+        return params[f"{pfx}.{li}.specific_weight"], params[f"{pfx}.{li}.specific_bias"]
+    return frozen[f"{pfx}.{li}.specific_weights.{d}"], frozen[f"{pfx}.{li}.specific_biases.{d}"]
+
+
+def star_fwd(spec, params, x, frozen):
+    """STAR.forward (model/star.py:39-80): h = relu(h @ (Wspec_i * Wsh) + bspec_i + bsh) per layer,
+    then the per-head final star layer [H->1] and PredictionLayer.  Weights are stored [in,out]."""
+    T = spec.T
+    nl = len(spec.mc.get("dnn_hidden_units", [256, 128]))
+    ps, heads = [], []
+    star_layers = [[None] * T for _ in range(nl)]
+    for i in range(T):
+        h = x
+        acts = []
+        for j in range(nl):
+            ws, bs = _star_w(params, frozen, "linears", j, i, T)
+            wsh, bsh = params[f"linears.{j}.shared_weight"], params[f"linears.{j}.shared_bias"]
+            y = relu((h @ (ws * wsh) + bs + bsh).astype(F32))
+            acts.append((h, y, ws))
+            star_layers[j][i] = y
+            h = y
+        ws, bs = _star_w(params, frozen, "final_layers", i, i, T)
+        wsh, bsh = params[f"final_layers.{i}.shared_weight"], params[f"final_layers.{i}.shared_bias"]
+        logit = (h @ (ws * wsh) + bs + bsh).astype(F32) + params[f"out.{i}.bias"]
+        ps.append(sigmoid(logit[:, 0]))
+        heads.append((h, acts, ws))
+    layers = {f"star_output_{j}": np.stack(star_layers[j], 1) for j in range(nl)}
+    return np.stack(ps, 1).astype(F32), dict(heads=heads, layers=layers, x=x)
+
+
+def star_bwd(spec, params, cache, dlogit):
+    grads = {}
+    T = spec.T
+    dx = np.zeros_like(cache["x"])
+    for i in range(T):
+        h, acts, ws_f = cache["heads"][i]
+        dz = dlogit[:, i:i + 1]
+        _acc(grads, f"out.{i}.bias", dz.sum(0))
+        wsh = params[f"final_layers.{i}.shared_weight"]
+        dWeff = (h.T @ dz).astype(F32)
+        _acc(grads, f"final_layers.{i}.shared_weight", dWeff * ws_f)
+        _acc(grads, f"final_layers.{i}.shared_bias", dz.sum(0))
+        if i == T - 1:
+            _acc(grads, f"final_layers.{i}.specific_weight", dWeff * wsh)
+            _acc(grads, f"final_layers.{i}.specific_bias", dz.sum(0))
+        dh = (dz @ (ws_f * wsh).T).astype(F32)
+        for j in range(len(acts) - 1, -1, -1):
+            xin, y, ws = acts[j]
+            wsh = params[f"linears.{j}.shared_weight"]
+            dzz = dh * (y > 0)
+            dWeff = (xin.T @ dzz).astype(F32)
+            _acc(grads, f"linears.{j}.shared_weight", dWeff * ws)
+            _acc(grads, f"linears.{j}.shared_bias", dzz.sum(0))
+            if i == T - 1:
+                _acc(grads, f"linears.{j}.specific_weight", dWeff * wsh)
+                _acc(grads, f"linears.{j}.specific_bias", dzz.sum(0))
+            dh = (dzz @ (ws * wsh).T).astype(F32)
+        dx += dh
+    return grads, dx.astype(F32)
+
+
+def _gatenn_fwd(params, pfx, gin):
+    """GateNN (model/pepnet.py:8-32): 2 * sigmoid(Linear(relu(Linear(x))))."""
+    h1 = relu(linear_fwd(gin, params[f"{pfx}.gate.0.weight"], params[f"{pfx}.gate.0.bias"]))
+    s = sigmoid(linear_fwd(h1, params[f"{pfx}.gate.2.weight"], params[f"{pfx}.gate.2.bias"]))
+    return (F32(2) * s).astype(F32), (gin, h1, s)
+
+
+def _gatenn_bwd(params, pfx, c, dgw, grads):
+    gin, h1, s = c
+    dz2 = (F32(2) * dgw * s * (F32(1) - s)).astype(F32)
+    dh1, dW2, db2 = linear_bwd(h1, params[f"{pfx}.gate.2.weight"], dz2)
+    _acc(grads, f"{pfx}.gate.2.weight", dW2)
+    _acc(grads, f"{pfx}.gate.2.bias", db2)
+    dz1 = dh1 * (h1 > 0)
+    _, dW1, db1 = linear_bwd(gin, params[f"{pfx}.gate.0.weight"], dz1)  # gate input is detached
+    _acc(grads, f"{pfx}.gate.0.weight", dW1)
+    _acc(grads, f"{pfx}.gate.0.bias", db1)
+
+
+def pepnet_fwd(spec, params, x):
+    """PepNet.forward (model/pepnet.py:121-157) with user_sf/item_sf empty: task_sf_emb = scene_emb."""
+    E = spec.emb
+    scene_pos = spec.sparse_names.index(spec.dc["scene_feature"])  # pepnet.py:97,:126 (offset == position)
+    scene = x[:, scene_pos * E:(scene_pos + 1) * E]
+    fg, fgc = _gatenn_fwd(params, "feature_gate", np.concatenate([x, scene], 1))
+    x2 = (fg * x).astype(F32)
+    gin = np.concatenate([x2, scene], 1)
+    nl = len(spec.mc.get("dnn_hidden_units", [256, 128]))
+    ps, tasks = [], []
+    for t in range(spec.T):
+        h = x2
+        lay = []
+        for l in range(nl + 1):
+            gw, gc = _gatenn_fwd(params, f"ppn.{t}.gate_layers.{l}", gin)
+            hin = (h * gw).astype(F32)
+            if l < nl:
+                y = relu(linear_fwd(hin, params[f"ppn.{t}.mlp_layers.{l}.0.weight"],
+                                    params[f"ppn.{t}.mlp_layers.{l}.0.bias"]))
+            else:
+                y = linear_fwd(hin, params[f"ppn.{t}.mlp_layers.{l}.weight"], params[f"ppn.{t}.mlp_layers.{l}.bias"])
+            lay.append((h, gw, gc, hin, y))
+            h = y
+        ps.append(sigmoid((h + params[f"out.{t}.bias"])[:, 0]))
+        tasks.append(lay)
+    return np.stack(ps, 1).astype(F32), dict(x=x, fg=fg, fgc=fgc, x2=x2, tasks=tasks, nl=nl, layers={})
+
+
+def pepnet_bwd(spec, params, cache, dlogit):
+    grads = {}
+    nl = cache["nl"]
+    dx2 = np.zeros_like(cache["x2"])
+    for t in range(spec.T):
+        dy = dlogit[:, t:t + 1]
+        _acc(grads, f"out.{t}.bias", dy.sum(0))
+        for l in range(nl, -1, -1):
+            h, gw, gc, hin, y = cache["tasks"][t][l]
+            if l < nl:
+                wk, bk = f"ppn.{t}.mlp_layers.{l}.0.weight", f"ppn.{t}.mlp_layers.{l}.0.bias"
+                dz = dy * (y > 0)
+            else:
+                wk, bk = f"ppn.{t}.mlp_layers.{l}.weight", f"ppn.{t}.mlp_layers.{l}.bias"
+                dz = dy
+            dhin, dW, db = linear_bwd(hin, params[wk], dz)
+            _acc(grads, wk, dW)
+            _acc(grads, bk, db)
+            _gatenn_bwd(params, f"ppn.{t}.gate_layers.{l}", gc, (dhin * h).astype(F32), grads)
+            dy = (dhin * gw).astype(F32)
+        dx2 += dy
+    _gatenn_bwd(params, "feature_gate", cache["fgc"], (dx2 * cache["x"]).astype(F32), grads)
+    dx = (dx2 * cache["fg"]).astype(F32)
+    return grads, dx
+
+
+_FWD = {"sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+
+
+def forward(spec, params, X, mask=None, frozen=None):
+    """model(X, domain_mask) -> probabilities [B,T]; also returns the cache for backward and the
+    save_layer_output tensors (e.g. model/mmoe.py:110-118)."""
+    x, idx = gather_dnn_input(spec, params, X)
+    if spec.model_name == "star":
+        p, cache = star_fwd(spec, params, x, frozen)
+    else:
+        p, cache = _FWD[spec.model_name](spec, params, x)
+    cache["dnn_input"] = x
+    cache["idx"] = idx
+    cache["p"] = p
+    return apply_mask(spec, p, mask), cache
+
+
+def loss_and_grads(spec, params, X, y, frozen=None):
+    """One pure reference step without the optimizer (model/basemodel.py:268-312, mask=None per SURVEY D3):
+    returns (sum-BCE loss, {state_dict key: gradient})."""
+    y = np.asarray(y, dtype=F32)
+    p, cache = forward(spec, params, X, None, frozen)
+    loss = sum(bce_sum(p[:, t], y[:, t]) for t in range(spec.T))
+    dlogit = bce_sigmoid_bwd(p, y)
+    if spec.model_name == "star":
+        grads, dx = star_bwd(spec, params, cache, dlogit)
+    else:
+        grads, dx = _BWD[spec.model_name](spec, params, cache, dlogit)
+    grads.update(scatter_table_grads(spec, dx, cache["idx"], params))
+    cache["d_dnn_input"] = dx
+    return loss, grads, cache
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizers: torch.optim defaults, dense over every parameter (model/basemodel.py:569-584)
+# ----------------------------------------------------------------------------------------------
+class DenseOptimizer:
+    def __init__(self, kind, lr):
+        self.kind, self.lr, self.t = kind, F32(lr), 0
+        self.state = {}
+
+    def step(self, params, grads):
+        """In-place update of params[key] for every key with a gradient (params without grad are skipped
+        like torch.optim does for p.grad is None)."""
+        self.t += 1
+        lr = self.lr
+        for k, g in grads.items():
+            p = params[k]
+            st = self.state.setdefault(k, {})
+            if self.kind == "sgd":
+                p -= lr * g
+            elif self.kind == "adam":  # betas (0.9, 0.999), eps 1e-8, no amsgrad, no weight decay
+                m = st.setdefault("m", np.zeros_like(p))
+                v = st.setdefault("v", np.zeros_like(p))
+                b1, b2 = 0.9, 0.999
+                m *= F32(b1)
+                m += F32(1 - b1) * g
+                v *= F32(b2)
+                v += F32(1 - b2) * g * g
+                bc1 = 1.0 - b1 ** self.t
+                bc2 = 1.0 - b2 ** self.t
+                step_size = F32(float(lr) / bc1)
+                denom = np.sqrt(v) / F32(np.sqrt(bc2)) + F32(1e-8)
+                p -= step_size * (m / denom)
+            elif self.kind == "adagrad":  # lr_decay 0, eps 1e-10, initial accumulator 0
+                s = st.setdefault("sum", np.zeros_like(p))
+                s += g * g
+                p -= lr * g / (np.sqrt(s) + F32(1e-10))
+            elif self.kind == "rmsprop":  # alpha 0.99, eps 1e-8, no momentum
+                sq = st.setdefault("sq", np.zeros_like(p))
+                sq *= F32(0.99)
+                sq += F32(0.01) * g * g
+                p -= lr * g / (np.sqrt(sq) + F32(1e-8))
+            else:
+                raise NotImplementedError(self.kind)  # basemodel.py:581
+
+
+def train_step(spec, params, opt, X, y, frozen=None):
+    """basemodel.py:268-313: forward, summed BCE, backward, dense optimizer step. Returns the loss."""
+    loss, grads, _ = loss_and_grads(spec, params, X, y, frozen)
+    opt.step(params, grads)
+    return loss
+
+
+def params_from_golden(g, prefix="state/"):
+    return OrderedDict((k[len(prefix):], np.array(g[k], dtype=F32)) for k in g.files if k.startswith(prefix))

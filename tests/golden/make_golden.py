@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the unmodified reference (alipay/MMLRec @ /root/reference) on CPU, instantiates the five
+hot-path models on shrunken vocabularies / hidden widths, and dumps inputs + expected outputs as
+compressed .npz fixtures next to this file.  The fixtures are data (inputs, weights, expected
+outputs); no reference source travels.  Everything under tests/ and oracle/ is checked against
+these files; the GPU box never sees /root/reference.
+
+What is captured per case:
+  cfg (json string), vocab, X0..X2 [B,Ftot] f32 (indices carried as floats, basemodel.py:262),
+  mask0 [B,D], y0..y2 [B,T], state/<key> (state_dict after re-drawing weights N(0,0.1)),
+  frozen/<key> (STAR's unregistered per-domain weights, utils.py:181-191),
+  dnn_input, layer/<name> (reference save_layer_output hooks, e.g. mmoe.py:110-118),
+  y_pred, y_pred_masked, loss, grad/<key> (dense [V,E] table grads: sparse=False, basemodel.py:122),
+  adam1/, adam3/, adagrad3/ (parameters after 1 and 3 reference train steps over batches 0..2,
+  basemodel.py:268-313), init_y_pred for the as-constructed (std=1e-4) weights.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import copy
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    raise SystemExit("reference tree not present; goldens are generated in the build container only")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from model.utils import SparseFeat, DenseFeat  # noqa: E402  (reference)
+from model.sharedbottom import SharedBottom  # noqa: E402
+from model.mmoe import MMOE  # noqa: E402
+from model.ple import PLE  # noqa: E402
+from model.star import STAR  # noqa: E402
+from model.pepnet import PepNet  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+B = 64
+
+
+def base_config(task_name, model_name, label_columns, emb, optimizer, lr, **model_kw):
+    cfg = {
+        "data_config": {"data_name": "golden", "label_columns": label_columns, "dense_columns": []},
+        "model_config": {
+            "task_name": task_name, "model_name": model_name, "task": "binary", "emb": emb,
+            "num_experts": 4, "shared_expert_num": 2, "specific_expert_num": 3, "num_levels": 2,
+            "expert_dnn_hidden_units": [32, 16], "dnn_hidden_units": [32, 32],
+            "bottom_dnn_hidden_units": [32, 16], "gate_dnn_hidden_units": [16],
+            "tower_dnn_hidden_units": [16], "l2_reg_linear": 0, "l2_reg_embedding": 0, "l2_reg_dnn": 0,
+            "dnn_use_bn": False, "dnn_dropout": 0.0, "dnn_activation": "relu", "use_cka_loss": False,
+        },
+        "optim_config": {"lr": lr, "optimizer": optimizer,
+                         "loss": ["binary_crossentropy"] * len(label_columns), "metrics": ["auc", "acc"],
+                         "early_stop": 3},
+        "training_config": {"train_batch_size": B, "test_batch_size": B, "epochs": 1},
+        "save_config": {"save_layer_output": False},
+    }
+    cfg["model_config"].update(model_kw)
+    return cfg
+
+
+def make_cases():
+    cases = []
+    # cfg1: SharedBottom / MovieLens shape (configs_mtl/config_movielens.json, model_name->sharedbottom)
+    c = base_config("mtl", "sharedbottom", ["label2", "label3"], 8, "adam", 0.01,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
+    cases.append(dict(name="sharedbottom_ml", cls=SharedBottom, cfg=c,
+                      vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # cfg2: MMoE / KuaiRec shape, E=16 (configs_mtl/config_kuairec.json shape, model_name->mmoe)
+    c = base_config("mtl", "mmoe", ["l1", "l2"], 16, "adam", 0.001,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"],
+                    expert_dnn_hidden_units=[32, 24], gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16])
+    v = [63, 4, 2, 2, 2, 48, 8, 48, 7, 40, 7, 64, 7, 2, 7, 50, 64, 15, 34, 3, 40, 48, 7, 5, 3, 2, 2, 2,
+         2, 2, 64, 80]
+    cases.append(dict(name="mmoe_kuairec", cls=MMOE, cfg=c, vocab=v, nd=0))
+    # cfg3: PLE / Ijcai shape (configs_mtl/config_ijcai.json, model_name->ple)
+    c = base_config("mtl", "ple", ["l1", "l2"], 8, "adam", 0.005,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"],
+                    expert_dnn_hidden_units=[32], gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16])
+    cases.append(dict(name="ple_ijcai", cls=PLE, cfg=c, vocab=[9, 3, 96, 64, 64, 80, 48], nd=0))
+    # cfg4: MMoE msl / AE-30 shape (configs_msl/config_AE.json, model_name->mmoe), scene = last sparse field
+    c = base_config("msl", "mmoe", ["label", "label"], 8, "adam", 0.005,
+                    task_types=["binary", "binary"])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    v = [96, 64, 64] + [48] * 4 + [32] * 8 + [24] * 8 + [10] * 6 + [2]
+    cases.append(dict(name="mmoe_ae30", cls=MMOE, cfg=c, vocab=v, nd=0, scene_last=True))
+    # cfg4 with dense columns (real-AE layout: sparse first then dense, data_utils.py:73-77)
+    c = copy.deepcopy(c)
+    cases.append(dict(name="mmoe_ae30d", cls=MMOE, cfg=c, vocab=v, nd=7, scene_last=True))
+    # cfg5: STAR + PepNet mtmsl / Amazon shape (configs_mtmsl/config_amazon.json)
+    for nm, cls in (("star", STAR), ("pepnet", PepNet)):
+        c = base_config("mtmsl", nm, ["label", "label", "label2", "label2"], 8, "adagrad", 0.01,
+                        task_types=["binary"] * 4)
+        c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                                 "scene_feature": "scene"})
+        cases.append(dict(name=f"{nm}_amazon", cls=cls, cfg=c,
+                          vocab=[2, 12, 23, 96, 64, 64, 48, 2], nd=0, scene_last=True))
+    return cases
+
+
+def feature_columns(case):
+    vocab, emb = case["vocab"], case["cfg"]["model_config"]["emb"]
+    names = [f"s{i}" for i in range(len(vocab))]
+    if case.get("scene_last"):
+        names[-1] = "scene"
+    cols = [SparseFeat(n, vocabulary_size=v, embedding_dim=emb) for n, v in zip(names, vocab)]
+    dn = [f"d{j}" for j in range(case["nd"])]
+    cols += [DenseFeat(n, 1) for n in dn]
+    case["cfg"]["data_config"]["dense_columns"] = dn
+    return cols, names, dn
+
+
+def draw_batch(gen, vocab, nd, T, task_name, num_domains):
+    cols = []
+    for i, v in enumerate(vocab):
+        if i % 3 == 0 and v > 4:  # skewed field: many duplicates inside the batch
+            u = torch.rand(B, generator=gen)
+            idx = torch.floor((v ** u - 1.0)).clamp(0, v - 1).long()
+        else:
+            idx = torch.randint(0, v, (B,), generator=gen)
+        cols.append(idx.float())
+    # force the edge rows 0 and V-1 to appear
+    cols[0][0] = 0.0
+    cols[0][1] = float(vocab[0] - 1)
+    X = torch.stack(cols, 1)
+    if nd:
+        X = torch.cat([X, torch.rand(B, nd, generator=gen)], 1)
+    if task_name == "msl":
+        lab = (torch.rand(B, 1, generator=gen) < 0.4).float()
+        y = lab.repeat(1, num_domains)
+    elif task_name == "mtmsl":
+        a = (torch.rand(B, 1, generator=gen) < 0.4).float()
+        b2 = (torch.rand(B, 1, generator=gen) < 0.3).float()
+        y = torch.cat([a.repeat(1, num_domains), b2.repeat(1, num_domains)], 1)
+    else:
+        y = (torch.rand(B, T, generator=gen) < 0.4).float()
+    return X.float(), y.float()
+
+
+def frozen_star_tensors(model):
+    """STAR keeps all-but-the-last domain's specific weights in plain Python lists (utils.py:181-191)."""
+    out = {}
+    for pfx, mods in (("linears", model.linears), ("final_layers", model.final_layers)):
+        for li, m in enumerate(mods):
+            for d, (w, b) in enumerate(zip(m.specific_weights, m.specific_biases)):
+                out[f"{pfx}.{li}.specific_weights.{d}"] = w.detach().numpy().copy()
+                out[f"{pfx}.{li}.specific_biases.{d}"] = b.detach().numpy().copy()
+    return out
+
+
+def ref_train_step(model, X, y):
+    """The reference's pure step: basemodel.py:268-313 minus logging/metrics."""
+    y_pred = model(X, None).squeeze()
+    model.optim.zero_grad()
+    loss = sum(model.loss_func[i](y_pred[:, i], y[:, i], reduction="sum") for i in range(model.num_tasks))
+    total = loss + model.get_regularization_loss() + model.aux_loss
+    total.backward()
+    model.optim.step()
+    return float(loss.item())
+
+
+def run_case(case):
+    name, cls, cfg = case["name"], case["cls"], case["cfg"]
+    cols, names, dn = feature_columns(case)
+    torch.manual_seed(0)
+    model = cls(cols, device="cpu", config=cfg)
+    T = model.num_tasks
+    D = cfg["data_config"].get("num_domains", 1)
+    task_name = cfg["model_config"]["task_name"]
+    gen = torch.Generator().manual_seed(1)
+    batches = [draw_batch(gen, case["vocab"], case["nd"], T, task_name, D) for _ in range(3)]
+    X0, y0 = batches[0]
+    out = {"cfg": np.array(json.dumps(cfg)), "vocab": np.array(case["vocab"], dtype=np.int64),
+           "sparse_names": np.array(names), "dense_names": np.array(dn)}
+    for i, (X, y) in enumerate(batches):
+        out[f"X{i}"] = X.numpy()
+        out[f"y{i}"] = y.numpy()
+    mask0 = None
+    if task_name in ("msl", "mtmsl"):
+        scene = X0[:, len(case["vocab"]) - 1]
+        mask0 = torch.stack([(scene == v).float() for v in cfg["data_config"]["mask_values"]], 1)
+        out["mask0"] = mask0.numpy()
+
+    # as-constructed weights (init_std=1e-4): outputs are ~0.5, recorded for completeness
+    model.train()
+    with torch.no_grad():
+        yp = model(X0, None)
+    out["init_y_pred"] = yp.numpy()
+
+    # non-trivial weights: re-draw every weight matrix / table N(0, 0.1); biases keep their init
+    g2 = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
+            elif k.startswith("out."):
+                p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
+        if cls is STAR:
+            for mods in (model.linears, model.final_layers):
+                for m in mods:
+                    for w in m.specific_weights:
+                        w.copy_(1.0 + torch.randn(w.shape, generator=g2) * 0.5)
+                    m.shared_weight.copy_(torch.randn(m.shared_weight.shape, generator=g2) * 0.2)
+    state0 = copy.deepcopy(model.state_dict())
+    for k, v in state0.items():
+        out[f"state/{k}"] = v.numpy().copy()
+    if cls is STAR:
+        for k, v in frozen_star_tensors(model).items():
+            out[f"frozen/{k}"] = v
+
+    # forward in eval mode with the layer-output hooks on
+    model.eval()
+    model.update_save(True)
+    with torch.no_grad():
+        yp = model(X0, None)
+        if hasattr(model, "layer_output_dict"):
+            for k, v in model.layer_output_dict.items():
+                out[f"layer/{k}"] = v.numpy().copy()
+        out["y_pred"] = yp.numpy().copy()
+        if mask0 is not None:
+            out["y_pred_masked"] = model(X0, mask0).numpy().copy()
+        sl, dl = model.input_from_feature_columns(X0, model.dnn_feature_columns, model.embedding_dict)
+        from model.utils import combined_dnn_input
+        out["dnn_input"] = combined_dnn_input(sl, dl).numpy().copy()
+    model.update_save(False)
+
+    # loss + gradients of one pure step (no optimizer)
+    model.train()
+    model.compile(cfg["optim_config"]["optimizer"], cfg["optim_config"]["loss"], ["auc", "acc"])
+    model.zero_grad()
+    y_pred = model(X0, None).squeeze()
+    loss = sum(model.loss_func[i](y_pred[:, i], y0[:, i], reduction="sum") for i in range(T))
+    (loss + model.get_regularization_loss() + model.aux_loss).backward()
+    out["loss"] = np.array(loss.item(), dtype=np.float64)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out[f"grad/{k}"] = p.grad.numpy().copy()
+        else:
+            out[f"nograd/{k}"] = np.array(1)
+
+    # optimizer trajectories: 1 and 3 steps of Adam and Adagrad over batches 0,1,2
+    for opt in ("adam", "adagrad"):
+        model.load_state_dict(state0)
+        model.compile(opt, cfg["optim_config"]["loss"], ["auc", "acc"])
+        losses = []
+        for i, (X, y) in enumerate(batches):
+            losses.append(ref_train_step(model, X, y))
+            if (opt == "adam" and i in (0, 2)) or (opt == "adagrad" and i == 2):
+                for k, v in model.state_dict().items():
+                    out[f"{opt}{i + 1}/{k}"] = v.numpy().copy()
+        out[f"{opt}_losses"] = np.array(losses, dtype=np.float64)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB, loss={out['loss']:.6f}, "
+          f"y_pred[0]={out['y_pred'][0]}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    for case in make_cases():
+        run_case(case)

@@ -1,0 +1,80 @@
+"""Pins oracle/mmlrec_oracle.py against fixtures produced by the unmodified reference (tests/golden/make_golden.py)."""
+import numpy as np
+
+from oracle import mmlrec_oracle as orc
+
+RTOL = 1e-4  # north_star: logits / embedding gradients within 1e-4 rel fp32
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def setup(g):
+    spec = orc.Spec.from_golden(g)
+    params = orc.params_from_golden(g)
+    frozen = orc.params_from_golden(g, "frozen/")
+    return spec, params, frozen
+
+
+def test_gather_bit_exact(golden):
+    name, g = golden
+    spec, params, _ = setup(g)
+    out, _ = orc.gather_dnn_input(spec, params, g["X0"])
+    assert out.dtype == np.float32
+    assert np.array_equal(out, g["dnn_input"])  # bit-exact
+
+
+def test_forward_and_layers(golden):
+    name, g = golden
+    spec, params, frozen = setup(g)
+    p, cache = orc.forward(spec, params, g["X0"], None, frozen)
+    assert rel_err(p, g["y_pred"]) < RTOL
+    for k in g.files:
+        if k.startswith("layer/") and k != "layer/dnn_input":
+            assert rel_err(cache["layers"][k[6:]], g[k]) < RTOL, k
+    if "y_pred_masked" in g.files:
+        pm, _ = orc.forward(spec, params, g["X0"], g["mask0"], frozen)
+        assert rel_err(pm, g["y_pred_masked"]) < RTOL
+
+
+def test_loss_and_grads(golden):
+    name, g = golden
+    spec, params, frozen = setup(g)
+    loss, grads, _ = orc.loss_and_grads(spec, params, g["X0"], g["y0"], frozen)
+    assert abs(loss - float(g["loss"])) / float(g["loss"]) < RTOL
+    gold_keys = {k[5:] for k in g.files if k.startswith("grad/")}
+    nograd = {k[7:] for k in g.files if k.startswith("nograd/")}
+    assert set(grads.keys()) == gold_keys, (set(grads) ^ gold_keys)
+    assert not (set(grads.keys()) & nograd)
+    for k in gold_keys:
+        assert grads[k].shape == g["grad/" + k].shape, k
+        assert rel_err(grads[k], g["grad/" + k]) < RTOL, k
+
+
+def test_optimizer_trajectories(golden):
+    name, g = golden
+    spec, _, frozen = setup(g)
+    for kind, checkpoints in (("adam", (1, 3)), ("adagrad", (3,))):
+        params = orc.params_from_golden(g)
+        opt = orc.DenseOptimizer(kind, spec.cfg["optim_config"]["lr"])
+        losses = []
+        for i in range(3):
+            losses.append(orc.train_step(spec, params, opt, g[f"X{i}"], g[f"y{i}"], frozen))
+            if (i + 1) in checkpoints:
+                for k in params:
+                    ref = g[f"{kind}{i + 1}/{k}"]
+                    # parameters move by ~lr per step: compare the UPDATE, not the value
+                    upd_ref = ref.astype(np.float64) - g["state/" + k].astype(np.float64)
+                    upd = params[k].astype(np.float64) - g["state/" + k].astype(np.float64)
+                    scale = max(np.abs(upd_ref).max(), 1e-30)
+                    # Adam/Adagrad divide by sqrt(accumulated g^2)+eps: a gradient at fp32-noise level can flip
+                    # the sign of its whole lr-sized update, so updates are compared robustly (outlier share)
+                    bad = (np.abs(upd - upd_ref) > 0.05 * scale).mean()
+                    assert bad < 1e-3, (kind, i + 1, k, bad)
+                    dv = np.abs(params[k].astype(np.float64) - ref)
+                    assert (dv > RTOL * np.abs(ref).max()).mean() < 1e-3, (kind, i + 1, k)
+                    assert dv.max() <= 2.5 * float(opt.lr) * (i + 1), (kind, i + 1, k)
+        assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL)
