@@ -1,0 +1,276 @@
+/*
+ * mmlrec.h -- C ABI of the MI355X-native MMLRec hot path (libmmlrec_hip.so).
+ *
+ * The reference (alipay/MMLRec) is pure Python/PyTorch and has no FFI of its own: the boundary it
+ * exposes is the nn.Module contract (forward(X, domain_mask) in model/{sharedbottom,mmoe,ple,star,pepnet}.py
+ * driven by BaseModel.fit, model/basemodel.py:261-313).  Everything below that contract is ATen.  This header
+ * declares the entry points that replace those ATen call sites; each one cites the reference lines whose
+ * arithmetic it takes over.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every function returns MML_OK (0) or a negative error code and never throws; mml_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - caller owns every buffer.  Nothing is allocated inside a call; kernels that need scratch take an
+ *     explicit workspace pointer + size and a *_workspace_bytes() query tells how much they need.
+ *   - descriptor arrays (mml_*_desc) live in HOST memory; they are copied into the kernel argument
+ *     block, so no hidden H2D traffic and the calls are hipGraph-capturable.
+ *   - all matrices are fp32 row-major with an explicit leading dimension (elements, not bytes).
+ *   - re-entrant on different streams; no global state besides the thread-local error string.
+ *   - device-side problems (an index outside its table) set bits in an optional int32 status word
+ *     instead of trapping: bit 0 = index < 0, bit 1 = index >= vocab (nn.Embedding raises IndexError
+ *     on CPU for these; the host wrapper turns a non-zero status into the same exception).
+ */
+#ifndef MMLREC_H
+#define MMLREC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MML_OK 0
+#define MML_ERR_ARG (-1)         /* bad argument (null pointer, size out of range, misaligned buffer) */
+#define MML_ERR_HIP (-2)         /* a HIP runtime call failed; see mml_last_error() */
+#define MML_ERR_UNSUPPORTED (-3) /* valid request the library does not implement */
+
+#define MML_MAX_FIELDS 64   /* sparse fields per gather/scatter launch (more: call again with the next slice) */
+#define MML_MAX_GROUP 16    /* GEMM problems per grouped launch */
+#define MML_MAX_SRC 8       /* accumulated sources per dgrad output */
+#define MML_MAX_EXPERTS 16  /* experts visible to one gate group */
+#define MML_MAX_GATES 8     /* gates per gate group */
+#define MML_MAX_HEADS 8     /* prediction heads per head launch */
+#define MML_MAX_OPT_TENSORS 32
+
+typedef void* mml_stream_t; /* hipStream_t */
+
+/* activation / derivative codes */
+#define MML_ACT_NONE 0
+#define MML_ACT_RELU 1
+#define MML_ACT_SIGMOID 2
+#define MML_ACT_SIGMOID2 3 /* 2*sigmoid(x): PepNet GateNN (model/pepnet.py:31-32) */
+
+/* optimizer kinds: torch.optim defaults as used by BaseModel._get_optim (model/basemodel.py:569-584) */
+#define MML_OPT_SGD 0
+#define MML_OPT_ADAM 1
+#define MML_OPT_ADAGRAD 2
+#define MML_OPT_RMSPROP 3
+
+int mml_version(void);
+const char* mml_last_error(void);
+/* out[0]=CU count, [1]=LDS bytes/CU, [2]=total HBM bytes, [3]=wavefront size, [4]=max clock kHz, [5]=gfx arch number */
+int mml_device_caps(int device, int64_t* out6);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  fused multi-field gather + concat.
+ * Replaces BaseModel.input_from_feature_columns (model/basemodel.py:461-487: per field
+ * nn.Embedding(X[:, c].long())) and combined_dnn_input (model/utils.py:434-446: cat + flatten + cat).
+ *   out[b, f*E + e]   = tables[f][trunc(X[b, col[f]]) * E + e]     f < F, e < E   (bit-exact copy)
+ *   out[b, F*E + j]   = X[b, dense_col0 + j]                       j < Nd
+ * X carries indices as fp32 (model/basemodel.py:262, :476) -> exact below 2^24 rows.
+ * tables/vocab/col are HOST arrays of length F (tables holds DEVICE pointers).
+ * ---------------------------------------------------------------------------------------------- */
+int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                   const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
+                   float* out, int64_t ldo, int32_t* status, mml_stream_t stream);
+/* same with native int32 indices idx[b*ldi + f] (additive API for vocabularies >= 2^24);
+ * dense values come from dense[b*ldd + j] (may be null when Nd == 0). */
+int mml_gather_fwd_idx32(const float* const* tables, const int64_t* vocab, int32_t F, int32_t E,
+                         const int32_t* idx, int64_t ldi, const float* dense, int64_t ldd, int32_t Nd, int64_t B,
+                         float* out, int64_t ldo, int32_t* status, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  sparse row-scatter backward of K1.
+ * Replaces aten::embedding_dense_backward triggered by sparse=False (model/basemodel.py:122,
+ * model/utils.py:476):  grad_tables[f][idx[b,f], :] += dOut[b, f*E:(f+1)*E]  (duplicates accumulate).
+ * grad_tables are dense [V_f, E] accumulators owned by the caller (zeroed by the caller, or kept zero
+ * between steps by mml_opt_step_rows).  Duplicate rows inside a workgroup are pre-reduced in LDS before
+ * one float atomic per (row, e) reaches HBM, so the result is order-dependent in the last bits.
+ * If `touched` is non-null the first writer of a row (per-table bitmap `seen[f]`, V_f bits rounded up to
+ * 32) appends the global row id rowbase[f] + idx to touched[0..cap) and bumps *touched_count: the compact row
+ * list the sparse-row optimizer walks.  rowbase is a HOST array of F+1 int64 (exclusive prefix sum of vocab).
+ * ---------------------------------------------------------------------------------------------- */
+int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                    const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
+                    uint32_t* const* seen, const int64_t* rowbase, int32_t* touched, int32_t* touched_count,
+                    int32_t touched_cap, int32_t* status, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  grouped GEMM family on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).
+ * Replaces nn.Linear + activation inside DNN.forward (model/utils.py:146-161: addmm, relu_) and the
+ * autograd mm/mm backward pair of each layer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* A;    /* [M, K] input activations                                  */
+  const float* W;    /* [N, K] nn.Linear weight layout (model/utils.py:130)        */
+  const float* bias; /* [N] or NULL                                                */
+  float* C;          /* [M, N] = act(A W^T + bias)                                 */
+  int64_t lda, ldw, ldc;
+  int32_t M, N, K;
+  int32_t act;       /* MML_ACT_*                                                  */
+  int32_t w_kn;      /* 0: W is [N,K] (nn.Linear); 1: W is [K,N] (STAR SharedSpecificLinear layout, model/utils.py:171) */
+  int32_t pad_;
+} mml_gemm_fwd_desc;
+int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
+
+typedef struct {
+  float* dA;           /* [M, K] = sum_s dC_s W_s  (then * act'(Y) if act != NONE)            */
+  const float* Y;      /* [M, K] forward OUTPUT of the layer that produced A (relu/sigmoid derivative source) or NULL */
+  int64_t ldda, ldy;
+  int32_t M, K;
+  int32_t act;         /* activation whose derivative is applied in the epilogue             */
+  int32_t n_src;
+  int32_t accumulate;  /* 1: dA += result (after the derivative), 0: overwrite                */
+  int32_t pad_;
+  const float* dC[MML_MAX_SRC]; /* [M, N_s] gradients w.r.t. the pre-activation outputs      */
+  const float* W[MML_MAX_SRC];  /* [N_s, K] (w_kn=0) or [K, N_s] (w_kn=1)                     */
+  int64_t lddc[MML_MAX_SRC], ldw[MML_MAX_SRC];
+  int32_t N[MML_MAX_SRC];
+  int32_t w_kn[MML_MAX_SRC];
+} mml_gemm_dgrad_desc;
+int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
+
+typedef struct {
+  const float* dC;  /* [M, N] gradient w.r.t. pre-activation output */
+  const float* A;   /* [M, K] layer input                            */
+  float* dW;        /* [N, K] (w_kn=0) or [K, N] (w_kn=1) = dC^T A   */
+  float* dbias;     /* [N] = column sums of dC, or NULL              */
+  int64_t lddc, lda, lddw;
+  int32_t M, N, K;
+  int32_t accumulate; /* 1: dW/dbias += ; 0: overwrite               */
+  int32_t w_kn;
+  int32_t pad_;
+} mml_gemm_wgrad_desc;
+/* The reduction over the batch is split across workgroups; partial tiles go to `workspace` and are
+ * summed in a fixed order by a second kernel (bitwise reproducible). */
+int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_desc* descs, int32_t n);
+int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* descs, int32_t n, void* workspace, int64_t workspace_bytes,
+                           mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  gate: skinny linear [Gd -> ne] (no bias) + softmax over experts + expert mix.
+ * Replaces gate_dnn_final_layer + softmax + matmul([B,1,Ne],[B,Ne,H]) (model/mmoe.py:80-88,
+ * model/ple.py:127-152).  A group = a list of expert outputs (each [B,H]) and up to MML_MAX_GATES gates, each
+ * mixing a subset of them (MMoE: every gate sees every expert; PLE CGC: task gate t sees its S specific
+ * experts + the shared ones, the shared gate sees all).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* G;   /* [B, Gd] gate-DNN output (or dnn_input when gate_dnn_hidden_units == []) */
+  const float* Wg;  /* [ne, Gd] nn.Linear(bias=False) weight                                   */
+  float* P;         /* [B, ne] softmax(G Wg^T)                                                 */
+  float* mix;       /* [B, H]  sum_e P[:,e] * E_{expert[e]}                                    */
+  /* backward only: */
+  const float* dmix; /* [B, H] gradient of mix                                                 */
+  float* dG;         /* [B, Gd] = (dlogits Wg) (* relu'(G) if g_relu)                          */
+  float* dWg;        /* [ne, Gd] = dlogits^T G                                                 */
+  int64_t ldg, ldp, ldmix, lddmix, lddg;
+  int32_t Gd, ne;
+  int32_t g_relu;    /* 1: G is a ReLU output, fold its derivative into dG                     */
+  int32_t active;    /* backward: 0 = this gate's mix was never consumed (PLE last-level shared gate, model/ple.py:146-152) */
+  int32_t expert[MML_MAX_EXPERTS]; /* indices into the group's expert list                    */
+} mml_gate_desc;
+typedef struct {
+  const float* E[MML_MAX_EXPERTS];  /* expert outputs, each [B, H]                            */
+  float* dE[MML_MAX_EXPERTS];       /* backward: gradient w.r.t. each expert's PRE-activation (relu' folded in when e_relu) */
+  int64_t lde[MML_MAX_EXPERTS], ldde[MML_MAX_EXPERTS];
+  int32_t n_experts, n_gates, H;
+  int32_t e_relu;                   /* experts end in ReLU (always true for DNN, model/utils.py:155-156) */
+  int64_t B;
+  mml_gate_desc gate[MML_MAX_GATES];
+} mml_gate_group;
+int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream);
+int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp);
+int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  prediction heads + loss.
+ * Replaces tower_dnn_final_layer (Linear(H->1, bias=False)), PredictionLayer (x + bias, sigmoid;
+ * model/utils.py:242-248), the optional domain-mask product (model/mmoe.py:101-106) and
+ * sum_t F.binary_cross_entropy(reduction='sum') (model/basemodel.py:294-296) with its backward.
+ * Forward-only (predict): y == NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* Hin;  /* [B, H] tower output (or the stream itself when tower_dnn_hidden_units == []) */
+  const float* w;    /* [H] final-layer weight ([1,H] row, or STAR's [H,1] column: same memory)       */
+  const float* w2;   /* optional second factor multiplied elementwise into w (STAR: specific * shared) or NULL */
+  const float* bias; /* [1] PredictionLayer bias (out.<t>.bias)                                        */
+  const float* bias2;/* optional extra bias terms summed in (STAR shared+specific final biases) or NULL; [n_bias2] */
+  float* dH;         /* [B, H] backward: dlogit * w (* relu'(Hin) if h_relu)                           */
+  float* dw;         /* [H] backward: sum_b dlogit * Hin  (gradient of the EFFECTIVE weight w*w2)      */
+  float* dbias;      /* [1] backward: sum_b dlogit                                                     */
+  int64_t ldh, lddh;
+  int32_t H;
+  int32_t h_relu;
+  int32_t n_bias2;
+  int32_t mask_col;  /* column of `mask` multiplied into the probability, or -1                        */
+} mml_head_desc;
+typedef struct {
+  int32_t n_heads; int32_t pad_;
+  int64_t B;
+  float* prob;        /* [B, ldprob] probabilities, head t in column t                                 */
+  int64_t ldprob;
+  const float* y;     /* [B, ldy] labels or NULL (forward only)                                        */
+  int64_t ldy;
+  const float* mask;  /* [B, ldmask] domain mask or NULL                                               */
+  int64_t ldmask;
+  float* loss;        /* [1] device scalar: sum of BCE over heads and samples (overwritten), or NULL   */
+  mml_head_desc head[MML_MAX_HEADS];
+} mml_head_group;
+int64_t mml_head_workspace_bytes(const mml_head_group* grp);
+int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream);
+/* forward + loss + backward of the heads in one pass (training) */
+int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6/K7  elementwise helpers for STAR / PepNet.
+ *   mul:      out = a * b                                  (STAR W_spec * W_shared, model/utils.py:215;
+ *                                                           PepNet hidden * gate, model/pepnet.py:77, :140)
+ *   mul_bwd:  da (+)= dout * b ; db (+)= dout * a          (either may be NULL = stop-gradient)
+ *   add_n:    out = sum_i in[i]                            (bias sums, gradient fan-in)
+ * ---------------------------------------------------------------------------------------------- */
+int mml_ew_mul(const float* a, const float* b, float* out, int64_t n, mml_stream_t stream);
+int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
+                   int32_t acc_b, int64_t n, mml_stream_t stream);
+int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mml_stream_t stream);
+/* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,
+ * model/pepnet.py:72, :139) */
+int mml_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate,
+               mml_stream_t stream);
+/* dst = act'(y) * dy for MML_ACT_SIGMOID2 / SIGMOID / RELU given the forward OUTPUT y (GateNN backward) */
+int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t n, int32_t act, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  optimizers (torch.optim.{SGD,Adam,Adagrad,RMSprop} defaults; model/basemodel.py:313, :569-584).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float* param; const float* grad; /* [n] */
+  float* state1;                   /* Adam m | Adagrad sum | RMSprop square_avg | SGD unused (NULL) */
+  float* state2;                   /* Adam v | others NULL                                          */
+  int64_t n;
+} mml_opt_tensor;
+typedef struct {
+  int32_t kind;      /* MML_OPT_* */
+  int32_t step;      /* 1-based step number used for Adam bias correction when step_dev == NULL */
+  const int32_t* step_dev; /* optional device counter (hipGraph replay): the kernel reads *step_dev instead */
+  float lr, beta1, beta2, eps, alpha;
+  int32_t zero_grad; /* 1: write zeros over grad after use (keeps dense table-gradient accumulators clean) */
+} mml_opt_hyper;
+/* dense update of up to MML_MAX_OPT_TENSORS whole tensors in one launch (tables included: the reference's
+ * optimizer touches every row of every table every step) */
+int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, const mml_opt_hyper* hyper, mml_stream_t stream);
+/* sparse-row update: only rows listed in touched[0 .. *touched_count) (global row ids over the concatenated
+ * tables; table f owns [rowbase[f], rowbase[f+1])).  Exactly equal to the dense update for SGD and Adagrad
+ * (rows with zero gradient do not move); for Adam/RMSprop it is the "lazy" variant, NOT the reference's result.
+ * Re-zeroes the gradient rows and clears their `seen` bits. */
+int mml_opt_step_rows(float* const* tables, float* const* grad_tables, float* const* state1, float* const* state2,
+                      uint32_t* const* seen, const int64_t* rowbase, int32_t F, int32_t E,
+                      const int32_t* touched, const int32_t* touched_count, int32_t touched_cap,
+                      const mml_opt_hyper* hyper, mml_stream_t stream);
+/* *counter += delta (single thread): Adam step counter, touched-list reset (delta = -*counter when reset != 0) */
+int mml_counter_update(int32_t* counter, int32_t delta, int32_t reset, mml_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMLREC_H */

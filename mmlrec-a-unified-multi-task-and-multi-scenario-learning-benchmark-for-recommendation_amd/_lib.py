@@ -1,0 +1,136 @@
+"""ctypes binding of include/mmlrec.h (libmmlrec_hip.so).  No CPU fallback: if the library is missing the
+import of any compute entry point fails loudly."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_FIELDS, MAX_GROUP, MAX_SRC, MAX_EXPERTS, MAX_GATES, MAX_HEADS, MAX_OPT_TENSORS = 64, 16, 8, 16, 8, 8, 32
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID2 = 0, 1, 2, 3
+OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_RMSPROP = 0, 1, 2, 3
+OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "adagrad": OPT_ADAGRAD, "rmsprop": OPT_RMSPROP}
+
+fp = C.c_void_p  # device pointers travel as integers
+i32, i64 = C.c_int32, C.c_int64
+
+
+class GemmFwdDesc(C.Structure):
+    _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("lda", i64), ("ldw", i64), ("ldc", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32)]
+
+
+class GemmDgradDesc(C.Structure):
+    _fields_ = [("dA", fp), ("Y", fp), ("ldda", i64), ("ldy", i64), ("M", i32), ("K", i32), ("act", i32),
+                ("n_src", i32), ("accumulate", i32), ("pad_", i32),
+                ("dC", fp * MAX_SRC), ("W", fp * MAX_SRC), ("lddc", i64 * MAX_SRC), ("ldw", i64 * MAX_SRC),
+                ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC)]
+
+
+class GemmWgradDesc(C.Structure):
+    _fields_ = [("dC", fp), ("A", fp), ("dW", fp), ("dbias", fp), ("lddc", i64), ("lda", i64), ("lddw", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("accumulate", i32), ("w_kn", i32), ("pad_", i32)]
+
+
+class GateDesc(C.Structure):
+    _fields_ = [("G", fp), ("Wg", fp), ("P", fp), ("mix", fp), ("dmix", fp), ("dG", fp), ("dWg", fp),
+                ("ldg", i64), ("ldp", i64), ("ldmix", i64), ("lddmix", i64), ("lddg", i64),
+                ("Gd", i32), ("ne", i32), ("g_relu", i32), ("active", i32), ("expert", i32 * MAX_EXPERTS)]
+
+
+class GateGroup(C.Structure):
+    _fields_ = [("E", fp * MAX_EXPERTS), ("dE", fp * MAX_EXPERTS), ("lde", i64 * MAX_EXPERTS),
+                ("ldde", i64 * MAX_EXPERTS), ("n_experts", i32), ("n_gates", i32), ("H", i32), ("e_relu", i32),
+                ("B", i64), ("gate", GateDesc * MAX_GATES)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("Hin", fp), ("w", fp), ("w2", fp), ("bias", fp), ("bias2", fp), ("dH", fp), ("dw", fp),
+                ("dbias", fp), ("ldh", i64), ("lddh", i64), ("H", i32), ("h_relu", i32), ("n_bias2", i32),
+                ("mask_col", i32)]
+
+
+class HeadGroup(C.Structure):
+    _fields_ = [("n_heads", i32), ("pad_", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
+                ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("head", HeadDesc * MAX_HEADS)]
+
+
+class OptTensor(C.Structure):
+    _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64)]
+
+
+class OptHyper(C.Structure):
+    _fields_ = [("kind", i32), ("step", i32), ("step_dev", fp), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("zero_grad", i32)]
+
+
+_PP = C.POINTER
+_SIGS = {
+    "mml_version": (C.c_int, []),
+    "mml_last_error": (C.c_char_p, []),
+    "mml_device_caps": (C.c_int, [C.c_int, _PP(i64)]),
+    "mml_gather_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
+    "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
+    "mml_scatter_bwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
+                                  fp, fp, i32, fp, fp]),
+    "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
+    "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
+    "mml_gemm_grouped_wgrad_workspace_bytes": (i64, [_PP(GemmWgradDesc), i32]),
+    "mml_gemm_grouped_wgrad": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, fp]),
+    "mml_gate_mix_fwd": (C.c_int, [_PP(GateGroup), fp]),
+    "mml_gate_mix_bwd_workspace_bytes": (i64, [_PP(GateGroup)]),
+    "mml_gate_mix_bwd": (C.c_int, [_PP(GateGroup), fp, i64, fp]),
+    "mml_head_workspace_bytes": (i64, [_PP(HeadGroup)]),
+    "mml_head_fwd": (C.c_int, [_PP(HeadGroup), fp]),
+    "mml_head_bce_fwd_bwd": (C.c_int, [_PP(HeadGroup), fp, i64, fp]),
+    "mml_ew_mul": (C.c_int, [fp, fp, fp, i64, fp]),
+    "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
+    "mml_ew_add_n": (C.c_int, [_PP(fp), i32, fp, i64, fp]),
+    "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
+    "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
+    "mml_opt_step_dense": (C.c_int, [_PP(OptTensor), i32, _PP(OptHyper), fp]),
+    "mml_opt_step_rows": (C.c_int, [_PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(i64), i32, i32, fp, fp, i32,
+                                    _PP(OptHyper), fp]),
+    "mml_counter_update": (C.c_int, [fp, i32, i32, fp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class MMLError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIBPATH
+
+
+def load():
+    """Load libmmlrec_hip.so (building it first when hipcc is available and the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIBPATH
+    if (not os.path.exists(path) or _build.needs_build()) and os.path.exists(_build.HIPCC):
+        _build.build_library(verbose=False)
+    if not os.path.exists(path):
+        raise MMLError(f"HIP extension {path} is missing and cannot be built (no hipcc): the MI355X path has no "
+                       "CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = library / header out of sync: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mml_last_error()
+        raise MMLError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or None."""
+    return None if t is None else t.data_ptr()

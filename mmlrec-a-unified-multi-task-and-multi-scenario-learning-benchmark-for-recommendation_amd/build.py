@@ -1,0 +1,80 @@
+"""Builds csrc/*.hip into lib/libmmlrec_hip.so for gfx950 with hipcc (no cmake, no JIT cache).
+
+The .so is kept in-tree (git-ignored) so it travels to the GPU box with the snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libmmlrec_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(LIBPATH):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        [os.path.join(os.path.dirname(HERE), "include", "mmlrec.h")]
+    return _newest(deps) > os.path.getmtime(LIBPATH)
+
+
+def build_library(force=False, verbose=True, jobs=None):
+    """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns its path."""
+    if not force and not needs_build():
+        return LIBPATH
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = sources()
+    if not srcs:
+        raise RuntimeError("no HIP sources under " + CSRC)
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    procs, objs = [], []
+    pending = list(srcs)
+    failed = []
+
+    def reap(block):
+        for item in list(procs):
+            p, src = item
+            if block:
+                p.wait()
+            if p.poll() is not None:
+                procs.remove(item)
+                if p.returncode != 0:
+                    failed.append(src)
+
+    while pending or procs:
+        while pending and len(procs) < jobs:
+            src = pending.pop(0)
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+            objs.append(obj)
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print("[mmlrec build]", " ".join(cmd), flush=True)
+            procs.append((subprocess.Popen(cmd), src))
+        reap(block=True)
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    if verbose:
+        print("[mmlrec build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

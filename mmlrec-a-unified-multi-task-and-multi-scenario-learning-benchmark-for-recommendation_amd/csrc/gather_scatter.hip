@@ -1,0 +1,276 @@
+// K1 fused multi-field gather(+dense copy) and K2 sparse row-scatter backward.
+//
+// K1 restates BaseModel.input_from_feature_columns + combined_dnn_input of the reference
+// (model/basemodel.py:461-487, model/utils.py:434-446) as ONE launch for all F fields: the output row
+// dnn_input[b, :] is F*E contiguous floats, so consecutive lanes write consecutive 16-byte pieces (fully
+// coalesced stores) while each lane pulls its piece of a table row with one 16-byte load.  HBM-bound.
+//
+// K2 restates aten::embedding_dense_backward (sparse=False, model/basemodel.py:122): row-granular float
+// atomics into dense [V,E] accumulators, shaped as E contiguous floats per row per wave-instruction.
+#include "common.hpp"
+
+namespace mml {
+
+struct FieldTable {
+  const float* tab[MML_MAX_FIELDS];
+  int64_t vocab[MML_MAX_FIELDS];
+  int32_t col[MML_MAX_FIELDS];
+};
+
+struct GatherArgs {
+  const float* X;      // fp32-encoded indices (+dense values) or null
+  const int32_t* idx;  // native indices or null
+  const float* dense;  // dense values for the idx32 variant
+  int64_t ldX, ldi, ldd;
+  int32_t F, E, dense_col0, Nd;
+  int64_t B;
+  float* out;
+  int64_t ldo;
+  int32_t* status;
+};
+
+// Reference semantics of X[:, c].long(): truncation toward zero (model/basemodel.py:476).
+__device__ __forceinline__ int64_t load_index(const GatherArgs& a, int64_t b, int f, const FieldTable& ft,
+                                              int& bad) {
+  int64_t i;
+  if (a.idx) {
+    i = a.idx[b * a.ldi + f];
+  } else {
+    float v = a.X[b * a.ldX + ft.col[f]];
+    i = (int64_t)v;  // v_cvt: truncates toward zero
+  }
+  const int64_t V = ft.vocab[f];
+  if (i < 0) {
+    bad |= 1;
+    i = 0;
+  } else if (i >= V) {
+    bad |= 2;
+    i = V - 1;
+  }
+  return i;
+}
+
+// One thread = one 16-byte piece of the output row (E % 4 == 0) or one dense scalar.
+// ITEMS independent (index -> row -> store) chains per thread keep several HBM requests in flight per lane.
+template <int ITEMS>
+__global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, const GatherArgs a) {
+  const int e4 = a.E >> 2;
+  const int nvec = a.F * e4;             // 16-byte pieces per sample
+  const int per_sample = nvec + a.Nd;    // + dense scalars
+  const int64_t total = a.B * per_sample;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < total; base += stride * ITEMS) {
+    float4 v[ITEMS];
+    int64_t dst[ITEMS];
+    int kind[ITEMS];  // 0 = skip, 1 = vec4, 2 = dense scalar
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int64_t item = base + (int64_t)i * stride;
+      kind[i] = 0;
+      if (item < total) {
+        const int64_t b = item / per_sample;
+        const int c = (int)(item - b * per_sample);
+        if (c < nvec) {
+          const int f = c / e4;
+          const int part = c - f * e4;
+          const int64_t row = load_index(a, b, f, ft, bad);
+          v[i] = *reinterpret_cast<const float4*>(ft.tab[f] + row * a.E + part * 4);
+          dst[i] = b * a.ldo + (int64_t)c * 4;
+          kind[i] = 1;
+        } else {
+          const int j = c - nvec;
+          v[i].x = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+          dst[i] = b * a.ldo + (int64_t)a.F * a.E + j;
+          kind[i] = 2;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (kind[i] == 1) {
+        *reinterpret_cast<float4*>(a.out + dst[i]) = v[i];
+      } else if (kind[i] == 2) {
+        a.out[dst[i]] = v[i].x;
+      }
+    }
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+// Generic path (E not a multiple of 4, or misaligned buffers): one thread per output float.
+__global__ __launch_bounds__(256) void gather_scalar_kernel(const FieldTable ft, const GatherArgs a) {
+  const int per_sample = a.F * a.E + a.Nd;
+  const int64_t total = a.B * per_sample;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+    const int64_t b = item / per_sample;
+    const int c = (int)(item - b * per_sample);
+    float v;
+    if (c < a.F * a.E) {
+      const int f = c / a.E;
+      const int e = c - f * a.E;
+      const int64_t row = load_index(a, b, f, ft, bad);
+      v = ft.tab[f][row * a.E + e];
+    } else {
+      const int j = c - a.F * a.E;
+      v = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+    }
+    a.out[b * a.ldo + c] = v;
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t stream) {
+  if (a.B == 0) return MML_OK;
+  bool vec = (a.E % 4 == 0) && (a.ldo % 4 == 0) && aligned16(a.out);
+  for (int f = 0; f < a.F && vec; ++f) vec = aligned16(ft.tab[f]);
+  const int threads = 256;
+  if (vec) {
+    constexpr int ITEMS = 4;
+    const int64_t total = a.B * ((int64_t)a.F * (a.E / 4) + a.Nd);
+    int64_t blocks = cdiv(total, (int64_t)threads * ITEMS);
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    hipLaunchKernelGGL(gather_vec4_kernel<ITEMS>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+  } else {
+    const int64_t total = a.B * ((int64_t)a.F * a.E + a.Nd);
+    int64_t blocks = cdiv(total, threads);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+  }
+  return check_launch("mml_gather_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 scatter
+// ------------------------------------------------------------------------------------------------
+struct ScatterArgs {
+  float* gtab[MML_MAX_FIELDS];
+  uint32_t* seen[MML_MAX_FIELDS];
+  int64_t rowbase[MML_MAX_FIELDS];
+  const float* X;
+  int64_t ldX;
+  int64_t B;
+  const float* dOut;
+  int64_t ldo;
+  int32_t F, E;
+  int32_t* touched;
+  int32_t* touched_count;
+  int32_t touched_cap;
+  int32_t* status;
+};
+
+// One lane = one gradient float: lanes run over e fastest, so every wave-instruction reads 256 contiguous
+// bytes of dOut and issues its float atomics as E-float contiguous row segments.
+__global__ __launch_bounds__(256) void scatter_atomic_kernel(const FieldTable ft, const ScatterArgs a) {
+  const int FE = a.F * a.E;
+  const int64_t total = a.B * FE;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+    const int64_t b = item / FE;
+    const int c = (int)(item - b * FE);
+    const int f = c / a.E;
+    const int e = c - f * a.E;
+    const float v = a.X[b * a.ldX + ft.col[f]];
+    int64_t row = (int64_t)v;
+    const int64_t V = ft.vocab[f];
+    if (row < 0) {
+      bad |= 1;
+      continue;
+    }
+    if (row >= V) {
+      bad |= 2;
+      continue;
+    }
+    const float g = a.dOut[b * a.ldo + c];
+    atomicAdd(a.gtab[f] + row * a.E + e, g);
+    if (a.touched && e == 0) {
+      const uint32_t bit = 1u << (row & 31);
+      const uint32_t old = atomicOr(a.seen[f] + (row >> 5), bit);
+      if (!(old & bit)) {
+        const int slot = atomicAdd(a.touched_count, 1);
+        if (slot < a.touched_cap) a.touched[slot] = (int32_t)(a.rowbase[f] + row);
+      }
+    }
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+static int fill_fields(FieldTable& ft, const float* const* tables, const int64_t* vocab, const int32_t* col,
+                       int32_t F, const char* who) {
+  MML_REQUIRE(F >= 0 && F <= MML_MAX_FIELDS, "%s: F=%d outside [0,%d]", who, F, MML_MAX_FIELDS);
+  MML_REQUIRE(F == 0 || (tables && vocab), "%s: null tables/vocab", who);
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(tables[f] != nullptr, "%s: table %d is null", who, f);
+    MML_REQUIRE(vocab[f] > 0, "%s: vocab[%d]=%lld", who, f, (long long)vocab[f]);
+    ft.tab[f] = tables[f];
+    ft.vocab[f] = vocab[f];
+    ft.col[f] = col ? col[f] : f;
+  }
+  return MML_OK;
+}
+
+extern "C" int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                              int32_t E, const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
+                              float* out, int64_t ldo, int32_t* status, mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, tables, vocab, col, F, "mml_gather_fwd");
+  if (rc) return rc;
+  MML_REQUIRE(B >= 0 && E > 0 && Nd >= 0, "mml_gather_fwd: bad sizes B=%lld E=%d Nd=%d", (long long)B, E, Nd);
+  MML_REQUIRE(B == 0 || (X && out), "mml_gather_fwd: null X/out");
+  MML_REQUIRE(ldo >= (int64_t)F * E + Nd, "mml_gather_fwd: ldo=%lld < F*E+Nd", (long long)ldo);
+  GatherArgs a{};
+  a.X = X; a.ldX = ldX; a.F = F; a.E = E; a.dense_col0 = dense_col0; a.Nd = Nd; a.B = B;
+  a.out = out; a.ldo = ldo; a.status = status;
+  return launch_gather(ft, a, to_stream(stream));
+}
+
+extern "C" int mml_gather_fwd_idx32(const float* const* tables, const int64_t* vocab, int32_t F, int32_t E,
+                                    const int32_t* idx, int64_t ldi, const float* dense, int64_t ldd, int32_t Nd,
+                                    int64_t B, float* out, int64_t ldo, int32_t* status, mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, tables, vocab, nullptr, F, "mml_gather_fwd_idx32");
+  if (rc) return rc;
+  MML_REQUIRE(B >= 0 && E > 0 && Nd >= 0, "mml_gather_fwd_idx32: bad sizes");
+  MML_REQUIRE(B == 0 || (idx && out), "mml_gather_fwd_idx32: null idx/out");
+  MML_REQUIRE(Nd == 0 || dense, "mml_gather_fwd_idx32: Nd>0 but dense is null");
+  MML_REQUIRE(ldo >= (int64_t)F * E + Nd, "mml_gather_fwd_idx32: ldo too small");
+  GatherArgs a{};
+  a.idx = idx; a.ldi = ldi; a.dense = dense; a.ldd = ldd; a.F = F; a.E = E; a.Nd = Nd; a.B = B;
+  a.out = out; a.ldo = ldo; a.status = status;
+  return launch_gather(ft, a, to_stream(stream));
+}
+
+extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                               int32_t E, const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
+                               uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
+                               int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, (const float* const*)grad_tables, vocab, col, F, "mml_scatter_bwd");
+  if (rc) return rc;
+  MML_REQUIRE(B >= 0 && E > 0, "mml_scatter_bwd: bad sizes");
+  MML_REQUIRE(B == 0 || (X && dOut), "mml_scatter_bwd: null X/dOut");
+  MML_REQUIRE(!touched || (seen && rowbase && touched_count && touched_cap > 0),
+              "mml_scatter_bwd: touched list needs seen/rowbase/touched_count/cap");
+  if (B == 0 || F == 0) return MML_OK;
+  ScatterArgs a{};
+  for (int f = 0; f < F; ++f) {
+    a.gtab[f] = grad_tables[f];
+    a.seen[f] = touched ? seen[f] : nullptr;
+    a.rowbase[f] = touched ? rowbase[f] : 0;
+    MML_REQUIRE(!touched || seen[f], "mml_scatter_bwd: seen[%d] is null", f);
+  }
+  a.X = X; a.ldX = ldX; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
+  a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
+  const int threads = 256;
+  int64_t blocks = cdiv(B * (int64_t)F * E, threads);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(scatter_atomic_kernel, dim3((unsigned)blocks), dim3(threads), 0, to_stream(stream), ft, a);
+  return check_launch("mml_scatter_bwd");
+}

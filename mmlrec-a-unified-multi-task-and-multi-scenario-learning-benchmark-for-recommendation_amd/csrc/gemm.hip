@@ -1,0 +1,577 @@
+// K3: grouped GEMM family for the expert / gate / tower MLPs on the fp32 MFMA pipe of gfx950.
+//
+// Restates DNN.forward (model/utils.py:146-161: Linear -> ReLU per layer) and the two autograd GEMMs of each
+// layer's backward.  v_mfma_f32_32x32x2_f32 gives exact fp32 products/accumulation (bitwise an fmaf chain), so
+// forward logits stay inside the 1e-4 tolerance the north star asks for without any reduced-precision step.
+//
+// One templated tile engine serves all three roles:
+//   fwd   : C[M,N]  = act(A[M,K] W^T + b)                 rows<-A (reduction-contiguous), cols<-W
+//   dgrad : dA[M,K] = (sum_s dC_s[M,N_s] W_s) * act'(Y)   rows<-dC_s, cols<-W_s, reduction = N_s, summed over s
+//   wgrad : dW[N,K] = dC[M,N]^T A[M,K]                    rows<-dC^T, cols<-A, reduction = batch, split across
+//                                                          workgroups into slabs + fixed-order reduce kernel
+// Block tile 128 x BN (BN = 128 or 64), 4 waves as 2x2, each wave (64 x BN/2) = MI x NI MFMA 32x32 tiles.
+// Operand tiles are staged global -> registers -> LDS with the next tile's global loads in flight during the
+// MFMAs.  An operand whose reduction index is contiguous in memory ("RC") is kept as [row][k] (pitch 36 floats:
+// conflict-free ds_read_b128 per 16-lane group); otherwise as [k][row] (pitch 132) and read with ds_read_b32.
+// k <-> (lane half h, step j) mapping inside an 8-deep group: k = 8q + 4h + j for BOTH operands.
+#include "common.hpp"
+#include "reduce.hpp"
+
+namespace mml {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int PITCH_RC = BK + 4;    // [row][k] layout
+constexpr int PITCH_NRC = 128 + 4;  // [k][row] layout (row extent always 128 slots; BN=64 uses half)
+constexpr int LDS_TILE = 128 * PITCH_RC;  // floats; >= BK * PITCH_NRC (4224 < 4608)
+
+struct Source {
+  const float* A;  // row operand
+  const float* B;  // col operand
+  int64_t lda, ldb;
+  int32_t Kred;    // reduction extent of this source
+  int32_t vecA, vecB;  // 16-byte vector loads legal
+};
+
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_SLAB = 2 };
+
+constexpr int MAX_SOURCES = 24;  // per launch, over all problems (kernel-argument block stays < 4 KiB)
+
+struct Problem {
+  int32_t src0, nsrc;  // sources [src0, src0 + nsrc) of Launch::src
+  int32_t M, N;        // output extent
+  float* C;
+  int64_t ldc;
+  const float* bias;   // fwd
+  const float* Y;      // dgrad derivative source
+  int64_t ldy;
+  int32_t act, accumulate;
+  int32_t tiles_n;     // ceil(N / BN)
+  int32_t tile0;       // first n-tile (fwd/dgrad) or first output tile (wgrad) of this problem in the launch
+  // wgrad only
+  int32_t tiles_m;
+  int32_t bias_cols;   // 0: bias partials are sums of the ROW operand (rows = n); 1: of the COL operand (w_kn)
+  float* bias_slab;    // [S][n] partial sums over the batch of dC, or null
+  int64_t slab_off;    // float offset of this problem's slab in the workspace
+};
+
+struct Launch {
+  Source src[MAX_SOURCES];
+  Problem p[MML_MAX_GROUP];
+  int32_t n;
+  int32_t total_ntiles;  // fwd/dgrad: sum of tiles_n ; wgrad: sum of tiles_m*tiles_n
+  int32_t tiles_m;       // fwd/dgrad: common M tiles
+  int32_t splits;        // wgrad: S
+  int32_t chunk;         // wgrad: batch rows per split (multiple of BK)
+  float* slab;           // wgrad workspace
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == MML_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == MML_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  if (act == MML_ACT_SIGMOID2) return 2.f / (1.f + __expf(-v));
+  return v;
+}
+
+__device__ __forceinline__ float act_bwd(float y, int act) {
+  if (act == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MML_ACT_SIGMOID2) {
+    const float s = 0.5f * y;
+    return 2.f * s * (1.f - s);
+  }
+  return 1.f;
+}
+
+// ---- global -> register tile fetch ---------------------------------------------------------------
+// RC: tile is [ROWS rows][BK k], memory k-contiguous. thread t, piece c: row = (t + 256c) / 8, k4 = (t + 256c) % 8.
+// !RC: tile is [BK k][ROWS rows], memory row-contiguous. row4 = idx % (ROWS/4), k = idx / (ROWS/4).
+template <bool RC, int ROWS>
+__device__ __forceinline__ void fetch_tile(float4 (&r)[ROWS / 32], const float* __restrict__ base, int64_t ld,
+                                           int row0, int nrows, int k0, int kend, bool vec, int tid) {
+  constexpr int PIECES = ROWS / 32;  // float4 per thread: ROWS*BK/4/256
+#pragma unroll
+  for (int c = 0; c < PIECES; ++c) {
+    const int idx = tid + 256 * c;
+    int row, k;
+    if (RC) {
+      row = row0 + idx / (BK / 4);
+      k = k0 + (idx % (BK / 4)) * 4;
+    } else {
+      row = row0 + (idx % (ROWS / 4)) * 4;
+      k = k0 + idx / (ROWS / 4);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RC) {
+      if (row < nrows && k < kend) {
+        const float* p = base + (int64_t)row * ld + k;
+        if (vec && k + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (k + 1 < kend) v.y = p[1];
+          if (k + 2 < kend) v.z = p[2];
+          if (k + 3 < kend) v.w = p[3];
+        }
+      }
+    } else {
+      if (k < kend && row < nrows) {
+        const float* p = base + (int64_t)k * ld + row;
+        if (vec && row + 3 < nrows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (row + 1 < nrows) v.y = p[1];
+          if (row + 2 < nrows) v.z = p[2];
+          if (row + 3 < nrows) v.w = p[3];
+        }
+      }
+    }
+    r[c] = v;
+  }
+}
+
+template <bool RC, int ROWS>
+__device__ __forceinline__ void stash_tile(const float4 (&r)[ROWS / 32], float* lds, int tid) {
+  constexpr int PIECES = ROWS / 32;
+#pragma unroll
+  for (int c = 0; c < PIECES; ++c) {
+    const int idx = tid + 256 * c;
+    if (RC) {
+      const int row = idx / (BK / 4), k4 = idx % (BK / 4);
+      *reinterpret_cast<float4*>(lds + row * PITCH_RC + k4 * 4) = r[c];
+    } else {
+      const int row4 = idx % (ROWS / 4), k = idx / (ROWS / 4);
+      *reinterpret_cast<float4*>(lds + k * PITCH_NRC + row4 * 4) = r[c];
+    }
+  }
+}
+
+// fragment for 8-deep group q: 4 values (j = 0..3) for row `row` (tile-local), lane half h.
+template <bool RC>
+__device__ __forceinline__ float4 read_frag(const float* lds, int row, int q, int h) {
+  if (RC) {
+    return *reinterpret_cast<const float4*>(lds + row * PITCH_RC + q * 8 + h * 4);
+  } else {
+    const float* p = lds + (q * 8 + h * 4) * PITCH_NRC + row;
+    return make_float4(p[0], p[PITCH_NRC], p[2 * PITCH_NRC], p[3 * PITCH_NRC]);
+  }
+}
+
+// ---- the tile engine -------------------------------------------------------------------------------
+// Accumulates sum_s sum_{k in [kbeg_s, kend_s)} rowop_s[row0+i][k] * colop_s[col0+j][k] into acc.
+template <bool ARC, bool BRC, int BN>
+__device__ __forceinline__ void tile_mainloop(f32x16 (&acc)[2][BN / 64], const Launch& L, const Problem& P, int row0,
+                                              int col0, int kbeg, int klen_limit, float* ldsA, float* ldsB,
+                                              float* bias_part /* per-thread partial batch sum of dC, or null */) {
+  constexpr int NI = BN / 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  float4 ra[BM / 32], rb[BN / 32];
+
+  for (int s = 0; s < P.nsrc; ++s) {
+    const Source& S = L.src[P.src0 + s];
+    int k0 = kbeg;
+    int kend = S.Kred;
+    if (klen_limit > 0 && kbeg + klen_limit < kend) kend = kbeg + klen_limit;
+    if (k0 >= kend) continue;
+    fetch_tile<ARC, BM>(ra, S.A, S.lda, row0, P.M, k0, kend, S.vecA, tid);
+    fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0, kend, S.vecB, tid);
+    for (; k0 < kend; k0 += BK) {
+      __syncthreads();  // previous step's LDS reads are done
+      stash_tile<ARC, BM>(ra, ldsA, tid);
+      stash_tile<BRC, BN>(rb, ldsB, tid);
+      __syncthreads();
+      if (k0 + BK < kend) {  // next tile's loads fly during the MFMAs
+        fetch_tile<ARC, BM>(ra, S.A, S.lda, row0, P.M, k0 + BK, kend, S.vecA, tid);
+        fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0 + BK, kend, S.vecB, tid);
+      }
+      if (bias_part != nullptr) {
+        // batch sums of dC over this k-slab (wgrad bias gradient); both operands are in [k][row] layout here
+        const float* src = P.bias_cols ? ldsB : ldsA;
+        if (tid < (P.bias_cols ? BN : BM)) {
+          float sacc = 0.f;
+#pragma unroll 8
+          for (int k = 0; k < BK; ++k) sacc += src[k * PITCH_NRC + tid];
+          *bias_part += sacc;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        float4 fa[2], fb[NI];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fa[mi] = read_frag<ARC>(ldsA, wm * 64 + mi * 32 + l31, q, h);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = read_frag<BRC>(ldsB, wn * (BN / 2) + ni * 32 + l31, q, h);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
+          }
+      }
+    }
+  }
+}
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of
+// virtual tile ids: the n-tiles that re-read one 128-row A panel then hit the same 4 MiB L2.  Bijective for any
+// grid size (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <bool ARC, bool BRC, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const Launch L) {
+  constexpr int NI = BN / 64;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_TILE];
+  float* ldsA = lds;
+  float* ldsB = lds + LDS_TILE;
+
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0, row0, col0, kbeg = 0, klen = 0, split = 0;
+  if (EPI != EPI_SLAB) {
+    const int mt = vid / L.total_ntiles;
+    int j = vid - mt * L.total_ntiles;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    j -= L.p[pi].tile0;
+    row0 = mt * BM;
+    col0 = j * BN;
+  } else {
+    split = vid / L.total_ntiles;
+    int j = vid - split * L.total_ntiles;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    j -= L.p[pi].tile0;
+    row0 = (j / L.p[pi].tiles_n) * BM;
+    col0 = (j % L.p[pi].tiles_n) * BN;
+    kbeg = split * L.chunk;
+    klen = L.chunk;
+  }
+  const Problem& P = L.p[pi];
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  float bsum = 0.f;
+  const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
+  tile_mainloop<ARC, BRC, BN>(acc, L, P, row0, col0, kbeg, klen, ldsA, ldsB, want_bias ? &bsum : nullptr);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  if (EPI == EPI_SLAB) {
+    if (want_bias) {
+      if (!P.bias_cols) {
+        if (tid < BM && row0 + tid < P.M) P.bias_slab[(int64_t)split * P.M + row0 + tid] = bsum;
+      } else {
+        if (tid < BN && col0 + tid < P.N) P.bias_slab[(int64_t)split * P.N + col0 + tid] = bsum;
+      }
+    }
+    float* slab = L.slab + P.slab_off + (int64_t)split * P.M * P.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < P.M && col < P.N) slab[(int64_t)row * P.N + col] = acc[mi][ni][r];
+        }
+      }
+    return;
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
+      if (col >= P.N) continue;
+      float b = 0.f;
+      if (EPI == EPI_FWD && P.bias) b = P.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= P.M) continue;
+        float v = acc[mi][ni][r];
+        float* dst = P.C + (int64_t)row * P.ldc + col;
+        if (EPI == EPI_FWD) {
+          v = act_fwd(v + b, P.act);
+        } else {
+          if (P.act != MML_ACT_NONE) v *= act_bwd(P.Y[(int64_t)row * P.ldy + col], P.act);
+          if (P.accumulate) v += *dst;
+        }
+        *dst = v;
+      }
+    }
+}
+
+static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
+
+template <int EPI>
+static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nblocks, hipStream_t st, const char* who) {
+  if (nblocks <= 0) return MML_OK;
+  if (nblocks > 0x7fffffff) {
+    set_error("%s: grid too large", who);
+    return MML_ERR_ARG;
+  }
+  dim3 g((unsigned)nblocks), b(256);
+#define MML_GO(A_, B_, N_) hipLaunchKernelGGL((gemm_kernel<A_, B_, N_, EPI>), g, b, 0, st, L)
+  if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
+  else if (arc && !brc) { if (bn == 128) MML_GO(true, false, 128); else MML_GO(true, false, 64); }
+  else if (!arc && !brc) { if (bn == 128) MML_GO(false, false, 128); else MML_GO(false, false, 64); }
+  else {
+    set_error("%s: unsupported operand layout", who);
+    return MML_ERR_UNSUPPORTED;
+  }
+#undef MML_GO
+  return check_launch(who);
+}
+
+static int pick_bn(const int32_t* Ns, int n) {
+  for (int i = 0; i < n; ++i)
+    if (Ns[i] % 128 != 0) return 64;
+  return 128;
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");
+  // split into runs of <= MML_MAX_GROUP problems with a uniform weight layout
+  int i = 0;
+  while (i < n) {
+    int j = i;
+    int32_t Ns[MML_MAX_GROUP];
+    Launch L{};
+    while (j < n && j - i < MML_MAX_GROUP && d[j].w_kn == d[i].w_kn && d[j].M == d[i].M) {
+      const mml_gemm_fwd_desc& q = d[j];
+      MML_REQUIRE(q.A && q.W && q.C, "mml_gemm_grouped_fwd: null pointer in problem %d", j);
+      MML_REQUIRE(q.M >= 0 && q.N > 0 && q.K > 0, "mml_gemm_grouped_fwd: bad sizes in problem %d", j);
+      MML_REQUIRE(q.lda >= q.K && q.ldc >= q.N && q.ldw >= (q.w_kn ? q.N : q.K),
+                  "mml_gemm_grouped_fwd: leading dimension too small in problem %d", j);
+      Problem& P = L.p[j - i];
+      P.nsrc = 1;
+      P.src0 = j - i;
+      Source& S0 = L.src[j - i];
+      S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
+      S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
+      P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
+      Ns[j - i] = q.N;
+      ++j;
+    }
+    L.n = j - i;
+    const int bn = pick_bn(Ns, L.n);
+    int t = 0;
+    for (int k = 0; k < L.n; ++k) {
+      L.p[k].tiles_n = (int)cdiv(L.p[k].N, bn);
+      L.p[k].tile0 = t;
+      t += L.p[k].tiles_n;
+    }
+    L.total_ntiles = t;
+    L.tiles_m = (int)cdiv(d[i].M, BM);
+    int rc = launch_tiles<EPI_FWD>(L, true, d[i].w_kn == 0, bn, (int64_t)L.tiles_m * t, to_stream(stream),
+                                   "mml_gemm_grouped_fwd");
+    if (rc) return rc;
+    i = j;
+  }
+  return MML_OK;
+}
+
+extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_dgrad: bad descriptor array");
+  int i = 0;
+  while (i < n) {
+    int j = i;
+    int32_t Ns[MML_MAX_GROUP];
+    Launch L{};
+    const int32_t lay = d[i].n_src > 0 ? d[i].w_kn[0] : 0;
+    int nsources = 0;
+    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) {
+      const mml_gemm_dgrad_desc& q = d[j];
+      MML_REQUIRE(q.dA && q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", j);
+      MML_REQUIRE(q.M >= 0 && q.K > 0 && q.ldda >= q.K, "mml_gemm_grouped_dgrad: bad sizes in problem %d", j);
+      MML_REQUIRE(q.act == MML_ACT_NONE || q.Y, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", j);
+      bool same = true;
+      for (int s = 0; s < q.n_src; ++s) same = same && (q.w_kn[s] == lay);
+      if ((!same || nsources + q.n_src > MAX_SOURCES) && j > i) break;
+      MML_REQUIRE(same, "mml_gemm_grouped_dgrad: mixed weight layouts inside problem %d", j);
+      Problem& P = L.p[j - i];
+      P.nsrc = q.n_src;
+      P.src0 = nsources;
+      for (int s = 0; s < q.n_src; ++s) {
+        MML_REQUIRE(q.dC[s] && q.W[s] && q.N[s] > 0, "mml_gemm_grouped_dgrad: null source %d in problem %d", s, j);
+        Source& S = L.src[nsources++];
+        S.A = q.dC[s]; S.lda = q.lddc[s]; S.B = q.W[s]; S.ldb = q.ldw[s];
+        S.Kred = q.N[s];
+        S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
+      }
+      P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
+      P.accumulate = q.accumulate;
+      Ns[j - i] = q.K;
+      ++j;
+    }
+    L.n = j - i;
+    const int bn = pick_bn(Ns, L.n);
+    int t = 0;
+    for (int k = 0; k < L.n; ++k) {
+      L.p[k].tiles_n = (int)cdiv(L.p[k].N, bn);
+      L.p[k].tile0 = t;
+      t += L.p[k].tiles_n;
+    }
+    L.total_ntiles = t;
+    L.tiles_m = (int)cdiv(d[i].M, BM);
+    // col operand = W: reduction index is W's row for [N,K] (not contiguous) and contiguous for [K,N]
+    int rc = launch_tiles<EPI_DGRAD>(L, true, lay == 1, bn, (int64_t)L.tiles_m * t, to_stream(stream),
+                                     "mml_gemm_grouped_dgrad");
+    if (rc) return rc;
+    i = j;
+  }
+  return MML_OK;
+}
+
+// wgrad planning shared by the workspace query and the launch
+namespace {
+struct WgradPlan {
+  int bn, S, chunk;
+  int64_t total_tiles;
+  int64_t slab_floats;  // all problems, all splits, incl. bias slabs
+};
+WgradPlan plan_wgrad(const mml_gemm_wgrad_desc* d, int i, int j) {
+  WgradPlan w{};
+  int32_t cols[MML_MAX_GROUP];
+  for (int k = i; k < j; ++k) cols[k - i] = d[k].w_kn ? d[k].N : d[k].K;
+  w.bn = pick_bn(cols, j - i);
+  int64_t tiles = 0, out_elems = 0, bias_elems = 0;
+  for (int k = i; k < j; ++k) {
+    const int rows = d[k].w_kn ? d[k].K : d[k].N, cls = d[k].w_kn ? d[k].N : d[k].K;
+    tiles += cdiv(rows, BM) * cdiv(cls, w.bn);
+    out_elems += (int64_t)d[k].N * d[k].K;
+    if (d[k].dbias) bias_elems += d[k].N;
+  }
+  w.total_tiles = tiles;
+  const int64_t M = d[i].M;
+  int64_t S = tiles > 0 ? 1024 / tiles : 1;  // aim at ~4 workgroups per CU
+  const int64_t maxS = cdiv(M, 8 * BK);      // at least 256 batch rows per split
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int64_t chunk = cdiv(cdiv(M, S), BK) * BK;
+  if (chunk < BK) chunk = BK;
+  S = cdiv(M, chunk);
+  if (S < 1) S = 1;
+  w.S = (int)S;
+  w.chunk = (int)chunk;
+  w.slab_floats = S * (out_elems + bias_elems);
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_desc* d, int32_t n) {
+  if (n <= 0 || !d) return 0;
+  int64_t best = 0;
+  int i = 0;
+  while (i < n) {
+    int j = i;
+    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
+    WgradPlan w = plan_wgrad(d, i, j);
+    if (w.slab_floats * 4 > best) best = w.slab_floats * 4;
+    i = j;
+  }
+  return best + 256;
+}
+
+extern "C" int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace,
+                                      int64_t workspace_bytes, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_wgrad: bad descriptor array");
+  if (n == 0) return MML_OK;
+  MML_REQUIRE(workspace && aligned16(workspace), "mml_gemm_grouped_wgrad: workspace null or misaligned");
+  int i = 0;
+  while (i < n) {
+    int j = i;
+    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
+    WgradPlan w = plan_wgrad(d, i, j);
+    MML_REQUIRE(w.slab_floats * 4 <= workspace_bytes, "mml_gemm_grouped_wgrad: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)(w.slab_floats * 4));
+    Launch L{};
+    ReduceLaunch R{};
+    L.n = j - i;
+    L.splits = w.S;
+    L.chunk = w.chunk;
+    L.slab = static_cast<float*>(workspace);
+    int64_t off = 0, rstart = 0;
+    int t = 0;
+    for (int k = i; k < j; ++k) {
+      const mml_gemm_wgrad_desc& q = d[k];
+      MML_REQUIRE(q.dC && q.A && q.dW, "mml_gemm_grouped_wgrad: null pointer in problem %d", k);
+      MML_REQUIRE(q.M >= 0 && q.N > 0 && q.K > 0, "mml_gemm_grouped_wgrad: bad sizes in problem %d", k);
+      MML_REQUIRE(q.lddc >= q.N && q.lda >= q.K && q.lddw >= (q.w_kn ? q.N : q.K),
+                  "mml_gemm_grouped_wgrad: leading dimension too small in problem %d", k);
+      Problem& P = L.p[k - i];
+      P.nsrc = 1;
+      P.src0 = k - i;
+      Source& S = L.src[k - i];
+      // rows of the output tile come from dC^T (n) unless the weight is stored [K,N]; both operands are
+      // batch-major in memory, i.e. NOT reduction-contiguous.
+      if (!q.w_kn) {
+        S.A = q.dC; S.lda = q.lddc; S.B = q.A; S.ldb = q.lda;
+        P.M = q.N; P.N = q.K;
+      } else {
+        S.A = q.A; S.lda = q.lda; S.B = q.dC; S.ldb = q.lddc;
+        P.M = q.K; P.N = q.N;
+      }
+      S.Kred = q.M;
+      S.vecA = vec_ok(S.A, S.lda); S.vecB = vec_ok(S.B, S.ldb);
+      P.tiles_m = (int)cdiv(P.M, BM);
+      P.tiles_n = (int)cdiv(P.N, w.bn);
+      P.tile0 = t;
+      t += P.tiles_m * P.tiles_n;
+      P.slab_off = off;
+      P.bias_cols = q.w_kn ? 1 : 0;
+      const int64_t elems = (int64_t)q.N * q.K;
+      ReduceSeg& g = R.seg[R.n++];
+      g.slab = L.slab + off; g.out = q.dW; g.n = elems; g.cols = q.w_kn ? q.N : q.K; g.ldo = q.lddw;
+      g.S = w.S; g.sstride = elems;
+      g.accumulate = q.accumulate; g.start = rstart;
+      rstart += elems;
+      off += (int64_t)w.S * elems;
+      P.bias_slab = nullptr;
+      if (q.dbias) {
+        P.bias_slab = L.slab + off;
+        ReduceSeg& b = R.seg[R.n++];
+        b.slab = L.slab + off; b.out = q.dbias; b.n = q.N; b.cols = q.N; b.ldo = q.N;
+        b.S = w.S; b.sstride = q.N;
+        b.accumulate = q.accumulate; b.start = rstart;
+        rstart += q.N;
+        off += (int64_t)w.S * q.N;
+      }
+    }
+    L.total_ntiles = t;
+    R.total = rstart;
+    int rc = launch_tiles<EPI_SLAB>(L, false, false, w.bn, (int64_t)t * w.S, to_stream(stream),
+                                    "mml_gemm_grouped_wgrad");
+    if (rc) return rc;
+    rc = launch_slab_reduce(R, to_stream(stream), "mml_gemm_grouped_wgrad(reduce)");
+    if (rc) return rc;
+    i = j;
+  }
+  return MML_OK;
+}

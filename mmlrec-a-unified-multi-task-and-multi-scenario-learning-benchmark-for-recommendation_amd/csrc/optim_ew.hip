@@ -1,0 +1,335 @@
+// K8 optimizers (torch.optim.{SGD,Adam,Adagrad,RMSprop} with their defaults, as built by
+// BaseModel._get_optim, model/basemodel.py:569-584, and stepped at :313) and the K6/K7 elementwise helpers for
+// STAR (model/utils.py:214-218) and PepNet (model/pepnet.py:31-32, :72-78, :139-140).
+// All of these are pure streaming kernels: 16-byte accesses per lane, grid-stride, HBM-bound.
+#include "common.hpp"
+
+namespace mml {
+
+struct OptLaunch {
+  mml_opt_tensor t[MML_MAX_OPT_TENSORS];
+  int32_t n;
+  int32_t pad_;
+  mml_opt_hyper h;
+};
+
+struct StepConsts {
+  float step_size;  // Adam: lr / (1 - beta1^t)
+  float inv_bc2s;   // Adam: 1 / sqrt(1 - beta2^t)
+};
+
+__device__ __forceinline__ StepConsts step_consts(const mml_opt_hyper& h) {
+  StepConsts c{h.lr, 1.f};
+  if (h.kind == MML_OPT_ADAM) {
+    const int t = h.step_dev ? *h.step_dev : h.step;
+    // torch computes the bias corrections in double precision on the host (python floats)
+    const double bc1 = 1.0 - pow((double)h.beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)h.beta2, (double)t);
+    c.step_size = (float)((double)h.lr / bc1);
+    c.inv_bc2s = (float)(1.0 / sqrt(bc2));
+  }
+  return c;
+}
+
+// One element of torch.optim's single-tensor update (the _single_tensor_* functions with default flags).
+__device__ __forceinline__ void opt_update(const mml_opt_hyper& h, const StepConsts& c, float& p, float g, float& s1,
+                                           float& s2) {
+  switch (h.kind) {
+    case MML_OPT_SGD:
+      p -= h.lr * g;
+      break;
+    case MML_OPT_ADAM: {
+      s1 = s1 + (1.f - h.beta1) * (g - s1);               // exp_avg.lerp_(grad, 1-beta1)
+      s2 = h.beta2 * s2 + (1.f - h.beta2) * g * g;        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+      const float denom = sqrtf(s2) * c.inv_bc2s + h.eps; // (sqrt(v) / sqrt(bc2)).add_(eps)
+      p -= c.step_size * (s1 / denom);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
+      break;
+    }
+    case MML_OPT_ADAGRAD:
+      s1 += g * g;                                        // state_sum.addcmul_(g, g)
+      p -= h.lr * (g / (sqrtf(s1) + h.eps));              // param.addcdiv_(g, sqrt(sum)+eps, value=-lr)
+      break;
+    case MML_OPT_RMSPROP:
+      s1 = h.alpha * s1 + (1.f - h.alpha) * g * g;        // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
+      p -= h.lr * (g / (sqrtf(s1) + h.eps));
+      break;
+  }
+}
+
+// blockIdx.y = tensor, blockIdx.x strides over that tensor in float4 chunks.
+__global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
+  const mml_opt_tensor& T = L.t[blockIdx.y];
+  const mml_opt_hyper& h = L.h;
+  const StepConsts c = step_consts(h);
+  const int64_t n4 = T.n >> 2;
+  const bool vec = aligned16(T.param) && aligned16(T.grad) && (!T.state1 || aligned16(T.state1)) &&
+                   (!T.state2 || aligned16(T.state2));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float* gw = const_cast<float*>(T.grad);
+  if (vec) {
+    for (int64_t i = tid; i < n4; i += stride) {
+      float4 p = reinterpret_cast<float4*>(T.param)[i];
+      const float4 g = reinterpret_cast<const float4*>(T.grad)[i];
+      float4 a = T.state1 ? reinterpret_cast<float4*>(T.state1)[i] : make_float4(0, 0, 0, 0);
+      float4 b = T.state2 ? reinterpret_cast<float4*>(T.state2)[i] : make_float4(0, 0, 0, 0);
+      opt_update(h, c, p.x, g.x, a.x, b.x);
+      opt_update(h, c, p.y, g.y, a.y, b.y);
+      opt_update(h, c, p.z, g.z, a.z, b.z);
+      opt_update(h, c, p.w, g.w, a.w, b.w);
+      reinterpret_cast<float4*>(T.param)[i] = p;
+      if (T.state1) reinterpret_cast<float4*>(T.state1)[i] = a;
+      if (T.state2) reinterpret_cast<float4*>(T.state2)[i] = b;
+      if (h.zero_grad) reinterpret_cast<float4*>(gw)[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  const int64_t tail0 = vec ? (n4 << 2) : 0;
+  for (int64_t i = tail0 + tid; i < T.n; i += stride) {
+    float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
+    opt_update(h, c, p, T.grad[i], a, b);
+    T.param[i] = p;
+    if (T.state1) T.state1[i] = a;
+    if (T.state2) T.state2[i] = b;
+    if (h.zero_grad) gw[i] = 0.f;
+  }
+}
+
+// sparse rows: one E-float row per group of lanes, rows taken from the touched list
+struct RowsLaunch {
+  float* tab[MML_MAX_FIELDS];
+  float* grad[MML_MAX_FIELDS];
+  float* s1[MML_MAX_FIELDS];
+  float* s2[MML_MAX_FIELDS];
+  uint32_t* seen[MML_MAX_FIELDS];
+  int64_t rowbase[MML_MAX_FIELDS + 1];
+  int32_t F, E;
+  const int32_t* touched;
+  const int32_t* touched_count;
+  int32_t cap;
+  int32_t pad_;
+  mml_opt_hyper h;
+};
+
+__global__ __launch_bounds__(256) void opt_rows_kernel(const RowsLaunch L) {
+  const mml_opt_hyper& h = L.h;
+  const StepConsts c = step_consts(h);
+  int32_t cnt = *L.touched_count;
+  if (cnt > L.cap) cnt = L.cap;
+  const int64_t total = (int64_t)cnt * L.E;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+    const int32_t li = (int32_t)(item / L.E);
+    const int e = (int)(item - (int64_t)li * L.E);
+    const int64_t grow = L.touched[li];
+    int f = 0;
+    while (f + 1 < L.F && grow >= L.rowbase[f + 1]) ++f;  // F <= 64: short scan (binary search not worth it)
+    const int64_t row = grow - L.rowbase[f];
+    const int64_t o = row * L.E + e;
+    float p = L.tab[f][o];
+    const float g = L.grad[f][o];
+    float a = L.s1[f] ? L.s1[f][o] : 0.f, b = L.s2[f] ? L.s2[f][o] : 0.f;
+    opt_update(h, c, p, g, a, b);
+    L.tab[f][o] = p;
+    if (L.s1[f]) L.s1[f][o] = a;
+    if (L.s2[f]) L.s2[f][o] = b;
+    L.grad[f][o] = 0.f;
+    if (e == 0) atomicAnd(L.seen[f] + (row >> 5), ~(1u << (row & 31)));
+  }
+}
+
+__global__ void counter_kernel(int32_t* c, int32_t delta, int32_t reset) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c = reset ? 0 : (*c + delta);
+}
+
+// ---- elementwise -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ew_mul_kernel(const float* a, const float* b, float* out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] * b[i];
+}
+
+__global__ __launch_bounds__(256) void ew_mul_bwd_kernel(const float* dout, const float* a, const float* b, float* da,
+                                                         float* db, int acc_a, int acc_b, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = dout[i];
+    if (da) {
+      const float v = d * b[i];
+      da[i] = acc_a ? da[i] + v : v;
+    }
+    if (db) {
+      const float v = d * a[i];
+      db[i] = acc_b ? db[i] + v : v;
+    }
+  }
+}
+
+struct AddN {
+  const float* in[16];
+  int32_t n_in;
+};
+__global__ __launch_bounds__(256) void ew_add_n_kernel(const AddN A, float* out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float s = 0.f;
+    for (int k = 0; k < A.n_in; ++k) s += A.in[k][i];
+    out[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows,
+                                                     int cols, int accumulate) {
+  const int64_t total = rows * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float v = src[r * lds_ + c];
+    float* d = dst + r * ldd + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const float* dy, float* dst, int64_t n, int act) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = y[i];
+    float d = 1.f;
+    if (act == MML_ACT_RELU) d = v > 0.f ? 1.f : 0.f;
+    else if (act == MML_ACT_SIGMOID) d = v * (1.f - v);
+    else if (act == MML_ACT_SIGMOID2) d = v * (1.f - 0.5f * v);  // y = 2s: dy/dx = 2 s (1-s) = y (1 - y/2)
+    dst[i] = d * dy[i];
+  }
+}
+
+static unsigned ew_grid(int64_t n) {
+  int64_t b = cdiv(n, 256);
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+static int check_hyper(const mml_opt_hyper* h, const char* who) {
+  MML_REQUIRE(h, "%s: null hyper", who);
+  MML_REQUIRE(h->kind >= MML_OPT_SGD && h->kind <= MML_OPT_RMSPROP, "%s: unknown optimizer kind %d", who, h->kind);
+  MML_REQUIRE(h->kind != MML_OPT_ADAM || h->step_dev || h->step >= 1, "%s: Adam needs step >= 1", who);
+  return MML_OK;
+}
+
+extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, const mml_opt_hyper* hyper,
+                                  mml_stream_t stream) {
+  int rc = check_hyper(hyper, "mml_opt_step_dense");
+  if (rc) return rc;
+  MML_REQUIRE(n >= 0 && (n == 0 || tensors), "mml_opt_step_dense: bad tensor array");
+  int i = 0;
+  while (i < n) {
+    OptLaunch L{};
+    L.h = *hyper;
+    int64_t nmax = 0;
+    // tensors of wildly different size in one launch waste empty workgroups: cut a group when the next
+    // tensor is 64x smaller/larger than the group's first
+    while (i < n && L.n < MML_MAX_OPT_TENSORS) {
+      const mml_opt_tensor& t = tensors[i];
+      MML_REQUIRE(t.param && t.grad && t.n >= 0, "mml_opt_step_dense: tensor %d malformed", i);
+      MML_REQUIRE(hyper->kind == MML_OPT_SGD || t.state1, "mml_opt_step_dense: tensor %d needs state1", i);
+      MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
+      if (L.n > 0 && (t.n > 64 * L.t[0].n || L.t[0].n > 64 * (t.n > 0 ? t.n : 1))) break;
+      L.t[L.n++] = t;
+      if (t.n > nmax) nmax = t.n;
+      ++i;
+    }
+    if (nmax == 0) continue;
+    int64_t bx = cdiv(cdiv(nmax, 4), 256);
+    if (bx > 256 * 8) bx = 256 * 8;
+    hipLaunchKernelGGL(opt_dense_kernel, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
+    rc = check_launch("mml_opt_step_dense");
+    if (rc) return rc;
+  }
+  return MML_OK;
+}
+
+extern "C" int mml_opt_step_rows(float* const* tables, float* const* grad_tables, float* const* state1,
+                                 float* const* state2, uint32_t* const* seen, const int64_t* rowbase, int32_t F,
+                                 int32_t E, const int32_t* touched, const int32_t* touched_count, int32_t touched_cap,
+                                 const mml_opt_hyper* hyper, mml_stream_t stream) {
+  int rc = check_hyper(hyper, "mml_opt_step_rows");
+  if (rc) return rc;
+  MML_REQUIRE(F >= 1 && F <= MML_MAX_FIELDS && E > 0, "mml_opt_step_rows: bad F/E");
+  MML_REQUIRE(tables && grad_tables && seen && rowbase && touched && touched_count && touched_cap > 0,
+              "mml_opt_step_rows: null argument");
+  RowsLaunch L{};
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(tables[f] && grad_tables[f] && seen[f], "mml_opt_step_rows: field %d null", f);
+    L.tab[f] = tables[f]; L.grad[f] = grad_tables[f]; L.seen[f] = seen[f];
+    L.s1[f] = state1 ? state1[f] : nullptr;
+    L.s2[f] = state2 ? state2[f] : nullptr;
+    MML_REQUIRE(hyper->kind == MML_OPT_SGD || L.s1[f], "mml_opt_step_rows: field %d needs state1", f);
+    MML_REQUIRE(hyper->kind != MML_OPT_ADAM || L.s2[f], "mml_opt_step_rows: field %d needs state2", f);
+    L.rowbase[f] = rowbase[f];
+  }
+  L.rowbase[F] = rowbase[F];
+  L.F = F; L.E = E; L.touched = touched; L.touched_count = touched_count; L.cap = touched_cap; L.h = *hyper;
+  // the row count lives on the device: size the grid for the capacity, surplus workgroups exit at once
+  int64_t blocks = cdiv((int64_t)touched_cap * E, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(opt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
+  return check_launch("mml_opt_step_rows");
+}
+
+extern "C" int mml_counter_update(int32_t* counter, int32_t delta, int32_t reset, mml_stream_t stream) {
+  MML_REQUIRE(counter, "mml_counter_update: null counter");
+  hipLaunchKernelGGL(counter_kernel, dim3(1), dim3(64), 0, to_stream(stream), counter, delta, reset);
+  return check_launch("mml_counter_update");
+}
+
+extern "C" int mml_ew_mul(const float* a, const float* b, float* out, int64_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "mml_ew_mul: null argument");
+  if (n == 0) return MML_OK;
+  hipLaunchKernelGGL(ew_mul_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), a, b, out, n);
+  return check_launch("mml_ew_mul");
+}
+
+extern "C" int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
+                              int32_t acc_b, int64_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || dout), "mml_ew_mul_bwd: null dout");
+  MML_REQUIRE(!da || b, "mml_ew_mul_bwd: da needs b");
+  MML_REQUIRE(!db || a, "mml_ew_mul_bwd: db needs a");
+  if (n == 0) return MML_OK;
+  hipLaunchKernelGGL(ew_mul_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), dout, a, b, da, db, acc_a,
+                     acc_b, n);
+  return check_launch("mml_ew_mul_bwd");
+}
+
+extern "C" int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mml_stream_t stream) {
+  MML_REQUIRE(in && n_in >= 1 && n_in <= 16 && out && n >= 0, "mml_ew_add_n: bad arguments");
+  if (n == 0) return MML_OK;
+  AddN A{};
+  A.n_in = n_in;
+  for (int i = 0; i < n_in; ++i) {
+    MML_REQUIRE(in[i], "mml_ew_add_n: input %d null", i);
+    A.in[i] = in[i];
+  }
+  hipLaunchKernelGGL(ew_add_n_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), A, out, n);
+  return check_launch("mml_ew_add_n");
+}
+
+extern "C" int mml_copy2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int32_t cols,
+                          int32_t accumulate, mml_stream_t stream) {
+  MML_REQUIRE(rows >= 0 && cols >= 0, "mml_copy2d: negative extent");
+  if (rows == 0 || cols == 0) return MML_OK;
+  MML_REQUIRE(src && dst && lds_ >= cols && ldd >= cols, "mml_copy2d: null pointer or leading dimension < cols");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, to_stream(stream), src, lds_, dst, ldd,
+                     rows, cols, accumulate);
+  return check_launch("mml_copy2d");
+}
+
+extern "C" int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t n, int32_t act, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || (y && dy && dst)), "mml_act_bwd: null argument");
+  MML_REQUIRE(act >= MML_ACT_NONE && act <= MML_ACT_SIGMOID2, "mml_act_bwd: unknown activation %d", act);
+  if (n == 0) return MML_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), y, dy, dst, n, act);
+  return check_launch("mml_act_bwd");
+}

@@ -1,0 +1,341 @@
+"""Thin torch-tensor front end of the C ABI (include/mmlrec.h): argument marshalling only, no arithmetic.
+
+torch is used for device memory and the current HIP stream; every number is produced by libmmlrec_hip.so.
+All functions require CUDA(HIP) tensors and raise MMLError otherwise -- there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_workspaces = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.MMLError("mmlrec_amd ops need tensors on an MI355X (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32_2d(t, name):
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise L.MMLError(f"{name}: expected a float32 2-D tensor with unit inner stride, got {t.dtype} {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (kept alive here; kernels only see the raw pointer)."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _ptr_array(tensors):
+    arr = (L.fp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def check_status(status, what="embedding lookup"):
+    """Turn the device status word into the exception nn.Embedding raises on CPU (IndexError)."""
+    v = int(status.item())
+    if v:
+        status.zero_()
+        raise IndexError(f"index out of range in {what} (status bits {v:#x}: 1 = negative, 2 = >= vocabulary)")
+
+
+# ---------------------------------------------------------------------------------------------- K1 / K2
+def gather_fwd(tables, X, cols, dense_col0=0, nd=0, out=None, status=None):
+    """dnn_input = concat_f table_f[X[:, cols[f]].long()] ++ X[:, dense_col0:dense_col0+nd]."""
+    lib = L.load()
+    _need_gpu(X, *tables)
+    X = _f32_2d(X, "X")
+    F = len(tables)
+    E = tables[0].shape[1]
+    B = X.shape[0]
+    K0 = F * E + nd
+    if out is None:
+        out = torch.empty((B, K0), dtype=torch.float32, device=X.device)
+    vocab = (L.i64 * F)(*[t.shape[0] for t in tables])
+    col = (L.i32 * F)(*cols)
+    rc = lib.mml_gather_fwd(_ptr_array(tables), vocab, col, F, E, X.data_ptr(), _ld(X), dense_col0, nd, B,
+                            out.data_ptr(), _ld(out), L.ptr(status), _stream())
+    L.check(rc, "mml_gather_fwd")
+    return out
+
+
+def gather_fwd_idx32(tables, idx, dense=None, out=None, status=None):
+    lib = L.load()
+    _need_gpu(idx, *tables)
+    F, E, B = len(tables), tables[0].shape[1], idx.shape[0]
+    nd = 0 if dense is None else dense.shape[1]
+    if out is None:
+        out = torch.empty((B, F * E + nd), dtype=torch.float32, device=idx.device)
+    vocab = (L.i64 * F)(*[t.shape[0] for t in tables])
+    rc = lib.mml_gather_fwd_idx32(_ptr_array(tables), vocab, F, E, idx.data_ptr(), idx.stride(0), L.ptr(dense),
+                                  0 if dense is None else dense.stride(0), nd, B, out.data_ptr(), _ld(out),
+                                  L.ptr(status), _stream())
+    L.check(rc, "mml_gather_fwd_idx32")
+    return out
+
+
+def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None):
+    """grad_tables[f][X[:, cols[f]].long()] += d_out[:, f*E:(f+1)*E] (float atomics)."""
+    lib = L.load()
+    _need_gpu(X, d_out, *grad_tables)
+    F, E, B = len(grad_tables), grad_tables[0].shape[1], X.shape[0]
+    vocab = (L.i64 * F)(*[t.shape[0] for t in grad_tables])
+    col = (L.i32 * F)(*cols)
+    seen_arr = _ptr_array(seen) if seen is not None else None
+    rb = (L.i64 * (F + 1))(*rowbase) if rowbase is not None else None
+    rc = lib.mml_scatter_bwd(_ptr_array(grad_tables), vocab, col, F, E, X.data_ptr(), _ld(X), B, d_out.data_ptr(),
+                             _ld(d_out), seen_arr, rb, L.ptr(touched), L.ptr(touched_count),
+                             0 if touched is None else touched.numel(), L.ptr(status), _stream())
+    L.check(rc, "mml_scatter_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- K3
+def make_fwd_descs(problems):
+    """problems: dicts with A [M,K], W ([N,K] or [K,N] if w_kn), bias or None, C [M,N], act, w_kn."""
+    arr = (L.GemmFwdDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        A, W, Cc = p["A"], p["W"], p["C"]
+        w_kn = int(p.get("w_kn", 0))
+        d.A, d.W, d.C = A.data_ptr(), W.data_ptr(), Cc.data_ptr()
+        d.bias = L.ptr(p.get("bias"))
+        d.lda, d.ldw, d.ldc = _ld(A), _ld(W), _ld(Cc)
+        d.M, d.K = A.shape
+        d.N = W.shape[1] if w_kn else W.shape[0]
+        d.act = int(p.get("act", L.ACT_NONE))
+        d.w_kn = w_kn
+    return arr
+
+
+def gemm_fwd(problems):
+    lib = L.load()
+    arr = make_fwd_descs(problems)
+    L.check(lib.mml_gemm_grouped_fwd(arr, len(problems), _stream()), "mml_gemm_grouped_fwd")
+
+
+def make_dgrad_descs(problems):
+    """problems: dicts with dA [M,K], Y (or None), act, accumulate, srcs = [(dC [M,N], W, w_kn), ...]."""
+    arr = (L.GemmDgradDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        dA = p["dA"]
+        d.dA = dA.data_ptr()
+        Y = p.get("Y")
+        d.Y = L.ptr(Y)
+        d.ldda = _ld(dA)
+        d.ldy = _ld(Y) if Y is not None else 0
+        d.M, d.K = dA.shape
+        d.act = int(p.get("act", L.ACT_NONE)) if Y is not None else L.ACT_NONE
+        d.accumulate = int(p.get("accumulate", 0))
+        srcs = p["srcs"]
+        d.n_src = len(srcs)
+        for s, (dC, W, w_kn) in enumerate(srcs):
+            d.dC[s], d.W[s] = dC.data_ptr(), W.data_ptr()
+            d.lddc[s], d.ldw[s] = _ld(dC), _ld(W)
+            d.N[s] = dC.shape[1]
+            d.w_kn[s] = int(w_kn)
+    return arr
+
+
+def gemm_dgrad(problems):
+    lib = L.load()
+    arr = make_dgrad_descs(problems)
+    L.check(lib.mml_gemm_grouped_dgrad(arr, len(problems), _stream()), "mml_gemm_grouped_dgrad")
+
+
+def make_wgrad_descs(problems):
+    """problems: dicts with dC [M,N], A [M,K], dW ([N,K] or [K,N] if w_kn), dbias or None, accumulate, w_kn."""
+    arr = (L.GemmWgradDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        dC, A, dW = p["dC"], p["A"], p["dW"]
+        d.dC, d.A, d.dW = dC.data_ptr(), A.data_ptr(), dW.data_ptr()
+        d.dbias = L.ptr(p.get("dbias"))
+        d.lddc, d.lda, d.lddw = _ld(dC), _ld(A), _ld(dW)
+        d.M, d.N = dC.shape
+        d.K = A.shape[1]
+        d.accumulate = int(p.get("accumulate", 0))
+        d.w_kn = int(p.get("w_kn", 0))
+    return arr
+
+
+def gemm_wgrad(problems):
+    lib = L.load()
+    arr = make_wgrad_descs(problems)
+    dev = problems[0]["dC"].device
+    nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(problems))
+    ws = workspace(nbytes, dev)
+    L.check(lib.mml_gemm_grouped_wgrad(arr, len(problems), ws.data_ptr(), ws.numel(), _stream()),
+            "mml_gemm_grouped_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------- K4
+def make_gate_group(experts, gates, B, H, d_experts=None, e_relu=True):
+    """experts: list of [B,H] tensors; gates: dicts with G, Wg, P, mix, expert (index list) and, for backward,
+    dmix, dG, dWg, g_relu, active."""
+    g = L.GateGroup()
+    g.n_experts, g.n_gates, g.H, g.B, g.e_relu = len(experts), len(gates), H, B, int(e_relu)
+    for x, e in enumerate(experts):
+        g.E[x], g.lde[x] = e.data_ptr(), _ld(e)
+        if d_experts is not None:
+            g.dE[x], g.ldde[x] = d_experts[x].data_ptr(), _ld(d_experts[x])
+    for i, q in enumerate(gates):
+        d = g.gate[i]
+        G, Wg, P = q["G"], q["Wg"], q["P"]
+        d.G, d.Wg, d.P = G.data_ptr(), Wg.data_ptr(), P.data_ptr()
+        d.ldg, d.ldp = _ld(G), _ld(P)
+        d.ne, d.Gd = Wg.shape
+        if not Wg.is_contiguous():
+            raise L.MMLError("gate weight must be contiguous")
+        if q.get("mix") is not None:
+            d.mix, d.ldmix = q["mix"].data_ptr(), _ld(q["mix"])
+        d.active = int(q.get("active", 1))
+        d.g_relu = int(q.get("g_relu", 1))
+        if q.get("dmix") is not None:
+            d.dmix, d.lddmix = q["dmix"].data_ptr(), _ld(q["dmix"])
+        if q.get("dG") is not None:
+            d.dG, d.lddg = q["dG"].data_ptr(), _ld(q["dG"])
+        if q.get("dWg") is not None:
+            d.dWg = q["dWg"].data_ptr()
+        for s, x in enumerate(q["expert"]):
+            d.expert[s] = x
+    return g
+
+
+def gate_mix_fwd(group):
+    lib = L.load()
+    L.check(lib.mml_gate_mix_fwd(C.byref(group), _stream()), "mml_gate_mix_fwd")
+
+
+def gate_mix_bwd(group, device):
+    lib = L.load()
+    ws = workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(group)), device)
+    L.check(lib.mml_gate_mix_bwd(C.byref(group), ws.data_ptr(), ws.numel(), _stream()), "mml_gate_mix_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- K5
+def make_head_group(heads, prob, y=None, mask=None, loss=None):
+    """heads: dicts with Hin [B,H], w [H] (any shape with H elements), bias [1], optional w2, bias2 (list of 1-element
+    tensors packed by the caller into one tensor), dH, dw, dbias, h_relu, mask_col."""
+    g = L.HeadGroup()
+    g.n_heads = len(heads)
+    g.B = prob.shape[0]
+    g.prob, g.ldprob = prob.data_ptr(), _ld(prob)
+    if y is not None:
+        g.y, g.ldy = y.data_ptr(), _ld(y)
+    if mask is not None:
+        g.mask, g.ldmask = mask.data_ptr(), _ld(mask)
+    g.loss = L.ptr(loss)
+    for t, q in enumerate(heads):
+        d = g.head[t]
+        Hin = q["Hin"]
+        d.Hin, d.ldh, d.H = Hin.data_ptr(), _ld(Hin), Hin.shape[1]
+        d.w, d.bias = q["w"].data_ptr(), q["bias"].data_ptr()
+        d.w2 = L.ptr(q.get("w2"))
+        b2 = q.get("bias2")
+        d.bias2 = L.ptr(b2)
+        d.n_bias2 = 0 if b2 is None else b2.numel()
+        if q.get("dH") is not None:
+            d.dH, d.lddh = q["dH"].data_ptr(), _ld(q["dH"])
+        d.dw, d.dbias = L.ptr(q.get("dw")), L.ptr(q.get("dbias"))
+        d.h_relu = int(q.get("h_relu", 1))
+        d.mask_col = int(q.get("mask_col", -1))
+    return g
+
+
+def head_fwd(group):
+    lib = L.load()
+    L.check(lib.mml_head_fwd(C.byref(group), _stream()), "mml_head_fwd")
+
+
+def head_bce_fwd_bwd(group, device):
+    lib = L.load()
+    ws = workspace(lib.mml_head_workspace_bytes(C.byref(group)), device)
+    L.check(lib.mml_head_bce_fwd_bwd(C.byref(group), ws.data_ptr(), ws.numel(), _stream()), "mml_head_bce_fwd_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- K6/K7
+def ew_mul(a, b, out):
+    L.check(L.load().mml_ew_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), _stream()), "mml_ew_mul")
+
+
+def ew_mul_bwd(dout, a, b, da=None, db=None, acc_a=False, acc_b=False):
+    L.check(L.load().mml_ew_mul_bwd(dout.data_ptr(), L.ptr(a), L.ptr(b), L.ptr(da), L.ptr(db), int(acc_a), int(acc_b),
+                                    dout.numel(), _stream()), "mml_ew_mul_bwd")
+
+
+def ew_add_n(inputs, out):
+    L.check(L.load().mml_ew_add_n(_ptr_array(inputs), len(inputs), out.data_ptr(), out.numel(), _stream()),
+            "mml_ew_add_n")
+
+
+def copy2d(src, dst, accumulate=False):
+    """dst[:, :] (+)= src[:, :] for 2-D row-strided views (column slices of wider buffers are fine)."""
+    rows, cols = src.shape
+    L.check(L.load().mml_copy2d(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), rows, cols, int(accumulate),
+                                _stream()), "mml_copy2d")
+
+
+def act_bwd(y, dy, dst, act):
+    L.check(L.load().mml_act_bwd(y.data_ptr(), dy.data_ptr(), dst.data_ptr(), y.numel(), act, _stream()), "mml_act_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- K8
+def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False):
+    h = L.OptHyper()
+    h.kind = L.OPT_KINDS[kind] if isinstance(kind, str) else int(kind)
+    h.step = int(step)
+    h.step_dev = L.ptr(step_dev)
+    h.lr = float(lr)
+    h.beta1, h.beta2 = 0.9, 0.999
+    h.eps = {L.OPT_ADAM: 1e-8, L.OPT_ADAGRAD: 1e-10, L.OPT_RMSPROP: 1e-8}.get(h.kind, 0.0)
+    h.alpha = 0.99
+    h.zero_grad = int(zero_grad)
+    return h
+
+
+def make_opt_tensors(entries):
+    """entries: (param, grad, state1 or None, state2 or None) with equal element counts, contiguous."""
+    arr = (L.OptTensor * len(entries))()
+    for d, (p, g, s1, s2) in zip(arr, entries):
+        d.param, d.grad, d.state1, d.state2, d.n = p.data_ptr(), g.data_ptr(), L.ptr(s1), L.ptr(s2), p.numel()
+    return arr
+
+
+def opt_step_dense(entries, hyper):
+    arr = make_opt_tensors(entries)
+    L.check(L.load().mml_opt_step_dense(arr, len(entries), C.byref(hyper), _stream()), "mml_opt_step_dense")
+
+
+def opt_step_rows(tables, grad_tables, state1, state2, seen, rowbase, touched, touched_count, hyper):
+    F, E = len(tables), tables[0].shape[1]
+    rb = (L.i64 * (F + 1))(*rowbase)
+    L.check(L.load().mml_opt_step_rows(_ptr_array(tables), _ptr_array(grad_tables),
+                                       _ptr_array(state1) if state1 is not None else None,
+                                       _ptr_array(state2) if state2 is not None else None,
+                                       _ptr_array(seen), rb, F, E, touched.data_ptr(), touched_count.data_ptr(),
+                                       touched.numel(), C.byref(hyper), _stream()), "mml_opt_step_rows")
+
+
+def counter_update(counter, delta=1, reset=False):
+    L.check(L.load().mml_counter_update(counter.data_ptr(), int(delta), int(reset), _stream()), "mml_counter_update")

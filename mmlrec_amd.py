@@ -1,0 +1,13 @@
+"""Import alias: `import mmlrec_amd` loads the package that lives in the (non-identifier) directory
+mmlrec-a-unified-multi-task-and-multi-scenario-learning-benchmark-for-recommendation_amd/."""
+import importlib.util
+import os
+import sys
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                    "mmlrec-a-unified-multi-task-and-multi-scenario-learning-benchmark-for-recommendation_amd")
+_spec = importlib.util.spec_from_file_location("mmlrec_amd", os.path.join(_DIR, "__init__.py"),
+                                               submodule_search_locations=[_DIR])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["mmlrec_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,396 @@
+"""Kernel-level parity: every C-ABI entry point on the MI355X against numpy / the oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mmlrec_oracle as orc  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("E,nd,B", [(8, 0, 1000), (16, 5, 333), (6, 3, 257), (8, 63, 4096)])
+def test_gather_bit_exact(ops, E, nd, B):
+    rng = np.random.default_rng(0)
+    vocab = [1, 2, 7, 100, 1000, 50000, 3]
+    F = len(vocab)
+    tabs = [rng.standard_normal((v, E)).astype(np.float32) for v in vocab]
+    # formula-defined bit patterns in one table: any bit flip is visible
+    tabs[5] = (np.arange(vocab[5] * E, dtype=np.uint32) * np.uint32(2654435761)).view(np.float32).reshape(vocab[5], E)
+    tabs[5] = np.where(np.isfinite(tabs[5]), tabs[5], np.float32(1.0)).astype(np.float32)
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    idx[0, :] = 0
+    idx[1, :] = np.array(vocab) - 1
+    X = np.concatenate([idx.astype(np.float32), rng.random((B, nd), dtype=np.float32)], 1)
+    ref = np.concatenate([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
+    status = ops.new_status(dev())
+    out = ops.gather_fwd([T(t) for t in tabs], T(X), list(range(F)), F, nd, status=status)
+    ops.check_status(status)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # native int32 index variant
+    out2 = ops.gather_fwd_idx32([T(t) for t in tabs], T(idx.astype(np.int32)),
+                                T(X[:, F:].copy()) if nd else None)
+    assert np.array_equal(out2.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_gather_out_of_range_sets_status(ops):
+    tabs = [torch.zeros(10, 8, device=dev())]
+    X = torch.tensor([[3.0], [10.0], [-1.0]], device=dev())
+    status = ops.new_status(dev())
+    ops.gather_fwd(tabs, X, [0], status=status)
+    with pytest.raises(IndexError):
+        ops.check_status(status)
+
+
+def test_gather_index_near_2pow24(ops):
+    V = (1 << 24)
+    tab = torch.arange(V, device=dev(), dtype=torch.float32).reshape(V, 1).repeat(1, 4)
+    X = torch.tensor([[float(V - 1)], [float(V - 2)], [0.0]], device=dev())
+    out = ops.gather_fwd([tab], X, [0])
+    assert out[:, 0].tolist() == [float(V - 1), float(V - 2), 0.0]
+
+
+@pytest.mark.parametrize("E,B", [(8, 5000), (16, 777), (5, 300)])
+def test_scatter_matches_index_add(ops, E, B):
+    rng = np.random.default_rng(1)
+    vocab = [2, 30, 1000, 20000]
+    F = len(vocab)
+    idx = np.stack([np.minimum((v ** rng.random(B)).astype(np.int64), v - 1) for v in vocab], 1)
+    X = idx.astype(np.float32)
+    d_out = rng.standard_normal((B, F * E + 3)).astype(np.float32)
+    ref = []
+    for f, v in enumerate(vocab):
+        g = np.zeros((v, E), np.float64)
+        np.add.at(g, idx[:, f], d_out[:, f * E:(f + 1) * E].astype(np.float64))
+        ref.append(g)
+    gt = [torch.zeros(v, E, device=dev()) for v in vocab]
+    seen = [torch.zeros((v + 31) // 32, dtype=torch.int32, device=dev()) for v in vocab]
+    rowbase = np.concatenate([[0], np.cumsum(vocab)]).tolist()
+    touched = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    count = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.scatter_bwd(gt, T(X), list(range(F)), T(d_out), seen=seen, rowbase=rowbase, touched=touched,
+                    touched_count=count)
+    for f in range(F):
+        assert rel(gt[f].cpu().numpy(), ref[f]) < 1e-5
+    n = int(count.item())
+    got = np.sort(touched[:n].cpu().numpy())
+    want = np.sort(np.concatenate([np.unique(idx[:, f]) + rowbase[f] for f in range(F)]))
+    assert np.array_equal(got, want)
+
+
+def _gemm_case(rng, M, N, K):
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    return A, W, b
+
+
+@pytest.mark.parametrize("M,shapes", [
+    (257, [(256, 240), (64, 240)]),          # AE-30 layer-1 experts + gates, ragged M
+    (512, [(128, 256)] * 4),                 # expert layer 2
+    (130, [(64, 128), (64, 128)]),           # towers
+    (100, [(5, 56), (8, 56), (1, 33)]),      # skinny / odd sizes, unaligned K
+    (4096, [(256, 512), (128, 512)]),        # KuaiRec E=16 first layer
+])
+def test_gemm_fwd(ops, M, shapes):
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(2)
+    A0 = rng.standard_normal((M, shapes[0][1])).astype(np.float32)
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        _, W, b = _gemm_case(rng, M, N, K)
+        A = A0 if K == A0.shape[1] else rng.standard_normal((M, K)).astype(np.float32)
+        act = [L.ACT_RELU, L.ACT_NONE, L.ACT_SIGMOID, L.ACT_SIGMOID2][i % 4]
+        z = A.astype(np.float64) @ W.T.astype(np.float64) + b
+        ref = {L.ACT_RELU: np.maximum(z, 0), L.ACT_NONE: z, L.ACT_SIGMOID: 1 / (1 + np.exp(-z)),
+               L.ACT_SIGMOID2: 2 / (1 + np.exp(-z))}[act]
+        Cc = torch.empty(M, N, device=dev())
+        probs.append(dict(A=T(A), W=T(W), bias=T(b), C=Cc, act=act))
+        refs.append(ref)
+    ops.gemm_fwd(probs)
+    for p, r in zip(probs, refs):
+        assert rel(p["C"].cpu().numpy(), r) < 2e-5
+
+
+def test_gemm_fwd_kn_layout_and_strided_output(ops):
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(3)
+    M, N, K = 300, 96, 64
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wkn = rng.standard_normal((K, N)).astype(np.float32)
+    big = torch.zeros(M, 3 * N, device=dev())
+    ops.gemm_fwd([dict(A=T(A), W=T(Wkn), bias=None, C=big[:, N:2 * N], act=L.ACT_NONE, w_kn=1)])
+    ref = A.astype(np.float64) @ Wkn.astype(np.float64)
+    assert rel(big[:, N:2 * N].cpu().numpy(), ref) < 2e-5
+    assert float(big[:, :N].abs().max()) == 0.0 and float(big[:, 2 * N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,srcN,w_kn", [(257, 240, [256, 256, 64], 0), (512, 128, [64], 0), (100, 56, [5, 8], 0),
+                                           (300, 64, [128], 1)])
+def test_gemm_dgrad(ops, M, K, srcN, w_kn):
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((M, K)).astype(np.float32)
+    Y = np.maximum(Y, 0)
+    srcs, ref = [], np.zeros((M, K))
+    for N in srcN:
+        dC = rng.standard_normal((M, N)).astype(np.float32)
+        W = rng.standard_normal((N, K)).astype(np.float32)
+        ref += dC.astype(np.float64) @ W.astype(np.float64)
+        srcs.append((T(dC), T(W.T.copy()) if w_kn else T(W), w_kn))
+    prev = rng.standard_normal((M, K)).astype(np.float32)
+    dA = T(prev)
+    ops.gemm_dgrad([dict(dA=dA, Y=T(Y), act=L.ACT_RELU, accumulate=1, srcs=srcs)])
+    assert rel(dA.cpu().numpy(), prev + ref * (Y > 0)) < 2e-5
+    dA2 = torch.empty(M, K, device=dev())
+    ops.gemm_dgrad([dict(dA=dA2, Y=None, srcs=srcs)])
+    assert rel(dA2.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,shapes", [(1000, [(256, 240), (64, 240)]), (4096, [(128, 256)] * 3), (333, [(5, 56), (1, 33)]),
+                                      (70000, [(64, 128)])])
+def test_gemm_wgrad(ops, M, shapes):
+    rng = np.random.default_rng(5)
+    probs, refs = [], []
+    for N, K in shapes:
+        dC = rng.standard_normal((M, N)).astype(np.float32)
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        probs.append(dict(dC=T(dC), A=T(A), dW=torch.empty(N, K, device=dev()), dbias=torch.empty(N, device=dev())))
+        refs.append((dC.astype(np.float64).T @ A.astype(np.float64), dC.astype(np.float64).sum(0)))
+    ops.gemm_wgrad(probs)
+    first = [p["dW"].clone() for p in probs]
+    for p, (rw, rb) in zip(probs, refs):
+        assert rel(p["dW"].cpu().numpy(), rw) < 2e-5
+        assert rel(p["dbias"].cpu().numpy(), rb) < 2e-5
+    ops.gemm_wgrad(probs)  # bitwise reproducible (fixed-order slab reduction)
+    for p, f in zip(probs, first):
+        assert torch.equal(p["dW"], f)
+
+
+def test_gemm_wgrad_kn_layout_accumulate(ops):
+    rng = np.random.default_rng(6)
+    M, N, K = 900, 40, 72
+    dC = rng.standard_normal((M, N)).astype(np.float32)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    prev = rng.standard_normal((K, N)).astype(np.float32)
+    dW = T(prev)
+    db = torch.zeros(N, device=dev())
+    ops.gemm_wgrad([dict(dC=T(dC), A=T(A), dW=dW, dbias=db, accumulate=1, w_kn=1)])
+    assert rel(dW.cpu().numpy(), prev + A.astype(np.float64).T @ dC.astype(np.float64)) < 2e-5
+    assert rel(db.cpu().numpy(), dC.astype(np.float64).sum(0)) < 2e-5
+
+
+def _gate_setup(rng, B, H, nexp, gate_sets, Gd):
+    E = [np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32) for _ in range(nexp)]
+    gates = []
+    for members in gate_sets:
+        G = np.maximum(rng.standard_normal((B, Gd)), 0).astype(np.float32)
+        Wg = (rng.standard_normal((len(members), Gd)) * 0.3).astype(np.float32)
+        gates.append((G, Wg, members))
+    return E, gates
+
+
+@pytest.mark.parametrize("B,H,nexp,gate_sets,Gd", [
+    (1000, 128, 4, [[0, 1, 2, 3], [0, 1, 2, 3]], 64),                        # MMoE
+    (515, 32, 8, [[0, 1, 2, 6, 7], [3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7]], 16),  # PLE CGC
+    (70, 300, 3, [[2, 0]], 100),                                             # odd sizes
+])
+def test_gate_mix_fwd_bwd(ops, B, H, nexp, gate_sets, Gd):
+    rng = np.random.default_rng(7)
+    E, gates = _gate_setup(rng, B, H, nexp, gate_sets, Gd)
+    Et = [T(e) for e in E]
+    gd = []
+    for G, Wg, members in gates:
+        gd.append(dict(G=T(G), Wg=T(Wg), P=torch.empty(B, len(members), device=dev()),
+                       mix=torch.empty(B, H, device=dev()), expert=members))
+    ops.gate_mix_fwd(ops.make_gate_group(Et, gd, B, H))
+    refs = []
+    for (G, Wg, members), q in zip(gates, gd):
+        p, mix = orc.gate_mix_fwd(orc.linear_fwd(G, Wg), np.stack([E[x] for x in members], 1))
+        assert rel(q["P"].cpu().numpy(), p) < 1e-5
+        assert rel(q["mix"].cpu().numpy(), mix) < 1e-5
+        refs.append(p)
+    # backward; the last gate of the PLE-like case is inactive (its mix is never consumed)
+    dE_ref = [np.zeros((B, H), np.float64) for _ in range(nexp)]
+    dEt = [torch.full((B, H), 7.0, device=dev()) for _ in range(nexp)]
+    for i, ((G, Wg, members), q, p) in enumerate(zip(gates, gd, refs)):
+        active = not (len(gate_sets) == 3 and i == 2)
+        dmix = rng.standard_normal((B, H)).astype(np.float32)
+        q.update(dmix=T(dmix), dG=torch.empty(B, Gd, device=dev()), dWg=torch.empty(len(members), Gd, device=dev()),
+                 active=int(active), g_relu=1)
+        if not active:
+            continue
+        ex = np.stack([E[x] for x in members], 1)
+        dlog, de = orc.gate_mix_bwd(p, ex, dmix)
+        for s, x in enumerate(members):
+            dE_ref[x] += de[:, s]
+        q["ref_dG"] = (dlog @ Wg) * (G > 0)
+        q["ref_dWg"] = dlog.T.astype(np.float64) @ G.astype(np.float64)
+    ops.gate_mix_bwd(ops.make_gate_group(Et, gd, B, H, d_experts=dEt), dev())
+    for x in range(nexp):
+        assert rel(dEt[x].cpu().numpy(), dE_ref[x] * (E[x] > 0)) < 2e-5
+    for q in gd:
+        if "ref_dG" in q:
+            assert rel(q["dG"].cpu().numpy(), q["ref_dG"]) < 2e-5
+            assert rel(q["dWg"].cpu().numpy(), q["ref_dWg"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,T_,masked", [(1000, 64, 2, False), (333, 16, 4, True), (64, 200, 1, False)])
+def test_head_bce(ops, B, H, T_, masked):
+    rng = np.random.default_rng(8)
+    y = (rng.random((B, T_)) < 0.4).astype(np.float32)
+    mask = (rng.random((B, 2)) < 0.5).astype(np.float32) if masked else None
+    heads, ref_loss = [], 0.0
+    prob = torch.empty(B, T_, device=dev())
+    loss = torch.zeros(1, device=dev())
+    for t in range(T_):
+        Hin = np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32)
+        w = (rng.standard_normal(H) * 0.5).astype(np.float32)
+        bias = rng.standard_normal(1).astype(np.float32)
+        logit = Hin.astype(np.float64) @ w + bias
+        p = 1 / (1 + np.exp(-logit))
+        m = mask[:, t % 2].astype(np.float64) if masked else 1.0
+        pm = p * m
+        lp = np.maximum(np.log(np.maximum(pm, 1e-300)), -100)
+        l1p = np.maximum(np.log1p(-pm), -100)
+        ref_loss += float(-(y[:, t] * lp + (1 - y[:, t]) * l1p).sum())
+        dlogit = (pm - y[:, t]) / np.maximum(pm * (1 - pm), 1e-12) * m * p * (1 - p)
+        heads.append(dict(Hin=T(Hin), w=T(w), bias=T(bias), dH=torch.empty(B, H, device=dev()),
+                          dw=torch.empty(H, device=dev()), dbias=torch.empty(1, device=dev()), h_relu=1,
+                          mask_col=(t % 2 if masked else -1),
+                          ref=(pm, dlogit[:, None] * w[None, :] * (Hin > 0), dlogit @ Hin.astype(np.float64),
+                               dlogit.sum())))
+    ops.head_bce_fwd_bwd(ops.make_head_group(heads, prob, y=T(y), mask=T(mask) if masked else None, loss=loss), dev())
+    assert abs(float(loss.item()) - ref_loss) / ref_loss < 1e-5
+    for t, h in enumerate(heads):
+        pm, dH, dw, db = h["ref"]
+        assert rel(prob[:, t].cpu().numpy(), pm) < 1e-5
+        assert rel(h["dH"].cpu().numpy(), dH) < 2e-5
+        assert rel(h["dw"].cpu().numpy(), dw) < 2e-5
+        assert abs(float(h["dbias"].item()) - db) < 2e-5 * max(abs(db), 1.0)
+    prob2 = torch.empty(B, T_, device=dev())
+    ops.head_fwd(ops.make_head_group(heads, prob2, mask=T(mask) if masked else None))
+    assert torch.equal(prob, prob2)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "rmsprop"])
+def test_optimizer_dense_matches_oracle(ops, kind):
+    rng = np.random.default_rng(9)
+    sizes = [7, 1024, 100003, 8 * 50000]
+    params = {str(i): rng.standard_normal(n).astype(np.float32) for i, n in enumerate(sizes)}
+    tp = {k: T(v) for k, v in params.items()}
+    s1 = {k: torch.zeros_like(v) for k, v in tp.items()}
+    s2 = {k: torch.zeros_like(v) for k, v in tp.items()}
+    opt = orc.DenseOptimizer(kind, 0.01)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=dev())
+    for step in range(1, 4):
+        grads = {k: (rng.standard_normal(v.shape) * (rng.random(v.shape) < 0.3)).astype(np.float32)
+                 for k, v in params.items()}
+        opt.step(params, grads)
+        tg = {k: T(v) for k, v in grads.items()}
+        ops.counter_update(step_dev, 1)
+        hyper = ops.make_hyper(kind, 0.01, step=step if step % 2 else 0, step_dev=None if step % 2 else step_dev,
+                               zero_grad=True)
+        ops.opt_step_dense([(tp[k], tg[k], s1[k] if kind != "sgd" else None, s2[k] if kind == "adam" else None)
+                            for k in params], hyper)
+        for k in params:
+            assert rel(tp[k].cpu().numpy(), params[k]) < 2e-6, (kind, step, k)
+            assert float(tg[k].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam"])
+def test_optimizer_rows(ops, kind):
+    """Sparse-row update equals the dense update exactly for SGD/Adagrad (rows with zero gradient do not move);
+    for Adam it equals a dense Adam restricted to the touched rows."""
+    rng = np.random.default_rng(10)
+    vocab, E, B = [50, 3000], 8, 400
+    F = len(vocab)
+    rowbase = np.concatenate([[0], np.cumsum(vocab)]).tolist()
+    tabs = [rng.standard_normal((v, E)).astype(np.float32) for v in vocab]
+    tt = [T(t) for t in tabs]
+    gt = [torch.zeros(v, E, device=dev()) for v in vocab]
+    s1 = [torch.zeros(v, E, device=dev()) for v in vocab]
+    s2 = [torch.zeros(v, E, device=dev()) for v in vocab]
+    seen = [torch.zeros((v + 31) // 32, dtype=torch.int32, device=dev()) for v in vocab]
+    touched = torch.zeros(B * F, dtype=torch.int32, device=dev())
+    count = torch.zeros(1, dtype=torch.int32, device=dev())
+    ref = {str(f): tabs[f].copy() for f in range(F)}
+    opt = orc.DenseOptimizer(kind, 0.05)
+    for step in range(1, 4):
+        idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+        d_out = rng.standard_normal((B, F * E)).astype(np.float32)
+        ops.counter_update(count, 0, reset=True)
+        ops.scatter_bwd(gt, T(idx.astype(np.float32)), list(range(F)), T(d_out), seen=seen, rowbase=rowbase,
+                        touched=touched, touched_count=count)
+        grads = {}
+        for f in range(F):
+            g = np.zeros_like(tabs[f])
+            np.add.at(g, idx[:, f], d_out[:, f * E:(f + 1) * E])
+            grads[str(f)] = g
+        if kind == "adam":  # lazy Adam: state of untouched rows is frozen -> emulate by masking the dense update
+            before = {k: v.copy() for k, v in ref.items()}
+            st_before = {k: {n: a.copy() for n, a in opt.state.get(k, {}).items()} for k in ref}
+        opt.step(ref, grads)
+        if kind == "adam":
+            for f in range(F):
+                k = str(f)
+                un = np.ones(vocab[f], bool)
+                un[np.unique(idx[:, f])] = False
+                ref[k][un] = before[k][un]
+                for n, a in st_before[k].items():
+                    opt.state[k][n][un] = a[un]
+        hyper = ops.make_hyper(kind, 0.05, step=step)
+        ops.opt_step_rows(tt, gt, s1 if kind != "sgd" else None, s2 if kind == "adam" else None, seen, rowbase,
+                          touched, count, hyper)
+        for f in range(F):
+            assert rel(tt[f].cpu().numpy(), ref[str(f)]) < 1e-5, (kind, step, f)
+            assert float(gt[f].abs().max()) == 0.0
+            assert int(seen[f].abs().max()) == 0
+
+
+def test_elementwise(ops):
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((300, 70)).astype(np.float32)
+    b = rng.standard_normal((300, 70)).astype(np.float32)
+    d = rng.standard_normal((300, 70)).astype(np.float32)
+    out = torch.empty(300, 70, device=dev())
+    ops.ew_mul(T(a), T(b), out)
+    assert np.array_equal(out.cpu().numpy(), a * b)
+    da, db = T(a.copy()), torch.empty(300, 70, device=dev())
+    ops.ew_mul_bwd(T(d), T(a), T(b), da=da, db=db, acc_a=True)
+    assert np.allclose(da.cpu().numpy(), a + d * b, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(db.cpu().numpy(), d * a)
+    s = torch.empty(300, 70, device=dev())
+    ops.ew_add_n([T(a), T(b), T(d)], s)
+    assert np.allclose(s.cpu().numpy(), a + b + d, rtol=1e-6, atol=1e-6)
+    wide = torch.zeros(300, 100, device=dev())
+    ops.copy2d(T(a), wide[:, 10:80])
+    ops.copy2d(T(b), wide[:, 10:80], accumulate=True)
+    assert np.allclose(wide[:, 10:80].cpu().numpy(), a + b, rtol=1e-6, atol=1e-6)
+    assert float(wide[:, :10].abs().max()) == 0.0 and float(wide[:, 80:].abs().max()) == 0.0
+    y = (2 / (1 + np.exp(-a))).astype(np.float32)
+    dst = torch.empty(300, 70, device=dev())
+    ops.act_bwd(T(y), T(d), dst, L.ACT_SIGMOID2)
+    sg = y / 2
+    assert np.allclose(dst.cpu().numpy(), d * 2 * sg * (1 - sg), rtol=1e-5, atol=1e-6)
