@@ -265,23 +265,22 @@ def test_head_bce(ops, B, H, T_, masked):
     loss = torch.zeros(1, device=dev())
     for t in range(T_):
         Hin = np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32)
-        w = (rng.standard_normal(H) * 0.5).astype(np.float32)
+        w = (rng.standard_normal(H) * 1.5 / np.sqrt(H)).astype(np.float32)
         bias = rng.standard_normal(1).astype(np.float32)
-        logit = Hin.astype(np.float64) @ w + bias
-        p = 1 / (1 + np.exp(-logit))
-        m = mask[:, t % 2].astype(np.float64) if masked else 1.0
-        pm = p * m
-        lp = np.maximum(np.log(np.maximum(pm, 1e-300)), -100)
-        l1p = np.maximum(np.log1p(-pm), -100)
-        ref_loss += float(-(y[:, t] * lp + (1 - y[:, t]) * l1p).sum())
-        dlogit = (pm - y[:, t]) / np.maximum(pm * (1 - pm), 1e-12) * m * p * (1 - p)
+        logit = (Hin.astype(np.float64) @ w + bias).astype(np.float32)
+        p = orc.sigmoid(logit)  # fp32 like the reference: saturates to exactly 0/1 for |logit| > ~17
+        m = mask[:, t % 2] if masked else np.float32(1.0)
+        pm = (p * m).astype(np.float32)
+        ref_loss += orc.bce_sum(pm, y[:, t])
+        pm64, p64 = pm.astype(np.float64), p.astype(np.float64)
+        dlogit = (pm64 - y[:, t]) / np.maximum(pm64 * (1 - pm64), 1e-12) * m * p64 * (1 - p64)
         heads.append(dict(Hin=T(Hin), w=T(w), bias=T(bias), dH=torch.empty(B, H, device=dev()),
                           dw=torch.empty(H, device=dev()), dbias=torch.empty(1, device=dev()), h_relu=1,
                           mask_col=(t % 2 if masked else -1),
                           ref=(pm, dlogit[:, None] * w[None, :] * (Hin > 0), dlogit @ Hin.astype(np.float64),
                                dlogit.sum())))
     ops.head_bce_fwd_bwd(ops.make_head_group(heads, prob, y=T(y), mask=T(mask) if masked else None, loss=loss), dev())
-    assert abs(float(loss.item()) - ref_loss) / ref_loss < 1e-5
+    assert abs(float(loss.item()) - ref_loss) / ref_loss < 1e-4
     for t, h in enumerate(heads):
         pm, dH, dw, db = h["ref"]
         assert rel(prob[:, t].cpu().numpy(), pm) < 1e-5
