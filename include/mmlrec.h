@@ -215,11 +215,14 @@ typedef struct {
   const float* mask;  /* [B, ldmask] domain mask or NULL                                               */
   int64_t ldmask;
   float* loss;        /* [1] device scalar: sum of BCE over heads and samples (overwritten), or NULL   */
+  const float* dprob; /* [B, lddprob] upstream dL/dprob used INSTEAD of the BCE gradient when y == NULL (autograd path) */
+  int64_t lddprob;
   mml_head_desc head[MML_MAX_HEADS];
 } mml_head_group;
 int64_t mml_head_workspace_bytes(const mml_head_group* grp);
 int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream);
-/* forward + loss + backward of the heads in one pass (training) */
+/* forward + loss + backward of the heads in one pass (training).  With y != NULL the loss is the summed BCE;
+ * with y == NULL and dprob != NULL the heads are differentiated against the given upstream gradient. */
 int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

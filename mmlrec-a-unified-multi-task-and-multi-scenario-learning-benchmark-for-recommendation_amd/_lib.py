@@ -51,7 +51,8 @@ class HeadDesc(C.Structure):
 
 class HeadGroup(C.Structure):
     _fields_ = [("n_heads", i32), ("pad_", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
-                ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("head", HeadDesc * MAX_HEADS)]
+                ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("dprob", fp), ("lddprob", i64),
+                ("head", HeadDesc * MAX_HEADS)]
 
 
 class OptTensor(C.Structure):

@@ -220,12 +220,17 @@ __global__ __launch_bounds__(ROW_BLOCK) void head_kernel(const mml_head_group g,
       const float pm = p * m;
       if (lane == 0) g.prob[b * g.ldprob + t] = pm;
       if (aux.train) {
-        const float y = g.y[b * g.ldy + t];
-        // F.binary_cross_entropy: log terms clamped at -100; backward divides by max(p(1-p), 1e-12)
-        const float lp = fmaxf(logf(pm), -100.f);
-        const float l1p = fmaxf(log1pf(-pm), -100.f);
-        if (lane == 0) lossacc += -(y * lp + (1.f - y) * l1p);
-        const float dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
+        float dpm;
+        if (g.y) {
+          const float y = g.y[b * g.ldy + t];
+          // F.binary_cross_entropy: log terms clamped at -100; backward divides by max(p(1-p), 1e-12)
+          const float lp = fmaxf(logf(pm), -100.f);
+          const float l1p = fmaxf(log1pf(-pm), -100.f);
+          if (lane == 0) lossacc += -(y * lp + (1.f - y) * l1p);
+          dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
+        } else {
+          dpm = g.dprob[b * g.lddprob + t];
+        }
         const float dlogit = dpm * m * p * (1.f - p);
         if (lane == 0) dbacc[t] += dlogit;
 #pragma unroll
@@ -360,7 +365,8 @@ static int check_head_group(const mml_head_group* g, bool train, const char* who
   MML_REQUIRE(g, "%s: null group", who);
   MML_REQUIRE(g->n_heads >= 1 && g->n_heads <= MML_MAX_HEADS && g->B >= 0, "%s: n_heads=%d", who, g->n_heads);
   MML_REQUIRE(g->prob && g->ldprob >= g->n_heads, "%s: prob null / ldprob", who);
-  MML_REQUIRE(!train || (g->y && g->ldy >= g->n_heads), "%s: training needs y", who);
+  MML_REQUIRE(!train || (g->y && g->ldy >= g->n_heads) || (g->dprob && g->lddprob >= g->n_heads),
+              "%s: training needs y or dprob", who);
   hmax = 0;
   for (int t = 0; t < g->n_heads; ++t) {
     const mml_head_desc& d = g->head[t];

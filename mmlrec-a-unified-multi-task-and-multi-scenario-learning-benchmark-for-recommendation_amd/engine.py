@@ -1,0 +1,637 @@
+"""Static step plans: a model's forward is recorded ONCE per batch size as a short list of C-ABI calls on
+pre-allocated device buffers, its backward is derived from that record, and a training step is
+`fwd calls + fused head/BCE call + bwd calls + optimizer calls` -- about 25 kernel launches for MMoE instead of
+the ~1 000 ATen ops the reference issues per step.  The call list is replayable inside a HIP graph
+(torch.cuda.CUDAGraph is used purely as the capture/replay plumbing).
+
+Gradient convention: `Val.grad` holds dL/d(pre-activation) once every consumer has contributed.  A consumer that is
+the ONLY consumer of a value folds the activation derivative into its own kernel epilogue (dgrad / gate / head
+kernels do this); otherwise consumers add raw contributions and one `mml_act_bwd` pass finalises the sum.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+ACT = {"none": L.ACT_NONE, None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID,
+       "sigmoid2": L.ACT_SIGMOID2}
+
+
+class PVal:
+    """A parameter tensor (or a tensor derived from parameters) with an optional gradient buffer."""
+
+    def __init__(self, data, grad=None, name="", needs_grad=True, is_table=False):
+        self.data, self.grad, self.name = data, grad, name
+        self.needs_grad = needs_grad and grad is not None
+        self.is_table = is_table
+        self.written = 0  # build-time counter: first writer overwrites, later writers accumulate
+
+
+class Val:
+    """A [B, n] activation living in a (possibly column-sliced) device buffer."""
+
+    def __init__(self, buf, act=L.ACT_NONE, needs_grad=True, name=""):
+        self.buf, self.act, self.needs_grad, self.name = buf, act, needs_grad, name
+        self.grad = None
+        self.consumers = []  # ops that would write a gradient into this value
+        self.written = 0
+        self.deriv_applied = False
+
+    @property
+    def n(self):
+        return self.buf.shape[1]
+
+
+def _claim(x):
+    acc = 1 if x.written else 0
+    x.written += 1
+    return acc
+
+
+class Plan:
+    def __init__(self, device, B, training):
+        self.device, self.B, self.training = device, int(B), bool(training)
+        self.ops = []
+        self.fwd, self.head_infer, self.head_train, self.head_bwd, self.bwd = [], [], [], [], []
+        self.keep = []  # ctypes descriptor blocks + buffers referenced by raw pointer
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.vals = {}
+        self.prob = None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        self.y = None
+        self.mask = None
+        self.dprob = None
+        self.X = None
+        self.layer_outputs = {}
+
+    # ---- buffers -----------------------------------------------------------------------------
+    def empty(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def zeros(self, *shape, dtype=torch.float32):
+        t = torch.zeros(*shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def val(self, n, act=L.ACT_NONE, needs_grad=True, name="", buf=None):
+        if buf is None:
+            ld = (n + 3) // 4 * 4  # keep rows 16-byte aligned for the vector paths
+            buf = self.empty(self.B, ld)[:, :n] if ld != n else self.empty(self.B, n)
+        return Val(buf, act, needs_grad, name)
+
+    def grad_of(self, v):
+        """Allocate v.grad on first use (same row pitch as the value)."""
+        if v.grad is None:
+            ld = (v.n + 3) // 4 * 4
+            v.grad = self.empty(self.B, ld)[:, :v.n] if ld != v.n else self.empty(self.B, v.n)
+        return v.grad
+
+    # ---- execution ---------------------------------------------------------------------------
+    @staticmethod
+    def _run(calls):
+        s = torch.cuda.current_stream().cuda_stream
+        for fn, args in calls:
+            rc = fn(*args, s)
+            if rc:
+                L.check(rc, fn.__name__)
+
+    def run_forward(self):
+        self._run(self.fwd)
+        self._run(self.head_infer)
+
+    def run_train_fwd_bwd(self):
+        """forward + summed-BCE loss + backward (gradients land in the PVal.grad buffers)."""
+        self._run(self.fwd)
+        self._run(self.head_train)
+        self._run(self.bwd)
+
+    def run_backward_from_dprob(self):
+        self._run(self.head_bwd)
+        self._run(self.bwd)
+
+    # ---- graph recording ---------------------------------------------------------------------
+    def add(self, op):
+        self.ops.append(op)
+        seen = set()
+        for v in op.inputs():
+            if isinstance(v, Val) and v.needs_grad and id(v) not in seen:
+                seen.add(id(v))
+                v.consumers.append(op)
+        self.fwd.extend(op.fwd_calls(self))
+        return op
+
+    def finish(self, head_op):
+        """Record the head op and derive the backward call list."""
+        self.head_op = head_op
+        for v in head_op.inputs():
+            if isinstance(v, Val) and v.needs_grad:
+                v.consumers.append(head_op)
+        self.head_infer = head_op.infer_calls(self)
+        if not self.training:
+            return
+        self.head_train = head_op.train_calls(self, use_dprob=False)
+        self.head_bwd = head_op.train_calls(self, use_dprob=True, claim=False)
+        for op in reversed(self.ops):
+            for v in op.outputs():
+                if isinstance(v, Val) and v.grad is not None and v.act != L.ACT_NONE and not v.deriv_applied:
+                    self.bwd.append((L.load().mml_act_bwd, (v.buf.data_ptr(), v.grad.data_ptr(), v.grad.data_ptr(),
+                                                            self._flat_numel(v), v.act)))
+                    v.deriv_applied = True
+            self.bwd.extend(op.bwd_calls(self))
+
+    def _flat_numel(self, v):
+        # act_bwd is a flat kernel: value and gradient must share the padded pitch (they do by construction)
+        if v.buf.stride(0) != v.grad.stride(0):
+            raise L.MMLError("value / gradient pitch mismatch for " + v.name)
+        if v.buf.stride(0) != v.n and v.buf.storage_offset() % v.buf.stride(0) != 0:
+            raise L.MMLError("cannot finalise a column-sliced value: " + v.name)
+        return self.B * v.buf.stride(0) if v.buf.stride(0) != v.n else self.B * v.n
+
+
+# ==================================================================================================
+# ops
+# ==================================================================================================
+class Op:
+    def inputs(self):
+        return []
+
+    def outputs(self):
+        return []
+
+    def fwd_calls(self, plan):
+        return []
+
+    def bwd_calls(self, plan):
+        return []
+
+
+class GatherOp(Op):
+    """K1/K2: multi-field gather (+dense copy) and its scatter backward."""
+
+    def __init__(self, tables, X, cols, dense_col0, nd, out, sparse_rows=None):
+        self.tables, self.X, self.cols, self.dense_col0, self.nd, self.out = tables, X, cols, dense_col0, nd, out
+        self.sparse_rows = sparse_rows  # TableRows bookkeeping (seen bitmaps, touched list) or None
+
+    def outputs(self):
+        return [self.out]
+
+    def fwd_calls(self, plan):
+        lib = L.load()
+        F = len(self.tables)
+        E = self.tables[0].data.shape[1]
+        tabs = ops._ptr_array([t.data for t in self.tables])
+        vocab = (L.i64 * F)(*[t.data.shape[0] for t in self.tables])
+        col = (L.i32 * F)(*self.cols)
+        plan.keep += [tabs, vocab, col]
+        return [(lib.mml_gather_fwd, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), self.dense_col0,
+                                      self.nd, plan.B, self.out.buf.data_ptr(), ops._ld(self.out.buf),
+                                      plan.status.data_ptr()))]
+
+    def bwd_calls(self, plan):
+        if self.out.grad is None or not any(t.needs_grad for t in self.tables):
+            return []
+        lib = L.load()
+        F = len(self.tables)
+        E = self.tables[0].data.shape[1]
+        gt = ops._ptr_array([t.grad for t in self.tables])
+        vocab = (L.i64 * F)(*[t.data.shape[0] for t in self.tables])
+        col = (L.i32 * F)(*self.cols)
+        plan.keep += [gt, vocab, col]
+        for t in self.tables:
+            _claim(t)
+        sr = self.sparse_rows
+        if sr is not None:
+            seen = ops._ptr_array(sr.seen)
+            rb = (L.i64 * (F + 1))(*sr.rowbase)
+            plan.keep += [seen, rb]
+            extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
+        else:
+            extra = (None, None, None, None, 0)
+        return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
+                                       self.out.grad.data_ptr(), ops._ld(self.out.grad)) + extra +
+                 (plan.status.data_ptr(),))]
+
+
+class LinearGroupOp(Op):
+    """K3: a set of independent Linear(+activation) problems launched together.
+    problems: dicts with x (Val), W (PVal), b (PVal or None), out (Val; out.act is the activation), w_kn."""
+
+    def __init__(self, problems):
+        self.p = problems
+
+    def inputs(self):
+        return [q["x"] for q in self.p]
+
+    def outputs(self):
+        return [q["out"] for q in self.p]
+
+    def fwd_calls(self, plan):
+        descs = ops.make_fwd_descs([dict(A=q["x"].buf, W=q["W"].data, bias=q["b"].data if q.get("b") else None,
+                                         C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0)) for q in self.p])
+        plan.keep.append(descs)
+        return [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)))]
+
+    def bwd_calls(self, plan):
+        lib = L.load()
+        calls = []
+        live = [q for q in self.p if q["out"].grad is not None]
+        # weight / bias gradients
+        wg = []
+        for q in live:
+            W, b = q["W"], q.get("b")
+            if not W.needs_grad:
+                continue
+            acc = _claim(W)
+            if b is not None and b.needs_grad:
+                if _claim(b) != acc:
+                    raise L.MMLError("weight and bias of one layer must be written in the same order")
+            wg.append(dict(dC=q["out"].grad, A=q["x"].buf, dW=W.grad, dbias=b.grad if (b and b.needs_grad) else None,
+                           accumulate=acc, w_kn=q.get("w_kn", 0)))
+        if wg:
+            descs = ops.make_wgrad_descs(wg)
+            nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(descs, len(wg))
+            ws = ops.workspace(nbytes, plan.device)
+            plan.keep += [descs, ws]
+            calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel())))
+        # input gradients: one dgrad problem per distinct input value
+        by_x = {}
+        for q in live:
+            if q["x"].needs_grad:
+                by_x.setdefault(id(q["x"]), (q["x"], []))[1].append(q)
+        waves = []  # chunk k of every input goes into launch k: chunks of ONE input must not run concurrently
+        for x, qs in by_x.values():
+            plan.grad_of(x)
+            chunks = [qs[i:i + L.MAX_SRC] for i in range(0, len(qs), L.MAX_SRC)]
+            fuse = len(chunks) == 1 and len(x.consumers) == 1 and x.act != L.ACT_NONE
+            for ci, ch in enumerate(chunks):
+                acc = _claim(x)
+                while len(waves) <= ci:
+                    waves.append([])
+                waves[ci].append(dict(dA=x.grad, Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
+                                      accumulate=acc,
+                                      srcs=[(q["out"].grad, q["W"].data, q.get("w_kn", 0)) for q in ch]))
+            if fuse:
+                x.deriv_applied = True
+        for dg in waves:
+            descs = ops.make_dgrad_descs(dg)
+            plan.keep.append(descs)
+            calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg))))
+        return calls
+
+
+class GateGroupOp(Op):
+    """K4: gates (skinny linear + softmax) mixing a shared list of expert outputs.
+    gates: dicts with G (Val), Wg (PVal), mix (Val), expert (indices into `experts`)."""
+
+    def __init__(self, experts, gates, H):
+        self.experts, self.gates, self.H = experts, gates, H
+
+    def inputs(self):
+        return list(self.experts) + [g["G"] for g in self.gates]
+
+    def outputs(self):
+        return [g["mix"] for g in self.gates]
+
+    def fwd_calls(self, plan):
+        for g in self.gates:
+            g["P"] = plan.empty(plan.B, len(g["expert"]))
+        grp = ops.make_gate_group([e.buf for e in self.experts],
+                                  [dict(G=g["G"].buf, Wg=g["Wg"].data, P=g["P"], mix=g["mix"].buf, expert=g["expert"])
+                                   for g in self.gates], plan.B, self.H)
+        plan.keep.append(grp)
+        return [(L.load().mml_gate_mix_fwd, (C.byref(grp),))]
+
+    def bwd_calls(self, plan):
+        lib = L.load()
+        if all(g["mix"].grad is None for g in self.gates):
+            return []
+        for e in self.experts:
+            if e.needs_grad and (len(e.consumers) != 1 or e.written):
+                raise NotImplementedError("an expert output feeding something besides one gate group")
+        e_relu = all(e.act == L.ACT_RELU for e in self.experts)
+        if not e_relu and any(e.act != L.ACT_NONE for e in self.experts):
+            raise NotImplementedError("gate group over experts with mixed activations")
+        gl = []
+        for g in self.gates:
+            G, active = g["G"], g["mix"].grad is not None
+            q = dict(G=G.buf, Wg=g["Wg"].data, P=g["P"], expert=g["expert"], active=int(active))
+            if active:
+                if G.needs_grad and (len(G.consumers) != 1 or G.written):
+                    raise NotImplementedError("a gate input feeding something besides its gate")
+                if _claim(g["Wg"]):
+                    raise NotImplementedError("a gate weight shared between gates")
+                fuse = G.act == L.ACT_RELU
+                if G.act not in (L.ACT_RELU, L.ACT_NONE):
+                    raise NotImplementedError("gate input activation")
+                q.update(dmix=g["mix"].grad, dG=plan.grad_of(G), dWg=g["Wg"].grad, g_relu=int(fuse))
+                _claim(G)
+                G.deriv_applied = True
+            gl.append(q)
+        dE = []
+        for e in self.experts:
+            dE.append(plan.grad_of(e))
+            _claim(e)
+            e.deriv_applied = True
+        grp = ops.make_gate_group([e.buf for e in self.experts], gl, plan.B, self.H, d_experts=dE, e_relu=e_relu)
+        ws = ops.workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)), plan.device)
+        plan.keep += [grp, ws]
+        return [(lib.mml_gate_mix_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()))]
+
+
+class HeadOp(Op):
+    """K5: prediction heads (+ summed BCE and its backward when training).
+    heads: dicts with Hin (Val), w (PVal with H elements), bias (PVal [1]), bias2 (PVal [1] or None)."""
+
+    def __init__(self, heads, mask_cols=None):
+        self.heads = heads
+        self.mask_cols = mask_cols
+
+    def inputs(self):
+        return [h["Hin"] for h in self.heads]
+
+    def _group(self, plan, train, use_dprob, claim):
+        T = len(self.heads)
+        if plan.prob is None:
+            plan.prob = plan.empty(plan.B, T)
+        hl, post = [], []
+        lib = L.load()
+        for t, h in enumerate(self.heads):
+            Hin = h["Hin"]
+            q = dict(Hin=Hin.buf, w=h["w"].data, bias=h["bias"].data,
+                     bias2=h["bias2"].data if h.get("bias2") is not None else None,
+                     mask_col=(self.mask_cols[t] if (self.mask_cols and plan.mask is not None) else -1))
+            if train:
+                sole = len(Hin.consumers) == 1
+                if sole:
+                    q["dH"] = plan.grad_of(Hin)
+                    q["h_relu"] = int(Hin.act == L.ACT_RELU)
+                    if Hin.act not in (L.ACT_RELU, L.ACT_NONE):
+                        raise NotImplementedError("head input activation")
+                    if claim:
+                        _claim(Hin)
+                        Hin.deriv_applied = True
+                else:
+                    tmp = h.setdefault("_dH_tmp", plan.empty(plan.B, Hin.n))
+                    q["dH"], q["h_relu"] = tmp, 0
+                    plan.grad_of(Hin)
+                    acc = _claim(Hin) if claim else h["_acc"]
+                    h["_acc"] = acc
+                    post.append((lib.mml_copy2d, (tmp.data_ptr(), ops._ld(tmp), Hin.grad.data_ptr(), ops._ld(Hin.grad),
+                                                  plan.B, Hin.n, acc)))
+                q["dw"] = h["w"].grad
+                q["dbias"] = h["bias"].grad
+                if claim:
+                    if _claim(h["w"]) or _claim(h["bias"]):
+                        raise NotImplementedError("head weights shared between heads")
+                b2 = h.get("bias2")
+                if b2 is not None and b2.needs_grad:
+                    acc = _claim(b2) if claim else h["_acc_b2"]
+                    h["_acc_b2"] = acc
+                    post.append((lib.mml_copy2d, (h["bias"].grad.data_ptr(), 1, b2.grad.data_ptr(), 1, 1, 1, acc)))
+            hl.append(q)
+        grp = ops.make_head_group(hl, plan.prob, y=plan.y if (train and not use_dprob) else None, mask=plan.mask,
+                                  loss=plan.loss if (train and not use_dprob) else None,
+                                  dprob=plan.dprob if use_dprob else None)
+        plan.keep.append(grp)
+        return grp, post
+
+    def infer_calls(self, plan):
+        grp, _ = self._group(plan, False, False, False)
+        return [(L.load().mml_head_fwd, (C.byref(grp),))]
+
+    def train_calls(self, plan, use_dprob, claim=True):
+        lib = L.load()
+        if use_dprob and plan.dprob is None:
+            plan.dprob = plan.empty(plan.B, len(self.heads))
+        grp, post = self._group(plan, True, use_dprob, claim)
+        ws = ops.workspace(lib.mml_head_workspace_bytes(C.byref(grp)), plan.device)
+        plan.keep.append(ws)
+        return [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()))] + post
+
+
+class MulOp(Op):
+    """out = a * b on whole contiguous [B,n] buffers (PepNet gating, model/pepnet.py:77, :140)."""
+
+    def __init__(self, a, b, out):
+        self.a, self.b, self.out = a, b, out
+        for v in (a, b, out):
+            if not v.buf.is_contiguous():
+                raise L.MMLError("MulOp needs contiguous buffers")
+
+    def inputs(self):
+        return [self.a, self.b]
+
+    def outputs(self):
+        return [self.out]
+
+    def fwd_calls(self, plan):
+        return [(L.load().mml_ew_mul, (self.a.buf.data_ptr(), self.b.buf.data_ptr(), self.out.buf.data_ptr(),
+                                       self.out.buf.numel()))]
+
+    def bwd_calls(self, plan):
+        if self.out.grad is None:
+            return []
+        if not self.out.grad.is_contiguous():
+            raise L.MMLError("MulOp needs a contiguous output gradient")
+        da = db = None
+        acc_a = acc_b = 0
+        if self.a.needs_grad:
+            da = plan.grad_of(self.a)
+            acc_a = _claim(self.a)
+        if self.b.needs_grad:
+            db = plan.grad_of(self.b)
+            acc_b = _claim(self.b)
+        if da is None and db is None:
+            return []
+        return [(L.load().mml_ew_mul_bwd, (self.out.grad.data_ptr(), self.a.buf.data_ptr(), self.b.buf.data_ptr(),
+                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.out.buf.numel()))]
+
+
+class CopyColsOp(Op):
+    """dst[:, :] = src[:, :] for column-sliced views; no gradient flows (used for detached concatenations,
+    model/pepnet.py:72, :139)."""
+
+    def __init__(self, src, dst):
+        self.src, self.dst = src, dst
+
+    def fwd_calls(self, plan):
+        return [(L.load().mml_copy2d, (self.src.data_ptr(), ops._ld(self.src), self.dst.data_ptr(), ops._ld(self.dst),
+                                       plan.B, self.src.shape[1], 0))]
+
+
+class PMulOp(Op):
+    """Derived parameter out = a * b (STAR: specific * shared weight, model/utils.py:215)."""
+
+    def __init__(self, a, b, out):
+        self.a, self.b, self.out = a, b, out
+
+    def fwd_calls(self, plan):
+        return [(L.load().mml_ew_mul, (self.a.data.data_ptr(), self.b.data.data_ptr(), self.out.data.data_ptr(),
+                                       self.out.data.numel()))]
+
+    def bwd_calls(self, plan):
+        if not self.out.written:
+            return []
+        da = self.a.grad if self.a.needs_grad else None
+        db = self.b.grad if self.b.needs_grad else None
+        if da is None and db is None:
+            return []
+        acc_a = _claim(self.a) if da is not None else 0
+        acc_b = _claim(self.b) if db is not None else 0
+        return [(L.load().mml_ew_mul_bwd, (self.out.grad.data_ptr(), self.a.data.data_ptr(), self.b.data.data_ptr(),
+                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.out.data.numel()))]
+
+
+class PAddOp(Op):
+    """Derived parameter out = sum(inputs) (STAR bias sums, model/utils.py:216)."""
+
+    def __init__(self, ins, out):
+        self.ins, self.out = ins, out
+
+    def fwd_calls(self, plan):
+        arr = ops._ptr_array([p.data for p in self.ins])
+        plan.keep.append(arr)
+        return [(L.load().mml_ew_add_n, (arr, len(self.ins), self.out.data.data_ptr(), self.out.data.numel()))]
+
+    def bwd_calls(self, plan):
+        if not self.out.written:
+            return []
+        calls = []
+        n = self.out.data.numel()
+        for p in self.ins:
+            if p.needs_grad:
+                calls.append((L.load().mml_copy2d, (self.out.grad.data_ptr(), n, p.grad.data_ptr(), n, 1, n, _claim(p))))
+        return calls
+
+
+# ==================================================================================================
+# parameter store + optimizer state shared by all plans of one model
+# ==================================================================================================
+class TableRows:
+    """Bookkeeping for the sparse-row table update: per-table `seen` bitmaps + the touched-row list."""
+
+    def __init__(self, vocab, device, cap):
+        self.rowbase = [0]
+        for v in vocab:
+            self.rowbase.append(self.rowbase[-1] + int(v))
+        self.seen = [torch.zeros((int(v) + 31) // 32, dtype=torch.int32, device=device) for v in vocab]
+        self.touched = torch.zeros(max(int(cap), 1), dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+class ParamStore:
+    """Gradient buffers and optimizer state for one model on one device.
+
+    Dense (MLP) parameter gradients live in ONE flat arena (a single buffer to all-reduce under data parallelism);
+    every table gets a dense [V,E] accumulator that is kept all-zero between steps (the optimizer kernels re-zero
+    what they consume), so the scatter can add into it without a per-step 400 MB memset."""
+
+    def __init__(self, model, device):
+        self.device = device
+        self.model = model
+        tables, dense = [], []
+        for name, p in model.named_parameters():
+            (tables if name.startswith("embedding_dict.") else dense).append((name, p))
+        self.sig = tuple(p.data_ptr() for _, p in tables + dense)
+        total = sum(p.numel() for _, p in dense)
+        self.arena = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+        self.pvals = {}
+        off = 0
+        for name, p in dense:
+            g = self.arena[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+            self.pvals[name] = PVal(p.data, g, name)
+        self.table_names = [n for n, _ in tables]
+        for name, p in tables:
+            self.pvals[name] = PVal(p.data, None, name, is_table=True)
+        self.table_grads_ready = False
+        self.opt = None
+        self.rows = None
+        self.extra = {}  # derived / frozen tensors registered by models (STAR)
+
+    def ensure_table_grads(self):
+        if not self.table_grads_ready:
+            for n in self.table_names:
+                pv = self.pvals[n]
+                pv.grad = torch.zeros_like(pv.data)
+                pv.needs_grad = True
+            self.table_grads_ready = True
+
+    def ensure_rows(self, cap):
+        if self.rows is None or self.rows.touched.numel() < cap:
+            self.rows = TableRows([self.pvals[n].data.shape[0] for n in self.table_names], self.device, cap)
+        return self.rows
+
+    def stale(self):
+        return self.sig != tuple(p.data_ptr() for _, p in self.model.named_parameters())
+
+    def reset_written(self):
+        for pv in self.pvals.values():
+            pv.written = 0
+        for pv in self.extra.values():
+            pv.written = 0
+
+
+class Optimizer:
+    """K8 front end: dense update for MLP parameters, dense ('dense_exact') or touched-row ('sparse_rows') update for
+    the tables.  'auto' = sparse rows when that is exactly the dense result (SGD, Adagrad), dense otherwise
+    (Adam/RMSprop decay the moments of untouched rows)."""
+
+    def __init__(self, store, kind, lr, table_update="auto"):
+        self.store, self.kind, self.lr = store, kind, float(lr)
+        if kind not in L.OPT_KINDS:
+            raise NotImplementedError(kind)  # model/basemodel.py:581
+        if table_update == "auto":
+            table_update = "sparse_rows" if kind in ("sgd", "adagrad") else "dense_exact"
+        if table_update not in ("dense_exact", "sparse_rows"):
+            raise ValueError("table_update must be auto, dense_exact or sparse_rows")
+        self.table_update = table_update
+        dev = store.device
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.state = {}
+        for name, pv in store.pvals.items():
+            s1 = torch.zeros_like(pv.data) if kind != "sgd" else None
+            s2 = torch.zeros_like(pv.data) if kind == "adam" else None
+            self.state[name] = (s1, s2)
+        self.steps_done = 0
+
+    def calls(self, plan):
+        """Optimizer call list for one step (appended after a plan's backward)."""
+        lib = L.load()
+        st = self.store
+        calls = [(lib.mml_counter_update, (self.step_dev.data_ptr(), 1, 0))]
+        dense = [(pv, n) for n, pv in st.pvals.items() if not pv.is_table and pv.written]
+        entries = [(pv.data, pv.grad) + self.state[n] for pv, n in dense]
+        tabs = [st.pvals[n] for n in st.table_names if st.pvals[n].written]
+        tnames = [n for n in st.table_names if st.pvals[n].written]
+        hyper = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=False)
+        plan.keep.append(hyper)
+        if entries:
+            arr = ops.make_opt_tensors(entries)
+            plan.keep.append(arr)
+            calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper))))
+        if tabs:
+            if self.table_update == "dense_exact":
+                hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
+                arr = ops.make_opt_tensors([(pv.data, pv.grad) + self.state[n] for pv, n in zip(tabs, tnames)])
+                plan.keep += [hz, arr]
+                calls.append((lib.mml_opt_step_dense, (arr, len(tabs), C.byref(hz))))
+            else:
+                rows = st.rows
+                F = len(tabs)
+                E = tabs[0].data.shape[1]
+                pt = ops._ptr_array([pv.data for pv in tabs])
+                pg = ops._ptr_array([pv.grad for pv in tabs])
+                p1 = ops._ptr_array([self.state[n][0] for n in tnames]) if self.kind != "sgd" else None
+                p2 = ops._ptr_array([self.state[n][1] for n in tnames]) if self.kind == "adam" else None
+                ps = ops._ptr_array(rows.seen)
+                rb = (L.i64 * (F + 1))(*rows.rowbase)
+                plan.keep += [pt, pg, p1, p2, ps, rb]
+                calls.append((lib.mml_opt_step_rows, (pt, pg, p1, p2, ps, rb, F, E, rows.touched.data_ptr(),
+                                                      rows.count.data_ptr(), rows.touched.numel(), C.byref(hyper))))
+                calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
+        return calls

@@ -1,0 +1,8 @@
+"""Drop-in model zoo for the hot path: same class names / constructor signatures as the reference's model/*.py."""
+from .basemodel import BaseModel  # noqa: F401
+from .mmoe import MMOE  # noqa: F401
+from .pepnet import PepNet  # noqa: F401
+from .ple import PLE  # noqa: F401
+from .sharedbottom import SharedBottom  # noqa: F401
+from .star import STAR  # noqa: F401
+from .utils import DenseFeat, SparseFeat, VarLenSparseFeat, get_feature_names  # noqa: F401

@@ -1,0 +1,56 @@
+"""MMoE (reference model/mmoe.py:8-119): Ne expert DNNs and T gate DNNs on the shared input, softmax-gated
+expert mix per task, T towers + heads.  Layer l of every expert AND gate DNN is one grouped MFMA launch."""
+import torch.nn as nn
+
+from .. import engine as E
+from .basemodel import BaseModel
+from .towers import build_tower_modules, emit_towers
+from .utils import DNN, emit_dnn_stacks
+
+
+class MMOE(BaseModel):
+    def __init__(self, dnn_feature_columns, init_std=0.0001, device="cpu", gpus=None, config=None):
+        super().__init__(linear_feature_columns=[], dnn_feature_columns=dnn_feature_columns, init_std=init_std,
+                         device=device, gpus=gpus, config=config)
+        mc = self.model_config
+        self.num_experts = mc.get("num_experts", 4)
+        self.input_dim = self.compute_input_dim(dnn_feature_columns)
+        self.expert_dnn_hidden_units = mc.get("expert_dnn_hidden_units", [256, 128])
+        self.gate_dnn_hidden_units = mc.get("gate_dnn_hidden_units", [64])
+        self.tower_dnn_hidden_units = mc.get("tower_dnn_hidden_units", [64])
+        l2 = mc.get("l2_reg_dnn", 0)
+        drop, act, bn = mc.get("dnn_dropout", 0), mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
+        kw = dict(activation=act, l2_reg=l2, dropout_rate=drop, use_bn=bn, init_std=init_std, device=device)
+        self.expert_dnn = nn.ModuleList([DNN(self.input_dim, self.expert_dnn_hidden_units, **kw)
+                                         for _ in range(self.num_experts)])
+        if len(self.gate_dnn_hidden_units) > 0:
+            self.gate_dnn = nn.ModuleList([DNN(self.input_dim, self.gate_dnn_hidden_units, **kw)
+                                           for _ in range(self.num_tasks)])
+            self.add_regularization_weight(
+                filter(lambda x: "weight" in x[0] and "bn" not in x[0], self.gate_dnn.named_parameters()), l2=l2)
+        gate_in = self.gate_dnn_hidden_units[-1] if len(self.gate_dnn_hidden_units) > 0 else self.input_dim
+        self.gate_dnn_final_layer = nn.ModuleList([nn.Linear(gate_in, self.num_experts, bias=False)
+                                                   for _ in range(self.num_tasks)])
+        build_tower_modules(self, self.expert_dnn_hidden_units[-1], self.tower_dnn_hidden_units, act, l2, drop, bn,
+                            init_std, device)
+        for module in (self.expert_dnn, self.gate_dnn_final_layer, self.tower_dnn_final_layer):
+            self.add_regularization_weight(
+                filter(lambda x: "weight" in x[0] and "bn" not in x[0], module.named_parameters()), l2=l2)
+        self.to(device)
+
+    def _build_graph(self, plan, store, x0):
+        Ne, T = self.num_experts, self.num_tasks
+        stacks = [self.expert_dnn[e].layer_problems(plan, store, f"expert_dnn.{e}", x0) for e in range(Ne)]
+        if hasattr(self, "gate_dnn"):
+            stacks += [self.gate_dnn[t].layer_problems(plan, store, f"gate_dnn.{t}", x0) for t in range(T)]
+        tops = emit_dnn_stacks(plan, stacks)
+        experts = tops[:Ne]
+        gate_in = tops[Ne:] if hasattr(self, "gate_dnn") else [x0] * T
+        H = self.expert_dnn_hidden_units[-1]
+        gates = [dict(G=gate_in[t], Wg=store.pvals[f"gate_dnn_final_layer.{t}.weight"],
+                      mix=plan.val(H, name=f"mmoe_out.{t}"), expert=list(range(Ne))) for t in range(T)]
+        plan.add(E.GateGroupOp(experts, gates, H))
+        plan.layer_outputs["expert_outputs"] = experts
+        plan.layer_outputs["mmoe_outputs"] = [g["mix"] for g in gates]
+        plan.layer_outputs["gate_outputs"] = [g["P"] for g in gates]
+        return emit_towers(self, plan, store, [g["mix"] for g in gates])

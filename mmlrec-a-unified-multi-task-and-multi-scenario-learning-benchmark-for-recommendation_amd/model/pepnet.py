@@ -1,0 +1,126 @@
+"""PepNet (reference model/pepnet.py:8-157): EPNet feature gate 2*sigmoid(MLP(cat(sg(dnn_input), scene_emb))) on the
+input, then per task a PPNet block whose every layer input is re-weighted by its own gate network driven by
+cat(sg(gated input), scene_emb).  Gate networks of all tasks/layers read the same input and launch as grouped GEMMs;
+the stop-gradients are explicit copies whose values carry no gradient buffer."""
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import engine as E
+from .basemodel import BaseModel
+from .utils import PredictionLayer, activation_layer
+
+
+class GateNN(nn.Module):
+    """Linear -> ReLU -> Linear -> Sigmoid, output doubled (reference model/pepnet.py:8-32)."""
+
+    def __init__(self, input_dim, hidden_dim=None, output_dim=None, hidden_activation="relu", dropout_rate=0.0,
+                 batch_norm=False, device="cpu"):
+        super().__init__()
+        if batch_norm or dropout_rate > 0:
+            raise NotImplementedError("GateNN batch_norm / dropout are outside the hot path")
+        if hidden_dim is None:
+            hidden_dim = output_dim
+        self.gate = nn.Sequential(nn.Linear(input_dim, hidden_dim), activation_layer(hidden_activation),
+                                  nn.Linear(hidden_dim, output_dim), nn.Sigmoid())
+        self.to(device)
+
+
+class PPNetBlock(nn.Module):
+    """Gated MLP parameter container (reference model/pepnet.py:34-78)."""
+
+    def __init__(self, input_dim, output_dim=1, gate_input_dim=32, gate_hidden_dim=None, hidden_units=[],
+                 hidden_activations="relu", dropout_rates=0.0, batch_norm=False, use_bias=True, device="cpu"):
+        super().__init__()
+        if batch_norm or dropout_rates or not use_bias or output_dim != 1:
+            raise NotImplementedError("PPNetBlock options outside the shipped PepNet configuration")
+        self.gate_layers = nn.ModuleList()
+        self.mlp_layers = nn.ModuleList()
+        dims = [input_dim] + list(hidden_units)
+        for i in range(len(dims) - 1):
+            dense = nn.Linear(dims[i], dims[i + 1], bias=use_bias)  # created before the gate: same RNG order as the reference
+            self.gate_layers.append(GateNN(gate_input_dim, gate_hidden_dim, output_dim=dims[i]))
+            self.mlp_layers.append(nn.Sequential(dense, activation_layer(hidden_activations)))
+        self.gate_layers.append(GateNN(gate_input_dim, gate_hidden_dim, output_dim=dims[-1]))
+        self.mlp_layers.append(nn.Linear(dims[-1], output_dim, bias=use_bias))
+        self.to(device)
+
+
+class PepNet(BaseModel):
+    def __init__(self, dnn_feature_columns, init_std=0.0001, device="cpu", gpus=None, config=None):
+        super().__init__(linear_feature_columns=[], dnn_feature_columns=dnn_feature_columns, init_std=init_std,
+                         device=device, gpus=gpus, config=config)
+        mc, dc = self.model_config, self.data_config
+        self.dnn_use_bn = mc.get("dnn_use_bn", False)
+        self.dnn_hidden_units = mc.get("dnn_hidden_units", [256, 128])
+        scene_emb_dim = mc.get("emb", 8)
+        scene_feature = dc.get("scene_feature", "")
+        self.user_sf, self.item_sf = dc.get("user_sf", ""), dc.get("item_sf", "")
+        if self.user_sf != "" or self.item_sf != "":
+            raise NotImplementedError("PepNet user_sf / item_sf side features are not planned yet (empty in every "
+                                      "shipped config)")
+        if scene_feature == "":
+            raise NotImplementedError("PepNet needs data_config.scene_feature")
+        self.scene_index = self.feature_index[scene_feature]
+        task_dim = scene_emb_dim
+        input_dim = self.compute_input_dim(dnn_feature_columns)
+        self.feature_gate = GateNN(input_dim=input_dim + scene_emb_dim, hidden_dim=128, output_dim=input_dim,
+                                   device=device)
+        self.ppn = nn.ModuleList([PPNetBlock(input_dim=input_dim, output_dim=1, gate_input_dim=input_dim + task_dim,
+                                             gate_hidden_dim=None, hidden_units=self.dnn_hidden_units, device=device)
+                                  for _ in range(self.num_tasks)])
+        self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
+        self.to(device)
+
+    def _gate_nn(self, plan, store, prefix, gin_vals):
+        """Two grouped launches for a list of (prefix, input value) gate networks: Linear+ReLU then Linear+2*sigmoid."""
+        l1, l2 = [], []
+        for pfx, gin in gin_vals:
+            w0 = store.pvals[f"{pfx}.gate.0.weight"]
+            h = plan.val(w0.data.shape[0], act=L.ACT_RELU, name=pfx + ".h")
+            l1.append(dict(x=gin, W=w0, b=store.pvals[f"{pfx}.gate.0.bias"], out=h))
+            w2 = store.pvals[f"{pfx}.gate.2.weight"]
+            g = plan.val(w2.data.shape[0], act=L.ACT_SIGMOID2, name=pfx + ".g")
+            l2.append(dict(x=h, W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g))
+        plan.add(E.LinearGroupOp(l1))
+        plan.add(E.LinearGroupOp(l2))
+        return [q["out"] for q in l2]
+
+    def _build_graph(self, plan, store, x0):
+        Edim = self.embedding_size
+        K0 = x0.n
+        T, nl = self.num_tasks, len(self.dnn_hidden_units)
+        p = self.scene_index[0]  # column offset used as list position (reference pepnet.py:97, :126)
+        scene = x0.buf[:, p * Edim:(p + 1) * Edim]
+
+        def gate_input(src_val, name):
+            buf = plan.empty(plan.B, K0 + Edim)
+            plan.add(E.CopyColsOp(src_val.buf, buf[:, :K0]))
+            plan.add(E.CopyColsOp(scene, buf[:, K0:]))
+            return E.Val(buf, L.ACT_NONE, needs_grad=False, name=name)
+
+        fg = self._gate_nn(plan, store, "feature_gate", [("feature_gate", gate_input(x0, "epnet_in"))])[0]
+        x2 = plan.val(K0, name="gated_input")
+        plan.add(E.MulOp(fg, x0, x2))
+        gin = gate_input(x2, "ppnet_in")
+        gws = self._gate_nn(plan, store, "ppn", [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T)
+                                                 for l in range(nl + 1)])
+        hidden = [x2] * T
+        heads = []
+        for l in range(nl + 1):
+            hins = []
+            for t in range(T):
+                hin = plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}")
+                plan.add(E.MulOp(hidden[t], gws[t * (nl + 1) + l], hin))
+                hins.append(hin)
+            if l < nl:
+                probs = [dict(x=hins[t], W=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.weight"],
+                              b=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.bias"],
+                              out=plan.val(self.dnn_hidden_units[l], act=L.ACT_RELU, name=f"ppn.{t}.h.{l}"))
+                         for t in range(T)]
+                plan.add(E.LinearGroupOp(probs))
+                hidden = [q["out"] for q in probs]
+            else:
+                heads = [dict(Hin=hins[t], w=store.pvals[f"ppn.{t}.mlp_layers.{l}.weight"],
+                              bias=store.pvals[f"out.{t}.bias"], bias2=store.pvals[f"ppn.{t}.mlp_layers.{l}.bias"])
+                         for t in range(T)]
+        return E.HeadOp(heads)

@@ -1,0 +1,71 @@
+"""STAR (reference model/star.py:8-80): per head i a stack of star layers
+h = relu(h @ (W_spec[i] * W_shared) + b_spec[i] + b_shared) and a final [H -> 1] star layer.  The Hadamard product of
+the weights is a tiny elementwise kernel per step; the GEMMs then run on the plain [K,N]-layout path.
+
+Reference quirk kept: only the LAST domain's specific tensors are registered parameters, so heads
+i < T-1 run on frozen specific weights times the trained shared ones."""
+import torch.nn as nn
+
+from .. import engine as E
+from .basemodel import BaseModel
+from .utils import PredictionLayer, SharedSpecificLinear, activation_code
+
+
+class STAR(BaseModel):
+    def __init__(self, dnn_feature_columns, init_std=0.0001, device="cpu", gpus=None, config=None):
+        super().__init__(linear_feature_columns=[], dnn_feature_columns=dnn_feature_columns, init_std=init_std,
+                         device=device, gpus=gpus, config=config)
+        mc = self.model_config
+        self.dnn_use_bn = mc.get("dnn_use_bn", False)
+        if self.dnn_use_bn:
+            raise NotImplementedError("STAR's DomainBatchNorm is outside the hot path (dead inside fit, SURVEY D3)")
+        self.dnn_hidden_units = mc.get("dnn_hidden_units", [256, 128])
+        self.act_code = activation_code(mc.get("dnn_activation", "relu"))
+        use_shared = mc.get("use_shared", True)
+        input_dim = self.compute_input_dim(dnn_feature_columns)
+        hidden_units = [input_dim] + list(self.dnn_hidden_units)
+        print(f"hidden_units:{hidden_units}")
+        T = self.num_tasks
+        self.linears = nn.ModuleList([SharedSpecificLinear(hidden_units[i], hidden_units[i + 1], T,
+                                                           use_shared=use_shared, device=device)
+                                      for i in range(len(hidden_units) - 1)])
+        self.final_layers = nn.ModuleList([SharedSpecificLinear(hidden_units[-1], 1, T, use_shared=use_shared,
+                                                                device=device) for _ in range(T)])
+        self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
+        self.to(device)
+
+    def _star_params(self, plan, store, prefix, module, d):
+        """(effective weight, effective bias) PVals of domain d of one SharedSpecificLinear, plus the ops producing
+        them (elementwise product / sum, re-run every step because the factors are trained)."""
+        T = self.num_tasks
+        if d == T - 1:
+            ws, bs = store.pvals[f"{prefix}.specific_weight"], store.pvals[f"{prefix}.specific_bias"]
+        else:
+            ws = E.PVal(module.specific_weights[d].data, None, f"{prefix}.frozen_w.{d}", needs_grad=False)
+            bs = E.PVal(module.specific_biases[d].data, None, f"{prefix}.frozen_b.{d}", needs_grad=False)
+        wsh, bsh = store.pvals[f"{prefix}.shared_weight"], store.pvals[f"{prefix}.shared_bias"]
+        weff = E.PVal(plan.empty(*wsh.data.shape), plan.zeros(*wsh.data.shape), f"{prefix}.weff.{d}")
+        beff = E.PVal(plan.empty(*bsh.data.shape), plan.zeros(*bsh.data.shape), f"{prefix}.beff.{d}")
+        plan.add(E.PMulOp(ws, wsh, weff))
+        plan.add(E.PAddOp([bs, bsh], beff))
+        return weff, beff
+
+    def _build_graph(self, plan, store, x0):
+        T, nl = self.num_tasks, len(self.dnn_hidden_units)
+        hs = [x0] * T
+        per_layer = []
+        for j in range(nl):
+            probs = []
+            for i in range(T):
+                weff, beff = self._star_params(plan, store, f"linears.{j}", self.linears[j], i)
+                o = plan.val(self.dnn_hidden_units[j], act=self.act_code, name=f"star.{j}.{i}")
+                probs.append(dict(x=hs[i], W=weff, b=beff, out=o, w_kn=1))
+            plan.add(E.LinearGroupOp(probs))
+            hs = [q["out"] for q in probs]
+            per_layer.append(hs)
+            plan.layer_outputs[f"star_output_{j}"] = hs
+        heads = []
+        for i in range(T):
+            weff, beff = self._star_params(plan, store, f"final_layers.{i}", self.final_layers[i], i)
+            heads.append(dict(Hin=hs[i], w=weff, bias=store.pvals[f"out.{i}.bias"], bias2=beff))
+        return E.HeadOp(heads)

@@ -1,0 +1,239 @@
+"""Feature schema and parameter containers (counterpart of the reference's model/utils.py).
+
+Names, constructor signatures, parameter registration order, initialisers and state_dict keys follow the reference
+so seeds and checkpoints carry over; the arithmetic does not live here -- modules only HOLD parameters and describe
+themselves to the step-plan builder (engine.py), which emits the HIP kernels.
+"""
+import math
+from collections import OrderedDict, namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import engine as E
+
+DEFAULT_GROUP_NAME = "default_group"
+
+
+# ---- feature columns (reference model/utils.py:328-395) ------------------------------------------
+class SparseFeat(namedtuple("SparseFeat", ["name", "vocabulary_size", "embedding_dim", "use_hash", "dtype",
+                                           "embedding_name", "group_name"])):
+    __slots__ = ()
+
+    def __new__(cls, name, vocabulary_size, embedding_dim=4, use_hash=False, dtype="int32", embedding_name=None,
+                group_name=DEFAULT_GROUP_NAME):
+        if embedding_dim == "auto":
+            embedding_dim = 6 * int(pow(vocabulary_size, 0.25))
+        if use_hash:
+            print("Notice! Feature Hashing on the fly is not supported")
+        return super().__new__(cls, name, vocabulary_size, embedding_dim, use_hash, dtype,
+                               name if embedding_name is None else embedding_name, group_name)
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+class VarLenSparseFeat(namedtuple("VarLenSparseFeat", ["sparsefeat", "maxlen", "combiner", "length_name"])):
+    """Accepted for API compatibility; the hot path never builds one (utils/data_utils.py:73-75), and the
+    step plans reject it."""
+    __slots__ = ()
+
+    def __new__(cls, sparsefeat, maxlen, combiner="mean", length_name=None):
+        return super().__new__(cls, sparsefeat, maxlen, combiner, length_name)
+
+    name = property(lambda self: self.sparsefeat.name)
+    vocabulary_size = property(lambda self: self.sparsefeat.vocabulary_size)
+    embedding_dim = property(lambda self: self.sparsefeat.embedding_dim)
+    embedding_name = property(lambda self: self.sparsefeat.embedding_name)
+    group_name = property(lambda self: self.sparsefeat.group_name)
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+class DenseFeat(namedtuple("DenseFeat", ["name", "dimension", "dtype"])):
+    __slots__ = ()
+
+    def __new__(cls, name, dimension=1, dtype="float32"):
+        return super().__new__(cls, name, dimension, dtype)
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+def build_input_features(feature_columns):
+    """{feature name: (first column, one-past-last column)} in X (reference model/utils.py:407-431)."""
+    features = OrderedDict()
+    start = 0
+    for feat in feature_columns:
+        if feat.name in features:
+            continue
+        if isinstance(feat, SparseFeat):
+            width = 1
+        elif isinstance(feat, DenseFeat):
+            width = feat.dimension
+        elif isinstance(feat, VarLenSparseFeat):
+            width = feat.maxlen
+        else:
+            raise TypeError("Invalid feature column type,got", type(feat))
+        features[feat.name] = (start, start + width)
+        start += width
+        if isinstance(feat, VarLenSparseFeat) and feat.length_name is not None and feat.length_name not in features:
+            features[feat.length_name] = (start, start + 1)
+            start += 1
+    return features
+
+
+def get_feature_names(feature_columns):
+    return list(build_input_features(feature_columns).keys())
+
+
+def create_embedding_matrix(feature_columns, init_std=0.0001, linear=False, sparse=False, device="cpu"):
+    """One nn.Embedding per sparse field, N(0, init_std) (reference model/utils.py:466-488).  Only the weight is
+    used: lookups go through the fused gather kernel."""
+    cols = [f for f in feature_columns if isinstance(f, (SparseFeat, VarLenSparseFeat))] if len(feature_columns) else []
+    cols = [f for f in cols if isinstance(f, SparseFeat)] + [f for f in cols if isinstance(f, VarLenSparseFeat)]
+    d = nn.ModuleDict({f.embedding_name: nn.Embedding(f.vocabulary_size, f.embedding_dim if not linear else 1,
+                                                      sparse=sparse) for f in cols})
+    for emb in d.values():
+        nn.init.normal_(emb.weight, mean=0, std=init_std)
+    return d.to(device)
+
+
+def get_mask(domain_values, mask_values, num_domains):
+    """One-hot [N, D] int mask of domain_values == mask_values[d] (reference model/utils.py:639-645)."""
+    dv = torch.as_tensor(np.asarray(domain_values), dtype=torch.float32).reshape(-1, 1).repeat(1, num_domains)
+    mv = torch.as_tensor(np.asarray(mask_values), dtype=torch.float32).reshape(1, -1).repeat(dv.shape[0], 1)
+    return (dv == mv).int()
+
+
+def activation_code(name):
+    if isinstance(name, str):
+        key = name.lower()
+        if key in E.ACT:
+            return E.ACT[key]
+    if name is None:
+        return L.ACT_NONE
+    raise NotImplementedError(f"activation {name!r} (the hot path supports relu / sigmoid / linear)")
+
+
+def activation_layer(act_name, hidden_size=None, dice_dim=2):
+    """Kept for API compatibility (modules built from it are descriptive only)."""
+    code = activation_code(act_name)
+    return {L.ACT_RELU: nn.ReLU(inplace=True), L.ACT_SIGMOID: nn.Sigmoid(), L.ACT_NONE: nn.Identity()}[code]
+
+
+# ---- parameter containers -------------------------------------------------------------------------
+class DNN(nn.Module):
+    """[Linear -> act] x L parameter stack (reference model/utils.py:92-161).  Weights N(0, init_std), biases keep
+    nn.Linear's default init.  BatchNorm / dropout are outside the accelerated path and rejected."""
+
+    def __init__(self, inputs_dim, hidden_units, activation="relu", l2_reg=0, dropout_rate=0, use_bn=False,
+                 init_std=0.0001, dice_dim=3, device="cpu"):
+        super().__init__()
+        if len(hidden_units) == 0:
+            raise ValueError("hidden_units is empty!!")
+        if use_bn or dropout_rate:
+            raise NotImplementedError("BatchNorm / dropout inside DNN are not on the MI355X hot path yet")
+        self.l2_reg, self.use_bn, self.dropout_rate, self.activation = l2_reg, use_bn, dropout_rate, activation
+        self.act_code = activation_code(activation)
+        dims = [inputs_dim] + list(hidden_units)
+        self.linears = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        for name, p in self.linears.named_parameters():
+            if "weight" in name:
+                nn.init.normal_(p, mean=0, std=init_std)
+        self.to(device)
+
+    @property
+    def out_dim(self):
+        return self.linears[-1].out_features
+
+    def layer_problems(self, plan, store, prefix, x):
+        """One LinearGroup problem per layer (the output value of layer l is the input of layer l+1); the caller
+        launches layer l of sibling stacks together (emit_dnn_stacks)."""
+        h = x
+        out = []
+        for l, lin in enumerate(self.linears):
+            o = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}")
+            out.append(dict(x=h, W=store.pvals[f"{prefix}.linears.{l}.weight"],
+                            b=store.pvals[f"{prefix}.linears.{l}.bias"], out=o))
+            h = o
+        return out
+
+    def forward(self, inputs):
+        from ..functional import linear_act
+        h = inputs
+        for lin in self.linears:
+            h = linear_act(h, lin.weight, lin.bias, self.act_code)
+        return h
+
+
+def emit_dnn_stacks(plan, stacks):
+    """stacks: list of per-stack problem lists (from DNN.layer_problems).  Layer l of every stack is launched as ONE
+    grouped GEMM (experts + gate DNNs of an MMoE share the input and the launch)."""
+    depth = max(len(s) for s in stacks)
+    for l in range(depth):
+        probs = [s[l] for s in stacks if len(s) > l]
+        plan.add(E.LinearGroupOp(probs))
+    return [s[-1]["out"] for s in stacks]
+
+
+class PredictionLayer(nn.Module):
+    """bias [1] + sigmoid for task == 'binary' (reference model/utils.py:225-248); fused into the head kernel."""
+
+    def __init__(self, task="binary", use_bias=True, **kwargs):
+        if task not in ["binary", "multiclass", "regression"]:
+            raise ValueError("task must be binary,multiclass or regression")
+        super().__init__()
+        self.use_bias, self.task = use_bias, task
+        if use_bias:
+            self.bias = nn.Parameter(torch.zeros((1,)))
+
+
+class SharedSpecificLinear(nn.Module):
+    """STAR layer: y = x @ (W_spec[d] * W_shared) + b_spec[d] + b_shared, weights stored [in, out]
+    (reference model/utils.py:163-223).  Reference quirk kept: the per-domain tensors live in plain
+    Python lists and the attribute `specific_weight` is overwritten in the loop, so ONLY the last domain's specific
+    weight/bias are registered parameters (state_dict keys `specific_weight` / `specific_bias`); the others are
+    frozen at their initial draw."""
+
+    def __init__(self, in_features, out_features, num_domains, use_shared=True, use_bias=True, device="cpu"):
+        super().__init__()
+        if not (use_shared and use_bias):
+            raise NotImplementedError("STAR hot path covers use_shared=True, use_bias=True (every shipped config)")
+        self.in_features, self.out_features, self.use_shared = in_features, out_features, use_shared
+        # drawn on the host generator whatever `device` is, so a seed gives the same weights as the CPU reference
+        # (the reference draws on `device`; its CUDA stream of random numbers is a different one anyway)
+        self.shared_weight = nn.Parameter(torch.empty((in_features, out_features)))
+        self.shared_bias = nn.Parameter(torch.empty(out_features))
+        self._reset(self.shared_weight, self.shared_bias)
+        self.specific_weights, self.specific_biases = [], []
+        for _ in range(num_domains):
+            self.specific_weight = nn.Parameter(torch.empty((in_features, out_features)))
+            self.specific_bias = nn.Parameter(torch.empty(out_features))
+            self._reset(self.specific_weight, self.specific_bias)
+            self.specific_weights.append(self.specific_weight)
+            self.specific_biases.append(self.specific_bias)
+        self.to(device)
+
+    def _reset(self, w, b):
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.shared_weight)
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        nn.init.uniform_(b, -bound, bound)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        # the frozen per-domain tensors are invisible to nn.Module; keep them on the module's device
+        n = len(self.specific_weights)
+        for d in range(n - 1):
+            self.specific_weights[d] = nn.Parameter(fn(self.specific_weights[d].data), requires_grad=False)
+            self.specific_biases[d] = nn.Parameter(fn(self.specific_biases[d].data), requires_grad=False)
+        self.specific_weights[n - 1] = self.specific_weight
+        self.specific_biases[n - 1] = self.specific_bias
+        return self
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}".format(self.in_features, self.out_features)

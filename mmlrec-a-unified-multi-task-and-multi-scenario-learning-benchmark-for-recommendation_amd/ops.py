@@ -234,7 +234,7 @@ def gate_mix_bwd(group, device):
 
 
 # ---------------------------------------------------------------------------------------------- K5
-def make_head_group(heads, prob, y=None, mask=None, loss=None):
+def make_head_group(heads, prob, y=None, mask=None, loss=None, dprob=None):
     """heads: dicts with Hin [B,H], w [H] (any shape with H elements), bias [1], optional w2, bias2 (list of 1-element
     tensors packed by the caller into one tensor), dH, dw, dbias, h_relu, mask_col."""
     g = L.HeadGroup()
@@ -246,6 +246,8 @@ def make_head_group(heads, prob, y=None, mask=None, loss=None):
     if mask is not None:
         g.mask, g.ldmask = mask.data_ptr(), _ld(mask)
     g.loss = L.ptr(loss)
+    if dprob is not None:
+        g.dprob, g.lddprob = dprob.data_ptr(), _ld(dprob)
     for t, q in enumerate(heads):
         d = g.head[t]
         Hin = q["Hin"]
