@@ -3,6 +3,11 @@ import of any compute entry point fails loudly."""
 import ctypes as C
 import os
 
+# torch must load ITS bundled HIP runtime before our library is opened: torch's libraries ask for "libamdhip64.so"
+# while ours asks for the SONAME "libamdhip64.so.7"; if ours is opened first the process ends up with two HIP
+# runtimes (/opt/rocm's and torch's) and every launch through the second one fails with "no ROCm-capable device".
+import torch  # noqa: F401,E402
+
 from . import build as _build
 
 MAX_FIELDS, MAX_GROUP, MAX_SRC, MAX_EXPERTS, MAX_GATES, MAX_HEADS, MAX_OPT_TENSORS = 64, 16, 8, 16, 8, 8, 32

@@ -24,6 +24,14 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace mml
 
+// hipGetLastError() is sticky per host thread: an error left behind by an unrelated earlier HIP call (e.g. a device
+// probe before the runtime was initialised) must not be blamed on our launch, so clear it first.
+#define MML_LAUNCH(...)          \
+  do {                           \
+    (void)hipGetLastError();     \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define MML_REQUIRE(cond, ...)                  \
   do {                                          \
     if (!(cond)) {                              \

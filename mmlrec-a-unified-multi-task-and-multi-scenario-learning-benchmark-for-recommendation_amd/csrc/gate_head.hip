@@ -11,6 +11,7 @@
 // written once per workgroup to a slab and summed in fixed order by the shared reduce kernel.
 #include "common.hpp"
 #include "reduce.hpp"
+#include "rows_fast.hpp"
 
 namespace mml {
 
@@ -311,7 +312,9 @@ extern "C" int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream) 
   int rc = check_gate_group(grp, false, "mml_gate_mix_fwd");
   if (rc) return rc;
   if (grp->B == 0) return MML_OK;
-  hipLaunchKernelGGL(gate_mix_fwd_kernel, dim3(row_grid(grp->B)), dim3(ROW_BLOCK), 0, to_stream(stream), *grp);
+  rc = gate_fwd_fast(grp, to_stream(stream));
+  if (rc <= 0) return rc;  // handled by the aligned fast path (or failed there)
+  MML_LAUNCH(gate_mix_fwd_kernel, dim3(row_grid(grp->B)), dim3(ROW_BLOCK), 0, to_stream(stream), *grp);
   return check_launch("mml_gate_mix_fwd");
 }
 
@@ -327,9 +330,9 @@ static int gate_bwd_layout(const mml_gate_group* g, GateBwdAux& aux) {
 
 extern "C" int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp) {
   if (!grp) return 0;
-  GateBwdAux aux{};
-  const int tot = gate_bwd_layout(grp, aux);
-  return (int64_t)row_grid(grp->B) * tot * 4 + 256;
+  int64_t tot = 0;
+  for (int i = 0; i < grp->n_gates && i < MML_MAX_GATES; ++i) tot += (int64_t)grp->gate[i].ne * grp->gate[i].Gd;
+  return (int64_t)256 * 8 * tot * 4 + 256;  // either path uses at most 2048 workgroups
 }
 
 extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes,
@@ -337,6 +340,30 @@ extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int6
   int rc = check_gate_group(grp, true, "mml_gate_mix_bwd");
   if (rc) return rc;
   if (grp->B == 0) return MML_OK;
+  {
+    GateFastAux fa{};
+    if (gate_fast_config(grp, true, fa)) {
+      MML_REQUIRE(workspace && (int64_t)fa.grid * fa.wg_total * 4 <= workspace_bytes,
+                  "mml_gate_mix_bwd: workspace too small");
+      fa.slab = static_cast<float*>(workspace);
+      rc = gate_bwd_fast(grp, fa, to_stream(stream));
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        ReduceLaunch R{};
+        int64_t start = 0;
+        for (int i = 0; i < grp->n_gates; ++i) {
+          const mml_gate_desc& d = grp->gate[i];
+          if (!d.active) continue;
+          ReduceSeg& s = R.seg[R.n++];
+          s.slab = fa.slab + fa.wg_off[i]; s.out = d.dWg; s.n = (int64_t)d.ne * d.Gd; s.sstride = fa.wg_total;
+          s.cols = d.Gd; s.ldo = d.Gd; s.accumulate = 0; s.start = start; s.S = fa.grid;
+          start += s.n;
+        }
+        R.total = start;
+        return launch_slab_reduce(R, to_stream(stream), "mml_gate_mix_bwd(reduce)");
+      }
+    }
+  }
   GateBwdAux aux{};
   const int tot = gate_bwd_layout(grp, aux);
   const int grid = row_grid(grp->B);
@@ -344,7 +371,7 @@ extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int6
   const size_t lds = (size_t)(tot + ROW_WAVES * MML_MAX_GATES * MML_MAX_EXPERTS) * 4;
   MML_REQUIRE(lds <= 64 * 1024, "mml_gate_mix_bwd: gate weights too large for the LDS accumulators (%zu B)", lds);
   aux.slab = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), lds, to_stream(stream), *grp, aux);
+  MML_LAUNCH(gate_mix_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), lds, to_stream(stream), *grp, aux);
   rc = check_launch("mml_gate_mix_bwd");
   if (rc) return rc;
   ReduceLaunch R{};
@@ -385,7 +412,7 @@ extern "C" int64_t mml_head_workspace_bytes(const mml_head_group* grp) {
   int hmax = 0;
   for (int t = 0; t < grp->n_heads && t < MML_MAX_HEADS; ++t)
     if (grp->head[t].H > hmax) hmax = grp->head[t].H;
-  return (int64_t)row_grid(grp->B) * (grp->n_heads * (hmax + 1) + 1) * 4 + 256;
+  return (int64_t)256 * 8 * (grp->n_heads * (hmax + 1) + 1) * 4 + 256;  // either path uses at most 2048 workgroups
 }
 
 extern "C" int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream) {
@@ -393,9 +420,13 @@ extern "C" int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream) {
   int rc = check_head_group(grp, false, "mml_head_fwd", hmax);
   if (rc) return rc;
   if (grp->B == 0) return MML_OK;
+  {
+    HeadFastAux fa{};
+    if (head_fast_config(grp, false, hmax, fa)) return head_fast(grp, fa, to_stream(stream));
+  }
   HeadAux aux{};
   aux.hmax = hmax;
-  hipLaunchKernelGGL(head_kernel, dim3(row_grid(grp->B)), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
+  MML_LAUNCH(head_kernel, dim3(row_grid(grp->B)), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
   return check_launch("mml_head_fwd");
 }
 
@@ -405,15 +436,23 @@ extern "C" int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, 
   int rc = check_head_group(grp, true, "mml_head_bce_fwd_bwd", hmax);
   if (rc) return rc;
   if (grp->B == 0) return MML_OK;
-  const int grid = row_grid(grp->B);
+  int grid = row_grid(grp->B);
   HeadAux aux{};
   aux.hmax = hmax;
   aux.stride = grp->n_heads * (hmax + 1) + 1;
   aux.train = 1;
+  HeadFastAux fa{};
+  const bool fast = head_fast_config(grp, true, hmax, fa) != 0;
+  if (fast) grid = fa.grid;
   MML_REQUIRE(workspace && (int64_t)grid * aux.stride * 4 <= workspace_bytes, "mml_head_bce_fwd_bwd: workspace too small");
   aux.slab = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
-  rc = check_launch("mml_head_bce_fwd_bwd");
+  if (fast) {
+    fa.slab = aux.slab; fa.stride = aux.stride; fa.train = 1;
+    rc = head_fast(grp, fa, to_stream(stream));
+  } else {
+    MML_LAUNCH(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
+    rc = check_launch("mml_head_bce_fwd_bwd");
+  }
   if (rc) return rc;
   ReduceLaunch R{};
   int64_t start = 0;

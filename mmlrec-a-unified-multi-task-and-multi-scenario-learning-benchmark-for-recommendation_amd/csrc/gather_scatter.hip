@@ -132,12 +132,12 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
     const int64_t total = a.B * ((int64_t)a.F * (a.E / 4) + a.Nd);
     int64_t blocks = cdiv(total, (int64_t)threads * ITEMS);
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
-    hipLaunchKernelGGL(gather_vec4_kernel<ITEMS>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    MML_LAUNCH(gather_vec4_kernel<ITEMS>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
   } else {
     const int64_t total = a.B * ((int64_t)a.F * a.E + a.Nd);
     int64_t blocks = cdiv(total, threads);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    MML_LAUNCH(gather_scalar_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
   }
   return check_launch("mml_gather_fwd");
 }
@@ -192,6 +192,62 @@ __global__ __launch_bounds__(256) void scatter_atomic_kernel(const FieldTable ft
       if (!(old & bit)) {
         const int slot = atomicAdd(a.touched_count, 1);
         if (slot < a.touched_cap) a.touched[slot] = (int32_t)(a.rowbase[f] + row);
+      }
+    }
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+// LDS-staged index dedup: one workgroup takes ONE field and a chunk of samples, folds duplicate rows in an
+// insert-only open-addressing hash table held in LDS (keys claimed with ds_cmpst, gradients added with ds_add_f32),
+// then flushes every occupied slot with E contiguous float atomics.  Hot rows of skewed / tiny-vocabulary fields
+// reach HBM once per chunk instead of once per sample, which removes the same-address serialisation of the atomics.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, const ScatterArgs a, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* keys = reinterpret_cast<int*>(smem);
+  float* acc = smem + SLOTS;
+  const int E = a.E;
+  const int f = blockIdx.x % a.F;  // neighbouring workgroups read neighbouring 4E-byte pieces of the same dOut rows
+  const int64_t c = blockIdx.x / a.F;
+  for (int i = threadIdx.x; i < SLOTS; i += 256) keys[i] = -1;
+  for (int i = threadIdx.x; i < SLOTS * E; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int64_t b0 = c * chunk;
+  const int nb = (int)((a.B - b0 < chunk) ? (a.B - b0) : chunk);
+  const int64_t V = ft.vocab[f];
+  const int colf = ft.col[f];
+  int bad = 0;
+  for (int item = threadIdx.x; item < nb * E; item += 256) {
+    const int s = item / E, e = item - s * E;
+    const int64_t b = b0 + s;
+    const int64_t row = (int64_t)a.X[b * a.ldX + colf];
+    if (row < 0) { bad |= 1; continue; }
+    if (row >= V) { bad |= 2; continue; }
+    const float g = a.dOut[b * a.ldo + f * E + e];
+    unsigned slot = ((unsigned)row * 2654435761u) >> 16;
+    slot &= (SLOTS - 1);
+    const int key = (int)row;
+    while (true) {
+      const int old = atomicCAS(&keys[slot], -1, key);
+      if (old == -1 || old == key) break;
+      slot = (slot + 1) & (SLOTS - 1);
+    }
+    atomicAdd(&acc[slot * E + e], g);
+  }
+  __syncthreads();
+  float* gt = a.gtab[f];
+  for (int item = threadIdx.x; item < SLOTS * E; item += 256) {
+    const int slot = item / E, e = item - slot * E;
+    const int key = keys[slot];
+    if (key < 0) continue;
+    atomicAdd(gt + (int64_t)key * E + e, acc[item]);
+    if (a.touched && e == 0) {
+      const uint32_t bit = 1u << (key & 31);
+      const uint32_t old = atomicOr(a.seen[f] + (key >> 5), bit);
+      if (!(old & bit)) {
+        const int at = atomicAdd(a.touched_count, 1);
+        if (at < a.touched_cap) a.touched[at] = (int32_t)(a.rowbase[f] + key);
       }
     }
   }
@@ -269,8 +325,22 @@ extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, 
   a.X = X; a.ldX = ldX; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
   const int threads = 256;
+  if (E <= 16) {
+    // dynamic LDS stays under the 64 KiB default limit: SLOTS * (1 + E) * 4 bytes = 36 KiB (4 workgroups per CU)
+    const int slots = (E <= 8) ? 1024 : 512;
+    const int chunk = slots / 2;  // load factor <= 0.5
+    const int64_t nblocks = (int64_t)F * cdiv(B, chunk);
+    const size_t lds = (size_t)slots * (1 + E) * 4;
+    if (nblocks <= 0x7fffffff) {
+      if (slots == 1024)
+        MML_LAUNCH(scatter_hash_kernel<1024>, dim3((unsigned)nblocks), dim3(threads), lds, to_stream(stream), ft, a, chunk);
+      else
+        MML_LAUNCH(scatter_hash_kernel<512>, dim3((unsigned)nblocks), dim3(threads), lds, to_stream(stream), ft, a, chunk);
+      return check_launch("mml_scatter_bwd");
+    }
+  }
   int64_t blocks = cdiv(B * (int64_t)F * E, threads);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(scatter_atomic_kernel, dim3((unsigned)blocks), dim3(threads), 0, to_stream(stream), ft, a);
+  MML_LAUNCH(scatter_atomic_kernel, dim3((unsigned)blocks), dim3(threads), 0, to_stream(stream), ft, a);
   return check_launch("mml_scatter_bwd");
 }

@@ -333,7 +333,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-#define MML_GO(A_, B_, N_) hipLaunchKernelGGL((gemm_kernel<A_, B_, N_, EPI>), g, b, 0, st, L)
+#define MML_GO(A_, B_, N_) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI>), g, b, 0, st, L)
   if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
   else if (arc && !brc) { if (bn == 128) MML_GO(true, false, 128); else MML_GO(true, false, 64); }
   else if (!arc && !brc) { if (bn == 128) MML_GO(false, false, 128); else MML_GO(false, false, 64); }

@@ -18,17 +18,23 @@ struct StepConsts {
   float inv_bc2s;   // Adam: 1 / sqrt(1 - beta2^t)
 };
 
+// Computed by ONE lane per workgroup (double-precision pow is hundreds of instructions) and broadcast through LDS.
 __device__ __forceinline__ StepConsts step_consts(const mml_opt_hyper& h) {
-  StepConsts c{h.lr, 1.f};
-  if (h.kind == MML_OPT_ADAM) {
-    const int t = h.step_dev ? *h.step_dev : h.step;
-    // torch computes the bias corrections in double precision on the host (python floats)
-    const double bc1 = 1.0 - pow((double)h.beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)h.beta2, (double)t);
-    c.step_size = (float)((double)h.lr / bc1);
-    c.inv_bc2s = (float)(1.0 / sqrt(bc2));
+  __shared__ StepConsts sc;
+  if (threadIdx.x == 0) {
+    StepConsts c{h.lr, 1.f};
+    if (h.kind == MML_OPT_ADAM) {
+      const int t = h.step_dev ? *h.step_dev : h.step;
+      // torch computes the bias corrections in double precision on the host (python floats)
+      const double bc1 = 1.0 - pow((double)h.beta1, (double)t);
+      const double bc2 = 1.0 - pow((double)h.beta2, (double)t);
+      c.step_size = (float)((double)h.lr / bc1);
+      c.inv_bc2s = (float)(1.0 / sqrt(bc2));
+    }
+    sc = c;
   }
-  return c;
+  __syncthreads();
+  return sc;
 }
 
 // One element of torch.optim's single-tensor update (the _single_tensor_* functions with default flags).
@@ -236,7 +242,8 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       MML_REQUIRE(t.param && t.grad && t.n >= 0, "mml_opt_step_dense: tensor %d malformed", i);
       MML_REQUIRE(hyper->kind == MML_OPT_SGD || t.state1, "mml_opt_step_dense: tensor %d needs state1", i);
       MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
-      if (L.n > 0 && (t.n > 64 * L.t[0].n || L.t[0].n > 64 * (t.n > 0 ? t.n : 1))) break;
+      const int64_t big = t.n > L.t[0].n ? t.n : L.t[0].n;
+      if (L.n > 0 && big > (1 << 20) && (t.n > 64 * L.t[0].n || L.t[0].n > 64 * (t.n > 0 ? t.n : 1))) break;
       L.t[L.n++] = t;
       if (t.n > nmax) nmax = t.n;
       ++i;
@@ -244,7 +251,7 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
     if (nmax == 0) continue;
     int64_t bx = cdiv(cdiv(nmax, 4), 256);
     if (bx > 256 * 8) bx = 256 * 8;
-    hipLaunchKernelGGL(opt_dense_kernel, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
+    MML_LAUNCH(opt_dense_kernel, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
     rc = check_launch("mml_opt_step_dense");
     if (rc) return rc;
   }
@@ -275,20 +282,20 @@ extern "C" int mml_opt_step_rows(float* const* tables, float* const* grad_tables
   // the row count lives on the device: size the grid for the capacity, surplus workgroups exit at once
   int64_t blocks = cdiv((int64_t)touched_cap * E, 256);
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(opt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
+  MML_LAUNCH(opt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
   return check_launch("mml_opt_step_rows");
 }
 
 extern "C" int mml_counter_update(int32_t* counter, int32_t delta, int32_t reset, mml_stream_t stream) {
   MML_REQUIRE(counter, "mml_counter_update: null counter");
-  hipLaunchKernelGGL(counter_kernel, dim3(1), dim3(64), 0, to_stream(stream), counter, delta, reset);
+  MML_LAUNCH(counter_kernel, dim3(1), dim3(64), 0, to_stream(stream), counter, delta, reset);
   return check_launch("mml_counter_update");
 }
 
 extern "C" int mml_ew_mul(const float* a, const float* b, float* out, int64_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "mml_ew_mul: null argument");
   if (n == 0) return MML_OK;
-  hipLaunchKernelGGL(ew_mul_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), a, b, out, n);
+  MML_LAUNCH(ew_mul_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), a, b, out, n);
   return check_launch("mml_ew_mul");
 }
 
@@ -298,7 +305,7 @@ extern "C" int mml_ew_mul_bwd(const float* dout, const float* a, const float* b,
   MML_REQUIRE(!da || b, "mml_ew_mul_bwd: da needs b");
   MML_REQUIRE(!db || a, "mml_ew_mul_bwd: db needs a");
   if (n == 0) return MML_OK;
-  hipLaunchKernelGGL(ew_mul_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), dout, a, b, da, db, acc_a,
+  MML_LAUNCH(ew_mul_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), dout, a, b, da, db, acc_a,
                      acc_b, n);
   return check_launch("mml_ew_mul_bwd");
 }
@@ -312,7 +319,7 @@ extern "C" int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, in
     MML_REQUIRE(in[i], "mml_ew_add_n: input %d null", i);
     A.in[i] = in[i];
   }
-  hipLaunchKernelGGL(ew_add_n_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), A, out, n);
+  MML_LAUNCH(ew_add_n_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), A, out, n);
   return check_launch("mml_ew_add_n");
 }
 
@@ -321,7 +328,7 @@ extern "C" int mml_copy2d(const float* src, int64_t lds_, float* dst, int64_t ld
   MML_REQUIRE(rows >= 0 && cols >= 0, "mml_copy2d: negative extent");
   if (rows == 0 || cols == 0) return MML_OK;
   MML_REQUIRE(src && dst && lds_ >= cols && ldd >= cols, "mml_copy2d: null pointer or leading dimension < cols");
-  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, to_stream(stream), src, lds_, dst, ldd,
+  MML_LAUNCH(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, to_stream(stream), src, lds_, dst, ldd,
                      rows, cols, accumulate);
   return check_launch("mml_copy2d");
 }
@@ -330,6 +337,6 @@ extern "C" int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t 
   MML_REQUIRE(n >= 0 && (n == 0 || (y && dy && dst)), "mml_act_bwd: null argument");
   MML_REQUIRE(act >= MML_ACT_NONE && act <= MML_ACT_SIGMOID2, "mml_act_bwd: unknown activation %d", act);
   if (n == 0) return MML_OK;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), y, dy, dst, n, act);
+  MML_LAUNCH(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), y, dy, dst, n, act);
   return check_launch("mml_act_bwd");
 }

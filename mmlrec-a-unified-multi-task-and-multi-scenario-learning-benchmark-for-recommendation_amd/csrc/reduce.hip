@@ -2,6 +2,7 @@
 
 namespace mml {
 
+// Many outputs, few partials (wgrad): one thread per output element, coalesced across outputs.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceLaunch R) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.total; i += stride) {
@@ -18,11 +19,45 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceLaunch R) 
   }
 }
 
+// Few outputs, many partials (row kernels: one partial per workgroup): one WAVEFRONT per output element.  Lane l sums
+// partials l, l+64, ... (64 independent load chains instead of one), then a fixed butterfly combines the lanes:
+// the summation order depends only on S, so the result is bitwise reproducible.
+__global__ __launch_bounds__(256) void slab_reduce_wave_kernel(const ReduceLaunch R) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < R.total; i += nwaves) {
+    int si = 0;
+    while (si + 1 < R.n && i >= R.seg[si + 1].start) ++si;
+    const ReduceSeg& g = R.seg[si];
+    const int64_t j = i - g.start;
+    float s = 0.f;
+    for (int k = lane; k < g.S; k += 64) s += g.slab[(int64_t)k * g.sstride + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      const int64_t r = j / g.cols, c = j - r * g.cols;
+      float* dst = g.out + r * g.ldo + c;
+      if (g.accumulate) s += *dst;
+      *dst = s;
+    }
+  }
+}
+
 int launch_slab_reduce(const ReduceLaunch& R, hipStream_t st, const char* who) {
   if (R.total <= 0) return MML_OK;
-  int64_t rb = cdiv(R.total, 256);
-  if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, R);
+  int maxS = 0;
+  for (int i = 0; i < R.n; ++i)
+    if (R.seg[i].S > maxS) maxS = R.seg[i].S;
+  if (R.total <= 32768 && maxS >= 64) {
+    int64_t rb = cdiv(R.total, 4);  // 4 waves per workgroup
+    if (rb > 4096) rb = 4096;
+    MML_LAUNCH(slab_reduce_wave_kernel, dim3((unsigned)rb), dim3(256), 0, st, R);
+  } else {
+    int64_t rb = cdiv(R.total, 256);
+    if (rb > 2048) rb = 2048;
+    MML_LAUNCH(slab_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, R);
+  }
   return check_launch(who);
 }
 

@@ -1,0 +1,457 @@
+// Fast paths of the row kernels (K4 gate, K5 head) for the common aligned case: every feature axis (H, Gd) is a
+// multiple of 4 floats with 16-byte aligned rows and at most 256 wide.
+//
+// Layout of the work: a wavefront is split into 64/LPS lane groups, ONE SAMPLE PER GROUP, and every lane owns one
+// 16-byte column slot of each row (LPS = 16, 32 or 64 lanes chosen so that one float4 per lane covers the widest
+// row).  All global traffic is therefore dwordx4 per lane and contiguous per sample; dot products finish with a
+// log2(LPS)-step butterfly inside the group.  Parameter gradients accumulate in registers over all samples a lane
+// group visits and are combined once per workgroup in a fixed order (wave shuffles -> LDS -> slab), so results are
+// bitwise reproducible.  Semantics are those of the generic kernels in gate_head.hip (which remain the fallback).
+#include "common.hpp"
+#include "reduce.hpp"
+#include "rows_fast.hpp"
+
+namespace mml {
+
+template <int LPS>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = LPS / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sum over the 64/LPS lane groups of a wave (same sub-lane in every group)
+template <int LPS>
+__device__ __forceinline__ float cross_group_sum(float v) {
+#pragma unroll
+  for (int off = LPS; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
+  acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+constexpr int FB = 256;          // threads per workgroup
+constexpr int FW = FB / 64;      // waves per workgroup
+
+// ------------------------------------------------------------------------------------------------ gate forward
+template <int LPS, int NE>
+__global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group g, const GateFastAux aux) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // gate weights, all gates back to back
+  for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
+    int gi = 0;
+    while (gi + 1 < g.n_gates && i >= aux.wg_off[gi + 1]) ++gi;
+    smem[i] = g.gate[gi].Wg[i - aux.wg_off[gi]];
+  }
+  __syncthreads();
+  constexpr int SPW = 64 / LPS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPS, grp = lane / LPS;
+  const int64_t stride = (int64_t)gridDim.x * FW * SPW;
+  const int64_t iters = (g.B + stride - 1) / stride;
+  const bool hcol = 4 * sub < g.H;
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;  // keep every lane in the shuffles; stores are predicated
+    for (int gi = 0; gi < g.n_gates; ++gi) {
+      const mml_gate_desc& d = g.gate[gi];
+      const float* W = smem + aux.wg_off[gi];
+      float p[NE];
+      const bool gcol = 4 * sub < d.Gd;
+      float4 Gv = gcol ? ld4(d.G + b * d.ldg + 4 * sub) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] = -INFINITY;
+        if (e < d.ne) {
+          float part = gcol ? dot4(Gv, ld4(W + e * d.Gd + 4 * sub)) : 0.f;
+          p[e] = group_sum<LPS>(part);
+        }
+      }
+      float m = p[0];
+#pragma unroll
+      for (int e = 1; e < NE; ++e) m = fmaxf(m, p[e]);
+      float den = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] = (e < d.ne) ? expf(p[e] - m) : 0.f;
+        den += p[e];
+      }
+      const float inv = 1.f / den;
+      float mine = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] *= inv;
+        if (sub == e) mine = p[e];
+      }
+      if (valid && sub < d.ne) d.P[b * d.ldp + sub] = mine;
+      if (hcol) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          if (e < d.ne) {
+            const int x = d.expert[e];
+            fma4(acc, p[e], ld4(g.E[x] + b * g.lde[x] + 4 * sub));
+          }
+        if (valid) st4(d.mix + b * d.ldmix + 4 * sub, acc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gate backward
+template <int LPS, int NE, int NG>
+__global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group g, const GateFastAux aux) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int SPW = 64 / LPS;
+  float* Wsm = smem;                                   // [wg_total] gate weights
+  float* coef_all = smem + aux.wg_total;               // [FW*SPW][NG*MML_MAX_EXPERTS] softmax coefficients per sample
+  float* red = coef_all + FW * SPW * NG * MML_MAX_EXPERTS;  // [FW][wg_total] per-wave dWg partials
+  for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
+    int gi = 0;
+    while (gi + 1 < g.n_gates && i >= aux.wg_off[gi + 1]) ++gi;
+    Wsm[i] = g.gate[gi].active ? g.gate[gi].Wg[i - aux.wg_off[gi]] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPS, grp = lane / LPS;
+  float* coef = coef_all + (wave * SPW + grp) * NG * MML_MAX_EXPERTS;
+  const int64_t stride = (int64_t)gridDim.x * FW * SPW;
+  const int64_t iters = (g.B + stride - 1) / stride;
+  const bool hcol = 4 * sub < g.H;
+
+  float4 wacc[NG][NE];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) wacc[gi][e] = make_float4(0, 0, 0, 0);
+
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;
+    for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
+    float4 dmv[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      dmv[gi] = make_float4(0, 0, 0, 0);
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      if (!d.active) continue;
+      if (hcol) dmv[gi] = ld4(d.dmix + b * d.lddmix + 4 * sub);
+      float dl[NE], p[NE];
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        dl[e] = 0.f;
+        p[e] = 0.f;
+        if (e < d.ne) {
+          const int x = d.expert[e];
+          const float part = hcol ? dot4(dmv[gi], ld4(g.E[x] + b * g.lde[x] + 4 * sub)) : 0.f;
+          dl[e] = group_sum<LPS>(part);
+          p[e] = d.P[b * d.ldp + e];
+          dot += p[e] * dl[e];
+          if (sub == 0) coef[gi * MML_MAX_EXPERTS + x] = p[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) dl[e] = valid ? p[e] * (dl[e] - dot) : 0.f;  // dlogit (0 for padding samples)
+      if (4 * sub < d.Gd) {
+        const float4 Gv = ld4(d.G + b * d.ldg + 4 * sub);
+        const float* W = Wsm + aux.wg_off[gi];
+        float4 dg = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          if (e < d.ne) {
+            fma4(dg, dl[e], ld4(W + e * d.Gd + 4 * sub));
+            fma4(wacc[gi][e], dl[e], Gv);
+          }
+        if (d.g_relu) {
+          if (!(Gv.x > 0.f)) dg.x = 0.f;
+          if (!(Gv.y > 0.f)) dg.y = 0.f;
+          if (!(Gv.z > 0.f)) dg.z = 0.f;
+          if (!(Gv.w > 0.f)) dg.w = 0.f;
+        }
+        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (hcol) {
+#pragma unroll 4
+      for (int x = 0; x < g.n_experts; ++x) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], dmv[gi]);
+        if (g.e_relu) {
+          const float4 Ev = ld4(g.E[x] + b * g.lde[x] + 4 * sub);
+          if (!(Ev.x > 0.f)) acc.x = 0.f;
+          if (!(Ev.y > 0.f)) acc.y = 0.f;
+          if (!(Ev.z > 0.f)) acc.z = 0.f;
+          if (!(Ev.w > 0.f)) acc.w = 0.f;
+        }
+        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // combine: lane groups of a wave (shuffles) -> per-wave LDS rows -> fixed-order sum over waves -> slab
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    if (gi >= g.n_gates || !g.gate[gi].active) continue;
+    const int Gd = g.gate[gi].Gd, ne = g.gate[gi].ne;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (e >= ne) continue;
+      float4 v = wacc[gi][e];
+      v.x = cross_group_sum<LPS>(v.x);
+      v.y = cross_group_sum<LPS>(v.y);
+      v.z = cross_group_sum<LPS>(v.z);
+      v.w = cross_group_sum<LPS>(v.w);
+      if (grp == 0 && 4 * sub < Gd) st4(red + wave * aux.wg_total + aux.wg_off[gi] + e * Gd + 4 * sub, v);
+    }
+  }
+  __syncthreads();
+  float* out = aux.slab + (int64_t)blockIdx.x * aux.wg_total;
+  for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) s += red[w * aux.wg_total + i];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ heads
+template <int LPS, int NT>
+__global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, const HeadFastAux aux) {
+  __shared__ float red[FW][NT * (4 * LPS + 1) + 1];
+  constexpr int SPW = 64 / LPS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPS, grp = lane / LPS;
+  const int64_t stride = (int64_t)gridDim.x * FW * SPW;
+  const int64_t iters = (g.B + stride - 1) / stride;
+  float4 dwacc[NT];
+  float dbacc[NT];
+  float lossacc = 0.f;
+  float4 wv[NT];
+  float bias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    dwacc[t] = make_float4(0, 0, 0, 0);
+    dbacc[t] = 0.f;
+    wv[t] = make_float4(0, 0, 0, 0);
+    bias[t] = 0.f;
+    if (t < g.n_heads) {
+      const mml_head_desc& d = g.head[t];
+      if (4 * sub < d.H) {
+        wv[t] = ld4(d.w + 4 * sub);
+        if (d.w2) {
+          const float4 w2 = ld4(d.w2 + 4 * sub);
+          wv[t].x *= w2.x; wv[t].y *= w2.y; wv[t].z *= w2.z; wv[t].w *= w2.w;
+        }
+      }
+      bias[t] = d.bias[0];
+      for (int i = 0; i < d.n_bias2; ++i) bias[t] += d.bias2[i];
+    }
+  }
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t >= g.n_heads) continue;
+      const mml_head_desc& d = g.head[t];
+      const bool col = 4 * sub < d.H;
+      const float4 hv = col ? ld4(d.Hin + b * d.ldh + 4 * sub) : make_float4(0, 0, 0, 0);
+      const float logit = group_sum<LPS>(dot4(hv, wv[t])) + bias[t];
+      const float p = 1.f / (1.f + expf(-logit));
+      const float m = (d.mask_col >= 0 && g.mask) ? g.mask[b * g.ldmask + d.mask_col] : 1.f;
+      const float pm = p * m;
+      if (valid && sub == 0) g.prob[b * g.ldprob + t] = pm;
+      if (aux.train) {
+        float dpm;
+        if (g.y) {
+          const float y = g.y[b * g.ldy + t];
+          const float lp = fmaxf(logf(pm), -100.f);
+          const float l1p = fmaxf(log1pf(-pm), -100.f);
+          if (valid && sub == 0) lossacc += -(y * lp + (1.f - y) * l1p);
+          dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
+        } else {
+          dpm = g.dprob[b * g.lddprob + t];
+        }
+        const float dlogit = valid ? dpm * m * p * (1.f - p) : 0.f;
+        if (sub == 0) dbacc[t] += dlogit;
+        if (col) {
+          fma4(dwacc[t], dlogit, hv);
+          float4 dh = make_float4(dlogit * wv[t].x, dlogit * wv[t].y, dlogit * wv[t].z, dlogit * wv[t].w);
+          if (d.h_relu) {
+            if (!(hv.x > 0.f)) dh.x = 0.f;
+            if (!(hv.y > 0.f)) dh.y = 0.f;
+            if (!(hv.z > 0.f)) dh.z = 0.f;
+            if (!(hv.w > 0.f)) dh.w = 0.f;
+          }
+          if (valid) st4(d.dH + b * d.lddh + 4 * sub, dh);
+        }
+      }
+    }
+  }
+  if (!aux.train) return;
+  constexpr int PH = 4 * LPS + 1;  // per head: dw (4*LPS slots) + dbias
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= g.n_heads) continue;
+    float4 v = dwacc[t];
+    v.x = cross_group_sum<LPS>(v.x);
+    v.y = cross_group_sum<LPS>(v.y);
+    v.z = cross_group_sum<LPS>(v.z);
+    v.w = cross_group_sum<LPS>(v.w);
+    const float db = cross_group_sum<LPS>(dbacc[t]);
+    if (grp == 0) {
+      red[wave][t * PH + 4 * sub + 0] = v.x;
+      red[wave][t * PH + 4 * sub + 1] = v.y;
+      red[wave][t * PH + 4 * sub + 2] = v.z;
+      red[wave][t * PH + 4 * sub + 3] = v.w;
+      if (sub == 0) red[wave][t * PH + 4 * LPS] = db;
+    }
+  }
+  const float ls = cross_group_sum<LPS>(lossacc);
+  if (lane == 0) red[wave][NT * PH] = ls;
+  __syncthreads();
+  float* out = aux.slab + (int64_t)blockIdx.x * aux.stride;
+  for (int i = threadIdx.x; i < g.n_heads * (aux.hmax + 1) + 1; i += FB) {
+    int src;
+    if (i == g.n_heads * (aux.hmax + 1)) {
+      src = NT * PH;
+    } else {
+      const int t = i / (aux.hmax + 1), h = i % (aux.hmax + 1);
+      src = t * PH + (h == aux.hmax ? 4 * LPS : h);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) s += red[w][src];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int pick_lps(int width) { return width <= 64 ? 16 : (width <= 128 ? 32 : (width <= 256 ? 64 : 0)); }
+
+int fast_row_grid(int64_t B, int lps) {
+  const int spb = FW * (64 / lps);
+  int64_t blocks = cdiv(B, spb);
+  if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: one partial slab row per workgroup goes to the reducer
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+static bool ok4(const void* p, int64_t ld) { return aligned16(p) && (ld % 4 == 0); }
+
+int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
+  if (g->H % 4 || g->H > 256) return 0;
+  int width = g->H, nemax = 0, off = 0;
+  for (int x = 0; x < g->n_experts; ++x) {
+    if (!ok4(g->E[x], g->lde[x])) return 0;
+    if (bwd && !ok4(g->dE[x], g->ldde[x])) return 0;
+  }
+  for (int i = 0; i < g->n_gates; ++i) {
+    const mml_gate_desc& d = g->gate[i];
+    if (d.Gd % 4 || d.Gd > 256 || !ok4(d.G, d.ldg) || !aligned16(d.Wg)) return 0;
+    if (!bwd && !ok4(d.mix, d.ldmix)) return 0;
+    if (bwd && d.active && (!ok4(d.dmix, d.lddmix) || !ok4(d.dG, d.lddg))) return 0;
+    if (d.Gd > width) width = d.Gd;
+    if (d.ne > nemax) nemax = d.ne;
+    aux.wg_off[i] = off;
+    off += d.ne * d.Gd;
+  }
+  aux.wg_total = off;
+  aux.lps = pick_lps(width);
+  aux.ne = nemax <= 4 ? 4 : (nemax <= 8 ? 8 : 16);
+  aux.ng = g->n_gates <= 2 ? 2 : (g->n_gates <= 4 ? 4 : 8);
+  if (bwd && aux.ne * aux.ng > 32) return 0;  // register budget of the dWg accumulators
+  aux.grid = fast_row_grid(g->B, aux.lps);
+  return aux.lps;
+}
+
+template <int LPS>
+static void launch_gate_fwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
+  const size_t lds = (size_t)aux.wg_total * 4;
+  dim3 gr(aux.grid), bl(FB);
+  if (aux.ne == 4) MML_LAUNCH((gate_fwd_fast_kernel<LPS, 4>), gr, bl, lds, st, g, aux);
+  else if (aux.ne == 8) MML_LAUNCH((gate_fwd_fast_kernel<LPS, 8>), gr, bl, lds, st, g, aux);
+  else MML_LAUNCH((gate_fwd_fast_kernel<LPS, 16>), gr, bl, lds, st, g, aux);
+}
+
+int gate_fwd_fast(const mml_gate_group* g, hipStream_t st) {
+  GateFastAux aux{};
+  if (!gate_fast_config(g, false, aux)) return 1;  // not handled
+  if ((size_t)aux.wg_total * 4 > 48 * 1024) return 1;
+  if (aux.lps == 16) launch_gate_fwd<16>(*g, aux, st);
+  else if (aux.lps == 32) launch_gate_fwd<32>(*g, aux, st);
+  else launch_gate_fwd<64>(*g, aux, st);
+  return check_launch("mml_gate_mix_fwd(fast)");
+}
+
+size_t gate_bwd_fast_lds(const GateFastAux& aux) {
+  const int spw = 64 / aux.lps;
+  return ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)FW * aux.wg_total) * 4;
+}
+
+template <int LPS>
+static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
+  const size_t lds = gate_bwd_fast_lds(aux);
+  dim3 gr(aux.grid), bl(FB);
+#define MML_GB(NE_, NG_) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_>), gr, bl, lds, st, g, aux)
+  if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
+  else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
+  else if (aux.ne == 4 && aux.ng == 8) MML_GB(4, 8);
+  else if (aux.ne == 8 && aux.ng == 2) MML_GB(8, 2);
+  else if (aux.ne == 8 && aux.ng == 4) MML_GB(8, 4);
+  else if (aux.ne == 16 && aux.ng == 2) MML_GB(16, 2);
+  else return 1;
+#undef MML_GB
+  return check_launch("mml_gate_mix_bwd(fast)");
+}
+
+int gate_bwd_fast(const mml_gate_group* g, GateFastAux& aux, hipStream_t st) {
+  if (gate_bwd_fast_lds(aux) > 60 * 1024) return 1;
+  if (aux.lps == 16) return launch_gate_bwd<16>(*g, aux, st);
+  if (aux.lps == 32) return launch_gate_bwd<32>(*g, aux, st);
+  return launch_gate_bwd<64>(*g, aux, st);
+}
+
+int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux& aux) {
+  if (hmax % 4 || hmax > 256) return 0;
+  for (int t = 0; t < g->n_heads; ++t) {
+    const mml_head_desc& d = g->head[t];
+    if (d.H % 4 || !ok4(d.Hin, d.ldh) || !aligned16(d.w) || (d.w2 && !aligned16(d.w2))) return 0;
+    if (train && !ok4(d.dH, d.lddh)) return 0;
+  }
+  aux.lps = pick_lps(hmax);
+  aux.nt = g->n_heads <= 2 ? 2 : (g->n_heads <= 4 ? 4 : 8);
+  aux.hmax = hmax;
+  aux.grid = fast_row_grid(g->B, aux.lps);
+  return aux.lps;
+}
+
+template <int LPS>
+static void launch_head(const mml_head_group& g, const HeadFastAux& aux, hipStream_t st) {
+  dim3 gr(aux.grid), bl(FB);
+  if (aux.nt == 2) MML_LAUNCH((head_fast_kernel<LPS, 2>), gr, bl, 0, st, g, aux);
+  else if (aux.nt == 4) MML_LAUNCH((head_fast_kernel<LPS, 4>), gr, bl, 0, st, g, aux);
+  else MML_LAUNCH((head_fast_kernel<LPS, 8>), gr, bl, 0, st, g, aux);
+}
+
+int head_fast(const mml_head_group* g, const HeadFastAux& aux, hipStream_t st) {
+  if (aux.lps == 16) launch_head<16>(*g, aux, st);
+  else if (aux.lps == 32) launch_head<32>(*g, aux, st);
+  else launch_head<64>(*g, aux, st);
+  return check_launch("mml_head(fast)");
+}
+
+}  // namespace mml

@@ -1,0 +1,29 @@
+// Internal interface between gate_head.hip (C-ABI entry points, generic kernels) and rows_fast.hip (aligned fast paths).
+#pragma once
+#include "common.hpp"
+
+namespace mml {
+
+struct GateFastAux {
+  int32_t wg_off[MML_MAX_GATES];  // float offset of gate i's weight block (all gates, active or not)
+  int32_t wg_total;
+  int32_t lps, ne, ng, grid;
+  int32_t pad_;
+  float* slab;                    // backward: [grid][wg_total] per-workgroup dWg partials
+};
+
+struct HeadFastAux {
+  float* slab;                    // [grid][stride]
+  int32_t stride, hmax, train;
+  int32_t lps, nt, grid;
+};
+
+// return the lane-group width (16/32/64) when the fast path applies, 0 otherwise
+int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux);
+int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux& aux);
+// return 1 = not handled (caller falls back), MML_OK, or a negative error
+int gate_fwd_fast(const mml_gate_group* g, hipStream_t st);
+int gate_bwd_fast(const mml_gate_group* g, GateFastAux& aux, hipStream_t st);
+int head_fast(const mml_head_group* g, const HeadFastAux& aux, hipStream_t st);
+
+}  // namespace mml

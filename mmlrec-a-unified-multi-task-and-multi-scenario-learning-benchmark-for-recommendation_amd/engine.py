@@ -94,10 +94,33 @@ class Plan:
     @staticmethod
     def _run(calls):
         s = torch.cuda.current_stream().cuda_stream
-        for fn, args in calls:
-            rc = fn(*args, s)
+        for c in calls:
+            rc = c[0](*c[1], s)
             if rc:
-                L.check(rc, fn.__name__)
+                L.check(rc, c[0].__name__)
+
+    @staticmethod
+    def run_timed(calls, acc):
+        """Diagnostic replay: brackets every C-ABI call with HIP events on the launch stream and adds
+        (milliseconds, launches) per call label into `acc` (used by bench.py for the roofline line)."""
+        s = torch.cuda.current_stream()
+        evs = []
+        for c in calls:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            rc = c[0](*c[1], s.cuda_stream)
+            b.record(s)
+            if rc:
+                L.check(rc, c[0].__name__)
+            evs.append((c, a, b))
+        torch.cuda.synchronize()
+        for c, a, b in evs:
+            meta = c[2] if len(c) > 2 else {"kernel": c[0].__name__}
+            e = acc.setdefault(meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            e["ms"] += a.elapsed_time(b)
+            e["launches"] += 1
+            e["flops"] += meta.get("flops", 0.0)
+            e["bytes"] += meta.get("bytes", 0.0)
 
     def run_forward(self):
         self._run(self.fwd)
@@ -155,6 +178,13 @@ class Plan:
 # ==================================================================================================
 # ops
 # ==================================================================================================
+def _gemm_symbol(arc, brc, cols, epi):
+    """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + launch_tiles), as rocprofv3
+    prints it: gemm_kernel<ARC, BRC, BN, EPI>."""
+    bn = 128 if all(c % 128 == 0 for c in cols) else 64
+    return "gemm_kernel<%s, %s, %d, %d>" % ("true" if arc else "false", "true" if brc else "false", bn, epi)
+
+
 class Op:
     def inputs(self):
         return []
@@ -187,9 +217,11 @@ class GatherOp(Op):
         vocab = (L.i64 * F)(*[t.data.shape[0] for t in self.tables])
         col = (L.i32 * F)(*self.cols)
         plan.keep += [tabs, vocab, col]
+        meta = dict(kernel="gather_vec4_kernel" if E % 4 == 0 else "gather_scalar_kernel",
+                    bytes=float(plan.B) * (F * (4 + 8 * E) + 8 * self.nd))  # index + row read + row write
         return [(lib.mml_gather_fwd, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), self.dense_col0,
                                       self.nd, plan.B, self.out.buf.data_ptr(), ops._ld(self.out.buf),
-                                      plan.status.data_ptr()))]
+                                      plan.status.data_ptr()), meta)]
 
     def bwd_calls(self, plan):
         if self.out.grad is None or not any(t.needs_grad for t in self.tables):
@@ -211,9 +243,10 @@ class GatherOp(Op):
             extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
         else:
             extra = (None, None, None, None, 0)
+        meta = dict(kernel="scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel", bytes=float(plan.B) * F * (4 + 12 * E))  # idx + grad read + row RMW
         return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
                                        self.out.grad.data_ptr(), ops._ld(self.out.grad)) + extra +
-                 (plan.status.data_ptr(),))]
+                 (plan.status.data_ptr(),), meta)]
 
 
 class LinearGroupOp(Op):
@@ -233,7 +266,10 @@ class LinearGroupOp(Op):
         descs = ops.make_fwd_descs([dict(A=q["x"].buf, W=q["W"].data, bias=q["b"].data if q.get("b") else None,
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0)) for q in self.p])
         plan.keep.append(descs)
-        return [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)))]
+        kn = self.p[0].get("w_kn", 0)
+        meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0),
+                    flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in self.p))
+        return [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
 
     def bwd_calls(self, plan):
         lib = L.load()
@@ -256,7 +292,9 @@ class LinearGroupOp(Op):
             nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(descs, len(wg))
             ws = ops.workspace(nbytes, plan.device)
             plan.keep += [descs, ws]
-            calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel())))
+            meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2),
+                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg))
+            calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel()), meta))
         # input gradients: one dgrad problem per distinct input value
         by_x = {}
         for q in live:
@@ -279,7 +317,11 @@ class LinearGroupOp(Op):
         for dg in waves:
             descs = ops.make_dgrad_descs(dg)
             plan.keep.append(descs)
-            calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg))))
+            kn = dg[0]["srcs"][0][2]
+            meta = dict(kernel=_gemm_symbol(True, bool(kn), [q["dA"].shape[1] for q in dg], 1),
+                        flops=sum(2.0 * plan.B * q["dA"].shape[1] * sum(sr[0].shape[1] for sr in q["srcs"])
+                                  for q in dg))
+            calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg)), meta))
         return calls
 
 
@@ -303,7 +345,8 @@ class GateGroupOp(Op):
                                   [dict(G=g["G"].buf, Wg=g["Wg"].data, P=g["P"], mix=g["mix"].buf, expert=g["expert"])
                                    for g in self.gates], plan.B, self.H)
         plan.keep.append(grp)
-        return [(L.load().mml_gate_mix_fwd, (C.byref(grp),))]
+        byts = 4.0 * plan.B * (len(self.experts) * self.H + sum(g["G"].n + len(g["expert"]) + self.H for g in self.gates))
+        return [(L.load().mml_gate_mix_fwd, (C.byref(grp),), dict(kernel="gate_fwd_kernel", bytes=byts))]
 
     def bwd_calls(self, plan):
         lib = L.load()
@@ -339,7 +382,10 @@ class GateGroupOp(Op):
         grp = ops.make_gate_group([e.buf for e in self.experts], gl, plan.B, self.H, d_experts=dE, e_relu=e_relu)
         ws = ops.workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)), plan.device)
         plan.keep += [grp, ws]
-        return [(lib.mml_gate_mix_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()))]
+        act = [g for g in self.gates if g["mix"].grad is not None]
+        byts = 4.0 * plan.B * (2 * len(self.experts) * self.H + sum(2 * g["G"].n + len(g["expert"]) + self.H for g in act))
+        return [(lib.mml_gate_mix_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
+                 dict(kernel="gate_bwd_kernel", bytes=byts))]
 
 
 class HeadOp(Op):
@@ -401,7 +447,8 @@ class HeadOp(Op):
 
     def infer_calls(self, plan):
         grp, _ = self._group(plan, False, False, False)
-        return [(L.load().mml_head_fwd, (C.byref(grp),))]
+        return [(L.load().mml_head_fwd, (C.byref(grp),),
+                 dict(kernel="head_kernel", bytes=4.0 * plan.B * sum(h["Hin"].n + 1 for h in self.heads)))]
 
     def train_calls(self, plan, use_dprob, claim=True):
         lib = L.load()
@@ -410,7 +457,9 @@ class HeadOp(Op):
         grp, post = self._group(plan, True, use_dprob, claim)
         ws = ops.workspace(lib.mml_head_workspace_bytes(C.byref(grp)), plan.device)
         plan.keep.append(ws)
-        return [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()))] + post
+        byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
+        return [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
+                 dict(kernel="head_kernel", bytes=byts))] + post
 
 
 class MulOp(Op):
@@ -613,13 +662,17 @@ class Optimizer:
         if entries:
             arr = ops.make_opt_tensors(entries)
             plan.keep.append(arr)
-            calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper))))
+            per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]
+            calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper)),
+                          dict(kernel="opt_dense_kernel(mlp)", bytes=float(per) * sum(e[0].numel() for e in entries))))
         if tabs:
             if self.table_update == "dense_exact":
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
                 arr = ops.make_opt_tensors([(pv.data, pv.grad) + self.state[n] for pv, n in zip(tabs, tnames)])
                 plan.keep += [hz, arr]
-                calls.append((lib.mml_opt_step_dense, (arr, len(tabs), C.byref(hz))))
+                per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind] + 4  # + re-zeroing the gradient
+                calls.append((lib.mml_opt_step_dense, (arr, len(tabs), C.byref(hz)),
+                              dict(kernel="opt_dense_kernel(tables)", bytes=float(per) * sum(pv.data.numel() for pv in tabs))))
             else:
                 rows = st.rows
                 F = len(tabs)

@@ -644,3 +644,91 @@ def train_step(spec, params, opt, X, y, frozen=None):
 
 def params_from_golden(g, prefix="state/"):
     return OrderedDict((k[len(prefix):], np.array(g[k], dtype=F32)) for k in g.files if k.startswith(prefix))
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter shapes (restating the constructors: model/mmoe.py:9-63, sharedbottom.py:10-50, ple.py:11-105,
+# star.py:9-37, pepnet.py:80-119) -- used to build random models at sizes no fixture covers
+# ----------------------------------------------------------------------------------------------
+def param_shapes(spec):
+    mc = spec.mc
+    T, K0, E = spec.T, spec.K0, spec.emb
+    shapes = OrderedDict()
+    for name, v in zip(spec.sparse_names, spec.vocab):
+        shapes[f"embedding_dict.{name}.weight"] = (v, E)
+
+    def dnn(prefix, k, units):
+        for l, u in enumerate(units):
+            shapes[f"{prefix}.linears.{l}.weight"] = (u, k)
+            shapes[f"{prefix}.linears.{l}.bias"] = (u,)
+            k = u
+        return k
+
+    def towers(in_dim):
+        tu = mc.get("tower_dnn_hidden_units", [64])
+        for t in range(T):
+            h = dnn(f"tower_dnn.{t}", in_dim, tu) if tu else in_dim
+            shapes[f"tower_dnn_final_layer.{t}.weight"] = (1, h)
+        for t in range(T):
+            shapes[f"out.{t}.bias"] = (1,)
+
+    name = spec.model_name
+    if name == "sharedbottom":
+        h = dnn("bottom_dnn", K0, mc.get("bottom_dnn_hidden_units", [256, 128]))
+        towers(h)
+    elif name in ("mmoe", "pcg"):
+        Ne = mc.get("num_experts", 4)
+        for e in range(Ne):
+            H = dnn(f"expert_dnn.{e}", K0, mc.get("expert_dnn_hidden_units", [256, 128]))
+        gu = mc.get("gate_dnn_hidden_units", [64])
+        G = K0
+        for t in range(T):
+            if gu:
+                G = dnn(f"gate_dnn.{t}", K0, gu)
+        for t in range(T):
+            shapes[f"gate_dnn_final_layer.{t}.weight"] = (Ne, G)
+        towers(H)
+    elif name == "ple":
+        S, Sh, Lv = mc.get("specific_expert_num", 3), mc.get("shared_expert_num", 1), mc.get("num_levels", 1)
+        eu, gu = mc.get("expert_dnn_hidden_units", [256, 128]), mc.get("gate_dnn_hidden_units", [64])
+        H = eu[-1]
+        for lv in range(Lv):
+            kin = K0 if lv == 0 else H
+            for i in range(T):
+                for j in range(S):
+                    dnn(f"specific_experts.{lv}.{i}.{j}", kin, eu)
+        for lv in range(Lv):
+            kin = K0 if lv == 0 else H
+            for j in range(S):  # built with specific_expert_num, ple.py:47
+                dnn(f"shared_experts.{lv}.0.{j}", kin, eu)
+        for lv in range(Lv):
+            kin = K0 if lv == 0 else H
+            for i in range(T):
+                dnn(f"specific_gate_dnn.{lv}.{i}.0", kin, gu)
+        for lv in range(Lv):
+            for i in range(T):
+                shapes[f"specific_gate_dnn_final_layer.{lv}.{i}.weight"] = (S + Sh, gu[-1])
+        for lv in range(Lv):
+            dnn(f"shared_gate_dnn.{lv}", K0 if lv == 0 else H, gu)
+        for lv in range(Lv):
+            shapes[f"shared_gate_dnn_final_layer.{lv}.weight"] = (T * S + Sh, gu[-1])
+        towers(H)
+    else:
+        raise NotImplementedError(f"param_shapes for {name} (use a golden fixture)")
+    return shapes
+
+
+def random_params(spec, rng, w_std=None, table_std=0.05):
+    """He-scaled random weights (so activations neither vanish nor explode) for parity runs at arbitrary sizes."""
+    params = OrderedDict()
+    for k, shp in param_shapes(spec).items():
+        if k.startswith("embedding_dict."):
+            params[k] = (rng.standard_normal(shp, dtype=np.float32) * F32(table_std))
+        elif len(shp) == 2:
+            std = w_std if w_std is not None else float(np.sqrt(2.0 / shp[1]))
+            params[k] = (rng.standard_normal(shp, dtype=np.float32) * F32(std))
+        elif k.startswith("out."):
+            params[k] = np.zeros(shp, dtype=F32)
+        else:
+            params[k] = (rng.standard_normal(shp, dtype=np.float32) * F32(0.05))
+    return params
