@@ -163,7 +163,7 @@ def main():
     allreduce = None
     if world > 1:
         from mmlrec_amd import parallel
-        allreduce = parallel.make_allreduce(dist)
+        parallel.shard_model(model, dist, args.batch)
 
     def make_batches(B):
         out = []
@@ -201,7 +201,7 @@ def main():
                                f"lr {cfg['optim_config']['lr']}",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
                    "table_update": model.optimizer().table_update, "hip_graph": not args.no_graph,
-                   "tables": "replicated" if world == 1 else "replicated+sparse-sync",
+                   "tables": "single GPU" if world == 1 else "table-wise sharded over ranks, all-to-all index/row/grad exchange",
                    "algorithmic_per_sample": per},
         "roofline": roof,
         "kernels_ms_per_step": {k: round(v["ms"] / main_r["bsteps"], 4) for k, v in

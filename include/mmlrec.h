@@ -240,6 +240,12 @@ int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mm
  * model/pepnet.py:72, :139) */
 int mml_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate,
                mml_stream_t stream);
+/* Up to MML_MAX_FIELDS strided column-block copies in ONE launch: for segment s, dst[s][r*ldd[s] + c] (+)= src[s][r*lds[s] + c],
+ * r < rows, c < width[s].  Packs / unpacks the per-field pieces of index, row and gradient blocks around the
+ * all-to-all exchange of table-sharded runs (no reference counterpart: the reference is single-process).
+ * All arrays are HOST arrays of n_seg entries holding device pointers / element strides. */
+int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst, const int64_t* ldd,
+                  const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate, mml_stream_t stream);
 /* dst = act'(y) * dy for MML_ACT_SIGMOID2 / SIGMOID / RELU given the forward OUTPUT y (GateNN backward) */
 int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t n, int32_t act, mml_stream_t stream);
 

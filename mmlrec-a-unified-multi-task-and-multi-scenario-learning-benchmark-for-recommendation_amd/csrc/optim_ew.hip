@@ -195,6 +195,32 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* src, int64_t l
   }
 }
 
+struct ColSegs {
+  const float* src[MML_MAX_FIELDS];
+  float* dst[MML_MAX_FIELDS];
+  int64_t lds_[MML_MAX_FIELDS], ldd[MML_MAX_FIELDS];
+  int32_t width[MML_MAX_FIELDS];
+  int32_t start[MML_MAX_FIELDS + 1];  // prefix sum of widths
+  int32_t n;
+};
+// One thread per (row, packed column): consecutive lanes walk the packed columns of one row, so each segment is
+// read and written in runs of `width` contiguous floats.
+__global__ __launch_bounds__(256) void copy_cols_kernel(const ColSegs S, int64_t rows, int accumulate) {
+  const int W = S.start[S.n];
+  const int64_t total = rows * W;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / W;
+    const int c = (int)(i - r * W);
+    int s = 0;
+    while (c >= S.start[s + 1]) ++s;
+    const int cc = c - S.start[s];
+    const float v = S.src[s][r * S.lds_[s] + cc];
+    float* d = S.dst[s] + r * S.ldd[s] + cc;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const float* dy, float* dst, int64_t n, int act) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -331,6 +357,32 @@ extern "C" int mml_copy2d(const float* src, int64_t lds_, float* dst, int64_t ld
   MML_LAUNCH(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, to_stream(stream), src, lds_, dst, ldd,
                      rows, cols, accumulate);
   return check_launch("mml_copy2d");
+}
+
+extern "C" int mml_copy_cols(const float* const* src, const int64_t* lds_, float* const* dst, const int64_t* ldd,
+                             const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate,
+                             mml_stream_t stream) {
+  MML_REQUIRE(n_seg >= 0 && rows >= 0, "mml_copy_cols: negative extent");
+  if (n_seg == 0 || rows == 0) return MML_OK;
+  MML_REQUIRE(src && lds_ && dst && ldd && width, "mml_copy_cols: null array");
+  for (int i0 = 0; i0 < n_seg; i0 += MML_MAX_FIELDS) {
+    ColSegs S{};
+    S.n = (n_seg - i0 < MML_MAX_FIELDS) ? (n_seg - i0) : MML_MAX_FIELDS;
+    int acc = 0;
+    for (int s = 0; s < S.n; ++s) {
+      const int k = i0 + s;
+      MML_REQUIRE(src[k] && dst[k] && width[k] > 0 && lds_[k] >= width[k] && ldd[k] >= width[k],
+                  "mml_copy_cols: segment %d malformed", k);
+      S.src[s] = src[k]; S.dst[s] = dst[k]; S.lds_[s] = lds_[k]; S.ldd[s] = ldd[k]; S.width[s] = width[k];
+      S.start[s] = acc;
+      acc += width[k];
+    }
+    S.start[S.n] = acc;
+    MML_LAUNCH(copy_cols_kernel, dim3(ew_grid(rows * acc)), dim3(256), 0, to_stream(stream), S, rows, accumulate);
+    int rc = check_launch("mml_copy_cols");
+    if (rc) return rc;
+  }
+  return MML_OK;
 }
 
 extern "C" int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t n, int32_t act, mml_stream_t stream) {

@@ -44,6 +44,9 @@ class Val:
         return self.buf.shape[1]
 
 
+PY = object()  # call-list marker: (PY, python_callable, args[, meta]) entries (collectives) next to (c_fn, args[, meta])
+
+
 def _claim(x):
     acc = 1 if x.written else 0
     x.written += 1
@@ -93,8 +96,11 @@ class Plan:
     # ---- execution ---------------------------------------------------------------------------
     @staticmethod
     def _run(calls):
-        s = torch.cuda.current_stream().cuda_stream
+        s = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         for c in calls:
+            if c[0] is PY:
+                c[1](*c[2])
+                continue
             rc = c[0](*c[1], s)
             if rc:
                 L.check(rc, c[0].__name__)
@@ -108,14 +114,20 @@ class Plan:
         for c in calls:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(s)
-            rc = c[0](*c[1], s.cuda_stream)
+            if c[0] is PY:
+                c[1](*c[2])
+            else:
+                rc = c[0](*c[1], s.cuda_stream)
+                if rc:
+                    L.check(rc, c[0].__name__)
             b.record(s)
-            if rc:
-                L.check(rc, c[0].__name__)
             evs.append((c, a, b))
         torch.cuda.synchronize()
         for c, a, b in evs:
-            meta = c[2] if len(c) > 2 else {"kernel": c[0].__name__}
+            if c[0] is PY:
+                meta = c[3] if len(c) > 3 else {"kernel": getattr(c[1], "__name__", "python")}
+            else:
+                meta = c[2] if len(c) > 2 else {"kernel": c[0].__name__}
             e = acc.setdefault(meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
             e["ms"] += a.elapsed_time(b)
             e["launches"] += 1
@@ -610,9 +622,12 @@ class ParamStore:
                 pv.needs_grad = True
             self.table_grads_ready = True
 
-    def ensure_rows(self, cap):
-        if self.rows is None or self.rows.touched.numel() < cap:
-            self.rows = TableRows([self.pvals[n].data.shape[0] for n in self.table_names], self.device, cap)
+    def ensure_rows(self, cap, names=None):
+        """Touched-row bookkeeping over the tables this rank updates (all of them unless `names` is given)."""
+        names = list(self.table_names if names is None else names)
+        if self.rows is None or self.rows.touched.numel() < cap or self.rows_names != names:
+            self.rows = TableRows([self.pvals[n].data.shape[0] for n in names], self.device, cap)
+            self.rows_names = names
         return self.rows
 
     def stale(self):

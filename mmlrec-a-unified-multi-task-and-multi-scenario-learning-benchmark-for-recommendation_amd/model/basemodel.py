@@ -244,8 +244,14 @@ class BaseModel(nn.Module):
                 pos += f.dimension
         x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input")
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
-        plan.add(E.GatherOp(tables, plan.X, [self.feature_index[f.name][0] for f in sp], dense_col0, nd, x0,
-                            sparse_rows=sparse_rows))
+        cols = [self.feature_index[f.name][0] for f in sp]
+        sharding = getattr(self, "_sharding", None)
+        if sharding is not None:
+            from ..parallel import ShardedGatherOp
+            plan.add(ShardedGatherOp(sharding, self._dist, tables, plan.X, cols, dense_col0, nd, x0,
+                                     sparse_rows=sparse_rows, group=self._dist_group))
+        else:
+            plan.add(E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)
         if self.task_name in ("msl", "mtmsl"):

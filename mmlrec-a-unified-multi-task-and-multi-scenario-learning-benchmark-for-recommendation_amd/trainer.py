@@ -12,12 +12,22 @@ class TrainStep:
         self.store = model._store()
         self.opt = model.optimizer()
         rows = None
+        sharding = getattr(model, "_sharding", None)
+        if allreduce is None and sharding is not None:
+            from .parallel import make_allreduce
+            allreduce = make_allreduce(model._dist, model._dist_group)
         if self.opt.table_update == "sparse_rows":
-            rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))
+            if sharding is None:
+                rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))
+            else:  # this rank serves world*B lookups for each of ITS fields
+                sp = model._sparse_cols()
+                names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in sharding.mine]
+                rows = self.store.ensure_rows(sharding.world * int(B) * max(len(names), 1), names)
         self.plan = model._record(B, True, False, self.store, sparse_rows=rows)
         self.opt_calls = self.opt.calls(self.plan)
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
-        self.use_graph = bool(use_graph)
+        # collectives are issued from Python between kernel launches: keep them out of HIP graph capture
+        self.use_graph = bool(use_graph) and sharding is None
         self.g_fb = self.g_opt = None
         self.calls = 0
 
