@@ -377,11 +377,18 @@ class BaseModel(nn.Module):
         return np.concatenate(cols, axis=-1)
 
     @staticmethod
-    def _epoch_permutation(n):
-        """Same draws as the reference's DataLoader(shuffle=True): the loader iterator takes one int64 from the
-        global generator for its base seed, RandomSampler takes another as the seed of a private generator and
-        yields torch.randperm(n) from it."""
+    def _loader_iter_draw():
+        """Every torch DataLoader iterator the reference creates (one per training epoch, one per predict call) takes
+        one int64 from the global generator for its base seed; mirroring the draw keeps seeded runs in lock-step."""
         torch.empty((), dtype=torch.int64).random_()
+
+    @classmethod
+    def _epoch_permutation(cls, n, shuffle):
+        """Same draws as the reference's DataLoader: base-seed draw, then (shuffle=True) RandomSampler draws the
+        seed of a private generator and yields torch.randperm(n) from it."""
+        cls._loader_iter_draw()
+        if not shuffle:
+            return torch.arange(n)
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         g = torch.Generator()
         g.manual_seed(seed)
@@ -426,7 +433,7 @@ class BaseModel(nn.Module):
         pred_epoch = torch.empty((n, self.num_tasks), dtype=torch.float32, device=dev)
         for epoch in range(initial_epoch, epochs):
             start_time = time.time()
-            perm = self._epoch_permutation(n) if shuffle else torch.arange(n)
+            perm = self._epoch_permutation(n, shuffle)
             perm_d = perm.to(dev)
             loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
             for s in range(steps_per_epoch):
@@ -504,6 +511,7 @@ class BaseModel(nn.Module):
         X = x if isinstance(x, np.ndarray) and x.ndim == 2 else self._as_matrix(x)
         dev = self._store().device
         Xd = torch.as_tensor(X, dtype=torch.float32).to(dev)
+        self._loader_iter_draw()
         outs, layers = [], {}
         with torch.no_grad():
             for s in range(0, Xd.shape[0], batch_size):
