@@ -101,6 +101,15 @@ int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32
  * Replaces nn.Linear + activation inside DNN.forward (model/utils.py:146-161: addmm, relu_) and the
  * autograd mm/mm backward pair of each layer.
  * ---------------------------------------------------------------------------------------------- */
+/* Arithmetic of the GEMM family (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain);
+ * 1 = split-bf16: each fp32 operand is staged as hi+lo bf16 and a product costs three v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (relative error <= 3*2^-18 per product, ~1e-5).  Default 0 (exact): with the current staging
+ * pipeline the split mode is load-latency bound and not faster on the MLP shapes, and its error flips more
+ * noise-level Adam updates; it is kept selectable (environment MMLREC_GEMM_MODE=1) for the pipelined kernel of a
+ * later round. */
+int mml_gemm_set_mode(int32_t mode);
+int mml_gemm_get_mode(void);
+
 typedef struct {
   const float* A;    /* [M, K] input activations                                  */
   const float* W;    /* [N, K] nn.Linear weight layout (model/utils.py:130)        */

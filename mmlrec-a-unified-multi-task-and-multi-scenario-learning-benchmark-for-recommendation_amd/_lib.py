@@ -78,6 +78,8 @@ _SIGS = {
     "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
     "mml_scatter_bwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
                                   fp, fp, i32, fp, fp]),
+    "mml_gemm_set_mode": (C.c_int, [i32]),
+    "mml_gemm_get_mode": (C.c_int, []),
     "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_gemm_grouped_wgrad_workspace_bytes": (i64, [_PP(GemmWgradDesc), i32]),

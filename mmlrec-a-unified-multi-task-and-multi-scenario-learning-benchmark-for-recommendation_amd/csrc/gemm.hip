@@ -17,6 +17,8 @@
 #include "common.hpp"
 #include "reduce.hpp"
 
+#include <stdlib.h>
+
 namespace mml {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -25,7 +27,7 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int PITCH_RC = BK + 4;    // [row][k] layout
 constexpr int PITCH_NRC = 128 + 4;  // [k][row] layout (row extent always 128 slots; BN=64 uses half)
-constexpr int LDS_TILE = 128 * PITCH_RC;  // floats; >= BK * PITCH_NRC (4224 < 4608)
+constexpr int LDS_TILE = 5120;  // floats per operand: f32 images need 128*36 = 4608 (>= 32*132), the bf16 hi+lo pair 2*128*40*2 B = 5120 floats
 
 struct Source {
   const float* A;  // row operand
@@ -100,8 +102,9 @@ __device__ __forceinline__ void fetch_tile(float4 (&r)[ROWS / 32], const float* 
       row = row0 + idx / (BK / 4);
       k = k0 + (idx % (BK / 4)) * 4;
     } else {
-      row = row0 + (idx % (ROWS / 4)) * 4;
-      k = k0 + idx / (ROWS / 4);
+      // thread = (row quad, PIECES consecutive k): lanes walk the row quads (512 contiguous bytes per k)
+      row = row0 + (tid % (ROWS / 4)) * 4;
+      k = k0 + (tid / (ROWS / 4)) * PIECES + c;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RC) {
@@ -143,11 +146,76 @@ __device__ __forceinline__ void stash_tile(const float4 (&r)[ROWS / 32], float* 
       const int row = idx / (BK / 4), k4 = idx % (BK / 4);
       *reinterpret_cast<float4*>(lds + row * PITCH_RC + k4 * 4) = r[c];
     } else {
-      const int row4 = idx % (ROWS / 4), k = idx / (ROWS / 4);
+      const int row4 = tid % (ROWS / 4), k = (tid / (ROWS / 4)) * PIECES + c;
       *reinterpret_cast<float4*>(lds + k * PITCH_NRC + row4 * 4) = r[c];
     }
   }
 }
+
+// ---- split-bf16 staging (MODE 1) -------------------------------------------------------------------
+// Every fp32 operand value x is staged as two bf16 planes hi = bf16(x), lo = bf16(x - hi); the product a*b is then
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA pipe with fp32 accumulation: |error| <= 3 * 2^-18 |a*b| per
+// product (the dropped terms), i.e. ~1e-5 relative -- inside the 1e-4 parity budget at 16/3 of the fp32-MFMA rate.
+// Both operands are kept as [row][k] bf16 images (pitch 40 elements = 80 B: conflict-free ds_read_b128 for the
+// 32x32x16 operand map); a [k][row] (row-contiguous) source is transposed for free in registers: a thread holds
+// 4 rows x PIECES consecutive k.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int PB = BK + 8;                 // bf16 elements per image row
+constexpr int PLANE = 128 * PB;            // elements per plane (hi or lo) of one operand
+
+__device__ __forceinline__ void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
+  const f32x2_t v = {x, y};
+  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32 (RNE)
+  const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+  const f32x2_t r = {x - __uint_as_float(hb << 16), y - __uint_as_float(hb & 0xffff0000u)};
+  hi = hb;
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+}
+
+template <bool RC, int ROWS>
+__device__ __forceinline__ void stash_tile_bf16(const float4 (&r)[ROWS / 32], unsigned short* hi, unsigned short* lo,
+                                                int tid) {
+  constexpr int PIECES = ROWS / 32;
+  if (RC) {
+#pragma unroll
+    for (int c = 0; c < PIECES; ++c) {
+      const int idx = tid + 256 * c;
+      const int row = idx / (BK / 4), k4 = idx % (BK / 4);
+      uint2 h, l;
+      split2(r[c].x, r[c].y, h.x, l.x);
+      split2(r[c].z, r[c].w, h.y, l.y);
+      *reinterpret_cast<uint2*>(hi + row * PB + k4 * 4) = h;
+      *reinterpret_cast<uint2*>(lo + row * PB + k4 * 4) = l;
+    }
+  } else {
+    const int row4 = tid % (ROWS / 4), kq = (tid / (ROWS / 4)) * PIECES;
+    const float* f = reinterpret_cast<const float*>(&r[0]);  // f[c*4 + j] = value at (k = kq + c, row = 4*row4 + j)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row4 * 4 + j;
+      if (PIECES == 4) {
+        uint2 h, l;
+        split2(f[0 * 4 + j], f[1 * 4 + j], h.x, l.x);
+        split2(f[2 * 4 + j], f[3 * 4 + j], h.y, l.y);
+        *reinterpret_cast<uint2*>(hi + row * PB + kq) = h;
+        *reinterpret_cast<uint2*>(lo + row * PB + kq) = l;
+      } else {
+        uint32_t h, l;
+        split2(f[0 * 4 + j], f[1 * 4 + j], h, l);
+        *reinterpret_cast<uint32_t*>(hi + row * PB + kq) = h;
+        *reinterpret_cast<uint32_t*>(lo + row * PB + kq) = l;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 read_frag_bf16(const unsigned short* plane, int row, int s, int h) {
+  return *reinterpret_cast<const bf16x8*>(plane + row * PB + 16 * s + 8 * h);
+}
+
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
 
 // fragment for 8-deep group q: 4 values (j = 0..3) for row `row` (tile-local), lane half h.
 template <bool RC>
@@ -162,10 +230,14 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int q, in
 
 // ---- the tile engine -------------------------------------------------------------------------------
 // Accumulates sum_s sum_{k in [kbeg_s, kend_s)} rowop_s[row0+i][k] * colop_s[col0+j][k] into acc.
-template <bool ARC, bool BRC, int BN>
+template <bool ARC, bool BRC, int BN, int MODE>
 __device__ __forceinline__ void tile_mainloop(f32x16 (&acc)[2][BN / 64], const Launch& L, const Problem& P, int row0,
                                               int col0, int kbeg, int klen_limit, float* ldsA, float* ldsB,
                                               float* bias_part /* per-thread partial batch sum of dC, or null */) {
+  unsigned short* hiA = reinterpret_cast<unsigned short*>(ldsA);  // MODE 1: [hi plane | lo plane] per operand
+  unsigned short* loA = hiA + PLANE;
+  unsigned short* hiB = reinterpret_cast<unsigned short*>(ldsB);
+  unsigned short* loB = hiB + PLANE;
   constexpr int NI = BN / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -183,22 +255,59 @@ __device__ __forceinline__ void tile_mainloop(f32x16 (&acc)[2][BN / 64], const L
     fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0, kend, S.vecB, tid);
     for (; k0 < kend; k0 += BK) {
       __syncthreads();  // previous step's LDS reads are done
-      stash_tile<ARC, BM>(ra, ldsA, tid);
-      stash_tile<BRC, BN>(rb, ldsB, tid);
+      if (MODE == 0) {
+        stash_tile<ARC, BM>(ra, ldsA, tid);
+        stash_tile<BRC, BN>(rb, ldsB, tid);
+      } else {
+        stash_tile_bf16<ARC, BM>(ra, hiA, loA, tid);
+        stash_tile_bf16<BRC, BN>(rb, hiB, loB, tid);
+      }
       __syncthreads();
       if (k0 + BK < kend) {  // next tile's loads fly during the MFMAs
         fetch_tile<ARC, BM>(ra, S.A, S.lda, row0, P.M, k0 + BK, kend, S.vecA, tid);
         fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0 + BK, kend, S.vecB, tid);
       }
       if (bias_part != nullptr) {
-        // batch sums of dC over this k-slab (wgrad bias gradient); both operands are in [k][row] layout here
-        const float* src = P.bias_cols ? ldsB : ldsA;
+        // batch sums of dC over this k-slab (wgrad bias gradient)
         if (tid < (P.bias_cols ? BN : BM)) {
           float sacc = 0.f;
+          if (MODE == 0) {  // both operands are in [k][row] layout here
+            const float* src = P.bias_cols ? ldsB : ldsA;
 #pragma unroll 8
-          for (int k = 0; k < BK; ++k) sacc += src[k * PITCH_NRC + tid];
+            for (int k = 0; k < BK; ++k) sacc += src[k * PITCH_NRC + tid];
+          } else {  // [row][k] bf16 hi/lo images
+            const unsigned short* ph = (P.bias_cols ? hiB : hiA) + tid * PB;
+            const unsigned short* pl = (P.bias_cols ? loB : loA) + tid * PB;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) sacc += bf16_bits_to_float(ph[k]) + bf16_bits_to_float(pl[k]);
+          }
           *bias_part += sacc;
         }
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+          bf16x8 ah[2], al[2], bh[NI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            ah[mi] = read_frag_bf16(hiA, wm * 64 + mi * 32 + l31, s2, h);
+            al[mi] = read_frag_bf16(loA, wm * 64 + mi * 32 + l31, s2, h);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = read_frag_bf16(hiB, wn * (BN / 2) + ni * 32 + l31, s2, h);
+            bl[ni] = read_frag_bf16(loB, wn * (BN / 2) + ni * 32 + l31, s2, h);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        continue;
       }
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
@@ -230,7 +339,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <bool ARC, bool BRC, int BN, int EPI>
+template <bool ARC, bool BRC, int BN, int EPI, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const Launch L) {
   constexpr int NI = BN / 64;
   __shared__ __attribute__((aligned(16))) float lds[2 * LDS_TILE];
@@ -268,7 +377,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Launch L) {
 
   float bsum = 0.f;
   const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
-  tile_mainloop<ARC, BRC, BN>(acc, L, P, row0, col0, kbeg, klen, ldsA, ldsB, want_bias ? &bsum : nullptr);
+  tile_mainloop<ARC, BRC, BN, MODE>(acc, L, P, row0, col0, kbeg, klen, ldsA, ldsB, want_bias ? &bsum : nullptr);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -325,6 +434,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Launch L) {
 
 static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
 
+// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per fp32 product)
+static int g_gemm_mode = -1;
+static int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("MMLREC_GEMM_MODE");
+    g_gemm_mode = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_gemm_mode;
+}
+
 template <int EPI>
 static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nblocks, hipStream_t st, const char* who) {
   if (nblocks <= 0) return MML_OK;
@@ -333,7 +452,12 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-#define MML_GO(A_, B_, N_) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI>), g, b, 0, st, L)
+  const int mode = gemm_mode();
+#define MML_GO(A_, B_, N_)                                                      \
+  do {                                                                          \
+    if (mode == 0) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, 0, st, L); \
+    else MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 1>), g, b, 0, st, L);           \
+  } while (0)
   if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
   else if (arc && !brc) { if (bn == 128) MML_GO(true, false, 128); else MML_GO(true, false, 64); }
   else if (!arc && !brc) { if (bn == 128) MML_GO(false, false, 128); else MML_GO(false, false, 64); }
@@ -354,6 +478,14 @@ static int pick_bn(const int32_t* Ns, int n) {
 }  // namespace mml
 
 using namespace mml;
+
+extern "C" int mml_gemm_set_mode(int32_t mode) {
+  MML_REQUIRE(mode == 0 || mode == 1, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+  g_gemm_mode = mode;
+  return MML_OK;
+}
+
+extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
 
 extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");

@@ -58,6 +58,11 @@ class Plan:
         self.device, self.B, self.training = device, int(B), bool(training)
         self.ops = []
         self.fwd, self.head_infer, self.head_train, self.head_bwd, self.bwd = [], [], [], [], []
+        # backward is kept in three pieces so a trainer can overlap them on two HIP streams: `bwd` = the critical
+        # chain (dgrads, gate/elementwise backward), `bwd_tail` = the table scatter (needs d(dnn_input), feeds the
+        # HBM-bound table optimizer), `bwd_side` = every weight-gradient GEMM (MFMA-bound, needs only values the
+        # chain has already produced).  Sequential order bwd -> bwd_tail -> bwd_side is always valid.
+        self.bwd_tail, self.bwd_side = [], []
         self.keep = []  # ctypes descriptor blocks + buffers referenced by raw pointer
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.vals = {}
@@ -143,10 +148,14 @@ class Plan:
         self._run(self.fwd)
         self._run(self.head_train)
         self._run(self.bwd)
+        self._run(self.bwd_tail)
+        self._run(self.bwd_side)
 
     def run_backward_from_dprob(self):
         self._run(self.head_bwd)
         self._run(self.bwd)
+        self._run(self.bwd_tail)
+        self._run(self.bwd_side)
 
     # ---- graph recording ---------------------------------------------------------------------
     def add(self, op):
@@ -176,7 +185,14 @@ class Plan:
                     self.bwd.append((L.load().mml_act_bwd, (v.buf.data_ptr(), v.grad.data_ptr(), v.grad.data_ptr(),
                                                             self._flat_numel(v), v.act)))
                     v.deriv_applied = True
-            self.bwd.extend(op.bwd_calls(self))
+            for c in op.bwd_calls(self):
+                meta = c[-1] if isinstance(c[-1], dict) else {}
+                if meta.get("side"):
+                    self.bwd_side.append(c)
+                elif meta.get("tail"):
+                    self.bwd_tail.append(c)
+                else:
+                    self.bwd.append(c)
 
     def _flat_numel(self, v):
         # act_bwd is a flat kernel: value and gradient must share the padded pitch (they do by construction)
@@ -192,9 +208,10 @@ class Plan:
 # ==================================================================================================
 def _gemm_symbol(arc, brc, cols, epi):
     """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + launch_tiles), as rocprofv3
-    prints it: gemm_kernel<ARC, BRC, BN, EPI>."""
+    prints it: gemm_kernel<ARC, BRC, BN, EPI, MODE>."""
     bn = 128 if all(c % 128 == 0 for c in cols) else 64
-    return "gemm_kernel<%s, %s, %d, %d>" % ("true" if arc else "false", "true" if brc else "false", bn, epi)
+    return "gemm_kernel<%s, %s, %d, %d, %d>" % ("true" if arc else "false", "true" if brc else "false", bn, epi,
+                                                L.load().mml_gemm_get_mode())
 
 
 class Op:
@@ -255,7 +272,8 @@ class GatherOp(Op):
             extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
         else:
             extra = (None, None, None, None, 0)
-        meta = dict(kernel="scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel", bytes=float(plan.B) * F * (4 + 12 * E))  # idx + grad read + row RMW
+        meta = dict(kernel="scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel",
+                    bytes=float(plan.B) * F * (4 + 12 * E), tail=True)  # idx + grad read + row RMW
         return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
                                        self.out.grad.data_ptr(), ops._ld(self.out.grad)) + extra +
                  (plan.status.data_ptr(),), meta)]
@@ -305,7 +323,7 @@ class LinearGroupOp(Op):
             ws = ops.workspace(nbytes, plan.device)
             plan.keep += [descs, ws]
             meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2),
-                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg))
+                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True)
             calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel()), meta))
         # input gradients: one dgrad problem per distinct input value
         by_x = {}
@@ -543,8 +561,10 @@ class PMulOp(Op):
             return []
         acc_a = _claim(self.a) if da is not None else 0
         acc_b = _claim(self.b) if db is not None else 0
+        # consumes a weight gradient -> belongs behind the wgrad GEMMs on the side list
         return [(L.load().mml_ew_mul_bwd, (self.out.grad.data_ptr(), self.a.data.data_ptr(), self.b.data.data_ptr(),
-                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.out.data.numel()))]
+                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.out.data.numel()),
+                 dict(kernel="ew_mul_bwd_kernel", side=True))]
 
 
 class PAddOp(Op):
@@ -565,7 +585,8 @@ class PAddOp(Op):
         n = self.out.data.numel()
         for p in self.ins:
             if p.needs_grad:
-                calls.append((L.load().mml_copy2d, (self.out.grad.data_ptr(), n, p.grad.data_ptr(), n, 1, n, _claim(p))))
+                calls.append((L.load().mml_copy2d, (self.out.grad.data_ptr(), n, p.grad.data_ptr(), n, 1, n, _claim(p)),
+                              dict(kernel="copy2d_kernel", side=True)))
         return calls
 
 
@@ -665,9 +686,16 @@ class Optimizer:
 
     def calls(self, plan):
         """Optimizer call list for one step (appended after a plan's backward)."""
+        c = self.calls_split(plan)
+        return c["pre"] + c["mlp"] + c["tables"]
+
+    def calls_split(self, plan):
+        """{'pre': step-counter bump (must run before anything reads it), 'mlp': dense MLP update, 'tables': table
+        update (+ touched-list reset)} so a trainer can put the two updates on different streams."""
         lib = L.load()
         st = self.store
-        calls = [(lib.mml_counter_update, (self.step_dev.data_ptr(), 1, 0))]
+        pre = [(lib.mml_counter_update, (self.step_dev.data_ptr(), 1, 0))]
+        calls = []
         dense = [(pv, n) for n, pv in st.pvals.items() if not pv.is_table and pv.written]
         entries = [(pv.data, pv.grad) + self.state[n] for pv, n in dense]
         tabs = [st.pvals[n] for n in st.table_names if st.pvals[n].written]
@@ -680,6 +708,7 @@ class Optimizer:
             per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]
             calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper)),
                           dict(kernel="opt_dense_kernel(mlp)", bytes=float(per) * sum(e[0].numel() for e in entries))))
+        mlp_calls, calls = calls, []
         if tabs:
             if self.table_update == "dense_exact":
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
@@ -702,4 +731,4 @@ class Optimizer:
                 calls.append((lib.mml_opt_step_rows, (pt, pg, p1, p2, ps, rb, F, E, rows.touched.data_ptr(),
                                                       rows.count.data_ptr(), rows.touched.numel(), C.byref(hyper))))
                 calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
-        return calls
+        return {"pre": pre, "mlp": mlp_calls, "tables": calls}

@@ -160,9 +160,11 @@ class ShardedGatherOp(E.Op):
         rsend, rrecv = sh.row_splits(B)  # gradient traffic runs the row exchange backwards
         self.grad_send = plan.empty(max(sum(rrecv), 1))
         self.grad_recv = plan.empty(max(sum(rsend), 1))
-        calls = [copy_cols_call(plan, sh.pack_grad_segments(self.out.grad, self.grad_send, B), B)]
+        pk = copy_cols_call(plan, sh.pack_grad_segments(self.out.grad, self.grad_send, B), B)
+        pk[2]["tail"] = True
+        calls = [pk]
         calls.append((E.PY, self._a2a, (self.grad_recv[:sum(rsend)], self.grad_send[:sum(rrecv)], rsend, rrecv),
-                      dict(kernel="all_to_all(row grads)")))
+                      dict(kernel="all_to_all(row grads)", tail=True)))
         if nfm:
             mine = [self.tables[f] for f in sh.mine]
             if not all(t.needs_grad for t in mine):
@@ -184,7 +186,7 @@ class ShardedGatherOp(E.Op):
             calls.append((lib.mml_scatter_bwd, (gt, vocab, col, nfm, Em, self.recv_idx.data_ptr(), nfm, W * B,
                                                 self.grad_recv.data_ptr(), nfm * Em) + extra +
                           (plan.status.data_ptr(),),
-                          dict(kernel="scatter_hash_kernel", bytes=float(W * B) * nfm * (4 + 12 * Em))))
+                          dict(kernel="scatter_hash_kernel", bytes=float(W * B) * nfm * (4 + 12 * Em), tail=True)))
         return calls
 
 

@@ -1,13 +1,19 @@
 """One fused training step = forward launches + head/BCE launch + backward launches + optimizer launches, recorded
 once per batch size and replayed (as HIP graphs when enabled).  Counterpart of the loop body of BaseModel.fit in the
-reference (model/basemodel.py:261-313) minus logging."""
+reference (model/basemodel.py:261-313) minus logging.
+
+Two HIP streams: after the backward chain has produced every dL/d(pre-activation), the step forks --
+  main stream : table scatter -> table optimizer            (HBM / atomics bound)
+  side stream : all weight-gradient GEMMs -> [all-reduce] -> MLP optimizer   (MFMA bound)
+-- and joins at the end, so the 3.2 GB table stream of the reference-exact dense Adam hides behind the wgrad GEMMs.
+"""
 import torch
 
 from . import engine as E
 
 
 class TrainStep:
-    def __init__(self, model, B, use_graph=True, allreduce=None):
+    def __init__(self, model, B, use_graph=True, allreduce=None, overlap=True):
         self.model = model
         self.store = model._store()
         self.opt = model.optimizer()
@@ -24,43 +30,57 @@ class TrainStep:
                 names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in sharding.mine]
                 rows = self.store.ensure_rows(sharding.world * int(B) * max(len(names), 1), names)
         self.plan = model._record(B, True, False, self.store, sparse_rows=rows)
-        self.opt_calls = self.opt.calls(self.plan)
+        self.opt_split = self.opt.calls_split(self.plan)
+        self.opt_calls = self.opt_split["pre"] + self.opt_split["mlp"] + self.opt_split["tables"]
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
         # collectives are issued from Python between kernel launches: keep them out of HIP graph capture
         self.use_graph = bool(use_graph) and sharding is None
+        self.overlap = bool(overlap)
+        self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
         self.g_fb = self.g_opt = None
         self.calls = 0
 
-    def _eager(self):
-        self.plan.run_train_fwd_bwd()
-        if self.allreduce is not None:
-            self.allreduce(self.store.arena)
-        E.Plan._run(self.opt_calls)
-
-    def _capture(self):
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.plan.run_train_fwd_bwd()
-            if self.allreduce is None:
-                E.Plan._run(self.opt_calls)
-        if self.allreduce is not None:
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                E.Plan._run(self.opt_calls)
+    def _body(self, with_allreduce=True):
+        p, run = self.plan, E.Plan._run
+        run(self.opt_split["pre"])
+        run(p.fwd)
+        run(p.head_train)
+        run(p.bwd)
+        if not self.overlap:
+            run(p.bwd_tail)
+            run(p.bwd_side)
+            if self.allreduce is not None and with_allreduce:
+                self.allreduce(self.store.arena)
+            run(self.opt_split["mlp"])
+            run(self.opt_split["tables"])
+            return
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.side.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            run(p.bwd_side)
+            if self.allreduce is not None and with_allreduce:
+                self.allreduce(self.store.arena)
+            run(self.opt_split["mlp"])
+            join = torch.cuda.Event()
+            join.record(self.side)
+        run(p.bwd_tail)
+        run(self.opt_split["tables"])
+        main.wait_event(join)
 
     def run(self):
         """plan.X / plan.y must hold the batch. After the call plan.prob / plan.loss hold this step's outputs.
-        The first call runs eagerly (HIP graph capture needs a warmed-up allocator/module state and does not execute
-        what it records); the second call captures, then every call replays."""
+        The first call runs eagerly (HIP graph capture needs warmed-up state and does not execute what it records);
+        the second call captures, then every call replays."""
         if not self.use_graph or self.calls == 0:
-            self._eager()
+            self._body()
         else:
             if self.g_fb is None:
                 torch.cuda.synchronize()
-                self._capture()
+                self.g_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_fb):
+                    self._body()
             self.g_fb.replay()
-            if self.allreduce is not None:
-                self.allreduce(self.store.arena)
-                self.g_opt.replay()
         self.calls += 1
         self.opt.steps_done += 1
