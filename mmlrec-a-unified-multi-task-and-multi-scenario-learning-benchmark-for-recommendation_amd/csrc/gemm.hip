@@ -339,12 +339,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// BN = 64 tiles need <= 128 VGPRs, so four workgroups (one wave each per SIMD) fit a CU; the exact-fp32 images take
+// 36 KiB of LDS per workgroup (4 x 36 = 144 KiB <= 160 KiB), the bf16 hi/lo images 40 KiB.
 template <bool ARC, bool BRC, int BN, int EPI, int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const Launch L) {
+__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Launch L) {
   constexpr int NI = BN / 64;
-  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_TILE];
+  constexpr int TILE_FLOATS = (MODE == 0) ? 128 * PITCH_RC : LDS_TILE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
   float* ldsA = lds;
-  float* ldsB = lds + LDS_TILE;
+  float* ldsB = lds + TILE_FLOATS;
 
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0, row0, col0, kbeg = 0, klen = 0, split = 0;
@@ -453,10 +456,19 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
   }
   dim3 g((unsigned)nblocks), b(256);
   const int mode = gemm_mode();
-#define MML_GO(A_, B_, N_)                                                      \
-  do {                                                                          \
-    if (mode == 0) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, 0, st, L); \
-    else MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 1>), g, b, 0, st, L);           \
+  // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  At four
+  // workgroups per CU they would own every VGPR of every SIMD and the optimizer's waves could not co-reside; an
+  // unused dynamic-LDS request caps them at three per CU (3 x 53 KiB), leaving a wave slot and 128 VGPRs per SIMD.
+  static int pad_env = -1;
+  if (pad_env < 0) {
+    const char* e = getenv("MMLREC_WGRAD_LDS_PAD");
+    pad_env = e ? atoi(e) : 17 * 1024;
+  }
+  const size_t dyn = (EPI == EPI_SLAB) ? (size_t)pad_env : 0;
+#define MML_GO(A_, B_, N_)                                                        \
+  do {                                                                            \
+    if (mode == 0) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L); \
+    else MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 1>), g, b, dyn, st, L);           \
   } while (0)
   if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
   else if (arc && !brc) { if (bn == 128) MML_GO(true, false, 128); else MML_GO(true, false, 64); }
@@ -470,8 +482,16 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
 }
 
 static int pick_bn(const int32_t* Ns, int n) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("MMLREC_GEMM_BN");
+    force = e ? atoi(e) : 0;
+  }
+  if (force == 64 || force == 128) return force;
+  // 128 x 64 tiles stay under 128 VGPRs -> four workgroups per CU; on the MLP shapes (N <= 512, K <= 512) that
+  // occupancy beats the better operand reuse of 128 x 128 tiles (measured: +8...25 %), which only pays on wide outputs
   for (int i = 0; i < n; ++i)
-    if (Ns[i] % 128 != 0) return 64;
+    if (Ns[i] % 128 != 0 || Ns[i] < 1024) return 64;
   return 128;
 }
 

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
       reinterpret_cast<float4*>(T.param)[i] = p;
       if (T.state1) reinterpret_cast<float4*>(T.state1)[i] = a;
       if (T.state2) reinterpret_cast<float4*>(T.state2)[i] = b;
-      if (h.zero_grad) reinterpret_cast<float4*>(gw)[i] = make_float4(0, 0, 0, 0);
+      // re-zero only what the scatter touched (~1 % of the rows): saves the 4 B/element store of a blind memset
+      if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
+        reinterpret_cast<float4*>(gw)[i] = make_float4(0, 0, 0, 0);
     }
   }
   const int64_t tail0 = vec ? (n4 << 2) : 0;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
     T.param[i] = p;
     if (T.state1) T.state1[i] = a;
     if (T.state2) T.state2[i] = b;
-    if (h.zero_grad) gw[i] = 0.f;
+    if (h.zero_grad && T.grad[i] != 0.f) gw[i] = 0.f;
   }
 }
 

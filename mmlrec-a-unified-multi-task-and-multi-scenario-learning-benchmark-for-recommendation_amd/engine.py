@@ -209,7 +209,7 @@ class Plan:
 def _gemm_symbol(arc, brc, cols, epi):
     """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + launch_tiles), as rocprofv3
     prints it: gemm_kernel<ARC, BRC, BN, EPI, MODE>."""
-    bn = 128 if all(c % 128 == 0 for c in cols) else 64
+    bn = 128 if all(c % 128 == 0 and c >= 1024 for c in cols) else 64  # mirrors pick_bn()
     return "gemm_kernel<%s, %s, %d, %d, %d>" % ("true" if arc else "false", "true" if brc else "false", bn, epi,
                                                 L.load().mml_gemm_get_mode())
 
@@ -714,7 +714,7 @@ class Optimizer:
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
                 arr = ops.make_opt_tensors([(pv.data, pv.grad) + self.state[n] for pv, n in zip(tabs, tnames)])
                 plan.keep += [hz, arr]
-                per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind] + 4  # + re-zeroing the gradient
+                per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]  # p,g,m,v read + p,m,v written
                 calls.append((lib.mml_opt_step_dense, (arr, len(tabs), C.byref(hz)),
                               dict(kernel="opt_dense_kernel(tables)", bytes=float(per) * sum(pv.data.numel() for pv in tabs))))
             else:
