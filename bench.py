@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=4096)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -115,16 +115,20 @@ def roofline_of(acc):
     else:
         achieved = e["bytes"] / e["launches"] / (avg_ms * 1e-3) / 1e9
         peak, unit, bound = 8000.0, "GB/s", "hbm"
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this same
+    # command; tools/pmc_traffic.sh -> profiles/traffic.json).  bench.py cannot run the profiler on itself.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(name)
+            t = json.load(open(tpath)).get(name)
+            traffic = round(float(t["hbm_bytes_per_launch"])) if t else None
         except Exception:
             traffic = None
     out = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": unit,
            "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
-           "launches_per_step": None}
+           "launches_per_step": None,
+           "algorithmic_per_launch": round((e["flops"] if e["flops"] > 0 else e["bytes"]) / e["launches"])}
     if note:
         out["note"] = note
     return out
@@ -138,6 +142,7 @@ def cpu_baseline(args):
     from mmlrec_amd import workloads as W
     cfg, names, vocab, dense = W.workload(args.workload)
     spec = orc.Spec(cfg, names, vocab, dense)
+    fast = orc.use_fast(True)  # C/OpenMP gather / scatter / dense-Adam loops of the oracle, when built
     rng = np.random.default_rng(0)
     params = orc.random_params(spec, rng)
     opt = orc.DenseOptimizer(cfg["optim_config"]["optimizer"], cfg["optim_config"]["lr"])
@@ -153,8 +158,9 @@ def cpu_baseline(args):
     return {"value": round(args.cpu_batch * args.cpu_steps / dt, 1), "unit": "samples/s", "cores": cores,
             "kind": "port",
             "sample": f"{args.cpu_steps} full train steps (fwd+BCE+bwd+dense {cfg['optim_config']['optimizer']}) of "
-                      f"{args.workload} at batch {args.cpu_batch}, {args.dist} indices; numpy oracle "
-                      f"(oracle/mmlrec_oracle.py, multi-threaded BLAS GEMMs + C/OpenMP row kernels when built)"}
+                      f"{args.workload} at batch {args.cpu_batch}, {args.dist} indices; oracle/mmlrec_oracle.py with "
+                      f"multi-threaded BLAS GEMMs and " + ("C/OpenMP" if fast else "numpy (single-thread)") +
+                      " gather/scatter/dense-Adam loops"}
 
 
 def main():

@@ -23,6 +23,36 @@ import numpy as np
 
 F32 = np.float32
 
+# optional C/OpenMP versions of the memory-bound loops (oracle/fast.c); numpy is always the fallback
+_FAST = None
+
+
+def use_fast(enable=True):
+    """Load oracle/_build/liboracle_fast.so (built by __graft_entry__.build()); returns True when active."""
+    global _FAST
+    if not enable:
+        _FAST = None
+        return False
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle_fast.so")
+    if not os.path.exists(path):
+        return False
+    lib = ctypes.CDLL(path)
+    lib.gather_fields.restype = lib.scatter_fields.restype = lib.adam_dense.restype = lib.adagrad_dense.restype = None
+    _FAST = lib
+    return True
+
+
+def _fp(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _ptrs(arrays):
+    import ctypes
+    return (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+
 
 # ----------------------------------------------------------------------------------------------
 # model description
@@ -75,13 +105,19 @@ def gather_dnn_input(spec, params, X):
     B = X.shape[0]
     E = spec.emb
     out = np.empty((B, spec.K0), dtype=F32)
-    idx_all = np.trunc(X[:, :spec.F]).astype(np.int64)
+    idx_all = np.ascontiguousarray(np.trunc(X[:, :spec.F]).astype(np.int64))
+    tabs = [params[f"embedding_dict.{name}.weight"] for name in spec.sparse_names]
     for f, name in enumerate(spec.sparse_names):
-        tab = params[f"embedding_dict.{name}.weight"]
         idx = idx_all[:, f]
-        if idx.min() < 0 or idx.max() >= tab.shape[0]:
+        if idx.min() < 0 or idx.max() >= tabs[f].shape[0]:
             raise IndexError(f"index out of range in field {name}")  # nn.Embedding raises IndexError on CPU
-        out[:, f * E:(f + 1) * E] = tab[idx]
+    if _FAST is not None and all(t.flags.c_contiguous and t.dtype == F32 for t in tabs):
+        import ctypes
+        _FAST.gather_fields(_ptrs(tabs), _fp(idx_all), ctypes.c_int64(B), spec.F, E, _fp(out),
+                            ctypes.c_int64(out.strides[0] // 4))
+    else:
+        for f in range(spec.F):
+            out[:, f * E:(f + 1) * E] = tabs[f][idx_all[:, f]]
     if spec.Nd:
         out[:, spec.F * E:] = X[:, spec.F:spec.F + spec.Nd]
     return out, idx_all
@@ -92,8 +128,15 @@ def scatter_table_grads(spec, d_dnn_input, idx_all, params):
     gradW_f = zeros[V_f,E]; gradW_f[idx] += g[:, f*E:(f+1)*E] with duplicates accumulating in batch order."""
     E = spec.emb
     grads = {}
-    for f, name in enumerate(spec.sparse_names):
-        key = f"embedding_dict.{name}.weight"
+    keys = [f"embedding_dict.{name}.weight" for name in spec.sparse_names]
+    if _FAST is not None:
+        import ctypes
+        gs = [np.zeros(params[k].shape, dtype=F32) for k in keys]
+        d = np.ascontiguousarray(d_dnn_input, dtype=F32)
+        _FAST.scatter_fields(_ptrs(gs), _fp(np.ascontiguousarray(idx_all)), ctypes.c_int64(d.shape[0]), spec.F, E,
+                             _fp(d), ctypes.c_int64(d.shape[1]))
+        return dict(zip(keys, gs))
+    for f, key in enumerate(keys):
         g = np.zeros_like(params[key], dtype=F32)
         np.add.at(g, idx_all[:, f], d_dnn_input[:, f * E:(f + 1) * E])
         grads[key] = g
@@ -610,9 +653,15 @@ class DenseOptimizer:
             if self.kind == "sgd":
                 p -= lr * g
             elif self.kind == "adam":  # betas (0.9, 0.999), eps 1e-8, no amsgrad, no weight decay
-                m = st.setdefault("m", np.zeros_like(p))
-                v = st.setdefault("v", np.zeros_like(p))
+                if "m" not in st:
+                    st["m"], st["v"] = np.zeros_like(p), np.zeros_like(p)
+                m, v = st["m"], st["v"]
                 b1, b2 = 0.9, 0.999
+                if _FAST is not None and p.size >= 1 << 16 and p.flags.c_contiguous and g.flags.c_contiguous:
+                    import ctypes
+                    _FAST.adam_dense(_fp(p), _fp(g), _fp(m), _fp(v), ctypes.c_int64(p.size), ctypes.c_float(lr),
+                                     ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(1e-8), self.t)
+                    continue
                 m *= F32(b1)
                 m += F32(1 - b1) * g
                 v *= F32(b2)
@@ -623,11 +672,20 @@ class DenseOptimizer:
                 denom = np.sqrt(v) / F32(np.sqrt(bc2)) + F32(1e-8)
                 p -= step_size * (m / denom)
             elif self.kind == "adagrad":  # lr_decay 0, eps 1e-10, initial accumulator 0
-                s = st.setdefault("sum", np.zeros_like(p))
+                if "sum" not in st:
+                    st["sum"] = np.zeros_like(p)
+                s = st["sum"]
+                if _FAST is not None and p.size >= 1 << 16 and p.flags.c_contiguous and g.flags.c_contiguous:
+                    import ctypes
+                    _FAST.adagrad_dense(_fp(p), _fp(g), _fp(s), ctypes.c_int64(p.size), ctypes.c_float(lr),
+                                        ctypes.c_float(1e-10))
+                    continue
                 s += g * g
                 p -= lr * g / (np.sqrt(s) + F32(1e-10))
             elif self.kind == "rmsprop":  # alpha 0.99, eps 1e-8, no momentum
-                sq = st.setdefault("sq", np.zeros_like(p))
+                if "sq" not in st:
+                    st["sq"] = np.zeros_like(p)
+                sq = st["sq"]
                 sq *= F32(0.99)
                 sq += F32(0.01) * g * g
                 p -= lr * g / (np.sqrt(sq) + F32(1e-8))
