@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step")
     ap.add_argument("--workload", default="mmoe_ae30")
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
-    ap.add_argument("--table-update", default="dense_exact", choices=["dense_exact", "sparse_rows", "auto"])
+    ap.add_argument("--table-update", default="dense_exact", choices=["dense_exact", "sparse_rows", "lazy_exact", "auto"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")

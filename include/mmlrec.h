@@ -96,6 +96,14 @@ int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32
                     uint32_t* const* seen, const int64_t* rowbase, int32_t* touched, int32_t* touched_count,
                     int32_t touched_cap, int32_t* status, mml_stream_t stream);
 
+/* Unique (field, row) list of a batch WITHOUT gradients: the scatter's LDS dedup run on the indices alone.  Appends
+ * rowbase[f] + row for every distinct row of X[:, col[f]] to touched[] (first-seen order, `seen` bitmaps as above).
+ * Used by the lazy-exact table optimizer, which must bring exactly these rows up to date BEFORE the gather reads
+ * them. */
+int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X, int64_t ldX,
+                     int64_t B, uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
+                     int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  grouped GEMM family on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).
  * Replaces nn.Linear + activation inside DNN.forward (model/utils.py:146-161: addmm, relu_) and the
@@ -284,7 +292,24 @@ int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, const mml_opt_h
 int mml_opt_step_rows(float* const* tables, float* const* grad_tables, float* const* state1, float* const* state2,
                       uint32_t* const* seen, const int64_t* rowbase, int32_t F, int32_t E,
                       const int32_t* touched, const int32_t* touched_count, int32_t touched_cap,
+                      int32_t* const* last /* per-table [V] "row is current as of step" words, or NULL */,
                       const mml_opt_hyper* hyper, mml_stream_t stream);
+/* Lazy-EXACT dense Adam/RMSprop for the tables.  The reference's optimizer updates every row every step: a row with
+ * zero gradient still decays its moments and moves by lr_t * m_t / (sqrt(v_t / bc2_t) + eps).  Those zero-gradient
+ * steps are a deterministic function of (p, m, v, step range), so they can be replayed when a row is next READ:
+ *   mml_opt_catchup_rows  replays steps last[row]+1 .. target for the listed rows (target = *step_dev - 1 or
+ *                         hyper->step - 1: the state the reference has before the current step), with the same
+ *                         per-step arithmetic as mml_opt_step_dense and an early exit once the update falls below
+ *                         half an ulp of p (from then on only the moments decay, in closed form);
+ *   mml_opt_catchup_dense does the same for EVERY row of one table (before evaluation / checkpointing).
+ * Together with mml_opt_step_rows(..., last, ...) this reproduces the dense trajectory while touching only the rows
+ * of the current batch. */
+int mml_opt_catchup_rows(float* const* tables, float* const* state1, float* const* state2, int32_t* const* last,
+                         const int64_t* rowbase, int32_t F, int32_t E, const int32_t* touched,
+                         const int32_t* touched_count, int32_t touched_cap, const mml_opt_hyper* hyper,
+                         mml_stream_t stream);
+int mml_opt_catchup_dense(float* table, float* state1, float* state2, int32_t* last, int64_t V, int32_t E,
+                          const mml_opt_hyper* hyper, mml_stream_t stream);
 /* *counter += delta (single thread): Adam step counter, touched-list reset (delta = -*counter when reset != 0) */
 int mml_counter_update(int32_t* counter, int32_t delta, int32_t reset, mml_stream_t stream);
 

@@ -98,7 +98,11 @@ _SIGS = {
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),
     "mml_opt_step_dense": (C.c_int, [_PP(OptTensor), i32, _PP(OptHyper), fp]),
     "mml_opt_step_rows": (C.c_int, [_PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(i64), i32, i32, fp, fp, i32,
-                                    _PP(OptHyper), fp]),
+                                    _PP(fp), _PP(OptHyper), fp]),
+    "mml_opt_catchup_rows": (C.c_int, [_PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(i64), i32, i32, fp, fp, i32,
+                                       _PP(OptHyper), fp]),
+    "mml_opt_catchup_dense": (C.c_int, [fp, fp, fp, fp, i64, i32, _PP(OptHyper), fp]),
+    "mml_index_unique": (C.c_int, [_PP(i64), _PP(i32), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp]),
     "mml_counter_update": (C.c_int, [fp, i32, i32, fp]),
 }
 EXPORTS = tuple(_SIGS)

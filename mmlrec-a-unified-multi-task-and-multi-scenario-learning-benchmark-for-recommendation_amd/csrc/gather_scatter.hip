@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
     const int64_t row = (int64_t)a.X[b * a.ldX + colf];
     if (row < 0) { bad |= 1; continue; }
     if (row >= V) { bad |= 2; continue; }
-    const float g = a.dOut[b * a.ldo + f * E + e];
+    const float g = a.dOut ? a.dOut[b * a.ldo + f * E + e] : 0.f;
     unsigned slot = ((unsigned)row * 2654435761u) >> 16;
     slot &= (SLOTS - 1);
     const int key = (int)row;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
       if (old == -1 || old == key) break;
       slot = (slot + 1) & (SLOTS - 1);
     }
-    atomicAdd(&acc[slot * E + e], g);
+    if (a.dOut) atomicAdd(&acc[slot * E + e], g);
   }
   __syncthreads();
   float* gt = a.gtab[f];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
     const int slot = item / E, e = item - slot * E;
     const int key = keys[slot];
     if (key < 0) continue;
-    atomicAdd(gt + (int64_t)key * E + e, acc[item]);
+    if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, acc[item]);
     if (a.touched && e == 0) {
       const uint32_t bit = 1u << (key & 31);
       const uint32_t old = atomicOr(a.seen[f] + (key >> 5), bit);
@@ -343,4 +343,37 @@ extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, 
   if (blocks > 256 * 16) blocks = 256 * 16;
   MML_LAUNCH(scatter_atomic_kernel, dim3((unsigned)blocks), dim3(threads), 0, to_stream(stream), ft, a);
   return check_launch("mml_scatter_bwd");
+}
+
+extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X,
+                                int64_t ldX, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
+                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                mml_stream_t stream) {
+  MML_REQUIRE(F >= 0 && F <= MML_MAX_FIELDS && vocab && seen && rowbase && touched && touched_count && touched_cap > 0,
+              "mml_index_unique: bad arguments");
+  MML_REQUIRE(E > 0 && E <= 16, "mml_index_unique: E must be in [1,16]");
+  if (B == 0 || F == 0) return MML_OK;
+  MML_REQUIRE(X, "mml_index_unique: null X");
+  FieldTable ft;
+  ScatterArgs a{};
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(vocab[f] > 0 && seen[f], "mml_index_unique: field %d malformed", f);
+    ft.tab[f] = nullptr;
+    ft.vocab[f] = vocab[f];
+    ft.col[f] = col ? col[f] : f;
+    a.seen[f] = seen[f];
+    a.rowbase[f] = rowbase[f];
+  }
+  a.X = X; a.ldX = ldX; a.B = B; a.dOut = nullptr; a.F = F; a.E = E;
+  a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
+  const int slots = (E <= 8) ? 1024 : 512;
+  const int chunk = slots / 2;
+  const int64_t nblocks = (int64_t)F * cdiv(B, chunk);
+  MML_REQUIRE(nblocks <= 0x7fffffff, "mml_index_unique: grid too large");
+  const size_t lds = (size_t)slots * (1 + E) * 4;
+  if (slots == 1024)
+    MML_LAUNCH(scatter_hash_kernel<1024>, dim3((unsigned)nblocks), dim3(256), lds, to_stream(stream), ft, a, chunk);
+  else
+    MML_LAUNCH(scatter_hash_kernel<512>, dim3((unsigned)nblocks), dim3(256), lds, to_stream(stream), ft, a, chunk);
+  return check_launch("mml_index_unique");
 }

@@ -111,6 +111,7 @@ struct RowsLaunch {
   uint32_t* seen[MML_MAX_FIELDS];
   int64_t rowbase[MML_MAX_FIELDS + 1];
   int32_t F, E;
+  int32_t* last[MML_MAX_FIELDS];  // lazy-exact mode: per-row "current as of step" words (or all null)
   const int32_t* touched;
   const int32_t* touched_count;
   int32_t cap;
@@ -141,7 +142,98 @@ __global__ __launch_bounds__(256) void opt_rows_kernel(const RowsLaunch L) {
     if (L.s1[f]) L.s1[f][o] = a;
     if (L.s2[f]) L.s2[f][o] = b;
     L.grad[f][o] = 0.f;
-    if (e == 0) atomicAnd(L.seen[f] + (row >> 5), ~(1u << (row & 31)));
+    if (e == 0) {
+      atomicAnd(L.seen[f] + (row >> 5), ~(1u << (row & 31)));
+      if (L.last[f]) L.last[f][row] = h.step_dev ? *h.step_dev : h.step;
+    }
+  }
+}
+
+// ---- lazy-exact catch-up ---------------------------------------------------------------------------
+// Replays the zero-gradient steps (from, to] of the dense optimizer for one element, with the per-step arithmetic of
+// opt_update (g = 0).  Bias corrections follow torch (double precision powers), advanced by recurrence.
+__device__ __forceinline__ void catchup_element(const mml_opt_hyper& h, int from, int to, float& p, float& m, float& v) {
+  if (to <= from) return;
+  if (h.kind == MML_OPT_ADAM) {
+    if (m == 0.f) {  // never had a gradient (or fully decayed): p cannot move, v only decays
+      v *= powf(h.beta2, (float)(to - from));
+      return;
+    }
+    double b1p = pow((double)h.beta1, (double)from), b2p = pow((double)h.beta2, (double)from);
+    int j = from;
+    while (j < to) {
+      ++j;
+      b1p *= (double)h.beta1;
+      b2p *= (double)h.beta2;
+      StepConsts c;
+      c.step_size = (float)((double)h.lr / (1.0 - b1p));
+      c.inv_bc2s = (float)(1.0 / sqrt(1.0 - b2p));
+      const float before = p;
+      opt_update(h, c, p, 0.f, m, v);
+      // the per-step move shrinks by ~0.9 per step once the bias-correction growth has died out (j > 16): when it
+      // no longer changes p in fp32 it never will again, and only the moments keep decaying
+      if (p == before && j - from > 16) {
+        const float rem = (float)(to - j);
+        m *= powf(h.beta1, rem);
+        v *= powf(h.beta2, rem);
+        return;
+      }
+    }
+  } else if (h.kind == MML_OPT_RMSPROP) {
+    m *= powf(h.alpha, (float)(to - from));  // `m` carries state1 = square_avg: p does not move, the average decays
+  }
+  // SGD / Adagrad: a zero gradient changes nothing
+}
+
+struct CatchupLaunch {
+  float* tab[MML_MAX_FIELDS];
+  float* s1[MML_MAX_FIELDS];
+  float* s2[MML_MAX_FIELDS];
+  int32_t* last[MML_MAX_FIELDS];
+  int64_t rowbase[MML_MAX_FIELDS + 1];
+  int32_t F, E;
+  const int32_t* touched;
+  const int32_t* touched_count;
+  int32_t cap;
+  int32_t dense;      // 1: every row of table 0 (V rows), no list
+  int64_t V;
+  mml_opt_hyper h;
+};
+
+__global__ __launch_bounds__(256) void opt_catchup_kernel(const CatchupLaunch L) {
+  const mml_opt_hyper& h = L.h;
+  const int target = (h.step_dev ? *h.step_dev : h.step) - (L.dense ? 0 : 1);
+  int64_t nrows;
+  if (L.dense) {
+    nrows = L.V;
+  } else {
+    int32_t cnt = *L.touched_count;
+    nrows = cnt > L.cap ? L.cap : cnt;
+  }
+  const int64_t total = nrows * L.E;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+    const int64_t li = item / L.E;
+    const int e = (int)(item - li * L.E);
+    int f = 0;
+    int64_t row = li;
+    if (!L.dense) {
+      const int64_t grow = L.touched[li];
+      while (f + 1 < L.F && grow >= L.rowbase[f + 1]) ++f;
+      row = grow - L.rowbase[f];
+    }
+    const int from = L.last[f][row];
+    if (from >= target) continue;
+    const int64_t o = row * L.E + e;
+    float p = L.tab[f][o];
+    float m = L.s1[f] ? L.s1[f][o] : 0.f, v = L.s2[f] ? L.s2[f][o] : 0.f;
+    catchup_element(h, from, target, p, m, v);
+    L.tab[f][o] = p;
+    if (L.s1[f]) L.s1[f][o] = m;
+    if (L.s2[f]) L.s2[f][o] = v;
+    // every lane of the row has read `from` above (same wave, in order), so lane 0 may now publish the new step
+    __builtin_amdgcn_wave_barrier();
+    if (e == 0) L.last[f][row] = target;
   }
 }
 
@@ -286,10 +378,52 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
   return MML_OK;
 }
 
+static int launch_catchup(CatchupLaunch& L, int64_t max_items, hipStream_t st, const char* who) {
+  int64_t blocks = cdiv(max_items, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  MML_LAUNCH(opt_catchup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L);
+  return check_launch(who);
+}
+
+extern "C" int mml_opt_catchup_rows(float* const* tables, float* const* state1, float* const* state2,
+                                    int32_t* const* last, const int64_t* rowbase, int32_t F, int32_t E,
+                                    const int32_t* touched, const int32_t* touched_count, int32_t touched_cap,
+                                    const mml_opt_hyper* hyper, mml_stream_t stream) {
+  int rc = check_hyper(hyper, "mml_opt_catchup_rows");
+  if (rc) return rc;
+  MML_REQUIRE(F >= 1 && F <= MML_MAX_FIELDS && E > 0 && tables && last && rowbase && touched && touched_count &&
+                  touched_cap > 0, "mml_opt_catchup_rows: bad arguments");
+  if (hyper->kind == MML_OPT_SGD || hyper->kind == MML_OPT_ADAGRAD) return MML_OK;  // zero gradients change nothing
+  CatchupLaunch L{};
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(tables[f] && last[f] && state1 && state1[f], "mml_opt_catchup_rows: field %d null", f);
+    MML_REQUIRE(hyper->kind != MML_OPT_ADAM || (state2 && state2[f]), "mml_opt_catchup_rows: field %d needs state2", f);
+    L.tab[f] = tables[f]; L.s1[f] = state1[f]; L.s2[f] = state2 ? state2[f] : nullptr; L.last[f] = last[f];
+    L.rowbase[f] = rowbase[f];
+  }
+  L.rowbase[F] = rowbase[F];
+  L.F = F; L.E = E; L.touched = touched; L.touched_count = touched_count; L.cap = touched_cap; L.h = *hyper;
+  return launch_catchup(L, (int64_t)touched_cap * E, to_stream(stream), "mml_opt_catchup_rows");
+}
+
+extern "C" int mml_opt_catchup_dense(float* table, float* state1, float* state2, int32_t* last, int64_t V, int32_t E,
+                                     const mml_opt_hyper* hyper, mml_stream_t stream) {
+  int rc = check_hyper(hyper, "mml_opt_catchup_dense");
+  if (rc) return rc;
+  MML_REQUIRE(table && last && V >= 0 && E > 0, "mml_opt_catchup_dense: bad arguments");
+  if (V == 0 || hyper->kind == MML_OPT_SGD || hyper->kind == MML_OPT_ADAGRAD) return MML_OK;
+  MML_REQUIRE(state1 && (hyper->kind != MML_OPT_ADAM || state2), "mml_opt_catchup_dense: optimizer state missing");
+  CatchupLaunch L{};
+  L.tab[0] = table; L.s1[0] = state1; L.s2[0] = state2; L.last[0] = last;
+  L.F = 1; L.E = E; L.dense = 1; L.V = V; L.h = *hyper;
+  return launch_catchup(L, V * E, to_stream(stream), "mml_opt_catchup_dense");
+}
+
 extern "C" int mml_opt_step_rows(float* const* tables, float* const* grad_tables, float* const* state1,
                                  float* const* state2, uint32_t* const* seen, const int64_t* rowbase, int32_t F,
                                  int32_t E, const int32_t* touched, const int32_t* touched_count, int32_t touched_cap,
-                                 const mml_opt_hyper* hyper, mml_stream_t stream) {
+                                 int32_t* const* last, const mml_opt_hyper* hyper, mml_stream_t stream) {
   int rc = check_hyper(hyper, "mml_opt_step_rows");
   if (rc) return rc;
   MML_REQUIRE(F >= 1 && F <= MML_MAX_FIELDS && E > 0, "mml_opt_step_rows: bad F/E");
@@ -304,6 +438,7 @@ extern "C" int mml_opt_step_rows(float* const* tables, float* const* grad_tables
     MML_REQUIRE(hyper->kind == MML_OPT_SGD || L.s1[f], "mml_opt_step_rows: field %d needs state1", f);
     MML_REQUIRE(hyper->kind != MML_OPT_ADAM || L.s2[f], "mml_opt_step_rows: field %d needs state2", f);
     L.rowbase[f] = rowbase[f];
+    L.last[f] = last ? last[f] : nullptr;
   }
   L.rowbase[F] = rowbase[F];
   L.F = F; L.E = E; L.touched = touched; L.touched_count = touched_count; L.cap = touched_cap; L.h = *hyper;

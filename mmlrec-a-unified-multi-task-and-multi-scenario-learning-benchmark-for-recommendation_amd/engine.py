@@ -662,9 +662,13 @@ class ParamStore:
 
 
 class Optimizer:
-    """K8 front end: dense update for MLP parameters, dense ('dense_exact') or touched-row ('sparse_rows') update for
-    the tables.  'auto' = sparse rows when that is exactly the dense result (SGD, Adagrad), dense otherwise
-    (Adam/RMSprop decay the moments of untouched rows)."""
+    """K8 front end: dense update for MLP parameters; for the tables one of
+      dense_exact : every row every step, like the reference's torch.optim over dense gradients;
+      sparse_rows : rows of the batch only -- exactly the dense result for SGD / Adagrad, "lazy Adam" otherwise;
+      lazy_exact  : rows of the batch only, but the zero-gradient steps a row skipped are replayed before it is next
+                    read (mml_opt_catchup_rows) and for all rows before evaluation (flush): the dense Adam / RMSprop
+                    trajectory at sparse cost (SURVEY.md A14 "hard part" solved without changing results).
+    'auto' = sparse_rows for SGD / Adagrad, dense_exact for Adam / RMSprop."""
 
     def __init__(self, store, kind, lr, table_update="auto"):
         self.store, self.kind, self.lr = store, kind, float(lr)
@@ -672,9 +676,13 @@ class Optimizer:
             raise NotImplementedError(kind)  # model/basemodel.py:581
         if table_update == "auto":
             table_update = "sparse_rows" if kind in ("sgd", "adagrad") else "dense_exact"
-        if table_update not in ("dense_exact", "sparse_rows"):
-            raise ValueError("table_update must be auto, dense_exact or sparse_rows")
+        if table_update == "lazy_exact" and kind in ("sgd", "adagrad"):
+            table_update = "sparse_rows"  # nothing to replay: zero gradients do not move these optimizers
+        if table_update not in ("dense_exact", "sparse_rows", "lazy_exact"):
+            raise ValueError("table_update must be auto, dense_exact, sparse_rows or lazy_exact")
         self.table_update = table_update
+        self.last = None   # lazy_exact: per-table int32 [V] "row is current as of step"
+        self.dirty = False
         dev = store.device
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.state = {}
@@ -695,6 +703,8 @@ class Optimizer:
         lib = L.load()
         st = self.store
         pre = [(lib.mml_counter_update, (self.step_dev.data_ptr(), 1, 0))]
+        if self.table_update == "lazy_exact":
+            pre += self._lazy_pre_calls(plan)
         calls = []
         dense = [(pv, n) for n, pv in st.pvals.items() if not pv.is_table and pv.written]
         entries = [(pv.data, pv.grad) + self.state[n] for pv, n in dense]
@@ -719,6 +729,7 @@ class Optimizer:
                               dict(kernel="opt_dense_kernel(tables)", bytes=float(per) * sum(pv.data.numel() for pv in tabs))))
             else:
                 rows = st.rows
+                lazy = self.table_update == "lazy_exact"
                 F = len(tabs)
                 E = tabs[0].data.shape[1]
                 pt = ops._ptr_array([pv.data for pv in tabs])
@@ -728,7 +739,51 @@ class Optimizer:
                 ps = ops._ptr_array(rows.seen)
                 rb = (L.i64 * (F + 1))(*rows.rowbase)
                 plan.keep += [pt, pg, p1, p2, ps, rb]
+                pl = ops._ptr_array([self.last[n] for n in tnames]) if lazy else None
+                plan.keep.append(pl)
                 calls.append((lib.mml_opt_step_rows, (pt, pg, p1, p2, ps, rb, F, E, rows.touched.data_ptr(),
-                                                      rows.count.data_ptr(), rows.touched.numel(), C.byref(hyper))))
+                                                      rows.count.data_ptr(), rows.touched.numel(), pl,
+                                                      C.byref(hyper)), dict(kernel="opt_rows_kernel")))
                 calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
         return {"pre": pre, "mlp": mlp_calls, "tables": calls}
+
+    # ---- lazy_exact ----------------------------------------------------------------------------------
+    def _lazy_pre_calls(self, plan):
+        """Before the gather: unique rows of the batch (LDS dedup on the indices) -> replay their skipped steps."""
+        lib, st = L.load(), self.store
+        gop = plan.ops[0]
+        if not isinstance(gop, GatherOp):
+            raise L.MMLError("lazy_exact table updates are not available on the table-sharded path yet")
+        names = st.table_names
+        rows = st.rows
+        if self.last is None:
+            self.last = {n: torch.zeros(st.pvals[n].data.shape[0], dtype=torch.int32, device=st.device) for n in names}
+        F = len(names)
+        E = st.pvals[names[0]].data.shape[1]
+        vocab = (L.i64 * F)(*[st.pvals[n].data.shape[0] for n in names])
+        col = (L.i32 * F)(*gop.cols)
+        ps = ops._ptr_array(rows.seen)
+        rb = (L.i64 * (F + 1))(*rows.rowbase)
+        pt = ops._ptr_array([st.pvals[n].data for n in names])
+        p1 = ops._ptr_array([self.state[n][0] for n in names])
+        p2 = ops._ptr_array([self.state[n][1] for n in names]) if self.kind == "adam" else None
+        pl = ops._ptr_array([self.last[n] for n in names])
+        hyper = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev)
+        plan.keep += [vocab, col, ps, rb, pt, p1, p2, pl, hyper]
+        return [
+            (lib.mml_index_unique, (vocab, col, F, E, gop.X.data_ptr(), ops._ld(gop.X), plan.B, ps, rb,
+                                    rows.touched.data_ptr(), rows.count.data_ptr(), rows.touched.numel(),
+                                    plan.status.data_ptr()), dict(kernel="scatter_hash_kernel(index_unique)")),
+            (lib.mml_opt_catchup_rows, (pt, p1, p2, pl, rb, F, E, rows.touched.data_ptr(), rows.count.data_ptr(),
+                                        rows.touched.numel(), C.byref(hyper)), dict(kernel="opt_catchup_kernel")),
+        ]
+
+    def flush(self):
+        """Bring EVERY table row to the current step (needed before anything outside the fused step reads a table)."""
+        if self.table_update != "lazy_exact" or not self.dirty or self.last is None:
+            return
+        hyper = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev)
+        for n in self.store.table_names:
+            s1, s2 = self.state[n]
+            ops.opt_catchup_dense(self.store.pvals[n].data, s1, s2 if self.kind == "adam" else None, self.last[n], hyper)
+        self.dirty = False

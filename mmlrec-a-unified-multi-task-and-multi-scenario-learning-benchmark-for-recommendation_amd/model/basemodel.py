@@ -179,6 +179,7 @@ class BaseModel(nn.Module):
 
     # ---- plan management -------------------------------------------------------------------------
     def __deepcopy__(self, memo):
+        self.flush_tables()
         caches = self._caches
         self.__dict__["_caches"] = {"store": None, "plans": {}, "steps": {}}
         try:
@@ -186,7 +187,9 @@ class BaseModel(nn.Module):
             new = cls.__new__(cls)
             memo[id(self)] = new
             for k, v in self.__dict__.items():
-                new.__dict__[k] = copy.deepcopy(v, memo)
+                # the fused optimizer (moments, gradient accumulators) stays with the live model: the copy is the
+                # "best model" snapshot used for predict(), like the reference's deepcopy(model) (basemodel.py:344)
+                new.__dict__[k] = None if k == "_optimizer" else copy.deepcopy(v, memo)
         finally:
             self.__dict__["_caches"] = caches
         return new
@@ -262,6 +265,18 @@ class BaseModel(nn.Module):
     def _build_graph(self, plan, store, x0):
         raise NotImplementedError
 
+    def flush_tables(self):
+        """lazy_exact table optimizer: replay the zero-gradient steps of rows the recent batches did not touch, so that
+        every table equals what the reference's dense optimizer holds.  Called automatically by forward / predict /
+        state_dict / deepcopy; a no-op for the other table-update modes."""
+        opt = getattr(self, "_optimizer", None)
+        if opt is not None:
+            opt.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_tables()
+        return super().state_dict(*args, **kwargs)
+
     def _load_batch(self, plan, X, mask=None, y=None):
         if X.shape != plan.X.shape:
             raise L.MMLError(f"X has shape {tuple(X.shape)}, the model expects [B, {plan.X.shape[1]}]")
@@ -278,6 +293,7 @@ class BaseModel(nn.Module):
         if not isinstance(X, torch.Tensor) or not X.is_cuda:
             raise L.MMLError("mmlrec_amd: forward() needs a CUDA(HIP) tensor on an MI355X; there is no CPU fallback")
         X = X.float()
+        self.flush_tables()
         masked = domain_mask is not None and self.task_name in ("msl", "mtmsl")
         if masked:
             domain_mask = domain_mask.float()

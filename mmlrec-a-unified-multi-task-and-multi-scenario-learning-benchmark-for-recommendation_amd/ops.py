@@ -329,14 +329,38 @@ def opt_step_dense(entries, hyper):
     L.check(L.load().mml_opt_step_dense(arr, len(entries), C.byref(hyper), _stream()), "mml_opt_step_dense")
 
 
-def opt_step_rows(tables, grad_tables, state1, state2, seen, rowbase, touched, touched_count, hyper):
+def opt_step_rows(tables, grad_tables, state1, state2, seen, rowbase, touched, touched_count, hyper, last=None):
     F, E = len(tables), tables[0].shape[1]
     rb = (L.i64 * (F + 1))(*rowbase)
     L.check(L.load().mml_opt_step_rows(_ptr_array(tables), _ptr_array(grad_tables),
                                        _ptr_array(state1) if state1 is not None else None,
                                        _ptr_array(state2) if state2 is not None else None,
                                        _ptr_array(seen), rb, F, E, touched.data_ptr(), touched_count.data_ptr(),
-                                       touched.numel(), C.byref(hyper), _stream()), "mml_opt_step_rows")
+                                       touched.numel(), _ptr_array(last) if last is not None else None,
+                                       C.byref(hyper), _stream()), "mml_opt_step_rows")
+
+
+def index_unique(vocab, cols, E, X, seen, rowbase, touched, touched_count, status=None):
+    F = len(vocab)
+    L.check(L.load().mml_index_unique((L.i64 * F)(*vocab), (L.i32 * F)(*cols), F, E, X.data_ptr(), _ld(X), X.shape[0],
+                                      _ptr_array(seen), (L.i64 * (F + 1))(*rowbase), touched.data_ptr(),
+                                      touched_count.data_ptr(), touched.numel(), L.ptr(status), _stream()),
+            "mml_index_unique")
+
+
+def opt_catchup_rows(tables, state1, state2, last, rowbase, touched, touched_count, hyper):
+    F, E = len(tables), tables[0].shape[1]
+    L.check(L.load().mml_opt_catchup_rows(_ptr_array(tables), _ptr_array(state1),
+                                          _ptr_array(state2) if state2 is not None else None, _ptr_array(last),
+                                          (L.i64 * (F + 1))(*rowbase), F, E, touched.data_ptr(),
+                                          touched_count.data_ptr(), touched.numel(), C.byref(hyper), _stream()),
+            "mml_opt_catchup_rows")
+
+
+def opt_catchup_dense(table, state1, state2, last, hyper):
+    L.check(L.load().mml_opt_catchup_dense(table.data_ptr(), L.ptr(state1), L.ptr(state2), last.data_ptr(),
+                                           table.shape[0], table.shape[1], C.byref(hyper), _stream()),
+            "mml_opt_catchup_dense")
 
 
 def counter_update(counter, delta=1, reset=False):

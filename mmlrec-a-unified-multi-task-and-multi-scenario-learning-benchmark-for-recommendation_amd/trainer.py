@@ -22,14 +22,18 @@ class TrainStep:
         if allreduce is None and sharding is not None:
             from .parallel import make_allreduce
             allreduce = make_allreduce(model._dist, model._dist_group)
-        if self.opt.table_update == "sparse_rows":
+        lazy = self.opt.table_update == "lazy_exact"
+        if lazy and sharding is not None:
+            raise NotImplementedError("lazy_exact table updates on the table-sharded path")
+        if self.opt.table_update in ("sparse_rows", "lazy_exact"):
             if sharding is None:
                 rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))
             else:  # this rank serves world*B lookups for each of ITS fields
                 sp = model._sparse_cols()
                 names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in sharding.mine]
                 rows = self.store.ensure_rows(sharding.world * int(B) * max(len(names), 1), names)
-        self.plan = model._record(B, True, False, self.store, sparse_rows=rows)
+        # lazy_exact lists the batch's rows in a pre-pass (before the gather), so the scatter only accumulates
+        self.plan = model._record(B, True, False, self.store, sparse_rows=None if lazy else rows)
         self.opt_split = self.opt.calls_split(self.plan)
         self.opt_calls = self.opt_split["pre"] + self.opt_split["mlp"] + self.opt_split["tables"]
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
@@ -84,3 +88,4 @@ class TrainStep:
             self.g_fb.replay()
         self.calls += 1
         self.opt.steps_done += 1
+        self.opt.dirty = True

@@ -67,9 +67,10 @@ def test_model_construction_on_cpu_and_loud_failure():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("table_update", ["auto", "lazy_exact"])
 @pytest.mark.parametrize("model_name", ["sharedbottom", "mmoe"])
 @pytest.mark.parametrize("shuffle", [False, True])
-def test_fit_epoch_logs_match_reference(tmp_path, model_name, shuffle, capsys):
+def test_fit_epoch_logs_match_reference(tmp_path, model_name, shuffle, table_update, capsys):
     import torch
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd import main as M
@@ -79,6 +80,7 @@ def test_fit_epoch_logs_match_reference(tmp_path, model_name, shuffle, capsys):
     want = gold[key]["epoch_logs"]
     a, b = synth_csv.write_csvs(str(tmp_path))
     cfg = synth_csv.config(a, b, str(tmp_path / "res.csv"), model_name)
+    cfg["model_config"]["table_update"] = table_update
     M.set_seed(0)
     train, test, mask, tin, tein, _, dfc = ctrdataset(cfg)
     model = M.get_model(model_name, dfc, cfg, "cuda")

@@ -121,7 +121,8 @@ def test_autograd_gradients(case):
 def test_fused_train_steps(case, graph):
     """Fused step (fwd + BCE + bwd + optimizer) reproduces the reference's parameters after 1 and 3 steps."""
     name, g = case
-    for kind, checkpoints, tu in (("adam", (1, 3), "dense_exact"), ("adagrad", (3,), "sparse_rows")):
+    for kind, checkpoints, tu in (("adam", (1, 3), "dense_exact"), ("adagrad", (3,), "sparse_rows"),
+                                  ("adam", (1, 3), "lazy_exact")):
         model, cfg = build(g, table_update=tu)
         load_state(model, g)
         model.optim_config["optimizer"] = kind
