@@ -59,7 +59,7 @@ def barrier(dist):
     torch.cuda.synchronize()
 
 
-def timed_steps(runner, batches, steps, warmup, dist):
+def timed_steps(runner, batches, steps, warmup, dist, flush=None):
     nb = len(batches)
 
     def one(i):
@@ -74,12 +74,21 @@ def timed_steps(runner, batches, steps, warmup, dist):
     t0 = time.perf_counter()
     for i in range(steps):
         one(warmup + i)
+    t_flush = 0.0
+    if flush is not None:  # lazy_exact: the deferred zero-gradient updates of every untouched row are paid HERE
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        flush()
+        torch.cuda.synchronize()
+        t_flush = time.perf_counter() - tf
     barrier(dist)
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if flush is not None:
+        return dt, t_flush
     return dt
 
 
@@ -201,6 +210,25 @@ def main():
             results[B]["acc"] = acc
             results[B]["bsteps"] = min(args.steps, 10)
 
+    # secondary measurement: the lazy_exact table optimizer (dense-Adam trajectory at touched-row cost); its timed
+    # region ENDS with the flush that brings every one of the 12.49 M rows to the reference state
+    lazy = {}
+    if world == 1 and args.table_update != "lazy_exact":
+        del runner
+        model2, _, _, _ = W.build_model(args.workload, dev, table_update="lazy_exact", use_hip_graph=not args.no_graph)
+        model2.compile(cfg["optim_config"]["optimizer"], cfg["optim_config"]["loss"], cfg["optim_config"]["metrics"])
+        model2.train()
+        for B in [args.batch] + ([args.alt_batch] if args.alt_batch and args.alt_batch != args.batch else []):
+            batches = make_batches(B)
+            r2 = model2.train_step_runner(B, use_graph=not args.no_graph)
+            steps = args.steps if B == args.batch else max(args.steps, 50)
+            dt, tf = timed_steps(r2, batches, steps, args.warmup, dist, flush=model2.flush_tables)
+            lazy[B] = {"batch_per_gpu": B, "unit": "samples/s", "steps": steps,
+                       "value_incl_final_flush": round(B * steps / dt, 1),
+                       "value_steps_only": round(B * steps / (dt - tf), 1),
+                       "ms_per_step_steps_only": round((dt - tf) / steps * 1e3, 4), "final_flush_ms": round(tf * 1e3, 3)}
+        del model2
+
     if rank != 0:
         return
     from mmlrec_amd import _lib
@@ -230,6 +258,13 @@ def main():
         r = results[args.alt_batch]
         line["alt"] = {"batch_per_gpu": args.alt_batch, "value": round(r["value"], 1), "unit": "samples/s",
                        "ms_per_step": round(r["ms"], 4), "steps": r["steps"]}
+    if lazy:
+        line["lazy_exact"] = {"note": "same dense-Adam trajectory (tests: <=2e-6 rel on parameters), table update "
+                                      "restricted to the batch's rows + replay of skipped zero-gradient steps; the "
+                                      "flush (replay for ALL 12.49M rows, needed only before evaluation/checkpoint: "
+                                      "once per epoch in fit()) is timed separately and also folded into "
+                                      "value_incl_final_flush over this short run",
+                              "runs": list(lazy.values())}
     if world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(args)
