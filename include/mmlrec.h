@@ -117,6 +117,10 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
  * later round. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);
+/* Unused dynamic LDS requested by the weight-gradient launches (process-wide, default 0).  A trainer that runs the
+ * wgrad GEMMs on a side stream next to an HBM-bound kernel (the dense table optimizer) sets ~17 KiB so that only three
+ * wgrad workgroups fit a CU and the other kernel's waves can co-reside. */
+int mml_gemm_set_wgrad_lds_pad(int32_t bytes);
 
 typedef struct {
   const float* A;    /* [M, K] input activations                                  */

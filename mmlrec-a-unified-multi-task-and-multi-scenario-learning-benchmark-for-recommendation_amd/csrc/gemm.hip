@@ -19,6 +19,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace mml {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -435,10 +437,340 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
     }
 }
 
+// ====================================================================================================
+// Direct-to-LDS fast path (exact fp32, 128 x 64 tiles, K step 16, three LDS stages)
+//
+// Same tile geometry and MFMA map as gemm_kernel, different staging: operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no per-lane guards), two k-steps ahead of the MFMAs, with
+// ONE raw s_barrier per k-step and a counted s_waitcnt vmcnt(3) (each wave issues exactly 3 loads per k-step).
+//   * reduction-contiguous operand ([rows][16 k], 64-B rows): the 16-B chunk a lane fetches is XOR-swizzled on the
+//     SOURCE side (phys = chunk ^ ((row >> 2) & 3)) because the LDS destination of a wave-instruction is lane-linear;
+//     reading (row, chunk) at phys is conflict-free for the ds_read_b128 lane groups;
+//   * row-contiguous operand ([16 k][rows]): plain image, fragments read with 4 x ds_read_b32 (lanes = consecutive
+//     rows -> conflict-free).
+// Rows past the end of an operand are clamped to the last valid row / chunk (their products only reach outputs the
+// epilogue discards), so no zero-fill is needed.  Eligibility (checked on the host, else gemm_kernel runs): every
+// reduction extent a multiple of 16, 16-byte aligned operands with ld % 4 == 0, row-contiguous extents % 4 == 0.
+// ====================================================================================================
+constexpr int GK = 16;
+constexpr int GSTAGES = 3;
+constexpr int GA = 128 * GK;  // floats per A stage
+constexpr int GB = 64 * GK;   // floats per B stage
+
+template <bool RC, int ROWS>
+__device__ __forceinline__ void glds_issue(float* stage, const float* __restrict__ base, int64_t ld, int row0,
+                                           int nrows, int k0, int wave, int lane) {
+  if (RC) {
+#pragma unroll
+    for (int t = wave; t < ROWS / 16; t += 4) {  // one wave-instruction = 16 rows x 64 B
+      const int rl = 16 * t + (lane >> 2);
+      int row = row0 + rl;
+      row = row < nrows ? row : nrows - 1;
+      const int c = (lane & 3) ^ ((rl >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(base + (int64_t)row * ld + k0 + 4 * c, stage + t * 256, 16, 0, 0);
+    }
+  } else {
+    constexpr int KR = 256 / ROWS;  // k-rows per wave-instruction (1 KiB): 2 for 128-wide rows, 4 for 64-wide
+    constexpr int CH = ROWS / 4;    // 16-B chunks per k-row
+#pragma unroll
+    for (int t = wave; t < GK / KR; t += 4) {
+      const int kr = t * KR + lane / CH;
+      int col = row0 + 4 * (lane % CH);
+      col = (col + 4 <= nrows) ? col : nrows - 4;
+      __builtin_amdgcn_global_load_lds(base + (int64_t)(k0 + kr) * ld + col, stage + t * 256, 16, 0, 0);
+    }
+  }
+}
+
+template <bool RC, int ROWS>
+__device__ __forceinline__ float4 glds_frag(const float* stage, int row, int q, int h) {
+  if (RC) {
+    const int phys = (2 * q + h) ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const float4*>(stage + row * GK + 4 * phys);
+  } else {
+    const float* p = stage + (8 * q + 4 * h) * ROWS + row;
+    return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
+  }
+}
+
+// LDS fragment reads as inline asm: hipcc treats an LDS-DMA in flight as a pending LDS store and would put
+// s_waitcnt vmcnt(0) in front of every C++-level ds_read (draining the two-step prefetch); asm reads are invisible to
+// that pass, so the counted vmcnt(3) above is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand and
+// followed by sched_barrier(0) so that no MFMA is hoisted above them (cdna guide, methodology rule 18).
+typedef __attribute__((address_space(3))) float lds_f32_t;
+__device__ __forceinline__ uint32_t lds_byte_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(const lds_f32_t*)p;
+}
+template <int OFF>
+__device__ __forceinline__ float4 ds_read128(uint32_t addr) {
+  float4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ float ds_read32(uint32_t addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int U0, int U1>
+__device__ __forceinline__ float2 ds_read2st64(uint32_t addr) {  // two dwords at addr + U0*256 B and addr + U1*256 B
+  float2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(U0), "n"(U1) : "memory");
+  return v;
+}
+// fragment (4 k-values) of one tile-local row, k-group Q, from the stage at byte offset SOFF (a multiple of 256).
+//   RC : `a` = byte address of (row, phys chunk of group Q) -- the caller picks the per-group address; +32 rows is an
+//        immediate (+2048 B);
+//   NRC: `a` = byte address of (k = 4h, row [+32 rows]); consecutive k are ROWS*4 B apart = 1 or 2 units of 256 B, so a
+//        fragment is two ds_read2st64_b32.
+template <bool RC, int ROWS, int SOFF, int MI, int Q>
+__device__ __forceinline__ float4 glds_frag_asm(uint32_t a) {
+  if (RC) {
+    return ds_read128<SOFF + MI * 32 * GK * 4>(a);
+  } else {
+    constexpr int SU = ROWS * 4 / 256;
+    constexpr int U = (SOFF + 8 * Q * ROWS * 4) / 256;
+    const float2 lo = ds_read2st64<U, U + SU>(a), hi = ds_read2st64<U + 2 * SU, U + 3 * SU>(a);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
+struct GCursor {
+  int s, k0, kend;
+};
+
+template <bool ARC, bool BRC, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
+  constexpr int BN = 64;
+  __shared__ __attribute__((aligned(16))) float lds[GSTAGES * (GA + GB)];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0, row0, col0, split = 0;
+  GCursor cur{0, 0, 0};
+  if (EPI != EPI_SLAB) {
+    const int mt = vid / L.total_ntiles;
+    int j = vid - mt * L.total_ntiles;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    j -= L.p[pi].tile0;
+    row0 = mt * BM;
+    col0 = j * BN;
+    cur.kend = L.src[L.p[pi].src0].Kred;
+  } else {
+    split = vid / L.total_ntiles;
+    int j = vid - split * L.total_ntiles;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    j -= L.p[pi].tile0;
+    row0 = (j / L.p[pi].tiles_n) * BM;
+    col0 = (j % L.p[pi].tiles_n) * BN;
+    cur.k0 = split * L.chunk;
+    const int kr = L.src[L.p[pi].src0].Kred;
+    cur.kend = (cur.k0 + L.chunk < kr) ? cur.k0 + L.chunk : kr;
+  }
+  const Problem& P = L.p[pi];
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
+
+  // flattened (source, k) step sequence with a two-step look-ahead
+  auto valid = [&](const GCursor& c) { return c.s < P.nsrc && c.k0 < c.kend; };
+  auto advance = [&](GCursor& c) {
+    c.k0 += GK;
+    if (c.k0 >= c.kend && EPI != EPI_SLAB) {
+      ++c.s;
+      c.k0 = 0;
+      c.kend = (c.s < P.nsrc) ? L.src[P.src0 + c.s].Kred : 0;
+    }
+  };
+  auto issue = [&](const GCursor& c, const int stage) {
+    const Source& S = L.src[P.src0 + c.s];
+    float* sa = lds + stage * (GA + GB);
+    glds_issue<ARC, BM>(sa, S.A, S.lda, row0, P.M, c.k0, wave, lane);
+    glds_issue<BRC, BN>(sa + GA, S.B, S.ldb, col0, P.N, c.k0, wave, lane);
+  };
+
+  // per-lane LDS byte addresses of this wave's fragments inside a stage (stage / k-group / +32-row offsets are
+  // instruction immediates)
+  const uint32_t lds0 = lds_byte_addr(lds);
+  uint32_t aA0, aA1, aB0, aB1;
+  {
+    const int ra = wm * 64 + l31, rb = wn * 32 + l31;
+    if (ARC) {
+      aA0 = lds0 + ra * GK * 4 + ((h ^ ((ra >> 2) & 3)) * 16);
+      aA1 = lds0 + ra * GK * 4 + (((2 + h) ^ ((ra >> 2) & 3)) * 16);
+    } else {  // row-contiguous image: aA0 = (k = 4h, row), aA1 = the same 32 rows further (not a 256-B multiple)
+      aA0 = lds0 + (4 * h * BM + ra) * 4;
+      aA1 = aA0 + 32 * 4;
+    }
+    if (BRC) {
+      aB0 = lds0 + rb * GK * 4 + ((h ^ ((rb >> 2) & 3)) * 16);
+      aB1 = lds0 + rb * GK * 4 + (((2 + h) ^ ((rb >> 2) & 3)) * 16);
+    } else {
+      aB0 = aB1 = lds0 + (4 * h * BN + rb) * 4;
+    }
+  }
+
+  GCursor pf = cur;  // prefetch cursor
+  int issued = 0;
+  if (valid(pf)) { issue(pf, 0); advance(pf); ++issued; }
+  if (valid(pf)) { issue(pf, 1); advance(pf); ++issued; }
+
+  // One k-step on a COMPILE-TIME stage index: with static LDS offsets hipcc can tell that the fragment reads of
+  // stage S never alias the in-flight LDS-DMA destination (stage S+2), so it does not drain vmcnt before them.
+  int i = 0;
+  auto step = [&](auto stage_c) {
+    constexpr int S = decltype(stage_c)::value;
+    // my own loads of step i have landed when at most the loads of ONE later step (3 instructions) are in flight
+    if (issued > i + 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's step-i tiles are in LDS; everyone is done reading stage (S+2)%3
+    if (valid(pf)) {
+      issue(pf, (S + 2) % GSTAGES);
+      advance(pf);
+      ++issued;
+    }
+    constexpr int SA = S * (GA + GB) * 4;  // byte offset of this stage's A image
+    constexpr int SB = SA + GA * 4;
+    if (want_bias) {
+      if (tid < (P.bias_cols ? BN : BM)) {  // both operands are [k][rows] images in a wgrad launch
+        const uint32_t ab = lds0 + (P.bias_cols ? SB : SA) + tid * 4;
+        const int R4 = (P.bias_cols ? BN : BM) * 4;
+        float sacc = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 8 reads in flight at a time (lgkmcnt is a 4-bit counter)
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v[k]) : "v"(ab + (half * 8 + k) * R4) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sacc += v[k];
+        }
+        bsum += sacc;
+      }
+    }
+    // all fragment reads of the step up front (<= 12 LDS instructions, inside the 4-bit lgkmcnt range): group 1 is in
+    // flight while group 0 multiplies
+    float4 fa0[2], fb0, fa1[2], fb1;
+    fa0[0] = glds_frag_asm<ARC, BM, SA, 0, 0>(ARC ? aA0 : aA0);
+    fa0[1] = glds_frag_asm<ARC, BM, SA, 1, 0>(ARC ? aA0 : aA1);
+    fb0 = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0);
+    fa1[0] = glds_frag_asm<ARC, BM, SA, 0, 1>(ARC ? aA1 : aA0);
+    fa1[1] = glds_frag_asm<ARC, BM, SA, 1, 1>(ARC ? aA1 : aA1);
+    fb1 = glds_frag_asm<BRC, BN, SB, 0, 1>(BRC ? aB1 : aB0);
+    constexpr int PER_Q = (ARC ? 2 : 4) + (BRC ? 1 : 2);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_Q) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].x, fb0.x, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].y, fb0.y, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].z, fb0.z, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].w, fb0.w, acc[mi], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].x, fb1.x, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].y, fb1.y, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].z, fb1.z, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].w, fb1.w, acc[mi], 0, 0, 0);
+    }
+    advance(cur);
+    ++i;
+  };
+  while (true) {
+    if (!valid(cur)) break;
+    step(std::integral_constant<int, 0>{});
+    if (!valid(cur)) break;
+    step(std::integral_constant<int, 1>{});
+    if (!valid(cur)) break;
+    step(std::integral_constant<int, 2>{});
+  }
+
+  // ---- epilogue (identical to gemm_kernel) ----
+  if (EPI == EPI_SLAB) {
+    if (want_bias) {
+      if (!P.bias_cols) {
+        if (tid < BM && row0 + tid < P.M) P.bias_slab[(int64_t)split * P.M + row0 + tid] = bsum;
+      } else {
+        if (tid < BN && col0 + tid < P.N) P.bias_slab[(int64_t)split * P.N + col0 + tid] = bsum;
+      }
+    }
+    float* slab = L.slab + P.slab_off + (int64_t)split * P.M * P.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int col = col0 + wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < P.M && col < P.N) slab[(int64_t)row * P.N + col] = acc[mi][r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int col = col0 + wn * 32 + l31;
+    if (col >= P.N) continue;
+    float b = 0.f;
+    if (EPI == EPI_FWD && P.bias) b = P.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= P.M) continue;
+      float v = acc[mi][r];
+      float* dst = P.C + (int64_t)row * P.ldc + col;
+      if (EPI == EPI_FWD) {
+        v = act_fwd(v + b, P.act);
+      } else {
+        if (P.act != MML_ACT_NONE) v *= act_bwd(P.Y[(int64_t)row * P.ldy + col], P.act);
+        if (P.accumulate) v += *dst;
+      }
+      *dst = v;
+    }
+  }
+}
+
+// host-side eligibility of a whole launch for the direct-to-LDS path
+static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("MMLREC_GEMM_GLDS");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || bn != 64) return false;
+  for (int i = 0; i < L.n; ++i) {
+    const Problem& P = L.p[i];
+    if (!arc && (P.M % 4 != 0 || P.M < 4)) return false;
+    if (!brc && (P.N % 4 != 0 || P.N < 4)) return false;
+    if (P.M < 1 || P.N < 1) return false;
+    for (int s = 0; s < P.nsrc; ++s) {
+      const Source& S = L.src[P.src0 + s];
+      if (S.Kred % GK != 0 || S.Kred < GK || !S.vecA || !S.vecB) return false;
+    }
+  }
+  if (epi == EPI_SLAB && L.chunk % GK != 0) return false;
+  return true;
+}
+
 static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
 
 // 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per fp32 product)
 static int g_gemm_mode = -1;
+static int g_wgrad_pad = -1;  // unused dynamic LDS requested by wgrad launches (caps their residency, see launch_tiles)
 static int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("MMLREC_GEMM_MODE");
@@ -459,12 +791,17 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  At four
   // workgroups per CU they would own every VGPR of every SIMD and the optimizer's waves could not co-reside; an
   // unused dynamic-LDS request caps them at three per CU (3 x 53 KiB), leaving a wave slot and 128 VGPRs per SIMD.
-  static int pad_env = -1;
-  if (pad_env < 0) {
+  if (g_wgrad_pad < 0) {
     const char* e = getenv("MMLREC_WGRAD_LDS_PAD");
-    pad_env = e ? atoi(e) : 17 * 1024;
+    g_wgrad_pad = e ? atoi(e) : 0;
   }
-  const size_t dyn = (EPI == EPI_SLAB) ? (size_t)pad_env : 0;
+  const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
+  if (mode == 0 && glds_ok(L, arc, brc, bn, EPI)) {
+    if (arc && brc) MML_LAUNCH((gemm_glds_kernel<true, true, EPI>), g, b, dyn, st, L);
+    else if (arc && !brc) MML_LAUNCH((gemm_glds_kernel<true, false, EPI>), g, b, dyn, st, L);
+    else MML_LAUNCH((gemm_glds_kernel<false, false, EPI>), g, b, dyn, st, L);
+    return check_launch(who);
+  }
 #define MML_GO(A_, B_, N_)                                                        \
   do {                                                                            \
     if (mode == 0) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L); \
@@ -506,6 +843,12 @@ extern "C" int mml_gemm_set_mode(int32_t mode) {
 }
 
 extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
+
+extern "C" int mml_gemm_set_wgrad_lds_pad(int32_t bytes) {
+  MML_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, "mml_gemm_set_wgrad_lds_pad: bytes outside [0, 65536]");
+  g_wgrad_pad = bytes;
+  return MML_OK;
+}
 
 extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");
