@@ -116,7 +116,7 @@ def roofline_of(acc):
     if e["flops"] > 0:
         achieved = e["flops"] / e["launches"] / (avg_ms * 1e-3) / 1e12
         unit, bound = "TFLOP/s", "mfma"
-        if name.endswith(", 1>"):  # split-bf16 mode: three bf16 MFMAs per algorithmic fp32 multiply-add
+        if name.startswith("gemm_kernel") and name.endswith(", 1>"):  # split-bf16 mode: three bf16 MFMAs per algorithmic fp32 multiply-add
             peak = 2500.0 / 3.0
             note = "algorithmic fp32 FLOP/s; peak = dense bf16 MFMA peak (2.5 PFLOP/s) / 3 MFMAs per product"
         else:

@@ -455,7 +455,6 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
 constexpr int GK = 16;
 constexpr int GSTAGES = 3;
 constexpr int GA = 128 * GK;  // floats per A stage
-constexpr int GB = 64 * GK;   // floats per B stage
 
 template <bool RC, int ROWS>
 __device__ __forceinline__ void glds_issue(float* stage, const float* __restrict__ base, int64_t ld, int row0,
@@ -540,9 +539,11 @@ struct GCursor {
   int s, k0, kend;
 };
 
-template <bool ARC, bool BRC, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
-  constexpr int BN = 64;
+template <bool ARC, bool BRC, int BN, int EPI>
+__global__ __launch_bounds__(256, (BN == 64 ? 4 : 3)) void gemm_glds_kernel(const Launch L) {
+  constexpr int NI = BN / 64;
+  constexpr int GB = BN * GK;        // floats per B stage
+  constexpr int LOADS = 2 + NI;      // LDS-DMA instructions per wave per k-step
   __shared__ __attribute__((aligned(16))) float lds[GSTAGES * (GA + GB)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -573,11 +574,13 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
   }
   const Problem& P = L.p[pi];
 
-  f32x16 acc[2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   float bsum = 0.f;
   const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
 
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
   const uint32_t lds0 = lds_byte_addr(lds);
   uint32_t aA0, aA1, aB0, aB1;
   {
-    const int ra = wm * 64 + l31, rb = wn * 32 + l31;
+    const int ra = wm * 64 + l31, rb = wn * (BN / 2) + l31;
     if (ARC) {
       aA0 = lds0 + ra * GK * 4 + ((h ^ ((ra >> 2) & 3)) * 16);
       aA1 = lds0 + ra * GK * 4 + (((2 + h) ^ ((ra >> 2) & 3)) * 16);
@@ -614,8 +617,9 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
     if (BRC) {
       aB0 = lds0 + rb * GK * 4 + ((h ^ ((rb >> 2) & 3)) * 16);
       aB1 = lds0 + rb * GK * 4 + (((2 + h) ^ ((rb >> 2) & 3)) * 16);
-    } else {
-      aB0 = aB1 = lds0 + (4 * h * BN + rb) * 4;
+    } else {  // per-subtile addresses (ni = 0 / 1), k-group via immediates
+      aB0 = lds0 + (4 * h * BN + rb) * 4;
+      aB1 = aB0 + 32 * 4;
     }
   }
 
@@ -629,8 +633,8 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
   int i = 0;
   auto step = [&](auto stage_c) {
     constexpr int S = decltype(stage_c)::value;
-    // my own loads of step i have landed when at most the loads of ONE later step (3 instructions) are in flight
-    if (issued > i + 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    // my own loads of step i have landed when at most the loads of ONE later step (LOADS instructions) are in flight
+    if (issued > i + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's step-i tiles are in LDS; everyone is done reading stage (S+2)%3
     if (valid(pf)) {
@@ -659,34 +663,43 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
         bsum += sacc;
       }
     }
-    // all fragment reads of the step up front (<= 12 LDS instructions, inside the 4-bit lgkmcnt range): group 1 is in
-    // flight while group 0 multiplies
-    float4 fa0[2], fb0, fa1[2], fb1;
-    fa0[0] = glds_frag_asm<ARC, BM, SA, 0, 0>(ARC ? aA0 : aA0);
-    fa0[1] = glds_frag_asm<ARC, BM, SA, 1, 0>(ARC ? aA0 : aA1);
-    fb0 = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0);
-    fa1[0] = glds_frag_asm<ARC, BM, SA, 0, 1>(ARC ? aA1 : aA0);
-    fa1[1] = glds_frag_asm<ARC, BM, SA, 1, 1>(ARC ? aA1 : aA1);
-    fb1 = glds_frag_asm<BRC, BN, SB, 0, 1>(BRC ? aB1 : aB0);
-    constexpr int PER_Q = (ARC ? 2 : 4) + (BRC ? 1 : 2);
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_Q) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].x, fb0.x, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].y, fb0.y, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].z, fb0.z, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi].w, fb0.w, acc[mi], 0, 0, 0);
+    // fragment reads: k-group 0 then k-group 1 (in flight while group 0 multiplies); RC operands take the per-group
+    // address + a sub-tile immediate, row-contiguous ones the per-sub-tile address + a group immediate
+    float4 fa[2][2], fb[2][NI];
+    constexpr int PER_Q = (ARC ? 2 : 4) + (BRC ? NI : 2 * NI);
+    constexpr bool UPFRONT = 2 * PER_Q <= 15;  // lgkmcnt is a 4-bit counter
+    fa[0][0] = glds_frag_asm<ARC, BM, SA, 0, 0>(aA0);
+    fa[0][1] = glds_frag_asm<ARC, BM, SA, 1, 0>(ARC ? aA0 : aA1);
+    fb[0][0] = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0);
+    if (NI == 2) fb[0][NI - 1] = glds_frag_asm<BRC, BN, SB, NI - 1, 0>(BRC ? aB0 : aB1);
+    if (!UPFRONT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fa[1][0] = glds_frag_asm<ARC, BM, SA, 0, 1>(ARC ? aA1 : aA0);
+    fa[1][1] = glds_frag_asm<ARC, BM, SA, 1, 1>(aA1);
+    fb[1][0] = glds_frag_asm<BRC, BN, SB, 0, 1>(BRC ? aB1 : aB0);
+    if (NI == 2) fb[1][NI - 1] = glds_frag_asm<BRC, BN, SB, NI - 1, 1>(aB1);
+    if (UPFRONT) {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_Q) : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].x, fb1.x, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].y, fb1.y, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].z, fb1.z, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi].w, fb1.w, acc[mi], 0, 0, 0);
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].x, fb[q][ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].y, fb[q][ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].z, fb[q][ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].w, fb[q][ni].w, acc[mi][ni], 0, 0, 0);
+        }
     }
     advance(cur);
     ++i;
@@ -711,19 +724,23 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
     }
     float* slab = L.slab + P.slab_off + (int64_t)split * P.M * P.N;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int col = col0 + wn * 32 + l31;
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < P.M && col < P.N) slab[(int64_t)row * P.N + col] = acc[mi][r];
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < P.M && col < P.N) slab[(int64_t)row * P.N + col] = acc[mi][ni][r];
+        }
       }
-    }
     return;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int col = col0 + wn * 32 + l31;
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
     if (col >= P.N) continue;
     float b = 0.f;
     if (EPI == EPI_FWD && P.bias) b = P.bias[col];
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(const Launch L) {
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (row >= P.M) continue;
-      float v = acc[mi][r];
+      float v = acc[mi][ni][r];
       float* dst = P.C + (int64_t)row * P.ldc + col;
       if (EPI == EPI_FWD) {
         v = act_fwd(v + b, P.act);
@@ -751,7 +768,7 @@ static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
     const char* e = getenv("MMLREC_GEMM_GLDS");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!enabled || bn != 64) return false;
+  if (!enabled || bn != 64) return false;  // the 128 x 128 instantiation measured ~2x slower (3 workgroups/CU)
   for (int i = 0; i < L.n; ++i) {
     const Problem& P = L.p[i];
     if (!arc && (P.M % 4 != 0 || P.M < 4)) return false;
@@ -797,9 +814,15 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
   }
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
   if (mode == 0 && glds_ok(L, arc, brc, bn, EPI)) {
-    if (arc && brc) MML_LAUNCH((gemm_glds_kernel<true, true, EPI>), g, b, dyn, st, L);
-    else if (arc && !brc) MML_LAUNCH((gemm_glds_kernel<true, false, EPI>), g, b, dyn, st, L);
-    else MML_LAUNCH((gemm_glds_kernel<false, false, EPI>), g, b, dyn, st, L);
+#define MML_GL(A_, B_)                                                              \
+  do {                                                                              \
+    if (bn == 64) MML_LAUNCH((gemm_glds_kernel<A_, B_, 64, EPI>), g, b, dyn, st, L); \
+    else MML_LAUNCH((gemm_glds_kernel<A_, B_, 128, EPI>), g, b, dyn, st, L);         \
+  } while (0)
+    if (arc && brc) MML_GL(true, true);
+    else if (arc && !brc) MML_GL(true, false);
+    else MML_GL(false, false);
+#undef MML_GL
     return check_launch(who);
   }
 #define MML_GO(A_, B_, N_)                                                        \

@@ -206,12 +206,19 @@ class Plan:
 # ==================================================================================================
 # ops
 # ==================================================================================================
-def _gemm_symbol(arc, brc, cols, epi):
-    """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + launch_tiles), as rocprofv3
-    prints it: gemm_kernel<ARC, BRC, BN, EPI, MODE>."""
+def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
+    """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + glds_ok + launch_tiles), as
+    rocprofv3 prints it: gemm_glds_kernel<ARC, BRC, BN, EPI> (direct-to-LDS fast path) or
+    gemm_kernel<ARC, BRC, BN, EPI, MODE>."""
     bn = 128 if all(c % 128 == 0 and c >= 1024 for c in cols) else 64  # mirrors pick_bn()
-    return "gemm_kernel<%s, %s, %d, %d, %d>" % ("true" if arc else "false", "true" if brc else "false", bn, epi,
-                                                L.load().mml_gemm_get_mode())
+    mode = L.load().mml_gemm_get_mode()
+    t, f = "true", "false"
+    glds = (mode == 0 and bn == 64 and all(k % 16 == 0 and k >= 16 for k in kreds) and len(kreds) > 0 and
+            all(x.data_ptr() % 16 == 0 and ops._ld(x) % 4 == 0 for x in tensors) and
+            all(e % 4 == 0 and e >= 4 for e in nrc_extents))
+    if glds:
+        return "gemm_glds_kernel<%s, %s, %d, %d>" % (t if arc else f, t if brc else f, bn, epi)
+    return "gemm_kernel<%s, %s, %d, %d, %d>" % (t if arc else f, t if brc else f, bn, epi, mode)
 
 
 class Op:
@@ -297,7 +304,10 @@ class LinearGroupOp(Op):
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0)) for q in self.p])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
-        meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0),
+        meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
+                                        kreds=[q["x"].n for q in self.p],
+                                        tensors=[q["x"].buf for q in self.p] + [q["W"].data for q in self.p],
+                                        nrc_extents=[q["out"].n for q in self.p] if kn else []),
                     flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in self.p))
         return [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
 
@@ -322,7 +332,9 @@ class LinearGroupOp(Op):
             nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(descs, len(wg))
             ws = ops.workspace(nbytes, plan.device)
             plan.keep += [descs, ws]
-            meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2),
+            meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2, kreds=[plan.B],
+                                            tensors=[q["dC"] for q in wg] + [q["A"] for q in wg],
+                                            nrc_extents=[d for q in wg for d in q["dW"].shape]),
                         flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True)
             calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel()), meta))
         # input gradients: one dgrad problem per distinct input value
@@ -348,7 +360,10 @@ class LinearGroupOp(Op):
             descs = ops.make_dgrad_descs(dg)
             plan.keep.append(descs)
             kn = dg[0]["srcs"][0][2]
-            meta = dict(kernel=_gemm_symbol(True, bool(kn), [q["dA"].shape[1] for q in dg], 1),
+            meta = dict(kernel=_gemm_symbol(True, bool(kn), [q["dA"].shape[1] for q in dg], 1,
+                                            kreds=[sr[0].shape[1] for q in dg for sr in q["srcs"]],
+                                            tensors=[t_ for q in dg for sr in q["srcs"] for t_ in sr[:2]],
+                                            nrc_extents=[] if kn else [q["dA"].shape[1] for q in dg]),
                         flops=sum(2.0 * plan.B * q["dA"].shape[1] * sum(sr[0].shape[1] for sr in q["srcs"])
                                   for q in dg))
             calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg)), meta))

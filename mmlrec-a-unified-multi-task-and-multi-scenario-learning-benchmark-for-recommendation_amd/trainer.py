@@ -46,10 +46,8 @@ class TrainStep:
 
     def _body(self, with_allreduce=True):
         p, run = self.plan, E.Plan._run
-        # cap wgrad residency only when an HBM-bound table stream runs beside it (value is read at launch/capture time)
-        from . import _lib
-        _lib.load().mml_gemm_set_wgrad_lds_pad(17 * 1024 if (self.overlap and self.opt.table_update == "dense_exact")
-                                                else 0)
+        # (mml_gemm_set_wgrad_lds_pad can cap the wgrad GEMMs' residency so that the table optimizer co-resides; with
+        # the direct-to-LDS GEMMs the standalone speed of wgrad at 4 workgroups/CU wins, so the pad stays 0)
         run(self.opt_split["pre"])
         run(p.fwd)
         run(p.head_train)

@@ -16,9 +16,9 @@ import sys
 
 def label(kernel_name, avg_bytes_hint=0):
     k = kernel_name.replace("void ", "").replace("mml::", "")
-    m = re.match(r"gemm_kernel<([^>]+)>", k)
+    m = re.match(r"(gemm_glds_kernel|gemm_kernel)<([^>]+)>", k)
     if m:
-        return "gemm_kernel<%s>" % m.group(1)
+        return "%s<%s>" % (m.group(1), m.group(2))
     for a, b in (("gather_vec4_kernel", "gather_vec4_kernel"), ("scatter_hash_kernel", "scatter_hash_kernel"),
                  ("gate_bwd_fast_kernel", "gate_bwd_kernel"), ("gate_fwd_fast_kernel", "gate_fwd_kernel"),
                  ("head_fast_kernel", "head_kernel"), ("opt_dense_kernel", "opt_dense_kernel"),
