@@ -32,6 +32,10 @@ def parse():
     ap.add_argument("--table-update", default="dense_exact", choices=["dense_exact", "sparse_rows", "lazy_exact", "auto"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
+                         "--kernel-trace of this command reports stand-alone kernel durations")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the secondary lazy_exact measurement")
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -116,9 +120,17 @@ def roofline_of(acc):
     if e["flops"] > 0:
         achieved = e["flops"] / e["launches"] / (avg_ms * 1e-3) / 1e12
         unit, bound = "TFLOP/s", "mfma"
-        if name.startswith("gemm_kernel") and name.endswith(", 1>"):  # split-bf16 mode: three bf16 MFMAs per algorithmic fp32 multiply-add
-            peak = 2500.0 / 3.0
-            note = "algorithmic fp32 FLOP/s; peak = dense bf16 MFMA peak (2.5 PFLOP/s) / 3 MFMAs per product"
+        planes = 0
+        if name.startswith("gemm_glds_kernel") and name.endswith((", 2>", ", 3>")):
+            planes = int(name[-2])
+        if name.startswith("gemm_kernel") and name.endswith(", 1>"):
+            planes = 2
+        if planes:  # fp32 emulated on the bf16 MFMA pipe: 3 (two planes) or 6 (three planes) MFMAs per product block
+            per = 3 if planes == 2 else 6
+            peak = 2500.0 / per
+            note = (f"algorithmic fp32 FLOP/s; the kernel issues {per} v_mfma_f32_32x32x16_bf16 per 32x32x16 product "
+                    f"block, so peak = dense bf16 MFMA peak (2.5 PFLOP/s) / {per}; frac = bf16 MFMA pipe utilisation. "
+                    f"The fp32 MFMA peak (v_mfma_f32_32x32x2_f32) is 157.3 TFLOP/s.")
         else:
             peak = 157.3
     else:
@@ -200,7 +212,7 @@ def main():
     results = {}
     for B in [args.batch] + ([args.alt_batch] if args.alt_batch and args.alt_batch != args.batch else []):
         batches = make_batches(B)
-        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce)
+        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=not args.serial)
         steps = args.steps if B == args.batch else max(args.steps, 50)
         dt = timed_steps(runner, batches, steps, args.warmup, dist)
         results[B] = dict(dt=dt, steps=steps, value=world * B * steps / dt, ms=dt / steps * 1e3,
@@ -213,7 +225,7 @@ def main():
     # secondary measurement: the lazy_exact table optimizer (dense-Adam trajectory at touched-row cost); its timed
     # region ENDS with the flush that brings every one of the 12.49 M rows to the reference state
     lazy = {}
-    if world == 1 and args.table_update != "lazy_exact":
+    if world == 1 and args.table_update != "lazy_exact" and not args.no_lazy:
         del runner
         model2, _, _, _ = W.build_model(args.workload, dev, table_update="lazy_exact", use_hip_graph=not args.no_graph)
         model2.compile(cfg["optim_config"]["optimizer"], cfg["optim_config"]["loss"], cfg["optim_config"]["metrics"])
@@ -232,7 +244,10 @@ def main():
     if rank != 0:
         return
     from mmlrec_amd import _lib
-    gemm_dtype = "f32" if _lib.load().mml_gemm_get_mode() == 0 else "f32 (GEMMs as 3x bf16 MFMA hi/lo split, f32 accumulate)"
+    gmode = _lib.load().mml_gemm_get_mode()
+    gemm_dtype = {0: "f32", 4: "f32 (GEMMs: fp32 MFMA, or fp32-equivalent 3-plane bf16 MFMA emulation with f32 accumulate where faster)",
+                  3: "f32 (GEMMs: fp32-equivalent 3-plane bf16 MFMA emulation, f32 accumulate)"}.get(
+        gmode, "f32 operands, GEMM products from 2 bf16 planes (~1e-5 rel), f32 accumulate")
     main_r = results[args.batch]
     roof = roofline_of(main_r["acc"])
     roof["launches_per_step"] = main_r["acc"][roof["kernel"]]["launches"] / main_r["bsteps"]
@@ -247,6 +262,7 @@ def main():
                                f"lr {cfg['optim_config']['lr']}",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
                    "table_update": model.optimizer().table_update, "hip_graph": not args.no_graph,
+                   "streams": 1 if args.serial else 2,
                    "tables": "single GPU" if world == 1 else "table-wise sharded over ranks, all-to-all index/row/grad exchange",
                    "algorithmic_per_sample": per},
         "roofline": roof,

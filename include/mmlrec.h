@@ -109,14 +109,21 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
  * Replaces nn.Linear + activation inside DNN.forward (model/utils.py:146-161: addmm, relu_) and the
  * autograd mm/mm backward pair of each layer.
  * ---------------------------------------------------------------------------------------------- */
-/* Arithmetic of the GEMM family (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain);
- * 1 = split-bf16: each fp32 operand is staged as hi+lo bf16 and a product costs three v_mfma_f32_32x32x16_bf16 with
- * fp32 accumulation (relative error <= 3*2^-18 per product, ~1e-5).  Default 0 (exact): with the current staging
- * pipeline the split mode is load-latency bound and not faster on the MLP shapes, and its error flips more
- * noise-level Adam updates; it is kept selectable (environment MMLREC_GEMM_MODE=1) for the pipelined kernel of a
- * later round. */
+/* Arithmetic of the GEMM family (process-wide):
+ *   0 = fp32 MFMA on every launch (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain);
+ *   4 = auto (DEFAULT): fp32-equivalent.  Where it is faster, every fp32 operand value is cut in registers into three
+ *       bf16 planes h + m + l == x (exact mantissa slices) and a 16-k product block costs six
+ *       v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh; the dropped terms are <= 2^-24 |a b|) with fp32
+ *       accumulation.  Max-norm error against float64 equals the fp32 MFMA's (4.7e-7 vs 4.3e-7 on a
+ *       8192 x 256 x 240 product, tools/bench_gemm.py); the other launches use the fp32 MFMA;
+ *   3 / 2 = three / two planes on every launch of the direct-to-LDS path (2: three products, ~1.2e-5 relative);
+ *   1 = staged split-bf16 kernel of an earlier design (hi + lo planes written to LDS, ~1e-5 relative).
+ * Environment MMLREC_GEMM_MODE overrides the default. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);
+/* Kernel symbol (as rocprofv3 prints it, without the mml:: prefix) of the calling thread's most recent GEMM launch;
+ * "" before the first one.  For profilers / benchmark labels. */
+const char* mml_gemm_last_kernel(void);
 /* Unused dynamic LDS requested by the weight-gradient launches (process-wide, default 0).  A trainer that runs the
  * wgrad GEMMs on a side stream next to an HBM-bound kernel (the dense table optimizer) sets ~17 KiB so that only three
  * wgrad workgroups fit a CU and the other kernel's waves can co-reside. */

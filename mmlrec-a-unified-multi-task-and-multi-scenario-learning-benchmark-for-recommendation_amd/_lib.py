@@ -80,6 +80,7 @@ _SIGS = {
                                   fp, fp, i32, fp, fp]),
     "mml_gemm_set_mode": (C.c_int, [i32]),
     "mml_gemm_get_mode": (C.c_int, []),
+    "mml_gemm_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),
     "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),

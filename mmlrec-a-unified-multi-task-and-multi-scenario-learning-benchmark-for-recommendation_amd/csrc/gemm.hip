@@ -539,8 +539,46 @@ struct GCursor {
   int s, k0, kend;
 };
 
-template <bool ARC, bool BRC, int BN, int EPI>
-__global__ __launch_bounds__(256, (BN == 64 ? 4 : 3)) void gemm_glds_kernel(const Launch L) {
+// fp32 value -> PL bf16 planes by mantissa slicing (h = top 8 significant bits, m = the next 8, l = the last 8; every
+// subtraction is exact, so h + m + l == x bit for bit when PL == 3).  Eight k-values of one operand row per lane,
+// packed as the 32x32x16 bf16 MFMA wants them.
+template <int PL>
+__device__ __forceinline__ void split_planes(const float4& v0, const float4& v1, bf16x8 (&out)[PL]) {
+  const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  uint32_t w[PL][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t u0 = __float_as_uint(x[2 * j]), u1 = __float_as_uint(x[2 * j + 1]);
+    w[0][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {bf16 bits of x0, bf16 bits of x1}, truncated
+    if (PL > 1) {
+      const float r0 = x[2 * j] - __uint_as_float(u0 & 0xffff0000u);
+      const float r1 = x[2 * j + 1] - __uint_as_float(u1 & 0xffff0000u);
+      const uint32_t q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+      if (PL == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 r = {r0, r1};
+        w[1][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));  // RNE: 2^-17 |x| left over
+      } else {
+        w[1][j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(q0 & 0xffff0000u);
+        const float s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+        w[PL - 1][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PL; ++p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t = {w[p][0], w[p][1], w[p][2], w[p][3]};
+    out[p] = __builtin_bit_cast(bf16x8, t);
+  }
+}
+
+// EMU = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  EMU = 2 / 3: fp32 emulated on the bf16 MFMA pipe from 2 / 3
+// bf16 planes per operand, 3 / 6 v_mfma_f32_32x32x16_bf16 per 16 k (products below 2^-16 / 2^-24 of |a*b| dropped),
+// fp32 accumulation.
+template <bool ARC, bool BRC, int BN, int EPI, int EMU>
+__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(const Launch L) {
   constexpr int NI = BN / 64;
   constexpr int GB = BN * GK;        // floats per B stage
   constexpr int LOADS = 2 + NI;      // LDS-DMA instructions per wave per k-step
@@ -684,22 +722,45 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 3)) void gemm_glds_kernel(cons
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_Q) : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (EMU == 0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q == 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].x, fb[q][ni].x, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].y, fb[q][ni].y, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].z, fb[q][ni].z, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].w, fb[q][ni].w, acc[mi][ni], 0, 0, 0);
+          }
       }
+    } else {
+      constexpr int PL = EMU == 0 ? 1 : EMU;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pb[NI][PL];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < NI; ++ni) split_planes<PL>(fb[0][ni], fb[1][ni], pb[ni]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        bf16x8 pa[PL];
+        split_planes<PL>(fa[0][mi], fa[1][mi], pa);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].x, fb[q][ni].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].y, fb[q][ni].y, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].z, fb[q][ni].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].w, fb[q][ni].w, acc[mi][ni], 0, 0, 0);
+          // smallest products first
+#pragma unroll
+          for (int lvl = PL - 1; lvl >= 0; --lvl)
+#pragma unroll
+            for (int ia = 0; ia <= lvl; ++ia)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[ia], pb[ni][lvl - ia], acc[mi][ni], 0, 0, 0);
         }
+      }
     }
     advance(cur);
     ++i;
@@ -768,7 +829,7 @@ static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
     const char* e = getenv("MMLREC_GEMM_GLDS");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!enabled || bn != 64) return false;  // the 128 x 128 instantiation measured ~2x slower (3 workgroups/CU)
+  if (!enabled) return false;
   for (int i = 0; i < L.n; ++i) {
     const Problem& P = L.p[i];
     if (!arc && (P.M % 4 != 0 || P.M < 4)) return false;
@@ -785,26 +846,42 @@ static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
 
 static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
 
-// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per fp32 product)
+// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
+// 1 = staged split-bf16 (gemm_kernel MODE 1: 3 x v_mfma_f32_32x32x16_bf16 per 16 k, ~1e-5 relative)
+// 2 / 3 = direct-to-LDS path with 2 / 3 bf16 planes per operand on every launch
+// 4 = auto (default): fp32-equivalent results (three planes, six products: max-norm error vs float64 equal to the
+//     fp32 MFMA's, tools/bench_gemm.py) on the launches where it is faster, the fp32 MFMA elsewhere
 static int g_gemm_mode = -1;
 static int g_wgrad_pad = -1;  // unused dynamic LDS requested by wgrad launches (caps their residency, see launch_tiles)
 static int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("MMLREC_GEMM_MODE");
-    g_gemm_mode = (e && e[0] == '1') ? 1 : 0;
+    g_gemm_mode = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 4;
   }
   return g_gemm_mode;
 }
 
+struct TileChoice {
+  int bn, emu;
+};
+
+static thread_local char g_last_kernel[96] = "";
+static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, int mode) {
+  snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d>", fam, arc ? "true" : "false",
+           brc ? "true" : "false", bn, epi, mode);
+}
+
 template <int EPI>
-static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nblocks, hipStream_t st, const char* who) {
+static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int64_t nblocks, hipStream_t st,
+                        const char* who) {
+  const int bn = tc.bn;
   if (nblocks <= 0) return MML_OK;
   if (nblocks > 0x7fffffff) {
     set_error("%s: grid too large", who);
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-  const int mode = gemm_mode();
+  const int mode = gemm_mode() == 1 ? 1 : tc.emu;  // 1 = staged split-bf16 kernel, else the glds plane count (0/2/3)
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  At four
   // workgroups per CU they would own every VGPR of every SIMD and the optimizer's waves could not co-reside; an
   // unused dynamic-LDS request caps them at three per CU (3 x 53 KiB), leaving a wave slot and 128 VGPRs per SIMD.
@@ -813,21 +890,30 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
     g_wgrad_pad = e ? atoi(e) : 0;
   }
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
-  if (mode == 0 && glds_ok(L, arc, brc, bn, EPI)) {
-#define MML_GL(A_, B_)                                                              \
-  do {                                                                              \
-    if (bn == 64) MML_LAUNCH((gemm_glds_kernel<A_, B_, 64, EPI>), g, b, dyn, st, L); \
-    else MML_LAUNCH((gemm_glds_kernel<A_, B_, 128, EPI>), g, b, dyn, st, L);         \
+  if (mode != 1 && glds_ok(L, arc, brc, bn, EPI)) {
+    note_kernel("gemm_glds_kernel", arc, brc, bn, EPI, mode);
+#define MML_GL2(A_, B_, N_)                                                                   \
+  do {                                                                                        \
+    if (mode == 0) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
+    else if (mode == 2) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
+    else MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
+  } while (0)
+#define MML_GL(A_, B_)                  \
+  do {                                  \
+    if (bn == 64) MML_GL2(A_, B_, 64);  \
+    else MML_GL2(A_, B_, 128);          \
   } while (0)
     if (arc && brc) MML_GL(true, true);
     else if (arc && !brc) MML_GL(true, false);
     else MML_GL(false, false);
 #undef MML_GL
+#undef MML_GL2
     return check_launch(who);
   }
+  note_kernel("gemm_kernel", arc, brc, bn, EPI, mode == 1 ? 1 : 0);
 #define MML_GO(A_, B_, N_)                                                        \
   do {                                                                            \
-    if (mode == 0) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L); \
+    if (mode != 1) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L); \
     else MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 1>), g, b, dyn, st, L);           \
   } while (0)
   if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
@@ -841,18 +927,39 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, int bn, int64_t nbl
   return check_launch(who);
 }
 
-static int pick_bn(const int32_t* Ns, int n) {
+// Tile width and arithmetic of one grouped launch.  kind: 0 fwd, 1 dgrad, 2 wgrad; kred = longest reduction extent.
+// Measured on MI355X at M = 65536 (tools/bench_gemm.py, us, fp32 MFMA 128x64 | 128x128  vs  3-plane 128x64 | 128x128):
+//   L1 4x(240->256)+2x(240->64): fwd 376|465 vs 409|342, wgrad 519|437 vs 450|308, dgrad 388|416 vs 402|300
+//   L2 4x(256->128):             fwd 183|203 vs 163|153, wgrad 225|214 vs 182|164, dgrad 303|437 vs 356|399
+//   towers 2x(128->64):          fwd  34| 65 vs  32| 50, wgrad  82| 74 vs  72| 62, dgrad  42| 51 vs  40| 44
+// 128x128 tiles run two workgroups per CU (<= 256 VGPRs), 128x64 four (<= 128 VGPRs).
+static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, int64_t row_tiles) {
   static int force = -1;
   if (force < 0) {
     const char* e = getenv("MMLREC_GEMM_BN");
     force = e ? atoi(e) : 0;
   }
-  if (force == 64 || force == 128) return force;
-  // 128 x 64 tiles stay under 128 VGPRs -> four workgroups per CU; on the MLP shapes (N <= 512, K <= 512) that
-  // occupancy beats the better operand reuse of 128 x 128 tiles (measured: +8...25 %), which only pays on wide outputs
-  for (int i = 0; i < n; ++i)
-    if (Ns[i] % 128 != 0 || Ns[i] < 1024) return 64;
-  return 128;
+  const int mode = gemm_mode();
+  TileChoice tc{64, 0};
+  if (mode == 1) {  // staged kernel: the old rule
+    tc.bn = 128;
+    for (int i = 0; i < n; ++i)
+      if (Ns[i] % 128 != 0 || Ns[i] < 1024) tc.bn = 64;
+    if (force == 64 || force == 128) tc.bn = force;
+    return tc;
+  }
+  int64_t pad64 = 0, pad128 = 0;
+  for (int i = 0; i < n; ++i) {
+    pad64 += cdiv(Ns[i], 64) * 64;
+    pad128 += cdiv(Ns[i], 128) * 128;
+  }
+  tc.bn = (pad128 * 100 <= pad64 * 115) ? 128 : 64;  // wide tiles unless > 15 % of their columns would be padding
+  if (row_tiles * (pad128 / 128) < 1024) tc.bn = 64;  // ... or they would not fill the 512 resident slots twice
+  if (kind == 1 && kred <= 128) tc.bn = 64;           // short reductions with a heavy epilogue want occupancy
+  if (force == 64 || force == 128) tc.bn = force;
+  if (mode == 0 || mode == 2 || mode == 3) tc.emu = mode;
+  else tc.emu = (tc.bn == 128 || kind != 1) ? 3 : 0;
+  return tc;
 }
 
 }  // namespace mml
@@ -860,12 +967,15 @@ static int pick_bn(const int32_t* Ns, int n) {
 using namespace mml;
 
 extern "C" int mml_gemm_set_mode(int32_t mode) {
-  MML_REQUIRE(mode == 0 || mode == 1, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+  MML_REQUIRE(mode >= 0 && mode <= 4, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (staged split-bf16), 2 or 3 "
+              "(fp32 emulated from 2 / 3 bf16 planes on the direct-to-LDS path) or 4 (auto, fp32-equivalent)");
   g_gemm_mode = mode;
   return MML_OK;
 }
 
 extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
+
+extern "C" const char* mml_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int mml_gemm_set_wgrad_lds_pad(int32_t bytes) {
   MML_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, "mml_gemm_set_wgrad_lds_pad: bytes outside [0, 65536]");
@@ -898,7 +1008,10 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       ++j;
     }
     L.n = j - i;
-    const int bn = pick_bn(Ns, L.n);
+    int64_t kred = 0;
+    for (int k = 0; k < L.n; ++k) kred = L.src[k].Kred > kred ? L.src[k].Kred : kred;
+    const TileChoice tc = pick_tiles(Ns, L.n, 0, kred, cdiv(d[i].M, BM));
+    const int bn = tc.bn;
     int t = 0;
     for (int k = 0; k < L.n; ++k) {
       L.p[k].tiles_n = (int)cdiv(L.p[k].N, bn);
@@ -907,7 +1020,7 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     }
     L.total_ntiles = t;
     L.tiles_m = (int)cdiv(d[i].M, BM);
-    int rc = launch_tiles<EPI_FWD>(L, true, d[i].w_kn == 0, bn, (int64_t)L.tiles_m * t, to_stream(stream),
+    int rc = launch_tiles<EPI_FWD>(L, true, d[i].w_kn == 0, tc, (int64_t)L.tiles_m * t, to_stream(stream),
                                    "mml_gemm_grouped_fwd");
     if (rc) return rc;
     i = j;
@@ -949,7 +1062,14 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
       ++j;
     }
     L.n = j - i;
-    const int bn = pick_bn(Ns, L.n);
+    int64_t kred = 0;
+    for (int k = 0; k < L.n; ++k) {
+      int64_t sum = 0;
+      for (int s2 = 0; s2 < L.p[k].nsrc; ++s2) sum += L.src[L.p[k].src0 + s2].Kred;
+      kred = sum > kred ? sum : kred;
+    }
+    const TileChoice tc = pick_tiles(Ns, L.n, 1, kred, cdiv(d[i].M, BM));
+    const int bn = tc.bn;
     int t = 0;
     for (int k = 0; k < L.n; ++k) {
       L.p[k].tiles_n = (int)cdiv(L.p[k].N, bn);
@@ -959,7 +1079,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     L.total_ntiles = t;
     L.tiles_m = (int)cdiv(d[i].M, BM);
     // col operand = W: reduction index is W's row for [N,K] (not contiguous) and contiguous for [K,N]
-    int rc = launch_tiles<EPI_DGRAD>(L, true, lay == 1, bn, (int64_t)L.tiles_m * t, to_stream(stream),
+    int rc = launch_tiles<EPI_DGRAD>(L, true, lay == 1, tc, (int64_t)L.tiles_m * t, to_stream(stream),
                                      "mml_gemm_grouped_dgrad");
     if (rc) return rc;
     i = j;
@@ -970,7 +1090,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
 // wgrad planning shared by the workspace query and the launch
 namespace {
 struct WgradPlan {
-  int bn, S, chunk;
+  int bn, emu, S, chunk;
   int64_t total_tiles;
   int64_t slab_floats;  // all problems, all splits, incl. bias slabs
 };
@@ -978,7 +1098,11 @@ WgradPlan plan_wgrad(const mml_gemm_wgrad_desc* d, int i, int j) {
   WgradPlan w{};
   int32_t cols[MML_MAX_GROUP];
   for (int k = i; k < j; ++k) cols[k - i] = d[k].w_kn ? d[k].N : d[k].K;
-  w.bn = pick_bn(cols, j - i);
+  int64_t rt = 0;
+  for (int k = i; k < j; ++k) rt = cdiv(d[k].w_kn ? d[k].K : d[k].N, BM) > rt ? cdiv(d[k].w_kn ? d[k].K : d[k].N, BM) : rt;
+  const TileChoice tc = pick_tiles(cols, j - i, 2, d[i].M, rt * cdiv(d[i].M, 8 * BK));
+  w.bn = tc.bn;
+  w.emu = tc.emu;
   int64_t tiles = 0, out_elems = 0, bias_elems = 0;
   for (int k = i; k < j; ++k) {
     const int rows = d[k].w_kn ? d[k].K : d[k].N, cls = d[k].w_kn ? d[k].N : d[k].K;
@@ -988,7 +1112,7 @@ WgradPlan plan_wgrad(const mml_gemm_wgrad_desc* d, int i, int j) {
   }
   w.total_tiles = tiles;
   const int64_t M = d[i].M;
-  int64_t S = tiles > 0 ? 1024 / tiles : 1;  // aim at ~4 workgroups per CU
+  int64_t S = tiles > 0 ? (w.bn == 128 ? 768 : 1024) / tiles : 1;  // ~3 (wide tiles: 2 resident) / ~4 workgroups per CU
   const int64_t maxS = cdiv(M, 8 * BK);      // at least 256 batch rows per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -1084,7 +1208,7 @@ extern "C" int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, v
     }
     L.total_ntiles = t;
     R.total = rstart;
-    int rc = launch_tiles<EPI_SLAB>(L, false, false, w.bn, (int64_t)t * w.S, to_stream(stream),
+    int rc = launch_tiles<EPI_SLAB>(L, false, false, TileChoice{w.bn, w.emu}, (int64_t)t * w.S, to_stream(stream),
                                     "mml_gemm_grouped_wgrad");
     if (rc) return rc;
     rc = launch_slab_reduce(R, to_stream(stream), "mml_gemm_grouped_wgrad(reduce)");

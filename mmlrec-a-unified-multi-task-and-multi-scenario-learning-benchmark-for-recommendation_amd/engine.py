@@ -126,14 +126,17 @@ class Plan:
                 if rc:
                     L.check(rc, c[0].__name__)
             b.record(s)
-            evs.append((c, a, b))
+            label = None
+            if c[0] is not PY and c[0].__name__.startswith("mml_gemm_grouped"):
+                label = L.load().mml_gemm_last_kernel().decode() or None
+            evs.append((c, a, b, label))
         torch.cuda.synchronize()
-        for c, a, b in evs:
+        for c, a, b, label in evs:
             if c[0] is PY:
                 meta = c[3] if len(c) > 3 else {"kernel": getattr(c[1], "__name__", "python")}
             else:
                 meta = c[2] if len(c) > 2 else {"kernel": c[0].__name__}
-            e = acc.setdefault(meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            e = acc.setdefault(label or meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
             e["ms"] += a.elapsed_time(b)
             e["launches"] += 1
             e["flops"] += meta.get("flops", 0.0)
@@ -207,18 +210,9 @@ class Plan:
 # ops
 # ==================================================================================================
 def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
-    """Kernel symbol the C side picks for a grouped launch (csrc/gemm.hip: pick_bn + glds_ok + launch_tiles), as
-    rocprofv3 prints it: gemm_glds_kernel<ARC, BRC, BN, EPI> (direct-to-LDS fast path) or
-    gemm_kernel<ARC, BRC, BN, EPI, MODE>."""
-    bn = 128 if all(c % 128 == 0 and c >= 1024 for c in cols) else 64  # mirrors pick_bn()
-    mode = L.load().mml_gemm_get_mode()
-    t, f = "true", "false"
-    glds = (mode == 0 and bn == 64 and all(k % 16 == 0 and k >= 16 for k in kreds) and len(kreds) > 0 and
-            all(x.data_ptr() % 16 == 0 and ops._ld(x) % 4 == 0 for x in tensors) and
-            all(e % 4 == 0 and e >= 4 for e in nrc_extents))
-    if glds:
-        return "gemm_glds_kernel<%s, %s, %d, %d>" % (t if arc else f, t if brc else f, bn, epi)
-    return "gemm_kernel<%s, %s, %d, %d, %d>" % (t if arc else f, t if brc else f, bn, epi, mode)
+    """Provisional label of a grouped GEMM launch; Plan.run_timed replaces it with the symbol the C side actually
+    launched (mml_gemm_last_kernel), which depends on the tile / arithmetic choice made in csrc/gemm.hip."""
+    return "gemm<%s>" % ("fwd", "dgrad", "wgrad")[epi]
 
 
 class Op:

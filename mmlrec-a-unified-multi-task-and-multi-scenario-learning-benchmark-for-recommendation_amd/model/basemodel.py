@@ -372,13 +372,13 @@ class BaseModel(nn.Module):
         return opt
 
     # ---- fused training step ---------------------------------------------------------------------
-    def train_step_runner(self, B, use_graph=None, allreduce=None):
+    def train_step_runner(self, B, use_graph=None, allreduce=None, overlap=True):
         """Returns a TrainStep for batch size B (cached)."""
         from ..trainer import TrainStep
         key = int(B)
         st = self._caches["steps"].get(key)
-        if st is None or st.store is not self._store():
-            st = TrainStep(self, B, self.use_hip_graph if use_graph is None else use_graph, allreduce)
+        if st is None or st.store is not self._store() or st.overlap != bool(overlap):
+            st = TrainStep(self, B, self.use_hip_graph if use_graph is None else use_graph, allreduce, overlap)
             self._caches["steps"][key] = st
         return st
 

@@ -26,8 +26,33 @@ def timeit(fn, rounds=7, inner=5):
     return ts[len(ts) // 2]
 
 
+def accuracy(dev):
+    """max-norm relative error of fwd / dgrad / wgrad against float64 torch on one L1-like problem."""
+    torch.manual_seed(0)
+    M, N, K = 8192, 256, 240
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=C, act=L.ACT_NONE)])
+    ref = A.double() @ W.double().t() + b.double()
+    e_f = float((C.double() - ref).abs().max() / ref.abs().max())
+    dC = torch.randn(M, N, device=dev)
+    dA = torch.empty(M, K, device=dev)
+    ops.gemm_dgrad([dict(dA=dA, Y=None, act=L.ACT_NONE, srcs=[(dC, W, 0)])])
+    ref = dC.double() @ W.double()
+    e_d = float((dA.double() - ref).abs().max() / ref.abs().max())
+    dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    ops.gemm_wgrad([dict(dC=dC, A=A, dW=dW, dbias=db)])
+    ref = dC.double().t() @ A.double()
+    e_w = float((dW.double() - ref).abs().max() / ref.abs().max())
+    print(f"accuracy vs float64 (max |err| / max |ref|): fwd {e_f:.2e}  dgrad {e_d:.2e}  wgrad {e_w:.2e}")
+
+
 def main():
     dev = torch.device("cuda:0")
+    print("gemm mode", L.load().mml_gemm_get_mode(), " MMLREC_GEMM_BN =", os.environ.get("MMLREC_GEMM_BN"))
+    accuracy(dev)
     cases = [("square 4096^3", 4096, [(4096, 4096)]),
              ("L1 experts+gates", 65536, [(256, 240)] * 4 + [(64, 240)] * 2),
              ("L1 experts only", 65536, [(256, 240)] * 4),
@@ -50,7 +75,12 @@ def main():
         t = timeit(lambda: ops.gemm_wgrad(probs_w))
         print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
         K0 = shapes[0][1]
-        if all(k == K0 for _, k in shapes):
+        if name.startswith("L2"):  # one dgrad problem per expert (single source each), as the step runs them
+            pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0)])
+                  for p in probs_f]
+            t = timeit(lambda: ops.gemm_dgrad(pd))
+            print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s  (one problem per expert)")
+        elif all(k == K0 for _, k in shapes):
             dA = torch.empty(M, K0, device=dev)
             pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) for p in probs_f[:8]])]
             fl = sum(2.0 * M * n * k for n, k in shapes[:8])
