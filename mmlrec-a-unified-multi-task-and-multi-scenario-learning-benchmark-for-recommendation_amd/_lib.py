@@ -125,8 +125,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIBPATH
-    if (not os.path.exists(path) or _build.needs_build()) and os.path.exists(_build.HIPCC):
+    path = os.environ.get("MMLREC_LIB") or _build.LIBPATH  # MMLREC_LIB: an alternative build (kernel ablations, tools/lab)
+    if path == _build.LIBPATH and (not os.path.exists(path) or _build.needs_build()) and os.path.exists(_build.HIPCC):
         _build.build_library(verbose=False)
     if not os.path.exists(path):
         raise MMLError(f"HIP extension {path} is missing and cannot be built (no hipcc): the MI355X path has no "

@@ -52,6 +52,7 @@ struct Problem {
   const float* Y;      // dgrad derivative source
   int64_t ldy;
   int32_t act, accumulate;
+  int32_t vec_out;     // C (and Y, when read) 16-byte aligned, ld % 4 == 0, N % 4 == 0: 16-byte epilogue accesses
   int32_t tiles_n;     // ceil(N / BN)
   int32_t tile0;       // first n-tile (fwd/dgrad) or first output tile (wgrad) of this problem in the launch
   // wgrad only
@@ -544,6 +545,16 @@ struct GCursor {
 // packed as the 32x32x16 bf16 MFMA wants them.
 template <int PL>
 __device__ __forceinline__ void split_planes(const float4& v0, const float4& v1, bf16x8 (&out)[PL]) {
+#ifdef MML_LAB_NO_CONVERT
+  {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t0 = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w)};
+    u4 t1 = {__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w)};
+#pragma unroll
+    for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
+    return;
+  }
+#endif
   const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
   uint32_t w[PL][4];
 #pragma unroll
@@ -578,66 +589,101 @@ __device__ __forceinline__ void split_planes(const float4& v0, const float4& v1,
 // bf16 planes per operand, 3 / 6 v_mfma_f32_32x32x16_bf16 per 16 k (products below 2^-16 / 2^-24 of |a*b| dropped),
 // fp32 accumulation.
 template <bool ARC, bool BRC, int BN, int EPI, int EMU>
-__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(const Launch L) {
+__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(const Launch Larg) {
+  // Read the descriptor straight from the kernel-argument segment (constant address space, scalar loads): the tile
+  // loop indexes it with loop-varying indices, which would otherwise make hipcc copy all ~3 KiB of it to scratch.
+  typedef const __attribute__((address_space(4))) Launch KLaunch;
+  KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int NI = BN / 64;
   constexpr int GB = BN * GK;        // floats per B stage
   constexpr int LOADS = 2 + NI;      // LDS-DMA instructions per wave per k-step
+  constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile (2 x NI x 4)
+  constexpr int AFTER_EPI = (LOADS + NSTORE < 63) ? LOADS + NSTORE : 63;
   __shared__ __attribute__((aligned(16))) float lds[GSTAGES * (GA + GB)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int vid = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0, row0, col0, split = 0;
-  GCursor cur{0, 0, 0};
-  if (EPI != EPI_SLAB) {
-    const int mt = vid / L.total_ntiles;
-    int j = vid - mt * L.total_ntiles;
+  // Persistent workgroups: tile ids first + n * gridDim.x.  The (tile, source, k) step sequence is flat, so the
+  // two-step look-ahead of the loads runs across tile boundaries (the next tile's first stages are in flight during
+  // this tile's last MFMAs and its epilogue stores drain under the next tile's MFMAs).
+  const int64_t total = (int64_t)(EPI == EPI_SLAB ? L.splits : L.tiles_m) * L.total_ntiles;
+  // Everything a step needs from the launch descriptor is copied into the cursor when it enters a tile (plain indexed
+  // loads from the kernel-argument block; references into `L` that vary over the loop make hipcc copy the whole
+  // descriptor to scratch).
+  struct Cursor {
+    int64_t vid;
+    int pi, row0, col0, split;
+    int s, k0, kend;
+    int M, N, nsrc, src0;
+    bool ok;
+  };
+  auto decode = [&](Cursor& c) __attribute__((always_inline)) {
+    c.ok = c.vid < total;
+    if (!c.ok) return;
+    const int outer = (int)(c.vid / L.total_ntiles);
+    int j = (int)(c.vid - (int64_t)outer * L.total_ntiles);
+    int pi = 0;
     while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
     j -= L.p[pi].tile0;
-    row0 = mt * BM;
-    col0 = j * BN;
-    cur.kend = L.src[L.p[pi].src0].Kred;
-  } else {
-    split = vid / L.total_ntiles;
-    int j = vid - split * L.total_ntiles;
-    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
-    j -= L.p[pi].tile0;
-    row0 = (j / L.p[pi].tiles_n) * BM;
-    col0 = (j % L.p[pi].tiles_n) * BN;
-    cur.k0 = split * L.chunk;
-    const int kr = L.src[L.p[pi].src0].Kred;
-    cur.kend = (cur.k0 + L.chunk < kr) ? cur.k0 + L.chunk : kr;
-  }
-  const Problem& P = L.p[pi];
-
-  f32x16 acc[2][NI];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  float bsum = 0.f;
-  const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
-
-  // flattened (source, k) step sequence with a two-step look-ahead
-  auto valid = [&](const GCursor& c) { return c.s < P.nsrc && c.k0 < c.kend; };
-  auto advance = [&](GCursor& c) {
-    c.k0 += GK;
-    if (c.k0 >= c.kend && EPI != EPI_SLAB) {
-      ++c.s;
+    c.pi = pi;
+    c.s = 0;
+    c.M = L.p[pi].M;
+    c.N = L.p[pi].N;
+    c.nsrc = L.p[pi].nsrc;
+    c.src0 = L.p[pi].src0;
+    if (EPI != EPI_SLAB) {
+      c.row0 = outer * BM;
+      c.col0 = j * BN;
+      c.split = 0;
       c.k0 = 0;
-      c.kend = (c.s < P.nsrc) ? L.src[P.src0 + c.s].Kred : 0;
+      c.kend = L.src[c.src0].Kred;
+    } else {
+      const int tn = L.p[pi].tiles_n;
+      c.split = outer;
+      c.row0 = (j / tn) * BM;
+      c.col0 = (j % tn) * BN;
+      c.k0 = outer * L.chunk;
+      const int kr = L.src[c.src0].Kred;
+      c.kend = (c.k0 + L.chunk < kr) ? c.k0 + L.chunk : kr;
+      if (c.k0 >= c.kend) c.kend = c.k0 + GK;  // (cannot happen: S = ceil(M / chunk))
     }
   };
-  auto issue = [&](const GCursor& c, const int stage) {
-    const Source& S = L.src[P.src0 + c.s];
-    float* sa = lds + stage * (GA + GB);
-    glds_issue<ARC, BM>(sa, S.A, S.lda, row0, P.M, c.k0, wave, lane);
-    glds_issue<BRC, BN>(sa + GA, S.B, S.ldb, col0, P.N, c.k0, wave, lane);
+  auto last_step = [&](const Cursor& c) __attribute__((always_inline)) { return c.k0 + GK >= c.kend && (EPI == EPI_SLAB || c.s + 1 >= c.nsrc); };
+  auto advance = [&](Cursor& c) __attribute__((always_inline)) {
+    c.k0 += GK;
+    if (c.k0 < c.kend) return;
+    if (EPI != EPI_SLAB && c.s + 1 < c.nsrc) {
+      ++c.s;
+      c.k0 = 0;
+      c.kend = L.src[c.src0 + c.s].Kred;
+      return;
+    }
+    c.vid += gridDim.x;
+    decode(c);
   };
+  auto issue = [&](const Cursor& c, const int stage) __attribute__((always_inline)) {
+#ifdef MML_LAB_NO_GLOBAL
+    return;
+#endif
+    const int si = c.src0 + c.s;
+    float* sa = lds + stage * (GA + GB);
+    glds_issue<ARC, BM>(sa, L.src[si].A, L.src[si].lda, c.row0, c.M, c.k0, wave, lane);
+    glds_issue<BRC, BN>(sa + GA, L.src[si].B, L.src[si].ldb, c.col0, c.N, c.k0, wave, lane);
+  };
+
+  f32x16 acc[2][NI];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  };
+  zero_acc();
+  float bsum = 0.f;
 
   // per-lane LDS byte addresses of this wave's fragments inside a stage (stage / k-group / +32-row offsets are
   // instruction immediates)
@@ -661,31 +707,135 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(cons
     }
   }
 
-  GCursor pf = cur;  // prefetch cursor
-  int issued = 0;
-  if (valid(pf)) { issue(pf, 0); advance(pf); ++issued; }
-  if (valid(pf)) { issue(pf, 1); advance(pf); ++issued; }
+  // ---- epilogue of the tile the compute cursor is on ----
+  // The MFMAs take the COLUMN operand as their A input, so a lane owns one output ROW (l31) and its 16 accumulator
+  // registers are four runs of 4 consecutive columns (8g + 4h + 0..3): the tile leaves as 16-byte stores, 16 * NI per
+  // wave (a wave can only have 63 VMEM operations in flight; 64 dword stores per tile would block it until they drain).
+  auto epilogue = [&](const Cursor& c, const bool want_bias) __attribute__((always_inline)) {
+#ifdef MML_LAB_NO_EPI
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    const int pi = c.pi;
+    const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
+    if (EPI == EPI_SLAB) {
+      if (want_bias) {
+        float* bs = L.p[pi].bias_slab;
+        if (!L.p[pi].bias_cols) {
+          if (tid < BM && row0 + tid < PM) bs[(int64_t)c.split * PM + row0 + tid] = bsum;
+        } else {
+          if (tid < BN && col0 + tid < PN) bs[(int64_t)c.split * PN + col0 + tid] = bsum;
+        }
+      }
+      float* slab = L.slab + L.p[pi].slab_off + (int64_t)c.split * PM * PN;  // PN % 4 == 0 (glds_ok)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = row0 + wm * 64 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+            if (row < PM && col < PN)
+              *reinterpret_cast<float4*>(slab + (int64_t)row * PN + col) =
+                  make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+          }
+      }
+      return;
+    }
+    float* const C = L.p[pi].C;
+    const int64_t ldc = L.p[pi].ldc;
+    const float* const bias = L.p[pi].bias;
+    const float* const Y = L.p[pi].Y;
+    const int64_t ldy = L.p[pi].ldy;
+    const int act = L.p[pi].act, accumulate = L.p[pi].accumulate;
+    const bool vec = L.p[pi].vec_out != 0;  // C (and Y) 16-byte aligned with ld % 4 == 0 and N % 4 == 0
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = row0 + wm * 64 + mi * 32 + l31;
+      if (row >= PM) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+          if (col >= PN) continue;
+          float v[4] = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+          float* dst = C + (int64_t)row * ldc + col;
+          if (vec) {
+            if (EPI == EPI_FWD) {
+              float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (bias) b4 = *reinterpret_cast<const float4*>(bias + col);
+              v[0] = act_fwd(v[0] + b4.x, act); v[1] = act_fwd(v[1] + b4.y, act);
+              v[2] = act_fwd(v[2] + b4.z, act); v[3] = act_fwd(v[3] + b4.w, act);
+            } else {
+              if (act != MML_ACT_NONE) {
+                const float4 y4 = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + col);
+                v[0] *= act_bwd(y4.x, act); v[1] *= act_bwd(y4.y, act);
+                v[2] *= act_bwd(y4.z, act); v[3] *= act_bwd(y4.w, act);
+              }
+              if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+              }
+            }
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (col + e >= PN) continue;
+              float x = v[e];
+              if (EPI == EPI_FWD) {
+                x = act_fwd(x + (bias ? bias[col + e] : 0.f), act);
+              } else {
+                if (act != MML_ACT_NONE) x *= act_bwd(Y[(int64_t)row * ldy + col + e], act);
+                if (accumulate) x += dst[e];
+              }
+              dst[e] = x;
+            }
+          }
+        }
+    }
+  };
+
+  Cursor cur;
+  cur.vid = xcd_remap(blockIdx.x, gridDim.x);
+  decode(cur);
+  Cursor pf = cur;  // prefetch cursor, two steps ahead
+  int issued = 0, i = 0;
+  int since_epi = 2;      // steps since an epilogue whose stores may still be in flight (0 / 1: they are)
+  bool epi_counted = false;  // that epilogue issued exactly NSTORE stores per wave (interior tile) and no loads
+  if (pf.ok) { issue(pf, 0); advance(pf); ++issued; }
+  if (pf.ok) { issue(pf, 1); advance(pf); ++issued; }
 
   // One k-step on a COMPILE-TIME stage index: with static LDS offsets hipcc can tell that the fragment reads of
   // stage S never alias the in-flight LDS-DMA destination (stage S+2), so it does not drain vmcnt before them.
-  int i = 0;
-  auto step = [&](auto stage_c) {
+  auto step = [&](auto stage_c) __attribute__((always_inline)) {
     constexpr int S = decltype(stage_c)::value;
-    // my own loads of step i have landed when at most the loads of ONE later step (LOADS instructions) are in flight
-    if (issued > i + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // My own loads of step i have landed when at most the loads of ONE later step (LOADS instructions) -- plus, for
+    // two steps after an interior tile's epilogue, its NSTORE stores, which were issued after them -- are in flight
+    // (VMEM operations of one wave complete in issue order).
+    if (issued > i + 1) {
+      if (since_epi < 2 && epi_counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_EPI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // everyone's step-i tiles are in LDS; everyone is done reading stage (S+2)%3
-    if (valid(pf)) {
+    if (pf.ok) {
       issue(pf, (S + 2) % GSTAGES);
       advance(pf);
       ++issued;
     }
+    ++since_epi;
     constexpr int SA = S * (GA + GB) * 4;  // byte offset of this stage's A image
     constexpr int SB = SA + GA * 4;
+    const bool bias_cols = (EPI == EPI_SLAB) && L.p[cur.pi].bias_cols != 0;
+    const bool want_bias =
+        (EPI == EPI_SLAB) && L.p[cur.pi].bias_slab != nullptr && (bias_cols ? cur.row0 == 0 : cur.col0 == 0);
     if (want_bias) {
-      if (tid < (P.bias_cols ? BN : BM)) {  // both operands are [k][rows] images in a wgrad launch
-        const uint32_t ab = lds0 + (P.bias_cols ? SB : SA) + tid * 4;
-        const int R4 = (P.bias_cols ? BN : BM) * 4;
+      if (tid < (bias_cols ? BN : BM)) {  // both operands are [k][rows] images in a wgrad launch
+        const uint32_t ab = lds0 + (bias_cols ? SB : SA) + tid * 4;
+        const int R4 = (bias_cols ? BN : BM) * 4;
         float sacc = 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {  // 8 reads in flight at a time (lgkmcnt is a 4-bit counter)
@@ -734,10 +884,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(cons
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].x, fb[q][ni].x, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].y, fb[q][ni].y, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].z, fb[q][ni].z, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi].w, fb[q][ni].w, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].x, fa[q][mi].x, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].y, fa[q][mi].y, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].z, fa[q][mi].z, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].w, fa[q][mi].w, acc[mi][ni], 0, 0, 0);
           }
       }
     } else {
@@ -757,70 +907,39 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(cons
 #pragma unroll
           for (int lvl = PL - 1; lvl >= 0; --lvl)
 #pragma unroll
-            for (int ia = 0; ia <= lvl; ++ia)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[ia], pb[ni][lvl - ia], acc[mi][ni], 0, 0, 0);
+            for (int ia = 0; ia <= lvl; ++ia) {
+#ifdef MML_LAB_NO_MFMA
+              acc[mi][ni][(lvl + ia) & 15] += __builtin_bit_cast(float4, pa[ia]).x * __builtin_bit_cast(float4, pb[ni][lvl - ia]).y;
+#else
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pb[ni][lvl - ia], pa[ia], acc[mi][ni], 0, 0, 0);
+#endif
+            }
         }
       }
+    }
+    if (last_step(cur)) {  // tile finished: write it out and start the next one on cleared accumulators
+      epilogue(cur, want_bias);
+      // interior fwd / slab tiles issue exactly NSTORE stores per wave and nothing else; any other epilogue (edge
+      // tiles, dgrad's loads of Y / the accumulate target) is followed by plain vmcnt(LOADS) waits, i.e. drains
+      epi_counted = (EPI != EPI_DGRAD) && !want_bias && cur.row0 + BM <= cur.M && cur.col0 + BN <= cur.N &&
+                    (EPI == EPI_SLAB || L.p[cur.pi].vec_out != 0);
+      since_epi = 0;
+      zero_acc();
+      bsum = 0.f;
     }
     advance(cur);
     ++i;
   };
   while (true) {
-    if (!valid(cur)) break;
+    if (!cur.ok) break;
     step(std::integral_constant<int, 0>{});
-    if (!valid(cur)) break;
+    if (!cur.ok) break;
     step(std::integral_constant<int, 1>{});
-    if (!valid(cur)) break;
+    if (!cur.ok) break;
     step(std::integral_constant<int, 2>{});
   }
-
-  // ---- epilogue (identical to gemm_kernel) ----
-  if (EPI == EPI_SLAB) {
-    if (want_bias) {
-      if (!P.bias_cols) {
-        if (tid < BM && row0 + tid < P.M) P.bias_slab[(int64_t)split * P.M + row0 + tid] = bsum;
-      } else {
-        if (tid < BN && col0 + tid < P.N) P.bias_slab[(int64_t)split * P.N + col0 + tid] = bsum;
-      }
-    }
-    float* slab = L.slab + P.slab_off + (int64_t)split * P.M * P.N;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < P.M && col < P.N) slab[(int64_t)row * P.N + col] = acc[mi][ni][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = col0 + wn * (BN / 2) + ni * 32 + l31;
-    if (col >= P.N) continue;
-    float b = 0.f;
-    if (EPI == EPI_FWD && P.bias) b = P.bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row >= P.M) continue;
-      float v = acc[mi][ni][r];
-      float* dst = P.C + (int64_t)row * P.ldc + col;
-      if (EPI == EPI_FWD) {
-        v = act_fwd(v + b, P.act);
-      } else {
-        if (P.act != MML_ACT_NONE) v *= act_bwd(P.Y[(int64_t)row * P.ldy + col], P.act);
-        if (P.accumulate) v += *dst;
-      }
-      *dst = v;
-    }
-  }
 }
+
 
 // host-side eligibility of a whole launch for the direct-to-LDS path
 static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
@@ -892,6 +1011,18 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
   if (mode != 1 && glds_ok(L, arc, brc, bn, EPI)) {
     note_kernel("gemm_glds_kernel", arc, brc, bn, EPI, mode);
+    // persistent workgroups: one per resident slot (4 per CU at <= 128 VGPRs, 2 at <= 256), each loops over tiles
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      cus = n;
+    }
+    const int64_t slots = (int64_t)cus * (dyn ? (bn == 64 ? 3 : 2) : (bn == 64 ? 4 : 2));
+    if (nblocks > slots) g = dim3((unsigned)slots);
+#ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
+#define MML_GL(A_, B_) MML_LAUNCH((gemm_glds_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
+#else
 #define MML_GL2(A_, B_, N_)                                                                   \
   do {                                                                                        \
     if (mode == 0) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
@@ -903,13 +1034,20 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     if (bn == 64) MML_GL2(A_, B_, 64);  \
     else MML_GL2(A_, B_, 128);          \
   } while (0)
+#endif
     if (arc && brc) MML_GL(true, true);
     else if (arc && !brc) MML_GL(true, false);
     else MML_GL(false, false);
 #undef MML_GL
+#ifndef MML_LAB
 #undef MML_GL2
+#endif
     return check_launch(who);
   }
+#ifdef MML_LAB
+  set_error("%s: lab build has only the direct-to-LDS kernel", who);
+  return MML_ERR_UNSUPPORTED;
+#else
   note_kernel("gemm_kernel", arc, brc, bn, EPI, mode == 1 ? 1 : 0);
 #define MML_GO(A_, B_, N_)                                                        \
   do {                                                                            \
@@ -925,6 +1063,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   }
 #undef MML_GO
   return check_launch(who);
+#endif
 }
 
 // Tile width and arithmetic of one grouped launch.  kind: 0 fwd, 1 dgrad, 2 wgrad; kred = longest reduction extent.
@@ -941,6 +1080,9 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
   }
   const int mode = gemm_mode();
   TileChoice tc{64, 0};
+#ifdef MML_LAB
+  return TileChoice{MML_LAB_BN, MML_LAB_EMU};
+#endif
   if (mode == 1) {  // staged kernel: the old rule
     tc.bn = 128;
     for (int i = 0; i < n; ++i)
@@ -1004,6 +1146,7 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
       S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
       P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
+      P.vec_out = (vec_ok(q.C, q.ldc) && q.N % 4 == 0 && (!q.bias || aligned16(q.bias))) ? 1 : 0;
       Ns[j - i] = q.N;
       ++j;
     }
@@ -1057,6 +1200,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
         S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
       }
       P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
+      P.vec_out = (vec_ok(q.dA, q.ldda) && q.K % 4 == 0 && (!q.Y || vec_ok(q.Y, q.ldy))) ? 1 : 0;
       P.accumulate = q.accumulate;
       Ns[j - i] = q.K;
       ++j;
@@ -1112,7 +1256,7 @@ WgradPlan plan_wgrad(const mml_gemm_wgrad_desc* d, int i, int j) {
   }
   w.total_tiles = tiles;
   const int64_t M = d[i].M;
-  int64_t S = tiles > 0 ? (w.bn == 128 ? 768 : 1024) / tiles : 1;  // ~3 (wide tiles: 2 resident) / ~4 workgroups per CU
+  int64_t S = tiles > 0 ? 1024 / tiles : 1;  // ~4 tiles per CU
   const int64_t maxS = cdiv(M, 8 * BK);      // at least 256 batch rows per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;

@@ -51,13 +51,18 @@ def accuracy(dev):
 
 def main():
     dev = torch.device("cuda:0")
-    print("gemm mode", L.load().mml_gemm_get_mode(), " MMLREC_GEMM_BN =", os.environ.get("MMLREC_GEMM_BN"))
-    accuracy(dev)
+    print("gemm mode", L.load().mml_gemm_get_mode(), " MMLREC_GEMM_BN =", os.environ.get("MMLREC_GEMM_BN"),
+          " lib =", os.environ.get("MMLREC_LIB"))
+    if not os.environ.get("MMLREC_LIB"):
+        accuracy(dev)
     cases = [("square 4096^3", 4096, [(4096, 4096)]),
              ("L1 experts+gates", 65536, [(256, 240)] * 4 + [(64, 240)] * 2),
              ("L1 experts only", 65536, [(256, 240)] * 4),
              ("L2 experts", 65536, [(128, 256)] * 4),
              ("towers", 65536, [(64, 128)] * 2)]
+    only = os.environ.get("CASES")
+    if only:
+        cases = [c for c in cases if any(c[0].startswith(o) for o in only.split(","))]
     for name, M, shapes in cases:
         A = {}
         probs_f, probs_w = [], []
