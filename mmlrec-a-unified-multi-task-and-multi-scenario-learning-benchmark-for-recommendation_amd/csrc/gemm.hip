@@ -507,6 +507,11 @@ __device__ __forceinline__ float4 ds_read128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
+__device__ __forceinline__ void ds_write128(uint32_t addr, const float4& v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(t) : "memory");
+}
 template <int OFF>
 __device__ __forceinline__ float ds_read32(uint32_t addr) {
   float v;
@@ -941,6 +946,750 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(cons
 }
 
 
+// ====================================================================================================
+// Software-pipelined direct-to-LDS kernel ("pipe"): same tiles, operand images and MFMA map as gemm_glds_kernel,
+// different schedule.
+//   * four LDS stages; the LDS-DMA of step i+3 is issued at the top of step i (two full steps of flight, as before);
+//   * the fragment reads of step i+1 are issued at the top of step i into a second register set, so no MFMA ever
+//     waits on LDS latency;
+//   * the fp32 -> bf16-plane cuts of the NEXT operands are placed in the shadow of the current MFMA blocks
+//     (sched_group_barrier: 1 MFMA : a few VALU), instead of one VALU phase followed by one MFMA phase;
+//   * DMA source pointers are per-lane running pointers (set up once per tile / source, one 64-bit add per load);
+//   * one copy of the epilogue (the step body is dispatched on i % 4 from a plain loop).
+// Per step and wave (BN = 128): carry-in = prepared A0, B0 and raw A1, B1 of this step;
+//   block 1: acc00 += A0 x B0   ||  prepare B1          block 3: acc10 += A1 x B0  ||  prepare next B0
+//   block 2: acc01 += A0 x B1   ||  prepare A1          block 4: acc11 += A1 x B1  ||  prepare next A0
+// ====================================================================================================
+constexpr int PSTAGES = 4;
+
+#ifdef MML_LAB_TIMES  // per-phase cycle sums of wave 0 of workgroup 0 (tools/lab): [0] wait+barrier [1] issue+scalar
+                      // [2] reads + blocks 1-2 [3] blocks 3-4 (+epilogue) [4] steps [5] epilogue-bearing steps' [3]
+__device__ unsigned long long g_lab_t[16];
+#define LAB_T(var) unsigned long long var = __builtin_readcyclecounter()
+#else
+#define LAB_T(var)
+#endif
+
+// one LDS-DMA wave-instruction: every lane moves 16 bytes from its own global address to lds_dst + 16 * lane
+__device__ __forceinline__ void dma16(const float* g, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(g, lds_dst, 16, 0, 0);
+}
+// ... and the 4-byte form: lds_dst + 4 * lane
+__device__ __forceinline__ void dma4(const float* g, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(g, lds_dst, 4, 0, 0);
+}
+
+struct RawFrag {
+  float4 q0, q1;  // k-group 0 and 1 of one 32-row sub-tile: the lane's 8 k-values of this step
+};
+template <int EMU>
+struct Prep {
+  bf16x8 p[EMU == 0 ? 1 : EMU];
+};
+template <>
+struct Prep<0> {
+  float4 q0, q1;
+};
+
+template <int EMU>
+__device__ __forceinline__ void prep_frag(const RawFrag& r, Prep<EMU>& o) {
+  if constexpr (EMU == 0) {
+    o.q0 = r.q0;
+    o.q1 = r.q1;
+  } else {
+    split_planes<EMU>(r.q0, r.q1, o.p);
+  }
+}
+
+// acc += rows(a) x cols(b); the COLUMN operand is the MFMA's A input (a lane then owns an output row, see epilogue)
+template <int EMU>
+__device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const Prep<EMU>& b) {
+  if constexpr (EMU == 0) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.x, a.q0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.y, a.q0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.z, a.q0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.w, a.q0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.x, a.q1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.y, a.q1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.z, a.q1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.w, a.q1.w, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int lvl = EMU - 1; lvl >= 0; --lvl)  // smallest products first
+#pragma unroll
+      for (int ia = 0; ia <= lvl; ++ia) {
+#ifdef MML_LAB_NO_MFMA
+        acc[(lvl + ia) & 15] += __builtin_bit_cast(float4, a.p[ia]).x * __builtin_bit_cast(float4, b.p[lvl - ia]).y;
+#else
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[lvl - ia], a.p[ia], acc, 0, 0, 0);
+#endif
+      }
+  }
+}
+
+// Keeps a prepared operand's conversion where it was written: without a use in the same block hipcc sinks the VALU
+// work of an operand that is only consumed by the NEXT step out of the MFMA shadow it was placed in.
+template <int EMU>
+__device__ __forceinline__ void pin_prep(Prep<EMU>& o) {
+  if constexpr (EMU == 0) {
+    asm volatile("" : "+v"(o.q0.x), "+v"(o.q0.y), "+v"(o.q0.z), "+v"(o.q0.w));
+    asm volatile("" : "+v"(o.q1.x), "+v"(o.q1.y), "+v"(o.q1.z), "+v"(o.q1.w));
+  } else {
+#pragma unroll
+    for (int p = 0; p < EMU; ++p) asm volatile("" : "+v"(o.p[p]));
+  }
+}
+
+// interleave hint for one block: NM MFMAs, each followed by NV VALU instructions of the neighbouring prepare
+template <int NM, int NV>
+__device__ __forceinline__ void interleave_hint() {
+#ifdef MML_LAB_NO_HINT
+  return;
+#endif
+#pragma unroll
+  for (int t = 0; t < NM; ++t) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float v) {
+  if (ACT == MML_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == MML_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  if (ACT == MML_ACT_SIGMOID2) return 2.f / (1.f + __expf(-v));
+  return v;
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd_t(float y) {
+  if (ACT == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (ACT == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (ACT == MML_ACT_SIGMOID2) {
+    const float s = 0.5f * y;
+    return 2.f * s * (1.f - s);
+  }
+  return 1.f;
+}
+
+template <bool ARC, bool BRC, int BN, int EPI, int EMU>
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
+  typedef const __attribute__((address_space(4))) Launch KLaunch;
+  KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();  // see gemm_glds_kernel
+  constexpr int NI = BN / 64;
+  constexpr int GB = BN * GK;
+  constexpr int STG = GA + GB;       // floats per stage
+  constexpr int LOADS = 2 + NI;      // LDS-DMA instructions per wave per k-step
+  constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile
+  constexpr int NBIAS = (EPI == EPI_FWD) ? 1 : 0;  // the next tile's bias DMA follows the stores
+  constexpr int AFTER_EPI = (LOADS + NSTORE + NBIAS < 63) ? LOADS + NSTORE + NBIAS : 63;
+  constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 2 ? 3 : 6);  // MFMAs per block
+  constexpr int NVALU = EMU == 0 ? 0 : (EMU == 2 ? 10 : 8); // VALU slots per MFMA of a block with one prepare
+  __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256];  // + one 64-float bias slot per wave
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int64_t total = (int64_t)(EPI == EPI_SLAB ? L.splits : L.tiles_m) * L.total_ntiles;
+  struct Cursor {
+    int64_t vid;
+    int pi, row0, col0, split;
+    int s, k0, kend;
+    int M, N, nsrc, src0;
+    bool ok;
+    bool want_bias, bias_cols;  // wgrad: this tile also sums the bias partials (of the row / column operand)
+    bool short_tile;            // fewer than three k-steps: the bias DMA may still be in flight at the epilogue
+    bool counted;               // interior tile with 16-byte stores: its epilogue leaves exactly NSTORE stores in flight
+  };
+  auto decode = [&](Cursor& c) __attribute__((always_inline)) {
+    c.ok = c.vid < total;
+    if (!c.ok) return;
+    const int outer = (int)(c.vid / L.total_ntiles);
+    int j = (int)(c.vid - (int64_t)outer * L.total_ntiles);
+    int pi = 0;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    j -= L.p[pi].tile0;
+    c.pi = pi;
+    c.s = 0;
+    c.M = L.p[pi].M;
+    c.N = L.p[pi].N;
+    c.nsrc = L.p[pi].nsrc;
+    c.src0 = L.p[pi].src0;
+    if (EPI != EPI_SLAB) {
+      c.row0 = outer * BM;
+      c.col0 = j * BN;
+      c.split = 0;
+      c.k0 = 0;
+      c.kend = L.src[c.src0].Kred;
+    } else {
+      const int tn = L.p[pi].tiles_n;
+      c.split = outer;
+      c.row0 = (j / tn) * BM;
+      c.col0 = (j % tn) * BN;
+      c.k0 = outer * L.chunk;
+      const int kr = L.src[c.src0].Kred;
+      c.kend = (c.k0 + L.chunk < kr) ? c.k0 + L.chunk : kr;
+      if (c.k0 >= c.kend) c.kend = c.k0 + GK;
+    }
+    c.bias_cols = (EPI == EPI_SLAB) && L.p[pi].bias_cols != 0;
+    c.want_bias = (EPI == EPI_SLAB) && L.p[pi].bias_slab != nullptr && (c.bias_cols ? c.row0 == 0 : c.col0 == 0);
+    c.short_tile = (EPI != EPI_SLAB) && (c.nsrc == 1) && (c.kend - c.k0 < 3 * GK);
+    c.counted = c.row0 + BM <= c.M && c.col0 + BN <= c.N && (EPI == EPI_SLAB || L.p[pi].vec_out != 0);
+  };
+  auto last_step = [&](const Cursor& c) __attribute__((always_inline)) {
+    return c.k0 + GK >= c.kend && (EPI == EPI_SLAB || c.s + 1 >= c.nsrc);
+  };
+  // returns true when the cursor moved to another (tile, source): running pointers must be set up again
+  auto advance = [&](Cursor& c) __attribute__((always_inline)) -> bool {
+    c.k0 += GK;
+    if (c.k0 < c.kend) return false;
+    if (EPI != EPI_SLAB && c.s + 1 < c.nsrc) {
+      ++c.s;
+      c.k0 = 0;
+      c.kend = L.src[c.src0 + c.s].Kred;
+      return true;
+    }
+    c.vid += gridDim.x;
+    decode(c);
+    return true;
+  };
+
+  // ---- LDS-DMA with running per-lane source pointers ----
+  const float* pa[2];
+  const float* pb[NI];
+  int64_t incA = 0, incB = 0;
+  auto setup_ptrs = [&](const Cursor& c) __attribute__((always_inline)) {
+    if (!c.ok) return;
+    const int si = c.src0 + c.s;
+    const float* A = L.src[si].A;
+    const float* B = L.src[si].B;
+    const int64_t lda = L.src[si].lda, ldb = L.src[si].ldb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = wave + 4 * j;
+      if (ARC) {
+        const int rl = 16 * t + (lane >> 2);
+        int row = c.row0 + rl;
+        row = row < c.M ? row : c.M - 1;
+        pa[j] = A + (int64_t)row * lda + c.k0 + 4 * ((lane & 3) ^ ((rl >> 2) & 3));
+      } else {
+        const int kr = t * 2 + lane / 32;  // 2 k-rows of 128 floats per wave-instruction
+        int col = c.row0 + 4 * (lane % 32);
+        col = (col + 4 <= c.M) ? col : c.M - 4;
+        pa[j] = A + (int64_t)(c.k0 + kr) * lda + col;
+      }
+    }
+    incA = ARC ? GK : GK * lda;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int t = wave + 4 * j;
+      if (BRC) {
+        const int rl = 16 * t + (lane >> 2);
+        int row = c.col0 + rl;
+        row = row < c.N ? row : c.N - 1;
+        pb[j] = B + (int64_t)row * ldb + c.k0 + 4 * ((lane & 3) ^ ((rl >> 2) & 3));
+      } else {
+        constexpr int KR = 256 / BN, CH = BN / 4;
+        const int kr = t * KR + lane / CH;
+        int col = c.col0 + 4 * (lane % CH);
+        col = (col + 4 <= c.N) ? col : c.N - 4;
+        pb[j] = B + (int64_t)(c.k0 + kr) * ldb + col;
+      }
+    }
+    incB = BRC ? GK : GK * ldb;
+  };
+  auto issue = [&](const int stage) __attribute__((always_inline)) {
+#ifndef MML_LAB_NO_GLOBAL
+    float* sa = lds + stage * STG;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dma16(pa[j], sa + (wave + 4 * j) * 256);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      dma16(pb[j], sa + GA + (wave + 4 * j) * 256);
+#endif
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pa[j] += incA;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pb[j] += incB;
+  };
+
+  // fwd: the bias values of this wave's 64 (BN/2) columns travel to LDS by one 4-byte LDS-DMA per lane when the compute
+  // cursor enters a tile, so the epilogue reads them with ds_read_b128 instead of eight dependent global loads.  Always
+  // exactly one VMEM operation (a dummy address when there is no bias): the counted waits rely on it.
+  float* const lds_bias = lds + PSTAGES * STG + wave * 64;
+  auto bias_dma = [&](const Cursor& c) __attribute__((always_inline)) {
+    if (EPI != EPI_FWD || !c.ok) return;
+    const float* bias = L.p[c.pi].bias;
+    int col = c.col0 + wn * (BN / 2) + lane;
+    col = col < c.N ? col : c.N - 1;
+    const float* src = bias ? bias + col : L.p[c.pi].C;
+    __builtin_amdgcn_sched_barrier(0);
+    dma4(src, lds_bias);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  f32x16 acc[2][NI];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  };
+  zero_acc();
+  float bsum = 0.f;
+
+  const uint32_t lds0 = lds_byte_addr(lds);
+  uint32_t aA0, aA1, aB0, aB1;
+  {
+    const int ra = wm * 64 + l31, rb = wn * (BN / 2) + l31;
+    if (ARC) {
+      aA0 = lds0 + ra * GK * 4 + ((h ^ ((ra >> 2) & 3)) * 16);
+      aA1 = lds0 + ra * GK * 4 + (((2 + h) ^ ((ra >> 2) & 3)) * 16);
+    } else {
+      aA0 = lds0 + (4 * h * BM + ra) * 4;
+      aA1 = aA0 + 32 * 4;
+    }
+    if (BRC) {
+      aB0 = lds0 + rb * GK * 4 + ((h ^ ((rb >> 2) & 3)) * 16);
+      aB1 = lds0 + rb * GK * 4 + (((2 + h) ^ ((rb >> 2) & 3)) * 16);
+    } else {
+      aB0 = lds0 + (4 * h * BN + rb) * 4;
+      aB1 = aB0 + 32 * 4;
+    }
+  }
+
+  // ---- epilogue: lane = output row, registers = four runs of 4 consecutive columns.  The activation is dispatched ONCE
+  // per tile (a per-element `switch` made this 10 000 instructions of branchy code that cost as much as 14 k-steps).
+  auto epilogue_slab = [&](const Cursor& c) __attribute__((always_inline)) {
+    const int pi = c.pi;
+    const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
+    if (c.want_bias) {
+      float* bs = L.p[pi].bias_slab;
+      if (!c.bias_cols) {
+        if (tid < BM && row0 + tid < PM) bs[(int64_t)c.split * PM + row0 + tid] = bsum;
+      } else {
+        if (tid < BN && col0 + tid < PN) bs[(int64_t)c.split * PN + col0 + tid] = bsum;
+      }
+    }
+    float* slab = L.slab + L.p[pi].slab_off + (int64_t)c.split * PM * PN;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = row0 + wm * 64 + mi * 32 + l31;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+          if (row < PM && col < PN)
+            *reinterpret_cast<float4*>(slab + (int64_t)row * PN + col) =
+                make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+        }
+    }
+  };
+  auto epilogue_act = [&](const Cursor& c, const uint32_t so_epi, auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;
+    const int pi = c.pi;
+    const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
+    float* const C = L.p[pi].C;
+    const int64_t ldc = L.p[pi].ldc;
+    const float* const bias = L.p[pi].bias;
+    const float* const Y = L.p[pi].Y;
+    const int64_t ldy = L.p[pi].ldy;
+    const bool accumulate = L.p[pi].accumulate != 0;
+    const bool vec = L.p[pi].vec_out != 0;
+    if (vec && BN == 64) {
+      // 128 x 64 tiles: a stage is 12 KiB, too small for four 4-KiB transposition areas -> per-lane 16-byte accesses
+      // (lane = row), all loads of a 32-row half before its stores
+      if (EPI == EPI_FWD && c.short_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float4 b4[NI][4];
+      if (EPI == EPI_FWD && bias) {
+        const uint32_t ab = lds_byte_addr(lds_bias) + 16 * h;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) b4[ni][g] = ds_read128<0>(ab + (ni * 32 + 8 * g) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = row0 + wm * 64 + mi * 32 + l31;
+        const bool row_ok = row < PM;
+        float4 y4[NI][4];
+        if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+              y4[ni][g] = (row_ok && col < PN) ? *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + col)
+                                               : make_float4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+            if (!row_ok || col >= PN) continue;
+            float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+            float* dst = C + (int64_t)row * ldc + col;
+            if (EPI == EPI_FWD) {
+              if (bias) {
+                v.x += b4[ni][g].x; v.y += b4[ni][g].y; v.z += b4[ni][g].z; v.w += b4[ni][g].w;
+              }
+              v.x = act_fwd_t<ACT>(v.x); v.y = act_fwd_t<ACT>(v.y); v.z = act_fwd_t<ACT>(v.z); v.w = act_fwd_t<ACT>(v.w);
+            } else {
+              if (ACT != MML_ACT_NONE) {
+                v.x *= act_bwd_t<ACT>(y4[ni][g].x); v.y *= act_bwd_t<ACT>(y4[ni][g].y);
+                v.z *= act_bwd_t<ACT>(y4[ni][g].z); v.w *= act_bwd_t<ACT>(y4[ni][g].w);
+              }
+              if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+              }
+            }
+            *reinterpret_cast<float4*>(dst) = v;
+          }
+      }
+    } else if (vec) {
+      // Each 32 x 32 sub-tile is turned row-major through this wave's 4 KiB of the stage buffer the step just consumed
+      // (idle until the next step's DMA, which every wave issues after the next barrier): a lane then moves 16 bytes
+      // of a row and a wave-instruction covers 8 rows x 128 B -- whole cache lines for the stores and for dgrad's
+      // reads of Y, instead of 32 rows x 32 B.  16-byte chunk c of row r sits at chunk c ^ (r & 7): conflict-free for
+      // the column-wise writes and the row-wise reads.
+      const uint32_t tb = lds0 + so_epi + wave * 4096;
+      const int R = lane >> 3, cc = lane & 7;
+      if (EPI == EPI_FWD && c.short_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias DMA landed?
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int colg = col0 + wn * (BN / 2) + ni * 32 + 4 * cc;  // this lane's 4 columns
+          const int rowb = row0 + wm * 64 + mi * 32 + R;             // ... of rows rowb + 8p
+          float4 y4[4];
+          if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {  // in flight during the LDS round trip
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const bool ok = rowb + 8 * p < PM && colg < PN;
+              y4[p] = ok ? *reinterpret_cast<const float4*>(Y + (int64_t)(rowb + 8 * p) * ldy + colg) : make_float4(0, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+            ds_write128(tb + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) * 16), v);
+          }
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == EPI_FWD && bias) b4 = ds_read128<0>(lds_byte_addr(lds_bias) + (ni * 32 + 4 * cc) * 4);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          float4 v[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) v[p] = ds_read128<0>(tb + (R + 8 * p) * 128 + ((cc ^ ((R + 8 * p) & 7)) * 16));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int row = rowb + 8 * p;
+            if (row >= PM || colg >= PN) continue;
+            float4 x = v[p];
+            if (EPI == EPI_FWD) {
+              x.x = act_fwd_t<ACT>(x.x + b4.x); x.y = act_fwd_t<ACT>(x.y + b4.y);
+              x.z = act_fwd_t<ACT>(x.z + b4.z); x.w = act_fwd_t<ACT>(x.w + b4.w);
+            } else {
+              if (ACT != MML_ACT_NONE) {
+                x.x *= act_bwd_t<ACT>(y4[p].x); x.y *= act_bwd_t<ACT>(y4[p].y);
+                x.z *= act_bwd_t<ACT>(y4[p].z); x.w *= act_bwd_t<ACT>(y4[p].w);
+              }
+              if (accumulate) {  // (rare: outputs summed over more than MML_MAX_SRC sources)
+                const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
+                x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+              }
+            }
+            *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;
+          }
+        }
+    } else {  // unaligned / odd-width outputs: element-wise
+#pragma unroll  // (full unroll: run-time indices would put the accumulators in scratch)
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = row0 + wm * 64 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (row >= PM || col >= PN) continue;
+            float x = acc[mi][ni][r];
+            float* dst = C + (int64_t)row * ldc + col;
+            if (EPI == EPI_FWD) {
+              x = act_fwd_t<ACT>(x + (bias ? bias[col] : 0.f));
+            } else {
+              if (ACT != MML_ACT_NONE) x *= act_bwd_t<ACT>(Y[(int64_t)row * ldy + col]);
+              if (accumulate) x += *dst;
+            }
+            *dst = x;
+          }
+      }
+    }
+  };
+  auto epilogue = [&](const Cursor& c, const uint32_t so_epi) __attribute__((always_inline)) {
+#ifdef MML_LAB_NO_EPI
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    if (EPI == EPI_SLAB) {
+      epilogue_slab(c);
+      return;
+    }
+    switch (L.p[c.pi].act) {
+      case MML_ACT_RELU: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_RELU>{}); break;
+      case MML_ACT_SIGMOID: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_SIGMOID>{}); break;
+      case MML_ACT_SIGMOID2: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_SIGMOID2>{}); break;
+      default: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_NONE>{}); break;
+    }
+  };
+
+  // ---- fragment reads of one stage: the stage's byte offset is a run-time VGPR add (the reads are inline asm, so the
+  // compiler's waitcnt pass never sees them next to the in-flight LDS-DMA) ----
+  auto read_a = [&](const uint32_t so, auto mic, RawFrag& r) __attribute__((always_inline)) {
+    constexpr int MI = decltype(mic)::value;
+    if (MI == 0) {
+      r.q0 = glds_frag_asm<ARC, BM, 0, 0, 0>(aA0 + so);
+      r.q1 = glds_frag_asm<ARC, BM, 0, 0, 1>((ARC ? aA1 : aA0) + so);
+    } else {
+      r.q0 = glds_frag_asm<ARC, BM, 0, 1, 0>((ARC ? aA0 : aA1) + so);
+      r.q1 = glds_frag_asm<ARC, BM, 0, 1, 1>(aA1 + so);
+    }
+  };
+  auto read_b = [&](const uint32_t so, auto nic, RawFrag& r) __attribute__((always_inline)) {
+    constexpr int NIX = decltype(nic)::value;
+    constexpr int SB = GA * 4;
+    if (NIX == 0) {
+      r.q0 = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0 + so);
+      r.q1 = glds_frag_asm<BRC, BN, SB, 0, 1>((BRC ? aB1 : aB0) + so);
+    } else {
+      r.q0 = glds_frag_asm<BRC, BN, SB, 1, 0>((BRC ? aB0 : aB1) + so);
+      r.q1 = glds_frag_asm<BRC, BN, SB, 1, 1>(aB1 + so);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- pipeline state: two register sets, indexed by step parity (the loop body is two steps) ----
+  Prep<EMU> PA0[2], PB0[2];
+  RawFrag RA1[2], RB1[2];
+
+  Cursor cur;
+  cur.vid = xcd_remap(blockIdx.x, gridDim.x);
+  decode(cur);
+  Cursor pf = cur;
+  setup_ptrs(pf);
+  bias_dma(cur);
+  int issued = 0, i = 0;
+  int epi_left = 0;  // steps (0..2) during which the stores of a counted epilogue may still be in flight
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+    if (pf.ok) {
+      issue(st);
+      if (advance(pf)) setup_ptrs(pf);
+      ++issued;
+    }
+  // stage 0 -> registers
+  if (issued >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    RawFrag a0, b0;
+    read_a(0u, I0{}, a0);
+    read_a(0u, I1{}, RA1[0]);
+    read_b(0u, I0{}, b0);
+    if (NI == 2) read_b(0u, I1{}, RB1[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    prep_frag<EMU>(a0, PA0[0]);
+    prep_frag<EMU>(b0, PB0[0]);
+  }
+
+  auto step = [&](auto par_c) __attribute__((always_inline)) {
+    constexpr int P = decltype(par_c)::value, Q = P ^ 1;
+    const int sidx = i & (PSTAGES - 1);
+    const uint32_t so_cur = (uint32_t)sidx * (STG * 4);
+    const uint32_t so_next = (uint32_t)((sidx + 1) & (PSTAGES - 1)) * (STG * 4);
+    LAB_T(t0);
+    // Stage i+1 (read below) was issued two steps ago: in steady state at most the loads of step i+2 are younger.
+    // Off the hot path: for two steps after a counted epilogue its stores are younger too; once the prefetch cursor
+    // has run out of work, drain.
+    if (__builtin_expect((epi_left | (pf.ok ? 0 : 1)) == 0, 1)) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else if (pf.ok && epi_left > 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_EPI) : "memory");
+      --epi_left;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      epi_left = 0;
+    }
+    __builtin_amdgcn_s_barrier();
+    LAB_T(t1);
+    if (pf.ok) {
+      issue((sidx + 3) & (PSTAGES - 1));
+#ifdef MML_LAB_TIMES
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long tp0 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool sw = advance(pf);
+      if (sw) setup_ptrs(pf);
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long tp1 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      if (blockIdx.x == 0 && tid == 0 && sw) { g_lab_t[11] += tp1 - tp0; g_lab_t[12] += 1; }
+#else
+      if (advance(pf)) setup_ptrs(pf);
+#endif
+      ++issued;
+    }
+    const bool bias_cols = cur.bias_cols;
+    if (EPI == EPI_SLAB && cur.want_bias) {
+      if (tid < (bias_cols ? BN : BM)) {
+        const uint32_t ab = lds0 + so_cur + (bias_cols ? GA * 4 : 0) + tid * 4;
+        const int R4 = (bias_cols ? BN : BM) * 4;
+        float sacc = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v[k]) : "v"(ab + (half * 8 + k) * R4) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sacc += v[k];
+        }
+        bsum += sacc;
+      }
+    }
+    // next step's fragments -> the other register set (in flight during blocks 1-2)
+    RawFrag na0, nb0;
+    LAB_T(t2);
+    read_b(so_next, I0{}, nb0);
+    read_a(so_next, I0{}, na0);
+    read_a(so_next, I1{}, RA1[Q]);
+    if (NI == 2) read_b(so_next, I1{}, RB1[Q]);
+    __builtin_amdgcn_sched_barrier(0);
+    Prep<EMU> PA1, PB1;
+#ifdef MML_LAB_TIMES
+    unsigned long long t3 = 0;
+#endif
+    if (NI == 2) {
+      prep_frag<EMU>(RB1[P], PB1);
+      mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
+      interleave_hint<NMFMA, NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+      prep_frag<EMU>(RA1[P], PA1);
+      mma_block<EMU>(acc[0][NI - 1], PA0[P], PB1);
+      interleave_hint<NMFMA, NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef MML_LAB_TIMES
+      t3 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      prep_frag<EMU>(nb0, PB0[Q]);
+      mma_block<EMU>(acc[1][0], PA1, PB0[P]);
+      pin_prep<EMU>(PB0[Q]);
+      interleave_hint<NMFMA, NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+      prep_frag<EMU>(na0, PA0[Q]);
+      mma_block<EMU>(acc[1][NI - 1], PA1, PB1);
+      pin_prep<EMU>(PA0[Q]);
+      interleave_hint<NMFMA, NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      prep_frag<EMU>(RA1[P], PA1);
+      mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
+      interleave_hint<NMFMA, NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      prep_frag<EMU>(nb0, PB0[Q]);
+      prep_frag<EMU>(na0, PA0[Q]);
+      mma_block<EMU>(acc[1][0], PA1, PB0[P]);
+      pin_prep<EMU>(PB0[Q]);
+      pin_prep<EMU>(PA0[Q]);
+      interleave_hint<NMFMA, 2 * NVALU>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool tile_end = last_step(cur);
+#ifdef MML_LAB_TIMES
+    const bool lab_last = tile_end;
+#endif
+    if (__builtin_expect(tile_end, 0)) {
+#ifdef MML_LAB_TIMES
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long te0 = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long te1 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      if (blockIdx.x == 0 && tid == 0) { g_lab_t[7] += te1 - te0; }
+#endif
+      epilogue(cur, so_cur);
+#ifdef MML_LAB_TIMES
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long te2 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      if (blockIdx.x == 0 && tid == 0) { g_lab_t[8] += te2 - te1; }
+#endif
+      // every load of the epilogue (bias, Y, accumulate target) was consumed before its store issued, so a counted
+      // tile leaves exactly NSTORE (or more: bias partials) stores in flight and nothing else
+      epi_left = cur.counted ? 2 : 0;
+      if (!cur.counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      zero_acc();
+      bsum = 0.f;
+#ifdef MML_LAB_TIMES
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long te3 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      if (blockIdx.x == 0 && tid == 0) { g_lab_t[9] += te3 - te2; }
+#endif
+    }
+#ifdef MML_LAB_TIMES
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long ta0 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    advance(cur);
+    if (__builtin_expect(tile_end, 0)) bias_dma(cur);
+#ifdef MML_LAB_TIMES
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long ta1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && tid == 0 && lab_last) { g_lab_t[10] += ta1 - ta0; }
+#endif
+    ++i;
+#ifdef MML_LAB_TIMES
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long t4 = __builtin_readcyclecounter();
+      if (blockIdx.x == 0 && tid == 0) {
+        g_lab_t[0] += t1 - t0; g_lab_t[1] += t2 - t1; g_lab_t[2] += t3 - t2;
+        if (lab_last) { g_lab_t[5] += t4 - t3; g_lab_t[6] += 1; } else { g_lab_t[3] += t4 - t3; }
+        g_lab_t[4] += 1;
+      }
+    }
+#endif
+  };
+
+  while (true) {
+    if (!cur.ok) break;
+    step(I0{});
+    if (!cur.ok) break;
+    step(I1{});
+  }
+}
+
 // host-side eligibility of a whole launch for the direct-to-LDS path
 static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
   static int enabled = -1;
@@ -1020,14 +1769,34 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     }
     const int64_t slots = (int64_t)cus * (dyn ? (bn == 64 ? 3 : 2) : (bn == 64 ? 4 : 2));
     if (nblocks > slots) g = dim3((unsigned)slots);
+    static int use_pipe = -1;
+    if (use_pipe < 0) {
+      const char* e = getenv("MMLREC_GEMM_PIPE");
+      use_pipe = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_pipe) note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, mode);
+    if (use_pipe && bn == 64) {
+      const int64_t s3 = (int64_t)cus * 3;  // the pipelined 128 x 64 kernel keeps three workgroups per CU
+      g = dim3((unsigned)(nblocks > s3 ? s3 : nblocks));
+    }
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
+#ifdef MML_LAB_GLDS
 #define MML_GL(A_, B_) MML_LAUNCH((gemm_glds_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
 #else
-#define MML_GL2(A_, B_, N_)                                                                   \
-  do {                                                                                        \
-    if (mode == 0) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
-    else if (mode == 2) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
-    else MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
+#define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
+#endif
+#else
+#define MML_GL2(A_, B_, N_)                                                                     \
+  do {                                                                                          \
+    if (use_pipe) {                                                                             \
+      if (mode == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
+      else if (mode == 2) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
+      else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
+    } else {                                                                                    \
+      if (mode == 0) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
+      else if (mode == 2) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
+      else MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
+    }                                                                                           \
   } while (0)
 #define MML_GL(A_, B_)                  \
   do {                                  \
@@ -1118,6 +1887,17 @@ extern "C" int mml_gemm_set_mode(int32_t mode) {
 extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
 
 extern "C" const char* mml_gemm_last_kernel(void) { return g_last_kernel; }
+
+#ifdef MML_LAB_TIMES
+extern "C" int mml_lab_times(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_t), sizeof(g_lab_t)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lab_t), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int mml_gemm_set_wgrad_lds_pad(int32_t bytes) {
   MML_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, "mml_gemm_set_wgrad_lds_pad: bytes outside [0, 65536]");
