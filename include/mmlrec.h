@@ -116,8 +116,7 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
  *       v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh; the dropped terms are <= 2^-24 |a b|) with fp32
  *       accumulation.  Max-norm error against float64 equals the fp32 MFMA's (4.7e-7 vs 4.3e-7 on a
  *       8192 x 256 x 240 product, tools/bench_gemm.py); the other launches use the fp32 MFMA;
- *   3 / 2 = three / two planes on every launch of the direct-to-LDS path (2: three products, ~1.2e-5 relative);
- *   1 = staged split-bf16 kernel of an earlier design (hi + lo planes written to LDS, ~1e-5 relative).
+ *   3 = the three-plane form on every launch of the LDS-DMA kernel.
  * Environment MMLREC_GEMM_MODE overrides the default. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);

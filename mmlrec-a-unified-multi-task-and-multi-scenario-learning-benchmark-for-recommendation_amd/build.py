@@ -63,17 +63,43 @@ def build_library(force=False, verbose=True, jobs=None):
             obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
             objs.append(obj)
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            stderr = None
+            if os.path.basename(src) == "gemm.hip":
+                # the pipelined GEMM counts its own VMEM operations (s_waitcnt vmcnt(N)): a register spill would add
+                # scratch traffic to that count and silently break the waits -> check the resource report
+                cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
+                stderr = open(obj + ".log", "w")
             if verbose:
                 print("[mmlrec build]", " ".join(cmd), flush=True)
-            procs.append((subprocess.Popen(cmd), src))
+            procs.append((subprocess.Popen(cmd, stderr=stderr), src))
         reap(block=True)
     if failed:
+        for src in failed:
+            log = os.path.join(objdir, os.path.basename(src)[:-4] + ".o.log")
+            if os.path.exists(log):
+                sys.stderr.write("".join(l for l in open(log) if "remark:" not in l)[-4000:])
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    check_no_scratch(os.path.join(objdir, "gemm.o.log"))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
     if verbose:
         print("[mmlrec build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIBPATH
+
+
+def check_no_scratch(log):
+    """Every gemm_pipe_kernel instantiation must use no scratch memory (see build_library)."""
+    if not os.path.exists(log):
+        return
+    name, bad = None, []
+    for line in open(log):
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize" in line and name and "gemm_pipe_kernel" in name:
+            if int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
+                bad.append(name)
+    if bad:
+        raise RuntimeError("register spills in the pipelined GEMM (counted vmcnt waits would break): " + ", ".join(bad))
 
 
 if __name__ == "__main__":

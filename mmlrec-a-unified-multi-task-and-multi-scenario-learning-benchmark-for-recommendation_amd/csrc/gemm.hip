@@ -29,7 +29,6 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int PITCH_RC = BK + 4;    // [row][k] layout
 constexpr int PITCH_NRC = 128 + 4;  // [k][row] layout (row extent always 128 slots; BN=64 uses half)
-constexpr int LDS_TILE = 5120;  // floats per operand: f32 images need 128*36 = 4608 (>= 32*132), the bf16 hi+lo pair 2*128*40*2 B = 5120 floats
 
 struct Source {
   const float* A;  // row operand
@@ -155,70 +154,8 @@ __device__ __forceinline__ void stash_tile(const float4 (&r)[ROWS / 32], float* 
   }
 }
 
-// ---- split-bf16 staging (MODE 1) -------------------------------------------------------------------
-// Every fp32 operand value x is staged as two bf16 planes hi = bf16(x), lo = bf16(x - hi); the product a*b is then
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA pipe with fp32 accumulation: |error| <= 3 * 2^-18 |a*b| per
-// product (the dropped terms), i.e. ~1e-5 relative -- inside the 1e-4 parity budget at 16/3 of the fp32-MFMA rate.
-// Both operands are kept as [row][k] bf16 images (pitch 40 elements = 80 B: conflict-free ds_read_b128 for the
-// 32x32x16 operand map); a [k][row] (row-contiguous) source is transposed for free in registers: a thread holds
-// 4 rows x PIECES consecutive k.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-constexpr int PB = BK + 8;                 // bf16 elements per image row
-constexpr int PLANE = 128 * PB;            // elements per plane (hi or lo) of one operand
-
-__device__ __forceinline__ void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
-  const f32x2_t v = {x, y};
-  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32 (RNE)
-  const uint32_t hb = __builtin_bit_cast(uint32_t, h);
-  const f32x2_t r = {x - __uint_as_float(hb << 16), y - __uint_as_float(hb & 0xffff0000u)};
-  hi = hb;
-  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
-}
-
-template <bool RC, int ROWS>
-__device__ __forceinline__ void stash_tile_bf16(const float4 (&r)[ROWS / 32], unsigned short* hi, unsigned short* lo,
-                                                int tid) {
-  constexpr int PIECES = ROWS / 32;
-  if (RC) {
-#pragma unroll
-    for (int c = 0; c < PIECES; ++c) {
-      const int idx = tid + 256 * c;
-      const int row = idx / (BK / 4), k4 = idx % (BK / 4);
-      uint2 h, l;
-      split2(r[c].x, r[c].y, h.x, l.x);
-      split2(r[c].z, r[c].w, h.y, l.y);
-      *reinterpret_cast<uint2*>(hi + row * PB + k4 * 4) = h;
-      *reinterpret_cast<uint2*>(lo + row * PB + k4 * 4) = l;
-    }
-  } else {
-    const int row4 = tid % (ROWS / 4), kq = (tid / (ROWS / 4)) * PIECES;
-    const float* f = reinterpret_cast<const float*>(&r[0]);  // f[c*4 + j] = value at (k = kq + c, row = 4*row4 + j)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = row4 * 4 + j;
-      if (PIECES == 4) {
-        uint2 h, l;
-        split2(f[0 * 4 + j], f[1 * 4 + j], h.x, l.x);
-        split2(f[2 * 4 + j], f[3 * 4 + j], h.y, l.y);
-        *reinterpret_cast<uint2*>(hi + row * PB + kq) = h;
-        *reinterpret_cast<uint2*>(lo + row * PB + kq) = l;
-      } else {
-        uint32_t h, l;
-        split2(f[0 * 4 + j], f[1 * 4 + j], h, l);
-        *reinterpret_cast<uint32_t*>(hi + row * PB + kq) = h;
-        *reinterpret_cast<uint32_t*>(lo + row * PB + kq) = l;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ bf16x8 read_frag_bf16(const unsigned short* plane, int row, int s, int h) {
-  return *reinterpret_cast<const bf16x8*>(plane + row * PB + 16 * s + 8 * h);
-}
-
-__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
 
 // fragment for 8-deep group q: 4 values (j = 0..3) for row `row` (tile-local), lane half h.
 template <bool RC>
@@ -233,14 +170,10 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int q, in
 
 // ---- the tile engine -------------------------------------------------------------------------------
 // Accumulates sum_s sum_{k in [kbeg_s, kend_s)} rowop_s[row0+i][k] * colop_s[col0+j][k] into acc.
-template <bool ARC, bool BRC, int BN, int MODE>
+template <bool ARC, bool BRC, int BN>
 __device__ __forceinline__ void tile_mainloop(f32x16 (&acc)[2][BN / 64], const Launch& L, const Problem& P, int row0,
                                               int col0, int kbeg, int klen_limit, float* ldsA, float* ldsB,
                                               float* bias_part /* per-thread partial batch sum of dC, or null */) {
-  unsigned short* hiA = reinterpret_cast<unsigned short*>(ldsA);  // MODE 1: [hi plane | lo plane] per operand
-  unsigned short* loA = hiA + PLANE;
-  unsigned short* hiB = reinterpret_cast<unsigned short*>(ldsB);
-  unsigned short* loB = hiB + PLANE;
   constexpr int NI = BN / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -258,59 +191,22 @@ __device__ __forceinline__ void tile_mainloop(f32x16 (&acc)[2][BN / 64], const L
     fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0, kend, S.vecB, tid);
     for (; k0 < kend; k0 += BK) {
       __syncthreads();  // previous step's LDS reads are done
-      if (MODE == 0) {
-        stash_tile<ARC, BM>(ra, ldsA, tid);
-        stash_tile<BRC, BN>(rb, ldsB, tid);
-      } else {
-        stash_tile_bf16<ARC, BM>(ra, hiA, loA, tid);
-        stash_tile_bf16<BRC, BN>(rb, hiB, loB, tid);
-      }
+      stash_tile<ARC, BM>(ra, ldsA, tid);
+      stash_tile<BRC, BN>(rb, ldsB, tid);
       __syncthreads();
       if (k0 + BK < kend) {  // next tile's loads fly during the MFMAs
         fetch_tile<ARC, BM>(ra, S.A, S.lda, row0, P.M, k0 + BK, kend, S.vecA, tid);
         fetch_tile<BRC, BN>(rb, S.B, S.ldb, col0, P.N, k0 + BK, kend, S.vecB, tid);
       }
       if (bias_part != nullptr) {
-        // batch sums of dC over this k-slab (wgrad bias gradient)
+        // batch sums of dC over this k-slab (wgrad bias gradient); both operands are in [k][row] layout here
         if (tid < (P.bias_cols ? BN : BM)) {
           float sacc = 0.f;
-          if (MODE == 0) {  // both operands are in [k][row] layout here
-            const float* src = P.bias_cols ? ldsB : ldsA;
+          const float* src = P.bias_cols ? ldsB : ldsA;
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) sacc += src[k * PITCH_NRC + tid];
-          } else {  // [row][k] bf16 hi/lo images
-            const unsigned short* ph = (P.bias_cols ? hiB : hiA) + tid * PB;
-            const unsigned short* pl = (P.bias_cols ? loB : loA) + tid * PB;
-#pragma unroll 8
-            for (int k = 0; k < BK; ++k) sacc += bf16_bits_to_float(ph[k]) + bf16_bits_to_float(pl[k]);
-          }
+          for (int k = 0; k < BK; ++k) sacc += src[k * PITCH_NRC + tid];
           *bias_part += sacc;
         }
-      }
-      if (MODE == 1) {
-#pragma unroll
-        for (int s2 = 0; s2 < BK / 16; ++s2) {
-          bf16x8 ah[2], al[2], bh[NI], bl[NI];
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            ah[mi] = read_frag_bf16(hiA, wm * 64 + mi * 32 + l31, s2, h);
-            al[mi] = read_frag_bf16(loA, wm * 64 + mi * 32 + l31, s2, h);
-          }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            bh[ni] = read_frag_bf16(hiB, wn * (BN / 2) + ni * 32 + l31, s2, h);
-            bl[ni] = read_frag_bf16(loB, wn * (BN / 2) + ni * 32 + l31, s2, h);
-          }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            }
-        }
-        continue;
       }
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
@@ -342,12 +238,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// BN = 64 tiles need <= 128 VGPRs, so four workgroups (one wave each per SIMD) fit a CU; the exact-fp32 images take
-// 36 KiB of LDS per workgroup (4 x 36 = 144 KiB <= 160 KiB), the bf16 hi/lo images 40 KiB.
-template <bool ARC, bool BRC, int BN, int EPI, int MODE>
+// BN = 64 tiles need <= 128 VGPRs, so four workgroups (one wave each per SIMD) fit a CU; the images take
+// 36 KiB of LDS per workgroup (4 x 36 = 144 KiB <= 160 KiB).
+template <bool ARC, bool BRC, int BN, int EPI>
 __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Launch L) {
   constexpr int NI = BN / 64;
-  constexpr int TILE_FLOATS = (MODE == 0) ? 128 * PITCH_RC : LDS_TILE;
+  constexpr int TILE_FLOATS = 128 * PITCH_RC;  // f32 images: 128*36 = 4608 floats (>= 32*132)
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
   float* ldsA = lds;
   float* ldsB = lds + TILE_FLOATS;
@@ -383,7 +279,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
 
   float bsum = 0.f;
   const bool want_bias = (EPI == EPI_SLAB) && P.bias_slab != nullptr && (P.bias_cols ? row0 == 0 : col0 == 0);
-  tile_mainloop<ARC, BRC, BN, MODE>(acc, L, P, row0, col0, kbeg, klen, ldsA, ldsB, want_bias ? &bsum : nullptr);
+  tile_mainloop<ARC, BRC, BN>(acc, L, P, row0, col0, kbeg, klen, ldsA, ldsB, want_bias ? &bsum : nullptr);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -439,63 +335,26 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
 }
 
 // ====================================================================================================
-// Direct-to-LDS fast path (exact fp32, 128 x 64 tiles, K step 16, three LDS stages)
+// LDS-DMA operand staging (used by gemm_pipe_kernel below)
 //
 // Same tile geometry and MFMA map as gemm_kernel, different staging: operand tiles go global -> LDS with
-// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no per-lane guards), two k-steps ahead of the MFMAs, with
-// ONE raw s_barrier per k-step and a counted s_waitcnt vmcnt(3) (each wave issues exactly 3 loads per k-step).
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no per-lane guards), K step 16, ahead of the MFMAs, with ONE
+// raw s_barrier per k-step and counted s_waitcnt vmcnt(N).
 //   * reduction-contiguous operand ([rows][16 k], 64-B rows): the 16-B chunk a lane fetches is XOR-swizzled on the
 //     SOURCE side (phys = chunk ^ ((row >> 2) & 3)) because the LDS destination of a wave-instruction is lane-linear;
 //     reading (row, chunk) at phys is conflict-free for the ds_read_b128 lane groups;
-//   * row-contiguous operand ([16 k][rows]): plain image, fragments read with 4 x ds_read_b32 (lanes = consecutive
-//     rows -> conflict-free).
+//   * row-contiguous operand ([16 k][rows]): plain image, fragments read with 2 x ds_read2st64_b32 (lanes =
+//     consecutive rows -> conflict-free).
 // Rows past the end of an operand are clamped to the last valid row / chunk (their products only reach outputs the
 // epilogue discards), so no zero-fill is needed.  Eligibility (checked on the host, else gemm_kernel runs): every
 // reduction extent a multiple of 16, 16-byte aligned operands with ld % 4 == 0, row-contiguous extents % 4 == 0.
 // ====================================================================================================
 constexpr int GK = 16;
-constexpr int GSTAGES = 3;
 constexpr int GA = 128 * GK;  // floats per A stage
-
-template <bool RC, int ROWS>
-__device__ __forceinline__ void glds_issue(float* stage, const float* __restrict__ base, int64_t ld, int row0,
-                                           int nrows, int k0, int wave, int lane) {
-  if (RC) {
-#pragma unroll
-    for (int t = wave; t < ROWS / 16; t += 4) {  // one wave-instruction = 16 rows x 64 B
-      const int rl = 16 * t + (lane >> 2);
-      int row = row0 + rl;
-      row = row < nrows ? row : nrows - 1;
-      const int c = (lane & 3) ^ ((rl >> 2) & 3);
-      __builtin_amdgcn_global_load_lds(base + (int64_t)row * ld + k0 + 4 * c, stage + t * 256, 16, 0, 0);
-    }
-  } else {
-    constexpr int KR = 256 / ROWS;  // k-rows per wave-instruction (1 KiB): 2 for 128-wide rows, 4 for 64-wide
-    constexpr int CH = ROWS / 4;    // 16-B chunks per k-row
-#pragma unroll
-    for (int t = wave; t < GK / KR; t += 4) {
-      const int kr = t * KR + lane / CH;
-      int col = row0 + 4 * (lane % CH);
-      col = (col + 4 <= nrows) ? col : nrows - 4;
-      __builtin_amdgcn_global_load_lds(base + (int64_t)(k0 + kr) * ld + col, stage + t * 256, 16, 0, 0);
-    }
-  }
-}
-
-template <bool RC, int ROWS>
-__device__ __forceinline__ float4 glds_frag(const float* stage, int row, int q, int h) {
-  if (RC) {
-    const int phys = (2 * q + h) ^ ((row >> 2) & 3);
-    return *reinterpret_cast<const float4*>(stage + row * GK + 4 * phys);
-  } else {
-    const float* p = stage + (8 * q + 4 * h) * ROWS + row;
-    return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
-  }
-}
 
 // LDS fragment reads as inline asm: hipcc treats an LDS-DMA in flight as a pending LDS store and would put
 // s_waitcnt vmcnt(0) in front of every C++-level ds_read (draining the two-step prefetch); asm reads are invisible to
-// that pass, so the counted vmcnt(3) above is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand and
+// that pass, so the counted vmcnt(N) of the kernel is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand and
 // followed by sched_barrier(0) so that no MFMA is hoisted above them (cdna guide, methodology rule 18).
 typedef __attribute__((address_space(3))) float lds_f32_t;
 __device__ __forceinline__ uint32_t lds_byte_addr(const float* p) {
@@ -541,10 +400,6 @@ __device__ __forceinline__ float4 glds_frag_asm(uint32_t a) {
   }
 }
 
-struct GCursor {
-  int s, k0, kend;
-};
-
 // fp32 value -> PL bf16 planes by mantissa slicing (h = top 8 significant bits, m = the next 8, l = the last 8; every
 // subtraction is exact, so h + m + l == x bit for bit when PL == 3).  Eight k-values of one operand row per lane,
 // packed as the 32x32x16 bf16 MFMA wants them.
@@ -589,362 +444,6 @@ __device__ __forceinline__ void split_planes(const float4& v0, const float4& v1,
     out[p] = __builtin_bit_cast(bf16x8, t);
   }
 }
-
-// EMU = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  EMU = 2 / 3: fp32 emulated on the bf16 MFMA pipe from 2 / 3
-// bf16 planes per operand, 3 / 6 v_mfma_f32_32x32x16_bf16 per 16 k (products below 2^-16 / 2^-24 of |a*b| dropped),
-// fp32 accumulation.
-template <bool ARC, bool BRC, int BN, int EPI, int EMU>
-__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_glds_kernel(const Launch Larg) {
-  // Read the descriptor straight from the kernel-argument segment (constant address space, scalar loads): the tile
-  // loop indexes it with loop-varying indices, which would otherwise make hipcc copy all ~3 KiB of it to scratch.
-  typedef const __attribute__((address_space(4))) Launch KLaunch;
-  KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
-  constexpr int NI = BN / 64;
-  constexpr int GB = BN * GK;        // floats per B stage
-  constexpr int LOADS = 2 + NI;      // LDS-DMA instructions per wave per k-step
-  constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile (2 x NI x 4)
-  constexpr int AFTER_EPI = (LOADS + NSTORE < 63) ? LOADS + NSTORE : 63;
-  __shared__ __attribute__((aligned(16))) float lds[GSTAGES * (GA + GB)];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-
-  // Persistent workgroups: tile ids first + n * gridDim.x.  The (tile, source, k) step sequence is flat, so the
-  // two-step look-ahead of the loads runs across tile boundaries (the next tile's first stages are in flight during
-  // this tile's last MFMAs and its epilogue stores drain under the next tile's MFMAs).
-  const int64_t total = (int64_t)(EPI == EPI_SLAB ? L.splits : L.tiles_m) * L.total_ntiles;
-  // Everything a step needs from the launch descriptor is copied into the cursor when it enters a tile (plain indexed
-  // loads from the kernel-argument block; references into `L` that vary over the loop make hipcc copy the whole
-  // descriptor to scratch).
-  struct Cursor {
-    int64_t vid;
-    int pi, row0, col0, split;
-    int s, k0, kend;
-    int M, N, nsrc, src0;
-    bool ok;
-  };
-  auto decode = [&](Cursor& c) __attribute__((always_inline)) {
-    c.ok = c.vid < total;
-    if (!c.ok) return;
-    const int outer = (int)(c.vid / L.total_ntiles);
-    int j = (int)(c.vid - (int64_t)outer * L.total_ntiles);
-    int pi = 0;
-    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
-    j -= L.p[pi].tile0;
-    c.pi = pi;
-    c.s = 0;
-    c.M = L.p[pi].M;
-    c.N = L.p[pi].N;
-    c.nsrc = L.p[pi].nsrc;
-    c.src0 = L.p[pi].src0;
-    if (EPI != EPI_SLAB) {
-      c.row0 = outer * BM;
-      c.col0 = j * BN;
-      c.split = 0;
-      c.k0 = 0;
-      c.kend = L.src[c.src0].Kred;
-    } else {
-      const int tn = L.p[pi].tiles_n;
-      c.split = outer;
-      c.row0 = (j / tn) * BM;
-      c.col0 = (j % tn) * BN;
-      c.k0 = outer * L.chunk;
-      const int kr = L.src[c.src0].Kred;
-      c.kend = (c.k0 + L.chunk < kr) ? c.k0 + L.chunk : kr;
-      if (c.k0 >= c.kend) c.kend = c.k0 + GK;  // (cannot happen: S = ceil(M / chunk))
-    }
-  };
-  auto last_step = [&](const Cursor& c) __attribute__((always_inline)) { return c.k0 + GK >= c.kend && (EPI == EPI_SLAB || c.s + 1 >= c.nsrc); };
-  auto advance = [&](Cursor& c) __attribute__((always_inline)) {
-    c.k0 += GK;
-    if (c.k0 < c.kend) return;
-    if (EPI != EPI_SLAB && c.s + 1 < c.nsrc) {
-      ++c.s;
-      c.k0 = 0;
-      c.kend = L.src[c.src0 + c.s].Kred;
-      return;
-    }
-    c.vid += gridDim.x;
-    decode(c);
-  };
-  auto issue = [&](const Cursor& c, const int stage) __attribute__((always_inline)) {
-#ifdef MML_LAB_NO_GLOBAL
-    return;
-#endif
-    const int si = c.src0 + c.s;
-    float* sa = lds + stage * (GA + GB);
-    glds_issue<ARC, BM>(sa, L.src[si].A, L.src[si].lda, c.row0, c.M, c.k0, wave, lane);
-    glds_issue<BRC, BN>(sa + GA, L.src[si].B, L.src[si].ldb, c.col0, c.N, c.k0, wave, lane);
-  };
-
-  f32x16 acc[2][NI];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  };
-  zero_acc();
-  float bsum = 0.f;
-
-  // per-lane LDS byte addresses of this wave's fragments inside a stage (stage / k-group / +32-row offsets are
-  // instruction immediates)
-  const uint32_t lds0 = lds_byte_addr(lds);
-  uint32_t aA0, aA1, aB0, aB1;
-  {
-    const int ra = wm * 64 + l31, rb = wn * (BN / 2) + l31;
-    if (ARC) {
-      aA0 = lds0 + ra * GK * 4 + ((h ^ ((ra >> 2) & 3)) * 16);
-      aA1 = lds0 + ra * GK * 4 + (((2 + h) ^ ((ra >> 2) & 3)) * 16);
-    } else {  // row-contiguous image: aA0 = (k = 4h, row), aA1 = the same 32 rows further (not a 256-B multiple)
-      aA0 = lds0 + (4 * h * BM + ra) * 4;
-      aA1 = aA0 + 32 * 4;
-    }
-    if (BRC) {
-      aB0 = lds0 + rb * GK * 4 + ((h ^ ((rb >> 2) & 3)) * 16);
-      aB1 = lds0 + rb * GK * 4 + (((2 + h) ^ ((rb >> 2) & 3)) * 16);
-    } else {  // per-subtile addresses (ni = 0 / 1), k-group via immediates
-      aB0 = lds0 + (4 * h * BN + rb) * 4;
-      aB1 = aB0 + 32 * 4;
-    }
-  }
-
-  // ---- epilogue of the tile the compute cursor is on ----
-  // The MFMAs take the COLUMN operand as their A input, so a lane owns one output ROW (l31) and its 16 accumulator
-  // registers are four runs of 4 consecutive columns (8g + 4h + 0..3): the tile leaves as 16-byte stores, 16 * NI per
-  // wave (a wave can only have 63 VMEM operations in flight; 64 dword stores per tile would block it until they drain).
-  auto epilogue = [&](const Cursor& c, const bool want_bias) __attribute__((always_inline)) {
-#ifdef MML_LAB_NO_EPI
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
-    const int pi = c.pi;
-    const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
-    if (EPI == EPI_SLAB) {
-      if (want_bias) {
-        float* bs = L.p[pi].bias_slab;
-        if (!L.p[pi].bias_cols) {
-          if (tid < BM && row0 + tid < PM) bs[(int64_t)c.split * PM + row0 + tid] = bsum;
-        } else {
-          if (tid < BN && col0 + tid < PN) bs[(int64_t)c.split * PN + col0 + tid] = bsum;
-        }
-      }
-      float* slab = L.slab + L.p[pi].slab_off + (int64_t)c.split * PM * PN;  // PN % 4 == 0 (glds_ok)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row = row0 + wm * 64 + mi * 32 + l31;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
-            if (row < PM && col < PN)
-              *reinterpret_cast<float4*>(slab + (int64_t)row * PN + col) =
-                  make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
-          }
-      }
-      return;
-    }
-    float* const C = L.p[pi].C;
-    const int64_t ldc = L.p[pi].ldc;
-    const float* const bias = L.p[pi].bias;
-    const float* const Y = L.p[pi].Y;
-    const int64_t ldy = L.p[pi].ldy;
-    const int act = L.p[pi].act, accumulate = L.p[pi].accumulate;
-    const bool vec = L.p[pi].vec_out != 0;  // C (and Y) 16-byte aligned with ld % 4 == 0 and N % 4 == 0
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int row = row0 + wm * 64 + mi * 32 + l31;
-      if (row >= PM) continue;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
-          if (col >= PN) continue;
-          float v[4] = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-          float* dst = C + (int64_t)row * ldc + col;
-          if (vec) {
-            if (EPI == EPI_FWD) {
-              float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (bias) b4 = *reinterpret_cast<const float4*>(bias + col);
-              v[0] = act_fwd(v[0] + b4.x, act); v[1] = act_fwd(v[1] + b4.y, act);
-              v[2] = act_fwd(v[2] + b4.z, act); v[3] = act_fwd(v[3] + b4.w, act);
-            } else {
-              if (act != MML_ACT_NONE) {
-                const float4 y4 = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + col);
-                v[0] *= act_bwd(y4.x, act); v[1] *= act_bwd(y4.y, act);
-                v[2] *= act_bwd(y4.z, act); v[3] *= act_bwd(y4.w, act);
-              }
-              if (accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(dst);
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-              }
-            }
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (col + e >= PN) continue;
-              float x = v[e];
-              if (EPI == EPI_FWD) {
-                x = act_fwd(x + (bias ? bias[col + e] : 0.f), act);
-              } else {
-                if (act != MML_ACT_NONE) x *= act_bwd(Y[(int64_t)row * ldy + col + e], act);
-                if (accumulate) x += dst[e];
-              }
-              dst[e] = x;
-            }
-          }
-        }
-    }
-  };
-
-  Cursor cur;
-  cur.vid = xcd_remap(blockIdx.x, gridDim.x);
-  decode(cur);
-  Cursor pf = cur;  // prefetch cursor, two steps ahead
-  int issued = 0, i = 0;
-  int since_epi = 2;      // steps since an epilogue whose stores may still be in flight (0 / 1: they are)
-  bool epi_counted = false;  // that epilogue issued exactly NSTORE stores per wave (interior tile) and no loads
-  if (pf.ok) { issue(pf, 0); advance(pf); ++issued; }
-  if (pf.ok) { issue(pf, 1); advance(pf); ++issued; }
-
-  // One k-step on a COMPILE-TIME stage index: with static LDS offsets hipcc can tell that the fragment reads of
-  // stage S never alias the in-flight LDS-DMA destination (stage S+2), so it does not drain vmcnt before them.
-  auto step = [&](auto stage_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(stage_c)::value;
-    // My own loads of step i have landed when at most the loads of ONE later step (LOADS instructions) -- plus, for
-    // two steps after an interior tile's epilogue, its NSTORE stores, which were issued after them -- are in flight
-    // (VMEM operations of one wave complete in issue order).
-    if (issued > i + 1) {
-      if (since_epi < 2 && epi_counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_EPI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // everyone's step-i tiles are in LDS; everyone is done reading stage (S+2)%3
-    if (pf.ok) {
-      issue(pf, (S + 2) % GSTAGES);
-      advance(pf);
-      ++issued;
-    }
-    ++since_epi;
-    constexpr int SA = S * (GA + GB) * 4;  // byte offset of this stage's A image
-    constexpr int SB = SA + GA * 4;
-    const bool bias_cols = (EPI == EPI_SLAB) && L.p[cur.pi].bias_cols != 0;
-    const bool want_bias =
-        (EPI == EPI_SLAB) && L.p[cur.pi].bias_slab != nullptr && (bias_cols ? cur.row0 == 0 : cur.col0 == 0);
-    if (want_bias) {
-      if (tid < (bias_cols ? BN : BM)) {  // both operands are [k][rows] images in a wgrad launch
-        const uint32_t ab = lds0 + (bias_cols ? SB : SA) + tid * 4;
-        const int R4 = (bias_cols ? BN : BM) * 4;
-        float sacc = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 8 reads in flight at a time (lgkmcnt is a 4-bit counter)
-          float v[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(v[k]) : "v"(ab + (half * 8 + k) * R4) : "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) sacc += v[k];
-        }
-        bsum += sacc;
-      }
-    }
-    // fragment reads: k-group 0 then k-group 1 (in flight while group 0 multiplies); RC operands take the per-group
-    // address + a sub-tile immediate, row-contiguous ones the per-sub-tile address + a group immediate
-    float4 fa[2][2], fb[2][NI];
-    constexpr int PER_Q = (ARC ? 2 : 4) + (BRC ? NI : 2 * NI);
-    constexpr bool UPFRONT = 2 * PER_Q <= 15;  // lgkmcnt is a 4-bit counter
-    fa[0][0] = glds_frag_asm<ARC, BM, SA, 0, 0>(aA0);
-    fa[0][1] = glds_frag_asm<ARC, BM, SA, 1, 0>(ARC ? aA0 : aA1);
-    fb[0][0] = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0);
-    if (NI == 2) fb[0][NI - 1] = glds_frag_asm<BRC, BN, SB, NI - 1, 0>(BRC ? aB0 : aB1);
-    if (!UPFRONT) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    fa[1][0] = glds_frag_asm<ARC, BM, SA, 0, 1>(ARC ? aA1 : aA0);
-    fa[1][1] = glds_frag_asm<ARC, BM, SA, 1, 1>(aA1);
-    fb[1][0] = glds_frag_asm<BRC, BN, SB, 0, 1>(BRC ? aB1 : aB0);
-    if (NI == 2) fb[1][NI - 1] = glds_frag_asm<BRC, BN, SB, NI - 1, 1>(aB1);
-    if (UPFRONT) {
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_Q) : "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (EMU == 0) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].x, fa[q][mi].x, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].y, fa[q][mi].y, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].z, fa[q][mi].z, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q][ni].w, fa[q][mi].w, acc[mi][ni], 0, 0, 0);
-          }
-      }
-    } else {
-      constexpr int PL = EMU == 0 ? 1 : EMU;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 pb[NI][PL];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) split_planes<PL>(fb[0][ni], fb[1][ni], pb[ni]);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        bf16x8 pa[PL];
-        split_planes<PL>(fa[0][mi], fa[1][mi], pa);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          // smallest products first
-#pragma unroll
-          for (int lvl = PL - 1; lvl >= 0; --lvl)
-#pragma unroll
-            for (int ia = 0; ia <= lvl; ++ia) {
-#ifdef MML_LAB_NO_MFMA
-              acc[mi][ni][(lvl + ia) & 15] += __builtin_bit_cast(float4, pa[ia]).x * __builtin_bit_cast(float4, pb[ni][lvl - ia]).y;
-#else
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pb[ni][lvl - ia], pa[ia], acc[mi][ni], 0, 0, 0);
-#endif
-            }
-        }
-      }
-    }
-    if (last_step(cur)) {  // tile finished: write it out and start the next one on cleared accumulators
-      epilogue(cur, want_bias);
-      // interior fwd / slab tiles issue exactly NSTORE stores per wave and nothing else; any other epilogue (edge
-      // tiles, dgrad's loads of Y / the accumulate target) is followed by plain vmcnt(LOADS) waits, i.e. drains
-      epi_counted = (EPI != EPI_DGRAD) && !want_bias && cur.row0 + BM <= cur.M && cur.col0 + BN <= cur.N &&
-                    (EPI == EPI_SLAB || L.p[cur.pi].vec_out != 0);
-      since_epi = 0;
-      zero_acc();
-      bsum = 0.f;
-    }
-    advance(cur);
-    ++i;
-  };
-  while (true) {
-    if (!cur.ok) break;
-    step(std::integral_constant<int, 0>{});
-    if (!cur.ok) break;
-    step(std::integral_constant<int, 1>{});
-    if (!cur.ok) break;
-    step(std::integral_constant<int, 2>{});
-  }
-}
-
 
 // ====================================================================================================
 // Software-pipelined direct-to-LDS kernel ("pipe"): same tiles, operand images and MFMA map as gemm_glds_kernel,
@@ -1082,8 +581,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
   constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile
   constexpr int NBIAS = (EPI == EPI_FWD) ? 1 : 0;  // the next tile's bias DMA follows the stores
   constexpr int AFTER_EPI = (LOADS + NSTORE + NBIAS < 63) ? LOADS + NSTORE + NBIAS : 63;
-  constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 2 ? 3 : 6);  // MFMAs per block
-  constexpr int NVALU = EMU == 0 ? 0 : (EMU == 2 ? 10 : 8); // VALU slots per MFMA of a block with one prepare
+  constexpr int NMFMA = EMU == 0 ? 8 : 6;  // MFMAs per block
+  constexpr int NVALU = EMU == 0 ? 0 : 8;  // VALU slots per MFMA of a block with one prepare
   __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256];  // + one 64-float bias slot per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1691,7 +1190,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
 }
 
 // host-side eligibility of a whole launch for the direct-to-LDS path
-static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
+static bool pipe_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MMLREC_GEMM_GLDS");
@@ -1714,17 +1213,16 @@ static bool glds_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
 
 static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
 
-// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
-// 1 = staged split-bf16 (gemm_kernel MODE 1: 3 x v_mfma_f32_32x32x16_bf16 per 16 k, ~1e-5 relative)
-// 2 / 3 = direct-to-LDS path with 2 / 3 bf16 planes per operand on every launch
-// 4 = auto (default): fp32-equivalent results (three planes, six products: max-norm error vs float64 equal to the
-//     fp32 MFMA's, tools/bench_gemm.py) on the launches where it is faster, the fp32 MFMA elsewhere
+// 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32) on every launch
+// 3 = three bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per 16-k block) on every LDS-DMA launch
+// 4 = auto (default): the three-plane form where it is faster, the fp32 MFMA elsewhere.  Both give fp32-equivalent
+//     results (max-norm error vs float64 4.7e-7 vs 4.3e-7, tools/bench_gemm.py).
 static int g_gemm_mode = -1;
 static int g_wgrad_pad = -1;  // unused dynamic LDS requested by wgrad launches (caps their residency, see launch_tiles)
 static int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("MMLREC_GEMM_MODE");
-    g_gemm_mode = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 4;
+    g_gemm_mode = (e && (e[0] == '0' || e[0] == '3')) ? e[0] - '0' : 4;
   }
   return g_gemm_mode;
 }
@@ -1749,54 +1247,34 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-  const int mode = gemm_mode() == 1 ? 1 : tc.emu;  // 1 = staged split-bf16 kernel, else the glds plane count (0/2/3)
-  // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  At four
-  // workgroups per CU they would own every VGPR of every SIMD and the optimizer's waves could not co-reside; an
-  // unused dynamic-LDS request caps them at three per CU (3 x 53 KiB), leaving a wave slot and 128 VGPRs per SIMD.
+  const int emu = tc.emu;  // 0 = fp32 MFMA, 3 = three bf16 planes
+  // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  An unused
+  // dynamic-LDS request (mml_gemm_set_wgrad_lds_pad) lowers their residency so that the optimizer's waves co-reside.
   if (g_wgrad_pad < 0) {
     const char* e = getenv("MMLREC_WGRAD_LDS_PAD");
     g_wgrad_pad = e ? atoi(e) : 0;
   }
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
-  if (mode != 1 && glds_ok(L, arc, brc, bn, EPI)) {
-    note_kernel("gemm_glds_kernel", arc, brc, bn, EPI, mode);
-    // persistent workgroups: one per resident slot (4 per CU at <= 128 VGPRs, 2 at <= 256), each loops over tiles
+  if (pipe_ok(L, arc, brc, bn, EPI)) {
+    note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, emu);
+    // persistent workgroups: one per resident slot (128 x 128 tiles: 2 per CU; 128 x 64: 3), each loops over tiles
     static int cus = 0;
     if (cus == 0) {
       int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
       cus = n;
     }
-    const int64_t slots = (int64_t)cus * (dyn ? (bn == 64 ? 3 : 2) : (bn == 64 ? 4 : 2));
+    const int64_t slots = (int64_t)cus * (bn == 64 ? 3 : 2);
     if (nblocks > slots) g = dim3((unsigned)slots);
-    static int use_pipe = -1;
-    if (use_pipe < 0) {
-      const char* e = getenv("MMLREC_GEMM_PIPE");
-      use_pipe = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (use_pipe) note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, mode);
-    if (use_pipe && bn == 64) {
-      const int64_t s3 = (int64_t)cus * 3;  // the pipelined 128 x 64 kernel keeps three workgroups per CU
-      g = dim3((unsigned)(nblocks > s3 ? s3 : nblocks));
-    }
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
-#ifdef MML_LAB_GLDS
-#define MML_GL(A_, B_) MML_LAUNCH((gemm_glds_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
-#else
 #define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
-#endif
 #else
-#define MML_GL2(A_, B_, N_)                                                                     \
-  do {                                                                                          \
-    if (use_pipe) {                                                                             \
-      if (mode == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
-      else if (mode == 2) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
-      else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
-    } else {                                                                                    \
-      if (mode == 0) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);      \
-      else if (mode == 2) MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 2>), g, b, dyn, st, L); \
-      else MML_LAUNCH((gemm_glds_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);                \
-    }                                                                                           \
+#define MML_GL2(A_, B_, N_)                                                              \
+  do {                                                                                   \
+    if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);  \
+    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);           \
   } while (0)
 #define MML_GL(A_, B_)                  \
   do {                                  \
@@ -1817,12 +1295,10 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   set_error("%s: lab build has only the direct-to-LDS kernel", who);
   return MML_ERR_UNSUPPORTED;
 #else
-  note_kernel("gemm_kernel", arc, brc, bn, EPI, mode == 1 ? 1 : 0);
-#define MML_GO(A_, B_, N_)                                                        \
-  do {                                                                            \
-    if (mode != 1) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L); \
-    else MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI, 1>), g, b, dyn, st, L);           \
-  } while (0)
+  // shapes the LDS-DMA path cannot take (reduction extents not a multiple of 16, unaligned operands): register-staged
+  // fp32 MFMA kernel
+  note_kernel("gemm_kernel", arc, brc, bn, EPI, 0);
+#define MML_GO(A_, B_, N_) MML_LAUNCH((gemm_kernel<A_, B_, N_, EPI>), g, b, dyn, st, L)
   if (arc && brc) { if (bn == 128) MML_GO(true, true, 128); else MML_GO(true, true, 64); }
   else if (arc && !brc) { if (bn == 128) MML_GO(true, false, 128); else MML_GO(true, false, 64); }
   else if (!arc && !brc) { if (bn == 128) MML_GO(false, false, 128); else MML_GO(false, false, 64); }
@@ -1836,11 +1312,12 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
 }
 
 // Tile width and arithmetic of one grouped launch.  kind: 0 fwd, 1 dgrad, 2 wgrad; kred = longest reduction extent.
-// Measured on MI355X at M = 65536 (tools/bench_gemm.py, us, fp32 MFMA 128x64 | 128x128  vs  3-plane 128x64 | 128x128):
-//   L1 4x(240->256)+2x(240->64): fwd 376|465 vs 409|342, wgrad 519|437 vs 450|308, dgrad 388|416 vs 402|300
-//   L2 4x(256->128):             fwd 183|203 vs 163|153, wgrad 225|214 vs 182|164, dgrad 303|437 vs 356|399
-//   towers 2x(128->64):          fwd  34| 65 vs  32| 50, wgrad  82| 74 vs  72| 62, dgrad  42| 51 vs  40| 44
-// 128x128 tiles run two workgroups per CU (<= 256 VGPRs), 128x64 four (<= 128 VGPRs).
+// Measured on MI355X at M = 65536 with gemm_pipe_kernel (tools/gsweep.sh, us):
+//                                  fp32 MFMA 128x64 | 128x128     three planes 128x64 | 128x128
+//   L1 4x(240->256)+2x(240->64)  fwd 346|345 wgrad 618|400 dgrad 384|330     fwd 295|262 wgrad 488|286 dgrad 304|241
+//   L2 4x(256->128)              fwd 179|152 wgrad 267|201 dgrad 228|234     fwd 145|113 wgrad 209|154 dgrad 202|197
+//   towers 2x(128->64)           fwd  40| 46 wgrad  93| 70 dgrad  44| 34     fwd  32| 36 wgrad  75| 59 dgrad  34| 27
+// 128x128 tiles run two workgroups per CU (<= 256 VGPRs), 128x64 three.
 static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, int64_t row_tiles) {
   static int force = -1;
   if (force < 0) {
@@ -1852,24 +1329,17 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
 #ifdef MML_LAB
   return TileChoice{MML_LAB_BN, MML_LAB_EMU};
 #endif
-  if (mode == 1) {  // staged kernel: the old rule
-    tc.bn = 128;
-    for (int i = 0; i < n; ++i)
-      if (Ns[i] % 128 != 0 || Ns[i] < 1024) tc.bn = 64;
-    if (force == 64 || force == 128) tc.bn = force;
-    return tc;
-  }
   int64_t pad64 = 0, pad128 = 0;
   for (int i = 0; i < n; ++i) {
     pad64 += cdiv(Ns[i], 64) * 64;
     pad128 += cdiv(Ns[i], 128) * 128;
   }
-  tc.bn = (pad128 * 100 <= pad64 * 115) ? 128 : 64;  // wide tiles unless > 15 % of their columns would be padding
+  tc.bn = (pad128 * 100 <= pad64 * 150) ? 128 : 64;  // wide tiles unless > 1/3 of their columns would be padding
   if (row_tiles * (pad128 / 128) < 1024) tc.bn = 64;  // ... or they would not fill the 512 resident slots twice
-  if (kind == 1 && kred <= 128) tc.bn = 64;           // short reductions with a heavy epilogue want occupancy
   if (force == 64 || force == 128) tc.bn = force;
-  if (mode == 0 || mode == 2 || mode == 3) tc.emu = mode;
-  else tc.emu = (tc.bn == 128 || kind != 1) ? 3 : 0;
+  tc.emu = (mode == 0) ? 0 : 3;
+  (void)kind;
+  (void)kred;
   return tc;
 }
 
@@ -1878,8 +1348,8 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
 using namespace mml;
 
 extern "C" int mml_gemm_set_mode(int32_t mode) {
-  MML_REQUIRE(mode >= 0 && mode <= 4, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (staged split-bf16), 2 or 3 "
-              "(fp32 emulated from 2 / 3 bf16 planes on the direct-to-LDS path) or 4 (auto, fp32-equivalent)");
+  MML_REQUIRE(mode == 0 || mode == 3 || mode == 4, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 3 (fp32 emulated "
+              "from three bf16 planes on every LDS-DMA launch) or 4 (auto)");
   g_gemm_mode = mode;
   return MML_OK;
 }
