@@ -68,6 +68,7 @@ def build_library(force=False, verbose=True, jobs=None):
                 # the pipelined GEMM counts its own VMEM operations (s_waitcnt vmcnt(N)): a register spill would add
                 # scratch traffic to that count and silently break the waits -> check the resource report
                 cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
+                cmd.insert(-4, "-save-temps=obj")  # keeps the device assembly next to the object (checked below)
                 stderr = open(obj + ".log", "w")
             if verbose:
                 print("[mmlrec build]", " ".join(cmd), flush=True)
@@ -80,6 +81,7 @@ def build_library(force=False, verbose=True, jobs=None):
                 sys.stderr.write("".join(l for l in open(log) if "remark:" not in l)[-4000:])
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     check_no_scratch(os.path.join(objdir, "gemm.o.log"))
+    check_async_lds(objdir)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
     if verbose:
         print("[mmlrec build]", " ".join(cmd), flush=True)
@@ -100,6 +102,19 @@ def check_no_scratch(log):
                 bad.append(name)
     if bad:
         raise RuntimeError("register spills in the pipelined GEMM (counted vmcnt waits would break): " + ", ".join(bad))
+
+
+def check_async_lds(objdir):
+    """No register written by an asm ds_read may be read before the hand-placed lgkmcnt wait (tools/check_async_lds.py)."""
+    asm = [f for f in glob.glob(os.path.join(objdir, "gemm*gfx950*.s"))]
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_async_lds.py")
+    if not asm or not os.path.exists(tool):
+        return
+    r = subprocess.run([sys.executable, tool, asm[0]], capture_output=True, text=True)
+    for f in glob.glob(os.path.join(objdir, "gemm-*")) + glob.glob(os.path.join(objdir, "gemm.hip-*")):
+        os.remove(f)  # -save-temps leftovers (tens of MB that would travel with every snapshot)
+    if r.returncode != 0:
+        raise RuntimeError("pipelined GEMM reads an LDS-loaded register before its wait:\n" + r.stdout[-2000:])
 
 
 if __name__ == "__main__":

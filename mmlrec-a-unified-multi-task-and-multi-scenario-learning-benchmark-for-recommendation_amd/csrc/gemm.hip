@@ -352,70 +352,89 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
 constexpr int GK = 16;
 constexpr int GA = 128 * GK;  // floats per A stage
 
-// LDS fragment reads as inline asm: hipcc treats an LDS-DMA in flight as a pending LDS store and would put
-// s_waitcnt vmcnt(0) in front of every C++-level ds_read (draining the two-step prefetch); asm reads are invisible to
-// that pass, so the counted vmcnt(N) of the kernel is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand and
-// followed by sched_barrier(0) so that no MFMA is hoisted above them (cdna guide, methodology rule 18).
+// LDS accesses as inline asm: hipcc treats an LDS-DMA in flight as a pending LDS store and would put
+// s_waitcnt vmcnt(0) in front of every C++-level ds_read (draining the prefetch); asm accesses are invisible to that
+// pass, so the counted vmcnt(N) of the kernel is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand.
+//
+// The price: to the compiler an asm ds_read has produced its value at once, so it feels free to COPY the destination
+// register before the data has landed (it did, to form register pairs for v_pk_add_f32).  Rule used throughout: a
+// value read this way is kept in a native vector type exactly as the instruction wrote it, is not touched until the
+// wait, and is passed through lds_landed() right after the wait; every real use hangs off lds_landed()'s output.
 typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t lds_byte_addr(const float* p) {
   return (uint32_t)(uintptr_t)(const lds_f32_t*)p;
 }
 template <int OFF>
-__device__ __forceinline__ float4 ds_read128(uint32_t addr) {
-  float4 v;
+__device__ __forceinline__ f32x4_t ds_read128(uint32_t addr) {
+  f32x4_t v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
-__device__ __forceinline__ void ds_write128(uint32_t addr, const float4& v) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(t) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ float ds_read32(uint32_t addr) {
-  float v;
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
+__device__ __forceinline__ void ds_write128(uint32_t addr, const f32x4_t& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 template <int U0, int U1>
-__device__ __forceinline__ float2 ds_read2st64(uint32_t addr) {  // two dwords at addr + U0*256 B and addr + U1*256 B
-  float2 v;
+__device__ __forceinline__ f32x2_t ds_read2st64(uint32_t addr) {  // two dwords at addr + U0*256 B and addr + U1*256 B
+  f32x2_t v;
   asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(U0), "n"(U1) : "memory");
   return v;
 }
-// fragment (4 k-values) of one tile-local row, k-group Q, from the stage at byte offset SOFF (a multiple of 256).
-//   RC : `a` = byte address of (row, phys chunk of group Q) -- the caller picks the per-group address; +32 rows is an
-//        immediate (+2048 B);
-//   NRC: `a` = byte address of (k = 4h, row [+32 rows]); consecutive k are ROWS*4 B apart = 1 or 2 units of 256 B, so a
-//        fragment is two ds_read2st64_b32.
-template <bool RC, int ROWS, int SOFF, int MI, int Q>
-__device__ __forceinline__ float4 glds_frag_asm(uint32_t a) {
-  if (RC) {
-    return ds_read128<SOFF + MI * 32 * GK * 4>(a);
-  } else {
-    constexpr int SU = ROWS * 4 / 256;
-    constexpr int U = (SOFF + 8 * Q * ROWS * 4) / 256;
-    const float2 lo = ds_read2st64<U, U + SU>(a), hi = ds_read2st64<U + 2 * SU, U + 3 * SU>(a);
-    return make_float4(lo.x, lo.y, hi.x, hi.y);
+__device__ __forceinline__ void lds_landed(f32x4_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void lds_landed(f32x2_t& v) { asm volatile("" : "+v"(v)); }
+
+// The lane's 8 k-values of one 32-row sub-tile for one k-step, as the LDS reads deliver them:
+//   reduction-contiguous image: two ds_read_b128 (k-groups 0 and 1);
+//   row-contiguous image      : four ds_read2st64_b32 (consecutive k are ROWS*4 B apart = 1 or 2 units of 256 B).
+template <bool RC>
+struct RawFrag {
+  f32x4_t q0, q1;
+  __device__ __forceinline__ void landed() { lds_landed(q0); lds_landed(q1); }
+  __device__ __forceinline__ void get(float (&x)[8]) const {
+    x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w;
   }
+};
+template <>
+struct RawFrag<false> {
+  f32x2_t p0, p1, p2, p3;
+  __device__ __forceinline__ void landed() { lds_landed(p0); lds_landed(p1); lds_landed(p2); lds_landed(p3); }
+  __device__ __forceinline__ void get(float (&x)[8]) const {
+    x[0] = p0.x; x[1] = p0.y; x[2] = p1.x; x[3] = p1.y; x[4] = p2.x; x[5] = p2.y; x[6] = p3.x; x[7] = p3.y;
+  }
+};
+// RC : a0 / a1 = byte address of (row, phys chunk of k-group 0 / 1); OFF = stage / +32-row immediate
+// NRC: a = byte address of (k = 4h, row); U = 256-B unit offset of the stage (+ sub-tile handled by the caller's address)
+template <int OFF>
+__device__ __forceinline__ void read_frag_rc(uint32_t a0, uint32_t a1, RawFrag<true>& r) {
+  r.q0 = ds_read128<OFF>(a0);
+  r.q1 = ds_read128<OFF>(a1);
+}
+template <int ROWS, int SOFF>
+__device__ __forceinline__ void read_frag_nrc(uint32_t a, RawFrag<false>& r) {
+  constexpr int SU = ROWS * 4 / 256;
+  constexpr int U0 = SOFF / 256, U1 = (SOFF + 8 * ROWS * 4) / 256;
+  r.p0 = ds_read2st64<U0, U0 + SU>(a);
+  r.p1 = ds_read2st64<U0 + 2 * SU, U0 + 3 * SU>(a);
+  r.p2 = ds_read2st64<U1, U1 + SU>(a);
+  r.p3 = ds_read2st64<U1 + 2 * SU, U1 + 3 * SU>(a);
 }
 
 // fp32 value -> PL bf16 planes by mantissa slicing (h = top 8 significant bits, m = the next 8, l = the last 8; every
 // subtraction is exact, so h + m + l == x bit for bit when PL == 3).  Eight k-values of one operand row per lane,
 // packed as the 32x32x16 bf16 MFMA wants them.
 template <int PL>
-__device__ __forceinline__ void split_planes(const float4& v0, const float4& v1, bf16x8 (&out)[PL]) {
+__device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&out)[PL]) {
 #ifdef MML_LAB_NO_CONVERT
   {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 t0 = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w)};
-    u4 t1 = {__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w)};
+    u4 t0 = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    u4 t1 = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
 #pragma unroll
     for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
     return;
   }
 #endif
-  const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
   uint32_t w[PL][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -478,25 +497,23 @@ __device__ __forceinline__ void dma4(const float* g, float* lds_dst) {
   __builtin_amdgcn_global_load_lds(g, lds_dst, 4, 0, 0);
 }
 
-struct RawFrag {
-  float4 q0, q1;  // k-group 0 and 1 of one 32-row sub-tile: the lane's 8 k-values of this step
-};
 template <int EMU>
 struct Prep {
   bf16x8 p[EMU == 0 ? 1 : EMU];
 };
 template <>
 struct Prep<0> {
-  float4 q0, q1;
+  float x[8];
 };
 
-template <int EMU>
-__device__ __forceinline__ void prep_frag(const RawFrag& r, Prep<EMU>& o) {
+template <int EMU, bool RC>
+__device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o) {
   if constexpr (EMU == 0) {
-    o.q0 = r.q0;
-    o.q1 = r.q1;
+    r.get(o.x);
   } else {
-    split_planes<EMU>(r.q0, r.q1, o.p);
+    float x[8];
+    r.get(x);
+    split_planes<EMU>(x, o.p);
   }
 }
 
@@ -504,14 +521,8 @@ __device__ __forceinline__ void prep_frag(const RawFrag& r, Prep<EMU>& o) {
 template <int EMU>
 __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const Prep<EMU>& b) {
   if constexpr (EMU == 0) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.x, a.q0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.y, a.q0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.z, a.q0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q0.w, a.q0.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.x, a.q1.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.y, a.q1.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.z, a.q1.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.q1.w, a.q1.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x[k], a.x[k], acc, 0, 0, 0);
   } else {
 #pragma unroll
     for (int lvl = EMU - 1; lvl >= 0; --lvl)  // smallest products first
@@ -531,8 +542,8 @@ __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const
 template <int EMU>
 __device__ __forceinline__ void pin_prep(Prep<EMU>& o) {
   if constexpr (EMU == 0) {
-    asm volatile("" : "+v"(o.q0.x), "+v"(o.q0.y), "+v"(o.q0.z), "+v"(o.q0.w));
-    asm volatile("" : "+v"(o.q1.x), "+v"(o.q1.y), "+v"(o.q1.z), "+v"(o.q1.w));
+    asm volatile("" : "+v"(o.x[0]), "+v"(o.x[1]), "+v"(o.x[2]), "+v"(o.x[3]));
+    asm volatile("" : "+v"(o.x[4]), "+v"(o.x[5]), "+v"(o.x[6]), "+v"(o.x[7]));
   } else {
 #pragma unroll
     for (int p = 0; p < EMU; ++p) asm volatile("" : "+v"(o.p[p]));
@@ -738,7 +749,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   };
   zero_acc();
-  float bsum = 0.f;
+  // wgrad bias partials: batch sums of the row (or, for [K,N] weights, the column) operand, taken from the raw
+  // fragments as they pass through the registers (16 adds per step) instead of re-reading the LDS image
+  float bs_cur[2] = {0.f, 0.f}, bs_next[2] = {0.f, 0.f};
+  auto sum8 = [](const auto& r) __attribute__((always_inline)) {
+    float x[8];
+    r.get(x);
+    return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+  };
 
   const uint32_t lds0 = lds_byte_addr(lds);
   uint32_t aA0, aA1, aB0, aB1;
@@ -767,10 +785,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
     if (c.want_bias) {
       float* bs = L.p[pi].bias_slab;
-      if (!c.bias_cols) {
-        if (tid < BM && row0 + tid < PM) bs[(int64_t)c.split * PM + row0 + tid] = bsum;
-      } else {
-        if (tid < BN && col0 + tid < PN) bs[(int64_t)c.split * PN + col0 + tid] = bsum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // lanes l and l + 32 hold the two k-halves of one row's sum
+        float v = bs_cur[t];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+        if (!c.bias_cols) {
+          const int row = row0 + wm * 64 + t * 32 + l31;
+          if (wn == 0 && h == 0 && row < PM) bs[(int64_t)c.split * PM + row] = v;
+        } else if (t < NI) {
+          const int col = col0 + wn * (BN / 2) + t * 32 + l31;
+          if (wm == 0 && h == 0 && col < PN) bs[(int64_t)c.split * PN + col] = v;
+        }
       }
     }
     float* slab = L.slab + L.p[pi].slab_off + (int64_t)c.split * PM * PN;
@@ -803,7 +829,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       // 128 x 64 tiles: a stage is 12 KiB, too small for four 4-KiB transposition areas -> per-lane 16-byte accesses
       // (lane = row), all loads of a 32-row half before its stores
       if (EPI == EPI_FWD && c.short_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      float4 b4[NI][4];
+      f32x4_t b4[NI][4];
       if (EPI == EPI_FWD && bias) {
         const uint32_t ab = lds_byte_addr(lds_bias) + 16 * h;
 #pragma unroll
@@ -811,6 +837,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
 #pragma unroll
           for (int g = 0; g < 4; ++g) b4[ni][g] = ds_read128<0>(ab + (ni * 32 + 8 * g) * 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) lds_landed(b4[ni][g]);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -863,55 +893,66 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       const uint32_t tb = lds0 + so_epi + wave * 4096;
       const int R = lane >> 3, cc = lane & 7;
       if (EPI == EPI_FWD && c.short_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias DMA landed?
+      float4 y4[4];  // dgrad: Y values of the sub-tile being written (row-major, like the stores)
+      auto load_y = [&](const int sidx, float4 (&y)[4]) __attribute__((always_inline)) {
+        const int mi = sidx / NI, ni = sidx % NI;
+        const int colg = col0 + wn * (BN / 2) + ni * 32 + 4 * cc;
+        const int rowb = row0 + wm * 64 + mi * 32 + R;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int p = 0; p < 4; ++p) {
+          const bool ok = rowb + 8 * p < PM && colg < PN;
+          y[p] = ok ? *reinterpret_cast<const float4*>(Y + (int64_t)(rowb + 8 * p) * ldy + colg) : make_float4(0, 0, 0, 0);
+        }
+      };
+      constexpr bool USE_Y = (EPI == EPI_DGRAD) && (ACT != MML_ACT_NONE);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
+      for (int sidx = 0; sidx < 2 * NI; ++sidx) {
+        const int mi = sidx / NI, ni = sidx % NI;
+        {
+          if (USE_Y) load_y(sidx, y4);  // in flight during the LDS round trip
           const int colg = col0 + wn * (BN / 2) + ni * 32 + 4 * cc;  // this lane's 4 columns
           const int rowb = row0 + wm * 64 + mi * 32 + R;             // ... of rows rowb + 8p
-          float4 y4[4];
-          if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {  // in flight during the LDS round trip
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              const bool ok = rowb + 8 * p < PM && colg < PN;
-              y4[p] = ok ? *reinterpret_cast<const float4*>(Y + (int64_t)(rowb + 8 * p) * ldy + colg) : make_float4(0, 0, 0, 0);
-            }
-          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+            const f32x4_t v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
             ds_write128(tb + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) * 16), v);
           }
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
           if (EPI == EPI_FWD && bias) b4 = ds_read128<0>(lds_byte_addr(lds_bias) + (ni * 32 + 4 * cc) * 4);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (EPI == EPI_FWD && bias) lds_landed(b4);
           __builtin_amdgcn_sched_barrier(0);
-          float4 v[4];
+          f32x4_t v[4];
 #pragma unroll
           for (int p = 0; p < 4; ++p) v[p] = ds_read128<0>(tb + (R + 8 * p) * 128 + ((cc ^ ((R + 8 * p) & 7)) * 16));
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int p = 0; p < 4; ++p) lds_landed(v[p]);
           __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            f32x4_t& x = v[p];
+            if (EPI == EPI_FWD) {
+              x.x = act_fwd_t<ACT>(x.x + b4.x); x.y = act_fwd_t<ACT>(x.y + b4.y);
+              x.z = act_fwd_t<ACT>(x.z + b4.z); x.w = act_fwd_t<ACT>(x.w + b4.w);
+            } else if (ACT != MML_ACT_NONE) {
+              x.x *= act_bwd_t<ACT>(y4[p].x); x.y *= act_bwd_t<ACT>(y4[p].y);
+              x.z *= act_bwd_t<ACT>(y4[p].z); x.w *= act_bwd_t<ACT>(y4[p].w);
+            }
+          }
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             const int row = rowb + 8 * p;
             if (row >= PM || colg >= PN) continue;
-            float4 x = v[p];
-            if (EPI == EPI_FWD) {
-              x.x = act_fwd_t<ACT>(x.x + b4.x); x.y = act_fwd_t<ACT>(x.y + b4.y);
-              x.z = act_fwd_t<ACT>(x.z + b4.z); x.w = act_fwd_t<ACT>(x.w + b4.w);
-            } else {
-              if (ACT != MML_ACT_NONE) {
-                x.x *= act_bwd_t<ACT>(y4[p].x); x.y *= act_bwd_t<ACT>(y4[p].y);
-                x.z *= act_bwd_t<ACT>(y4[p].z); x.w *= act_bwd_t<ACT>(y4[p].w);
-              }
-              if (accumulate) {  // (rare: outputs summed over more than MML_MAX_SRC sources)
-                const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
-                x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
-              }
+            float4 x = make_float4(v[p].x, v[p].y, v[p].z, v[p].w);
+            if (EPI == EPI_DGRAD && accumulate) {  // (rare: outputs summed over more than MML_MAX_SRC sources)
+              const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
+              x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
             }
             *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;
           }
         }
+      }
     } else {  // unaligned / odd-width outputs: element-wise
 #pragma unroll  // (full unroll: run-time indices would put the accumulators in scratch)
       for (int mi = 0; mi < 2; ++mi) {
@@ -953,33 +994,24 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
 
   // ---- fragment reads of one stage: the stage's byte offset is a run-time VGPR add (the reads are inline asm, so the
   // compiler's waitcnt pass never sees them next to the in-flight LDS-DMA) ----
-  auto read_a = [&](const uint32_t so, auto mic, RawFrag& r) __attribute__((always_inline)) {
+  auto read_a = [&](const uint32_t so, auto mic, RawFrag<ARC>& r) __attribute__((always_inline)) {
     constexpr int MI = decltype(mic)::value;
-    if (MI == 0) {
-      r.q0 = glds_frag_asm<ARC, BM, 0, 0, 0>(aA0 + so);
-      r.q1 = glds_frag_asm<ARC, BM, 0, 0, 1>((ARC ? aA1 : aA0) + so);
-    } else {
-      r.q0 = glds_frag_asm<ARC, BM, 0, 1, 0>((ARC ? aA0 : aA1) + so);
-      r.q1 = glds_frag_asm<ARC, BM, 0, 1, 1>(aA1 + so);
-    }
+    if constexpr (ARC) read_frag_rc<MI * 32 * GK * 4>(aA0 + so, aA1 + so, r);
+    else read_frag_nrc<BM, 0>((MI == 0 ? aA0 : aA1) + so, r);
   };
-  auto read_b = [&](const uint32_t so, auto nic, RawFrag& r) __attribute__((always_inline)) {
+  auto read_b = [&](const uint32_t so, auto nic, RawFrag<BRC>& r) __attribute__((always_inline)) {
     constexpr int NIX = decltype(nic)::value;
     constexpr int SB = GA * 4;
-    if (NIX == 0) {
-      r.q0 = glds_frag_asm<BRC, BN, SB, 0, 0>(aB0 + so);
-      r.q1 = glds_frag_asm<BRC, BN, SB, 0, 1>((BRC ? aB1 : aB0) + so);
-    } else {
-      r.q0 = glds_frag_asm<BRC, BN, SB, 1, 0>((BRC ? aB0 : aB1) + so);
-      r.q1 = glds_frag_asm<BRC, BN, SB, 1, 1>(aB1 + so);
-    }
+    if constexpr (BRC) read_frag_rc<SB + NIX * 32 * GK * 4>(aB0 + so, aB1 + so, r);
+    else read_frag_nrc<BN, SB>((NIX == 0 ? aB0 : aB1) + so, r);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
   // ---- pipeline state: two register sets, indexed by step parity (the loop body is two steps) ----
   Prep<EMU> PA0[2], PB0[2];
-  RawFrag RA1[2], RB1[2];
+  RawFrag<ARC> RA1[2];
+  RawFrag<BRC> RB1[2];
 
   Cursor cur;
   cur.vid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1001,13 +1033,27 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   {
-    RawFrag a0, b0;
+    RawFrag<ARC> a0;
+    RawFrag<BRC> b0;
     read_a(0u, I0{}, a0);
     read_a(0u, I1{}, RA1[0]);
     read_b(0u, I0{}, b0);
     if (NI == 2) read_b(0u, I1{}, RB1[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    a0.landed();
+    RA1[0].landed();
+    b0.landed();
+    if (NI == 2) RB1[0].landed();
     __builtin_amdgcn_sched_barrier(0);
+    if (EPI == EPI_SLAB) {
+      if (!cur.bias_cols) {
+        bs_cur[0] = sum8(a0);
+        bs_cur[1] = sum8(RA1[0]);
+      } else {
+        bs_cur[0] = sum8(b0);
+        if (NI == 2) bs_cur[1] = sum8(RB1[0]);
+      }
+    }
     prep_frag<EMU>(a0, PA0[0]);
     prep_frag<EMU>(b0, PB0[0]);
   }
@@ -1049,28 +1095,9 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
 #endif
       ++issued;
     }
-    const bool bias_cols = cur.bias_cols;
-    if (EPI == EPI_SLAB && cur.want_bias) {
-      if (tid < (bias_cols ? BN : BM)) {
-        const uint32_t ab = lds0 + so_cur + (bias_cols ? GA * 4 : 0) + tid * 4;
-        const int R4 = (bias_cols ? BN : BM) * 4;
-        float sacc = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float v[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(v[k]) : "v"(ab + (half * 8 + k) * R4) : "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) sacc += v[k];
-        }
-        bsum += sacc;
-      }
-    }
     // next step's fragments -> the other register set (in flight during blocks 1-2)
-    RawFrag na0, nb0;
+    RawFrag<ARC> na0;
+    RawFrag<BRC> nb0;
     LAB_T(t2);
     read_b(so_next, I0{}, nb0);
     read_a(so_next, I0{}, na0);
@@ -1091,11 +1118,24 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       interleave_hint<NMFMA, NVALU>();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      nb0.landed();
+      na0.landed();
+      RA1[Q].landed();
+      RB1[Q].landed();
       __builtin_amdgcn_sched_barrier(0);
 #ifdef MML_LAB_TIMES
       t3 = __builtin_readcyclecounter();
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      if (EPI == EPI_SLAB) {  // (the bias operand of the NEXT step's tile: fixed per launch group in practice)
+        if (!cur.bias_cols) {
+          bs_next[0] = sum8(na0);
+          bs_next[1] = sum8(RA1[Q]);
+        } else {
+          bs_next[0] = sum8(nb0);
+          bs_next[1] = sum8(RB1[Q]);
+        }
+      }
       prep_frag<EMU>(nb0, PB0[Q]);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
       pin_prep<EMU>(PB0[Q]);
@@ -1112,7 +1152,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       interleave_hint<NMFMA, NVALU>();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      nb0.landed();
+      na0.landed();
+      RA1[Q].landed();
       __builtin_amdgcn_sched_barrier(0);
+      if (EPI == EPI_SLAB) {
+        if (!cur.bias_cols) {
+          bs_next[0] = sum8(na0);
+          bs_next[1] = sum8(RA1[Q]);
+        } else {
+          bs_next[0] = sum8(nb0);
+        }
+      }
       prep_frag<EMU>(nb0, PB0[Q]);
       prep_frag<EMU>(na0, PA0[Q]);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
@@ -1146,7 +1197,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       epi_left = cur.counted ? 2 : 0;
       if (!cur.counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       zero_acc();
-      bsum = 0.f;
+      bs_cur[0] = 0.f;
+      bs_cur[1] = 0.f;
 #ifdef MML_LAB_TIMES
       __builtin_amdgcn_sched_barrier(0);
       unsigned long long te3 = __builtin_readcyclecounter();
@@ -1159,6 +1211,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     unsigned long long ta0 = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    if (EPI == EPI_SLAB) {  // the fragments read in this step belong to the next one
+      bs_cur[0] += bs_next[0];
+      bs_cur[1] += bs_next[1];
+    }
     advance(cur);
     if (__builtin_expect(tile_end, 0)) bias_dma(cur);
 #ifdef MML_LAB_TIMES
@@ -1282,9 +1338,15 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     else MML_GL2(A_, B_, 128);          \
   } while (0)
 #endif
-    if (arc && brc) MML_GL(true, true);
-    else if (arc && !brc) MML_GL(true, false);
-    else MML_GL(false, false);
+    // (weight-gradient launches are always row-contiguous on both operands, the others reduction-contiguous on A)
+    if constexpr (EPI == EPI_SLAB) {
+      if (!arc && !brc) MML_GL(false, false);
+      else { set_error("%s: unsupported operand layout", who); return MML_ERR_UNSUPPORTED; }
+    } else {
+      if (arc && brc) MML_GL(true, true);
+      else if (arc && !brc) MML_GL(true, false);
+      else { set_error("%s: unsupported operand layout", who); return MML_ERR_UNSUPPORTED; }
+    }
 #undef MML_GL
 #ifndef MML_LAB
 #undef MML_GL2
