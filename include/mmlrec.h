@@ -174,6 +174,12 @@ typedef struct {
 int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_desc* descs, int32_t n);
 int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* descs, int32_t n, void* workspace, int64_t workspace_bytes,
                            mml_stream_t stream);
+/* The same in two launches: phase 1 writes the per-chunk partial products to the workspace, phase 2 reduces them into
+ * dW / dbias (phase 0 = both, as mml_gemm_grouped_wgrad).  A trainer that runs several weight-gradient GEMMs next to
+ * an HBM-bound kernel issues all partials first and the (small, bandwidth-hungry) reductions last; each call then
+ * needs its own workspace. */
+int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* descs, int32_t n, void* workspace,
+                                 int64_t workspace_bytes, int32_t phase, mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  gate: skinny linear [Gd -> ne] (no bias) + softmax over experts + expert mix.

@@ -86,6 +86,7 @@ _SIGS = {
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_gemm_grouped_wgrad_workspace_bytes": (i64, [_PP(GemmWgradDesc), i32]),
     "mml_gemm_grouped_wgrad": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, fp]),
+    "mml_gemm_grouped_wgrad_phase": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, i32, fp]),
     "mml_gate_mix_fwd": (C.c_int, [_PP(GateGroup), fp]),
     "mml_gate_mix_bwd_workspace_bytes": (i64, [_PP(GateGroup)]),
     "mml_gate_mix_bwd": (C.c_int, [_PP(GateGroup), fp, i64, fp]),

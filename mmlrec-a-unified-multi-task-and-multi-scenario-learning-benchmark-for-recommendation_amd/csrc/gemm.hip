@@ -1568,7 +1568,7 @@ WgradPlan plan_wgrad(const mml_gemm_wgrad_desc* d, int i, int j) {
   }
   w.total_tiles = tiles;
   const int64_t M = d[i].M;
-  int64_t S = tiles > 0 ? 1024 / tiles : 1;  // ~4 tiles per CU
+  int64_t S = tiles > 0 ? (w.bn == 128 ? 512 : 768) / tiles : 1;  // one batch chunk per resident (persistent) workgroup
   const int64_t maxS = cdiv(M, 8 * BK);      // at least 256 batch rows per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -1591,30 +1591,33 @@ extern "C" int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_d
     int j = i;
     while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
     WgradPlan w = plan_wgrad(d, i, j);
-    if (w.slab_floats * 4 > best) best = w.slab_floats * 4;
+    best += ((w.slab_floats * 4 + 255) / 256) * 256;  // groups are laid out one after another (phased launches)
     i = j;
   }
   return best + 256;
 }
 
-extern "C" int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace,
-                                      int64_t workspace_bytes, mml_stream_t stream) {
+extern "C" int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace,
+                                            int64_t workspace_bytes, int32_t phase, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_wgrad: bad descriptor array");
+  MML_REQUIRE(phase >= 0 && phase <= 2, "mml_gemm_grouped_wgrad_phase: phase must be 0 (both), 1 (partials) or 2 (reduce)");
   if (n == 0) return MML_OK;
   MML_REQUIRE(workspace && aligned16(workspace), "mml_gemm_grouped_wgrad: workspace null or misaligned");
   int i = 0;
+  int64_t ws_off = 0;  // bytes: every group of problems owns its own piece of the workspace
   while (i < n) {
     int j = i;
     while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
     WgradPlan w = plan_wgrad(d, i, j);
-    MML_REQUIRE(w.slab_floats * 4 <= workspace_bytes, "mml_gemm_grouped_wgrad: workspace %lld < %lld bytes",
-                (long long)workspace_bytes, (long long)(w.slab_floats * 4));
+    MML_REQUIRE(ws_off + w.slab_floats * 4 <= workspace_bytes, "mml_gemm_grouped_wgrad: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)(ws_off + w.slab_floats * 4));
     Launch L{};
     ReduceLaunch R{};
     L.n = j - i;
     L.splits = w.S;
     L.chunk = w.chunk;
-    L.slab = static_cast<float*>(workspace);
+    L.slab = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
+    ws_off += ((w.slab_floats * 4 + 255) / 256) * 256;
     int64_t off = 0, rstart = 0;
     int t = 0;
     for (int k = i; k < j; ++k) {
@@ -1664,12 +1667,19 @@ extern "C" int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, v
     }
     L.total_ntiles = t;
     R.total = rstart;
-    int rc = launch_tiles<EPI_SLAB>(L, false, false, TileChoice{w.bn, w.emu}, (int64_t)t * w.S, to_stream(stream),
-                                    "mml_gemm_grouped_wgrad");
+    int rc = MML_OK;
+    if (phase != 2)
+      rc = launch_tiles<EPI_SLAB>(L, false, false, TileChoice{w.bn, w.emu}, (int64_t)t * w.S, to_stream(stream),
+                                  "mml_gemm_grouped_wgrad");
     if (rc) return rc;
-    rc = launch_slab_reduce(R, to_stream(stream), "mml_gemm_grouped_wgrad(reduce)");
+    if (phase != 1) rc = launch_slab_reduce(R, to_stream(stream), "mml_gemm_grouped_wgrad(reduce)");
     if (rc) return rc;
     i = j;
   }
   return MML_OK;
+}
+
+extern "C" int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace,
+                                      int64_t workspace_bytes, mml_stream_t stream) {
+  return mml_gemm_grouped_wgrad_phase(d, n, workspace, workspace_bytes, 0, stream);
 }

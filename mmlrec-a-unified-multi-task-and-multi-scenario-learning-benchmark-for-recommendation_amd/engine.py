@@ -127,7 +127,8 @@ class Plan:
                     L.check(rc, c[0].__name__)
             b.record(s)
             label = None
-            if c[0] is not PY and c[0].__name__.startswith("mml_gemm_grouped"):
+            meta0 = c[2] if (c[0] is not PY and len(c) > 2 and isinstance(c[2], dict)) else {}
+            if str(meta0.get("kernel", "")).startswith("gemm<"):
                 label = L.load().mml_gemm_last_kernel().decode() or None
             evs.append((c, a, b, label))
         torch.cuda.synchronize()
@@ -196,6 +197,10 @@ class Plan:
                     self.bwd_tail.append(c)
                 else:
                     self.bwd.append(c)
+        # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
+        # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
+        # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
+        # list stays in program order: partial products and reduction of one layer back to back.)
 
     def _flat_numel(self, v):
         # act_bwd is a flat kernel: value and gradient must share the padded pitch (they do by construction)
@@ -324,13 +329,16 @@ class LinearGroupOp(Op):
         if wg:
             descs = ops.make_wgrad_descs(wg)
             nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(descs, len(wg))
-            ws = ops.workspace(nbytes, plan.device)
+            # own workspace: all partial-product launches of the step run before the first reduction (see Plan)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=plan.device)
             plan.keep += [descs, ws]
             meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2, kreds=[plan.B],
                                             tensors=[q["dC"] for q in wg] + [q["A"] for q in wg],
                                             nrc_extents=[d for q in wg for d in q["dW"].shape]),
-                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True)
-            calls.append((lib.mml_gemm_grouped_wgrad, (descs, len(wg), ws.data_ptr(), ws.numel()), meta))
+                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True, rank=0)
+            calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 1), meta))
+            calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 2),
+                          dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1)))
         # input gradients: one dgrad problem per distinct input value
         by_x = {}
         for q in live:
