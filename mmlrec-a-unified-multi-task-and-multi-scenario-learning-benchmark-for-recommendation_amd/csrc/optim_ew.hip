@@ -4,12 +4,14 @@
 // All of these are pure streaming kernels: 16-byte accesses per lane, grid-stride, HBM-bound.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace mml {
 
 struct OptLaunch {
   mml_opt_tensor t[MML_MAX_OPT_TENSORS];
   int32_t n;
-  int32_t pad_;
+  int32_t variant;  // streaming form of the vector loop (tuning knob MMLREC_OPT_VARIANT): bit 0 = nontemporal, bit 1 = 2x unroll
   mml_opt_hyper h;
 };
 
@@ -74,21 +76,58 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float* gw = const_cast<float*>(T.grad);
   if (vec) {
-    for (int64_t i = tid; i < n4; i += stride) {
-      float4 p = reinterpret_cast<float4*>(T.param)[i];
-      const float4 g = reinterpret_cast<const float4*>(T.grad)[i];
-      float4 a = T.state1 ? reinterpret_cast<float4*>(T.state1)[i] : make_float4(0, 0, 0, 0);
-      float4 b = T.state2 ? reinterpret_cast<float4*>(T.state2)[i] : make_float4(0, 0, 0, 0);
-      opt_update(h, c, p.x, g.x, a.x, b.x);
-      opt_update(h, c, p.y, g.y, a.y, b.y);
-      opt_update(h, c, p.z, g.z, a.z, b.z);
-      opt_update(h, c, p.w, g.w, a.w, b.w);
-      reinterpret_cast<float4*>(T.param)[i] = p;
-      if (T.state1) reinterpret_cast<float4*>(T.state1)[i] = a;
-      if (T.state2) reinterpret_cast<float4*>(T.state2)[i] = b;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const bool nt = (L.variant & 1) != 0;
+    const int unroll = (L.variant & 2) ? 2 : 1;
+    f4* P = reinterpret_cast<f4*>(T.param);
+    f4* G = reinterpret_cast<f4*>(gw);
+    f4* S1 = reinterpret_cast<f4*>(T.state1);
+    f4* S2 = reinterpret_cast<f4*>(T.state2);
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto ld = [&](const f4* q) { return nt ? __builtin_nontemporal_load(q) : *q; };
+    auto st = [&](f4* q, const f4& v) {
+      if (nt) __builtin_nontemporal_store(v, q);
+      else *q = v;
+    };
+    auto one = [&](f4& p, const f4& g, f4& a, f4& b) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = p[e], ae = a[e], be = b[e];
+        opt_update(h, c, pe, g[e], ae, be);
+        p[e] = pe;
+        a[e] = ae;
+        b[e] = be;
+      }
+    };
+    int64_t i = tid;
+    if (unroll == 2) {
+      for (; i + stride < n4; i += 2 * stride) {  // eight 16-byte loads in flight per thread
+        const int64_t j = i + stride;
+        f4 p0 = ld(P + i), p1 = ld(P + j);
+        const f4 g0 = ld(G + i), g1 = ld(G + j);
+        f4 a0 = S1 ? ld(S1 + i) : zero, a1 = S1 ? ld(S1 + j) : zero;
+        f4 b0 = S2 ? ld(S2 + i) : zero, b1 = S2 ? ld(S2 + j) : zero;
+        one(p0, g0, a0, b0);
+        one(p1, g1, a1, b1);
+        st(P + i, p0);
+        st(P + j, p1);
+        if (S1) { st(S1 + i, a0); st(S1 + j, a1); }
+        if (S2) { st(S2 + i, b0); st(S2 + j, b1); }
+        if (h.zero_grad && (g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f)) G[i] = zero;
+        if (h.zero_grad && (g1.x != 0.f || g1.y != 0.f || g1.z != 0.f || g1.w != 0.f)) G[j] = zero;
+      }
+    }
+    for (; i < n4; i += stride) {
+      f4 p = ld(P + i);
+      const f4 g = ld(G + i);
+      f4 a = S1 ? ld(S1 + i) : zero;
+      f4 b = S2 ? ld(S2 + i) : zero;
+      one(p, g, a, b);
+      st(P + i, p);
+      if (S1) st(S1 + i, a);
+      if (S2) st(S2 + i, b);
       // re-zero only what the scatter touched (~1 % of the rows): saves the 4 B/element store of a blind memset
-      if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
-        reinterpret_cast<float4*>(gw)[i] = make_float4(0, 0, 0, 0);
+      if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f)) G[i] = zero;
     }
   }
   const int64_t tail0 = vec ? (n4 << 2) : 0;
@@ -373,6 +412,12 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
     if (nmax == 0) continue;
     int64_t bx = cdiv(cdiv(nmax, 4), 256);
     if (bx > 256 * 8) bx = 256 * 8;
+    static int variant = -1;
+    if (variant < 0) {
+      const char* e = getenv("MMLREC_OPT_VARIANT");
+      variant = e ? atoi(e) : 0;
+    }
+    L.variant = variant;
     MML_LAUNCH(opt_dense_kernel, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
     rc = check_launch("mml_opt_step_dense");
     if (rc) return rc;

@@ -11,6 +11,8 @@
 #include "reduce.hpp"
 #include "rows_fast.hpp"
 
+#include <stdlib.h>
+
 namespace mml {
 
 template <int LPS>
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 }
 
 // ------------------------------------------------------------------------------------------------ gate backward
-template <int LPS, int NE, int NG>
+template <int LPS, int NE, int NG, bool IDENT>
 __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group g, const GateFastAux aux) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SPW = 64 / LPS;
@@ -132,6 +134,91 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 #pragma unroll
     for (int e = 0; e < NE; ++e) wacc[gi][e] = make_float4(0, 0, 0, 0);
 
+  if constexpr (IDENT) {
+  // every gate mixes experts 0..ne-1 in order (MMoE): one set of expert rows serves all gates and the final dE loop
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;
+    for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
+    // every load of the sample first (a store between two loads would serialise their latencies): upstream
+    // gradients, expert rows, softmax probabilities, gate inputs
+    float4 dmv[NG], Gv[NG], Ev[NE];
+    float pv[NG][NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) Ev[e] = (hcol && e < g.n_experts) ? ld4(g.E[e] + b * g.lde[e] + 4 * sub) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      dmv[gi] = make_float4(0, 0, 0, 0);
+      Gv[gi] = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) pv[gi][e] = 0.f;
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      if (!d.active) continue;
+      if (hcol) dmv[gi] = ld4(d.dmix + b * d.lddmix + 4 * sub);
+      if (4 * sub < d.Gd) Gv[gi] = ld4(d.G + b * d.ldg + 4 * sub);
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (e < d.ne) pv[gi][e] = d.P[b * d.ldp + e];
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      if (!d.active) continue;
+      float dl[NE];
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        dl[e] = 0.f;
+        if (e < d.ne) {
+          const float part = hcol ? dot4(dmv[gi], Ev[e]) : 0.f;
+          dl[e] = group_sum<LPS>(part);
+          dot += pv[gi][e] * dl[e];
+          if (sub == 0) coef[gi * MML_MAX_EXPERTS + e] = pv[gi][e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) dl[e] = valid ? pv[gi][e] * (dl[e] - dot) : 0.f;  // dlogit (0 for padding samples)
+      if (4 * sub < d.Gd) {
+        const float* W = Wsm + aux.wg_off[gi];
+        float4 dg = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          if (e < d.ne) {
+            fma4(dg, dl[e], ld4(W + e * d.Gd + 4 * sub));
+            fma4(wacc[gi][e], dl[e], Gv[gi]);
+          }
+        if (d.g_relu) {
+          if (!(Gv[gi].x > 0.f)) dg.x = 0.f;
+          if (!(Gv[gi].y > 0.f)) dg.y = 0.f;
+          if (!(Gv[gi].z > 0.f)) dg.z = 0.f;
+          if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
+        }
+        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (hcol) {
+#pragma unroll
+      for (int x = 0; x < NE; ++x) {
+        if (x >= g.n_experts) continue;
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], dmv[gi]);
+        if (g.e_relu) {
+          if (!(Ev[x].x > 0.f)) acc.x = 0.f;
+          if (!(Ev[x].y > 0.f)) acc.y = 0.f;
+          if (!(Ev[x].z > 0.f)) acc.z = 0.f;
+          if (!(Ev[x].w > 0.f)) acc.w = 0.f;
+        }
+        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  } else {
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -199,6 +286,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
   }
   // combine: lane groups of a wave (shuffles) -> per-wave LDS rows -> fixed-order sum over waves -> slab
 #pragma unroll
@@ -342,10 +430,10 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_lps(int width) { return width <= 64 ? 16 : (width <= 128 ? 32 : (width <= 256 ? 64 : 0)); }
 
-int fast_row_grid(int64_t B, int lps) {
+int fast_row_grid(int64_t B, int lps, int per_cu = 4) {
   const int spb = FW * (64 / lps);
   int64_t blocks = cdiv(B, spb);
-  if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: one partial slab row per workgroup goes to the reducer
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: one partial slab row per workgroup goes to the reducer
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -370,11 +458,25 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
     off += d.ne * d.Gd;
   }
   aux.wg_total = off;
+  aux.ident = 1;
+  for (int i = 0; i < g->n_gates; ++i) {
+    const mml_gate_desc& d = g->gate[i];
+    if (d.ne != g->n_experts) aux.ident = 0;
+    for (int e = 0; e < d.ne; ++e)
+      if (d.expert[e] != e) aux.ident = 0;
+  }
   aux.lps = pick_lps(width);
   aux.ne = nemax <= 4 ? 4 : (nemax <= 8 ? 8 : 16);
   aux.ng = g->n_gates <= 2 ? 2 : (g->n_gates <= 4 ? 4 : 8);
   if (bwd && aux.ne * aux.ng > 32) return 0;  // register budget of the dWg accumulators
-  aux.grid = fast_row_grid(g->B, aux.lps);
+  static int fwd_per_cu = -1;
+  if (fwd_per_cu < 0) {
+    const char* e = getenv("MMLREC_GATE_FWD_WGS");
+    fwd_per_cu = e ? atoi(e) : 8;
+  }
+  // the forward kernel writes no per-workgroup partials and needs 34 VGPRs: eight workgroups (32 waves) per CU hide
+  // the dependent G -> expert-row loads of a sample behind other samples
+  aux.grid = fast_row_grid(g->B, aux.lps, bwd ? 4 : fwd_per_cu);
   return aux.lps;
 }
 
@@ -406,7 +508,11 @@ template <int LPS>
 static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
   const size_t lds = gate_bwd_fast_lds(aux);
   dim3 gr(aux.grid), bl(FB);
-#define MML_GB(NE_, NG_) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_>), gr, bl, lds, st, g, aux)
+#define MML_GB(NE_, NG_)                                                                       \
+  do {                                                                                         \
+    if (aux.ident && NE_ * NG_ <= 8) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, true>), gr, bl, lds, st, g, aux); \
+    else MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, false>), gr, bl, lds, st, g, aux);   \
+  } while (0)
   if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
   else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
   else if (aux.ne == 4 && aux.ng == 8) MML_GB(4, 8);

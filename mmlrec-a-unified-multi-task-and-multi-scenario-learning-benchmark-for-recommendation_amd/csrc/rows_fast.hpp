@@ -8,7 +8,7 @@ struct GateFastAux {
   int32_t wg_off[MML_MAX_GATES];  // float offset of gate i's weight block (all gates, active or not)
   int32_t wg_total;
   int32_t lps, ne, ng, grid;
-  int32_t pad_;
+  int32_t ident;                  // every gate mixes experts 0..ne-1 in order (MMoE): backward reuses its expert-row loads
   float* slab;                    // backward: [grid][wg_total] per-workgroup dWg partials
 };
 
