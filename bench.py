@@ -74,6 +74,11 @@ def timed_steps(runner, batches, steps, warmup, dist, flush=None):
 
     for i in range(warmup):
         one(i)
+    # Keep the host out of the timed region: a cyclic-GC pass that happens to run here destroys HIP graphs / events of
+    # an earlier phase (tens of ms of hipFree + synchronisation; seen as a one-off 60 ms gap in the kernel trace)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier(dist)
     t0 = time.perf_counter()
     for i in range(steps):
@@ -87,6 +92,7 @@ def timed_steps(runner, batches, steps, warmup, dist, flush=None):
         t_flush = time.perf_counter() - tf
     barrier(dist)
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

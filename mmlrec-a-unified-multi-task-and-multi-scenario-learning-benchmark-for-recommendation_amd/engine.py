@@ -220,6 +220,11 @@ def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
     return "gemm<%s>" % ("fwd", "dgrad", "wgrad")[epi]
 
 
+def _opt_dense_symbol(numel):
+    """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: opt_dense_kernel<STREAM>)."""
+    return "opt_dense_kernel<%s>" % ("true" if numel >= (1 << 24) else "false")
+
+
 class Op:
     def inputs(self):
         return []
@@ -734,16 +739,32 @@ class Optimizer:
             plan.keep.append(arr)
             per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]
             calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper)),
-                          dict(kernel="opt_dense_kernel(mlp)", bytes=float(per) * sum(e[0].numel() for e in entries))))
+                          dict(kernel=_opt_dense_symbol(sum(e[0].numel() for e in entries)),
+                               bytes=float(per) * sum(e[0].numel() for e in entries))))
         mlp_calls, calls = calls, []
         if tabs:
             if self.table_update == "dense_exact":
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
-                arr = ops.make_opt_tensors([(pv.data, pv.grad) + self.state[n] for pv, n in zip(tabs, tnames)])
-                plan.keep += [hz, arr]
+                plan.keep.append(hz)
                 per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]  # p,g,m,v read + p,m,v written
-                calls.append((lib.mml_opt_step_dense, (arr, len(tabs), C.byref(hz)),
-                              dict(kernel="opt_dense_kernel(tables)", bytes=float(per) * sum(pv.data.numel() for pv in tabs))))
+                # one C call = one launch (the same size rule mml_opt_step_dense applies inside a call), so that a
+                # call's label is the kernel symbol a profiler reports
+                order = sorted(range(len(tabs)), key=lambda i: -tabs[i].data.numel())
+                groups = []
+                for i in order:
+                    n_i = tabs[i].data.numel()
+                    if groups:
+                        first = tabs[groups[-1][0]].data.numel()
+                        if not (first > (1 << 20) and first > 64 * max(n_i, 1)):
+                            groups[-1].append(i)
+                            continue
+                    groups.append([i])
+                for grp in groups:
+                    arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] for i in grp])
+                    plan.keep.append(arr)
+                    numel = sum(tabs[i].data.numel() for i in grp)
+                    calls.append((lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
+                                  dict(kernel=_opt_dense_symbol(numel), bytes=float(per) * numel)))
             else:
                 rows = st.rows
                 lazy = self.table_update == "lazy_exact"

@@ -21,7 +21,8 @@ def label(kernel_name, avg_bytes_hint=0):
         return "%s<%s>" % (m.group(1), m.group(2))
     for a, b in (("gather_vec4_kernel", "gather_vec4_kernel"), ("scatter_hash_kernel", "scatter_hash_kernel"),
                  ("gate_bwd_fast_kernel", "gate_bwd_kernel"), ("gate_fwd_fast_kernel", "gate_fwd_kernel"),
-                 ("head_fast_kernel", "head_kernel"), ("opt_dense_kernel", "opt_dense_kernel"),
+                 ("head_fast_kernel", "head_kernel"), ("opt_dense_kernel<true>", "opt_dense_kernel<true>"),
+                 ("opt_dense_kernel<false>", "opt_dense_kernel<false>"),
                  ("slab_reduce", "slab_reduce")):
         if k.startswith(a):
             return b
@@ -48,15 +49,6 @@ def main():
     res = {}
     for lab in sorted(set(fetch) | set(write)):
         fv, wv = fetch.get(lab, []), write.get(lab, [])
-        if lab == "opt_dense_kernel":  # two launches per step: tables (huge) and MLP (tiny) -> split by size
-            for name, pick in (("opt_dense_kernel(tables)", max), ("opt_dense_kernel(mlp)", min)):
-                big = lambda vals: [v for v in vals if (v > 0.5 * max(vals)) == (pick is max)] if vals else []
-                f2, w2 = big(fv), big(wv)
-                if f2 and w2:
-                    fb, wb = 2 * 1024 * sum(f2) / len(f2), 1024 * sum(w2) / len(w2)
-                    res[name] = {"hbm_bytes_per_launch": fb + wb, "read_bytes": fb, "write_bytes": wb,
-                                 "launches_sampled": len(f2)}
-            continue
         if not fv or not wv:
             continue
         fb, wb = 2 * 1024 * sum(fv) / len(fv), 1024 * sum(wv) / len(wv)
