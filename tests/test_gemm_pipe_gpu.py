@@ -1,0 +1,166 @@
+"""Edge cases of the LDS-DMA GEMM kernel (csrc/gemm.hip: gemm_pipe_kernel) against float64 torch: short reductions (the
+bias DMA may still be in flight at the epilogue), ragged row / column counts (edge tiles take the drained, uncounted
+wait path), outputs that cannot take 16-byte accesses, every activation, multi-problem groups of unequal width,
+multi-source + accumulating dgrad, [K,N] weight layout, both tile widths and both arithmetic modes.
+
+Restates nn.Linear + activation (model/utils.py:146-161) and its autograd pair; tolerance = the north star's 1e-4
+relative (max-norm), as in tests/test_models_gpu.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib as L, ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    lib = L.load()
+    mode0 = lib.mml_gemm_get_mode()
+    yield torch, L, ops, lib
+    lib.mml_gemm_set_mode(mode0)
+
+
+def rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def act_ref(torch, z, act, L):
+    if act == L.ACT_RELU:
+        return torch.relu(z)
+    if act == L.ACT_SIGMOID:
+        return torch.sigmoid(z)
+    if act == L.ACT_SIGMOID2:
+        return 2 * torch.sigmoid(z)
+    return z
+
+
+def dact_ref(torch, y, act, L):
+    if act == L.ACT_RELU:
+        return (y > 0).double()
+    if act == L.ACT_SIGMOID:
+        return y * (1 - y)
+    if act == L.ACT_SIGMOID2:
+        return y * (1 - y / 2)
+    return torch.ones_like(y)
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("M,K,Ns", [
+    (128, 16, [64]),            # one k-step per tile
+    (300, 32, [128, 4]),        # two k-steps, ragged M, a 4-column problem in the group
+    (4096 + 37, 48, [100]),     # three k-steps, N % 64 != 0 (edge tile, 16-byte stores still legal)
+    (1000, 240, [256, 256, 64]),
+    (260, 64, [130]),           # N % 4 != 0 -> element-wise epilogue
+    (70000, 128, [128, 128]),   # > 512 row tiles: persistent workgroups walk several tiles, 128 x 128 tiles
+])
+def test_pipe_fwd(env, mode, M, K, Ns):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(mode)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    acts = [L.ACT_RELU, L.ACT_NONE, L.ACT_SIGMOID, L.ACT_SIGMOID2]
+    probs = []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev) if i % 2 == 0 else None
+        probs.append(dict(A=A, W=W, bias=b, C=torch.full((M, N), float("nan"), device=dev), act=acts[i % 4]))
+    ops.gemm_fwd(probs)
+    torch.cuda.synchronize()
+    assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
+    for p in probs:
+        z = A.double() @ p["W"].double().t()
+        if p["bias"] is not None:
+            z = z + p["bias"].double()
+        assert rel(p["C"], act_ref(torch, z, p["act"], L)) < RTOL
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("M,K,srcNs,w_kn,act,accumulate", [
+    (128, 64, [16], 0, "relu", 0),            # one k-step, Y read in the epilogue
+    (515, 256, [128], 0, "relu", 0),          # the layer-2 shape: 8 k-steps + Y
+    (515, 240, [256, 256, 64, 64], 0, "none", 0),   # multi-source (layer 1)
+    (515, 128, [64, 32], 0, "sigmoid", 1),    # two sources, accumulate into an existing gradient
+    (300, 100, [48], 0, "none", 0),           # output width % 64 != 0
+    (300, 128, [48, 16], 1, "relu", 0),       # [K,N] weights
+    (70000, 128, [128], 0, "relu", 0),
+])
+def test_pipe_dgrad(env, mode, M, K, srcNs, w_kn, act, accumulate):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(mode)
+    dev = torch.device("cuda:0")
+    act = {"relu": L.ACT_RELU, "none": L.ACT_NONE, "sigmoid": L.ACT_SIGMOID}[act]
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    srcs, ref = [], torch.zeros(M, K, dtype=torch.float64, device=dev)
+    for N in srcNs:
+        dC = torch.randn(M, N, generator=g).to(dev)
+        W = (torch.randn(K, N, generator=g) if w_kn else torch.randn(N, K, generator=g)).to(dev) / N ** 0.5
+        srcs.append((dC, W, w_kn))
+        ref += dC.double() @ (W.double().t() if w_kn else W.double())
+    Y = torch.rand(M, K, generator=g).to(dev) - (0.5 if act == L.ACT_RELU else 0.0)
+    if act != L.ACT_NONE:
+        ref = ref * dact_ref(torch, Y.double(), act, L)
+    old = torch.randn(M, K, generator=g).to(dev)
+    dA = old.clone() if accumulate else torch.full((M, K), float("nan"), device=dev)
+    if accumulate:
+        ref = ref + old.double()
+    ops.gemm_dgrad([dict(dA=dA, Y=Y if act != L.ACT_NONE else None, act=act, accumulate=accumulate, srcs=srcs)])
+    torch.cuda.synchronize()
+    assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
+    assert rel(dA, ref) < RTOL
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("M,shapes,w_kn", [
+    (4096, [(64, 16)], 0),
+    (4096 + 16, [(256, 240), (64, 240)], 0),     # batch not a multiple of the chunk
+    (8192, [(128, 256), (4, 64)], 0),            # a 4-row problem next to a wide one
+    (8192, [(100, 48)], 0),                      # N % 64 != 0, K % 64 != 0
+    (8192, [(64, 128), (64, 128)], 1),           # [K,N] gradients: bias partials from the column operand
+    (70000, [(256, 240)], 0),
+])
+def test_pipe_wgrad(env, mode, M, shapes, w_kn):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(mode)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + len(shapes))
+    probs, As = [], {}
+    for N, K in shapes:
+        if K not in As:
+            As[K] = torch.randn(M, K, generator=g).to(dev)
+        dC = torch.randn(M, N, generator=g).to(dev)
+        dW = torch.full((K, N) if w_kn else (N, K), float("nan"), device=dev)
+        probs.append(dict(dC=dC, A=As[K], dW=dW, dbias=torch.full((N,), float("nan"), device=dev), w_kn=w_kn))
+    ops.gemm_wgrad(probs)
+    torch.cuda.synchronize()
+    assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
+    for p in probs:
+        ref = p["dC"].double().t() @ p["A"].double()
+        assert rel(p["dW"], ref.t() if w_kn else ref) < RTOL
+        assert rel(p["dbias"], p["dC"].double().sum(0)) < RTOL
+
+
+def test_pipe_is_bitwise_repeatable(env):
+    """Fixed tile order, fixed reduction order: two launches of the same problem give identical bits (the scatter's
+    float atomics are the only order-dependent arithmetic of the step)."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 20000, 256, 240
+    A, dC = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        ops.gemm_wgrad([dict(dC=dC, A=A, dW=dW, dbias=db)])
+        outs.append((dW.clone(), db.clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
