@@ -138,6 +138,11 @@ typedef struct {
   int32_t act;       /* MML_ACT_*                                                  */
   int32_t w_kn;      /* 0: W is [N,K] (nn.Linear); 1: W is [K,N] (STAR SharedSpecificLinear layout, model/utils.py:171) */
   int32_t pad_;
+  /* Optional (training): when non-NULL and act == MML_ACT_RELU, bit (c & 31) of relu_mask[r * ldmask + (c >> 5)] is
+   * set to (C[r][c] > 0) -- 1 bit per output instead of the 4 bytes mml_gemm_grouped_dgrad would otherwise re-read
+   * to apply relu'.  ldmask >= ceil(N / 32) words per row. */
+  uint32_t* relu_mask;
+  int64_t ldmask;
 } mml_gemm_fwd_desc;
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
@@ -155,6 +160,9 @@ typedef struct {
   int64_t lddc[MML_MAX_SRC], ldw[MML_MAX_SRC];
   int32_t N[MML_MAX_SRC];
   int32_t w_kn[MML_MAX_SRC];
+  /* Optional: the sign mask mml_gemm_grouped_fwd wrote for Y (act must be MML_ACT_RELU); used instead of Y. */
+  const uint32_t* relu_mask;
+  int64_t ldmask;
 } mml_gemm_dgrad_desc;
 int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
 

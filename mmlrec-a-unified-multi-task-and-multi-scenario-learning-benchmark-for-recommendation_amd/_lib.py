@@ -21,14 +21,15 @@ i32, i64 = C.c_int32, C.c_int64
 
 class GemmFwdDesc(C.Structure):
     _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("lda", i64), ("ldw", i64), ("ldc", i64),
-                ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32)]
+                ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32),
+                ("relu_mask", fp), ("ldmask", i64)]
 
 
 class GemmDgradDesc(C.Structure):
     _fields_ = [("dA", fp), ("Y", fp), ("ldda", i64), ("ldy", i64), ("M", i32), ("K", i32), ("act", i32),
                 ("n_src", i32), ("accumulate", i32), ("pad_", i32),
                 ("dC", fp * MAX_SRC), ("W", fp * MAX_SRC), ("lddc", i64 * MAX_SRC), ("ldw", i64 * MAX_SRC),
-                ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC)]
+                ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC), ("relu_mask", fp), ("ldmask", i64)]
 
 
 class GemmWgradDesc(C.Structure):

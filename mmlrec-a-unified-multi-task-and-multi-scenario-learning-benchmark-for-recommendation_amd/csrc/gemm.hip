@@ -50,6 +50,8 @@ struct Problem {
   const float* bias;   // fwd
   const float* Y;      // dgrad derivative source
   int64_t ldy;
+  uint32_t* mask;      // relu sign bits: written by fwd, read by dgrad instead of Y (or null)
+  int64_t ldmask;      // words per row
   int32_t act, accumulate;
   int32_t vec_out;     // C (and Y, when read) 16-byte aligned, ld % 4 == 0, N % 4 == 0: 16-byte epilogue accesses
   int32_t tiles_n;     // ceil(N / BN)
@@ -325,8 +327,16 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
         float* dst = P.C + (int64_t)row * P.ldc + col;
         if (EPI == EPI_FWD) {
           v = act_fwd(v + b, P.act);
+          if (P.mask) {  // relu sign bits: the 32 lanes of a half-wave are the 32 columns of one mask word
+            const unsigned long long bal = __ballot(v > 0.f);
+            if (l31 == 0) P.mask[(int64_t)row * P.ldmask + (col >> 5)] = (uint32_t)(h ? (bal >> 32) : bal);
+          }
         } else {
-          if (P.act != MML_ACT_NONE) v *= act_bwd(P.Y[(int64_t)row * P.ldy + col], P.act);
+          if (P.mask) {
+            if (!((P.mask[(int64_t)row * P.ldmask + (col >> 5)] >> l31) & 1u)) v = 0.f;
+          } else if (P.act != MML_ACT_NONE) {
+            v *= act_bwd(P.Y[(int64_t)row * P.ldy + col], P.act);
+          }
           if (P.accumulate) v += *dst;
         }
         *dst = v;
@@ -825,6 +835,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     const int64_t ldy = L.p[pi].ldy;
     const bool accumulate = L.p[pi].accumulate != 0;
     const bool vec = L.p[pi].vec_out != 0;
+    // relu sign bits (1 bit per output, word [row][col / 32]): written by the forward launch, read by dgrad in place of
+    // Y.  The host only passes a mask together with act == RELU.
+    uint32_t* const mask = (ACT == MML_ACT_RELU) ? L.p[pi].mask : nullptr;
+    const int64_t ldmask = L.p[pi].ldmask;
+    const bool use_mask = (EPI == EPI_DGRAD) && mask != nullptr;
+    auto xor_lane = [&](uint32_t v, int m) __attribute__((always_inline)) {
+      return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, (int)v);
+    };
     if (vec && BN == 64) {
       // 128 x 64 tiles: a stage is 12 KiB, too small for four 4-KiB transposition areas -> per-lane 16-byte accesses
       // (lane = row), all loads of a 32-row half before its stores
@@ -848,7 +866,16 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
         const int row = row0 + wm * 64 + mi * 32 + l31;
         const bool row_ok = row < PM;
         float4 y4[NI][4];
-        if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {
+        uint32_t mw[NI];  // this row's mask word per 32-column group: read (dgrad) or built (fwd)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mw[ni] = 0u;
+        if (use_mask) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int cg = col0 + wn * (BN / 2) + ni * 32;
+            if (row_ok && cg < PN) mw[ni] = mask[(int64_t)row * ldmask + (cg >> 5)];
+          }
+        } else if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -871,8 +898,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
                 v.x += b4[ni][g].x; v.y += b4[ni][g].y; v.z += b4[ni][g].z; v.w += b4[ni][g].w;
               }
               v.x = act_fwd_t<ACT>(v.x); v.y = act_fwd_t<ACT>(v.y); v.z = act_fwd_t<ACT>(v.z); v.w = act_fwd_t<ACT>(v.w);
+              if (mask) {
+                const uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                mw[ni] |= nib << (8 * g + 4 * h);
+              }
             } else {
-              if (ACT != MML_ACT_NONE) {
+              if (use_mask) {
+                const uint32_t nib = mw[ni] >> (8 * g + 4 * h);
+                if (!(nib & 1u)) v.x = 0.f;
+                if (!(nib & 2u)) v.y = 0.f;
+                if (!(nib & 4u)) v.z = 0.f;
+                if (!(nib & 8u)) v.w = 0.f;
+              } else if (ACT != MML_ACT_NONE) {
                 v.x *= act_bwd_t<ACT>(y4[ni][g].x); v.y *= act_bwd_t<ACT>(y4[ni][g].y);
                 v.z *= act_bwd_t<ACT>(y4[ni][g].z); v.w *= act_bwd_t<ACT>(y4[ni][g].w);
               }
@@ -883,6 +920,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
             }
             *reinterpret_cast<float4*>(dst) = v;
           }
+        if (EPI == EPI_FWD && mask) {  // the two half-waves hold the odd / even 4-column groups of the same rows
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const uint32_t w = mw[ni] | xor_lane(mw[ni], 32);
+            const int cg = col0 + wn * (BN / 2) + ni * 32;
+            if (h == 0 && row_ok && cg < PN) mask[(int64_t)row * ldmask + (cg >> 5)] = w;
+          }
+        }
       }
     } else if (vec) {
       // Each 32 x 32 sub-tile is turned row-major through this wave's 4 KiB of the stage buffer the step just consumed
@@ -904,7 +949,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           y[p] = ok ? *reinterpret_cast<const float4*>(Y + (int64_t)(rowb + 8 * p) * ldy + colg) : make_float4(0, 0, 0, 0);
         }
       };
-      constexpr bool USE_Y = (EPI == EPI_DGRAD) && (ACT != MML_ACT_NONE);
+      const bool USE_Y = (EPI == EPI_DGRAD) && (ACT != MML_ACT_NONE) && !use_mask;
 #pragma unroll
       for (int sidx = 0; sidx < 2 * NI; ++sidx) {
         const int mi = sidx / NI, ni = sidx % NI;
@@ -912,6 +957,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           if (USE_Y) load_y(sidx, y4);  // in flight during the LDS round trip
           const int colg = col0 + wn * (BN / 2) + ni * 32 + 4 * cc;  // this lane's 4 columns
           const int rowb = row0 + wm * 64 + mi * 32 + R;             // ... of rows rowb + 8p
+          uint32_t mw[4];  // mask word of row rowb + 8p (all eight lanes of a row read / build the same word)
+          if (use_mask) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              mw[p] = (rowb + 8 * p < PM && colg < PN) ? mask[(int64_t)(rowb + 8 * p) * ldmask + (colg >> 5)] : 0u;
+          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4_t v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
@@ -935,10 +986,40 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
             if (EPI == EPI_FWD) {
               x.x = act_fwd_t<ACT>(x.x + b4.x); x.y = act_fwd_t<ACT>(x.y + b4.y);
               x.z = act_fwd_t<ACT>(x.z + b4.z); x.w = act_fwd_t<ACT>(x.w + b4.w);
+            } else if (use_mask) {
+              const uint32_t nib = mw[p] >> (4 * cc);
+              if (!(nib & 1u)) x.x = 0.f;
+              if (!(nib & 2u)) x.y = 0.f;
+              if (!(nib & 4u)) x.z = 0.f;
+              if (!(nib & 8u)) x.w = 0.f;
             } else if (ACT != MML_ACT_NONE) {
               x.x *= act_bwd_t<ACT>(y4[p].x); x.y *= act_bwd_t<ACT>(y4[p].y);
               x.z *= act_bwd_t<ACT>(y4[p].z); x.w *= act_bwd_t<ACT>(y4[p].w);
             }
+          }
+          if (EPI == EPI_FWD && mask) {  // eight lanes (cc = 0..7) hold the eight nibbles of a row's word
+            uint32_t wsel = 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const f32x4_t& x = v[p];
+              uint32_t w = ((x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u))
+                           << (4 * cc);
+              // OR the eight nibbles into lane cc == 0 with three DPP row shifts (lane i takes lane i + 4, + 2, + 1:
+              // lanes 0..3 of every group of 8 only ever read inside their group; the other lanes' results are unused)
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xf, 0xf, true);
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x102, 0xf, 0xf, true);
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x101, 0xf, 0xf, true);
+              // ... and hand the word of row R + 8p to lane cc == p (row_shr:p), so that ONE store instruction writes the
+              // four words of this lane group
+              uint32_t moved = w;
+              if (p == 1) moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x111, 0xf, 0xf, true);
+              if (p == 2) moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x112, 0xf, 0xf, true);
+              if (p == 3) moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x113, 0xf, 0xf, true);
+              if (cc == p) wsel = moved;
+            }
+            const int mrow = rowb + 8 * cc;  // lane cc < 4 owns row R + 8 cc
+            const int cg = col0 + wn * (BN / 2) + ni * 32;
+            if (cc < 4 && mrow < PM && cg < PN) mask[(int64_t)mrow * ldmask + (cg >> 5)] = wsel;
           }
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
@@ -958,21 +1039,35 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       for (int mi = 0; mi < 2; ++mi) {
         const int row = row0 + wm * 64 + mi * 32 + l31;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni) {
+          const int cg = col0 + wn * (BN / 2) + ni * 32;
+          uint32_t mw = 0u;
+          if (use_mask && row < PM && cg < PN) mw = mask[(int64_t)row * ldmask + (cg >> 5)];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const int bit = 8 * (r >> 2) + 4 * h + (r & 3);
+            const int col = cg + bit;
             if (row >= PM || col >= PN) continue;
             float x = acc[mi][ni][r];
             float* dst = C + (int64_t)row * ldc + col;
             if (EPI == EPI_FWD) {
               x = act_fwd_t<ACT>(x + (bias ? bias[col] : 0.f));
+              if (mask && x > 0.f) mw |= 1u << bit;
             } else {
-              if (ACT != MML_ACT_NONE) x *= act_bwd_t<ACT>(Y[(int64_t)row * ldy + col]);
+              if (use_mask) {
+                if (!((mw >> bit) & 1u)) x = 0.f;
+              } else if (ACT != MML_ACT_NONE) {
+                x *= act_bwd_t<ACT>(Y[(int64_t)row * ldy + col]);
+              }
               if (accumulate) x += *dst;
             }
             *dst = x;
           }
+          if (EPI == EPI_FWD && mask) {
+            const uint32_t w = mw | xor_lane(mw, 32);
+            if (h == 0 && row < PM && cg < PN) mask[(int64_t)row * ldmask + (cg >> 5)] = w;
+          }
+        }
       }
     }
   };
@@ -1458,6 +1553,8 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
       S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
       P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
+      MML_REQUIRE(!q.relu_mask || q.ldmask * 32 >= q.N, "mml_gemm_grouped_fwd: ldmask too small in problem %d", j);
+      P.mask = (q.act == MML_ACT_RELU) ? q.relu_mask : nullptr; P.ldmask = q.ldmask;
       P.vec_out = (vec_ok(q.C, q.ldc) && q.N % 4 == 0 && (!q.bias || aligned16(q.bias))) ? 1 : 0;
       Ns[j - i] = q.N;
       ++j;
@@ -1496,7 +1593,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
       const mml_gemm_dgrad_desc& q = d[j];
       MML_REQUIRE(q.dA && q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", j);
       MML_REQUIRE(q.M >= 0 && q.K > 0 && q.ldda >= q.K, "mml_gemm_grouped_dgrad: bad sizes in problem %d", j);
-      MML_REQUIRE(q.act == MML_ACT_NONE || q.Y, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", j);
+      MML_REQUIRE(q.act == MML_ACT_NONE || q.Y || q.relu_mask, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", j);
       bool same = true;
       for (int s = 0; s < q.n_src; ++s) same = same && (q.w_kn[s] == lay);
       if ((!same || nsources + q.n_src > MAX_SOURCES) && j > i) break;
@@ -1512,6 +1609,9 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
         S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
       }
       P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
+      MML_REQUIRE(!q.relu_mask || (q.act == MML_ACT_RELU && q.ldmask * 32 >= q.K),
+                  "mml_gemm_grouped_dgrad: relu_mask needs act == RELU and ldmask >= K/32 (problem %d)", j);
+      P.mask = const_cast<uint32_t*>(q.relu_mask); P.ldmask = q.ldmask;
       P.vec_out = (vec_ok(q.dA, q.ldda) && q.K % 4 == 0 && (!q.Y || vec_ok(q.Y, q.ldy))) ? 1 : 0;
       P.accumulate = q.accumulate;
       Ns[j - i] = q.K;

@@ -38,6 +38,7 @@ class Val:
         self.consumers = []  # ops that would write a gradient into this value
         self.written = 0
         self.deriv_applied = False
+        self.mask = None  # int32 [B, ceil(n/32)] relu sign bits (training plans, written by the producing GEMM)
 
     @property
     def n(self):
@@ -304,8 +305,15 @@ class LinearGroupOp(Op):
         return [q["out"] for q in self.p]
 
     def fwd_calls(self, plan):
+        # training plans: a ReLU output also leaves its sign bits (1 bit per element) for the dgrad that will apply
+        # relu' to its gradient -- 32x less to re-read than the activations themselves
+        for q in self.p:
+            out = q["out"]
+            if plan.training and out.act == L.ACT_RELU and out.mask is None:
+                out.mask = torch.zeros(plan.B, (out.n + 31) // 32, dtype=torch.int32, device=plan.device)
         descs = ops.make_fwd_descs([dict(A=q["x"].buf, W=q["W"].data, bias=q["b"].data if q.get("b") else None,
-                                         C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0)) for q in self.p])
+                                         C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
+                                         mask=q["out"].mask) for q in self.p])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
         meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
@@ -359,6 +367,7 @@ class LinearGroupOp(Op):
                 while len(waves) <= ci:
                     waves.append([])
                 waves[ci].append(dict(dA=x.grad, Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
+                                      mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
                                       accumulate=acc,
                                       srcs=[(q["out"].grad, q["W"].data, q.get("w_kn", 0)) for q in ch]))
             if fuse:

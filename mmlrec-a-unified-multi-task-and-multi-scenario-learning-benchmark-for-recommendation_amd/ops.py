@@ -126,6 +126,9 @@ def make_fwd_descs(problems):
         d.N = W.shape[1] if w_kn else W.shape[0]
         d.act = int(p.get("act", L.ACT_NONE))
         d.w_kn = w_kn
+        m = p.get("mask")
+        d.relu_mask = L.ptr(m)
+        d.ldmask = _ld(m) if m is not None else 0
     return arr
 
 
@@ -155,6 +158,9 @@ def make_dgrad_descs(problems):
             d.lddc[s], d.ldw[s] = _ld(dC), _ld(W)
             d.N[s] = dC.shape[1]
             d.w_kn[s] = int(w_kn)
+        m = p.get("mask")
+        d.relu_mask = L.ptr(m)
+        d.ldmask = _ld(m) if m is not None else 0
     return arr
 
 

@@ -164,3 +164,40 @@ def test_pipe_is_bitwise_repeatable(env):
         outs.append((dW.clone(), db.clone()))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("M,K,N", [
+    (300, 64, 128),      # 128 x 64 tiles (few row tiles): per-lane-row epilogue
+    (70000, 128, 256),   # 128 x 128 tiles: row-major epilogue through LDS
+    (515, 48, 100),      # ragged columns: last mask word partly used
+    (260, 64, 130),      # element-wise epilogue
+    (200, 24, 96),       # K % 16 != 0 -> register-staged fallback kernel
+])
+def test_relu_sign_mask_round_trip(env, mode, M, K, N):
+    """Forward writes bit (c & 31) of mask[r, c >> 5] = (relu output > 0); dgrad with the mask == dgrad reading Y."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(mode)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    Cc = torch.empty(M, N, device=dev)
+    words = (N + 31) // 32
+    mask = torch.full((M, words), -1, dtype=torch.int32, device=dev)
+    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=Cc, act=L.ACT_RELU, mask=mask)])
+    torch.cuda.synchronize()
+    bits = ((mask.cpu().numpy().astype(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, words * 32)
+    assert np.array_equal(bits[:, :N].astype(bool), (Cc > 0).cpu().numpy())
+    # next layer's dgrad onto this activation: derivative from the mask vs from Y
+    N2 = 64
+    dC = torch.randn(M, N2, generator=g).to(dev)
+    W2 = (torch.randn(N2, N, generator=g) / N ** 0.5).to(dev)
+    d_y, d_m = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm_dgrad([dict(dA=d_y, Y=Cc, act=L.ACT_RELU, srcs=[(dC, W2, 0)])])
+    ops.gemm_dgrad([dict(dA=d_m, Y=Cc, act=L.ACT_RELU, mask=mask, srcs=[(dC, W2, 0)])])
+    torch.cuda.synchronize()
+    assert torch.equal(d_y, d_m)
+    ref = (dC.double() @ W2.double()) * (Cc > 0).double()
+    assert rel(d_m, ref) < RTOL
