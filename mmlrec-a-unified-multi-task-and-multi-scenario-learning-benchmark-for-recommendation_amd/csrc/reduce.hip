@@ -11,7 +11,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceLaunch R) 
     const ReduceSeg& g = R.seg[si];
     const int64_t j = i - g.start;
     float s = 0.f;
-    for (int k = 0; k < g.S; ++k) s += g.slab[(int64_t)k * g.sstride + j];
+    const float* src = g.slab + j;
+    int k = 0;
+    // eight independent loads in flight, then the adds in the fixed order k = 0, 1, 2, ... (bitwise reproducible)
+    for (; k + 8 <= g.S; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * g.sstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < g.S; ++k) s += src[(int64_t)k * g.sstride];
     const int64_t r = j / g.cols, c = j - r * g.cols;
     float* dst = g.out + r * g.ldo + c;
     if (g.accumulate) s += *dst;
