@@ -13,6 +13,7 @@ struct OptLaunch {
   int32_t n;
   int32_t variant;  // streaming form of the vector loop (tuning knob MMLREC_OPT_VARIANT): bit 0 = nontemporal, bit 1 = 2x unroll
   mml_opt_hyper h;
+  int64_t chunk0[MML_MAX_OPT_TENSORS + 1];  // flat kernel: first 4-element chunk of tensor i in the concatenation
 };
 
 struct StepConsts {
@@ -141,6 +142,59 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
     if (T.state1) T.state1[i] = a;
     if (T.state2) T.state2[i] = b;
     if (h.zero_grad && T.grad[i] != 0.f) gw[i] = 0.f;
+  }
+}
+
+// Many tensors of very different sizes (MLP weights and biases, the small tables) in ONE balanced launch: the tensors
+// are concatenated in units of 4 elements and a thread strides over that index space; the tensor of a chunk is found
+// by bisection of the prefix table (kept in LDS with the descriptors: a per-lane index into the kernel-argument block
+// would send it to scratch).
+__global__ __launch_bounds__(256) void opt_flat_kernel(const OptLaunch L) {
+  __shared__ mml_opt_tensor ts[MML_MAX_OPT_TENSORS];
+  __shared__ int64_t pre[MML_MAX_OPT_TENSORS + 1];
+  for (int i = threadIdx.x; i < L.n; i += 256) ts[i] = L.t[i];
+  for (int i = threadIdx.x; i <= L.n; i += 256) pre[i] = L.chunk0[i];
+  const mml_opt_hyper& h = L.h;
+  const StepConsts c = step_consts(h);  // (contains the __syncthreads that also publishes ts / pre)
+  const int64_t total = pre[L.n];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < total; ch += stride) {
+    int lo = 0, hi = L.n;  // largest t with pre[t] <= ch
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= ch) lo = mid;
+      else hi = mid;
+    }
+    const mml_opt_tensor T = ts[lo];
+    const int64_t e0 = (ch - pre[lo]) << 2;
+    float* gw = const_cast<float*>(T.grad);
+    const bool vec = (e0 + 4 <= T.n) && aligned16(T.param) && aligned16(T.grad) && (!T.state1 || aligned16(T.state1)) &&
+                     (!T.state2 || aligned16(T.state2));
+    if (vec) {
+      float4 p = *reinterpret_cast<float4*>(T.param + e0);
+      const float4 g = *reinterpret_cast<const float4*>(T.grad + e0);
+      float4 a = T.state1 ? *reinterpret_cast<float4*>(T.state1 + e0) : make_float4(0, 0, 0, 0);
+      float4 b = T.state2 ? *reinterpret_cast<float4*>(T.state2 + e0) : make_float4(0, 0, 0, 0);
+      opt_update(h, c, p.x, g.x, a.x, b.x);
+      opt_update(h, c, p.y, g.y, a.y, b.y);
+      opt_update(h, c, p.z, g.z, a.z, b.z);
+      opt_update(h, c, p.w, g.w, a.w, b.w);
+      *reinterpret_cast<float4*>(T.param + e0) = p;
+      if (T.state1) *reinterpret_cast<float4*>(T.state1 + e0) = a;
+      if (T.state2) *reinterpret_cast<float4*>(T.state2 + e0) = b;
+      if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
+        *reinterpret_cast<float4*>(gw + e0) = make_float4(0, 0, 0, 0);
+    } else {
+      for (int64_t i = e0; i < e0 + 4 && i < T.n; ++i) {
+        float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
+        const float g = T.grad[i];
+        opt_update(h, c, p, g, a, b);
+        T.param[i] = p;
+        if (T.state1) T.state1[i] = a;
+        if (T.state2) T.state2[i] = b;
+        if (h.zero_grad && g != 0.f) gw[i] = 0.f;
+      }
+    }
   }
 }
 
@@ -398,35 +452,40 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
   while (i < n) {
     OptLaunch L{};
     L.h = *hyper;
-    int64_t nmax = 0;
-    // tensors of wildly different size in one launch waste empty workgroups: cut a group when the next
-    // tensor is 64x smaller/larger than the group's first
+    int64_t total = 0, chunks = 0;
     while (i < n && L.n < MML_MAX_OPT_TENSORS) {
       const mml_opt_tensor& t = tensors[i];
       MML_REQUIRE(t.param && t.grad && t.n >= 0, "mml_opt_step_dense: tensor %d malformed", i);
       MML_REQUIRE(hyper->kind == MML_OPT_SGD || t.state1, "mml_opt_step_dense: tensor %d needs state1", i);
       MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
-      const int64_t big = t.n > L.t[0].n ? t.n : L.t[0].n;
-      if (L.n > 0 && big > (1 << 20) && (t.n > 64 * L.t[0].n || L.t[0].n > 64 * (t.n > 0 ? t.n : 1))) break;
+      L.chunk0[L.n] = chunks;
       L.t[L.n++] = t;
-      if (t.n > nmax) nmax = t.n;
+      total += t.n;
+      chunks += cdiv(t.n, 4);
       ++i;
     }
-    if (nmax == 0) continue;
-    int64_t bx = cdiv(cdiv(nmax, 4), 256);
-    if (bx > 256 * 8) bx = 256 * 8;
+    L.chunk0[L.n] = chunks;
+    if (total == 0) continue;
     static int variant = -1;
     if (variant < 0) {
       const char* e = getenv("MMLREC_OPT_VARIANT");
       variant = e ? atoi(e) : 0;
     }
     L.variant = variant;
-    int64_t total = 0;
-    for (int k = 0; k < L.n; ++k) total += L.t[k].n;
-    if (total >= ((int64_t)1 << 24))
+    // A group dominated by one huge tensor (the dense table update) streams with the per-tensor kernel (blockIdx.y =
+    // tensor: no index search on the 2.7 GB stream); everything else (dozens of tensors from 64 B to a few MB) goes
+    // through the flat kernel, where every workgroup has the same amount of work.
+    int64_t nmax = 0;
+    for (int k = 0; k < L.n; ++k) nmax = L.t[k].n > nmax ? L.t[k].n : nmax;
+    if (total >= ((int64_t)1 << 24) && L.n <= 4) {
+      int64_t bx = cdiv(cdiv(nmax, 4), 256);
+      if (bx > 256 * 8) bx = 256 * 8;
       MML_LAUNCH(opt_dense_kernel<true>, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
-    else
-      MML_LAUNCH(opt_dense_kernel<false>, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
+    } else {
+      int64_t bx = cdiv(chunks, 256);
+      if (bx > 256 * 8) bx = 256 * 8;
+      MML_LAUNCH(opt_flat_kernel, dim3((unsigned)bx), dim3(256), 0, to_stream(stream), L);
+    }
     rc = check_launch("mml_opt_step_dense");
     if (rc) return rc;
   }

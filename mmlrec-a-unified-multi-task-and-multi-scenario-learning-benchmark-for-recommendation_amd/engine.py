@@ -221,9 +221,9 @@ def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
     return "gemm<%s>" % ("fwd", "dgrad", "wgrad")[epi]
 
 
-def _opt_dense_symbol(numel):
-    """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: opt_dense_kernel<STREAM>)."""
-    return "opt_dense_kernel<%s>" % ("true" if numel >= (1 << 24) else "false")
+def _opt_dense_symbol(numel, ntensors):
+    """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: mml_opt_step_dense's choice)."""
+    return "opt_dense_kernel<true>" if (numel >= (1 << 24) and ntensors <= 4) else "opt_flat_kernel"
 
 
 class Op:
@@ -748,7 +748,7 @@ class Optimizer:
             plan.keep.append(arr)
             per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]
             calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper)),
-                          dict(kernel=_opt_dense_symbol(sum(e[0].numel() for e in entries)),
+                          dict(kernel=_opt_dense_symbol(sum(e[0].numel() for e in entries), len(entries)),
                                bytes=float(per) * sum(e[0].numel() for e in entries))))
         mlp_calls, calls = calls, []
         if tabs:
@@ -758,22 +758,19 @@ class Optimizer:
                 per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]  # p,g,m,v read + p,m,v written
                 # one C call = one launch (the same size rule mml_opt_step_dense applies inside a call), so that a
                 # call's label is the kernel symbol a profiler reports
-                order = sorted(range(len(tabs)), key=lambda i: -tabs[i].data.numel())
-                groups = []
-                for i in order:
-                    n_i = tabs[i].data.numel()
-                    if groups:
-                        first = tabs[groups[-1][0]].data.numel()
-                        if not (first > (1 << 20) and first > 64 * max(n_i, 1)):
-                            groups[-1].append(i)
-                            continue
-                    groups.append([i])
+                # the huge tables stream through opt_dense_kernel<true> (one call), every other table shares one
+                # balanced opt_flat_kernel launch (the same split mml_opt_step_dense makes for a mixed call)
+                big = [i for i in range(len(tabs)) if tabs[i].data.numel() >= (1 << 22)]
+                if len(big) > 4 or sum(tabs[i].data.numel() for i in big) < (1 << 24):
+                    big = []
+                small = [i for i in range(len(tabs)) if i not in big]
+                groups = [g_ for g_ in (big, small) if g_]
                 for grp in groups:
                     arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] for i in grp])
                     plan.keep.append(arr)
                     numel = sum(tabs[i].data.numel() for i in grp)
                     calls.append((lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
-                                  dict(kernel=_opt_dense_symbol(numel), bytes=float(per) * numel)))
+                                  dict(kernel=_opt_dense_symbol(numel, len(grp)), bytes=float(per) * numel)))
             else:
                 rows = st.rows
                 lazy = self.table_update == "lazy_exact"
