@@ -591,7 +591,9 @@ __device__ __forceinline__ float act_bwd_t(float y) {
   return 1.f;
 }
 
-template <bool ARC, bool BRC, int BN, int EPI, int EMU>
+// BCOLS (weight-gradient launches only): the bias partials are batch sums of the COLUMN operand ([K,N] weights) instead
+// of the row operand; uniform per launch (the host groups problems by layout), so the per-step sums carry no branch.
+template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
   typedef const __attribute__((address_space(4))) Launch KLaunch;
   KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();  // see gemm_glds_kernel
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       c.kend = (c.k0 + L.chunk < kr) ? c.k0 + L.chunk : kr;
       if (c.k0 >= c.kend) c.kend = c.k0 + GK;
     }
-    c.bias_cols = (EPI == EPI_SLAB) && L.p[pi].bias_cols != 0;
+    c.bias_cols = (EPI == EPI_SLAB) && BCOLS;
     c.want_bias = (EPI == EPI_SLAB) && L.p[pi].bias_slab != nullptr && (c.bias_cols ? c.row0 == 0 : c.col0 == 0);
     c.short_tile = (EPI != EPI_SLAB) && (c.nsrc == 1) && (c.kend - c.k0 < 3 * GK);
     c.counted = c.row0 + BM <= c.M && c.col0 + BN <= c.N && (EPI == EPI_SLAB || L.p[pi].vec_out != 0);
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
         // lanes l and l + 32 hold the two k-halves of one row's sum
         float v = bs_cur[t];
         v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
-        if (!c.bias_cols) {
+        if (!BCOLS) {
           const int row = row0 + wm * 64 + t * 32 + l31;
           if (wn == 0 && h == 0 && row < PM) bs[(int64_t)c.split * PM + row] = v;
         } else if (t < NI) {
@@ -1141,7 +1143,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     if (NI == 2) RB1[0].landed();
     __builtin_amdgcn_sched_barrier(0);
     if (EPI == EPI_SLAB) {
-      if (!cur.bias_cols) {
+      if (!BCOLS) {
         bs_cur[0] = sum8(a0);
         bs_cur[1] = sum8(RA1[0]);
       } else {
@@ -1222,8 +1224,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       t3 = __builtin_readcyclecounter();
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (EPI == EPI_SLAB) {  // (the bias operand of the NEXT step's tile: fixed per launch group in practice)
-        if (!cur.bias_cols) {
+      if (EPI == EPI_SLAB) {
+        if (!BCOLS) {
           bs_next[0] = sum8(na0);
           bs_next[1] = sum8(RA1[Q]);
         } else {
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       RA1[Q].landed();
       __builtin_amdgcn_sched_barrier(0);
       if (EPI == EPI_SLAB) {
-        if (!cur.bias_cols) {
+        if (!BCOLS) {
           bs_next[0] = sum8(na0);
           bs_next[1] = sum8(RA1[Q]);
         } else {
@@ -1383,9 +1385,13 @@ struct TileChoice {
 };
 
 static thread_local char g_last_kernel[96] = "";
-static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, int mode) {
-  snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d>", fam, arc ? "true" : "false",
-           brc ? "true" : "false", bn, epi, mode);
+static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, int mode, int bcols = -1) {
+  if (bcols < 0)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d>", fam, arc ? "true" : "false",
+             brc ? "true" : "false", bn, epi);
+  else
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s>", fam, arc ? "true" : "false",
+             brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false");
 }
 
 template <int EPI>
@@ -1399,6 +1405,8 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   }
   dim3 g((unsigned)nblocks), b(256);
   const int emu = tc.emu;  // 0 = fp32 MFMA, 3 = three bf16 planes
+  const bool bcols = (EPI == EPI_SLAB) && L.n > 0 && L.p[0].bias_cols != 0;  // (uniform per launch: see the wgrad entry)
+  (void)bcols;
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  An unused
   // dynamic-LDS request (mml_gemm_set_wgrad_lds_pad) lowers their residency so that the optimizer's waves co-reside.
   if (g_wgrad_pad < 0) {
@@ -1407,7 +1415,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   }
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
   if (pipe_ok(L, arc, brc, bn, EPI)) {
-    note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, emu);
+    note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, emu, bcols ? 1 : 0);
     // persistent workgroups: one per resident slot (128 x 128 tiles: 2 per CU; 128 x 64: 3), each loops over tiles
     static int cus = 0;
     if (cus == 0) {
@@ -1420,12 +1428,17 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     const int64_t slots = (int64_t)cus * (bn == 64 ? 3 : 2);
     if (nblocks > slots) g = dim3((unsigned)slots);
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
-#define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU>), g, b, dyn, st, L)
+#define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU, false>), g, b, dyn, st, L)
 #else
-#define MML_GL2(A_, B_, N_)                                                              \
-  do {                                                                                   \
-    if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0>), g, b, dyn, st, L);  \
-    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3>), g, b, dyn, st, L);           \
+#define MML_GL3(A_, B_, N_, C_)                                                              \
+  do {                                                                                       \
+    if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);  \
+    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, C_>), g, b, dyn, st, L);           \
+  } while (0)
+#define MML_GL2(A_, B_, N_)                                  \
+  do {                                                       \
+    if (EPI == EPI_SLAB && bcols) MML_GL3(A_, B_, N_, (EPI == EPI_SLAB)); \
+    else MML_GL3(A_, B_, N_, false);                         \
   } while (0)
 #define MML_GL(A_, B_)                  \
   do {                                  \
@@ -1445,6 +1458,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
 #undef MML_GL
 #ifndef MML_LAB
 #undef MML_GL2
+#undef MML_GL3
 #endif
     return check_launch(who);
   }
@@ -1689,7 +1703,7 @@ extern "C" int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_d
   int i = 0;
   while (i < n) {
     int j = i;
-    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
+    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M && d[j].w_kn == d[i].w_kn) ++j;
     WgradPlan w = plan_wgrad(d, i, j);
     best += ((w.slab_floats * 4 + 255) / 256) * 256;  // groups are laid out one after another (phased launches)
     i = j;
@@ -1707,7 +1721,7 @@ extern "C" int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* d, int32_
   int64_t ws_off = 0;  // bytes: every group of problems owns its own piece of the workspace
   while (i < n) {
     int j = i;
-    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) ++j;
+    while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M && d[j].w_kn == d[i].w_kn) ++j;
     WgradPlan w = plan_wgrad(d, i, j);
     MML_REQUIRE(ws_off + w.slab_floats * 4 <= workspace_bytes, "mml_gemm_grouped_wgrad: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)(ws_off + w.slab_floats * 4));
