@@ -127,12 +127,12 @@ def roofline_of(acc):
         achieved = e["flops"] / e["launches"] / (avg_ms * 1e-3) / 1e12
         unit, bound = "TFLOP/s", "mfma"
         planes = 0
-        if name.startswith("gemm_glds_kernel") and name.endswith((", 2>", ", 3>")):
-            planes = int(name[-2])
-        if name.startswith("gemm_kernel") and name.endswith(", 1>"):
-            planes = 2
+        import re
+        m = re.match(r"gemm_pipe_kernel<\w+, \w+, \d+, \d+, (\d+)", name)
+        if m and int(m.group(1)) in (1, 3):
+            planes = int(m.group(1))
         if planes:  # fp32 emulated on the bf16 MFMA pipe: 3 (two planes) or 6 (three planes) MFMAs per product block
-            per = 3 if planes == 2 else 6
+            per = {1: 1, 2: 3, 3: 6}[planes]
             peak = 2500.0 / per
             note = (f"algorithmic fp32 FLOP/s; the kernel issues {per} v_mfma_f32_32x32x16_bf16 per 32x32x16 product "
                     f"block, so peak = dense bf16 MFMA peak (2.5 PFLOP/s) / {per}; frac = bf16 MFMA pipe utilisation. "
@@ -252,7 +252,8 @@ def main():
     from mmlrec_amd import _lib
     gmode = _lib.load().mml_gemm_get_mode()
     gemm_dtype = {0: "f32", 4: "f32 (GEMMs: fp32 MFMA, or fp32-equivalent 3-plane bf16 MFMA emulation with f32 accumulate where faster)",
-                  3: "f32 (GEMMs: fp32-equivalent 3-plane bf16 MFMA emulation, f32 accumulate)"}.get(
+                  3: "f32 (GEMMs: fp32-equivalent 3-plane bf16 MFMA emulation, f32 accumulate)",
+                  1: "bf16 GEMM operands (rounded in registers), f32 accumulate, f32 everywhere else"}.get(
         gmode, "f32 operands, GEMM products from 2 bf16 planes (~1e-5 rel), f32 accumulate")
     main_r = results[args.batch]
     roof = roofline_of(main_r["acc"])

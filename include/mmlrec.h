@@ -116,7 +116,9 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
  *       v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh; the dropped terms are <= 2^-24 |a b|) with fp32
  *       accumulation.  Max-norm error against float64 equals the fp32 MFMA's (4.7e-7 vs 4.3e-7 on a
  *       8192 x 256 x 240 product, tools/bench_gemm.py); the other launches use the fp32 MFMA;
- *   3 = the three-plane form on every launch of the LDS-DMA kernel.
+ *   3 = the three-plane form on every launch of the LDS-DMA kernel;
+ *   1 = REDUCED precision, opt-in: operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per 16-k block,
+ *       fp32 accumulation (~3e-3 relative per product; not covered by the 1e-4 parity contract).
  * Environment MMLREC_GEMM_MODE overrides the default. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);

@@ -449,6 +449,12 @@ __device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&out)[
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t u0 = __float_as_uint(x[2 * j]), u1 = __float_as_uint(x[2 * j + 1]);
+    if (PL == 1) {  // plain bf16 operands: round to nearest even (v_cvt_pk_bf16_f32)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 xx = {x[2 * j], x[2 * j + 1]};
+      w[0][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xx, bf16x2_t));
+      continue;
+    }
     w[0][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {bf16 bits of x0, bf16 bits of x1}, truncated
     if (PL > 1) {
       const float r0 = x[2 * j] - __uint_as_float(u0 & 0xffff0000u);
@@ -604,8 +610,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
   constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile
   constexpr int NBIAS = (EPI == EPI_FWD) ? 1 : 0;  // the next tile's bias DMA follows the stores
   constexpr int AFTER_EPI = (LOADS + NSTORE + NBIAS < 63) ? LOADS + NSTORE + NBIAS : 63;
-  constexpr int NMFMA = EMU == 0 ? 8 : 6;  // MFMAs per block
-  constexpr int NVALU = EMU == 0 ? 0 : 8;  // VALU slots per MFMA of a block with one prepare
+  constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 1 ? 1 : 6);  // MFMAs per block
+  constexpr int NVALU = EMU == 0 ? 0 : 8;  // VALU slots per MFMA of a block with one prepare (EMU 1: 4 cvt_pk)
   __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256];  // + one 64-float bias slot per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1367,6 +1373,8 @@ static bool pipe_ok(const Launch& L, bool arc, bool brc, int bn, int epi) {
 static inline int32_t vec_ok(const float* p, int64_t ld) { return (aligned16(p) && (ld % 4 == 0)) ? 1 : 0; }
 
 // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32) on every launch
+// 1 = bf16 operands (round-to-nearest-even in registers), fp32 accumulation: ONE v_mfma_f32_32x32x16_bf16 per 16-k
+//     block.  Opt-in reduced precision (~3e-3 relative per product; BASELINE's KuaiRec configuration names bf16).
 // 3 = three bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per 16-k block) on every LDS-DMA launch
 // 4 = auto (default): the three-plane form where it is faster, the fp32 MFMA elsewhere.  Both give fp32-equivalent
 //     results (max-norm error vs float64 4.7e-7 vs 4.3e-7, tools/bench_gemm.py).
@@ -1375,7 +1383,7 @@ static int g_wgrad_pad = -1;  // unused dynamic LDS requested by wgrad launches 
 static int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("MMLREC_GEMM_MODE");
-    g_gemm_mode = (e && (e[0] == '0' || e[0] == '3')) ? e[0] - '0' : 4;
+    g_gemm_mode = (e && (e[0] == '0' || e[0] == '1' || e[0] == '3')) ? e[0] - '0' : 4;
   }
   return g_gemm_mode;
 }
@@ -1404,7 +1412,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-  const int emu = tc.emu;  // 0 = fp32 MFMA, 3 = three bf16 planes
+  const int emu = tc.emu;  // 0 = fp32 MFMA, 1 = bf16 operands, 3 = three bf16 planes
   const bool bcols = (EPI == EPI_SLAB) && L.n > 0 && L.p[0].bias_cols != 0;  // (uniform per launch: see the wgrad entry)
   (void)bcols;
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  An unused
@@ -1432,8 +1440,9 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
 #else
 #define MML_GL3(A_, B_, N_, C_)                                                              \
   do {                                                                                       \
-    if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);  \
-    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, C_>), g, b, dyn, st, L);           \
+    if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);       \
+    else if (emu == 1) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 1, C_>), g, b, dyn, st, L);  \
+    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, C_>), g, b, dyn, st, L);                \
   } while (0)
 #define MML_GL2(A_, B_, N_)                                  \
   do {                                                       \
@@ -1508,7 +1517,7 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
   tc.bn = (pad128 * 100 <= pad64 * 150) ? 128 : 64;  // wide tiles unless > 1/3 of their columns would be padding
   if (row_tiles * (pad128 / 128) < 1024) tc.bn = 64;  // ... or they would not fill the 512 resident slots twice
   if (force == 64 || force == 128) tc.bn = force;
-  tc.emu = (mode == 0) ? 0 : 3;
+  tc.emu = (mode == 0) ? 0 : (mode == 1 ? 1 : 3);
   (void)kind;
   (void)kred;
   return tc;
@@ -1519,7 +1528,8 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
 using namespace mml;
 
 extern "C" int mml_gemm_set_mode(int32_t mode) {
-  MML_REQUIRE(mode == 0 || mode == 3 || mode == 4, "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 3 (fp32 emulated "
+  MML_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 4,
+              "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16 operands, reduced precision), 3 (fp32 emulated "
               "from three bf16 planes on every LDS-DMA launch) or 4 (auto)");
   g_gemm_mode = mode;
   return MML_OK;

@@ -305,10 +305,15 @@ class LinearGroupOp(Op):
         return [q["out"] for q in self.p]
 
     def fwd_calls(self, plan):
+        # training plans: a ReLU output also leaves its sign bits (1 bit per element) for the dgrad that will apply
+        # relu' to its gradient -- 32x less to re-read than the activations themselves
+        for q in self.p:
+            out = q["out"]
+            if plan.training and out.act == L.ACT_RELU and out.mask is None:
+                out.mask = torch.zeros(plan.B, (out.n + 31) // 32, dtype=torch.int32, device=plan.device)
         descs = ops.make_fwd_descs([dict(A=q["x"].buf, W=q["W"].data, bias=q["b"].data if q.get("b") else None,
-                                         C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0)) for q in self.p])
-        for i, q in enumerate(self.p):
-            q["out"].fwd_desc = (descs, i)  # a consumer that fuses relu' into its dgrad asks for the sign mask here
+                                         C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
+                                         mask=q["out"].mask) for q in self.p])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
         meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
@@ -361,13 +366,6 @@ class LinearGroupOp(Op):
                 acc = _claim(x)
                 while len(waves) <= ci:
                     waves.append([])
-                if fuse and x.act == L.ACT_RELU and x.mask is None and getattr(x, "fwd_desc", None) is not None:
-                    # the producing GEMM now also writes this value's relu sign bits (1 bit per element): 32x less
-                    # for the dgrad epilogue to read than the activations themselves
-                    x.mask = torch.zeros(plan.B, (x.n + 31) // 32, dtype=torch.int32, device=plan.device)
-                    fd, fi = x.fwd_desc
-                    fd[fi].relu_mask = x.mask.data_ptr()
-                    fd[fi].ldmask = x.mask.stride(0)
                 waves[ci].append(dict(dA=x.grad, Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
                                       mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
                                       accumulate=acc,

@@ -41,6 +41,10 @@ class TrainStep:
         self.use_graph = bool(use_graph) and sharding is None
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
+        # fork / join events live as long as the step (and its captured graph): events created and destroyed inside a
+        # stream capture were the prime suspect of a sporadic segfault in hipGraphLaunch
+        self.ev_fork = torch.cuda.Event() if self.overlap else None
+        self.ev_join = torch.cuda.Event() if self.overlap else None
         self.g_fb = self.g_opt = None
         self.calls = 0
 
@@ -61,7 +65,7 @@ class TrainStep:
             run(self.opt_split["tables"])
             return
         main = torch.cuda.current_stream()
-        fork = torch.cuda.Event()
+        fork, join = self.ev_fork, self.ev_join
         fork.record(main)
         self.side.wait_event(fork)
         with torch.cuda.stream(self.side):
@@ -69,7 +73,6 @@ class TrainStep:
             if self.allreduce is not None and with_allreduce:
                 self.allreduce(self.store.arena)
             run(self.opt_split["mlp"])
-            join = torch.cuda.Event()
             join.record(self.side)
         run(p.bwd_tail)
         run(self.opt_split["tables"])
