@@ -41,56 +41,81 @@ class TrainStep:
         self.use_graph = bool(use_graph) and sharding is None
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
-        # fork / join events live as long as the step (and its captured graph): events created and destroyed inside a
-        # stream capture were the prime suspect of a sporadic segfault in hipGraphLaunch
+        # fork / join events live as long as the step
         self.ev_fork = torch.cuda.Event() if self.overlap else None
         self.ev_join = torch.cuda.Event() if self.overlap else None
-        self.g_fb = self.g_opt = None
+        self.g_fb = self.g_side = self.g_tail = None
         self.calls = 0
 
-    def _body(self, with_allreduce=True):
+    def _front(self):
         p, run = self.plan, E.Plan._run
-        # (mml_gemm_set_wgrad_lds_pad can cap the wgrad GEMMs' residency so that the table optimizer co-resides; with
-        # the direct-to-LDS GEMMs the standalone speed of wgrad at 4 workgroups/CU wins, so the pad stays 0)
         run(self.opt_split["pre"])
         run(p.fwd)
         run(p.head_train)
         run(p.bwd)
-        if not self.overlap:
-            run(p.bwd_tail)
-            run(p.bwd_side)
-            if self.allreduce is not None and with_allreduce:
-                self.allreduce(self.store.arena)
-            run(self.opt_split["mlp"])
-            run(self.opt_split["tables"])
-            return
+
+    def _side(self, with_allreduce=True):
+        E.Plan._run(self.plan.bwd_side)
+        if self.allreduce is not None and with_allreduce:
+            self.allreduce(self.store.arena)
+        E.Plan._run(self.opt_split["mlp"])
+
+    def _tail(self):
+        E.Plan._run(self.plan.bwd_tail)
+        E.Plan._run(self.opt_split["tables"])
+
+    def _forked(self, side, tail):
         main = torch.cuda.current_stream()
-        fork, join = self.ev_fork, self.ev_join
-        fork.record(main)
-        self.side.wait_event(fork)
+        self.ev_fork.record(main)
+        self.side.wait_event(self.ev_fork)
         with torch.cuda.stream(self.side):
-            run(p.bwd_side)
-            if self.allreduce is not None and with_allreduce:
-                self.allreduce(self.store.arena)
-            run(self.opt_split["mlp"])
-            join.record(self.side)
-        run(p.bwd_tail)
-        run(self.opt_split["tables"])
-        main.wait_event(join)
+            side()
+            self.ev_join.record(self.side)
+        tail()
+        main.wait_event(self.ev_join)
+
+    def _body(self, with_allreduce=True):
+        # (mml_gemm_set_wgrad_lds_pad can cap the wgrad GEMMs' residency so that the table optimizer co-resides; with
+        # the direct-to-LDS GEMMs the standalone speed of wgrad at 4 workgroups/CU wins, so the pad stays 0)
+        self._front()
+        if not self.overlap:
+            self._tail()
+            self._side(with_allreduce)
+            return
+        self._forked(lambda: self._side(with_allreduce), self._tail)
+
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
 
     def run(self):
         """plan.X / plan.y must hold the batch. After the call plan.prob / plan.loss hold this step's outputs.
         The first call runs eagerly (HIP graph capture needs warmed-up state and does not execute what it records);
-        the second call captures, then every call replays."""
+        the second call captures, then every call replays.
+
+        With two streams the step is THREE single-stream graphs (front, side, tail) forked and joined with events at
+        replay time, not one graph with two branches: hipGraphLaunch of a multi-branch graph walks past the end of the
+        exec's parallel-stream vector when one of those streams shares a hardware queue with the launch stream
+        (hip::Graph::UpdateStreams, ROCm 7.0 runtime bundled with torch 2.10) -- a sporadic segfault that depends on
+        how many streams the process has created.  Single-branch graphs never enter that loop."""
         if not self.use_graph or self.calls == 0:
             self._body()
+        elif not self.overlap:
+            if self.g_fb is None:
+                torch.cuda.synchronize()
+                self.g_fb = self._capture(self._body)
+            self.g_fb.replay()
         else:
             if self.g_fb is None:
                 torch.cuda.synchronize()
-                self.g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_fb):
-                    self._body()
+                self.g_fb = self._capture(self._front)
+                self.g_side = self._capture(self._side)
+                self.g_tail = self._capture(self._tail)
+                torch.cuda.synchronize()
             self.g_fb.replay()
+            self._forked(self.g_side.replay, self.g_tail.replay)
         self.calls += 1
         self.opt.steps_done += 1
         self.opt.dirty = True
