@@ -208,8 +208,14 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
   int* keys = reinterpret_cast<int*>(smem);
   float* acc = smem + SLOTS;
   const int E = a.E;
-  const int f = blockIdx.x % a.F;  // neighbouring workgroups read neighbouring 4E-byte pieces of the same dOut rows
-  const int64_t c = blockIdx.x / a.F;
+  // The F workgroups of one sample chunk read neighbouring 4E-byte pieces of the same dOut rows (and neighbouring X
+  // columns): consecutive workgroup ids are dealt round-robin to the 8 XCDs, so the chunk is chosen from the XCD slot
+  // (id % 8) and the field from the position inside the XCD -- the F readers of a 128-byte line then share ONE L2
+  // instead of fetching the line into up to four of them.
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int f = j % a.F;
+  const int64_t c = (int64_t)(j / a.F) * 8 + xcd;
+  if (c * chunk >= a.B) return;
   for (int i = threadIdx.x; i < SLOTS; i += 256) keys[i] = -1;
   for (int i = threadIdx.x; i < SLOTS * E; i += 256) acc[i] = 0.f;
   __syncthreads();
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
   const int nb = (int)((a.B - b0 < chunk) ? (a.B - b0) : chunk);
   const int64_t V = ft.vocab[f];
   const int colf = ft.col[f];
+  const bool POW2E = (E & (E - 1)) == 0 && E <= 64;  // the E lanes of a sample are an aligned lane group
   int bad = 0;
   for (int item = threadIdx.x; item < nb * E; item += 256) {
     const int s = item / E, e = item - s * E;
@@ -228,11 +235,14 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
     unsigned slot = ((unsigned)row * 2654435761u) >> 16;
     slot &= (SLOTS - 1);
     const int key = (int)row;
-    while (true) {
-      const int old = atomicCAS(&keys[slot], -1, key);
-      if (old == -1 || old == key) break;
-      slot = (slot + 1) & (SLOTS - 1);
+    if (!POW2E || e == 0) {  // one lane per sample claims the slot ...
+      while (true) {
+        const int old = atomicCAS(&keys[slot], -1, key);
+        if (old == -1 || old == key) break;
+        slot = (slot + 1) & (SLOTS - 1);
+      }
     }
+    if (POW2E) slot = (unsigned)__shfl((int)slot, (int)(threadIdx.x & 63) & ~(E - 1));  // ... its E lanes follow
     if (a.dOut) atomicAdd(&acc[slot * E + e], g);
   }
   __syncthreads();
@@ -341,7 +351,7 @@ extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, 
     // dynamic LDS stays under the 64 KiB default limit: SLOTS * (1 + E) * 4 bytes = 36 KiB (4 workgroups per CU)
     const int slots = (E <= 8) ? 1024 : 512;
     const int chunk = slots / 2;  // load factor <= 0.5
-    const int64_t nblocks = (int64_t)F * cdiv(B, chunk);
+    const int64_t nblocks = (int64_t)F * 8 * cdiv(cdiv(B, chunk), 8);  // 8 XCD slots x F fields x chunk groups
     const size_t lds = (size_t)slots * (1 + E) * 4 + (touched ? (size_t)slots * 4 : 0);
     if (nblocks <= 0x7fffffff) {
       if (slots == 1024)
@@ -380,7 +390,7 @@ extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
   const int slots = (E <= 8) ? 1024 : 512;
   const int chunk = slots / 2;
-  const int64_t nblocks = (int64_t)F * cdiv(B, chunk);
+  const int64_t nblocks = (int64_t)F * 8 * cdiv(cdiv(B, chunk), 8);  // 8 XCD slots x F fields x chunk groups
   MML_REQUIRE(nblocks <= 0x7fffffff, "mml_index_unique: grid too large");
   const size_t lds = (size_t)slots * (1 + E) * 4 + (size_t)slots * 4;
   if (slots == 1024)
