@@ -204,7 +204,9 @@ def main():
     T = W.num_tasks(cfg)
 
     allreduce = None
-    if world > 1:
+    # MMLREC_BENCH_FORCE_SHARD=1 with --gpus 2 and WORLD_SIZE=1 walks the table-sharded code path (exchange, no HIP
+    # graph, per-call timing of the collectives) on a single GPU: a smoke test of the N > 1 bench, not a measurement
+    if world > 1 or (dist is not None and os.environ.get("MMLREC_BENCH_FORCE_SHARD") == "1"):
         from mmlrec_amd import parallel
         parallel.shard_model(model, dist, args.batch)
 
@@ -247,6 +249,9 @@ def main():
                        "ms_per_step_steps_only": round((dt - tf) / steps * 1e3, 4), "final_flush_ms": round(tf * 1e3, 3)}
         del model2
 
+    if dist is not None:
+        barrier(dist)
+        dist.destroy_process_group()
     if rank != 0:
         return
     from mmlrec_amd import _lib
@@ -294,9 +299,15 @@ def main():
         except Exception as e:  # never lose the GPU line to a host-side problem
             line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                     "sample": f"failed: {e!r}"}
+    # RCCL writes its version banner through C stdio (block-buffered when stdout is a pipe or a file): push it out
+    # first, so that the JSON line is the LAST line of stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -413,6 +413,53 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const ColSegs S, int64_t
   }
 }
 
+// The same copy in 16-byte pieces (every segment start, width, leading dimension and base pointer a multiple of four
+// floats -- the row / row-gradient exchange buffers with E % 4 == 0): segment tables and the column -> segment map are
+// staged in LDS once per workgroup, so the inner loop is one LDS lookup + one float4 load + one float4 store.
+constexpr int COPY_COLS_MAX_W4 = 1024;
+__global__ __launch_bounds__(256) void copy_cols_vec4_kernel(const ColSegs S, int64_t rows, int accumulate) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ const float* s_src[MML_MAX_FIELDS];
+  __shared__ float* s_dst[MML_MAX_FIELDS];
+  __shared__ int64_t s_lds[MML_MAX_FIELDS], s_ldd[MML_MAX_FIELDS];
+  __shared__ int32_t s_start[MML_MAX_FIELDS + 1];
+  __shared__ uint8_t seg_of[COPY_COLS_MAX_W4];
+  const int W4 = S.start[S.n] >> 2;
+  for (int k = threadIdx.x; k < S.n; k += 256) {
+    s_src[k] = S.src[k]; s_dst[k] = S.dst[k]; s_lds[k] = S.lds_[k]; s_ldd[k] = S.ldd[k];
+  }
+  for (int k = threadIdx.x; k <= S.n; k += 256) s_start[k] = S.start[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < W4; c += 256) {
+    int lo = 0, hi = S.n - 1;  // last segment whose start <= 4c
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_start[mid] <= 4 * c) lo = mid; else hi = mid - 1;
+    }
+    seg_of[c] = (uint8_t)lo;
+  }
+  __syncthreads();
+  const int64_t total = rows * W4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r;
+    int c;
+    if (total < 0x7fffffff) {  // 32-bit division when it fits
+      const uint32_t ri = (uint32_t)i / (uint32_t)W4;
+      r = ri;
+      c = (int)((uint32_t)i - ri * (uint32_t)W4);
+    } else {
+      r = i / W4;
+      c = (int)(i - r * W4);
+    }
+    const int sg = seg_of[c];
+    const int cc = 4 * c - s_start[sg];
+    const f4 v = *reinterpret_cast<const f4*>(s_src[sg] + r * s_lds[sg] + cc);
+    f4* d = reinterpret_cast<f4*>(s_dst[sg] + r * s_ldd[sg] + cc);
+    *d = accumulate ? *d + v : v;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const float* dy, float* dst, int64_t n, int act) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -629,7 +676,14 @@ extern "C" int mml_copy_cols(const float* const* src, const int64_t* lds_, float
       acc += width[k];
     }
     S.start[S.n] = acc;
-    MML_LAUNCH(copy_cols_kernel, dim3(ew_grid(rows * acc)), dim3(256), 0, to_stream(stream), S, rows, accumulate);
+    bool v4 = (acc >> 2) <= COPY_COLS_MAX_W4;
+    for (int s = 0; s < S.n && v4; ++s)
+      v4 = S.width[s] % 4 == 0 && S.lds_[s] % 4 == 0 && S.ldd[s] % 4 == 0 && aligned16(S.src[s]) && aligned16(S.dst[s]);
+    if (v4)
+      MML_LAUNCH(copy_cols_vec4_kernel, dim3(ew_grid(rows * (acc >> 2))), dim3(256), 0, to_stream(stream), S, rows,
+                 accumulate);
+    else
+      MML_LAUNCH(copy_cols_kernel, dim3(ew_grid(rows * acc)), dim3(256), 0, to_stream(stream), S, rows, accumulate);
     int rc = check_launch("mml_copy_cols");
     if (rc) return rc;
   }

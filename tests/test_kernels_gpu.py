@@ -395,6 +395,44 @@ def test_elementwise(ops):
     assert np.allclose(dst.cpu().numpy(), d * 2 * sg * (1 - sg), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("widths,rows,accumulate", [
+    ([8, 8, 16, 8], 1000, 0),        # every segment a multiple of four floats: 16-byte kernel
+    ([8] * 30, 4099, 1),             # the row-exchange shape (30 fields, E = 8), accumulate
+    ([8, 3, 1, 12], 777, 0),         # odd widths: element-wise kernel
+    ([1] * 30, 2048, 0),             # the index pack (one column per field)
+    ([64] * 33, 300, 0),             # more than 1024 float4 columns would need the fallback: 33*16 = 528 stays vec
+])
+def test_copy_cols_segments(ops, widths, rows, accumulate):
+    """mml_copy_cols: segment s copies src_s[:, :w_s] -> dst_s[:, :w_s] (column windows of wider matrices), bit-exact."""
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(sum(widths) + rows)
+    n = len(widths)
+    W = sum(widths)
+    src_big = torch.randn(rows, W + 8, generator=g).to(dev())
+    dst_big = torch.randn(rows, W + 12, generator=g).to(dev())
+    ref = dst_big.clone()
+    srcs, dsts, c = [], [], 0
+    perm = list(range(n))[::-1]  # destination windows in reverse order of the source windows
+    offs = np.concatenate([[0], np.cumsum(widths)])
+    doff = np.concatenate([[0], np.cumsum([widths[p] for p in perm])])
+    for s in range(n):
+        srcs.append(src_big[:, offs[s]:offs[s] + widths[s]])
+        k = perm.index(s)
+        dsts.append(dst_big[:, 4 + doff[k]:4 + doff[k] + widths[s]])
+        r = ref[:, 4 + doff[k]:4 + doff[k] + widths[s]]
+        r.copy_(r + srcs[-1] if accumulate else srcs[-1])
+    src = ops._ptr_array(srcs)
+    dst = ops._ptr_array(dsts)
+    lds = (L.i64 * n)(*[src_big.stride(0)] * n)
+    ldd = (L.i64 * n)(*[dst_big.stride(0)] * n)
+    wid = (L.i32 * n)(*widths)
+    rc = lib.mml_copy_cols(src, lds, dst, ldd, wid, n, rows, accumulate, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst_big, ref)
+
+
 @pytest.mark.parametrize("kind", ["adam", "rmsprop"])
 def test_lazy_exact_optimizer_matches_dense_trajectory(ops, kind):
     """Touched-rows-only updates + catch-up of the skipped zero-gradient steps == the reference's dense optimizer
