@@ -190,6 +190,23 @@ def cpu_baseline(args):
                       " gather/scatter/dense-Adam loops"}
 
 
+def describe_workload(name, cfg, vocab, dense):
+    mc = cfg["model_config"]
+    keys = {"mmoe": ("expert", "gate", "tower"), "ple": ("expert", "gate", "tower"),
+            "sharedbottom": ("bottom", "tower")}.get(mc["model_name"], ())
+    parts = [f"{k}s {mc[k + '_dnn_hidden_units']}" for k in keys]
+    if mc["model_name"] in ("mmoe",):
+        parts.insert(0, f"{mc['num_experts']} experts")
+    if mc["model_name"] == "ple":
+        parts.insert(0, f"{mc.get('num_levels', 2)} levels x ({mc.get('specific_expert_num', 3)} specific + "
+                        f"{mc.get('shared_expert_num', 2)} shared) experts")
+    if not keys:
+        parts.append(f"layers {mc['dnn_hidden_units']}")
+    return (f"{name}: {len(vocab)} sparse fields{f' + {len(dense)} dense' if dense else ''}, "
+            f"{sum(vocab) / 1e6:.2f}M rows ({max(vocab):.0e}-row top table), E={mc['emb']}, {mc['model_name']} "
+            f"{', '.join(parts)}, {cfg['optim_config']['optimizer']} lr {cfg['optim_config']['lr']}")
+
+
 def main():
     args = parse()
     rank, local, world, dist = dist_setup(args.gpus)
@@ -265,13 +282,12 @@ def main():
     roof["launches_per_step"] = main_r["acc"][roof["kernel"]]["launches"] / main_r["bsteps"]
     per = W.algorithmic_per_sample(cfg, vocab, len(dense))
     line = {
-        "metric": "train-step samples/sec, MMoE AliExpress-shape batch",
+        "metric": "train-step samples/sec, MMoE AliExpress-shape batch" if args.workload.startswith("mmoe_ae30")
+                  else f"train-step samples/sec, {args.workload}",
         "value": round(main_r["value"], 1), "unit": "samples/s", "n_gpus": world, "steps": main_r["steps"],
         "warmup": args.warmup, "ms_per_step": round(main_r["ms"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": gemm_dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload}: 30 sparse fields, 12.49M rows (1e7-row top table), E=8, MMoE 4 "
-                               f"experts [256,128], gates [64], towers [64], {cfg['optim_config']['optimizer']} "
-                               f"lr {cfg['optim_config']['lr']}",
+        "config": {"workload": describe_workload(args.workload, cfg, vocab, dense),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
                    "table_update": model.optimizer().table_update, "hip_graph": not args.no_graph,
                    "streams": 1 if args.serial else 2,

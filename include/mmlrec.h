@@ -283,6 +283,20 @@ int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mm
  * model/pepnet.py:72, :139) */
 int mml_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate,
                mml_stream_t stream);
+/* n independent strided 2-D copies in ONE launch (item i: dst[r, c] (+)= src[r, c], r < rows, c < cols): the engine's
+ * zero-padded weight copies for layers whose reduction length is not a multiple of the GEMM k-step (K0 = 303 with the
+ * 63 dense AliExpress columns, configs_msl/config_AE.json:18-23), one launch per layer group instead of one per weight.
+ * `d` is a HOST array. */
+typedef struct mml_copy2d_desc {
+  const float* src;
+  int64_t lds;
+  float* dst;
+  int64_t ldd;
+  int64_t rows;
+  int32_t cols;
+  int32_t accumulate;
+} mml_copy2d_desc;
+int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
 /* Up to MML_MAX_FIELDS strided column-block copies in ONE launch: for segment s, dst[s][r*ldd[s] + c] (+)= src[s][r*lds[s] + c],
  * r < rows, c < width[s].  Packs / unpacks the per-field pieces of index, row and gradient blocks around the
  * all-to-all exchange of table-sharded runs (no reference counterpart: the reference is single-process).

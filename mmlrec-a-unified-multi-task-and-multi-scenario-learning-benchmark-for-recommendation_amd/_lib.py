@@ -65,6 +65,11 @@ class OptTensor(C.Structure):
     _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64)]
 
 
+class Copy2dDesc(C.Structure):
+    _fields_ = [("src", fp), ("lds", i64), ("dst", fp), ("ldd", i64), ("rows", i64), ("cols", i32),
+                ("accumulate", i32)]
+
+
 class OptHyper(C.Structure):
     _fields_ = [("kind", i32), ("step", i32), ("step_dev", fp), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("zero_grad", i32)]
@@ -98,6 +103,7 @@ _SIGS = {
     "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
     "mml_ew_add_n": (C.c_int, [_PP(fp), i32, fp, i64, fp]),
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
+    "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),
     "mml_opt_step_dense": (C.c_int, [_PP(OptTensor), i32, _PP(OptHyper), fp]),

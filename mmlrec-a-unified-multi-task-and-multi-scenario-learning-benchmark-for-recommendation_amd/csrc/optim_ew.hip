@@ -387,6 +387,24 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* src, int64_t l
   }
 }
 
+constexpr int COPY2D_BATCH = 32;
+struct Copy2dBatch {
+  mml_copy2d_desc d[COPY2D_BATCH];
+};
+// blockIdx.y = item; blockIdx.x strides over that item's elements
+__global__ __launch_bounds__(256) void copy2d_batch_kernel(const Copy2dBatch Bt) {
+  const mml_copy2d_desc& D = Bt.d[blockIdx.y];
+  const int64_t total = D.rows * D.cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / D.cols;
+    const int c = (int)(i - r * D.cols);
+    const float v = D.src[r * D.lds + c];
+    float* q = D.dst + r * D.ldd + c;
+    *q = D.accumulate ? *q + v : v;
+  }
+}
+
 struct ColSegs {
   const float* src[MML_MAX_FIELDS];
   float* dst[MML_MAX_FIELDS];
@@ -655,6 +673,29 @@ extern "C" int mml_copy2d(const float* src, int64_t lds_, float* dst, int64_t ld
   MML_LAUNCH(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, to_stream(stream), src, lds_, dst, ldd,
                      rows, cols, accumulate);
   return check_launch("mml_copy2d");
+}
+
+extern "C" int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_copy2d_batch: null descriptor array");
+  for (int i0 = 0; i0 < n; i0 += COPY2D_BATCH) {
+    Copy2dBatch Bt{};
+    int m = 0;
+    int64_t most = 0;
+    for (int i = i0; i < n && m < COPY2D_BATCH; ++i) {
+      const mml_copy2d_desc& D = d[i];
+      MML_REQUIRE(D.rows >= 0 && D.cols >= 0, "mml_copy2d_batch: item %d has a negative extent", i);
+      if (D.rows == 0 || D.cols == 0) continue;
+      MML_REQUIRE(D.src && D.dst && D.lds >= D.cols && D.ldd >= D.cols,
+                  "mml_copy2d_batch: item %d: null pointer or leading dimension < cols", i);
+      Bt.d[m++] = D;
+      most = D.rows * D.cols > most ? D.rows * D.cols : most;
+    }
+    if (m == 0) continue;
+    MML_LAUNCH(copy2d_batch_kernel, dim3(ew_grid(most), (unsigned)m), dim3(256), 0, to_stream(stream), Bt);
+    int rc = check_launch("mml_copy2d_batch");
+    if (rc) return rc;
+  }
+  return MML_OK;
 }
 
 extern "C" int mml_copy_cols(const float* const* src, const int64_t* lds_, float* const* dst, const int64_t* ldd,

@@ -39,6 +39,10 @@ class Val:
         self.written = 0
         self.deriv_applied = False
         self.mask = None  # int32 [B, ceil(n/32)] relu sign bits (training plans, written by the producing GEMM)
+        # > 0: the value owns its rows up to column kpad (a multiple of 16) and the columns [n, kpad) are zero and
+        # never written -- a GEMM may then read it as a [B, kpad] operand (LinearGroupOp: reduction lengths that
+        # are not a multiple of the 16-wide k-step, e.g. 30 x 8 embedding columns + 63 dense columns = 303)
+        self.kpad = 0
 
     @property
     def n(self):
@@ -86,17 +90,32 @@ class Plan:
         self.keep.append(t)
         return t
 
-    def val(self, n, act=L.ACT_NONE, needs_grad=True, name="", buf=None):
+    def _rows(self, n, pad_k=False):
+        """[B, n] view of a fresh buffer with 16-byte aligned rows.  pad_k: when n is not a multiple of 16 the row is
+        padded with ZERO columns up to the next multiple (returns the padded width, else 0)."""
+        if pad_k and n % 16:
+            kp = (n + 15) // 16 * 16
+            return self.zeros(self.B, kp)[:, :n], kp
+        ld = (n + 3) // 4 * 4
+        return (self.empty(self.B, ld)[:, :n] if ld != n else self.empty(self.B, n)), 0
+
+    def val(self, n, act=L.ACT_NONE, needs_grad=True, name="", buf=None, pad_k=False):
+        """pad_k: for values that feed a GEMM as the reduction operand (see Val.kpad)."""
+        kp = 0
         if buf is None:
-            ld = (n + 3) // 4 * 4  # keep rows 16-byte aligned for the vector paths
-            buf = self.empty(self.B, ld)[:, :n] if ld != n else self.empty(self.B, n)
-        return Val(buf, act, needs_grad, name)
+            buf, kp = self._rows(n, pad_k)
+        v = Val(buf, act, needs_grad, name)
+        v.kpad = kp
+        return v
 
     def grad_of(self, v):
         """Allocate v.grad on first use (same row pitch as the value)."""
         if v.grad is None:
-            ld = (v.n + 3) // 4 * 4
-            v.grad = self.empty(self.B, ld)[:, :v.n] if ld != v.n else self.empty(self.B, v.n)
+            if v.kpad:
+                v.grad = self.zeros(self.B, v.kpad)[:, :v.n]
+            else:
+                ld = (v.n + 3) // 4 * 4
+                v.grad = self.empty(self.B, ld)[:, :v.n] if ld != v.n else self.empty(self.B, v.n)
         return v.grad
 
     # ---- execution ---------------------------------------------------------------------------
@@ -291,6 +310,31 @@ class GatherOp(Op):
                  (plan.status.data_ptr(),), meta)]
 
 
+def _padded_view(buf, kp):
+    """[B, kp] view over a value / gradient allocated by Plan._rows (columns [n, kp) are zero)."""
+    if buf.stride(0) < kp or buf.stride(1) != 1:
+        raise L.MMLError("value does not own zero-padded rows")
+    return buf.as_strided((buf.shape[0], kp), (buf.stride(0), 1), buf.storage_offset())
+
+
+def _copy2d_batch_call(plan, pairs):
+    """One launch copying src[:, :cols] -> dst[:, :cols] for every (src, dst) pair (cols = the narrower of the two)."""
+    arr = (L.Copy2dDesc * len(pairs))()
+    for d, (src, dst) in zip(arr, pairs):
+        d.src, d.lds, d.dst, d.ldd = src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)
+        d.rows, d.cols, d.accumulate = src.shape[0], min(src.shape[1], dst.shape[1]), 0
+    plan.keep.append(arr)
+    return (L.load().mml_copy2d_batch, (arr, len(pairs)),
+            dict(kernel="copy2d_batch_kernel", bytes=8.0 * sum(min(a.numel(), b.numel()) for a, b in pairs)))
+
+
+def _kpad_of(q):
+    x = q["x"]
+    if x.kpad and x.n % 16 and not q.get("w_kn", 0) and x.buf.stride(0) >= x.kpad:
+        return x.kpad
+    return 0
+
+
 class LinearGroupOp(Op):
     """K3: a set of independent Linear(+activation) problems launched together.
     problems: dicts with x (Val), W (PVal), b (PVal or None), out (Val; out.act is the activation), w_kn."""
@@ -311,17 +355,29 @@ class LinearGroupOp(Op):
             out = q["out"]
             if plan.training and out.act == L.ACT_RELU and out.mask is None:
                 out.mask = torch.zeros(plan.B, (out.n + 31) // 32, dtype=torch.int32, device=plan.device)
-        descs = ops.make_fwd_descs([dict(A=q["x"].buf, W=q["W"].data, bias=q["b"].data if q.get("b") else None,
+        # reduction length not a multiple of 16: run the GEMM on the zero-padded operand pair (the value's own padded
+        # rows, a padded copy of the weight refreshed every step) instead of dropping to the register-staged kernel
+        pads = []
+        for q in self.p:
+            kp = _kpad_of(q)
+            if kp:
+                q["Ap"] = _padded_view(q["x"].buf, kp)
+                q["Wp"] = plan.zeros(q["W"].data.shape[0], kp)
+                pads.append((q["W"].data, q["Wp"]))
+        pre = [_copy2d_batch_call(plan, pads)] if pads else []
+        descs = ops.make_fwd_descs([dict(A=q.get("Ap", q["x"].buf), W=q.get("Wp", q["W"].data),
+                                         bias=q["b"].data if q.get("b") else None,
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
                                          mask=q["out"].mask) for q in self.p])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
         meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
-                                        kreds=[q["x"].n for q in self.p],
-                                        tensors=[q["x"].buf for q in self.p] + [q["W"].data for q in self.p],
+                                        kreds=[q.get("Ap", q["x"].buf).shape[1] for q in self.p],
+                                        tensors=[q.get("Ap", q["x"].buf) for q in self.p] +
+                                                [q.get("Wp", q["W"].data) for q in self.p],
                                         nrc_extents=[q["out"].n for q in self.p] if kn else []),
                     flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in self.p))
-        return [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
+        return pre + [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
 
     def bwd_calls(self, plan):
         lib = L.load()
@@ -337,6 +393,11 @@ class LinearGroupOp(Op):
             if b is not None and b.needs_grad:
                 if _claim(b) != acc:
                     raise L.MMLError("weight and bias of one layer must be written in the same order")
+            if "Ap" in q and not acc:
+                q["dWp"] = plan.empty(W.data.shape[0], q["Ap"].shape[1])
+                wg.append(dict(dC=q["out"].grad, A=q["Ap"], dW=q["dWp"], dbias=b.grad if (b and b.needs_grad) else None,
+                               accumulate=0, w_kn=0, unpad=(q["dWp"], W.grad)))
+                continue
             wg.append(dict(dC=q["out"].grad, A=q["x"].buf, dW=W.grad, dbias=b.grad if (b and b.needs_grad) else None,
                            accumulate=acc, w_kn=q.get("w_kn", 0)))
         if wg:
@@ -352,6 +413,11 @@ class LinearGroupOp(Op):
             calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 1), meta))
             calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 2),
                           dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1)))
+            unpad = [q["unpad"] for q in wg if "unpad" in q]  # padded weight gradients -> the parameters' [N, K]
+            if unpad:
+                c = _copy2d_batch_call(plan, unpad)
+                c[2]["side"] = True
+                calls.append(c)
         # input gradients: one dgrad problem per distinct input value
         by_x = {}
         for q in live:
@@ -366,10 +432,13 @@ class LinearGroupOp(Op):
                 acc = _claim(x)
                 while len(waves) <= ci:
                     waves.append([])
-                waves[ci].append(dict(dA=x.grad, Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
+                padded = x.kpad and all("Wp" in q for q in ch)  # every source reads the zero-padded weight copy
+                waves[ci].append(dict(dA=_padded_view(x.grad, x.kpad) if padded else x.grad,
+                                      Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
                                       mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
                                       accumulate=acc,
-                                      srcs=[(q["out"].grad, q["W"].data, q.get("w_kn", 0)) for q in ch]))
+                                      srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0))
+                                            for q in ch]))
             if fuse:
                 x.deriv_applied = True
         for dg in waves:
@@ -528,9 +597,17 @@ class MulOp(Op):
 
     def __init__(self, a, b, out):
         self.a, self.b, self.out = a, b, out
-        for v in (a, b, out):
-            if not v.buf.is_contiguous():
-                raise L.MMLError("MulOp needs contiguous buffers")
+        self.flat = self._flat_numel((a, b, out))
+
+    @staticmethod
+    def _flat_numel(vals):
+        """The flat kernels run over whole buffers: contiguous [B, n], or rows of one common zero-padded pitch."""
+        if all(v.buf.is_contiguous() for v in vals):
+            return vals[0].buf.numel()
+        st = vals[0].buf.stride(0)
+        if all(v.kpad == st and v.buf.stride(0) == st and v.n == vals[0].n for v in vals):
+            return vals[0].buf.shape[0] * st
+        raise L.MMLError("MulOp needs contiguous buffers (or one common zero-padded pitch)")
 
     def inputs(self):
         return [self.a, self.b]
@@ -540,13 +617,13 @@ class MulOp(Op):
 
     def fwd_calls(self, plan):
         return [(L.load().mml_ew_mul, (self.a.buf.data_ptr(), self.b.buf.data_ptr(), self.out.buf.data_ptr(),
-                                       self.out.buf.numel()))]
+                                       self.flat))]
 
     def bwd_calls(self, plan):
         if self.out.grad is None:
             return []
-        if not self.out.grad.is_contiguous():
-            raise L.MMLError("MulOp needs a contiguous output gradient")
+        if self.out.grad.stride(0) != self.out.buf.stride(0):
+            raise L.MMLError("MulOp: value / gradient pitch mismatch")
         da = db = None
         acc_a = acc_b = 0
         if self.a.needs_grad:
@@ -558,7 +635,7 @@ class MulOp(Op):
         if da is None and db is None:
             return []
         return [(L.load().mml_ew_mul_bwd, (self.out.grad.data_ptr(), self.a.buf.data_ptr(), self.b.buf.data_ptr(),
-                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.out.buf.numel()))]
+                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.flat))]
 
 
 class CopyColsOp(Op):

@@ -245,7 +245,7 @@ class BaseModel(nn.Module):
                 if self.feature_index[f.name][0] != pos:
                     raise NotImplementedError("dense feature columns must be contiguous in X")
                 pos += f.dimension
-        x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input")
+        x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input", pad_k=True)
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
         cols = [self.feature_index[f.name][0] for f in sp]
         sharding = getattr(self, "_sharding", None)

@@ -76,10 +76,10 @@ class PepNet(BaseModel):
         l1, l2 = [], []
         for pfx, gin in gin_vals:
             w0 = store.pvals[f"{pfx}.gate.0.weight"]
-            h = plan.val(w0.data.shape[0], act=L.ACT_RELU, name=pfx + ".h")
+            h = plan.val(w0.data.shape[0], act=L.ACT_RELU, name=pfx + ".h", pad_k=True)
             l1.append(dict(x=gin, W=w0, b=store.pvals[f"{pfx}.gate.0.bias"], out=h))
             w2 = store.pvals[f"{pfx}.gate.2.weight"]
-            g = plan.val(w2.data.shape[0], act=L.ACT_SIGMOID2, name=pfx + ".g")
+            g = plan.val(w2.data.shape[0], act=L.ACT_SIGMOID2, name=pfx + ".g", pad_k=True)
             l2.append(dict(x=h, W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g))
         plan.add(E.LinearGroupOp(l1))
         plan.add(E.LinearGroupOp(l2))
@@ -93,13 +93,14 @@ class PepNet(BaseModel):
         scene = x0.buf[:, p * Edim:(p + 1) * Edim]
 
         def gate_input(src_val, name):
-            buf = plan.empty(plan.B, K0 + Edim)
-            plan.add(E.CopyColsOp(src_val.buf, buf[:, :K0]))
-            plan.add(E.CopyColsOp(scene, buf[:, K0:]))
-            return E.Val(buf, L.ACT_NONE, needs_grad=False, name=name)
+            # (zero-padded rows: K0 + E is rarely a multiple of the GEMM's 16-wide k-step, e.g. 64 + 8)
+            v = plan.val(K0 + Edim, needs_grad=False, name=name, pad_k=True)
+            plan.add(E.CopyColsOp(src_val.buf, v.buf[:, :K0]))
+            plan.add(E.CopyColsOp(scene, v.buf[:, K0:]))
+            return v
 
         fg = self._gate_nn(plan, store, "feature_gate", [("feature_gate", gate_input(x0, "epnet_in"))])[0]
-        x2 = plan.val(K0, name="gated_input")
+        x2 = plan.val(K0, name="gated_input", pad_k=True)
         plan.add(E.MulOp(fg, x0, x2))
         gin = gate_input(x2, "ppnet_in")
         gws = self._gate_nn(plan, store, "ppn", [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T)
@@ -109,13 +110,13 @@ class PepNet(BaseModel):
         for l in range(nl + 1):
             hins = []
             for t in range(T):
-                hin = plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}")
+                hin = plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True)
                 plan.add(E.MulOp(hidden[t], gws[t * (nl + 1) + l], hin))
                 hins.append(hin)
             if l < nl:
                 probs = [dict(x=hins[t], W=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.weight"],
                               b=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.bias"],
-                              out=plan.val(self.dnn_hidden_units[l], act=L.ACT_RELU, name=f"ppn.{t}.h.{l}"))
+                              out=plan.val(self.dnn_hidden_units[l], act=L.ACT_RELU, name=f"ppn.{t}.h.{l}", pad_k=True))
                          for t in range(T)]
                 plan.add(E.LinearGroupOp(probs))
                 hidden = [q["out"] for q in probs]

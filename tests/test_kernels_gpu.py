@@ -395,6 +395,30 @@ def test_elementwise(ops):
     assert np.allclose(dst.cpu().numpy(), d * 2 * sg * (1 - sg), rtol=1e-5, atol=1e-6)
 
 
+def test_copy2d_batch(ops):
+    """mml_copy2d_batch: independent [rows_i, cols_i] copies (different shapes and pitches) in one launch."""
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 303), (64, 303), (4, 56), (1, 1), (128, 72)] * 8  # 40 items: more than one launch
+    items, refs = [], []
+    arr = (L.Copy2dDesc * len(shapes))()
+    for k, (r, c) in enumerate(shapes):
+        src = torch.randn(r, c + 3, generator=g).to(dev())
+        dst = torch.randn(r, c + 13, generator=g).to(dev())
+        acc = k % 2
+        ref = dst.clone()
+        ref[:, :c] = ref[:, :c] + src[:, :c] if acc else src[:, :c]
+        d = arr[k]
+        d.src, d.lds, d.dst, d.ldd, d.rows, d.cols, d.accumulate = src.data_ptr(), c + 3, dst.data_ptr(), c + 13, r, c, acc
+        items.append((src, dst))
+        refs.append(ref)
+    assert lib.mml_copy2d_batch(arr, len(shapes), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for (src, dst), ref in zip(items, refs):
+        assert torch.equal(dst, ref)
+
+
 @pytest.mark.parametrize("widths,rows,accumulate", [
     ([8, 8, 16, 8], 1000, 0),        # every segment a multiple of four floats: 16-byte kernel
     ([8] * 30, 4099, 1),             # the row-exchange shape (30 fields, E = 8), accumulate
