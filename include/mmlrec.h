@@ -278,6 +278,11 @@ int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t wor
 int mml_ew_mul(const float* a, const float* b, float* out, int64_t n, mml_stream_t stream);
 int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
                    int32_t acc_b, int64_t n, mml_stream_t stream);
+/* mul_bwd with the derivative of the activation that PRODUCED an operand folded in (act_* != MML_ACT_NONE: the operand
+ * holds the activation's output and this product is its only consumer; the gradient written is then the one w.r.t. the
+ * pre-activation): PepNet's h * 2*sigmoid(gate) products, model/pepnet.py:72-78 -- saves the separate act' pass */
+int mml_ew_mul_bwd_act(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
+                       int32_t acc_b, int64_t n, int32_t act_a, int32_t act_b, mml_stream_t stream);
 int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mml_stream_t stream);
 /* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,
  * model/pepnet.py:72, :139) */

@@ -101,6 +101,7 @@ _SIGS = {
     "mml_head_bce_fwd_bwd": (C.c_int, [_PP(HeadGroup), fp, i64, fp]),
     "mml_ew_mul": (C.c_int, [fp, fp, fp, i64, fp]),
     "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
+    "mml_ew_mul_bwd_act": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, i32, i32, fp]),
     "mml_ew_add_n": (C.c_int, [_PP(fp), i32, fp, i64, fp]),
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),

@@ -345,17 +345,28 @@ __global__ __launch_bounds__(256) void ew_mul_kernel(const float* a, const float
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] * b[i];
 }
 
+// act_a / act_b: the operand is the OUTPUT of that activation and this product is its only consumer, so the
+// activation's derivative (from the output value, like mml_act_bwd) is folded into the gradient written here
+__device__ __forceinline__ float act_deriv_from_output(float y, int act) {
+  if (act == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MML_ACT_SIGMOID2) return y * (1.f - 0.5f * y);
+  return 1.f;
+}
 __global__ __launch_bounds__(256) void ew_mul_bwd_kernel(const float* dout, const float* a, const float* b, float* da,
-                                                         float* db, int acc_a, int acc_b, int64_t n) {
+                                                         float* db, int acc_a, int acc_b, int64_t n, int act_a,
+                                                         int act_b) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float d = dout[i];
+    const float av = (db || act_a) ? a[i] : 0.f;
+    const float bv = (da || act_b) ? b[i] : 0.f;
     if (da) {
-      const float v = d * b[i];
+      const float v = d * bv * act_deriv_from_output(av, act_a);
       da[i] = acc_a ? da[i] + v : v;
     }
     if (db) {
-      const float v = d * a[i];
+      const float v = d * av * act_deriv_from_output(bv, act_b);
       db[i] = acc_b ? db[i] + v : v;
     }
   }
@@ -641,15 +652,25 @@ extern "C" int mml_ew_mul(const float* a, const float* b, float* out, int64_t n,
   return check_launch("mml_ew_mul");
 }
 
-extern "C" int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
-                              int32_t acc_b, int64_t n, mml_stream_t stream) {
+extern "C" int mml_ew_mul_bwd_act(const float* dout, const float* a, const float* b, float* da, float* db,
+                                  int32_t acc_a, int32_t acc_b, int64_t n, int32_t act_a, int32_t act_b,
+                                  mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || dout), "mml_ew_mul_bwd: null dout");
   MML_REQUIRE(!da || b, "mml_ew_mul_bwd: da needs b");
   MML_REQUIRE(!db || a, "mml_ew_mul_bwd: db needs a");
+  MML_REQUIRE(act_a >= MML_ACT_NONE && act_a <= MML_ACT_SIGMOID2 && act_b >= MML_ACT_NONE && act_b <= MML_ACT_SIGMOID2,
+              "mml_ew_mul_bwd: unknown activation");
+  MML_REQUIRE((!act_a || (a && da && !acc_a)) && (!act_b || (b && db && !acc_b)),
+              "mml_ew_mul_bwd: a folded activation derivative needs the operand, its gradient, and no accumulation");
   if (n == 0) return MML_OK;
   MML_LAUNCH(ew_mul_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), dout, a, b, da, db, acc_a,
-                     acc_b, n);
+                     acc_b, n, act_a, act_b);
   return check_launch("mml_ew_mul_bwd");
+}
+
+extern "C" int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
+                              int32_t acc_b, int64_t n, mml_stream_t stream) {
+  return mml_ew_mul_bwd_act(dout, a, b, da, db, acc_a, acc_b, n, MML_ACT_NONE, MML_ACT_NONE, stream);
 }
 
 extern "C" int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mml_stream_t stream) {

@@ -617,7 +617,7 @@ class MulOp(Op):
 
     def fwd_calls(self, plan):
         return [(L.load().mml_ew_mul, (self.a.buf.data_ptr(), self.b.buf.data_ptr(), self.out.buf.data_ptr(),
-                                       self.flat))]
+                                       self.flat), dict(kernel="ew_mul_kernel", bytes=12.0 * self.flat))]
 
     def bwd_calls(self, plan):
         if self.out.grad is None:
@@ -634,8 +634,18 @@ class MulOp(Op):
             acc_b = _claim(self.b)
         if da is None and db is None:
             return []
-        return [(L.load().mml_ew_mul_bwd, (self.out.grad.data_ptr(), self.a.buf.data_ptr(), self.b.buf.data_ptr(),
-                                           L.ptr(da), L.ptr(db), acc_a, acc_b, self.flat))]
+        # an operand that is an activation's output and feeds nothing else: fold act' into the gradient written here
+        # (Plan.finish would otherwise add a separate read-modify-write pass over it)
+        acts = []
+        for v, g, acc in ((self.a, da, acc_a), (self.b, db, acc_b)):
+            fold = (g is not None and not acc and v.act != L.ACT_NONE and not v.deriv_applied and
+                    len(v.consumers) == 1)
+            acts.append(v.act if fold else L.ACT_NONE)
+            if fold:
+                v.deriv_applied = True
+        return [(L.load().mml_ew_mul_bwd_act, (self.out.grad.data_ptr(), self.a.buf.data_ptr(), self.b.buf.data_ptr(),
+                                               L.ptr(da), L.ptr(db), acc_a, acc_b, self.flat, acts[0], acts[1]),
+                 dict(kernel="ew_mul_bwd_kernel", bytes=4.0 * self.flat * (3 + (da is not None) + (db is not None))))]
 
 
 class CopyColsOp(Op):

@@ -380,6 +380,19 @@ def test_elementwise(ops):
     ops.ew_mul_bwd(T(d), T(a), T(b), da=da, db=db, acc_a=True)
     assert np.allclose(da.cpu().numpy(), a + d * b, rtol=1e-6, atol=1e-6)
     assert np.array_equal(db.cpu().numpy(), d * a)
+    # folded activation derivatives: a is a relu output, b a 2*sigmoid output, each consumed only by this product
+    lib = L.load()
+    ar = np.maximum(a, 0).astype(np.float32)
+    bs = (2 / (1 + np.exp(-b))).astype(np.float32)
+    da2, db2 = torch.empty(300, 70, device=dev()), torch.empty(300, 70, device=dev())
+    tar, tbs, td = T(ar), T(bs), T(d)
+    rc = lib.mml_ew_mul_bwd_act(td.data_ptr(), tar.data_ptr(), tbs.data_ptr(), da2.data_ptr(), db2.data_ptr(), 0, 0,
+                                ar.size, L.ACT_RELU, L.ACT_SIGMOID2, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.allclose(da2.cpu().numpy(), d * bs * (ar > 0), rtol=1e-6, atol=1e-7)
+    assert np.allclose(db2.cpu().numpy(), d * ar * bs * (1 - bs / 2), rtol=1e-5, atol=1e-7)
+    assert lib.mml_ew_mul_bwd_act(td.data_ptr(), tar.data_ptr(), tbs.data_ptr(), da2.data_ptr(), db2.data_ptr(), 1, 0,
+                                  ar.size, L.ACT_RELU, 0, torch.cuda.current_stream().cuda_stream) != 0  # acc + fold
     s = torch.empty(300, 70, device=dev())
     ops.ew_add_n([T(a), T(b), T(d)], s)
     assert np.allclose(s.cpu().numpy(), a + b + d, rtol=1e-6, atol=1e-6)
