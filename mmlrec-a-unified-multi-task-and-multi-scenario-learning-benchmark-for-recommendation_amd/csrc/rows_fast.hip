@@ -114,12 +114,17 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   constexpr int SPW = 64 / LPS;
   float* Wsm = smem;                                   // [wg_total] gate weights
   float* coef_all = smem + aux.wg_total;               // [FW*SPW][NG*MML_MAX_EXPERTS] softmax coefficients per sample
-  float* red = coef_all + FW * SPW * NG * MML_MAX_EXPERTS;  // [FW][wg_total] per-wave dWg partials
+  // dWg partial sums live in LDS, one [wg_total] region per LANE GROUP (= per sample slot of a wave): the group's lanes
+  // read-modify-write their own 16 bytes, no atomics, fixed order.  (In registers they cost NG*NE float4 per lane --
+  // 128 VGPRs for a PLE level with 3 gates over 8 experts, one or two waves per SIMD for a kernel that lives on
+  // memory-level parallelism.)
+  float* red = coef_all + FW * SPW * NG * MML_MAX_EXPERTS;  // [FW*SPW][wg_total]
   for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
     int gi = 0;
     while (gi + 1 < g.n_gates && i >= aux.wg_off[gi + 1]) ++gi;
     Wsm[i] = g.gate[gi].active ? g.gate[gi].Wg[i - aux.wg_off[gi]] : 0.f;
   }
+  for (int i = threadIdx.x; i < FW * SPW * aux.wg_total; i += FB) red[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPS, grp = lane / LPS;
@@ -128,11 +133,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
 
-  float4 wacc[NG][NE];
-#pragma unroll
-  for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-    for (int e = 0; e < NE; ++e) wacc[gi][e] = make_float4(0, 0, 0, 0);
+  float* myred = red + (wave * SPW + grp) * aux.wg_total;
 
   if constexpr (IDENT) {
   // every gate mixes experts 0..ne-1 in order (MMoE): one set of expert rows serves all gates and the final dE loop
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
         for (int e = 0; e < NE; ++e)
           if (e < d.ne) {
             fma4(dg, dl[e], ld4(W + e * d.Gd + 4 * sub));
-            fma4(wacc[gi][e], dl[e], Gv[gi]);
+            float* r = myred + aux.wg_off[gi] + e * d.Gd + 4 * sub;
+            float4 t = ld4(r);
+            fma4(t, dl[e], Gv[gi]);
+            st4(r, t);
           }
         if (d.g_relu) {
           if (!(Gv[gi].x > 0.f)) dg.x = 0.f;
@@ -257,7 +261,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
         for (int e = 0; e < NE; ++e)
           if (e < d.ne) {
             fma4(dg, dl[e], ld4(W + e * d.Gd + 4 * sub));
-            fma4(wacc[gi][e], dl[e], Gv);
+            float* r = myred + aux.wg_off[gi] + e * d.Gd + 4 * sub;
+            float4 t = ld4(r);
+            fma4(t, dl[e], Gv);
+            st4(r, t);
           }
         if (d.g_relu) {
           if (!(Gv.x > 0.f)) dg.x = 0.f;
@@ -288,28 +295,13 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
     __builtin_amdgcn_wave_barrier();
   }
   }
-  // combine: lane groups of a wave (shuffles) -> per-wave LDS rows -> fixed-order sum over waves -> slab
-#pragma unroll
-  for (int gi = 0; gi < NG; ++gi) {
-    if (gi >= g.n_gates || !g.gate[gi].active) continue;
-    const int Gd = g.gate[gi].Gd, ne = g.gate[gi].ne;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      if (e >= ne) continue;
-      float4 v = wacc[gi][e];
-      v.x = cross_group_sum<LPS>(v.x);
-      v.y = cross_group_sum<LPS>(v.y);
-      v.z = cross_group_sum<LPS>(v.z);
-      v.w = cross_group_sum<LPS>(v.w);
-      if (grp == 0 && 4 * sub < Gd) st4(red + wave * aux.wg_total + aux.wg_off[gi] + e * Gd + 4 * sub, v);
-    }
-  }
+  // combine: fixed-order sum over the lane-group regions -> slab
   __syncthreads();
   float* out = aux.slab + (int64_t)blockIdx.x * aux.wg_total;
   for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < FW; ++w) s += red[w * aux.wg_total + i];
+    for (int w = 0; w < FW * SPW; ++w) s += red[w * aux.wg_total + i];
     out[i] = s;
   }
 }
@@ -467,8 +459,8 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
   }
   aux.lps = pick_lps(width);
   aux.ne = nemax <= 4 ? 4 : (nemax <= 8 ? 8 : 16);
-  aux.ng = g->n_gates <= 2 ? 2 : (g->n_gates <= 4 ? 4 : 8);
-  if (bwd && aux.ne * aux.ng > 32) return 0;  // register budget of the dWg accumulators
+  aux.ng = g->n_gates <= 2 ? 2 : (g->n_gates == 3 ? 3 : (g->n_gates <= 4 ? 4 : 8));  // 3: a PLE level at T = 2
+  if (bwd && aux.ne * aux.ng > 32) return 0;  // register budget (upstream gradients, coefficients)
   static int fwd_per_cu = -1;
   if (fwd_per_cu < 0) {
     const char* e = getenv("MMLREC_GATE_FWD_WGS");
@@ -501,7 +493,7 @@ int gate_fwd_fast(const mml_gate_group* g, hipStream_t st) {
 
 size_t gate_bwd_fast_lds(const GateFastAux& aux) {
   const int spw = 64 / aux.lps;
-  return ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)FW * aux.wg_total) * 4;
+  return ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)FW * spw * aux.wg_total) * 4;
 }
 
 template <int LPS>
@@ -517,6 +509,8 @@ static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipS
   else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
   else if (aux.ne == 4 && aux.ng == 8) MML_GB(4, 8);
   else if (aux.ne == 8 && aux.ng == 2) MML_GB(8, 2);
+  else if (aux.ne == 8 && aux.ng == 3) MML_GB(8, 3);
+  else if (aux.ne == 4 && aux.ng == 3) MML_GB(4, 3);
   else if (aux.ne == 8 && aux.ng == 4) MML_GB(8, 4);
   else if (aux.ne == 16 && aux.ng == 2) MML_GB(16, 2);
   else return 1;
