@@ -37,4 +37,11 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(out, f"{tag}_kernel_stats_bench_line.json"), "w").write(lines[-1])
+gout = os.path.join(root, "gpurun_out")
+for src, dst in (("secondary.jsonl", f"{tag}_secondary.jsonl"), ("bench_default.json", f"{tag}_bench_line.json")):
+    p = os.path.join(gout, src)
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            open(os.path.join(out, dst), "w").write("".join(lines if src.endswith("jsonl") else lines[-1:]))
 print("profiles updated:", sorted(os.listdir(out)))
