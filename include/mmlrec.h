@@ -308,6 +308,17 @@ int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
  * All arrays are HOST arrays of n_seg entries holding device pointers / element strides. */
 int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst, const int64_t* ldd,
                   const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate, mml_stream_t stream);
+/* ----------------------------------------------------------------------------------------------
+ * Per-batch AUC on the device.  Replaces sklearn.metrics.roc_auc_score run on the host for every
+ * training step (model/basemodel.py:316-331; the epoch log averages the per-step values, :335-337): for every segment
+ * of `seg` consecutive rows (the last one may be shorter) and every column c < cols,
+ *     auc[s * cols + c] = roc_auc_score(y[rows, c] > 0.5, pred[rows, c])
+ * with sklearn's tie handling (Mann-Whitney with half credit inside a tie group, evaluated in integer arithmetic), NaN
+ * when the segment holds a single class (sklearn raises ValueError there).  seg <= 4096 (one workgroup sorts one
+ * segment column in LDS); larger segments return MML_ERR_UNSUPPORTED.  `auc` is a DEVICE array of ceil(n/seg)*cols doubles.
+ * ---------------------------------------------------------------------------------------------- */
+int mml_auc_segments(const float* pred, int64_t ldp, const float* y, int64_t ldy, int64_t n, int32_t cols, int32_t seg,
+                     double* auc, mml_stream_t stream);
 /* dst = act'(y) * dy for MML_ACT_SIGMOID2 / SIGMOID / RELU given the forward OUTPUT y (GateNN backward) */
 int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t n, int32_t act, mml_stream_t stream);
 

@@ -465,9 +465,15 @@ class BaseModel(nn.Module):
             epoch_logs = {"loss": float(loss_dev.item()) / n, "cka_loss": 0.0}
             # per-batch train metrics, averaged over steps exactly like the reference (:316-337), computed once
             # per epoch on the host instead of once per step
-            pe = pred_epoch.cpu().numpy().astype("float64")
-            ye = y[perm.numpy()]
+            dev_metrics = self._device_batch_metrics(pred_epoch, yd, perm_d, batch_size)
+            pe = ye = None
             for name, fn in self.metrics.items():
+                if name in dev_metrics:
+                    epoch_logs[name] = dev_metrics[name]
+                    continue
+                if pe is None:
+                    pe = pred_epoch.cpu().numpy().astype("float64")
+                    ye = y[perm.numpy()]
                 vals = []
                 for s in range(steps_per_epoch):
                     sl = slice(s * batch_size, (s + 1) * batch_size)
@@ -499,6 +505,40 @@ class BaseModel(nn.Module):
             if early_stop >= self.optim_config.get("early_stop", 3):
                 break
         return best_model if best_model is not None else self  # reference D7: unbound when nothing improved
+
+    def _device_batch_metrics(self, pred, yd, perm_d, batch_size):
+        """Per-batch `auc` / `acc` averaged over the steps of an epoch, computed where the predictions already are
+        (reference: sklearn on the host after every step, model/basemodel.py:316-337).  Same task-mode reductions as
+        _metric: msl -> (label 0, sum of the heads); mtmsl -> per label group; mtl -> sklearn's multilabel behaviour
+        (macro-average AUC over tasks, exact-match accuracy).  Returns {} when a metric cannot be done on the device
+        (batches over 4096 rows): the caller then falls back to the host path."""
+        want = [m for m in self.metrics if m in ("auc", "acc", "accuracy")]
+        if not want or batch_size > 4096 or not pred.is_cuda:
+            return {}
+        ye = yd.index_select(0, perm_d)
+        if self.task_name == "msl":
+            yt, pt = ye[:, :1], pred.sum(-1, keepdim=True)
+        elif self.task_name == "mtmsl":
+            D = self.num_domains
+            yt = ye[:, [0, D]]
+            pt = torch.stack([pred[:, :D].sum(-1), pred[:, D:].sum(-1)], -1)
+        else:
+            yt, pt = ye, pred
+        yt, pt = yt.contiguous(), pt.contiguous()
+        n = pt.shape[0]
+        steps = (n - 1) // batch_size + 1
+        out = {}
+        if "auc" in want:
+            a = ops.auc_segments(pt, yt, batch_size)            # [steps, C]; NaN = single-class batch
+            out["auc"] = float(a.mean(1).sum().item()) / steps  # macro average over columns, mean over steps
+        for name in ("acc", "accuracy"):
+            if name in want:
+                hit = ((pt > 0.5) == (yt > 0.5)).all(1).to(torch.float64)  # exact match over the columns
+                seg = torch.arange(n, device=pt.device) // batch_size
+                per = torch.zeros(steps, dtype=torch.float64, device=pt.device).index_add_(0, seg, hit)
+                cnt = torch.zeros(steps, dtype=torch.float64, device=pt.device).index_add_(0, seg, torch.ones_like(hit))
+                out[name] = float((per / cnt).sum().item()) / steps
+        return out
 
     def _metric(self, fn, y_true, y_pred):
         """Task-mode specific metric reduction (reference :320-331, :383-392)."""

@@ -371,3 +371,15 @@ def opt_catchup_dense(table, state1, state2, last, hyper):
 
 def counter_update(counter, delta=1, reset=False):
     L.check(L.load().mml_counter_update(counter.data_ptr(), int(delta), int(reset), _stream()), "mml_counter_update")
+
+
+def auc_segments(pred, y, seg):
+    """AUC of every (segment of `seg` rows, column) pair of device matrices pred / y [n, C] -> float64 [ceil(n/seg), C]
+    (NaN where a segment holds one class).  Device counterpart of the per-step sklearn roc_auc_score of the reference
+    loop (model/basemodel.py:316-331)."""
+    lib = L.load()
+    n, c = pred.shape
+    out = torch.empty(((n + seg - 1) // seg, c), dtype=torch.float64, device=pred.device)
+    L.check(lib.mml_auc_segments(pred.data_ptr(), pred.stride(0), y.data_ptr(), y.stride(0), n, c, int(seg),
+                                 out.data_ptr(), _stream()), "mml_auc_segments")
+    return out

@@ -530,3 +530,38 @@ def test_lazy_exact_optimizer_matches_dense_trajectory(ops, kind):
                     assert rel(fv[f].cpu().numpy(), dv[f].cpu().numpy()) < 2e-5, (kind, step, f, "state2")
     for f in range(F):
         assert float(lG[f].abs().max()) == 0.0 and int(seen[f].abs().max()) == 0
+
+
+@pytest.mark.parametrize("n,cols,seg", [(1000, 2, 256), (4096 * 3 + 17, 1, 4096), (5000, 3, 1000), (300, 2, 300), (64, 1, 7)])
+def test_auc_segments_match_sklearn(ops, n, cols, seg):
+    """mml_auc_segments == sklearn.metrics.roc_auc_score per (batch, column) -- what the reference evaluates on the
+    host after every step (model/basemodel.py:316-331) -- including heavy ties, exact 0 / 1 predictions, -0.0, and
+    single-class batches (sklearn raises; the kernel reports NaN)."""
+    from sklearn.metrics import roc_auc_score
+    rng = np.random.default_rng(n + seg)
+    pred = rng.random((n, cols)).astype(np.float32)
+    pred[:, 0] = np.round(pred[:, 0] * 8) / 8           # nine distinct values: large tie groups incl. 0.0 and 1.0
+    if cols > 1:
+        pred[::7, 1] = -0.0
+        pred[1::7, 1] = 0.0
+    y = (rng.random((n, cols)) < 0.3).astype(np.float32)
+    y[:min(seg, n), -1] = 1.0                             # first segment of the last column: one class only
+    got = ops.auc_segments(T(pred), T(y), seg).cpu().numpy()
+    nseg = (n + seg - 1) // seg
+    assert got.shape == (nseg, cols)
+    for s in range(nseg):
+        sl = slice(s * seg, min(n, (s + 1) * seg))
+        for c in range(cols):
+            yt = y[sl, c]
+            if yt.min() == yt.max():
+                assert np.isnan(got[s, c])
+                continue
+            want = roc_auc_score(yt, pred[sl, c].astype(np.float64))
+            assert abs(got[s, c] - want) < 1e-12, (s, c, got[s, c], want)
+
+
+def test_auc_segments_rejects_long_segments(ops):
+    from mmlrec_amd import _lib as L
+    p = torch.rand(10000, 1, device=dev())
+    with pytest.raises(L.MMLError):
+        ops.auc_segments(p, (p > 0.5).float(), 5000)
