@@ -68,6 +68,15 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
       float p[NE];
       const bool gcol = 4 * sub < d.Gd;
       float4 Gv = gcol ? ld4(d.G + b * d.ldg + 4 * sub) : make_float4(0, 0, 0, 0);
+      // the expert rows of this gate, requested before the logits / softmax arithmetic that hides their latency:
+      // straight-line loads with a clamped expert slot (a load inside `if (e < ne)` sits in its own basic block and
+      // is waited for one at a time)
+      float4 Ev[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int x = d.expert[e < d.ne ? e : d.ne - 1];
+        Ev[e] = hcol ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+      }
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         p[e] = -INFINITY;
@@ -96,11 +105,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
       if (hcol) {
         float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
-          if (e < d.ne) {
-            const int x = d.expert[e];
-            fma4(acc, p[e], ld4(g.E[x] + b * g.lde[x] + 4 * sub));
-          }
+        for (int e = 0; e < NE; ++e) fma4(acc, p[e], Ev[e]);  // p[e] == 0 beyond the gate's expert count
         if (valid) st4(d.mix + b * d.ldmix + 4 * sub, acc);
       }
     }
@@ -238,17 +243,26 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
       if (hcol) dmv[gi] = ld4(d.dmix + b * d.lddmix + 4 * sub);
       float dl[NE], p[NE];
       float dot = 0.f;
+      {
+        // all loads of the gate first, in straight-line code (clamped expert slot), then the reductions
+        float4 Ev[NE];
 #pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        dl[e] = 0.f;
-        p[e] = 0.f;
-        if (e < d.ne) {
-          const int x = d.expert[e];
-          const float part = hcol ? dot4(dmv[gi], ld4(g.E[x] + b * g.lde[x] + 4 * sub)) : 0.f;
-          dl[e] = group_sum<LPS>(part);
-          p[e] = d.P[b * d.ldp + e];
-          dot += p[e] * dl[e];
-          if (sub == 0) coef[gi * MML_MAX_EXPERTS + x] = p[e];
+        for (int e = 0; e < NE; ++e) {
+          const int ec = e < d.ne ? e : d.ne - 1;
+          const int x = d.expert[ec];
+          Ev[e] = hcol ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+          p[e] = d.P[b * d.ldp + ec];
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          dl[e] = 0.f;
+          if (e < d.ne) {
+            dl[e] = group_sum<LPS>(dot4(dmv[gi], Ev[e]));
+            dot += p[e] * dl[e];
+            if (sub == 0) coef[gi * MML_MAX_EXPERTS + d.expert[e]] = p[e];
+          } else {
+            p[e] = 0.f;
+          }
         }
       }
 #pragma unroll
