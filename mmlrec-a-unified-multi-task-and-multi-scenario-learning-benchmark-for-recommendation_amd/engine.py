@@ -558,11 +558,20 @@ class HeadOp(Op):
                     h["_acc"] = acc
                     post.append((lib.mml_copy2d, (tmp.data_ptr(), ops._ld(tmp), Hin.grad.data_ptr(), ops._ld(Hin.grad),
                                                   plan.B, Hin.n, acc)))
-                q["dw"] = h["w"].grad
                 q["dbias"] = h["bias"].grad
                 if claim:
-                    if _claim(h["w"]) or _claim(h["bias"]):
-                        raise NotImplementedError("head weights shared between heads")
+                    h["_acc_w"] = _claim(h["w"])
+                    if _claim(h["bias"]):
+                        raise NotImplementedError("head bias shared between heads")
+                if h["_acc_w"]:
+                    # a weight shared by several heads (reference model/mlp.py:28): this head's gradient goes to a
+                    # scratch row that is added to the parameter's gradient after the launch
+                    tmpw = h.setdefault("_dw_tmp", plan.empty(h["w"].data.numel()))
+                    q["dw"] = tmpw
+                    n = tmpw.numel()
+                    post.append((lib.mml_copy2d, (tmpw.data_ptr(), n, h["w"].grad.data_ptr(), n, 1, n, 1)))
+                else:
+                    q["dw"] = h["w"].grad
                 b2 = h.get("bias2")
                 if b2 is not None and b2.needs_grad:
                     acc = _claim(b2) if claim else h["_acc_b2"]

@@ -257,10 +257,15 @@ class BaseModel(nn.Module):
             plan.add(E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)
-        if self.task_name in ("msl", "mtmsl"):
-            head.mask_cols = [i if self.task_name == "msl" else i % self.num_domains for i in range(T)]
+        head.mask_cols = self._head_mask_cols()
         plan.finish(head)
         return plan
+
+    def _head_mask_cols(self):
+        """Column of domain_mask that multiplies head i (e.g. model/mmoe.py:101-106), or None for unmasked heads."""
+        if self.task_name in ("msl", "mtmsl"):
+            return [i if self.task_name == "msl" else i % self.num_domains for i in range(self.num_tasks)]
+        return None
 
     def _build_graph(self, plan, store, x0):
         raise NotImplementedError

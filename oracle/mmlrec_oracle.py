@@ -312,6 +312,37 @@ def sharedbottom_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
+def mlp_fwd(spec, params, x):
+    """MLP.forward (model/mlp.py:36-66): a chain of one-layer DNN blocks, ONE final Linear(H -> 1, no bias) shared by
+    all tasks, then a PredictionLayer per task applied to that SAME logit tensor.  PredictionLayer adds its bias IN
+    PLACE (`output = X; output += self.bias`, model/utils.py:242-245), so the biases pile up on the shared tensor:
+    head t sees z + b_0 + ... + b_t.  Restated as the reference behaves."""
+    n = len(spec.mc.get("dnn_hidden_units", [256, 128]))
+    h, acts, layers = x, [], {}
+    for i in range(n):
+        h, a = dnn_fwd(params, f"mlp_layers.{i}", h)
+        acts.append(a)
+        layers[f"mlp_output_{i}"] = h
+    z = linear_fwd(h, params["final_layer.weight"])[:, 0]
+    ps = []
+    for t in range(spec.T):
+        z = (z + params[f"out.{t}.bias"][0]).astype(F32)
+        ps.append(sigmoid(z))
+    return np.stack(ps, 1).astype(F32), dict(acts=acts, last=h, layers=layers)
+
+
+def mlp_bwd(spec, params, cache, dlogit):
+    grads = {}
+    for j in range(spec.T):  # bias j reaches the logits of heads j, j+1, ...
+        _acc(grads, f"out.{j}.bias", dlogit[:, j:].sum(axis=(0, 1), keepdims=False).reshape(1))
+    dz = dlogit.sum(1, keepdims=True).astype(F32)  # every head reads the same logit
+    dh, dW, _ = linear_bwd(cache["last"], params["final_layer.weight"], dz, has_bias=False)
+    _acc(grads, "final_layer.weight", dW)
+    for i in reversed(range(len(cache["acts"]))):
+        dh = dnn_bwd(params, f"mlp_layers.{i}", cache["acts"][i], dh, grads)
+    return grads, dh
+
+
 def mmoe_fwd(spec, params, x):
     """MMOE.forward (model/mmoe.py:65-119)."""
     Ne = int(spec.mc.get("num_experts", 4))
@@ -600,8 +631,8 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_FWD = {"mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):
@@ -615,6 +646,8 @@ def forward(spec, params, X, mask=None, frozen=None):
     cache["dnn_input"] = x
     cache["idx"] = idx
     cache["p"] = p
+    if spec.model_name == "mlp" and spec.task_name != "msl":  # model/mlp.py:53-54 masks in the msl mode only
+        mask = None
     return apply_mask(spec, p, mask), cache
 
 
@@ -731,7 +764,14 @@ def param_shapes(spec):
             shapes[f"out.{t}.bias"] = (1,)
 
     name = spec.model_name
-    if name == "sharedbottom":
+    if name == "mlp":
+        k = K0
+        for i, u in enumerate(mc.get("dnn_hidden_units", [256, 128])):
+            k = dnn(f"mlp_layers.{i}", k, [u])
+        shapes["final_layer.weight"] = (1, k)
+        for t in range(T):
+            shapes[f"out.{t}.bias"] = (1,)
+    elif name == "sharedbottom":
         h = dnn("bottom_dnn", K0, mc.get("bottom_dnn_hidden_units", [256, 128]))
         towers(h)
     elif name in ("mmoe", "pcg"):

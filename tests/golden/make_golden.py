@@ -39,6 +39,7 @@ from model.mmoe import MMOE  # noqa: E402
 from model.ple import PLE  # noqa: E402
 from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
+from model.mlp import MLP  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 B = 64
@@ -102,6 +103,16 @@ def make_cases():
                                  "scene_feature": "scene"})
         cases.append(dict(name=f"{nm}_amazon", cls=cls, cfg=c,
                           vocab=[2, 12, 23, 96, 64, 64, 48, 2], nd=0, scene_last=True))
+    # SURVEY 8(f) rank 3, first of the remaining model zoo: MLP (model/mlp.py) on the MovieLens shape
+    c = base_config("mtl", "mlp", ["label2", "label3"], 8, "adam", 0.01,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"], dnn_hidden_units=[32, 16])
+    cases.append(dict(name="mlp_ml", cls=MLP, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # ... and in the msl mode (heads masked by domain, model/mlp.py:53-54) with dense columns
+    c = base_config("msl", "mlp", ["label", "label"], 8, "adam", 0.005, task_types=["binary", "binary"],
+                    dnn_hidden_units=[32, 16])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="mlp_ae", cls=MLP, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=5, scene_last=True))
     return cases
 
 
@@ -264,5 +275,7 @@ def run_case(case):
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])  # optional: names of the cases to (re)generate
     for case in make_cases():
-        run_case(case)
+        if not only or case["name"] in only:
+            run_case(case)
