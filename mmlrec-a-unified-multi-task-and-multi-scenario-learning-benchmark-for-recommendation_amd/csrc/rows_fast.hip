@@ -113,7 +113,9 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 }
 
 // ------------------------------------------------------------------------------------------------ gate backward
-template <int LPS, int NE, int NG, bool IDENT>
+// MODE 0: any expert lists; 1: every gate mixes experts 0..ne-1 in order (MMoE); 2: any membership, but at most NE
+// experts in the group -- every expert row is loaded ONCE per sample and serves all gates (PLE levels)
+template <int LPS, int NE, int NG, int MODE>
 __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group g, const GateFastAux aux) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SPW = 64 / LPS;
@@ -130,6 +132,17 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
     Wsm[i] = g.gate[gi].active ? g.gate[gi].Wg[i - aux.wg_off[gi]] : 0.f;
   }
   for (int i = threadIdx.x; i < FW * SPW * aux.wg_total; i += FB) red[i] = 0.f;
+  int* smap = reinterpret_cast<int*>(red + FW * SPW * aux.wg_total);  // [NG][NE] slot of expert x in gate gi, or -1
+  if constexpr (MODE == 2) {
+    for (int i = threadIdx.x; i < NG * NE; i += FB) {
+      const int gi = i / NE, x = i - gi * NE;
+      int slot = -1;
+      if (gi < g.n_gates && g.gate[gi].active)
+        for (int k = 0; k < g.gate[gi].ne; ++k)
+          if (g.gate[gi].expert[k] == x) slot = k;
+      smap[i] = slot;
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPS, grp = lane / LPS;
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 
   float* myred = red + (wave * SPW + grp) * aux.wg_total;
 
-  if constexpr (IDENT) {
+  if constexpr (MODE == 1) {
   // every gate mixes experts 0..ne-1 in order (MMoE): one set of expert rows serves all gates and the final dE loop
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
@@ -209,6 +222,92 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (hcol) {
+#pragma unroll
+      for (int x = 0; x < NE; ++x) {
+        if (x >= g.n_experts) continue;
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], dmv[gi]);
+        if (g.e_relu) {
+          if (!(Ev[x].x > 0.f)) acc.x = 0.f;
+          if (!(Ev[x].y > 0.f)) acc.y = 0.f;
+          if (!(Ev[x].z > 0.f)) acc.z = 0.f;
+          if (!(Ev[x].w > 0.f)) acc.w = 0.f;
+        }
+        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  } else if constexpr (MODE == 2) {
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;
+    for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
+    // all loads of the sample first: every expert row once, the upstream gradients and gate inputs of every gate
+    float4 Ev[NE], dmv[NG], Gv[NG];
+#pragma unroll
+    for (int x = 0; x < NE; ++x)
+      Ev[x] = (hcol && x < g.n_experts) ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      dmv[gi] = make_float4(0, 0, 0, 0);
+      Gv[gi] = make_float4(0, 0, 0, 0);
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      if (!d.active) continue;
+      if (hcol) dmv[gi] = ld4(d.dmix + b * d.lddmix + 4 * sub);
+      if (4 * sub < d.Gd) Gv[gi] = ld4(d.G + b * d.ldg + 4 * sub);
+      // softmax probabilities, by EXPERT index, through LDS: lane x of the group fetches the one of expert x
+      if (sub < NE) {
+        const int slot = smap[gi * NE + sub];
+        if (slot >= 0) coef[gi * MML_MAX_EXPERTS + sub] = d.P[b * d.ldp + slot];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      if (!d.active) continue;
+      float dl[NE];
+      float dot = 0.f;
+#pragma unroll
+      for (int x = 0; x < NE; ++x) {
+        dl[x] = 0.f;
+        const int slot = __builtin_amdgcn_readfirstlane(smap[gi * NE + x]);
+        if (slot >= 0) {
+          dl[x] = group_sum<LPS>(hcol ? dot4(dmv[gi], Ev[x]) : 0.f);
+          dot += coef[gi * MML_MAX_EXPERTS + x] * dl[x];
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < NE; ++x) dl[x] = valid ? coef[gi * MML_MAX_EXPERTS + x] * (dl[x] - dot) : 0.f;  // dlogit
+      if (4 * sub < d.Gd) {
+        const float* W = Wsm + aux.wg_off[gi];
+        float4 dg = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < NE; ++x) {
+          const int slot = __builtin_amdgcn_readfirstlane(smap[gi * NE + x]);
+          if (slot >= 0) {
+            fma4(dg, dl[x], ld4(W + slot * d.Gd + 4 * sub));
+            float* r = myred + aux.wg_off[gi] + slot * d.Gd + 4 * sub;
+            float4 t = ld4(r);
+            fma4(t, dl[x], Gv[gi]);
+            st4(r, t);
+          }
+        }
+        if (d.g_relu) {
+          if (!(Gv[gi].x > 0.f)) dg.x = 0.f;
+          if (!(Gv[gi].y > 0.f)) dg.y = 0.f;
+          if (!(Gv[gi].z > 0.f)) dg.z = 0.f;
+          if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
+        }
+        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+      }
+    }
     if (hcol) {
 #pragma unroll
       for (int x = 0; x < NE; ++x) {
@@ -507,17 +606,24 @@ int gate_fwd_fast(const mml_gate_group* g, hipStream_t st) {
 
 size_t gate_bwd_fast_lds(const GateFastAux& aux) {
   const int spw = 64 / aux.lps;
-  return ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)FW * spw * aux.wg_total) * 4;
+  return ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)FW * spw * aux.wg_total +
+          (size_t)aux.ng * aux.ne) * 4;
 }
 
 template <int LPS>
 static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
   const size_t lds = gate_bwd_fast_lds(aux);
   dim3 gr(aux.grid), bl(FB);
+  static int forced = -2;  // MMLREC_GATE_BWD_MODE=0|1|2: measurement knob (default: best applicable mode)
+  if (forced == -2) {
+    const char* e = getenv("MMLREC_GATE_BWD_MODE");
+    forced = e ? atoi(e) : -1;
+  }
 #define MML_GB(NE_, NG_)                                                                       \
   do {                                                                                         \
-    if (aux.ident && NE_ * NG_ <= 8) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, true>), gr, bl, lds, st, g, aux); \
-    else MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, false>), gr, bl, lds, st, g, aux);   \
+    if (aux.ident && NE_ * NG_ <= 8 && forced != 2 && forced != 0) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 1>), gr, bl, lds, st, g, aux); \
+    else if (g.n_experts <= NE_ && NE_ * NG_ <= 32 && forced != 0) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 2>), gr, bl, lds, st, g, aux); \
+    else MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 0>), gr, bl, lds, st, g, aux);   \
   } while (0)
   if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
   else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
