@@ -112,6 +112,94 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
   }
 }
 
+// Load-once forward (at most NE experts in the group, any membership): the softmax of every gate first, its
+// probabilities scattered BY EXPERT INDEX into a per-lane-group LDS row, then every expert row is read once and feeds all
+// gates' mixtures.  (The per-gate kernel above re-reads shared experts for every gate that mixes them: 2x the expert
+// traffic for MMoE, 2.25x for a PLE level -- and the second read misses L2: PMC 296 MB read vs 167 MB algorithmic.)
+template <int LPS, int NE, int NG>
+__global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group g, const GateFastAux aux) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int SPW = 64 / LPS;
+  float* coef_all = smem + aux.wg_total;  // [FW*SPW][NG*MML_MAX_EXPERTS]
+  int* emap = reinterpret_cast<int*>(coef_all + FW * SPW * NG * MML_MAX_EXPERTS);  // [NG][NE] expert of gate slot e
+  for (int i = threadIdx.x; i < aux.wg_total; i += FB) {
+    int gi = 0;
+    while (gi + 1 < g.n_gates && i >= aux.wg_off[gi + 1]) ++gi;
+    smem[i] = g.gate[gi].Wg[i - aux.wg_off[gi]];
+  }
+  for (int i = threadIdx.x; i < NG * NE; i += FB) {
+    const int gi = i / NE, e = i - gi * NE;
+    emap[i] = (gi < g.n_gates && e < g.gate[gi].ne) ? g.gate[gi].expert[e] : 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPS, grp = lane / LPS;
+  float* coef = coef_all + (wave * SPW + grp) * NG * MML_MAX_EXPERTS;
+  const int64_t stride = (int64_t)gridDim.x * FW * SPW;
+  const int64_t iters = (g.B + stride - 1) / stride;
+  const bool hcol = 4 * sub < g.H;
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    const bool valid = b < g.B;
+    if (!valid) b = g.B - 1;
+    for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
+    float4 Ev[NE], Gv[NG];
+#pragma unroll
+    for (int x = 0; x < NE; ++x)
+      Ev[x] = (hcol && x < g.n_experts) ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+      Gv[gi] = (gi < g.n_gates && 4 * sub < g.gate[gi].Gd) ? ld4(g.gate[gi].G + b * g.gate[gi].ldg + 4 * sub)
+                                                            : make_float4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();  // coef zeroed before the scattered writes below
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi >= g.n_gates) continue;
+      const mml_gate_desc& d = g.gate[gi];
+      const float* W = smem + aux.wg_off[gi];
+      const bool gcol = 4 * sub < d.Gd;
+      float p[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] = -INFINITY;
+        if (e < d.ne) p[e] = group_sum<LPS>(gcol ? dot4(Gv[gi], ld4(W + e * d.Gd + 4 * sub)) : 0.f);
+      }
+      float m = p[0];
+#pragma unroll
+      for (int e = 1; e < NE; ++e) m = fmaxf(m, p[e]);
+      float den = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] = (e < d.ne) ? expf(p[e] - m) : 0.f;
+        den += p[e];
+      }
+      const float inv = 1.f / den;
+      float mine = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        p[e] *= inv;
+        if (sub == e) mine = p[e];
+      }
+      if (sub < d.ne) {
+        if (valid) d.P[b * d.ldp + sub] = mine;
+        coef[gi * MML_MAX_EXPERTS + emap[gi * NE + sub]] = mine;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (hcol) {
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi >= g.n_gates) continue;
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < NE; ++x) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], Ev[x]);
+        if (valid) st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 4 * sub, acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gate backward
 // MODE 0: any expert lists; 1: every gate mixes experts 0..ne-1 in order (MMoE); 2: any membership, but at most NE
 // experts in the group -- every expert row is loaded ONCE per sample and serves all gates (PLE levels)
@@ -587,8 +675,27 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
 
 template <int LPS>
 static void launch_gate_fwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
-  const size_t lds = (size_t)aux.wg_total * 4;
   dim3 gr(aux.grid), bl(FB);
+  static int forced = -2;  // MMLREC_GATE_FWD_MODE=0: per-gate kernel everywhere (measurement knob)
+  if (forced == -2) {
+    const char* e = getenv("MMLREC_GATE_FWD_MODE");
+    forced = e ? atoi(e) : -1;
+  }
+  const int spw = 64 / LPS;
+  const size_t lds1 = ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)aux.ng * aux.ne) * 4;
+  if (forced != 0 && g.n_experts <= aux.ne && aux.ne * aux.ng <= 32 && lds1 <= 60 * 1024) {
+#define MML_GF(NE_, NG_) MML_LAUNCH((gate_fwd_once_kernel<LPS, NE_, NG_>), gr, bl, lds1, st, g, aux)
+    if (aux.ne == 4 && aux.ng == 2) { MML_GF(4, 2); return; }
+    if (aux.ne == 4 && aux.ng == 3) { MML_GF(4, 3); return; }
+    if (aux.ne == 4 && aux.ng == 4) { MML_GF(4, 4); return; }
+    if (aux.ne == 4 && aux.ng == 8) { MML_GF(4, 8); return; }
+    if (aux.ne == 8 && aux.ng == 2) { MML_GF(8, 2); return; }
+    if (aux.ne == 8 && aux.ng == 3) { MML_GF(8, 3); return; }
+    if (aux.ne == 8 && aux.ng == 4) { MML_GF(8, 4); return; }
+    if (aux.ne == 16 && aux.ng == 2) { MML_GF(16, 2); return; }
+#undef MML_GF
+  }
+  const size_t lds = (size_t)aux.wg_total * 4;
   if (aux.ne == 4) MML_LAUNCH((gate_fwd_fast_kernel<LPS, 4>), gr, bl, lds, st, g, aux);
   else if (aux.ne == 8) MML_LAUNCH((gate_fwd_fast_kernel<LPS, 8>), gr, bl, lds, st, g, aux);
   else MML_LAUNCH((gate_fwd_fast_kernel<LPS, 16>), gr, bl, lds, st, g, aux);
