@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run `rm -rf gpurun_out/traffic gpurun_out/prof_serial` HERE first: gpurun merges new files next to old ones)
 # End-of-round evidence pass on the GPU box: smoke, PMC traffic, serial kernel stats, the default bench line, secondary
 # workloads.  Everything lands in gpurun_out/; tools/update_profiles.py copies the judged pieces into profiles/.
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
