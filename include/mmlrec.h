@@ -308,6 +308,12 @@ int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
  * All arrays are HOST arrays of n_seg entries holding device pointers / element strides. */
 int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst, const int64_t* ldd,
                   const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate, mml_stream_t stream);
+/* ESMM output stage (model/esmm.py:58-62): p_out[b] = (ctr, ctr * cvr) from the two head probabilities p_raw[b] = (ctr,
+ * cvr).  With labels y: loss[0] = summed BCE of both outputs (model/basemodel.py:294-296) and d_raw = dLoss / d(ctr, cvr);
+ * without labels but with d_out (= dL / d p_out from autograd): d_raw by the chain rule.  Feed d_raw to
+ * mml_head_bce_fwd_bwd as `dprob`.  Any of y, d_out, d_raw, loss may be null. */
+int mml_esmm_combine(const float* p_raw, int64_t ldr, const float* y, int64_t ldy, const float* d_out, int64_t lddo,
+                     float* p_out, int64_t ldo, float* d_raw, int64_t lddr, float* loss, int64_t B, mml_stream_t stream);
 /* ----------------------------------------------------------------------------------------------
  * Per-batch AUC on the device.  Replaces sklearn.metrics.roc_auc_score run on the host for every
  * training step (model/basemodel.py:316-331; the epoch log averages the per-step values, :335-337): for every segment

@@ -106,6 +106,7 @@ _SIGS = {
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
+    "mml_esmm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp]),
     "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),
     "mml_opt_step_dense": (C.c_int, [_PP(OptTensor), i32, _PP(OptHyper), fp]),

@@ -533,6 +533,7 @@ class HeadOp(Op):
         T = len(self.heads)
         if plan.prob is None:
             plan.prob = plan.empty(plan.B, T)
+        prob_buf, dprob_buf = self._prob_buffers(plan, use_dprob)
         hl, post = [], []
         lib = L.load()
         for t, h in enumerate(self.heads):
@@ -558,11 +559,15 @@ class HeadOp(Op):
                     h["_acc"] = acc
                     post.append((lib.mml_copy2d, (tmp.data_ptr(), ops._ld(tmp), Hin.grad.data_ptr(), ops._ld(Hin.grad),
                                                   plan.B, Hin.n, acc)))
-                q["dbias"] = h["bias"].grad
                 if claim:
                     h["_acc_w"] = _claim(h["w"])
-                    if _claim(h["bias"]):
-                        raise NotImplementedError("head bias shared between heads")
+                    h["_acc_b"] = _claim(h["bias"])
+                if h["_acc_b"]:  # a bias shared by several heads (reference model/esmm.py:55-56: one PredictionLayer)
+                    tmpb = h.setdefault("_db_tmp", plan.empty(1))
+                    q["dbias"] = tmpb
+                    post.append((lib.mml_copy2d, (tmpb.data_ptr(), 1, h["bias"].grad.data_ptr(), 1, 1, 1, 1)))
+                else:
+                    q["dbias"] = h["bias"].grad
                 if h["_acc_w"]:
                     # a weight shared by several heads (reference model/mlp.py:28): this head's gradient goes to a
                     # scratch row that is added to the parameter's gradient after the launch
@@ -578,11 +583,15 @@ class HeadOp(Op):
                     h["_acc_b2"] = acc
                     post.append((lib.mml_copy2d, (h["bias"].grad.data_ptr(), 1, b2.grad.data_ptr(), 1, 1, 1, acc)))
             hl.append(q)
-        grp = ops.make_head_group(hl, plan.prob, y=plan.y if (train and not use_dprob) else None, mask=plan.mask,
+        grp = ops.make_head_group(hl, prob_buf, y=plan.y if (train and not use_dprob) else None, mask=plan.mask,
                                   loss=plan.loss if (train and not use_dprob) else None,
-                                  dprob=plan.dprob if use_dprob else None)
+                                  dprob=dprob_buf if use_dprob else None)
         plan.keep.append(grp)
         return grp, post
+
+    def _prob_buffers(self, plan, use_dprob):
+        """(where the heads write their probabilities, where they read dL/dprob from)."""
+        return plan.prob, plan.dprob
 
     def infer_calls(self, plan):
         grp, _ = self._group(plan, False, False, False)
@@ -599,6 +608,48 @@ class HeadOp(Op):
         byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
         return [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
                  dict(kernel="head_kernel", bytes=byts))] + post
+
+
+class EsmmHeadOp(HeadOp):
+    """ESMM (reference model/esmm.py:46-62): two sigmoid heads (ctr, cvr) whose product is the second output.
+    The heads run on a raw probability buffer; mml_esmm_combine turns it into [ctr, ctr*cvr], evaluates the summed BCE
+    and hands dLoss/d(ctr, cvr) back to the head kernel's dprob path."""
+
+    def _prob_buffers(self, plan, use_dprob):
+        if getattr(self, "_raw", None) is None or self._raw.shape[0] != plan.B:
+            self._raw = plan.empty(plan.B, 2)
+            self._draw = plan.empty(plan.B, 2)
+        return self._raw, self._draw
+
+    def _combine(self, plan, y, dout, draw, loss):
+        return (L.load().mml_esmm_combine,
+                (self._raw.data_ptr(), 2, L.ptr(y), 2 if y is not None else 0, L.ptr(dout),
+                 ops._ld(dout) if dout is not None else 0, plan.prob.data_ptr(), ops._ld(plan.prob), L.ptr(draw),
+                 2 if draw is not None else 0, L.ptr(loss), plan.B),
+                dict(kernel="esmm_combine_kernel", bytes=4.0 * plan.B * 8))
+
+    def infer_calls(self, plan):
+        calls = super().infer_calls(plan)
+        return calls + [self._combine(plan, None, None, None, None)]
+
+    def train_calls(self, plan, use_dprob, claim=True):
+        lib = L.load()
+        if use_dprob:  # autograd hands dL/d[ctr, ctcvr]; the raw probabilities are those of the forward pass
+            if plan.dprob is None:
+                plan.dprob = plan.empty(plan.B, 2)
+            pre = [self._combine(plan, None, plan.dprob, self._prob_buffers(plan, True)[1], None)]
+        else:
+            fwd, _ = self._group(plan, False, False, False)
+            if plan.y.stride(0) != 2:
+                raise L.MMLError("ESMM expects a contiguous [B, 2] label buffer")
+            pre = [(lib.mml_head_fwd, (C.byref(fwd),), dict(kernel="head_kernel")),
+                   self._combine(plan, plan.y, None, self._draw, plan.loss)]
+        grp, post = self._group(plan, True, True, claim)
+        ws = ops.workspace(lib.mml_head_workspace_bytes(C.byref(grp)), plan.device)
+        plan.keep.append(ws)
+        byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
+        return pre + [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
+                       dict(kernel="head_kernel", bytes=byts))] + post
 
 
 class MulOp(Op):

@@ -343,6 +343,40 @@ def mlp_bwd(spec, params, cache, dlogit):
     return grads, dh
 
 
+def esmm_fwd(spec, params, x):
+    """ESMM.forward (model/esmm.py:46-71): ctr / cvr towers, both through the single PredictionLayer `out`
+    (model/basemodel.py:132), outputs [ctr, ctr * cvr]."""
+    hc, ac = dnn_fwd(params, "ctr_dnn", x)
+    hv, av = dnn_fwd(params, "cvr_dnn", x)
+    b = params["out.bias"]
+    c = sigmoid((linear_fwd(hc, params["ctr_dnn_final_layer.weight"]) + b)[:, 0])
+    v = sigmoid((linear_fwd(hv, params["cvr_dnn_final_layer.weight"]) + b)[:, 0])
+    p = np.stack([c, c * v], 1).astype(F32)
+    return p, dict(ac=ac, av=av, hc=hc, hv=hv, c=c, v=v, layers={"target0_output": hc, "target1_output": hv})
+
+
+def esmm_bwd(spec, params, cache, dprob):
+    """dprob = dLoss / d[ctr, ctcvr] (NOT d/dlogit: the second output is a product, model/esmm.py:58)."""
+    c, v = cache["c"], cache["v"]
+    dc = (dprob[:, 0] + dprob[:, 1] * v).astype(F32)
+    dv = (dprob[:, 1] * c).astype(F32)
+    dzc = (dc * c * (F32(1) - c)).astype(F32)[:, None]
+    dzv = (dv * v * (F32(1) - v)).astype(F32)[:, None]
+    grads = {}
+    _acc(grads, "out.bias", (dzc.sum(0) + dzv.sum(0)).astype(F32))
+    dhc, dW, _ = linear_bwd(cache["hc"], params["ctr_dnn_final_layer.weight"], dzc, has_bias=False)
+    _acc(grads, "ctr_dnn_final_layer.weight", dW)
+    dhv, dW, _ = linear_bwd(cache["hv"], params["cvr_dnn_final_layer.weight"], dzv, has_bias=False)
+    _acc(grads, "cvr_dnn_final_layer.weight", dW)
+    dx = dnn_bwd(params, "ctr_dnn", cache["ac"], dhc, grads) + dnn_bwd(params, "cvr_dnn", cache["av"], dhv, grads)
+    return grads, dx.astype(F32)
+
+
+def bce_prob_bwd(p, y):
+    """d BCE / d p as PyTorch evaluates it: (p - y) / max(p (1 - p), 1e-12)."""
+    return ((p - y) / np.maximum(p * (F32(1) - p), F32(1e-12))).astype(F32)
+
+
 def mmoe_fwd(spec, params, x):
     """MMOE.forward (model/mmoe.py:65-119)."""
     Ne = int(spec.mc.get("num_experts", 4))
@@ -631,7 +665,7 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_FWD = {"esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
 _BWD = {"mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
@@ -660,6 +694,8 @@ def loss_and_grads(spec, params, X, y, frozen=None):
     dlogit = bce_sigmoid_bwd(p, y)
     if spec.model_name == "star":
         grads, dx = star_bwd(spec, params, cache, dlogit)
+    elif spec.model_name == "esmm":
+        grads, dx = esmm_bwd(spec, params, cache, bce_prob_bwd(p, y))
     else:
         grads, dx = _BWD[spec.model_name](spec, params, cache, dlogit)
     grads.update(scatter_table_grads(spec, dx, cache["idx"], params))
@@ -764,7 +800,13 @@ def param_shapes(spec):
             shapes[f"out.{t}.bias"] = (1,)
 
     name = spec.model_name
-    if name == "mlp":
+    if name == "esmm":
+        shapes["out.bias"] = (1,)
+        for twr in ("ctr", "cvr"):
+            h = dnn(f"{twr}_dnn", K0, mc.get("expert_dnn_hidden_units", [256, 128]))
+        shapes["ctr_dnn_final_layer.weight"] = (1, h)
+        shapes["cvr_dnn_final_layer.weight"] = (1, h)
+    elif name == "mlp":
         k = K0
         for i, u in enumerate(mc.get("dnn_hidden_units", [256, 128])):
             k = dnn(f"mlp_layers.{i}", k, [u])

@@ -40,6 +40,7 @@ from model.ple import PLE  # noqa: E402
 from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
+from model.esmm import ESMM  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 B = 64
@@ -113,6 +114,10 @@ def make_cases():
     c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
                              "scene_feature": "scene"})
     cases.append(dict(name="mlp_ae", cls=MLP, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=5, scene_last=True))
+    # ESMM (model/esmm.py): outputs [ctr, ctr * cvr], one PredictionLayer for both heads
+    c = base_config("mtl", "esmm", ["label2", "label3"], 8, "adam", 0.01,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
+    cases.append(dict(name="esmm_ml", cls=ESMM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=3))
     return cases
 
 
