@@ -652,6 +652,76 @@ class EsmmHeadOp(HeadOp):
                        dict(kernel="head_kernel", bytes=byts))] + post
 
 
+class JoinOp(Op):
+    """parts[j] are column slices of whole.buf (torch.cat of the reference done by writing in place, e.g.
+    model/cross_stitch.py:18): no launch; on the way back the parts' gradients ARE the column slices of whole.grad."""
+
+    def __init__(self, parts, whole):
+        self.parts, self.whole = parts, whole
+        off = 0
+        for v in parts:
+            if v.buf.data_ptr() != whole.buf[:, off:off + v.n].data_ptr() or v.buf.stride(0) != whole.buf.stride(0):
+                raise L.MMLError("JoinOp: part is not the expected column slice of the whole")
+            if v.act != whole.act:
+                raise L.MMLError("JoinOp: parts and whole must carry the same activation")
+            off += v.n
+
+    def inputs(self):
+        return list(self.parts)
+
+    def outputs(self):
+        return [self.whole]
+
+    def fwd_calls(self, plan):
+        return []
+
+    def bwd_calls(self, plan):
+        if self.whole.grad is None:
+            return []
+        off = 0
+        for v in self.parts:
+            v.grad = self.whole.grad[:, off:off + v.n]
+            v.deriv_applied = True  # Plan.finish / the consumer's dgrad has applied act' on the whole already
+            v.written = 1
+            off += v.n
+        return []
+
+
+class SplitOp(Op):
+    """The inverse: parts[j] are column slices of whole (torch slicing, model/cross_stitch.py:22-27); their gradient
+    buffers are slices of whole.grad from the start, so consumers write straight into it."""
+
+    def __init__(self, plan, whole, widths):
+        self.whole, self.parts = whole, []
+        if plan.training and whole.needs_grad:
+            plan.grad_of(whole)
+        off = 0
+        for j, w in enumerate(widths):
+            v = Val(whole.buf[:, off:off + w], L.ACT_NONE, whole.needs_grad, f"{whole.name}.{j}")
+            if whole.grad is not None:
+                v.grad = whole.grad[:, off:off + w]
+            self.parts.append(v)
+            off += w
+
+    def inputs(self):
+        return [self.whole]
+
+    def outputs(self):
+        return list(self.parts)
+
+    def fwd_calls(self, plan):
+        return []
+
+    def bwd_calls(self, plan):
+        if any(v.written for v in self.parts):
+            if not all(v.written for v in self.parts):
+                raise L.MMLError("SplitOp: every slice needs a consumer that writes its gradient")
+            self.whole.written = 1
+        else:
+            self.whole.grad = None
+        return []
+
+
 class MulOp(Op):
     """out = a * b on whole contiguous [B,n] buffers (PepNet gating, model/pepnet.py:77, :140)."""
 

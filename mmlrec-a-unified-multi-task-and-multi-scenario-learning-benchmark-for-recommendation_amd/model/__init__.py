@@ -1,5 +1,6 @@
 """Drop-in model zoo for the hot path: same class names / constructor signatures as the reference's model/*.py."""
 from .basemodel import BaseModel  # noqa: F401
+from .cross_stitch import CrossStitch  # noqa: F401
 from .esmm import ESMM  # noqa: F401
 from .mlp import MLP  # noqa: F401
 from .mmoe import MMOE  # noqa: F401

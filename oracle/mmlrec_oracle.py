@@ -343,6 +343,49 @@ def mlp_bwd(spec, params, cache, dlogit):
     return grads, dh
 
 
+def cross_stitch_fwd(spec, params, x):
+    """CrossStitch.forward (model/cross_stitch.py:82-121): shared layer, then per level T one-layer DNNs and a stitch
+    (cat of the T activations times cross_stitch_weight [in, out], model/cross_stitch.py:17-19), then towers."""
+    T = spec.T
+    units = spec.mc.get("dnn_hidden_units", [256, 128])
+    sh, a_sh = dnn_fwd(params, "shared_layer", x)
+    ins, levels = [sh] * T, []
+    for i, d in enumerate(units):
+        hs, acts = [], []
+        for j in range(T):
+            h, a = dnn_fwd(params, f"cross_stitch.task_layer_{i}.{j}", ins[j])
+            hs.append(h)
+            acts.append(a)
+        cat = np.concatenate(hs, 1)
+        mix = (cat @ params[f"cross_stitch.gate_{i}.cross_stitch_weight"]).astype(F32)
+        levels.append((acts, cat))
+        ins = [mix[:, j * d:(j + 1) * d] for j in range(T)]
+    p, tc = _towers_fwd(spec, params, ins)
+    layers = {"cross_stitch_outputs": np.stack(ins, 1)}
+    if tc[0][1]:
+        layers["tower_outputs"] = np.stack([c[0] for c in tc], 1)
+    return p, dict(a_sh=a_sh, levels=levels, towers=tc, layers=layers)
+
+
+def cross_stitch_bwd(spec, params, cache, dlogit):
+    T = spec.T
+    units = spec.mc.get("dnn_hidden_units", [256, 128])
+    grads = {}
+    dins = _towers_bwd(spec, params, cache["towers"], dlogit, grads)
+    for i in reversed(range(len(units))):
+        d = units[i]
+        acts, cat = cache["levels"][i]
+        dmix = np.concatenate(dins, 1).astype(F32)
+        W = params[f"cross_stitch.gate_{i}.cross_stitch_weight"]
+        _acc(grads, f"cross_stitch.gate_{i}.cross_stitch_weight", (cat.T @ dmix).astype(F32))
+        dcat = (dmix @ W.T).astype(F32)
+        dins = [dnn_bwd(params, f"cross_stitch.task_layer_{i}.{j}", acts[j], dcat[:, j * d:(j + 1) * d], grads)
+                for j in range(T)]
+    dsh = sum(dins).astype(F32)  # every task's first layer reads the same shared activation
+    dx = dnn_bwd(params, "shared_layer", cache["a_sh"], dsh, grads)
+    return grads, dx
+
+
 def esmm_fwd(spec, params, x):
     """ESMM.forward (model/esmm.py:46-71): ctr / cvr towers, both through the single PredictionLayer `out`
     (model/basemodel.py:132), outputs [ctr, ctr * cvr]."""
@@ -665,8 +708,8 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_FWD = {"cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):
@@ -800,7 +843,16 @@ def param_shapes(spec):
             shapes[f"out.{t}.bias"] = (1,)
 
     name = spec.model_name
-    if name == "esmm":
+    if name == "cross_stitch":
+        units = mc.get("dnn_hidden_units", [256, 128])
+        k = dnn("shared_layer", K0, [mc.get("shared_hidden_unit", 256)])
+        for i, d in enumerate(units):
+            for j in range(T):
+                dnn(f"cross_stitch.task_layer_{i}.{j}", k, [d])
+            shapes[f"cross_stitch.gate_{i}.cross_stitch_weight"] = (T * d, T * d)
+            k = d
+        towers(k)
+    elif name == "esmm":
         shapes["out.bias"] = (1,)
         for twr in ("ctr", "cvr"):
             h = dnn(f"{twr}_dnn", K0, mc.get("expert_dnn_hidden_units", [256, 128]))

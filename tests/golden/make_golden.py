@@ -41,6 +41,7 @@ from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
+from model.cross_stitch import CrossStitch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 B = 64
@@ -118,6 +119,13 @@ def make_cases():
     c = base_config("mtl", "esmm", ["label2", "label3"], 8, "adam", 0.01,
                     task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
     cases.append(dict(name="esmm_ml", cls=ESMM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=3))
+    # Cross-Stitch (model/cross_stitch.py): msl mode so that the masked heads are covered too
+    c = base_config("msl", "cross_stitch", ["label", "label"], 8, "adam", 0.005, task_types=["binary", "binary"],
+                    shared_hidden_unit=32, dnn_hidden_units=[32, 16], tower_dnn_hidden_units=[16])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="cross_stitch_ae", cls=CrossStitch, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=4,
+                      scene_last=True))
     return cases
 
 
