@@ -470,6 +470,93 @@ def mmoe_bwd(spec, params, cache, dlogit):
     return grads, dx.astype(F32)
 
 
+def hmoe_fwd(spec, params, x):
+    """HMOE.forward (model/hmoe.py:83-153): the MMoE body up to the tower DNNs, then per task a softmax task-weight gate
+    over the T tower outputs (the others detached, :124-129) in front of the final Linear + PredictionLayer."""
+    T = spec.T
+    p0, c = mmoe_fwd_body(spec, params, x)
+    towers, tws = c["tower_outs"], []
+    has_tw = "task_weight.0.linears.0.weight" in params
+    stack = np.stack(towers, 1)  # [B,T,Ht]
+    ps, outs = [], []
+    for i in range(T):
+        if has_tw:
+            g, gacts = dnn_fwd(params, f"task_weight.{i}", x)
+        else:
+            g, gacts = x, []
+        logits = linear_fwd(g, params[f"task_weight_final_layer.{i}.weight"])
+        w, mix = gate_mix_fwd(logits, stack)
+        tws.append((g, gacts, w))
+        outs.append(mix)
+        ps.append(head_fwd(params, i, mix, f"tower_dnn_final_layer.{i}.weight"))
+    c.update(tws=tws, task_outs=outs, tstack=stack)
+    return np.stack(ps, 1).astype(F32), c
+
+
+def mmoe_fwd_body(spec, params, x):
+    """experts, gates, mixtures and tower DNNs of MMoE / HMoE without the heads."""
+    Ne = int(spec.mc.get("num_experts", 4))
+    eo, eacts = [], []
+    for e in range(Ne):
+        h, a = dnn_fwd(params, f"expert_dnn.{e}", x)
+        eo.append(h)
+        eacts.append(a)
+    experts = np.stack(eo, 1)
+    has_gate_dnn = "gate_dnn.0.linears.0.weight" in params
+    gates, mixes = [], []
+    for t in range(spec.T):
+        g, gacts = dnn_fwd(params, f"gate_dnn.{t}", x) if has_gate_dnn else (x, [])
+        p, mix = gate_mix_fwd(linear_fwd(g, params[f"gate_dnn_final_layer.{t}.weight"]), experts)
+        gates.append((g, gacts, p))
+        mixes.append(mix)
+    has_tower = "tower_dnn.0.linears.0.weight" in params
+    touts, tacts = [], []
+    for t in range(spec.T):
+        h, a = dnn_fwd(params, f"tower_dnn.{t}", mixes[t]) if has_tower else (mixes[t], [])
+        touts.append(h)
+        tacts.append(a)
+    layers = {"expert_outputs": experts, "mmoe_outputs": np.stack(mixes, 1),
+              "gate_outputs": np.stack([g[2] for g in gates], 1)}
+    if has_tower:
+        layers["tower_outputs"] = np.stack(touts, 1)
+    return None, dict(x=x, experts=experts, eacts=eacts, gates=gates, tower_outs=touts, tower_acts=tacts,
+                      layers=layers)
+
+
+def hmoe_bwd(spec, params, cache, dlogit):
+    T = spec.T
+    grads = {}
+    x = cache["x"]
+    dx = np.zeros_like(x)
+    dtower = [None] * T
+    for i in range(T):
+        g, gacts, w = cache["tws"][i]
+        dz = dlogit[:, i:i + 1]
+        _acc(grads, f"out.{i}.bias", dz.sum(0))
+        dmix, dW, _ = linear_bwd(cache["task_outs"][i], params[f"tower_dnn_final_layer.{i}.weight"], dz, has_bias=False)
+        _acc(grads, f"tower_dnn_final_layer.{i}.weight", dW)
+        dlogits, dstack = gate_mix_bwd(w, cache["tstack"], dmix)
+        dtower[i] = dstack[:, i]  # towers j != i are detached in task i's mixture
+        Wt = params[f"task_weight_final_layer.{i}.weight"]
+        dg, dWt, _ = linear_bwd(g, Wt, dlogits, has_bias=False)
+        _acc(grads, f"task_weight_final_layer.{i}.weight", dWt)
+        dx += dnn_bwd(params, f"task_weight.{i}", gacts, dg, grads) if gacts else dg
+    Ne = cache["experts"].shape[1]
+    dexperts = np.zeros_like(cache["experts"])
+    for t in range(T):
+        dm = dnn_bwd(params, f"tower_dnn.{t}", cache["tower_acts"][t], dtower[t], grads) if cache["tower_acts"][t] \
+            else dtower[t]
+        g, gacts, p = cache["gates"][t]
+        dlogits, de = gate_mix_bwd(p, cache["experts"], dm)
+        dexperts += de
+        dg, dW, _ = linear_bwd(g, params[f"gate_dnn_final_layer.{t}.weight"], dlogits, has_bias=False)
+        _acc(grads, f"gate_dnn_final_layer.{t}.weight", dW)
+        dx += dnn_bwd(params, f"gate_dnn.{t}", gacts, dg, grads) if gacts else dg
+    for e in range(Ne):
+        dx += dnn_bwd(params, f"expert_dnn.{e}", cache["eacts"][e], dexperts[:, e], grads)
+    return grads, dx.astype(F32)
+
+
 def ple_fwd(spec, params, x):
     """PLE.forward / cgc_net (model/ple.py:107-198).  Quirks kept: `specific_expert_num` shared
     experts are constructed but only `shared_expert_num` are used (ple.py:47 vs :120-121); the last level's
@@ -708,8 +795,8 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_FWD = {"hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):

@@ -41,6 +41,7 @@ from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
+from model.hmoe import HMOE  # noqa: E402
 from model.cross_stitch import CrossStitch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -126,6 +127,11 @@ def make_cases():
                              "scene_feature": "scene"})
     cases.append(dict(name="cross_stitch_ae", cls=CrossStitch, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=4,
                       scene_last=True))
+    # HMoE (model/hmoe.py): MMoE + task-level mixture of the tower outputs (others detached)
+    c = base_config("mtl", "hmoe", ["l1", "l2"], 8, "adam", 0.005, task_names=["ctr", "ctcvr"],
+                    task_types=["binary", "binary"], expert_dnn_hidden_units=[32, 16], gate_dnn_hidden_units=[16],
+                    tower_dnn_hidden_units=[16], task_weight_hidden_units=[16])
+    cases.append(dict(name="hmoe_ml", cls=HMOE, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
     return cases
 
 
