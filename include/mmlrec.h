@@ -308,6 +308,30 @@ int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
  * All arrays are HOST arrays of n_seg entries holding device pointers / element strides. */
 int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst, const int64_t* ldd,
                   const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate, mml_stream_t stream);
+/* Two-token attention of AITM (model/aitm.py:84-93): per sample, tokens t = 0, 1 with V_t, K_t, Q_t in R^H:
+ * s_t = <K_t, Q_t> / sqrt_h, a = softmax(s_0, s_1), out = a_0 V_0 + a_1 V_1.  fwd writes out and (if non-null) the
+ * weights A [B,2]; bwd reads A and dout and OVERWRITES dV, dK, dQ of both tokens.  All pointers are device pointers,
+ * leading dimensions in elements. */
+typedef struct mml_attn2_desc {
+  const float* V[2];
+  const float* K[2];
+  const float* Q[2];
+  int64_t ldv[2], ldk[2], ldq[2];
+  float* out;
+  int64_t ldo;
+  float* A;
+  const float* dout;
+  int64_t lddo;
+  float* dV[2];
+  float* dK[2];
+  float* dQ[2];
+  int64_t lddv[2], lddk[2], lddq[2];
+  int64_t B;
+  int32_t H;
+  float sqrt_h; /* the divisor: (float)sqrt(H) in the reference */
+} mml_attn2_desc;
+int mml_attn2_fwd(const mml_attn2_desc* d, mml_stream_t stream);
+int mml_attn2_bwd(const mml_attn2_desc* d, mml_stream_t stream);
 /* ESMM output stage (model/esmm.py:58-62): p_out[b] = (ctr, ctr * cvr) from the two head probabilities p_raw[b] = (ctr,
  * cvr).  With labels y: loss[0] = summed BCE of both outputs (model/basemodel.py:294-296) and d_raw = dLoss / d(ctr, cvr);
  * without labels but with d_out (= dL / d p_out from autograd): d_raw by the chain rule.  Feed d_raw to

@@ -70,6 +70,13 @@ class Copy2dDesc(C.Structure):
                 ("accumulate", i32)]
 
 
+class Attn2Desc(C.Structure):
+    _fields_ = [("V", fp * 2), ("K", fp * 2), ("Q", fp * 2), ("ldv", i64 * 2), ("ldk", i64 * 2), ("ldq", i64 * 2),
+                ("out", fp), ("ldo", i64), ("A", fp), ("dout", fp), ("lddo", i64), ("dV", fp * 2), ("dK", fp * 2),
+                ("dQ", fp * 2), ("lddv", i64 * 2), ("lddk", i64 * 2), ("lddq", i64 * 2), ("B", i64), ("H", i32),
+                ("sqrt_h", C.c_float)]
+
+
 class OptHyper(C.Structure):
     _fields_ = [("kind", i32), ("step", i32), ("step_dev", fp), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("zero_grad", i32)]
@@ -106,6 +113,8 @@ _SIGS = {
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
+    "mml_attn2_fwd": (C.c_int, [_PP(Attn2Desc), fp]),
+    "mml_attn2_bwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_esmm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp]),
     "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),

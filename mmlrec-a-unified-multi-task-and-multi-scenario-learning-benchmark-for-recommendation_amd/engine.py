@@ -652,6 +652,51 @@ class EsmmHeadOp(HeadOp):
                        dict(kernel="head_kernel", bytes=byts))] + post
 
 
+class Attn2Op(Op):
+    """Two-token attention of AITM (model/aitm.py:84-93): tokens = [(V0, K0, Q0), (V1, K1, Q1)] of [B, H] values -> out."""
+
+    def __init__(self, tokens, out, sqrt_h):
+        self.tokens, self.out, self.sqrt_h = tokens, out, float(sqrt_h)
+
+    def inputs(self):
+        return [v for tok in self.tokens for v in tok]
+
+    def outputs(self):
+        return [self.out]
+
+    def _desc(self, plan):
+        d = L.Attn2Desc()
+        for t, (V, K, Q) in enumerate(self.tokens):
+            d.V[t], d.K[t], d.Q[t] = V.buf.data_ptr(), K.buf.data_ptr(), Q.buf.data_ptr()
+            d.ldv[t], d.ldk[t], d.ldq[t] = ops._ld(V.buf), ops._ld(K.buf), ops._ld(Q.buf)
+        d.out, d.ldo = self.out.buf.data_ptr(), ops._ld(self.out.buf)
+        d.A = self.A.data_ptr()
+        d.B, d.H, d.sqrt_h = plan.B, self.out.n, self.sqrt_h
+        return d
+
+    def fwd_calls(self, plan):
+        self.A = plan.empty(plan.B, 2)
+        d = self._desc(plan)
+        plan.keep.append(d)
+        return [(L.load().mml_attn2_fwd, (C.byref(d),), dict(kernel="attn2_fwd_kernel", bytes=4.0 * plan.B * 7 * self.out.n))]
+
+    def bwd_calls(self, plan):
+        if self.out.grad is None:
+            return []
+        d = self._desc(plan)
+        d.dout, d.lddo = self.out.grad.data_ptr(), ops._ld(self.out.grad)
+        for t, (V, K, Q) in enumerate(self.tokens):
+            for v in (V, K, Q):
+                if v.act != L.ACT_NONE or len(v.consumers) != 1:
+                    raise NotImplementedError("Attn2Op inputs must be plain linear outputs with this op as sole consumer")
+                plan.grad_of(v)
+                _claim(v)
+            d.dV[t], d.dK[t], d.dQ[t] = V.grad.data_ptr(), K.grad.data_ptr(), Q.grad.data_ptr()
+            d.lddv[t], d.lddk[t], d.lddq[t] = ops._ld(V.grad), ops._ld(K.grad), ops._ld(Q.grad)
+        plan.keep.append(d)
+        return [(L.load().mml_attn2_bwd, (C.byref(d),), dict(kernel="attn2_bwd_kernel", bytes=4.0 * plan.B * 14 * self.out.n))]
+
+
 class JoinOp(Op):
     """parts[j] are column slices of whole.buf (torch.cat of the reference done by writing in place, e.g.
     model/cross_stitch.py:18): no launch; on the way back the parts' gradients ARE the column slices of whole.grad."""

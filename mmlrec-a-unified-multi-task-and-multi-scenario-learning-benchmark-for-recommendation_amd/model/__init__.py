@@ -1,4 +1,5 @@
 """Drop-in model zoo for the hot path: same class names / constructor signatures as the reference's model/*.py."""
+from .aitm import AITM  # noqa: F401
 from .basemodel import BaseModel  # noqa: F401
 from .cross_stitch import CrossStitch  # noqa: F401
 from .esmm import ESMM  # noqa: F401

@@ -343,6 +343,65 @@ def mlp_bwd(spec, params, cache, dlogit):
     return grads, dh
 
 
+def aitm_fwd(spec, params, x):
+    """AITM.forward (model/aitm.py:75-111): bottoms, then for task i >= 1 the attention over the two tokens
+    p = g_{i-1}(feat[i-1]) and q = feat[i] with V = h1(.), K = h2(.), Q = h3(.) (:84-93), towers."""
+    T = spec.T
+    H = spec.mc.get("expert_dnn_hidden_units", [256, 128])[-1]
+    sq = F32(np.sqrt(H))
+    feat, bacts, att = [], [], []
+    for i in range(T):
+        h, a = dnn_fwd(params, f"bottom.{i}", x)
+        feat.append(h)
+        bacts.append(a)
+    raw = list(feat)
+    for i in range(1, T):
+        p = linear_fwd(feat[i - 1], params[f"g.{i - 1}.weight"], params[f"g.{i - 1}.bias"])
+        q = feat[i]
+        tok = np.stack([p, q], 1)  # [B,2,H]
+        V = (tok @ params["h1.weight"].T + params["h1.bias"]).astype(F32)
+        K = (tok @ params["h2.weight"].T + params["h2.bias"]).astype(F32)
+        Q = (tok @ params["h3.weight"].T + params["h3.bias"]).astype(F32)
+        s = ((K * Q).sum(2, keepdims=True, dtype=F32) / sq).astype(F32)
+        a = softmax_rows(s[:, :, 0])[:, :, None]
+        att.append(dict(prev=feat[i - 1], tok=tok, V=V, K=K, Q=Q, a=a))
+        feat[i] = (a * V).sum(1).astype(F32)
+    probs, tc = _towers_fwd(spec, params, feat)
+    return probs, dict(bacts=bacts, att=att, towers=tc, sq=sq, layers={})
+
+
+def aitm_bwd(spec, params, cache, dlogit):
+    T = spec.T
+    grads = {}
+    dfeat = _towers_bwd(spec, params, cache["towers"], dlogit, grads)
+    for i in reversed(range(1, T)):
+        c = cache["att"][i - 1]
+        a, V, K, Q, tok = c["a"], c["V"], c["K"], c["Q"], c["tok"]
+        do = dfeat[i][:, None, :]
+        dV = (a * do).astype(F32)
+        da = (do * V).sum(2, keepdims=True)
+        ds = (a * (da - (a * da).sum(1, keepdims=True)) / cache["sq"]).astype(F32)
+        dK, dQ = (ds * Q).astype(F32), (ds * K).astype(F32)
+        dtok = np.zeros_like(tok)
+        B2 = tok.reshape(-1, tok.shape[2])
+        for nm, d in (("h1", dV), ("h2", dK), ("h3", dQ)):
+            d2 = d.reshape(-1, d.shape[2])
+            _acc(grads, f"{nm}.weight", (d2.T @ B2).astype(F32))
+            _acc(grads, f"{nm}.bias", d2.sum(0).astype(F32))
+            dtok += (d @ params[f"{nm}.weight"]).astype(F32)
+        dp, dq = dtok[:, 0], dtok[:, 1]
+        dprev, dW, db = linear_bwd(c["prev"], params[f"g.{i - 1}.weight"], dp, has_bias=True)
+        _acc(grads, f"g.{i - 1}.weight", dW)
+        _acc(grads, f"g.{i - 1}.bias", db)
+        dfeat[i] = dq
+        dfeat[i - 1] = (dfeat[i - 1] + dprev).astype(F32)
+    dx = None
+    for i in range(T):
+        d = dnn_bwd(params, f"bottom.{i}", cache["bacts"][i], dfeat[i], grads)
+        dx = d if dx is None else dx + d
+    return grads, dx.astype(F32)
+
+
 def cross_stitch_fwd(spec, params, x):
     """CrossStitch.forward (model/cross_stitch.py:82-121): shared layer, then per level T one-layer DNNs and a stitch
     (cat of the T activations times cross_stitch_weight [in, out], model/cross_stitch.py:17-19), then towers."""
@@ -795,8 +854,8 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_FWD = {"aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):
@@ -811,6 +870,8 @@ def forward(spec, params, X, mask=None, frozen=None):
     cache["idx"] = idx
     cache["p"] = p
     if spec.model_name == "mlp" and spec.task_name != "msl":  # model/mlp.py:53-54 masks in the msl mode only
+        mask = None
+    if spec.model_name == "aitm" and spec.task_name != "msl":  # model/aitm.py:104-105
         mask = None
     return apply_mask(spec, p, mask), cache
 

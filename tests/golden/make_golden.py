@@ -41,6 +41,7 @@ from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
+from model.aitm import AITM  # noqa: E402
 from model.hmoe import HMOE  # noqa: E402
 from model.cross_stitch import CrossStitch  # noqa: E402
 
@@ -132,6 +133,10 @@ def make_cases():
                     task_types=["binary", "binary"], expert_dnn_hidden_units=[32, 16], gate_dnn_hidden_units=[16],
                     tower_dnn_hidden_units=[16], task_weight_hidden_units=[16])
     cases.append(dict(name="hmoe_ml", cls=HMOE, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # AITM (model/aitm.py): two bottoms, two-token attention transfer from task 0 to task 1
+    c = base_config("mtl", "aitm", ["l1", "l2"], 8, "adam", 0.005, task_names=["ctr", "ctcvr"],
+                    task_types=["binary", "binary"], expert_dnn_hidden_units=[32, 24], tower_dnn_hidden_units=[16])
+    cases.append(dict(name="aitm_ml", cls=AITM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=2))
     return cases
 
 

@@ -565,3 +565,41 @@ def test_auc_segments_rejects_long_segments(ops):
     p = torch.rand(10000, 1, device=dev())
     with pytest.raises(L.MMLError):
         ops.auc_segments(p, (p > 0.5).float(), 5000)
+
+
+@pytest.mark.parametrize("B,H", [(257, 24), (1000, 128), (3, 7)])
+def test_attn2_fwd_bwd(ops, B, H):
+    """mml_attn2_fwd / _bwd == the two-token attention of AITM (reference model/aitm.py:84-93) in float64."""
+    import ctypes as C
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(B + H)
+    V, K, Q = (rng.standard_normal((2, B, H)).astype(np.float32) for _ in range(3))
+    dout = rng.standard_normal((B, H)).astype(np.float32)
+    tV, tK, tQ = [T(V[t]) for t in range(2)], [T(K[t]) for t in range(2)], [T(Q[t]) for t in range(2)]
+    out, A, tdo = torch.empty(B, H, device=dev()), torch.empty(B, 2, device=dev()), T(dout)
+    g = [[torch.empty(B, H, device=dev()) for _ in range(2)] for _ in range(3)]
+    d = L.Attn2Desc()
+    for t in range(2):
+        d.V[t], d.K[t], d.Q[t] = tV[t].data_ptr(), tK[t].data_ptr(), tQ[t].data_ptr()
+        d.ldv[t] = d.ldk[t] = d.ldq[t] = H
+        d.dV[t], d.dK[t], d.dQ[t] = g[0][t].data_ptr(), g[1][t].data_ptr(), g[2][t].data_ptr()
+        d.lddv[t] = d.lddk[t] = d.lddq[t] = H
+    d.out, d.ldo, d.A, d.dout, d.lddo = out.data_ptr(), H, A.data_ptr(), tdo.data_ptr(), H
+    d.B, d.H, d.sqrt_h = B, H, float(np.float32(np.sqrt(H)))
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mml_attn2_fwd(C.byref(d), st) == 0
+    assert lib.mml_attn2_bwd(C.byref(d), st) == 0
+    torch.cuda.synchronize()
+    V64, K64, Q64, do64 = V.astype(np.float64), K.astype(np.float64), Q.astype(np.float64), dout.astype(np.float64)
+    s = (K64 * Q64).sum(2) / np.sqrt(H)                      # [2,B]
+    a = np.exp(s - s.max(0)) / np.exp(s - s.max(0)).sum(0)   # softmax over the two tokens
+    ref = (a[:, :, None] * V64).sum(0)
+    assert rel(out.cpu().numpy(), ref) < 1e-5
+    assert rel(A.cpu().numpy(), a.T) < 1e-5
+    da = (do64[None] * V64).sum(2)
+    ds = a * (da - (a * da).sum(0)) / np.sqrt(H)
+    for t in range(2):
+        assert rel(g[0][t].cpu().numpy(), a[t][:, None] * do64) < 1e-5
+        assert rel(g[1][t].cpu().numpy(), ds[t][:, None] * Q64[t]) < 2e-5
+        assert rel(g[2][t].cpu().numpy(), ds[t][:, None] * K64[t]) < 2e-5

@@ -20,13 +20,13 @@ def rel(a, b):
 
 def build(g, device="cuda:0", **model_kw):
     import mmlrec_amd  # noqa: F401
-    from mmlrec_amd.model import ESMM, HMOE, MLP, MMOE, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from mmlrec_amd.model import AITM, ESMM, HMOE, MLP, MMOE, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg = json.loads(str(g["cfg"]))
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(str(n), int(v), embedding_dim=emb) for n, v in zip(g["sparse_names"], g["vocab"])]
     cols += [DenseFeat(str(n), 1) for n in g["dense_names"]]
-    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE}[
+    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(0)
     model = cls(cols, device=device, config=cfg)
