@@ -9,7 +9,7 @@ from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import emit_towers
-from .utils import DNN, PredictionLayer, emit_dnn_stacks
+from .utils import DNN, PredictionLayer, dnn_options, emit_dnn_stacks, l2_on_weights
 
 
 class AITM(BaseModel):
@@ -19,38 +19,34 @@ class AITM(BaseModel):
         mc = self.model_config
         self.task_names = mc.get("task_names", ["ctr", "ctcvr"])
         self.task_types = mc.get("task_types", ["binary", "binary"])
+        self.num_tasks = T = len(self.task_names)
+        # the reference's argument checks (model/aitm.py:31-41)
+        if T != 2:
+            raise ValueError("the length of task_names must be equal to 2")
+        if not dnn_feature_columns:
+            raise ValueError("dnn_feature_columns is null!")
+        if len(self.task_types) != T:
+            raise ValueError("num_tasks must be equal to the length of task_types")
+        bad = [t for t in self.task_types if t != "binary"]
+        if bad:
+            raise ValueError("task must be binary in ESMM, {} is illegal".format(bad[0]))
         self.input_dim = self.compute_input_dim(dnn_feature_columns)
         self.bottom_dnn_hidden_units = mc.get("expert_dnn_hidden_units", [256, 128])
         self.tower_dnn_hidden_units = mc.get("tower_dnn_hidden_units", [64])
-        l2 = mc.get("l2_reg_dnn", 0)
-        drop, act, bn = mc.get("dnn_dropout", 0), mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
-        self.num_tasks = len(self.task_names)
-        if self.num_tasks != 2:
-            raise ValueError("the length of task_names must be equal to 2")
-        if len(dnn_feature_columns) == 0:
-            raise ValueError("dnn_feature_columns is null!")
-        if len(self.task_types) != self.num_tasks:
-            raise ValueError("num_tasks must be equal to the length of task_types")
-        for task_type in self.task_types:
-            if task_type != "binary":
-                raise ValueError("task must be binary in ESMM, {} is illegal".format(task_type))
-        H, T = self.bottom_dnn_hidden_units[-1], self.num_tasks
-        # registration (and random-draw) order of the reference: g, h1, h2, h3, bottom, tower_dnn, final layers, out
-        self.g = nn.ModuleList([nn.Linear(H, H) for _ in range(T - 1)])
-        self.h1, self.h2, self.h3 = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
-        kw = dict(activation=act, dropout_rate=drop, use_bn=bn, init_std=init_std, device=device)
-        self.bottom = nn.ModuleList([DNN(self.input_dim, self.bottom_dnn_hidden_units, l2_reg=l2, **kw)
-                                     for _ in range(T)])
-        if len(self.tower_dnn_hidden_units) > 0:
-            self.tower_dnn = nn.ModuleList([DNN(H, self.tower_dnn_hidden_units, **kw) for _ in range(T)])
-            self.add_regularization_weight(
-                filter(lambda x: "weight" in x[0] and "bn" not in x[0], self.tower_dnn.named_parameters()), l2=l2)
-        Ht = self.tower_dnn_hidden_units[-1] if len(self.tower_dnn_hidden_units) > 0 else H
-        self.tower_dnn_final_layer = nn.ModuleList([nn.Linear(Ht, 1, bias=False) for _ in range(T)])
-        self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
-        for mods in (self.bottom, self.tower_dnn_final_layer):
-            self.add_regularization_weight(
-                filter(lambda x: "weight" in x[0] and "bn" not in x[0], mods.named_parameters()), l2=l2)
+        H, l2 = self.bottom_dnn_hidden_units[-1], mc.get("l2_reg_dnn", 0)
+        opts = dnn_options(mc, init_std, device)
+        # registration (= random-draw) order of the reference: g, h1, h2, h3, bottom, tower_dnn, final layers, out
+        self.g = nn.ModuleList(nn.Linear(H, H) for _ in range(T - 1))
+        self.h1, self.h2, self.h3 = (nn.Linear(H, H) for _ in range(3))
+        self.bottom = nn.ModuleList(DNN(self.input_dim, self.bottom_dnn_hidden_units, l2_reg=l2, **opts)
+                                    for _ in range(T))
+        Ht = H
+        if self.tower_dnn_hidden_units:
+            self.tower_dnn = nn.ModuleList(DNN(H, self.tower_dnn_hidden_units, **opts) for _ in range(T))
+            Ht = self.tower_dnn_hidden_units[-1]
+        self.tower_dnn_final_layer = nn.ModuleList(nn.Linear(Ht, 1, bias=False) for _ in range(T))
+        self.out = nn.ModuleList(PredictionLayer(task) for task in self.task_types)
+        l2_on_weights(self, (getattr(self, "tower_dnn", None), self.bottom, self.tower_dnn_final_layer), l2)
         self.to(device)
 
     def _head_mask_cols(self):

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .. import engine as E
 from .basemodel import BaseModel
-from .utils import DNN, emit_dnn_stacks
+from .utils import DNN, dnn_options, emit_dnn_stacks, l2_on_weights
 
 
 class ESMM(BaseModel):
@@ -15,21 +15,14 @@ class ESMM(BaseModel):
         mc = self.model_config
         if self.num_tasks != 2:
             raise ValueError("ESMM has exactly two outputs (ctr, ctcvr)")
+        units = self.expert_dnn_hidden_units = mc.get("expert_dnn_hidden_units", [256, 128])
         self.input_dim = self.compute_input_dim(dnn_feature_columns)
-        self.expert_dnn_hidden_units = mc.get("expert_dnn_hidden_units", [256, 128])
-        l2 = mc.get("l2_reg_dnn", 0)
-        drop, act, bn = mc.get("dnn_dropout", 0), mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
-        self.ctr_dnn = DNN(self.input_dim, self.expert_dnn_hidden_units, activation=act, dropout_rate=drop,
-                           use_bn=bn, init_std=init_std, device=device)
-        self.cvr_dnn = DNN(self.input_dim, self.expert_dnn_hidden_units, activation=act, dropout_rate=drop,
-                           use_bn=bn, init_std=init_std, device=device)
-        self.ctr_dnn_final_layer = nn.Linear(self.expert_dnn_hidden_units[-1], 1, bias=False)
-        self.cvr_dnn_final_layer = nn.Linear(self.expert_dnn_hidden_units[-1], 1, bias=False)
-        for dnn in (self.ctr_dnn, self.cvr_dnn):
-            self.add_regularization_weight(
-                filter(lambda x: "weight" in x[0] and "bn" not in x[0], dnn.named_parameters()), l2=l2)
-        self.add_regularization_weight(self.ctr_dnn_final_layer.weight, l2=l2)
-        self.add_regularization_weight(self.cvr_dnn_final_layer.weight, l2=l2)
+        opts = dnn_options(mc, init_std, device)
+        # registration (= random-draw) order of the reference: ctr tower, cvr tower, then the two final layers
+        self.ctr_dnn, self.cvr_dnn = DNN(self.input_dim, units, **opts), DNN(self.input_dim, units, **opts)
+        self.ctr_dnn_final_layer, self.cvr_dnn_final_layer = (nn.Linear(units[-1], 1, bias=False) for _ in range(2))
+        l2_on_weights(self, (self.ctr_dnn, self.cvr_dnn, self.ctr_dnn_final_layer.weight,
+                             self.cvr_dnn_final_layer.weight), mc.get("l2_reg_dnn", 0))
         self.to(device)
 
     def _head_mask_cols(self):

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import engine as E
 from .basemodel import BaseModel
-from .utils import DNN, PredictionLayer, emit_dnn_stacks
+from .utils import DNN, PredictionLayer, emit_dnn_stacks, l2_on_weights
 
 
 class MLP(BaseModel):
@@ -17,20 +17,20 @@ class MLP(BaseModel):
         super().__init__(linear_feature_columns=[], dnn_feature_columns=dnn_feature_columns, init_std=init_std,
                          device=device, gpus=gpus, config=config)
         mc = self.model_config
+        if not dnn_feature_columns:
+            raise ValueError("dnn_feature_columns is null!")
         self.dnn_use_bn = mc.get("dnn_use_bn", False)
         self.dnn_hidden_units = mc.get("dnn_hidden_units", [256, 128])
+        widths = [self.compute_input_dim(dnn_feature_columns), *self.dnn_hidden_units]
+        print(f"hidden_units:{widths}")
         l2 = mc.get("l2_reg_dnn", 0)
-        if len(dnn_feature_columns) == 0:
-            raise ValueError("dnn_feature_columns is null!")
-        units = [self.compute_input_dim(dnn_feature_columns)] + list(self.dnn_hidden_units)
-        print(f"hidden_units:{units}")
-        # (the reference passes neither init_std nor dropout / bn here: DNN defaults, model/mlp.py:24-26)
-        self.mlp_layers = nn.ModuleList([DNN(inputs_dim=units[i], hidden_units=[units[i + 1]], activation="relu",
-                                             l2_reg=l2, device=device) for i in range(len(self.dnn_hidden_units))])
-        self.final_layer = nn.Linear(self.dnn_hidden_units[-1], 1, bias=False)
-        self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
-        self.add_regularization_weight(
-            filter(lambda x: "weight" in x[0] and "bn" not in x[0], self.mlp_layers.named_parameters()), l2=l2)
+        # one single-layer DNN block per width step; the reference passes neither init_std nor dropout / bn here, so
+        # the blocks are built with the DNN defaults (model/mlp.py:24-26)
+        self.mlp_layers = nn.ModuleList(DNN(inputs_dim=k, hidden_units=[n], activation="relu", l2_reg=l2, device=device)
+                                        for k, n in zip(widths[:-1], widths[1:]))
+        self.final_layer = nn.Linear(widths[-1], 1, bias=False)
+        self.out = nn.ModuleList(PredictionLayer(task) for task in self.task_types)
+        l2_on_weights(self, (self.mlp_layers,), l2)
         self.to(device)
 
     def _head_mask_cols(self):

@@ -237,3 +237,22 @@ class SharedSpecificLinear(nn.Module):
 
     def extra_repr(self):
         return "in_features={}, out_features={}".format(self.in_features, self.out_features)
+
+
+def l2_on_weights(model, modules, l2):
+    """Puts every non-BN `weight` of the given modules (or bare weight tensors) on the model's L2 list -- the
+    add_regularization_weight(filter(...)) idiom the reference repeats after each sub-network (e.g. model/mmoe.py:59-62)."""
+    for m in modules:
+        if m is None:
+            continue
+        if isinstance(m, nn.Parameter):
+            model.add_regularization_weight(m, l2=l2)
+        else:
+            model.add_regularization_weight(
+                [(n, p) for n, p in m.named_parameters() if "weight" in n and "bn" not in n], l2=l2)
+
+
+def dnn_options(mc, init_std, device):
+    """(activation, keyword arguments) every DNN of a model is built with, from model_config."""
+    return dict(activation=mc.get("dnn_activation", "relu"), dropout_rate=mc.get("dnn_dropout", 0),
+                use_bn=mc.get("dnn_use_bn", False), init_std=init_std, device=device)
