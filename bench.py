@@ -202,7 +202,9 @@ def describe_workload(name, cfg, vocab, dense):
     if mc["model_name"] == "ple":
         parts.insert(0, f"{mc.get('num_levels', 2)} levels x ({mc.get('specific_expert_num', 3)} specific + "
                         f"{mc.get('shared_expert_num', 2)} shared) experts")
-    if not keys:
+    if mc["model_name"] in ("esmm", "hmoe", "aitm"):
+        parts.append(f"towers/experts {mc['expert_dnn_hidden_units']}")
+    elif not keys:
         parts.append(f"layers {mc['dnn_hidden_units']}")
     return (f"{name}: {len(vocab)} sparse fields{f' + {len(dense)} dense' if dense else ''}, "
             f"{sum(vocab) / 1e6:.2f}M rows ({max(vocab):.0e}-row top table), E={mc['emb']}, {mc['model_name']} "
