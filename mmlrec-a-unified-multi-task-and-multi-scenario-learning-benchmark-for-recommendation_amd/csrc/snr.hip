@@ -1,0 +1,89 @@
+// Sub-network-routing gate of SNR-trans (reference model/snr_trans.py:8-50): every (output o, input j) pair owns a fixed
+// [units, units] transformation M_oj (plain Python lists in the reference: never registered, never optimised) scaled by
+// a learned hard-concrete coefficient
+//     s = sigmoid(log u - log(1 - u) + log(alpha) / beta),  z = clamp(s * (eps - gamma) + gamma, 0, 1).
+// out_o = sum_j z_oj (x_j @ M_oj) = [x_0 | x_1 | ...] @ [z_o0 M_o0 ; z_o1 M_o1 ; ...]: the scaled blocks are
+// materialised once per step (fwd kernel below) and the routing becomes ONE [K,N]-layout GEMM per output; the
+// gradient of z_oj is the Frobenius product <dW'_oj, M_oj> of the weight gradient that GEMM's wgrad produces (bwd).
+// A few hundred kB of parameters per step: one workgroup per block forward; one workgroup in total backward, so the
+// sums (and d alpha, which collects every block) have a fixed order.
+#include "common.hpp"
+
+namespace mml {
+
+struct SnrConsts {
+  float beta, gamma, eps;
+};
+
+__device__ __forceinline__ float snr_z(float u, float alpha, const SnrConsts& c, float* dz_du, float* dz_dalpha) {
+  const float logit = logf(u) - logf(1.f - u) + logf(alpha) / c.beta;
+  const float s = 1.f / (1.f + expf(-logit));
+  const float sb = s * (c.eps - c.gamma) + c.gamma;
+  const bool live = sb > 0.f && sb <= 1.f;  // the reference's (s_ > 0) * s_, then (z > 1) + (z <= 1) * z
+  const float z = sb <= 0.f ? 0.f : (sb > 1.f ? 1.f : sb);
+  if (dz_du) {
+    const float ds = live ? (c.eps - c.gamma) * s * (1.f - s) : 0.f;
+    *dz_du = ds * (1.f / u + 1.f / (1.f - u));
+    *dz_dalpha = ds / (alpha * c.beta);
+  }
+  return z;
+}
+
+__global__ __launch_bounds__(256) void snr_weights_fwd_kernel(const float* u, const float* alpha, const float* M, float* W,
+                                                              int64_t block, SnrConsts c) {
+  const float z = snr_z(u[blockIdx.x], alpha[0], c, nullptr, nullptr);
+  const float* m = M + (int64_t)blockIdx.x * block;
+  float* w = W + (int64_t)blockIdx.x * block;
+  for (int64_t i = threadIdx.x; i < block; i += 256) w[i] = z * m[i];
+}
+
+__global__ __launch_bounds__(256) void snr_weights_bwd_kernel(const float* dW, const float* M, const float* u,
+                                                              const float* alpha, float* du, float* dalpha, int acc_u,
+                                                              int acc_alpha, int nblocks, int64_t block, SnrConsts c) {
+  __shared__ float red[4];
+  float da = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    float acc = 0.f;
+    const float* g = dW + (int64_t)b * block;
+    const float* m = M + (int64_t)b * block;
+    for (int64_t i = threadIdx.x; i < block; i += 256) acc += g[i] * m[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float dz = red[0] + red[1] + red[2] + red[3];
+      float dzu, dza;
+      snr_z(u[b], alpha[0], c, &dzu, &dza);
+      const float v = dz * dzu;
+      du[b] = acc_u ? du[b] + v : v;
+      da += dz * dza;
+    }
+  }
+  if (threadIdx.x == 0) dalpha[0] = acc_alpha ? dalpha[0] + da : da;
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+extern "C" int mml_snr_gate_weights_fwd(const float* u, const float* alpha, const float* M, float* W, int32_t n_blocks,
+                                        int64_t block, float beta, float gamma, float eps, mml_stream_t stream) {
+  MML_REQUIRE(n_blocks >= 0 && block >= 0, "mml_snr_gate_weights_fwd: negative extent");
+  if (n_blocks == 0 || block == 0) return MML_OK;
+  MML_REQUIRE(u && alpha && M && W && beta != 0.f, "mml_snr_gate_weights_fwd: null argument");
+  MML_LAUNCH(snr_weights_fwd_kernel, dim3((unsigned)n_blocks), dim3(256), 0, to_stream(stream), u, alpha, M, W, block,
+             SnrConsts{beta, gamma, eps});
+  return check_launch("mml_snr_gate_weights_fwd");
+}
+
+extern "C" int mml_snr_gate_weights_bwd(const float* dW, const float* M, const float* u, const float* alpha, float* du,
+                                        float* dalpha, int32_t acc_u, int32_t acc_alpha, int32_t n_blocks, int64_t block,
+                                        float beta, float gamma, float eps, mml_stream_t stream) {
+  MML_REQUIRE(n_blocks >= 0 && block >= 0, "mml_snr_gate_weights_bwd: negative extent");
+  if (n_blocks == 0) return MML_OK;
+  MML_REQUIRE(dW && M && u && alpha && du && dalpha && beta != 0.f, "mml_snr_gate_weights_bwd: null argument");
+  MML_LAUNCH(snr_weights_bwd_kernel, dim3(1), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du, dalpha, (int)acc_u,
+             (int)acc_alpha, (int)n_blocks, block, SnrConsts{beta, gamma, eps});
+  return check_launch("mml_snr_gate_weights_bwd");
+}

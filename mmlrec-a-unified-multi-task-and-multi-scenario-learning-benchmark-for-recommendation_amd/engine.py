@@ -860,6 +860,35 @@ class PMulOp(Op):
                  dict(kernel="ew_mul_bwd_kernel", side=True))]
 
 
+class SnrWeightsOp(Op):
+    """Routing weights of an SNR-trans gate (model/snr_trans.py:38-50): W[o][j] = z(u[o][j], alpha) * M[o][j] for the
+    frozen [units, units] blocks M; views[o] are PVals over W[o] seen as the [n_in*units, units] ([K,N]) weight of
+    output o's routing GEMM.  Backward turns their weight gradients into du and dalpha."""
+    BETA, GAMMA, EPS = 0.9, -0.1, 1.1
+
+    def __init__(self, u, alpha, M, W, dW, views):
+        self.u, self.alpha, self.M, self.W, self.dW, self.views = u, alpha, M, W, dW, views
+        self.n_blocks = M.shape[0] * M.shape[1]
+        self.block = M.shape[2] * M.shape[3]
+
+    def fwd_calls(self, plan):
+        return [(L.load().mml_snr_gate_weights_fwd,
+                 (self.u.data.data_ptr(), self.alpha.data.data_ptr(), self.M.data_ptr(), self.W.data_ptr(),
+                  self.n_blocks, self.block, self.BETA, self.GAMMA, self.EPS),
+                 dict(kernel="snr_weights_fwd_kernel", bytes=8.0 * self.W.numel()))]
+
+    def bwd_calls(self, plan):
+        if not any(v.written for v in self.views):
+            return []
+        if not all(v.written for v in self.views):
+            raise L.MMLError("SnrWeightsOp: every routing weight needs its gradient")
+        return [(L.load().mml_snr_gate_weights_bwd,
+                 (self.dW.data_ptr(), self.M.data_ptr(), self.u.data.data_ptr(), self.alpha.data.data_ptr(),
+                  self.u.grad.data_ptr(), self.alpha.grad.data_ptr(), _claim(self.u), _claim(self.alpha),
+                  self.n_blocks, self.block, self.BETA, self.GAMMA, self.EPS),
+                 dict(kernel="snr_weights_bwd_kernel", bytes=8.0 * self.W.numel(), side=True))]
+
+
 class PAddOp(Op):
     """Derived parameter out = sum(inputs) (STAR bias sums, model/utils.py:216)."""
 

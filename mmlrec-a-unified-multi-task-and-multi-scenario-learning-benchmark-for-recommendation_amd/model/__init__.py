@@ -9,5 +9,6 @@ from .mmoe import MMOE  # noqa: F401
 from .pepnet import PepNet  # noqa: F401
 from .ple import PLE  # noqa: F401
 from .sharedbottom import SharedBottom  # noqa: F401
+from .snr_trans import SNR_trans  # noqa: F401
 from .star import STAR  # noqa: F401
 from .utils import DenseFeat, SparseFeat, VarLenSparseFeat, get_feature_names  # noqa: F401

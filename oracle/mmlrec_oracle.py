@@ -343,6 +343,62 @@ def mlp_bwd(spec, params, cache, dlogit):
     return grads, dh
 
 
+def snr_z(u, alpha, beta=0.9, gamma=-0.1, eps=1.1):
+    """Hard-concrete routing coefficients and their derivatives (model/snr_trans.py:40-43)."""
+    u64, a64 = u.astype(np.float64), float(alpha[0])
+    s = 1.0 / (1.0 + np.exp(-(np.log(u64) - np.log(1 - u64) + np.log(a64) / beta)))
+    sb = s * (eps - gamma) + gamma
+    live = (sb > 0) & (sb <= 1)
+    z = np.where(sb <= 0, 0.0, np.where(sb > 1, 1.0, sb))
+    ds = np.where(live, (eps - gamma) * s * (1 - s), 0.0)
+    return z.astype(F32), (ds * (1 / u64 + 1 / (1 - u64))).astype(F32), (ds / (a64 * beta)).astype(F32)
+
+
+def snr_trans_fwd(spec, params, x, frozen):
+    """SNR_trans.forward (model/snr_trans.py:120-163): per level Ne one-layer experts, then the routing gate
+    out_o = sum_j z_oj (x_j @ M_oj) with the frozen trans_matrix blocks M (never registered: :30-34)."""
+    Ne = int(spec.mc.get("num_experts", 4))
+    units = spec.mc.get("expert_dnn_hidden_units", [256, 128])
+    ins, levels = [x] * Ne, []
+    for i in range(len(units)):
+        hs, acts = [], []
+        for j in range(Ne):
+            h, a = dnn_fwd(params, f"trans.trans{i + 1}.{j}", ins[j])
+            hs.append(h)
+            acts.append(a)
+        M = frozen[f"trans.gate{i + 1}.trans_matrix"]  # [No, Ne, d, d]
+        z, dzu, dza = snr_z(params[f"trans.gate{i + 1}.u"], params[f"trans.gate{i + 1}.alpha"])
+        prods = [[(hs[j] @ M[o, j]).astype(F32) for j in range(Ne)] for o in range(M.shape[0])]
+        outs = [sum(prods[o][j] * z[o, j] for j in range(Ne)).astype(F32) for o in range(M.shape[0])]
+        levels.append(dict(hs=hs, acts=acts, M=M, z=z, dzu=dzu, dza=dza, prods=prods))
+        ins = outs
+    p, tc = _towers_fwd(spec, params, ins)
+    return p, dict(levels=levels, towers=tc, x=x, layers={})
+
+
+def snr_trans_bwd(spec, params, cache, dlogit):
+    Ne = int(spec.mc.get("num_experts", 4))
+    grads = {}
+    douts = _towers_bwd(spec, params, cache["towers"], dlogit, grads)
+    dx = np.zeros_like(cache["x"])
+    nlev = len(cache["levels"])
+    for i in reversed(range(nlev)):
+        c = cache["levels"][i]
+        M, z = c["M"], c["z"]
+        No = M.shape[0]
+        dz = np.array([[float((douts[o].astype(np.float64) * c["prods"][o][j]).sum()) for j in range(Ne)]
+                       for o in range(No)])
+        _acc(grads, f"trans.gate{i + 1}.u", (dz * c["dzu"]).astype(F32))
+        _acc(grads, f"trans.gate{i + 1}.alpha", np.array([(dz * c["dza"]).sum()], dtype=F32))
+        dhs = [sum((douts[o] @ M[o, j].T) * z[o, j] for o in range(No)).astype(F32) for j in range(Ne)]
+        dins = [dnn_bwd(params, f"trans.trans{i + 1}.{j}", c["acts"][j], dhs[j], grads) for j in range(Ne)]
+        if i == 0:
+            dx = sum(dins).astype(F32)
+        else:
+            douts = dins
+    return grads, dx
+
+
 def aitm_fwd(spec, params, x):
     """AITM.forward (model/aitm.py:75-111): bottoms, then for task i >= 1 the attention over the two tokens
     p = g_{i-1}(feat[i-1]) and q = feat[i] with V = h1(.), K = h2(.), Q = h3(.) (:84-93), towers."""
@@ -855,7 +911,7 @@ def pepnet_bwd(spec, params, cache, dlogit):
 
 
 _FWD = {"aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_BWD = {"snr_trans": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):
@@ -864,6 +920,8 @@ def forward(spec, params, X, mask=None, frozen=None):
     x, idx = gather_dnn_input(spec, params, X)
     if spec.model_name == "star":
         p, cache = star_fwd(spec, params, x, frozen)
+    elif spec.model_name == "snr_trans":
+        p, cache = snr_trans_fwd(spec, params, x, frozen)
     else:
         p, cache = _FWD[spec.model_name](spec, params, x)
     cache["dnn_input"] = x

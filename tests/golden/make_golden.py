@@ -41,6 +41,7 @@ from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
+from model.snr_trans import SNR_trans  # noqa: E402
 from model.aitm import AITM  # noqa: E402
 from model.hmoe import HMOE  # noqa: E402
 from model.cross_stitch import CrossStitch  # noqa: E402
@@ -137,6 +138,13 @@ def make_cases():
     c = base_config("mtl", "aitm", ["l1", "l2"], 8, "adam", 0.005, task_names=["ctr", "ctcvr"],
                     task_types=["binary", "binary"], expert_dnn_hidden_units=[32, 24], tower_dnn_hidden_units=[16])
     cases.append(dict(name="aitm_ml", cls=AITM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=2))
+    # SNR-trans (model/snr_trans.py; the model of the shipped configs_msl/config_IAAC.json), msl mode
+    c = base_config("msl", "snr_trans", ["label", "label"], 8, "adam", 0.005, task_types=["binary", "binary"],
+                    num_experts=3, expert_dnn_hidden_units=[32, 16], tower_dnn_hidden_units=[16])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="snr_trans_ae", cls=SNR_trans, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=3,
+                      scene_last=True))
     return cases
 
 
@@ -233,7 +241,11 @@ def run_case(case):
     g2 = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for k, p in model.named_parameters():
-            if p.dim() >= 2:
+            if k.endswith(".u") and cls is SNR_trans:     # routing parameters must stay inside (0, 1)
+                p.copy_(torch.rand(p.shape, generator=g2) * 0.9 + 0.05)
+            elif k.endswith(".alpha") and cls is SNR_trans:
+                p.copy_(torch.rand(p.shape, generator=g2) + 0.5)
+            elif p.dim() >= 2:
                 p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
             elif k.startswith("out."):
                 p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
@@ -249,6 +261,11 @@ def run_case(case):
     if cls is STAR:
         for k, v in frozen_star_tensors(model).items():
             out[f"frozen/{k}"] = v
+    if cls is SNR_trans:  # the unregistered trans_matrix lists (snr_trans.py:30-34), stacked [outputs, inputs, d, d]
+        for gname, mod in model.trans.items():
+            if gname.startswith("gate"):
+                out[f"frozen/trans.{gname}.trans_matrix"] = torch.stack(
+                    [torch.stack([m.detach() for m in row]) for row in mod.trans_matrix]).numpy().copy()
 
     # forward in eval mode with the layer-output hooks on
     model.eval()
