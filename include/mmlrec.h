@@ -312,12 +312,14 @@ int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst
  * fwd  W[b] = z(u[b], alpha) * M[b]  with the hard-concrete z = clamp(sigmoid(log u - log(1-u) + log(alpha)/beta)
  *      * (eps - gamma) + gamma, 0, 1);  the routing is then one [K,N] GEMM per output on the concatenated inputs;
  * bwd  dz[b] = <dW[b], M[b]>, du[b] (+)= dz[b] dz/du, dalpha (+)= sum_b dz[b] dz/dalpha (fixed order).
- * M is the reference's unregistered (hence frozen) trans_matrix stack. */
+ * M is the reference's unregistered (hence frozen) trans_matrix stack.
+ * zw = 1: one coefficient per block (u has n_blocks entries); zw = units: one per output column of a block (MSSM,
+ * model/mssm.py:26-29: u has n_blocks * zw entries and is itself unregistered there -> du may be null). */
 int mml_snr_gate_weights_fwd(const float* u, const float* alpha, const float* M, float* W, int32_t n_blocks,
-                             int64_t block, float beta, float gamma, float eps, mml_stream_t stream);
+                             int64_t block, int32_t zw, float beta, float gamma, float eps, mml_stream_t stream);
 int mml_snr_gate_weights_bwd(const float* dW, const float* M, const float* u, const float* alpha, float* du,
                              float* dalpha, int32_t acc_u, int32_t acc_alpha, int32_t n_blocks, int64_t block,
-                             float beta, float gamma, float eps, mml_stream_t stream);
+                             int32_t zw, float beta, float gamma, float eps, mml_stream_t stream);
 /* Two-token attention of AITM (model/aitm.py:84-93): per sample, tokens t = 0, 1 with V_t, K_t, Q_t in R^H:
  * s_t = <K_t, Q_t> / sqrt_h, a = softmax(s_0, s_1), out = a_0 V_0 + a_1 V_1.  fwd writes out and (if non-null) the
  * weights A [B,2]; bwd reads A and dout and OVERWRITES dV, dK, dQ of both tokens.  All pointers are device pointers,

@@ -113,8 +113,8 @@ _SIGS = {
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
-    "mml_snr_gate_weights_fwd": (C.c_int, [fp, fp, fp, fp, i32, i64, C.c_float, C.c_float, C.c_float, fp]),
-    "mml_snr_gate_weights_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i64, C.c_float, C.c_float,
+    "mml_snr_gate_weights_fwd": (C.c_int, [fp, fp, fp, fp, i32, i64, i32, C.c_float, C.c_float, C.c_float, fp]),
+    "mml_snr_gate_weights_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i64, i32, C.c_float, C.c_float,
                                            C.c_float, fp]),
     "mml_attn2_fwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_attn2_bwd": (C.c_int, [_PP(Attn2Desc), fp]),

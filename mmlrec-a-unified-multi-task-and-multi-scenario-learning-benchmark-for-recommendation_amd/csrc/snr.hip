@@ -29,12 +29,51 @@ __device__ __forceinline__ float snr_z(float u, float alpha, const SnrConsts& c,
   return z;
 }
 
+// zw = 1: one coefficient per block (SNR-trans); zw = units: one per OUTPUT COLUMN of the block (MSSM, whose u is a
+// [units] vector per pair, model/mssm.py:26-29): element e of a row-major [in, out] block belongs to column e % zw
 __global__ __launch_bounds__(256) void snr_weights_fwd_kernel(const float* u, const float* alpha, const float* M, float* W,
-                                                              int64_t block, SnrConsts c) {
-  const float z = snr_z(u[blockIdx.x], alpha[0], c, nullptr, nullptr);
+                                                              int64_t block, int zw, SnrConsts c) {
   const float* m = M + (int64_t)blockIdx.x * block;
   float* w = W + (int64_t)blockIdx.x * block;
-  for (int64_t i = threadIdx.x; i < block; i += 256) w[i] = z * m[i];
+  if (zw == 1) {
+    const float z = snr_z(u[blockIdx.x], alpha[0], c, nullptr, nullptr);
+    for (int64_t i = threadIdx.x; i < block; i += 256) w[i] = z * m[i];
+  } else {
+    const float* ub = u + (int64_t)blockIdx.x * zw;
+    for (int64_t i = threadIdx.x; i < block; i += 256) w[i] = snr_z(ub[i % zw], alpha[0], c, nullptr, nullptr) * m[i];
+  }
+}
+
+// per-column variant of the backward: thread t owns columns t, t + 256, ... of every block
+__global__ __launch_bounds__(256) void snr_weights_bwd_cols_kernel(const float* dW, const float* M, const float* u,
+                                                                   const float* alpha, float* du, float* dalpha,
+                                                                   int acc_u, int acc_alpha, int nblocks, int64_t block,
+                                                                   int zw, SnrConsts c) {
+  __shared__ float red[4];
+  float da = 0.f;
+  const int rows = (int)(block / zw);
+  for (int b = 0; b < nblocks; ++b) {
+    const float* g = dW + (int64_t)b * block;
+    const float* m = M + (int64_t)b * block;
+    for (int col = threadIdx.x; col < zw; col += 256) {
+      float dz = 0.f;
+      for (int k = 0; k < rows; ++k) dz += g[(int64_t)k * zw + col] * m[(int64_t)k * zw + col];
+      float dzu, dza;
+      snr_z(u[(int64_t)b * zw + col], alpha[0], c, &dzu, &dza);
+      if (du) {
+        const float v = dz * dzu;
+        du[(int64_t)b * zw + col] = acc_u ? du[(int64_t)b * zw + col] + v : v;
+      }
+      da += dz * dza;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) da += __shfl_down(da, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3];
+    dalpha[0] = acc_alpha ? dalpha[0] + t : t;
+  }
 }
 
 __global__ __launch_bounds__(256) void snr_weights_bwd_kernel(const float* dW, const float* M, const float* u,
@@ -68,21 +107,29 @@ __global__ __launch_bounds__(256) void snr_weights_bwd_kernel(const float* dW, c
 using namespace mml;
 
 extern "C" int mml_snr_gate_weights_fwd(const float* u, const float* alpha, const float* M, float* W, int32_t n_blocks,
-                                        int64_t block, float beta, float gamma, float eps, mml_stream_t stream) {
+                                        int64_t block, int32_t zw, float beta, float gamma, float eps,
+                                        mml_stream_t stream) {
   MML_REQUIRE(n_blocks >= 0 && block >= 0, "mml_snr_gate_weights_fwd: negative extent");
   if (n_blocks == 0 || block == 0) return MML_OK;
   MML_REQUIRE(u && alpha && M && W && beta != 0.f, "mml_snr_gate_weights_fwd: null argument");
+  MML_REQUIRE(zw >= 1 && block % zw == 0, "mml_snr_gate_weights_fwd: zw must divide the block size");
   MML_LAUNCH(snr_weights_fwd_kernel, dim3((unsigned)n_blocks), dim3(256), 0, to_stream(stream), u, alpha, M, W, block,
-             SnrConsts{beta, gamma, eps});
+             (int)zw, SnrConsts{beta, gamma, eps});
   return check_launch("mml_snr_gate_weights_fwd");
 }
 
 extern "C" int mml_snr_gate_weights_bwd(const float* dW, const float* M, const float* u, const float* alpha, float* du,
                                         float* dalpha, int32_t acc_u, int32_t acc_alpha, int32_t n_blocks, int64_t block,
-                                        float beta, float gamma, float eps, mml_stream_t stream) {
+                                        int32_t zw, float beta, float gamma, float eps, mml_stream_t stream) {
   MML_REQUIRE(n_blocks >= 0 && block >= 0, "mml_snr_gate_weights_bwd: negative extent");
   if (n_blocks == 0) return MML_OK;
-  MML_REQUIRE(dW && M && u && alpha && du && dalpha && beta != 0.f, "mml_snr_gate_weights_bwd: null argument");
+  MML_REQUIRE(dW && M && u && alpha && dalpha && beta != 0.f, "mml_snr_gate_weights_bwd: null argument");
+  MML_REQUIRE(zw >= 1 && block % zw == 0, "mml_snr_gate_weights_bwd: zw must divide the block size");
+  MML_REQUIRE(du || zw > 1, "mml_snr_gate_weights_bwd: du may only be null for frozen per-column coefficients (zw > 1)");
+  if (zw > 1)
+    MML_LAUNCH(snr_weights_bwd_cols_kernel, dim3(1), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du, dalpha,
+               (int)acc_u, (int)acc_alpha, (int)n_blocks, block, (int)zw, SnrConsts{beta, gamma, eps});
+  else
   MML_LAUNCH(snr_weights_bwd_kernel, dim3(1), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du, dalpha, (int)acc_u,
              (int)acc_alpha, (int)n_blocks, block, SnrConsts{beta, gamma, eps});
   return check_launch("mml_snr_gate_weights_bwd");

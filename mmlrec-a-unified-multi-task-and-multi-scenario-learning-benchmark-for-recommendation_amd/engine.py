@@ -861,20 +861,26 @@ class PMulOp(Op):
 
 
 class SnrWeightsOp(Op):
-    """Routing weights of an SNR-trans gate (model/snr_trans.py:38-50): W[o][j] = z(u[o][j], alpha) * M[o][j] for the
-    frozen [units, units] blocks M; views[o] are PVals over W[o] seen as the [n_in*units, units] ([K,N]) weight of
-    output o's routing GEMM.  Backward turns their weight gradients into du and dalpha."""
+    """Routing weights of an SNR-trans / MSSM gate (model/snr_trans.py:38-50, model/mssm.py:40-58): W[o][j] =
+    M[o][j] scaled by the hard-concrete z(u, alpha) -- one coefficient per block (u: PVal [No, Ne], learned) or one per
+    output column (u: frozen tensor [No, Ne, units], MSSM).  views[o] are PVals over W[o] seen as the [n_in*units,
+    units] ([K,N]) weight of output o's routing GEMM.  Backward turns their weight gradients into du and dalpha."""
     BETA, GAMMA, EPS = 0.9, -0.1, 1.1
 
     def __init__(self, u, alpha, M, W, dW, views):
         self.u, self.alpha, self.M, self.W, self.dW, self.views = u, alpha, M, W, dW, views
         self.n_blocks = M.shape[0] * M.shape[1]
         self.block = M.shape[2] * M.shape[3]
+        self.u_learned = isinstance(u, PVal)
+        self.u_data = u.data if self.u_learned else u
+        self.zw = 1 if self.u_data.numel() == self.n_blocks else M.shape[3]
+        if self.u_data.numel() != self.n_blocks * self.zw:
+            raise L.MMLError("SnrWeightsOp: u must hold one coefficient per block or per block column")
 
     def fwd_calls(self, plan):
         return [(L.load().mml_snr_gate_weights_fwd,
-                 (self.u.data.data_ptr(), self.alpha.data.data_ptr(), self.M.data_ptr(), self.W.data_ptr(),
-                  self.n_blocks, self.block, self.BETA, self.GAMMA, self.EPS),
+                 (self.u_data.data_ptr(), self.alpha.data.data_ptr(), self.M.data_ptr(), self.W.data_ptr(),
+                  self.n_blocks, self.block, self.zw, self.BETA, self.GAMMA, self.EPS),
                  dict(kernel="snr_weights_fwd_kernel", bytes=8.0 * self.W.numel()))]
 
     def bwd_calls(self, plan):
@@ -882,10 +888,11 @@ class SnrWeightsOp(Op):
             return []
         if not all(v.written for v in self.views):
             raise L.MMLError("SnrWeightsOp: every routing weight needs its gradient")
+        du, acc_u = (self.u.grad.data_ptr(), _claim(self.u)) if self.u_learned else (None, 0)
         return [(L.load().mml_snr_gate_weights_bwd,
-                 (self.dW.data_ptr(), self.M.data_ptr(), self.u.data.data_ptr(), self.alpha.data.data_ptr(),
-                  self.u.grad.data_ptr(), self.alpha.grad.data_ptr(), _claim(self.u), _claim(self.alpha),
-                  self.n_blocks, self.block, self.BETA, self.GAMMA, self.EPS),
+                 (self.dW.data_ptr(), self.M.data_ptr(), self.u_data.data_ptr(), self.alpha.data.data_ptr(), du,
+                  self.alpha.grad.data_ptr(), acc_u, _claim(self.alpha), self.n_blocks, self.block, self.zw, self.BETA,
+                  self.GAMMA, self.EPS),
                  dict(kernel="snr_weights_bwd_kernel", bytes=8.0 * self.W.numel(), side=True))]
 
 

@@ -6,6 +6,7 @@ from .esmm import ESMM  # noqa: F401
 from .hmoe import HMOE  # noqa: F401
 from .mlp import MLP  # noqa: F401
 from .mmoe import MMOE  # noqa: F401
+from .mssm import MSSM  # noqa: F401
 from .pepnet import PepNet  # noqa: F401
 from .ple import PLE  # noqa: F401
 from .sharedbottom import SharedBottom  # noqa: F401

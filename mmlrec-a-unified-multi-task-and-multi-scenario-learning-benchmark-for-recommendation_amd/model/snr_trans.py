@@ -59,17 +59,20 @@ class SNR_trans(BaseModel):
                             opts["use_bn"], init_std, device)
         self.to(device)
 
+    _DICT, _EXPERT = "trans", "trans"  # ModuleDict attribute and the key stem of its expert lists
+
     def _build_graph(self, plan, store, x0):
         Ne = self.num_experts
         ins = [x0] * Ne
+        mods, stem = getattr(self, self._DICT), f"{self._DICT}.{self._EXPERT}"
         for i, d in enumerate(self.expert_dnn_hidden_units):
             if d % 4:
-                raise NotImplementedError("SNR-trans widths must be multiples of 4 (16-byte column slices)")
-            g = self.trans[f"gate{i + 1}"]
+                raise NotImplementedError("routing widths must be multiples of 4 (16-byte column slices)")
+            g = mods[f"gate{i + 1}"]
             No = g.output_dim
             cat = plan.val(Ne * d, act=L.ACT_RELU, name=f"snr.{i}.cat")
             parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], L.ACT_RELU, name=f"snr.{i}.expert.{j}") for j in range(Ne)]
-            pfx = f"trans.trans{i + 1}"
+            pfx = f"{stem}{i + 1}"
             plan.add(E.LinearGroupOp([dict(x=ins[j], W=store.pvals[f"{pfx}.{j}.linears.0.weight"],
                                            b=store.pvals[f"{pfx}.{j}.linears.0.bias"], out=parts[j])
                                       for j in range(Ne)]))
@@ -77,7 +80,8 @@ class SNR_trans(BaseModel):
             W = plan.empty(No, Ne * d, d)
             dW = plan.zeros(No, Ne * d, d) if plan.training else None
             views = [E.PVal(W[o], dW[o] if dW is not None else None, f"snr.{i}.w.{o}") for o in range(No)]
-            plan.add(E.SnrWeightsOp(store.pvals[f"trans.gate{i + 1}.u"], store.pvals[f"trans.gate{i + 1}.alpha"],
+            u = store.pvals.get(f"{self._DICT}.gate{i + 1}.u", None)  # learned (SNR-trans) or frozen tensor (MSSM)
+            plan.add(E.SnrWeightsOp(u if u is not None else g.u, store.pvals[f"{self._DICT}.gate{i + 1}.alpha"],
                                     g.trans_matrix, W, dW, views))
             outs = [plan.val(d, name=f"snr.{i}.out.{o}") for o in range(No)]
             plan.add(E.LinearGroupOp([dict(x=cat, W=views[o], b=None, out=outs[o], w_kn=1) for o in range(No)]))

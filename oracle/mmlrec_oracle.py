@@ -359,15 +359,19 @@ def snr_trans_fwd(spec, params, x, frozen):
     out_o = sum_j z_oj (x_j @ M_oj) with the frozen trans_matrix blocks M (never registered: :30-34)."""
     Ne = int(spec.mc.get("num_experts", 4))
     units = spec.mc.get("expert_dnn_hidden_units", [256, 128])
+    # MSSM (model/mssm.py:128-179) is the same network with other key names and per-COLUMN coefficients whose seeds u
+    # are unregistered too ([No, Ne, d], from the fixture's frozen set); a [d] z scales the columns of x_j @ M_oj
+    dct, stem = ("mssm", "mssm.expert") if spec.model_name == "mssm" else ("trans", "trans.trans")
     ins, levels = [x] * Ne, []
     for i in range(len(units)):
         hs, acts = [], []
         for j in range(Ne):
-            h, a = dnn_fwd(params, f"trans.trans{i + 1}.{j}", ins[j])
+            h, a = dnn_fwd(params, f"{stem}{i + 1}.{j}", ins[j])
             hs.append(h)
             acts.append(a)
-        M = frozen[f"trans.gate{i + 1}.trans_matrix"]  # [No, Ne, d, d]
-        z, dzu, dza = snr_z(params[f"trans.gate{i + 1}.u"], params[f"trans.gate{i + 1}.alpha"])
+        M = frozen[f"{dct}.gate{i + 1}.trans_matrix"]  # [No, Ne, d, d]
+        ukey = f"{dct}.gate{i + 1}.u"
+        z, dzu, dza = snr_z(params[ukey] if ukey in params else frozen[ukey], params[f"{dct}.gate{i + 1}.alpha"])
         prods = [[(hs[j] @ M[o, j]).astype(F32) for j in range(Ne)] for o in range(M.shape[0])]
         outs = [sum(prods[o][j] * z[o, j] for j in range(Ne)).astype(F32) for o in range(M.shape[0])]
         levels.append(dict(hs=hs, acts=acts, M=M, z=z, dzu=dzu, dza=dza, prods=prods))
@@ -386,12 +390,16 @@ def snr_trans_bwd(spec, params, cache, dlogit):
         c = cache["levels"][i]
         M, z = c["M"], c["z"]
         No = M.shape[0]
-        dz = np.array([[float((douts[o].astype(np.float64) * c["prods"][o][j]).sum()) for j in range(Ne)]
+        per_col = z.ndim == 3
+        dz = np.array([[(douts[o].astype(np.float64) * c["prods"][o][j]).sum(0) if per_col else
+                        float((douts[o].astype(np.float64) * c["prods"][o][j]).sum()) for j in range(Ne)]
                        for o in range(No)])
-        _acc(grads, f"trans.gate{i + 1}.u", (dz * c["dzu"]).astype(F32))
-        _acc(grads, f"trans.gate{i + 1}.alpha", np.array([(dz * c["dza"]).sum()], dtype=F32))
-        dhs = [sum((douts[o] @ M[o, j].T) * z[o, j] for o in range(No)).astype(F32) for j in range(Ne)]
-        dins = [dnn_bwd(params, f"trans.trans{i + 1}.{j}", c["acts"][j], dhs[j], grads) for j in range(Ne)]
+        dct, stem = ("mssm", "mssm.expert") if spec.model_name == "mssm" else ("trans", "trans.trans")
+        if not per_col:  # SNR-trans: u is a registered parameter; MSSM's u never learns
+            _acc(grads, f"{dct}.gate{i + 1}.u", (dz * c["dzu"]).astype(F32))
+        _acc(grads, f"{dct}.gate{i + 1}.alpha", np.array([(dz * c["dza"]).sum()], dtype=F32))
+        dhs = [sum((douts[o] * z[o, j]) @ M[o, j].T for o in range(No)).astype(F32) for j in range(Ne)]
+        dins = [dnn_bwd(params, f"{stem}{i + 1}.{j}", c["acts"][j], dhs[j], grads) for j in range(Ne)]
         if i == 0:
             dx = sum(dins).astype(F32)
         else:
@@ -911,7 +919,7 @@ def pepnet_bwd(spec, params, cache, dlogit):
 
 
 _FWD = {"aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"snr_trans": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_BWD = {"snr_trans": snr_trans_bwd, "mssm": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):
@@ -920,7 +928,7 @@ def forward(spec, params, X, mask=None, frozen=None):
     x, idx = gather_dnn_input(spec, params, X)
     if spec.model_name == "star":
         p, cache = star_fwd(spec, params, x, frozen)
-    elif spec.model_name == "snr_trans":
+    elif spec.model_name in ("snr_trans", "mssm"):
         p, cache = snr_trans_fwd(spec, params, x, frozen)
     else:
         p, cache = _FWD[spec.model_name](spec, params, x)

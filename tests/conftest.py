@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "star_amazon",
                 "pepnet_amazon", "mlp_ml", "mlp_ae", "esmm_ml",
-                "cross_stitch_ae", "hmoe_ml", "aitm_ml", "snr_trans_ae"]
+                "cross_stitch_ae", "hmoe_ml", "aitm_ml", "snr_trans_ae",
+                "mssm_ml"]
 
 
 def pytest_configure(config):

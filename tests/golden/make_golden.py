@@ -42,6 +42,7 @@ from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
 from model.snr_trans import SNR_trans  # noqa: E402
+from model.mssm import MSSM  # noqa: E402
 from model.aitm import AITM  # noqa: E402
 from model.hmoe import HMOE  # noqa: E402
 from model.cross_stitch import CrossStitch  # noqa: E402
@@ -145,6 +146,13 @@ def make_cases():
                              "scene_feature": "scene"})
     cases.append(dict(name="snr_trans_ae", cls=SNR_trans, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=3,
                       scene_last=True))
+    # MSSM (model/mssm.py; shipped configs_mtmsl/config_movielens.json and, with BN, configs_mtl/config_census.json)
+    c = base_config("mtmsl", "mssm", ["label", "label", "label2", "label2"], 8, "adagrad", 0.01,
+                    task_types=["binary"] * 4, num_experts=3, expert_dnn_hidden_units=[32, 16],
+                    tower_dnn_hidden_units=[16])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="mssm_ml", cls=MSSM, cfg=c, vocab=[2, 12, 23, 96, 64, 64, 48, 2], nd=0, scene_last=True))
     return cases
 
 
@@ -243,7 +251,7 @@ def run_case(case):
         for k, p in model.named_parameters():
             if k.endswith(".u") and cls is SNR_trans:     # routing parameters must stay inside (0, 1)
                 p.copy_(torch.rand(p.shape, generator=g2) * 0.9 + 0.05)
-            elif k.endswith(".alpha") and cls is SNR_trans:
+            elif k.endswith(".alpha") and cls in (SNR_trans, MSSM):
                 p.copy_(torch.rand(p.shape, generator=g2) + 0.5)
             elif p.dim() >= 2:
                 p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
@@ -261,6 +269,13 @@ def run_case(case):
     if cls is STAR:
         for k, v in frozen_star_tensors(model).items():
             out[f"frozen/{k}"] = v
+    if cls is MSSM:  # unregistered u vectors and trans_matrix lists (mssm.py:26-36)
+        for gname, mod in model.mssm.items():
+            if gname.startswith("gate"):
+                out[f"frozen/mssm.{gname}.trans_matrix"] = torch.stack(
+                    [torch.stack([m.detach() for m in row]) for row in mod.trans_matrix]).numpy().copy()
+                out[f"frozen/mssm.{gname}.u"] = torch.stack(
+                    [torch.stack([m.detach() for m in row]) for row in mod.u]).numpy().copy()
     if cls is SNR_trans:  # the unregistered trans_matrix lists (snr_trans.py:30-34), stacked [outputs, inputs, d, d]
         for gname, mod in model.trans.items():
             if gname.startswith("gate"):

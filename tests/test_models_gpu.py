@@ -20,13 +20,13 @@ def rel(a, b):
 
 def build(g, device="cuda:0", **model_kw):
     import mmlrec_amd  # noqa: F401
-    from mmlrec_amd.model import AITM, ESMM, HMOE, MLP, MMOE, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from mmlrec_amd.model import AITM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg = json.loads(str(g["cfg"]))
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(str(n), int(v), embedding_dim=emb) for n, v in zip(g["sparse_names"], g["vocab"])]
     cols += [DenseFeat(str(n), 1) for n in g["dense_names"]]
-    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans}[
+    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(0)
     model = cls(cols, device=device, config=cfg)
@@ -38,9 +38,9 @@ def load_state(model, g, prefix="state/"):
     model.load_state_dict(sd, strict=True)
     # STAR: unregistered per-domain tensors (reference utils.py:181-191), e.g. frozen/linears.0.specific_weights.1
     for k in g.files:
-        if k.startswith("frozen/trans."):  # SNR-trans: the unregistered trans_matrix stack of a gate
-            gate_name = k.split(".")[1]
-            tm = model.trans[gate_name].trans_matrix
+        if k.startswith("frozen/trans.") or k.startswith("frozen/mssm."):  # SNR-trans / MSSM: unregistered gate tensors
+            dct, gate_name, attr = k[len("frozen/"):].split(".")
+            tm = getattr(getattr(model, dct)[gate_name], attr)
             tm.copy_(torch.from_numpy(np.array(g[k])).to(tm.device))
             continue
         if k.startswith("frozen/"):
