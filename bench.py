@@ -202,7 +202,7 @@ def describe_workload(name, cfg, vocab, dense):
     if mc["model_name"] == "ple":
         parts.insert(0, f"{mc.get('num_levels', 2)} levels x ({mc.get('specific_expert_num', 3)} specific + "
                         f"{mc.get('shared_expert_num', 2)} shared) experts")
-    if mc["model_name"] in ("esmm", "hmoe", "aitm"):
+    if mc["model_name"] in ("esmm", "hmoe", "aitm", "snr_trans", "mssm"):
         parts.append(f"towers/experts {mc['expert_dnn_hidden_units']}")
     elif not keys:
         parts.append(f"layers {mc['dnn_hidden_units']}")

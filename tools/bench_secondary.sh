@@ -19,7 +19,7 @@ for B in 4096 65536; do
   run pepnet_amazon_b$B "MMLREC_GEMM_MODE=4" --workload pepnet_amazon --batch $B
   run ae30d_b$B        "MMLREC_GEMM_MODE=4" --workload mmoe_ae30d --batch $B
 done
-for w in mlp_ae30 esmm_ae30 cross_stitch_ae30 hmoe_ae30 aitm_ae30; do
+for w in mlp_ae30 esmm_ae30 cross_stitch_ae30 hmoe_ae30 aitm_ae30 snr_trans_ae30 mssm_ae30; do
   run ${w}_b65536 "MMLREC_GEMM_MODE=4" --workload $w --batch 65536
 done
 python3 - <<'PY'
