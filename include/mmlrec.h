@@ -319,7 +319,8 @@ int mml_snr_gate_weights_fwd(const float* u, const float* alpha, const float* M,
                              int64_t block, int32_t zw, float beta, float gamma, float eps, mml_stream_t stream);
 int mml_snr_gate_weights_bwd(const float* dW, const float* M, const float* u, const float* alpha, float* du,
                              float* dalpha, int32_t acc_u, int32_t acc_alpha, int32_t n_blocks, int64_t block,
-                             int32_t zw, float beta, float gamma, float eps, mml_stream_t stream);
+                             int32_t zw, float beta, float gamma, float eps, float* workspace /* n_blocks floats */,
+                             mml_stream_t stream);
 /* Two-token attention of AITM (model/aitm.py:84-93): per sample, tokens t = 0, 1 with V_t, K_t, Q_t in R^H:
  * s_t = <K_t, Q_t> / sqrt_h, a = softmax(s_0, s_1), out = a_0 V_0 + a_1 V_1.  fwd writes out and (if non-null) the
  * weights A [B,2]; bwd reads A and dout and OVERWRITES dV, dK, dQ of both tokens.  All pointers are device pointers,

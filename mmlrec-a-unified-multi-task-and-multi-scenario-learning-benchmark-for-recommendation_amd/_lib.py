@@ -115,7 +115,7 @@ _SIGS = {
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
     "mml_snr_gate_weights_fwd": (C.c_int, [fp, fp, fp, fp, i32, i64, i32, C.c_float, C.c_float, C.c_float, fp]),
     "mml_snr_gate_weights_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i64, i32, C.c_float, C.c_float,
-                                           C.c_float, fp]),
+                                           C.c_float, fp, fp]),
     "mml_attn2_fwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_attn2_bwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_esmm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp]),

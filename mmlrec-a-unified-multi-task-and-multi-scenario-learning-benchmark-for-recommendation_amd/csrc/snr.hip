@@ -44,17 +44,20 @@ __global__ __launch_bounds__(256) void snr_weights_fwd_kernel(const float* u, co
   }
 }
 
-// per-column variant of the backward: thread t owns columns t, t + 256, ... of every block
-__global__ __launch_bounds__(256) void snr_weights_bwd_cols_kernel(const float* dW, const float* M, const float* u,
-                                                                   const float* alpha, float* du, float* dalpha,
-                                                                   int acc_u, int acc_alpha, int nblocks, int64_t block,
-                                                                   int zw, SnrConsts c) {
+// backward, stage 1: one workgroup per block.  zw == 1: dz = <dW_b, M_b>; zw > 1: one dz per output column (thread t owns
+// columns t, t + 256, ...).  Writes du (when u learns) and the block's contribution to d alpha into part[b].
+__global__ __launch_bounds__(256) void snr_weights_bwd_kernel(const float* dW, const float* M, const float* u,
+                                                              const float* alpha, float* du, float* part, int acc_u,
+                                                              int64_t block, int zw, SnrConsts c) {
   __shared__ float red[4];
-  float da = 0.f;
-  const int rows = (int)(block / zw);
-  for (int b = 0; b < nblocks; ++b) {
-    const float* g = dW + (int64_t)b * block;
-    const float* m = M + (int64_t)b * block;
+  const int b = blockIdx.x;
+  const float* g = dW + (int64_t)b * block;
+  const float* m = M + (int64_t)b * block;
+  float acc = 0.f;  // zw == 1: the block's dot product; zw > 1: this thread's share of d alpha
+  if (zw == 1) {
+    for (int64_t i = threadIdx.x; i < block; i += 256) acc += g[i] * m[i];
+  } else {
+    const int rows = (int)(block / zw);
     for (int col = threadIdx.x; col < zw; col += 256) {
       float dz = 0.f;
       for (int k = 0; k < rows; ++k) dz += g[(int64_t)k * zw + col] * m[(int64_t)k * zw + col];
@@ -64,42 +67,31 @@ __global__ __launch_bounds__(256) void snr_weights_bwd_cols_kernel(const float* 
         const float v = dz * dzu;
         du[(int64_t)b * zw + col] = acc_u ? du[(int64_t)b * zw + col] + v : v;
       }
-      da += dz * dza;
+      acc += dz * dza;
     }
   }
-  for (int o = 32; o > 0; o >>= 1) da += __shfl_down(da, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = da;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = red[0] + red[1] + red[2] + red[3];
-    dalpha[0] = acc_alpha ? dalpha[0] + t : t;
+    if (zw == 1) {
+      float dzu, dza;
+      snr_z(u[b], alpha[0], c, &dzu, &dza);
+      const float v = t * dzu;
+      du[b] = acc_u ? du[b] + v : v;
+      part[b] = t * dza;
+    } else {
+      part[b] = t;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void snr_weights_bwd_kernel(const float* dW, const float* M, const float* u,
-                                                              const float* alpha, float* du, float* dalpha, int acc_u,
-                                                              int acc_alpha, int nblocks, int64_t block, SnrConsts c) {
-  __shared__ float red[4];
-  float da = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    float acc = 0.f;
-    const float* g = dW + (int64_t)b * block;
-    const float* m = M + (int64_t)b * block;
-    for (int64_t i = threadIdx.x; i < block; i += 256) acc += g[i] * m[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float dz = red[0] + red[1] + red[2] + red[3];
-      float dzu, dza;
-      snr_z(u[b], alpha[0], c, &dzu, &dza);
-      const float v = dz * dzu;
-      du[b] = acc_u ? du[b] + v : v;
-      da += dz * dza;
-    }
-  }
-  if (threadIdx.x == 0) dalpha[0] = acc_alpha ? dalpha[0] + da : da;
+// stage 2: d alpha = sum of the per-block contributions, in block order
+__global__ void snr_alpha_kernel(const float* part, float* dalpha, int nblocks, int acc_alpha) {
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[b];
+  dalpha[0] = acc_alpha ? dalpha[0] + s : s;
 }
 
 }  // namespace mml
@@ -120,17 +112,17 @@ extern "C" int mml_snr_gate_weights_fwd(const float* u, const float* alpha, cons
 
 extern "C" int mml_snr_gate_weights_bwd(const float* dW, const float* M, const float* u, const float* alpha, float* du,
                                         float* dalpha, int32_t acc_u, int32_t acc_alpha, int32_t n_blocks, int64_t block,
-                                        int32_t zw, float beta, float gamma, float eps, mml_stream_t stream) {
+                                        int32_t zw, float beta, float gamma, float eps, float* workspace,
+                                        mml_stream_t stream) {
   MML_REQUIRE(n_blocks >= 0 && block >= 0, "mml_snr_gate_weights_bwd: negative extent");
   if (n_blocks == 0) return MML_OK;
-  MML_REQUIRE(dW && M && u && alpha && dalpha && beta != 0.f, "mml_snr_gate_weights_bwd: null argument");
+  MML_REQUIRE(dW && M && u && alpha && dalpha && workspace && beta != 0.f, "mml_snr_gate_weights_bwd: null argument");
   MML_REQUIRE(zw >= 1 && block % zw == 0, "mml_snr_gate_weights_bwd: zw must divide the block size");
   MML_REQUIRE(du || zw > 1, "mml_snr_gate_weights_bwd: du may only be null for frozen per-column coefficients (zw > 1)");
-  if (zw > 1)
-    MML_LAUNCH(snr_weights_bwd_cols_kernel, dim3(1), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du, dalpha,
-               (int)acc_u, (int)acc_alpha, (int)n_blocks, block, (int)zw, SnrConsts{beta, gamma, eps});
-  else
-  MML_LAUNCH(snr_weights_bwd_kernel, dim3(1), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du, dalpha, (int)acc_u,
-             (int)acc_alpha, (int)n_blocks, block, SnrConsts{beta, gamma, eps});
+  MML_LAUNCH(snr_weights_bwd_kernel, dim3((unsigned)n_blocks), dim3(256), 0, to_stream(stream), dW, M, u, alpha, du,
+             workspace, (int)acc_u, block, (int)zw, SnrConsts{beta, gamma, eps});
+  int rc = check_launch("mml_snr_gate_weights_bwd");
+  if (rc) return rc;
+  MML_LAUNCH(snr_alpha_kernel, dim3(1), dim3(1), 0, to_stream(stream), workspace, dalpha, (int)n_blocks, (int)acc_alpha);
   return check_launch("mml_snr_gate_weights_bwd");
 }

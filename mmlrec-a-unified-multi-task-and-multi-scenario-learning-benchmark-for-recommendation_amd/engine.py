@@ -892,7 +892,7 @@ class SnrWeightsOp(Op):
         return [(L.load().mml_snr_gate_weights_bwd,
                  (self.dW.data_ptr(), self.M.data_ptr(), self.u_data.data_ptr(), self.alpha.data.data_ptr(), du,
                   self.alpha.grad.data_ptr(), acc_u, _claim(self.alpha), self.n_blocks, self.block, self.zw, self.BETA,
-                  self.GAMMA, self.EPS),
+                  self.GAMMA, self.EPS, plan.empty(self.n_blocks).data_ptr()),
                  dict(kernel="snr_weights_bwd_kernel", bytes=8.0 * self.W.numel(), side=True))]
 
 
