@@ -310,7 +310,8 @@ class BaseModel(nn.Module):
             self._load_batch(plan, X, domain_mask if masked else None)
             plan.run_forward()
             out = plan.prob.clone()
-        ops.check_status(plan.status, "embedding lookup (nn.Embedding semantics)")
+        if not getattr(self, "_defer_status", False):  # predict() checks once after its last batch (one host sync)
+            ops.check_status(plan.status, "embedding lookup (nn.Embedding semantics)")
         if not self.training and self.save_layer_output:
             self.layer_output_dict = self._collect_layer_outputs(plan)
         return out
@@ -574,12 +575,18 @@ class BaseModel(nn.Module):
         Xd = torch.as_tensor(X, dtype=torch.float32).to(dev)
         self._loader_iter_draw()
         outs, layers = [], {}
-        with torch.no_grad():
-            for s in range(0, Xd.shape[0], batch_size):
-                outs.append(self.forward(Xd[s:s + batch_size], None))
-                if self.save_layer_output:
-                    for k, v in self.layer_output_dict.items():
-                        layers.setdefault(k, []).append(v.cpu().numpy())
+        self._defer_status = True
+        try:
+            with torch.no_grad():
+                for s in range(0, Xd.shape[0], batch_size):
+                    outs.append(self.forward(Xd[s:s + batch_size], None))
+                    if self.save_layer_output:
+                        for k, v in self.layer_output_dict.items():
+                            layers.setdefault(k, []).append(v.cpu().numpy())
+        finally:
+            self._defer_status = False
+        for pl in self._caches["plans"].values():  # out-of-range indices of ANY batch are sticky in the plan's status word
+            ops.check_status(pl.status, "embedding lookup (nn.Embedding semantics)")
         pred = torch.cat(outs).cpu().numpy().astype("float64")
         self.train(was_training)
         if self.save_layer_output:
