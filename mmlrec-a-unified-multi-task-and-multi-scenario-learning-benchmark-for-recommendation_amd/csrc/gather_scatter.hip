@@ -57,42 +57,47 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, c
   const int e4 = a.E >> 2;
   const int nvec = a.F * e4;             // 16-byte pieces per sample
   const int per_sample = nvec + a.Nd;    // + dense scalars
-  const int64_t total = a.B * per_sample;
+  // A thread keeps ONE output column slot c and walks ITEMS consecutive samples: the (sample, slot) split costs one
+  // 32-bit division per ITEMS items instead of a 64-bit one per item, the field / piece decode happens once per
+  // thread, and neighbouring lanes still write neighbouring 16-byte pieces of the same row.
+  const int64_t groups = (a.B + ITEMS - 1) / ITEMS;          // sample groups
+  const int64_t total = groups * per_sample;                 // threads' work items
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int bad = 0;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < total; base += stride * ITEMS) {
-    float4 v[ITEMS];
-    int64_t dst[ITEMS];
-    int kind[ITEMS];  // 0 = skip, 1 = vec4, 2 = dense scalar
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int64_t item = base + (int64_t)i * stride;
-      kind[i] = 0;
-      if (item < total) {
-        const int64_t b = item / per_sample;
-        const int c = (int)(item - b * per_sample);
-        if (c < nvec) {
-          const int f = c / e4;
-          const int part = c - f * e4;
-          const int64_t row = load_index(a, b, f, ft, bad);
-          v[i] = *reinterpret_cast<const float4*>(ft.tab[f] + row * a.E + part * 4);
-          dst[i] = b * a.ldo + (int64_t)c * 4;
-          kind[i] = 1;
-        } else {
-          const int j = c - nvec;
-          v[i].x = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
-          dst[i] = b * a.ldo + (int64_t)a.F * a.E + j;
-          kind[i] = 2;
-        }
-      }
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < total; base += stride) {
+    int64_t grp;
+    int c;
+    if (total < 0x7fffffff) {
+      const uint32_t q = (uint32_t)base / (uint32_t)per_sample;
+      grp = q;
+      c = (int)((uint32_t)base - q * (uint32_t)per_sample);
+    } else {
+      grp = base / per_sample;
+      c = (int)(base - grp * per_sample);
     }
+    const int64_t b0 = grp * ITEMS;
+    if (c < nvec) {
+      const int f = c / e4;
+      const int part = c - f * e4;
+      const float* tab = ft.tab[f] + part * 4;
+      float4 v[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      if (kind[i] == 1) {
-        *reinterpret_cast<float4*>(a.out + dst[i]) = v[i];
-      } else if (kind[i] == 2) {
-        a.out[dst[i]] = v[i].x;
-      }
+      for (int i = 0; i < ITEMS; ++i)
+        if (b0 + i < a.B) {
+          const int64_t row = load_index(a, b0 + i, f, ft, bad);
+          v[i] = *reinterpret_cast<const float4*>(tab + row * a.E);
+        }
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i)
+        if (b0 + i < a.B) *reinterpret_cast<float4*>(a.out + (b0 + i) * a.ldo + (int64_t)c * 4) = v[i];
+    } else {
+      const int j = c - nvec;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i)
+        if (b0 + i < a.B) {
+          const int64_t b = b0 + i;
+          a.out[b * a.ldo + (int64_t)a.F * a.E + j] = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+        }
     }
   }
   if (bad && a.status) atomicOr(a.status, bad);
@@ -129,8 +134,8 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
   const int threads = 256;
   if (vec) {
     constexpr int ITEMS = 4;
-    const int64_t total = a.B * ((int64_t)a.F * (a.E / 4) + a.Nd);
-    int64_t blocks = cdiv(total, (int64_t)threads * ITEMS);
+    const int64_t total = cdiv(a.B, (int64_t)ITEMS) * ((int64_t)a.F * (a.E / 4) + a.Nd);
+    int64_t blocks = cdiv(total, (int64_t)threads);
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
     MML_LAUNCH(gather_vec4_kernel<ITEMS>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
   } else {
