@@ -308,6 +308,20 @@ int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
  * All arrays are HOST arrays of n_seg entries holding device pointers / element strides. */
 int mml_copy_cols(const float* const* src, const int64_t* lds, float* const* dst, const int64_t* ldd,
                   const int32_t* width, int32_t n_seg, int64_t rows, int32_t accumulate, mml_stream_t stream);
+/* BatchNorm1d inside DNN (model/utils.py:132-134, :153-154: fc -> bn -> activation; torch defaults eps 1e-5, momentum
+ * 0.1).  fwd, training != 0: batch statistics (mean / rstd are written for the backward), running statistics and
+ * num_batches_tracked updated in place; training == 0: running statistics.  y = act(gamma (z - mean) rstd + beta).
+ * bwd: dy is the gradient w.r.t. the BN output (activation derivative already applied by the caller);
+ * dgamma / dbeta are written (or accumulated), dz = gamma rstd (dy - (sum dy + xhat sum dy xhat) / B).
+ * Workspace: mml_bn_workspace_bytes(B, n) for either call. */
+int64_t mml_bn_workspace_bytes(int64_t B, int32_t n);
+int mml_bn_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               int64_t* num_batches_tracked, float* mean, float* rstd, float* y, int64_t ldy, int64_t B, int32_t n,
+               int32_t act, int32_t training, float eps, float momentum, void* workspace, int64_t workspace_bytes,
+               mml_stream_t stream);
+int mml_bn_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* gamma, const float* mean,
+               const float* rstd, float* dz, int64_t lddz, float* dgamma, float* dbeta, int32_t accumulate, int64_t B,
+               int32_t n, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
 /* SNR-trans routing weights (model/snr_trans.py:38-50).  n_blocks = outputs x inputs blocks of `block` floats each:
  * fwd  W[b] = z(u[b], alpha) * M[b]  with the hard-concrete z = clamp(sigmoid(log u - log(1-u) + log(alpha)/beta)
  *      * (eps - gamma) + gamma, 0, 1);  the routing is then one [K,N] GEMM per output on the concatenated inputs;

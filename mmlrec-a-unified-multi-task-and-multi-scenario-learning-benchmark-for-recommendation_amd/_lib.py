@@ -113,6 +113,10 @@ _SIGS = {
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
+    "mml_bn_workspace_bytes": (C.c_int64, [i64, i32]),
+    "mml_bn_fwd": (C.c_int, [fp, i64, fp, fp, fp, fp, fp, fp, fp, fp, i64, i64, i32, i32, i32, C.c_float, C.c_float, fp,
+                             i64, fp]),
+    "mml_bn_bwd": (C.c_int, [fp, i64, fp, i64, fp, fp, fp, fp, i64, fp, fp, i32, i64, i32, fp, i64, fp]),
     "mml_snr_gate_weights_fwd": (C.c_int, [fp, fp, fp, fp, i32, i64, i32, C.c_float, C.c_float, C.c_float, fp]),
     "mml_snr_gate_weights_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i64, i32, C.c_float, C.c_float,
                                            C.c_float, fp, fp]),

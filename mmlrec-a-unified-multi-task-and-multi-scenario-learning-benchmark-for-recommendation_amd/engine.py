@@ -652,6 +652,61 @@ class EsmmHeadOp(HeadOp):
                        dict(kernel="head_kernel", bytes=byts))] + post
 
 
+class BNOp(Op):
+    """BatchNorm1d between a layer's Linear and its activation (reference model/utils.py:153-157): z -> y = act(bn(z)).
+    Batch statistics (and the in-place running-statistics update) when the module is in training mode, running
+    statistics otherwise -- `plan.bn_training`, NOT plan.training: a no_grad forward of a model in train() mode still
+    normalises with the batch and moves the running statistics, exactly like torch."""
+    EPS, MOMENTUM = 1e-5, 0.1
+
+    def __init__(self, z, y, gamma, beta, module):
+        self.z, self.y, self.gamma, self.beta, self.m = z, y, gamma, beta, module
+
+    def inputs(self):
+        return [self.z]
+
+    def outputs(self):
+        return [self.y]
+
+    def _ws(self, plan):
+        nbytes = int(L.load().mml_bn_workspace_bytes(plan.B, self.z.n))
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=plan.device)
+        plan.keep.append(ws)
+        return ws
+
+    def fwd_calls(self, plan):
+        n = self.z.n
+        self.mean, self.rstd = plan.empty(n), plan.empty(n)
+        ws = self._ws(plan)
+        m = self.m
+        return [(L.load().mml_bn_fwd,
+                 (self.z.buf.data_ptr(), ops._ld(self.z.buf), self.gamma.data.data_ptr(), self.beta.data.data_ptr(),
+                  m.running_mean.data_ptr(), m.running_var.data_ptr(), m.num_batches_tracked.data_ptr(),
+                  self.mean.data_ptr(), self.rstd.data_ptr(), self.y.buf.data_ptr(), ops._ld(self.y.buf), plan.B, n,
+                  self.y.act, int(getattr(plan, "bn_training", plan.training)), self.EPS, self.MOMENTUM, ws.data_ptr(),
+                  ws.numel()),
+                 dict(kernel="bn_fwd", bytes=4.0 * plan.B * n * 3))]
+
+    def bwd_calls(self, plan):
+        if self.y.grad is None:
+            return []
+        if not getattr(plan, "bn_training", plan.training):
+            raise L.MMLError("backward through BatchNorm in eval mode is not supported")
+        plan.grad_of(self.z)
+        _claim(self.z)
+        acc = _claim(self.gamma)
+        if _claim(self.beta) != acc:
+            raise L.MMLError("BatchNorm weight and bias must be written in the same order")
+        ws = self._ws(plan)
+        n = self.z.n
+        return [(L.load().mml_bn_bwd,
+                 (self.y.grad.data_ptr(), ops._ld(self.y.grad), self.z.buf.data_ptr(), ops._ld(self.z.buf),
+                  self.gamma.data.data_ptr(), self.mean.data_ptr(), self.rstd.data_ptr(), self.z.grad.data_ptr(),
+                  ops._ld(self.z.grad), self.gamma.grad.data_ptr(), self.beta.grad.data_ptr(), acc, plan.B, n,
+                  ws.data_ptr(), ws.numel()),
+                 dict(kernel="bn_bwd", bytes=4.0 * plan.B * n * 5))]
+
+
 class Attn2Op(Op):
     """Two-token attention of AITM (model/aitm.py:84-93): tokens = [(V0, K0, Q0), (V1, K1, Q1)] of [B, H] values -> out."""
 

@@ -216,7 +216,8 @@ class BaseModel(nn.Module):
 
     def _get_plan(self, B, training, masked):
         store = self._store()
-        key = (int(B), bool(training), bool(masked))
+        # (BatchNorm follows the MODULE's mode, whether or not gradients are recorded: it is part of the key)
+        key = (int(B), bool(training), bool(masked), bool(self.training))
         plan = self._caches["plans"].get(key)
         if plan is None:
             plan = self._record(B, training, masked, store)
@@ -225,6 +226,7 @@ class BaseModel(nn.Module):
 
     def _record(self, B, training, masked, store, sparse_rows=None):
         plan = E.Plan(store.device, B, training)
+        plan.bn_training = bool(self.training)
         plan.generation = 0
         sp, de = self._sparse_cols(), self._dense_cols()
         ftot = max(e for _, e in self.feature_index.values())

@@ -31,6 +31,8 @@ class CrossStitch(BaseModel):
         self.tower_dnn_hidden_units = mc.get("tower_dnn_hidden_units", [64])
         l2 = mc.get("l2_reg_dnn", 0)
         drop, act, bn = mc.get("dnn_dropout", 0), mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
+        if mc.get("dnn_use_bn", False):
+            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         self.input_dim = self.compute_input_dim(dnn_feature_columns)
         T = self.num_tasks
 

@@ -48,6 +48,8 @@ class MSSM(SNR_trans):
             raise ValueError("num_tasks must be greater than 1")
         if self.num_experts <= 1:
             raise ValueError("num_experts must be greater than 1")
+        if mc.get("dnn_use_bn", False):
+            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         act, bn = mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
         units, Ne, T = self.expert_dnn_hidden_units, self.num_experts, self.num_tasks
         self.mssm = nn.ModuleDict()

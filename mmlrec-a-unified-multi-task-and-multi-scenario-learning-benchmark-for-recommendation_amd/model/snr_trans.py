@@ -47,6 +47,8 @@ class SNR_trans(BaseModel):
             raise ValueError("num_tasks must be greater than 1")
         if self.num_experts <= 1:
             raise ValueError("num_experts must be greater than 1")
+        if mc.get("dnn_use_bn", False):
+            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         l2 = mc.get("l2_reg_dnn", 0)
         opts = dnn_options(mc, init_std, device)
         units, Ne, T = self.expert_dnn_hidden_units, self.num_experts, self.num_tasks

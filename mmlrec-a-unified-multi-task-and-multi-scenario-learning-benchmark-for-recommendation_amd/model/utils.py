@@ -135,12 +135,14 @@ class DNN(nn.Module):
         super().__init__()
         if len(hidden_units) == 0:
             raise ValueError("hidden_units is empty!!")
-        if use_bn or dropout_rate:
-            raise NotImplementedError("BatchNorm / dropout inside DNN are not on the MI355X hot path yet")
+        if dropout_rate:
+            raise NotImplementedError("dropout inside DNN is not on the MI355X hot path (every shipped config uses 0)")
         self.l2_reg, self.use_bn, self.dropout_rate, self.activation = l2_reg, use_bn, dropout_rate, activation
         self.act_code = activation_code(activation)
         dims = [inputs_dim] + list(hidden_units)
         self.linears = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        if use_bn:  # fc -> bn -> activation (reference :132-134, :153-157); registered right after the linears
+            self.bn = nn.ModuleList([nn.BatchNorm1d(dims[i + 1]) for i in range(len(dims) - 1)])
         for name, p in self.linears.named_parameters():
             if "weight" in name:
                 nn.init.normal_(p, mean=0, std=init_std)
@@ -156,14 +158,22 @@ class DNN(nn.Module):
         h = x
         out = []
         for l, lin in enumerate(self.linears):
-            o = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}")
-            out.append(dict(x=h, W=store.pvals[f"{prefix}.linears.{l}.weight"],
-                            b=store.pvals[f"{prefix}.linears.{l}.bias"], out=o))
-            h = o
+            q = dict(x=h, W=store.pvals[f"{prefix}.linears.{l}.weight"], b=store.pvals[f"{prefix}.linears.{l}.bias"])
+            if self.use_bn:  # the GEMM writes the pre-normalisation value; emit_dnn_stacks adds the BatchNorm op
+                q["out"] = plan.val(lin.out_features, name=f"{prefix}.{l}.z")
+                q["bn"] = dict(y=plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}"),
+                               gamma=store.pvals[f"{prefix}.bn.{l}.weight"], beta=store.pvals[f"{prefix}.bn.{l}.bias"],
+                               module=self.bn[l])
+                h = q["bn"]["y"]
+            else:
+                q["out"] = h = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}")
+            out.append(q)
         return out
 
     def forward(self, inputs):
         from ..functional import linear_act
+        if self.use_bn:
+            raise NotImplementedError("stand-alone DNN.forward with BatchNorm: use the model's forward")
         h = inputs
         for lin in self.linears:
             h = linear_act(h, lin.weight, lin.bias, self.act_code)
@@ -177,7 +187,11 @@ def emit_dnn_stacks(plan, stacks):
     for l in range(depth):
         probs = [s[l] for s in stacks if len(s) > l]
         plan.add(E.LinearGroupOp(probs))
-    return [s[-1]["out"] for s in stacks]
+        for q in probs:
+            if "bn" in q:
+                b = q["bn"]
+                plan.add(E.BNOp(q["out"], b["y"], b["gamma"], b["beta"], b["module"]))
+    return [s[-1]["bn"]["y"] if "bn" in s[-1] else s[-1]["out"] for s in stacks]
 
 
 class PredictionLayer(nn.Module):

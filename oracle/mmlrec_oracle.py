@@ -81,8 +81,8 @@ class Spec:
             self.T = len(self.dc["label_columns"])
         else:
             self.T = len(self.mc.get("task_names", ["ctr", "ctcvr"]))
-        if self.mc.get("dnn_use_bn", False) or self.mc.get("dnn_dropout", 0) != 0:
-            raise NotImplementedError("oracle covers the hot-path configs only (no BN / dropout)")
+        if self.mc.get("dnn_dropout", 0) != 0:
+            raise NotImplementedError("oracle covers dropout 0 only (every shipped config)")
         if self.mc.get("dnn_activation", "relu") != "relu":
             raise NotImplementedError("oracle covers relu towers only")
 
@@ -175,17 +175,49 @@ def softmax_rows(z):
     return (e / e.sum(1, keepdims=True)).astype(F32)
 
 
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+_MODE = {"training": False}  # module mode of the restated model: BatchNorm uses batch statistics when True
+
+
+def set_training(flag):
+    """model.train() / model.eval() of the restatement (only BatchNorm layers care, model/utils.py:153-154)."""
+    _MODE["training"] = bool(flag)
+
+
 def dnn_fwd(params, prefix, x):
-    """DNN.forward (model/utils.py:146-161): [Linear -> ReLU]* (BN off, dropout 0 in the hot-path configs).
-    Returns output and the list of per-layer (input, output) for backward."""
+    """DNN.forward (model/utils.py:146-161): [Linear -> (BatchNorm1d) -> ReLU]* (dropout 0 in the shipped configs).
+    BatchNorm1d as torch does it: batch mean / biased variance in training mode, with the running statistics moved by
+    momentum 0.1 (unbiased variance) and num_batches_tracked incremented IN `params`; running statistics in eval mode.
+    Returns output and the per-layer records for backward."""
     acts = []
     l = 0
     h = x
     while f"{prefix}.linears.{l}.weight" in params:
         W = params[f"{prefix}.linears.{l}.weight"]
         b = params[f"{prefix}.linears.{l}.bias"]
-        y = relu(linear_fwd(h, W, b))
-        acts.append((h, y))
+        z = linear_fwd(h, W, b)
+        bn = None
+        gk = f"{prefix}.bn.{l}.weight"
+        if gk in params:
+            g, be = params[gk], params[f"{prefix}.bn.{l}.bias"]
+            if _MODE["training"]:
+                z64 = z.astype(np.float64)
+                mu, var = z64.mean(0), z64.var(0)
+                B = z.shape[0]
+                rm, rv = f"{prefix}.bn.{l}.running_mean", f"{prefix}.bn.{l}.running_var"
+                params[rm] = ((1 - BN_MOMENTUM) * params[rm] + BN_MOMENTUM * mu).astype(F32)
+                params[rv] = ((1 - BN_MOMENTUM) * params[rv] + BN_MOMENTUM * var * B / max(B - 1, 1)).astype(F32)
+                nb = f"{prefix}.bn.{l}.num_batches_tracked"
+                params[nb] = np.asarray(params[nb]) + 1
+            else:
+                mu = params[f"{prefix}.bn.{l}.running_mean"].astype(np.float64)
+                var = params[f"{prefix}.bn.{l}.running_var"].astype(np.float64)
+            rstd = 1.0 / np.sqrt(var + BN_EPS)
+            xhat = ((z - mu) * rstd).astype(F32)
+            bn = (xhat, rstd.astype(F32))
+            z = (xhat * g + be).astype(F32)
+        y = relu(z)
+        acts.append((h, y, bn))
         h = y
         l += 1
     if l == 0:
@@ -196,8 +228,15 @@ def dnn_fwd(params, prefix, x):
 def dnn_bwd(params, prefix, acts, dy, grads):
     """Backward of dnn_fwd; accumulates into grads[key]; returns d(input)."""
     for l in range(len(acts) - 1, -1, -1):
-        x, y = acts[l]
-        dz = dy * (y > 0)
+        x, y, bn = acts[l] if len(acts[l]) == 3 else (*acts[l], None)
+        dz = (dy * (y > 0)).astype(F32)
+        if bn is not None:  # BatchNorm backward with batch statistics
+            xhat, rstd = bn
+            g = params[f"{prefix}.bn.{l}.weight"]
+            dbeta, dgamma = dz.sum(0), (dz * xhat).sum(0)
+            _acc(grads, f"{prefix}.bn.{l}.weight", dgamma.astype(F32))
+            _acc(grads, f"{prefix}.bn.{l}.bias", dbeta.astype(F32))
+            dz = (g * rstd * (dz - (dbeta + xhat * dgamma) / dz.shape[0])).astype(F32)
         W = params[f"{prefix}.linears.{l}.weight"]
         dx, dW, db = linear_bwd(x, W, dz)
         _acc(grads, f"{prefix}.linears.{l}.weight", dW)
@@ -946,7 +985,12 @@ def loss_and_grads(spec, params, X, y, frozen=None):
     """One pure reference step without the optimizer (model/basemodel.py:268-312, mask=None per SURVEY D3):
     returns (sum-BCE loss, {state_dict key: gradient})."""
     y = np.asarray(y, dtype=F32)
-    p, cache = forward(spec, params, X, None, frozen)
+    was = _MODE["training"]
+    set_training(True)  # basemodel.py:261 model.train()
+    try:
+        p, cache = forward(spec, params, X, None, frozen)
+    finally:
+        set_training(was)
     loss = sum(bce_sum(p[:, t], y[:, t]) for t in range(spec.T))
     dlogit = bce_sigmoid_bwd(p, y)
     if spec.model_name == "star":

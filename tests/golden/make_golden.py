@@ -153,6 +153,14 @@ def make_cases():
     c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
                              "scene_feature": "scene"})
     cases.append(dict(name="mssm_ml", cls=MSSM, cfg=c, vocab=[2, 12, 23, 96, 64, 64, 48, 2], nd=0, scene_last=True))
+    # BatchNorm inside DNN (model/utils.py:132-134; the shipped config_census / msl config_amazon set dnn_use_bn)
+    c = base_config("mtl", "sharedbottom", ["label2", "label3"], 8, "adam", 0.01,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"], dnn_use_bn=True)
+    cases.append(dict(name="sharedbottom_bn", cls=SharedBottom, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=2))
+    c = base_config("mtl", "mmoe", ["l1", "l2"], 8, "adagrad", 0.01, task_names=["ctr", "ctcvr"],
+                    task_types=["binary", "binary"], dnn_use_bn=True, expert_dnn_hidden_units=[32, 16],
+                    gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16])
+    cases.append(dict(name="mmoe_bn", cls=MMOE, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
     return cases
 
 
@@ -249,7 +257,9 @@ def run_case(case):
     g2 = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for k, p in model.named_parameters():
-            if k.endswith(".u") and cls is SNR_trans:     # routing parameters must stay inside (0, 1)
+            if ".bn." in k:                                # BatchNorm affine parameters: away from (1, 0)
+                p.copy_((1.0 if k.endswith("weight") else 0.0) + torch.randn(p.shape, generator=g2) * 0.2)
+            elif k.endswith(".u") and cls is SNR_trans:     # routing parameters must stay inside (0, 1)
                 p.copy_(torch.rand(p.shape, generator=g2) * 0.9 + 0.05)
             elif k.endswith(".alpha") and cls in (SNR_trans, MSSM):
                 p.copy_(torch.rand(p.shape, generator=g2) + 0.5)

@@ -603,3 +603,61 @@ def test_attn2_fwd_bwd(ops, B, H):
         assert rel(g[0][t].cpu().numpy(), a[t][:, None] * do64) < 1e-5
         assert rel(g[1][t].cpu().numpy(), ds[t][:, None] * Q64[t]) < 2e-5
         assert rel(g[2][t].cpu().numpy(), ds[t][:, None] * K64[t]) < 2e-5
+
+
+@pytest.mark.parametrize("B,n,act", [(1000, 48, "relu"), (4099, 130, "none"), (300, 7, "relu")])
+def test_batchnorm_fwd_bwd(ops, B, n, act):
+    """mml_bn_fwd / mml_bn_bwd == torch.nn.BatchNorm1d semantics (reference model/utils.py:132-134, :153-157) in float64:
+    several row chunks, odd widths, strided rows, running statistics and the batch counter, eval mode."""
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(B + n)
+    z = (rng.standard_normal((B, n)) * 2 + 0.5).astype(np.float32)
+    gamma, beta = (1 + 0.2 * rng.standard_normal(n)).astype(np.float32), (0.1 * rng.standard_normal(n)).astype(np.float32)
+    rm0, rv0 = rng.standard_normal(n).astype(np.float32), (1 + rng.random(n)).astype(np.float32)
+    dy = rng.standard_normal((B, n)).astype(np.float32)
+    acode = L.ACT_RELU if act == "relu" else L.ACT_NONE
+    zb = torch.zeros(B, n + 5, device=dev())
+    zb[:, :n] = T(z)
+    tz = zb[:, :n]
+    tg, tb, rm, rv = T(gamma), T(beta), T(rm0.copy()), T(rv0.copy())
+    nbt = torch.tensor([3], dtype=torch.int64, device=dev())
+    mean, rstd = torch.empty(n, device=dev()), torch.empty(n, device=dev())
+    y = torch.empty(B, n, device=dev())
+    nbytes = int(lib.mml_bn_workspace_bytes(B, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.mml_bn_fwd(tz.data_ptr(), tz.stride(0), tg.data_ptr(), tb.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                        nbt.data_ptr(), mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), n, B, n, acode, 1, 1e-5, 0.1,
+                        ws.data_ptr(), nbytes, st)
+    assert rc == 0
+    z64 = z.astype(np.float64)
+    mu, var = z64.mean(0), z64.var(0)
+    xhat = (z64 - mu) / np.sqrt(var + 1e-5)
+    pre = xhat * gamma + beta
+    ref = np.maximum(pre, 0) if act == "relu" else pre
+    assert rel(y.cpu().numpy(), ref) < 1e-5
+    assert rel(rm.cpu().numpy(), 0.9 * rm0 + 0.1 * mu) < 1e-5
+    assert rel(rv.cpu().numpy(), 0.9 * rv0 + 0.1 * var * B / (B - 1)) < 1e-5
+    assert int(nbt.item()) == 4
+    # backward (dy = gradient w.r.t. the BatchNorm output, activation derivative already applied)
+    dyr = dy * (pre > 0) if act == "relu" else dy
+    tdy = T(dyr.astype(np.float32))
+    dz, dg, db = torch.empty(B, n, device=dev()), torch.empty(n, device=dev()), torch.empty(n, device=dev())
+    rc = lib.mml_bn_bwd(tdy.data_ptr(), n, tz.data_ptr(), tz.stride(0), tg.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                        dz.data_ptr(), n, dg.data_ptr(), db.data_ptr(), 0, B, n, ws.data_ptr(), nbytes, st)
+    assert rc == 0
+    d64 = dyr.astype(np.float64)
+    dbeta, dgamma = d64.sum(0), (d64 * xhat).sum(0)
+    dz_ref = gamma / np.sqrt(var + 1e-5) * (d64 - (dbeta + xhat * dgamma) / B)
+    assert rel(db.cpu().numpy(), dbeta) < 1e-5 and rel(dg.cpu().numpy(), dgamma) < 1e-5
+    assert rel(dz.cpu().numpy(), dz_ref) < 2e-5
+    # eval mode: running statistics, nothing is updated
+    rm1, rv1 = rm.clone(), rv.clone()
+    rc = lib.mml_bn_fwd(tz.data_ptr(), tz.stride(0), tg.data_ptr(), tb.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                        nbt.data_ptr(), mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), n, B, n, acode, 0, 1e-5, 0.1,
+                        ws.data_ptr(), nbytes, st)
+    assert rc == 0
+    pre = (z64 - rm1.cpu().numpy()) / np.sqrt(rv1.cpu().numpy().astype(np.float64) + 1e-5) * gamma + beta
+    assert rel(y.cpu().numpy(), np.maximum(pre, 0) if act == "relu" else pre) < 1e-5
+    assert torch.equal(rm, rm1) and torch.equal(rv, rv1) and int(nbt.item()) == 4

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, bn_noise_keys, load_golden
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # north_star tolerance: forward logits and embedding gradients within 1e-4 rel fp32
@@ -113,9 +113,14 @@ def test_autograd_gradients(case):
                for i in range(yp.shape[1]))
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < RTOL
+    noise_bias, _ = bn_noise_keys(model.state_dict().keys())
+    gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad/"))
     for n, p in model.named_parameters():
         if "grad/" + n in g.files:
             assert p.grad is not None, n
+            if n in noise_bias:  # structurally zero gradient (bias in front of a BatchNorm): rounding noise on both sides
+                assert float(p.grad.abs().max()) < 1e-5 * gscale, n
+                continue
             assert rel(p.grad.cpu().numpy(), g["grad/" + n]) < RTOL, n
         else:
             assert "nograd/" + n in g.files
@@ -145,10 +150,14 @@ def test_fused_train_steps(case, graph):
             losses.append(float(step.plan.loss.item()))
             if (i + 1) in checkpoints:
                 sd = model.state_dict()
+                noise_bias, noise_rm = bn_noise_keys(sd.keys())
                 for k in sd:
                     ref = g[f"{kind}{i + 1}/{k}"].astype(np.float64)
                     got = sd[k].cpu().numpy().astype(np.float64)
                     dv = np.abs(got - ref)
+                    if k in noise_bias or (k in noise_rm and i > 0):  # see conftest.bn_noise_keys
+                        assert dv.max() <= 2.5 * lr * (i + 1), (kind, i + 1, k)
+                        continue
                     # Adam/Adagrad divide by sqrt(sum g^2): gradients at fp32-noise level may flip a whole lr-sized
                     # update, hence outlier share + absolute bound instead of a pure max-relative test
                     assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, (kind, i + 1, k)
