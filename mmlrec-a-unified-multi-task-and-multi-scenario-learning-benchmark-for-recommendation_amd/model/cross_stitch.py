@@ -10,7 +10,7 @@ from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import build_tower_modules, emit_towers
-from .utils import DNN, emit_dnn_stacks
+from .utils import DNN, emit_blocks_into, emit_dnn_stacks
 
 
 class CrossStitchLayer(nn.Module):
@@ -31,8 +31,6 @@ class CrossStitch(BaseModel):
         self.tower_dnn_hidden_units = mc.get("tower_dnn_hidden_units", [64])
         l2 = mc.get("l2_reg_dnn", 0)
         drop, act, bn = mc.get("dnn_dropout", 0), mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
-        if mc.get("dnn_use_bn", False):
-            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         self.input_dim = self.compute_input_dim(dnn_feature_columns)
         T = self.num_tasks
 
@@ -61,9 +59,8 @@ class CrossStitch(BaseModel):
             parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], L.ACT_RELU, name=f"cross_stitch.{i}.task.{j}")
                      for j in range(T)]
             pfx = f"cross_stitch.task_layer_{i}"
-            plan.add(E.LinearGroupOp([dict(x=ins[j], W=store.pvals[f"{pfx}.{j}.linears.0.weight"],
-                                           b=store.pvals[f"{pfx}.{j}.linears.0.bias"], out=parts[j])
-                                      for j in range(T)]))
+            emit_blocks_into(plan, store, self.cross_stitch[f"task_layer_{i}"], [f"{pfx}.{j}" for j in range(T)], ins,
+                             parts)
             plan.add(E.JoinOp(parts, cat))
             mix = plan.val(T * d, name=f"cross_stitch.{i}.mix")
             plan.add(E.LinearGroupOp([dict(x=cat, W=store.pvals[f"cross_stitch.gate_{i}.cross_stitch_weight"], b=None,

@@ -5,7 +5,7 @@ with a coefficient PER OUTPUT COLUMN of every (output, input) transformation: ou
 Reference behaviour kept: both the coefficient seeds `u` (one [units] vector per pair) and the transformations live in
 plain Python lists (model/mssm.py:26-36), so neither is in state_dict nor optimised; a gate learns its scalar `alpha`
 only.  Same lowering as SNR-trans (one [K,N] GEMM per output on column-scaled frozen blocks).
-BatchNorm inside the deeper expert levels (`dnn_use_bn`, config_census) is not on the MI355X path yet."""
+BatchNorm inside the expert blocks and towers (`dnn_use_bn`, config_census) runs through BNOp."""
 import torch
 import torch.nn as nn
 
@@ -48,18 +48,14 @@ class MSSM(SNR_trans):
             raise ValueError("num_tasks must be greater than 1")
         if self.num_experts <= 1:
             raise ValueError("num_experts must be greater than 1")
-        if mc.get("dnn_use_bn", False):
-            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         act, bn = mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
         units, Ne, T = self.expert_dnn_hidden_units, self.num_experts, self.num_tasks
         self.mssm = nn.ModuleDict()
         for i, d in enumerate(units):
             k = self.input_dim if i == 0 else units[i - 1]
-            # (only the deeper levels receive dnn_use_bn in the reference, model/mssm.py:82-101)
             self.mssm[f"expert{i + 1}"] = nn.ModuleList(
-                DNN(k, [d], activation=act, use_bn=bn if i > 0 else False, init_std=init_std, device=device)
-                for _ in range(Ne))
+                DNN(k, [d], activation=act, use_bn=bn, init_std=init_std, device=device) for _ in range(Ne))
             self.mssm[f"gate{i + 1}"] = gate(Ne, T if i == len(units) - 1 else Ne, d, device=device)
-        build_tower_modules(self, units[-1], self.tower_dnn_hidden_units, act, mc.get("l2_reg_dnn", 0), 0, False,
+        build_tower_modules(self, units[-1], self.tower_dnn_hidden_units, act, mc.get("l2_reg_dnn", 0), 0, bn,
                             init_std, device)
         self.to(device)

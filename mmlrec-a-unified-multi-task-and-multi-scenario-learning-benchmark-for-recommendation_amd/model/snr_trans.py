@@ -13,7 +13,7 @@ from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import build_tower_modules, emit_towers
-from .utils import DNN, dnn_options
+from .utils import DNN, dnn_options, emit_blocks_into
 
 
 class gate(nn.Module):  # (lower-case class name of the reference: it shows in nothing but repr)
@@ -47,8 +47,6 @@ class SNR_trans(BaseModel):
             raise ValueError("num_tasks must be greater than 1")
         if self.num_experts <= 1:
             raise ValueError("num_experts must be greater than 1")
-        if mc.get("dnn_use_bn", False):
-            raise NotImplementedError("BatchNorm inside this model's expert / task blocks is not on the MI355X path yet")
         l2 = mc.get("l2_reg_dnn", 0)
         opts = dnn_options(mc, init_std, device)
         units, Ne, T = self.expert_dnn_hidden_units, self.num_experts, self.num_tasks
@@ -75,9 +73,7 @@ class SNR_trans(BaseModel):
             cat = plan.val(Ne * d, act=L.ACT_RELU, name=f"snr.{i}.cat")
             parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], L.ACT_RELU, name=f"snr.{i}.expert.{j}") for j in range(Ne)]
             pfx = f"{stem}{i + 1}"
-            plan.add(E.LinearGroupOp([dict(x=ins[j], W=store.pvals[f"{pfx}.{j}.linears.0.weight"],
-                                           b=store.pvals[f"{pfx}.{j}.linears.0.bias"], out=parts[j])
-                                      for j in range(Ne)]))
+            emit_blocks_into(plan, store, mods[f"{self._EXPERT}{i + 1}"], [f"{pfx}.{j}" for j in range(Ne)], ins, parts)
             plan.add(E.JoinOp(parts, cat))
             W = plan.empty(No, Ne * d, d)
             dW = plan.zeros(No, Ne * d, d) if plan.training else None

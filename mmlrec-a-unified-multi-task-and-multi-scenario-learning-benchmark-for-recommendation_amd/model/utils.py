@@ -194,6 +194,27 @@ def emit_dnn_stacks(plan, stacks):
     return [s[-1]["bn"]["y"] if "bn" in s[-1] else s[-1]["out"] for s in stacks]
 
 
+def emit_blocks_into(plan, store, blocks, prefixes, ins, outs):
+    """One grouped launch for single-layer DNN blocks whose outputs are GIVEN values (column slices of a concatenation
+    buffer: cross-stitch / SNR-trans / MSSM levels).  A block with BatchNorm writes its Linear output to a scratch value
+    and the BatchNorm op produces the given one."""
+    probs = []
+    for blk, pfx, x, o in zip(blocks, prefixes, ins, outs):
+        q = dict(x=x, W=store.pvals[f"{pfx}.linears.0.weight"], b=store.pvals[f"{pfx}.linears.0.bias"])
+        if blk.use_bn:
+            q["out"] = plan.val(o.n, name=o.name + ".z")
+            q["bn"] = dict(y=o, gamma=store.pvals[f"{pfx}.bn.0.weight"], beta=store.pvals[f"{pfx}.bn.0.bias"],
+                           module=blk.bn[0])
+        else:
+            q["out"] = o
+        probs.append(q)
+    plan.add(E.LinearGroupOp(probs))
+    for q in probs:
+        if "bn" in q:
+            b = q["bn"]
+            plan.add(E.BNOp(q["out"], b["y"], b["gamma"], b["beta"], b["module"]))
+
+
 class PredictionLayer(nn.Module):
     """bias [1] + sigmoid for task == 'binary' (reference model/utils.py:225-248); fused into the head kernel."""
 

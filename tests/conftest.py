@@ -12,7 +12,8 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "star_amazon",
                 "pepnet_amazon", "mlp_ml", "mlp_ae", "esmm_ml",
                 "cross_stitch_ae", "hmoe_ml", "aitm_ml", "snr_trans_ae",
-                "mssm_ml", "sharedbottom_bn", "mmoe_bn"]
+                "mssm_ml", "sharedbottom_bn", "mmoe_bn",
+                "mssm_bn", "cross_stitch_bn"]
 
 
 def pytest_configure(config):

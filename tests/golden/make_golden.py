@@ -161,6 +161,16 @@ def make_cases():
                     task_types=["binary", "binary"], dnn_use_bn=True, expert_dnn_hidden_units=[32, 16],
                     gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16])
     cases.append(dict(name="mmoe_bn", cls=MMOE, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # MSSM with BatchNorm in the deeper expert level (the shipped configs_mtl/config_census.json turns dnn_use_bn on)
+    c = base_config("mtl", "mssm", ["l1", "l2"], 8, "adam", 0.005, task_names=["ctr", "ctcvr"],
+                    task_types=["binary", "binary"], num_experts=3, expert_dnn_hidden_units=[32, 16],
+                    tower_dnn_hidden_units=[16], dnn_use_bn=True)
+    cases.append(dict(name="mssm_bn", cls=MSSM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # Cross-Stitch with BatchNorm in every block
+    c = base_config("mtl", "cross_stitch", ["l1", "l2"], 8, "adagrad", 0.01, task_names=["ctr", "ctcvr"],
+                    task_types=["binary", "binary"], shared_hidden_unit=32, dnn_hidden_units=[32, 16],
+                    tower_dnn_hidden_units=[16], dnn_use_bn=True)
+    cases.append(dict(name="cross_stitch_bn", cls=CrossStitch, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
     return cases
 
 
