@@ -17,8 +17,10 @@ class STAR(BaseModel):
                          device=device, gpus=gpus, config=config)
         mc = self.model_config
         self.dnn_use_bn = mc.get("dnn_use_bn", False)
-        if self.dnn_use_bn:
-            raise NotImplementedError("STAR's DomainBatchNorm is outside the hot path (dead inside fit, SURVEY D3)")
+        # dnn_use_bn (the shipped configs_msl/config_amazon.json): the reference builds a DomainBatchNorm whose tensors
+        # are unregistered lists (no state_dict keys, ones / zeros: no random draws) and applies it only when forward()
+        # is given a domain mask (model/star.py:50-51) -- which fit() and predict() never do.  The model
+        # therefore trains and predicts exactly like the one without the flag; the masked forward is rejected below.
         self.dnn_hidden_units = mc.get("dnn_hidden_units", [256, 128])
         self.act_code = activation_code(mc.get("dnn_activation", "relu"))
         use_shared = mc.get("use_shared", True)
@@ -51,6 +53,9 @@ class STAR(BaseModel):
         return weff, beff
 
     def _build_graph(self, plan, store, x0):
+        if self.dnn_use_bn and plan.mask is not None:
+            raise NotImplementedError("STAR's DomainBatchNorm (forward with a domain mask and dnn_use_bn) is not on the "
+                                      "MI355X path; fit() / predict() never take it (SURVEY D3)")
         T, nl = self.num_tasks, len(self.dnn_hidden_units)
         hs = [x0] * T
         per_layer = []

@@ -230,3 +230,30 @@ def test_bf16_operand_mode_kuairec():
         assert rms > 1e-6  # (the mode really is in effect)
     finally:
         lib.mml_gemm_set_mode(mode0)
+
+
+def test_star_with_dnn_use_bn_trains_like_without():
+    """The shipped configs_msl/config_amazon.json sets dnn_use_bn for STAR: the reference's DomainBatchNorm is only applied
+    when forward() receives a domain mask (model/star.py:50-51), which fit() / predict() never pass -- so
+    the flag must not change construction, state_dict, the unmasked forward or a training step; the masked forward is
+    rejected loudly."""
+    g = load_golden("star_amazon")
+    outs, sds = [], []
+    for flag in (False, True):
+        model, cfg = build(g, dnn_use_bn=flag)
+        load_state(model, g)
+        model.compile("adagrad", cfg["optim_config"]["loss"], ["auc"])
+        model.train()
+        step = model.train_step_runner(64)
+        step.plan.X.copy_(torch.from_numpy(g["X0"]).cuda())
+        step.plan.y.copy_(torch.from_numpy(g["y0"]).cuda())
+        step.run()
+        model.eval()
+        with torch.no_grad():
+            outs.append(model(torch.from_numpy(g["X1"]).cuda()).cpu())
+        sds.append({k: v.cpu() for k, v in model.state_dict().items()})
+        if flag:
+            with pytest.raises(NotImplementedError):
+                model(torch.from_numpy(g["X0"]).cuda(), torch.from_numpy(g["mask0"]).cuda())
+    assert torch.equal(outs[0], outs[1])
+    assert sds[0].keys() == sds[1].keys() and all(torch.equal(sds[0][k], sds[1][k]) for k in sds[0])
