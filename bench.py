@@ -259,16 +259,20 @@ def main():
         B = args.batch
         batches = make_batches(B)
         model.eval()
+        import gc
         with torch.no_grad():
             for i in range(3):
                 model(batches[i % 4][0])
             torch.cuda.synchronize()
+            gc.collect()   # (as in timed_steps: a cyclic-GC pass that destroys the HIP graphs / events of the earlier
+            gc.disable()   # phases inside the timed loop costs tens of ms once)
             n_inf = max(args.steps, 20)
             t0 = time.perf_counter()
             for i in range(n_inf):
                 model(batches[i % 4][0])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            gc.enable()
         model.train()
         infer = {"value": round(B * n_inf / dt, 1), "unit": "samples/s", "batch": B, "ms_per_batch": round(dt / n_inf * 1e3, 4),
                  "path": "model.forward(X) in eval mode under no_grad (what predict() runs per batch)"}
