@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--table-update", default="dense_exact", choices=["dense_exact", "sparse_rows", "lazy_exact", "auto"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--parallel-mode", default="row_sharded", choices=["row_sharded", "replicated", "table_wise"],
+                    help="how the tables are spread over the ranks when --gpus > 1 (mmlrec_amd/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
@@ -120,7 +122,7 @@ def roofline_of(acc):
     """Dominant kernel by total time; compute-bound GEMMs are priced against the fp32 MFMA peak
     (157.3 TFLOP/s, MI355X_MICROARCH.md), streaming kernels against the 8 TB/s HBM3E spec."""
     # (collectives of the table-sharded path are timed in `acc` too; the roofline is a statement about a HIP kernel)
-    name = max((k for k in acc if not k.startswith("all_to_all") and not k.startswith("all_reduce")),
+    name = max((k for k in acc if not k.startswith(("all_to_all", "all_reduce", "all_gather", "row_sharded_"))),
                key=lambda k: acc[k]["ms"])
     e = acc[name]
     avg_ms = e["ms"] / e["launches"]
@@ -229,7 +231,7 @@ def main():
     # graph, per-call timing of the collectives) on a single GPU: a smoke test of the N > 1 bench, not a measurement
     if world > 1 or (dist is not None and os.environ.get("MMLREC_BENCH_FORCE_SHARD") == "1"):
         from mmlrec_amd import parallel
-        parallel.shard_model(model, dist, args.batch)
+        parallel.shard_model(model, dist, args.batch, mode=args.parallel_mode)
 
     def make_batches(B):
         out = []
@@ -321,14 +323,20 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
                    "table_update": model.optimizer().table_update, "hip_graph": not args.no_graph,
                    "streams": 1 if args.serial else 2,
-                   "tables": "single GPU" if world == 1 else "table-wise sharded over ranks, all-to-all index/row/grad exchange",
+                   "tables": "single GPU" if getattr(model, "_parallel", None) is None else
+                             {"row_sharded": "row-wise sharded over ranks (owner = (row + field) mod N), one all-to-all "
+                                             "per direction: keys / rows / row gradients",
+                              "replicated": "replicated, all-gather of (index, row-gradient) pairs",
+                              "table_wise": "table-wise sharded over ranks, all-to-all index/row/grad exchange"}[
+                                 args.parallel_mode],
                    "algorithmic_per_sample": per},
         "roofline": roof,
         "kernels_ms_per_step": {k: round(v["ms"] / main_r["bsteps"], 4) for k, v in
                                 sorted(main_r["acc"].items(), key=lambda kv: -kv[1]["ms"])},
         "mean_loss_per_sample": round(main_r["loss"], 5),
     }
-    comm = {k: v for k, v in main_r["acc"].items() if k.startswith("all_to_all") or k.startswith("all_reduce")}
+    comm = {k: v for k, v in main_r["acc"].items()
+            if k.startswith(("all_to_all", "all_reduce", "all_gather", "row_sharded_"))}
     if comm:  # serial, event-bracketed time of the exchange steps of rank 0 (second, instrumented pass)
         line["collectives_ms_per_step"] = {k: round(v["ms"] / main_r["bsteps"], 4) for k, v in comm.items()}
     if args.alt_batch and args.alt_batch in results:

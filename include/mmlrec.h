@@ -104,6 +104,43 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
                      int64_t B, uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
                      int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream);
 
+/* Native-index variants (int32 idx[b*ldi + f], fields in array order): vocabularies >= 2^24 and the
+ * owner side of row-sharded tables, which sees lookups as keys into its flat row space (F = 1). */
+int mml_scatter_bwd_idx32(float* const* grad_tables, const int64_t* vocab, int32_t F, int32_t E, const int32_t* idx,
+                          int64_t ldi, int64_t B, const float* dOut, int64_t ldo, uint32_t* const* seen,
+                          const int64_t* rowbase, int32_t* touched, int32_t* touched_count, int32_t touched_cap,
+                          int32_t* status, mml_stream_t stream);
+int mml_index_unique_idx32(const int64_t* vocab, int32_t F, int32_t E, const int32_t* idx, int64_t ldi, int64_t B,
+                           uint32_t* const* seen, const int64_t* rowbase, int32_t* touched, int32_t* touched_count,
+                           int32_t touched_cap, int32_t* status, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise sharded tables (replaces the reference's dead --is_parallel stub, main.py:81-83,
+ * model/basemodel.py:235-238).  Row r of field f lives on rank (r + f) mod world at local row r / world; a rank keeps
+ * its F shards back to back in one flat [R, E] buffer and a lookup travels as the int32 key keybase[f] + r / world.
+ *   mml_route_count  counters[0..world) = lookups of the batch bound for each owner (counters[world..2*world) is
+ *                    cleared for mml_route_place); indices are validated / clamped like mml_gather_fwd (status bits).
+ *   mml_route_place  send_keys[B*F] = keys grouped by owner (owner segments in rank order: the send layout of ONE
+ *                    all-to-all over all fields), pos[b*F + f] = position of (b, f)'s key in send_keys.  Needs the
+ *                    counters of mml_route_count on the same batch.  Order inside an owner segment is unspecified.
+ *   mml_rows_permute dst[pos[b*F+f], :] = src[b, f*E:(f+1)*E]: packs d(dnn_input) into the send order of the gradient
+ *                    exchange (the inverse direction is mml_gather_fwd_idx32 on the received row block).
+ *   mml_shard_rows   shard[l, :] = table[l*world + first, :] (to_table = 0; rows past the table end are zero) or the
+ *                    inverse copy (to_table = 1); first = (rank - f) mod world.
+ * X / idx: exactly one is non-null (fp32-encoded indices with column map col[], or native int32 [B, ldi]).
+ * col, vocab, keybase are HOST arrays of F entries; counters, send_keys, pos, status are DEVICE buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int mml_route_count(const float* X, int64_t ldX, const int32_t* idx, int64_t ldi, const int32_t* col,
+                    const int64_t* vocab, int32_t F, int64_t B, int32_t world, int32_t* counters, int32_t* status,
+                    mml_stream_t stream);
+int mml_route_place(const float* X, int64_t ldX, const int32_t* idx, int64_t ldi, const int32_t* col,
+                    const int64_t* vocab, const int64_t* keybase, int32_t F, int64_t B, int32_t world,
+                    int32_t* counters, int32_t* send_keys, int32_t* pos, int32_t* status, mml_stream_t stream);
+int mml_rows_permute(const float* src, int64_t lds, const int32_t* pos, int32_t F, int32_t E, int64_t B, float* dst,
+                     mml_stream_t stream);
+int mml_shard_rows(float* table, int64_t V, float* shard, int64_t rows_local, int32_t E, int32_t world, int32_t first,
+                   int32_t to_table, mml_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  grouped GEMM family on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).
  * Replaces nn.Linear + activation inside DNN.forward (model/utils.py:146-161: addmm, relu_) and the

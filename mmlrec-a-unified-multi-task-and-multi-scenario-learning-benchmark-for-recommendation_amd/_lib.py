@@ -91,6 +91,13 @@ _SIGS = {
     "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
     "mml_scatter_bwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
                                   fp, fp, i32, fp, fp]),
+    "mml_scatter_bwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
+                                        fp, fp, i32, fp, fp]),
+    "mml_index_unique_idx32": (C.c_int, [_PP(i64), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp]),
+    "mml_route_count": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), i32, i64, i32, fp, fp, fp]),
+    "mml_route_place": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), _PP(i64), i32, i64, i32, fp, fp, fp, fp, fp]),
+    "mml_rows_permute": (C.c_int, [fp, i64, fp, i32, i32, i64, fp, fp]),
+    "mml_shard_rows": (C.c_int, [fp, i64, fp, i64, i32, i32, i32, i32, fp]),
     "mml_gemm_set_mode": (C.c_int, [i32]),
     "mml_gemm_get_mode": (C.c_int, []),
     "mml_gemm_last_kernel": (C.c_char_p, []),

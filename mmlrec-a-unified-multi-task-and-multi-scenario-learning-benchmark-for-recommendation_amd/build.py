@@ -33,17 +33,40 @@ def needs_build():
 
 
 def build_library(force=False, verbose=True, jobs=None):
-    """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns its path."""
+    """Compile the HIP sources for gfx950 (only those newer than their object) and link the C-ABI shared library.
+    Returns its path.  Concurrent callers (one process per GPU) are serialised by a file lock and the library is
+    replaced atomically, so no rank ever maps a half-written file."""
     if not force and not needs_build():
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while we waited
+                return LIBPATH
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    srcs = sources()
-    if not srcs:
+    all_srcs = sources()
+    if not all_srcs:
         raise RuntimeError("no HIP sources under " + CSRC)
-    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
-    procs, objs = [], []
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(os.path.dirname(HERE), "include", "mmlrec.h")]
+    hdr_time = _newest(hdrs)
+
+    def stale(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        return force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+
+    srcs = [s for s in all_srcs if stale(s)]
+    jobs = jobs or max(1, min(len(srcs), (os.cpu_count() or 2) - 1))
+    procs = []
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in all_srcs]
     pending = list(srcs)
     failed = []
 
@@ -61,7 +84,6 @@ def build_library(force=False, verbose=True, jobs=None):
         while pending and len(procs) < jobs:
             src = pending.pop(0)
             obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-            objs.append(obj)
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             stderr = None
             if os.path.basename(src) == "gemm.hip":
@@ -82,10 +104,12 @@ def build_library(force=False, verbose=True, jobs=None):
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     check_no_scratch(os.path.join(objdir, "gemm.o.log"))
     check_async_lds(objdir)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    tmp = LIBPATH + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print("[mmlrec build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIBPATH)
     return LIBPATH
 
 

@@ -156,6 +156,8 @@ struct ScatterArgs {
   int64_t rowbase[MML_MAX_FIELDS];
   const float* X;
   int64_t ldX;
+  const int32_t* idx;  // native indices idx[b * ldi + f] (used instead of X when non-null)
+  int64_t ldi;
   int64_t B;
   const float* dOut;
   int64_t ldo;
@@ -178,8 +180,7 @@ __global__ __launch_bounds__(256) void scatter_atomic_kernel(const FieldTable ft
     const int c = (int)(item - b * FE);
     const int f = c / a.E;
     const int e = c - f * a.E;
-    const float v = a.X[b * a.ldX + ft.col[f]];
-    int64_t row = (int64_t)v;
+    const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + ft.col[f]];
     const int64_t V = ft.vocab[f];
     if (row < 0) {
       bad |= 1;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
   for (int item = threadIdx.x; item < nb * E; item += 256) {
     const int s = item / E, e = item - s * E;
     const int64_t b = b0 + s;
-    const int64_t row = (int64_t)a.X[b * a.ldX + colf];
+    const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + colf];
     if (row < 0) { bad |= 1; continue; }
     if (row >= V) { bad |= 2; continue; }
     const float g = a.dOut ? a.dOut[b * a.ldo + f * E + e] : 0.f;
@@ -330,15 +331,16 @@ extern "C" int mml_gather_fwd_idx32(const float* const* tables, const int64_t* v
   return launch_gather(ft, a, to_stream(stream));
 }
 
-extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
-                               int32_t E, const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
-                               uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
-                               int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream) {
+static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                        int32_t E, const float* X, int64_t ldX, const int32_t* idx, int64_t ldi, int64_t B,
+                        const float* dOut, int64_t ldo, uint32_t* const* seen, const int64_t* rowbase,
+                        int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                        mml_stream_t stream) {
   FieldTable ft;
   int rc = fill_fields(ft, (const float* const*)grad_tables, vocab, col, F, "mml_scatter_bwd");
   if (rc) return rc;
   MML_REQUIRE(B >= 0 && E > 0, "mml_scatter_bwd: bad sizes");
-  MML_REQUIRE(B == 0 || (X && dOut), "mml_scatter_bwd: null X/dOut");
+  MML_REQUIRE(B == 0 || ((X || idx) && dOut), "mml_scatter_bwd: null X/dOut");
   MML_REQUIRE(!touched || (seen && rowbase && touched_count && touched_cap > 0),
               "mml_scatter_bwd: touched list needs seen/rowbase/touched_count/cap");
   if (B == 0 || F == 0) return MML_OK;
@@ -349,7 +351,7 @@ extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, 
     a.rowbase[f] = touched ? rowbase[f] : 0;
     MML_REQUIRE(!touched || seen[f], "mml_scatter_bwd: seen[%d] is null", f);
   }
-  a.X = X; a.ldX = ldX; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
+  a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
   const int threads = 256;
   if (E <= 16) {
@@ -372,15 +374,32 @@ extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, 
   return check_launch("mml_scatter_bwd");
 }
 
-extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X,
-                                int64_t ldX, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
-                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
-                                mml_stream_t stream) {
+extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                               int32_t E, const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
+                               uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
+                               int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream) {
+  return scatter_impl(grad_tables, vocab, col, F, E, X, ldX, nullptr, 0, B, dOut, ldo, seen, rowbase, touched,
+                      touched_count, touched_cap, status, stream);
+}
+
+extern "C" int mml_scatter_bwd_idx32(float* const* grad_tables, const int64_t* vocab, int32_t F, int32_t E,
+                                     const int32_t* idx, int64_t ldi, int64_t B, const float* dOut, int64_t ldo,
+                                     uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
+                                     int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                     mml_stream_t stream) {
+  return scatter_impl(grad_tables, vocab, nullptr, F, E, nullptr, 0, idx, ldi, B, dOut, ldo, seen, rowbase, touched,
+                      touched_count, touched_cap, status, stream);
+}
+
+static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X, int64_t ldX,
+                       const int32_t* idx, int64_t ldi, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
+                       int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                       mml_stream_t stream) {
   MML_REQUIRE(F >= 0 && F <= MML_MAX_FIELDS && vocab && seen && rowbase && touched && touched_count && touched_cap > 0,
               "mml_index_unique: bad arguments");
   MML_REQUIRE(E > 0 && E <= 16, "mml_index_unique: E must be in [1,16]");
   if (B == 0 || F == 0) return MML_OK;
-  MML_REQUIRE(X, "mml_index_unique: null X");
+  MML_REQUIRE(X || idx, "mml_index_unique: null X");
   FieldTable ft;
   ScatterArgs a{};
   for (int f = 0; f < F; ++f) {
@@ -391,7 +410,7 @@ extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_
     a.seen[f] = seen[f];
     a.rowbase[f] = rowbase[f];
   }
-  a.X = X; a.ldX = ldX; a.B = B; a.dOut = nullptr; a.F = F; a.E = E;
+  a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = nullptr; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
   const int slots = (E <= 8) ? 1024 : 512;
   const int chunk = slots / 2;
@@ -403,4 +422,20 @@ extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_
   else
     MML_LAUNCH(scatter_hash_kernel<512>, dim3((unsigned)nblocks), dim3(256), lds, to_stream(stream), ft, a, chunk);
   return check_launch("mml_index_unique");
+}
+
+extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X,
+                                int64_t ldX, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
+                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                mml_stream_t stream) {
+  return unique_impl(vocab, col, F, E, X, ldX, nullptr, 0, B, seen, rowbase, touched, touched_count, touched_cap,
+                     status, stream);
+}
+
+extern "C" int mml_index_unique_idx32(const int64_t* vocab, int32_t F, int32_t E, const int32_t* idx, int64_t ldi,
+                                      int64_t B, uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
+                                      int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                      mml_stream_t stream) {
+  return unique_impl(vocab, nullptr, F, E, nullptr, 0, idx, ldi, B, seen, rowbase, touched, touched_count,
+                     touched_cap, status, stream);
 }

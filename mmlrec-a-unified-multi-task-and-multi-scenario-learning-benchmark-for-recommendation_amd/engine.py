@@ -269,6 +269,13 @@ class GatherOp(Op):
     def outputs(self):
         return [self.out]
 
+    def index_view(self, plan):
+        """(index matrix, rows) the table update of this step is built from (the global batch under replication)."""
+        return self.X, plan.B
+
+    def pre_index_calls(self, plan):
+        return []
+
     def fwd_calls(self, plan):
         lib = L.load()
         F = len(self.tables)
@@ -1014,6 +1021,12 @@ class ParamStore:
         self.table_names = [n for n, _ in tables]
         for name, p in tables:
             self.pvals[name] = PVal(p.data, None, name, is_table=True)
+        par = getattr(model, "_parallel", None)
+        if par is not None and par.mode == "row_sharded":
+            # the trained rows of this rank live in ONE flat buffer (parallel.RowSharding); the full per-field tables
+            # stay registered (state_dict / predict contract) but are never written by a step
+            self.pvals["embedding_shard"] = PVal(par.shard, None, "embedding_shard", is_table=True)
+            self.table_names = ["embedding_shard"]
         self.table_grads_ready = False
         self.opt = None
         self.rows = None
@@ -1045,6 +1058,21 @@ class ParamStore:
             pv.written = 0
 
 
+class _OptState(dict):
+    """name -> (state1, state2), zero-initialised on first use (a row-sharded run never touches the full tables)."""
+
+    def __init__(self, store, kind):
+        super().__init__()
+        self.store, self.kind = store, kind
+
+    def __missing__(self, name):
+        pv = self.store.pvals[name]
+        s1 = torch.zeros_like(pv.data) if self.kind != "sgd" else None
+        s2 = torch.zeros_like(pv.data) if self.kind == "adam" else None
+        self[name] = (s1, s2)
+        return self[name]
+
+
 class Optimizer:
     """K8 front end: dense update for MLP parameters; for the tables one of
       dense_exact : every row every step, like the reference's torch.optim over dense gradients;
@@ -1069,11 +1097,7 @@ class Optimizer:
         self.dirty = False
         dev = store.device
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.state = {}
-        for name, pv in store.pvals.items():
-            s1 = torch.zeros_like(pv.data) if kind != "sgd" else None
-            s2 = torch.zeros_like(pv.data) if kind == "adam" else None
-            self.state[name] = (s1, s2)
+        self.state = _OptState(store, kind)  # moments are allocated when a tensor is first updated
         self.steps_done = 0
 
     def calls(self, plan):
@@ -1149,8 +1173,6 @@ class Optimizer:
         """Before the gather: unique rows of the batch (LDS dedup on the indices) -> replay their skipped steps."""
         lib, st = L.load(), self.store
         gop = plan.ops[0]
-        if not isinstance(gop, GatherOp):
-            raise L.MMLError("lazy_exact table updates are not available on the table-sharded path yet")
         names = st.table_names
         rows = st.rows
         if self.last is None:
@@ -1158,7 +1180,6 @@ class Optimizer:
         F = len(names)
         E = st.pvals[names[0]].data.shape[1]
         vocab = (L.i64 * F)(*[st.pvals[n].data.shape[0] for n in names])
-        col = (L.i32 * F)(*gop.cols)
         ps = ops._ptr_array(rows.seen)
         rb = (L.i64 * (F + 1))(*rows.rowbase)
         pt = ops._ptr_array([st.pvals[n].data for n in names])
@@ -1166,13 +1187,33 @@ class Optimizer:
         p2 = ops._ptr_array([self.state[n][1] for n in names]) if self.kind == "adam" else None
         pl = ops._ptr_array([self.last[n] for n in names])
         hyper = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev)
-        plan.keep += [vocab, col, ps, rb, pt, p1, p2, pl, hyper]
-        return [
-            (lib.mml_index_unique, (vocab, col, F, E, gop.X.data_ptr(), ops._ld(gop.X), plan.B, ps, rb,
+        plan.keep += [vocab, ps, rb, pt, p1, p2, pl, hyper]
+        catchup = (lib.mml_opt_catchup_rows, (pt, p1, p2, pl, rb, F, E, rows.touched.data_ptr(), rows.count.data_ptr(),
+                                              rows.touched.numel(), C.byref(hyper)), dict(kernel="opt_catchup_kernel"))
+        if getattr(gop, "owns_lazy", False):
+            # row-sharded tables: the keys to bring up to date only exist on the owner after the index exchange, so
+            # the gather op launches (unique -> catch-up) itself, on the flat shard (F == 1)
+            if F != 1:
+                raise L.MMLError("row-sharded lazy_exact expects the single flat shard")
+
+            def launch(keys_ptr, n, stream):
+                if n:
+                    L.check(lib.mml_index_unique_idx32(vocab, 1, E, keys_ptr, 1, n, ps, rb, rows.touched.data_ptr(),
+                                                       rows.count.data_ptr(), rows.touched.numel(),
+                                                       plan.status.data_ptr(), stream), "mml_index_unique_idx32")
+                    L.check(catchup[0](*catchup[1], stream), "mml_opt_catchup_rows")
+            gop.lazy_launch = launch
+            return []
+        if not isinstance(gop, GatherOp):
+            raise L.MMLError("lazy_exact table updates are not available on the table-wise sharded path")
+        X, nrows = gop.index_view(plan)
+        col = (L.i32 * F)(*gop.cols)
+        plan.keep.append(col)
+        return gop.pre_index_calls(plan) + [
+            (lib.mml_index_unique, (vocab, col, F, E, X.data_ptr(), ops._ld(X), nrows, ps, rb,
                                     rows.touched.data_ptr(), rows.count.data_ptr(), rows.touched.numel(),
                                     plan.status.data_ptr()), dict(kernel="scatter_hash_kernel(index_unique)")),
-            (lib.mml_opt_catchup_rows, (pt, p1, p2, pl, rb, F, E, rows.touched.data_ptr(), rows.count.data_ptr(),
-                                        rows.touched.numel(), C.byref(hyper)), dict(kernel="opt_catchup_kernel")),
+            catchup,
         ]
 
     def flush(self):

@@ -122,7 +122,8 @@ def run(args):
                       metrics=oc.get("metrics", ["auc", "acc"]))
         if dist is not None:
             from . import parallel
-            parallel.shard_model(model, dist, tc.get("train_batch_size", 4096))
+            parallel.shard_model(model, dist, tc.get("train_batch_size", 4096),
+                                 mode=mc.get("parallel_mode", "row_sharded"))  # additive key (parallel.MODES)
         best = model.fit(train_in, train[target].values, batch_size=tc.get("train_batch_size", 4096),
                          epochs=tc.get("epochs", 10), validation_data=(test_in, test[target].values))
         if sc.get("save_layer_output", False):

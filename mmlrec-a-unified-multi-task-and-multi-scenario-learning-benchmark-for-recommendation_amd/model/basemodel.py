@@ -224,7 +224,7 @@ class BaseModel(nn.Module):
             self._caches["plans"][key] = plan
         return plan
 
-    def _record(self, B, training, masked, store, sparse_rows=None):
+    def _record(self, B, training, masked, store, sparse_rows=None, lazy=False):
         plan = E.Plan(store.device, B, training)
         plan.bn_training = bool(self.training)
         plan.generation = 0
@@ -250,12 +250,20 @@ class BaseModel(nn.Module):
         x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input", pad_k=True)
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
         cols = [self.feature_index[f.name][0] for f in sp]
-        sharding = getattr(self, "_sharding", None)
-        if sharding is not None:
+        par = getattr(self, "_parallel", None)
+        if par is not None and par.mode == "table_wise":
             from ..parallel import ShardedGatherOp
-            plan.add(ShardedGatherOp(sharding, self._dist, tables, plan.X, cols, dense_col0, nd, x0,
-                                     sparse_rows=sparse_rows, group=self._dist_group))
-        else:
+            plan.add(ShardedGatherOp(par, tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
+        elif par is not None and training and par.mode == "row_sharded":
+            from ..parallel import RowShardedGatherOp
+            plan.add(RowShardedGatherOp(par, store.pvals["embedding_shard"], plan.X, cols, dense_col0, nd, x0,
+                                        sparse_rows=sparse_rows))
+        elif par is not None and training and par.mode == "replicated":
+            from ..parallel import ReplicatedGatherOp
+            op = ReplicatedGatherOp(par, tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)
+            op.x_in_pre = bool(lazy)  # lazy_exact gathers the global index matrix before its catch-up pass
+            plan.add(op)
+        else:  # single GPU, and inference on the (synchronised) full tables of a row-sharded / replicated model
             plan.add(E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)
@@ -279,6 +287,10 @@ class BaseModel(nn.Module):
         opt = getattr(self, "_optimizer", None)
         if opt is not None:
             opt.flush()
+        par = getattr(self, "_parallel", None)
+        if par is not None and par.dirty:  # collective: every rank reaches this point (parallel.py)
+            from ..parallel import sync_tables
+            sync_tables(self)
 
     def state_dict(self, *args, **kwargs):
         self.flush_tables()
@@ -420,6 +432,14 @@ class BaseModel(nn.Module):
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, initial_epoch=0, validation_split=0.0,
             validation_data=None, shuffle=True):
+        """Counterpart of BaseModel.fit of the reference (model/basemodel.py:135-371).
+
+        Multi-GPU (after parallel.shard_model; every rank calls fit with the SAME data and the same seed): the epoch
+        permutation is dealt to the ranks like torch's DistributedSampler does -- padded with its own first entries to
+        a multiple of the world size, rank r takes entries r, r + world, ... -- so every rank runs the same number of
+        steps with the same batch sizes; `batch_size` is per rank (global batch = world * batch_size).  Loss and the
+        per-step train metrics in the epoch log are averaged over ranks; validation runs on every rank (identical
+        results), on the synchronised tables."""
         if self._has_regularization():
             raise NotImplementedError("non-zero l1/l2 regularisation is not in the fused step yet (every shipped "
                                       "config sets l2_reg_* = 0)")
@@ -448,16 +468,24 @@ class BaseModel(nn.Module):
         Xd = torch.as_tensor(X_all, dtype=torch.float32).to(dev)
         yd = torch.as_tensor(y, dtype=torch.float32).to(dev)
         self.train()
+        par = getattr(self, "_parallel", None)
+        world, rank = (par.world, par.rank) if par is not None else (1, 0)
+        n_total, n = n, -(-n // world)  # from here on n = samples of THIS rank per epoch
         steps_per_epoch = (n - 1) // batch_size + 1
         print(dev)
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
-            n, 0 if val_y is None else len(val_y), steps_per_epoch))
+            n_total, 0 if val_y is None else len(val_y), steps_per_epoch))
         best_auc, early_stop, best_model = 0, 0, None
         self.history = []
         pred_epoch = torch.empty((n, self.num_tasks), dtype=torch.float32, device=dev)
         for epoch in range(initial_epoch, epochs):
             start_time = time.time()
-            perm = self._epoch_permutation(n, shuffle)
+            perm = self._epoch_permutation(n_total, shuffle)
+            if world > 1:
+                pad = n * world - n_total
+                if pad:
+                    perm = torch.cat([perm, perm[:pad]])
+                perm = perm[rank::world].contiguous()
             perm_d = perm.to(dev)
             loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
             for s in range(steps_per_epoch):
@@ -470,7 +498,9 @@ class BaseModel(nn.Module):
                 loss_dev += step.plan.loss
             for st in self._caches["steps"].values():
                 ops.check_status(st.plan.status, "embedding lookup (nn.Embedding semantics)")
-            epoch_logs = {"loss": float(loss_dev.item()) / n, "cka_loss": 0.0}
+            if world > 1:
+                par.comm.all_reduce(loss_dev)
+            epoch_logs = {"loss": float(loss_dev.item()) / (n * world), "cka_loss": 0.0}
             # per-batch train metrics, averaged over steps exactly like the reference (:316-337), computed once
             # per epoch on the host instead of once per step
             dev_metrics = self._device_batch_metrics(pred_epoch, yd, perm_d, batch_size)
@@ -487,6 +517,12 @@ class BaseModel(nn.Module):
                     sl = slice(s * batch_size, (s + 1) * batch_size)
                     vals.append(self._metric(fn, ye[sl], pe[sl]))
                 epoch_logs[name] = np.sum(vals) / steps_per_epoch
+            if world > 1:  # mean over ranks of the per-rank step averages
+                names = [m for m in self.metrics]
+                t = torch.tensor([epoch_logs[m] for m in names], dtype=torch.float64, device=dev)
+                par.comm.all_reduce(t)
+                for m, v in zip(names, (t / world).tolist()):
+                    epoch_logs[m] = v
             if do_validation:
                 eval_result = self.evaluate(val_x, val_y, batch_size)
                 print(eval_result)
@@ -512,6 +548,7 @@ class BaseModel(nn.Module):
             self.history.append(epoch_logs)
             if early_stop >= self.optim_config.get("early_stop", 3):
                 break
+        self.flush_tables()  # multi-GPU: leave every rank's full tables equal to the trained state (collective)
         return best_model if best_model is not None else self  # reference D7: unbound when nothing improved
 
     def _device_batch_metrics(self, pred, yd, perm_d, batch_size):

@@ -112,6 +112,51 @@ def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=No
     L.check(rc, "mml_scatter_bwd")
 
 
+def scatter_bwd_idx32(grad_tables, idx, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None):
+    """grad_tables[f][idx[:, f]] += d_out[:, f*E:(f+1)*E] with native int32 indices [B, F]."""
+    lib = L.load()
+    _need_gpu(idx, d_out, *grad_tables)
+    F, E, B = len(grad_tables), grad_tables[0].shape[1], idx.shape[0]
+    vocab = (L.i64 * F)(*[t.shape[0] for t in grad_tables])
+    seen_arr = _ptr_array(seen) if seen is not None else None
+    rb = (L.i64 * (F + 1))(*rowbase) if rowbase is not None else None
+    rc = lib.mml_scatter_bwd_idx32(_ptr_array(grad_tables), vocab, F, E, idx.data_ptr(), idx.stride(0), B,
+                                   d_out.data_ptr(), _ld(d_out), seen_arr, rb, L.ptr(touched), L.ptr(touched_count),
+                                   0 if touched is None else touched.numel(), L.ptr(status), _stream())
+    L.check(rc, "mml_scatter_bwd_idx32")
+
+
+def route(X, cols, vocab, keybase, world, status=None):
+    """Row-sharded routing of a batch (csrc/shard.hip): returns (counts [world] int32, send_keys [B*F] int32 grouped by
+    owner, pos [B, F] int32)."""
+    lib = L.load()
+    _need_gpu(X)
+    F, B = len(vocab), X.shape[0]
+    col = (L.i32 * F)(*cols)
+    voc = (L.i64 * F)(*vocab)
+    kb = (L.i64 * F)(*keybase[:F])
+    counters = torch.zeros(2 * world, dtype=torch.int32, device=X.device)
+    keys = torch.empty(B * F, dtype=torch.int32, device=X.device)
+    pos = torch.empty(B, F, dtype=torch.int32, device=X.device)
+    s = _stream()
+    if X.dtype == torch.int32:
+        xa = (None, 0, X.data_ptr(), X.stride(0))
+    else:
+        xa = (_f32_2d(X, "X").data_ptr(), _ld(X), None, 0)
+    L.check(lib.mml_route_count(*xa, col, voc, F, B, world, counters.data_ptr(), L.ptr(status), s), "mml_route_count")
+    counts = counters[:world].clone()
+    L.check(lib.mml_route_place(*xa, col, voc, kb, F, B, world, counters.data_ptr(), keys.data_ptr(), pos.data_ptr(),
+                                L.ptr(status), s), "mml_route_place")
+    return counts, keys, pos
+
+
+def rows_permute(src, pos, E, dst):
+    """dst[pos[b, f]] = src[b, f*E:(f+1)*E]."""
+    B, F = pos.shape
+    L.check(L.load().mml_rows_permute(src.data_ptr(), _ld(src), pos.data_ptr(), F, E, B, dst.data_ptr(), _stream()),
+            "mml_rows_permute")
+
+
 # ---------------------------------------------------------------------------------------------- K3
 def make_fwd_descs(problems):
     """problems: dicts with A [M,K], W ([N,K] or [K,N] if w_kn), bias or None, C [M,N], act, w_kn."""

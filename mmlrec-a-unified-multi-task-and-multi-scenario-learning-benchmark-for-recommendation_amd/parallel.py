@@ -1,19 +1,32 @@
 """Multi-GPU execution: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl"), no reference
-behaviour to match (the reference's --is_parallel path is a broken stub).
+behaviour to match (the reference's --is_parallel path is a broken stub, main.py:81-83, model/basemodel.py:235-238,
+SURVEY 2.1 / D6).  Contract: an N-rank step on a batch split N ways == a 1-rank step on the whole batch.
 
-Scheme ("table-wise sharding"): samples are data-parallel (each rank trains on its own batch shard, MLP gradients are
-summed with ONE all-reduce of the flat gradient arena -- the loss is a plain sum, so no averaging); every embedding
-TABLE lives on exactly one rank, chosen by a longest-processing-time greedy over (rows to update + lookups to serve).
-Per step and per direction there is ONE all-to-all with sizes that are static functions of (B, fields per rank):
+Samples are data-parallel in every mode: each rank trains on its own batch shard and the MLP gradients are summed with
+ONE all-reduce of the flat gradient arena (the loss is a plain sum, so no averaging).  The tables come in three modes:
 
-  forward : pack X[:, field] columns per owner -> all_to_all(indices) -> owner runs the fused gather kernel on the
-            world*B samples it received -> all_to_all(rows) -> unpack into dnn_input [B, F*E + Nd]
-  backward: pack d(dnn_input) per owner -> all_to_all(row gradients) -> owner runs the scatter kernel and updates ITS
-            tables only (no table all-reduce at all; dense Adam touches 1/world of the rows per rank)
+  row_sharded (default; the one BASELINE.json's configs 4 / 5 name): row r of field f lives on rank (r + f) mod N at
+      local row r // N; a rank keeps its F shards back to back in ONE flat [R, E] buffer (`embedding_shard`), so a
+      lookup travels as a single int32 key into the owner's flat row space and the owner-side gather / scatter /
+      optimizer are single-table launches.  Per step and direction ONE all-to-all over all fields:
+        forward : route (count, place) -> all_to_all(keys) -> owner gather -> all_to_all(rows) -> expand to dnn_input
+        backward: pack d(dnn_input) -> all_to_all(row gradients) -> owner scatter + optimizer on its shard only
+      Per-owner counts depend on the data: they are exchanged first (one tiny all-to-all + ONE host read per step).
+      Every rank updates 1/N of every table (dense Adam streams 1/N of the rows), so the load is balanced by
+      construction and `lazy_exact` works unchanged on the flat shard.
+  replicated: every rank holds every table and gathers locally; the (index, row-gradient) pairs of all ranks are
+      all-gathered (fixed sizes, no host read) and every rank applies the same update to its copy.  Float atomics make
+      the copies differ in the last bits; `sync_tables` re-broadcasts rank 0's copy.
+  table_wise: every TABLE lives on one rank (longest-processing-time greedy); static all-to-all split sizes.  Kept
+      from round 1; unbalanced for AE-30 (the owner of the 1e7-row table carries 80 % of the dense-Adam rows).
 
-Static split sizes mean no host synchronisation and no index sorting in the step.  Row-wise sharding of a single table
-(needed only when one table outgrows a GPU's 288 GB) is a later extension of the same exchange.
+The full `embedding_dict.<name>.weight` parameters stay on every rank (state_dict / predict contract, 400 MB for
+AE-30); in row_sharded mode they are stale while training and `sync_tables` (all-gather of the shards) refreshes them --
+BaseModel.flush_tables does that before anything outside the fused step reads a table.  All of these are collective
+calls: every rank must reach them.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -21,6 +34,274 @@ from . import engine as E
 from . import ops
 
 
+class Comm:
+    """The few collectives the step needs, on one process group.  RCCL ("nccl") moves device buffers directly; under
+    "gloo" (the world-2 tests: two processes on one GPU or on CPU) device buffers are staged through the host."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.staged = dist.get_backend(group) == "gloo"
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def _stage(self, t):
+        return t.detach().cpu() if (self.staged and t.is_cuda) else t
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        o, i = self._stage(out), self._stage(inp)
+        self.dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+        if o is not out:
+            out.copy_(o)
+
+    def all_reduce(self, t):
+        s = self._stage(t)
+        self.dist.all_reduce(s, op=self.dist.ReduceOp.SUM, group=self.group)
+        if s is not t:
+            t.copy_(s)
+
+    def all_reduce_max(self, t):
+        s = self._stage(t)
+        self.dist.all_reduce(s, op=self.dist.ReduceOp.MAX, group=self.group)
+        if s is not t:
+            t.copy_(s)
+
+    def all_gather_into_tensor(self, out, inp):
+        o, i = self._stage(out), self._stage(inp)
+        if self.staged:
+            parts = list(o.view(self.world, -1).unbind(0))
+            self.dist.all_gather(parts, i.reshape(-1).contiguous(), group=self.group)
+        else:
+            self.dist.all_gather_into_tensor(o, i, group=self.group)
+        if o is not out:
+            out.copy_(o)
+
+    def broadcast(self, t, src):
+        s = self._stage(t)
+        self.dist.broadcast(s, src=src, group=self.group)
+        if s is not t:
+            t.copy_(s)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+# ======================================================================================================
+# row-wise sharding
+# ======================================================================================================
+class RowSharding:
+    """Host-side arithmetic of the row-wise layout (the device side is csrc/shard.hip)."""
+
+    def __init__(self, vocab, emb, world, rank):
+        self.vocab = [int(v) for v in vocab]
+        self.emb, self.world, self.rank = int(emb), int(world), int(rank)
+        self.rows_local = [(v + self.world - 1) // self.world for v in self.vocab]  # same on every rank
+        self.keybase = [0]
+        for n in self.rows_local:
+            self.keybase.append(self.keybase[-1] + n)
+        self.R = self.keybase[-1]
+        if self.R >= 2 ** 31:
+            raise L.MMLError("row-sharded tables: a rank's flat row space must fit int32 keys")
+
+    def owner(self, f, r):
+        return (r + f) % self.world
+
+    def key(self, f, r):
+        return self.keybase[f] + r // self.world
+
+    def first(self, f, rank=None):
+        """Smallest row of field f that rank owns."""
+        rank = self.rank if rank is None else rank
+        return (rank - f) % self.world
+
+    def owned_rows(self, f, rank=None):
+        """Number of REAL rows of field f on a rank (the shard may end in padding rows)."""
+        v, first = self.vocab[f], self.first(f, rank)
+        return 0 if first >= v else (v - 1 - first) // self.world + 1
+
+    # ---- device helpers ---------------------------------------------------------------------------
+    def tables_to_shard(self, tables, shard=None, rank=None):
+        """flat[keybase[f] + l] = tables[f][l * world + first(f)] (padding rows zero)."""
+        dev = tables[0].device
+        if shard is None:
+            shard = torch.empty(self.R, self.emb, dtype=torch.float32, device=dev)
+        lib, s = L.load(), ops._stream()
+        for f, t in enumerate(tables):
+            L.check(lib.mml_shard_rows(t.data_ptr(), t.shape[0], shard[self.keybase[f]:].data_ptr(), self.rows_local[f],
+                                       self.emb, self.world, self.first(f, rank), 0, s), "mml_shard_rows")
+        return shard
+
+    def shard_to_tables(self, shard, tables, rank=None):
+        lib, s = L.load(), ops._stream()
+        for f, t in enumerate(tables):
+            L.check(lib.mml_shard_rows(t.data_ptr(), t.shape[0], shard[self.keybase[f]:].data_ptr(), self.rows_local[f],
+                                       self.emb, self.world, self.first(f, rank), 1, s), "mml_shard_rows")
+
+
+class RowShardedGatherOp(E.Op):
+    """K1/K2 over row-sharded tables.  The exchange sizes are only known at run time, so forward and backward are one
+    Python-issued entry each (engine.PY): kernels + collectives launched eagerly; everything between them has static
+    shapes and is replayed from HIP graphs by the trainer."""
+    owns_lazy = True  # the lazy-exact catch-up runs on the owner side, inside the forward exchange
+
+    def __init__(self, par, shard_pv, X, cols, dense_col0, nd, out, sparse_rows=None):
+        self.par, self.sh, self.comm = par, par.sharding, par.comm
+        self.shard, self.X, self.cols, self.dense_col0, self.nd, self.out = shard_pv, X, cols, dense_col0, nd, out
+        self.sparse_rows = sparse_rows
+        self.lazy_launch = None
+        self.stats = {"n_recv": 0, "steps": 0}
+
+    def outputs(self):
+        return [self.out]
+
+    # ---- build time --------------------------------------------------------------------------------
+    def fwd_calls(self, plan):
+        sh, dev = self.sh, plan.device
+        F, W, B = len(sh.vocab), sh.world, plan.B
+        self.F, self.B = F, B
+        self.col = (L.i32 * F)(*self.cols)
+        self.vocab = (L.i64 * F)(*sh.vocab)
+        self.keybase = (L.i64 * F)(*sh.keybase[:F])
+        self.counters = torch.zeros(2 * W, dtype=torch.int32, device=dev)
+        self.cnt_pair = torch.zeros(2, W, dtype=torch.int32, device=dev)
+        self.send_keys = torch.empty(B * F, dtype=torch.int32, device=dev)
+        self.pos = torch.empty(B, F, dtype=torch.int32, device=dev)
+        self.rows_recv = torch.empty(B * F, sh.emb, dtype=torch.float32, device=dev)
+        self.recv_keys = self.rows_send = self.grad_recv = None
+        self.n_recv = 0
+        # owner side: ONE table = the flat shard
+        self.o_tab = ops._ptr_array([self.shard.data])
+        self.o_vocab = (L.i64 * 1)(sh.R)
+        # expansion: F "fields" that all read the received row block
+        self.x_tab = ops._ptr_array([self.rows_recv] * F)
+        self.x_vocab = (L.i64 * F)(*([B * F] * F))
+        self.status = plan.status
+        plan.keep.append(self)
+        return [(E.PY, self._forward, (), dict(kernel="row_sharded_forward_exchange"))]
+
+    def bwd_calls(self, plan):
+        if self.out.grad is None:
+            return []
+        if not self.shard.needs_grad:
+            raise L.MMLError("row-sharded tables need the shard's gradient accumulator (ParamStore.ensure_table_grads)")
+        E._claim(self.shard)
+        self.grad_send = torch.empty(self.B * self.F, self.sh.emb, dtype=torch.float32, device=plan.device)
+        self.o_grad = ops._ptr_array([self.shard.grad])
+        sr = self.sparse_rows
+        if sr is not None:
+            self.o_seen = ops._ptr_array(sr.seen)
+            self.o_rb = (L.i64 * 2)(*sr.rowbase)
+            self.o_extra = (self.o_seen, self.o_rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
+        else:
+            self.o_extra = (None, None, None, None, 0)
+        return [(E.PY, self._backward, (), dict(kernel="row_sharded_backward_exchange", tail=True))]
+
+    # ---- run time ----------------------------------------------------------------------------------
+    def _grow(self, n):
+        if self.recv_keys is None or self.recv_keys.numel() < n:
+            cap = max(int(n * 1.25) + 1024, 1)
+            dev, Em = self.send_keys.device, self.sh.emb
+            self.recv_keys = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.rows_send = torch.empty(cap, Em, dtype=torch.float32, device=dev)
+            self.grad_recv = torch.empty(cap, Em, dtype=torch.float32, device=dev)
+
+    def _forward(self):
+        lib, sh, comm = L.load(), self.sh, self.comm
+        s = ops._stream()
+        B, F, W, Em = self.B, self.F, sh.world, sh.emb
+        Xp, ldX = self.X.data_ptr(), ops._ld(self.X)
+        st = self.status.data_ptr()
+        L.check(lib.mml_route_count(Xp, ldX, None, 0, self.col, self.vocab, F, B, W, self.counters.data_ptr(), st, s),
+                "mml_route_count")
+        self.cnt_pair[0].copy_(self.counters[:W])  # (mml_route_place moves the cursors, not the counts)
+        L.check(lib.mml_route_place(Xp, ldX, None, 0, self.col, self.vocab, self.keybase, F, B, W,
+                                    self.counters.data_ptr(), self.send_keys.data_ptr(), self.pos.data_ptr(), st, s),
+                "mml_route_place")
+        comm.all_to_all_single(self.cnt_pair[1], self.cnt_pair[0])
+        pair = self.cnt_pair.cpu()  # the one host read of the step: split sizes of the three exchanges
+        self.send_splits, self.recv_splits = pair[0].tolist(), pair[1].tolist()
+        n = self.n_recv = int(sum(self.recv_splits))
+        self.stats["n_recv"] += n
+        self.stats["steps"] += 1
+        self._grow(n)
+        comm.all_to_all_single(self.recv_keys[:n], self.send_keys, self.recv_splits, self.send_splits)
+        if self.lazy_launch is not None:  # bring exactly the rows about to be read up to date (lazy-exact Adam)
+            self.lazy_launch(self.recv_keys.data_ptr(), n, s)
+        if n:
+            L.check(lib.mml_gather_fwd_idx32(self.o_tab, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, None, 0, 0,
+                                             n, self.rows_send.data_ptr(), Em, st, s), "mml_gather_fwd_idx32(owner)")
+        comm.all_to_all_single(self.rows_recv.view(-1), self.rows_send.view(-1)[:n * Em],
+                               [c * Em for c in self.send_splits], [c * Em for c in self.recv_splits])
+        dense = self.X[:, self.dense_col0:].data_ptr() if self.nd else None
+        L.check(lib.mml_gather_fwd_idx32(self.x_tab, self.x_vocab, F, Em, self.pos.data_ptr(), F, dense, ldX, self.nd, B,
+                                         self.out.buf.data_ptr(), ops._ld(self.out.buf), st, s),
+                "mml_gather_fwd_idx32(expand)")
+
+    def _backward(self):
+        lib, sh, comm = L.load(), self.sh, self.comm
+        s = ops._stream()
+        B, F, Em, n = self.B, self.F, sh.emb, self.n_recv
+        g = self.out.grad
+        L.check(lib.mml_rows_permute(g.data_ptr(), ops._ld(g), self.pos.data_ptr(), F, Em, B, self.grad_send.data_ptr(),
+                                     s), "mml_rows_permute")
+        comm.all_to_all_single(self.grad_recv.view(-1)[:n * Em], self.grad_send.view(-1),
+                               [c * Em for c in self.recv_splits], [c * Em for c in self.send_splits])
+        if n:
+            L.check(lib.mml_scatter_bwd_idx32(self.o_grad, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, n,
+                                              self.grad_recv.data_ptr(), Em, *self.o_extra, self.status.data_ptr(), s),
+                    "mml_scatter_bwd_idx32(owner)")
+
+
+class ReplicatedGatherOp(E.GatherOp):
+    """Tables replicated: local gather; backward = all-gather of (indices, row gradients), then every rank scatters
+    the WHOLE global batch into its own copy (identical updates, fixed sizes, no host read)."""
+
+    def __init__(self, par, *a, **k):
+        super().__init__(*a, **k)
+        self.par, self.comm = par, par.comm
+
+    def fwd_calls(self, plan):
+        W = self.comm.world
+        self.X_all = plan.empty(W * plan.B, self.X.shape[1])
+        return super().fwd_calls(plan)
+
+    def index_view(self, plan):
+        return self.X_all, self.comm.world * plan.B
+
+    def pre_index_calls(self, plan):
+        """Indices of the global batch (needed before the lazy-exact catch-up and by the scatter)."""
+        return [(E.PY, self.comm.all_gather_into_tensor, (self.X_all, self.X), dict(kernel="all_gather(indices)"))]
+
+    def bwd_calls(self, plan):
+        if self.out.grad is None or not any(t.needs_grad for t in self.tables):
+            return []
+        W = self.comm.world
+        g = self.out.grad
+        ld = g.stride(0)
+        g_full = g.as_strided((plan.B, ld), (ld, 1), g.storage_offset())
+        self.g_all = plan.empty(W * plan.B, ld)
+        local_X, local_g = self.X, self.out.grad
+        calls = []
+        if not getattr(self, "x_in_pre", False):
+            calls += self.pre_index_calls(plan)
+        calls.append((E.PY, self.comm.all_gather_into_tensor, (self.g_all, g_full), dict(kernel="all_gather(row grads)")))
+        # the inherited scatter over the gathered batch
+        self.X, B0 = self.X_all, plan.B
+        self.out.grad = self.g_all[:, :g.shape[1]]
+        plan.B = W * B0
+        try:
+            sc = super().bwd_calls(plan)
+        finally:
+            self.X, self.out.grad, plan.B = local_X, local_g, B0
+        for c in calls:
+            c[3]["tail"] = True
+        return calls + sc
+
+
+# ======================================================================================================
+# table-wise sharding (round 1)
+# ======================================================================================================
 class FieldSharding:
     """Which rank owns which sparse field, and where each field sits inside its owner's blocks."""
 
@@ -107,10 +388,11 @@ def copy_cols_call(plan, segs, rows, accumulate=0):
 
 
 class ShardedGatherOp(E.Op):
-    """K1/K2 across ranks: index / row / gradient exchange around the local fused gather and scatter kernels."""
+    """K1/K2 with whole tables on owner ranks: index / row / gradient exchange around the local fused gather and
+    scatter kernels (static split sizes)."""
 
-    def __init__(self, sharding, dist, tables, X, cols, dense_col0, nd, out, sparse_rows=None, group=None):
-        self.sh, self.dist, self.group = sharding, dist, group
+    def __init__(self, par, tables, X, cols, dense_col0, nd, out, sparse_rows=None):
+        self.sh, self.comm = par.sharding, par.comm
         self.tables, self.X, self.cols, self.dense_col0, self.nd, self.out = tables, X, cols, dense_col0, nd, out
         self.sparse_rows = sparse_rows
 
@@ -118,7 +400,7 @@ class ShardedGatherOp(E.Op):
         return [self.out]
 
     def _a2a(self, out, inp, out_splits, in_splits):
-        self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+        self.comm.all_to_all_single(out, inp, out_splits, in_splits)
 
     def fwd_calls(self, plan):
         sh, lib = self.sh, L.load()
@@ -190,28 +472,87 @@ class ShardedGatherOp(E.Op):
         return calls
 
 
-def make_allreduce(dist, group=None):
+# ======================================================================================================
+# model-level switch
+# ======================================================================================================
+MODES = ("row_sharded", "replicated", "table_wise")
+
+
+class ParallelState:
+    """What a model needs to know about its process group.  Never deep-copied: fit()'s best-model snapshot is a plain
+    single-GPU model holding the synchronised tables."""
+
+    def __init__(self, comm, mode, sharding):
+        self.comm, self.mode, self.sharding = comm, mode, sharding
+        self.shard = None      # row_sharded: this rank's flat [R, E] rows
+        self.dirty = False     # the full embedding_dict tables are behind the trained state
+
+    def __deepcopy__(self, memo):
+        return None
+
+    @property
+    def world(self):
+        return self.comm.world
+
+    @property
+    def rank(self):
+        return self.comm.rank
+
+
+def make_allreduce(par):
     """Sum of the flat MLP-gradient arena over ranks (loss is reduction='sum', model/basemodel.py:295)."""
-    def allreduce(arena):
-        dist.all_reduce(arena, op=dist.ReduceOp.SUM, group=group)
-    return allreduce
+    return par.comm.all_reduce
 
 
-def shard_model(model, dist, batch_per_rank, group=None):
-    """Switch a model to table-wise sharded execution on the current process group."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+def _full_tables(model):
+    return [model.embedding_dict[f.embedding_name].weight.data for f in model._sparse_cols()]
+
+
+def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded"):
+    """Switch a model to multi-GPU execution on the current process group (collective: every rank calls it on an
+    identically initialised model).  Returns the ParallelState (also stored as model._parallel)."""
+    if mode not in MODES:
+        raise ValueError(f"mode must be one of {MODES}")
+    comm = Comm(dist, group)
     vocab = [f.vocabulary_size for f in model._sparse_cols()]
-    model._sharding = FieldSharding(vocab, model.embedding_size, world, rank, batch_per_rank)
-    model._dist, model._dist_group = dist, group
-    model._caches = {"store": model._caches.get("store"), "plans": {}, "steps": {}}
-    return model._sharding
+    Em = model.embedding_size
+    if mode == "row_sharded":
+        sharding = RowSharding(vocab, Em, comm.world, comm.rank)
+    elif mode == "table_wise":
+        sharding = FieldSharding(vocab, Em, comm.world, comm.rank, batch_per_rank)
+    else:
+        sharding = None
+    par = ParallelState(comm, mode, sharding)
+    if mode == "row_sharded":
+        tabs = _full_tables(model)
+        if not tabs[0].is_cuda:
+            raise L.MMLError("shard_model: move the model to its MI355X first (no CPU path)")
+        par.shard = sharding.tables_to_shard(tabs)
+    model._parallel = par
+    model._caches = {"store": None, "plans": {}, "steps": {}}
+    if getattr(model, "_optimizer", None) is not None:
+        model._optimizer = None  # optimizer state follows the parameter store (moments restart with the new layout)
+    return par
 
 
 def sync_tables(model):
-    """Broadcast every table from its owner so all ranks hold the trained rows (before eval / state_dict)."""
-    sh = getattr(model, "_sharding", None)
-    if sh is None:
+    """Make every rank's full embedding_dict tables equal to the trained state (collective).
+    row_sharded: all-gather of the flat shards; table_wise: broadcast from each owner; replicated: rank 0's copy."""
+    par = getattr(model, "_parallel", None)
+    if par is None:
         return
-    for f, feat in enumerate(model._sparse_cols()):
-        w = model.embedding_dict[feat.embedding_name].weight.data
-        model._dist.broadcast(w, src=sh.owner[f], group=model._dist_group)
+    comm = par.comm
+    tabs = _full_tables(model)
+    if par.mode == "row_sharded":
+        sh = par.sharding
+        allsh = torch.empty(comm.world, sh.R, sh.emb, dtype=torch.float32, device=par.shard.device)
+        comm.all_gather_into_tensor(allsh, par.shard)
+        for k in range(comm.world):
+            sh.shard_to_tables(allsh[k], tabs, rank=k)
+    elif par.mode == "table_wise":
+        for f, w in enumerate(tabs):
+            comm.broadcast(w, src=par.sharding.owner[f])
+    else:
+        for w in tabs:
+            comm.broadcast(w, src=0)
+    par.dirty = False

@@ -6,10 +6,62 @@ Two HIP streams: after the backward chain has produced every dL/d(pre-activation
   main stream : table scatter -> table optimizer            (HBM / atomics bound)
   side stream : all weight-gradient GEMMs -> [all-reduce] -> MLP optimizer   (MFMA bound)
 -- and joins at the end, so the 3.2 GB table stream of the reference-exact dense Adam hides behind the wgrad GEMMs.
+
+Multi-GPU steps (parallel.py) contain Python-issued entries (collectives, the row-sharded exchange with its run-time
+sizes).  Those run eagerly; the runs of C-ABI calls between them -- static shapes, static pointers -- are still captured
+and replayed as HIP graphs (`Segments`).
 """
 import torch
 
 from . import engine as E
+
+
+class Segments:
+    """A call list cut at its Python-issued entries: [graphable run, PY entry, graphable run, ...]."""
+
+    def __init__(self, calls, use_graph, min_calls=2):
+        self.parts = []  # ("c", [calls]) | ("py", call)
+        run = []
+        for c in calls:
+            if c[0] is E.PY:
+                if run:
+                    self.parts.append(["c", run, None])
+                    run = []
+                self.parts.append(["py", c, None])
+            else:
+                run.append(c)
+        if run:
+            self.parts.append(["c", run, None])
+        self.use_graph = bool(use_graph)
+        self.min_calls = min_calls
+        self.captured = False
+
+    def capture(self):
+        """Record every long-enough run as its own single-stream HIP graph (nothing executes)."""
+        if not self.use_graph or self.captured:
+            return
+        for p in self.parts:
+            if p[0] == "c" and len(p[1]) >= self.min_calls:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    E.Plan._run(p[1])
+                p[2] = g
+        self.captured = True
+
+    def run(self, skip_py=None):
+        for kind, item, graph in self.parts:
+            if kind == "py":
+                if skip_py is not None and skip_py(item):
+                    continue
+                item[1](*item[2])
+            elif graph is not None:
+                graph.replay()
+            else:
+                E.Plan._run(item)
+
+    @property
+    def n_graphs(self):
+        return sum(1 for p in self.parts if p[2] is not None)
 
 
 class TrainStep:
@@ -18,51 +70,45 @@ class TrainStep:
         self.store = model._store()
         self.opt = model.optimizer()
         rows = None
-        sharding = getattr(model, "_sharding", None)
-        if allreduce is None and sharding is not None:
+        par = getattr(model, "_parallel", None)
+        self.par = par
+        if allreduce is None and par is not None:
             from .parallel import make_allreduce
-            allreduce = make_allreduce(model._dist, model._dist_group)
+            allreduce = make_allreduce(par)
         lazy = self.opt.table_update == "lazy_exact"
-        if lazy and sharding is not None:
-            raise NotImplementedError("lazy_exact table updates on the table-sharded path")
+        if lazy and par is not None and par.mode == "table_wise":
+            raise NotImplementedError("lazy_exact table updates on the table-wise sharded path (use row_sharded)")
         if self.opt.table_update in ("sparse_rows", "lazy_exact"):
-            if sharding is None:
+            if par is None:
                 rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))
+            elif par.mode == "row_sharded":  # one flat table: at most every local row is touched
+                rows = self.store.ensure_rows(par.sharding.R)
+            elif par.mode == "replicated":
+                rows = self.store.ensure_rows(par.world * int(B) * max(len(model._sparse_cols()), 1))
             else:  # this rank serves world*B lookups for each of ITS fields
                 sp = model._sparse_cols()
-                names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in sharding.mine]
-                rows = self.store.ensure_rows(sharding.world * int(B) * max(len(names), 1), names)
+                names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in par.sharding.mine]
+                rows = self.store.ensure_rows(par.world * int(B) * max(len(names), 1), names)
         # lazy_exact lists the batch's rows in a pre-pass (before the gather), so the scatter only accumulates
-        self.plan = model._record(B, True, False, self.store, sparse_rows=None if lazy else rows)
+        self.plan = model._record(B, True, False, self.store, sparse_rows=None if lazy else rows, lazy=lazy)
         self.opt_split = self.opt.calls_split(self.plan)
         self.opt_calls = self.opt_split["pre"] + self.opt_split["mlp"] + self.opt_split["tables"]
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
-        # collectives are issued from Python between kernel launches: keep them out of HIP graph capture
-        self.use_graph = bool(use_graph) and sharding is None
+        self.use_graph = bool(use_graph)
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
         # fork / join events live as long as the step
         self.ev_fork = torch.cuda.Event() if self.overlap else None
         self.ev_join = torch.cuda.Event() if self.overlap else None
-        self.g_fb = self.g_side = self.g_tail = None
+        p = self.plan
+        ar = [(E.PY, self._allreduce, (), dict(kernel="all_reduce(mlp grads)"))] if allreduce is not None else []
+        self.front = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd, self.use_graph)
+        self.sideq = Segments(p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
+        self.tail = Segments(p.bwd_tail + self.opt_split["tables"], self.use_graph)
         self.calls = 0
 
-    def _front(self):
-        p, run = self.plan, E.Plan._run
-        run(self.opt_split["pre"])
-        run(p.fwd)
-        run(p.head_train)
-        run(p.bwd)
-
-    def _side(self, with_allreduce=True):
-        E.Plan._run(self.plan.bwd_side)
-        if self.allreduce is not None and with_allreduce:
-            self.allreduce(self.store.arena)
-        E.Plan._run(self.opt_split["mlp"])
-
-    def _tail(self):
-        E.Plan._run(self.plan.bwd_tail)
-        E.Plan._run(self.opt_split["tables"])
+    def _allreduce(self):
+        self.allreduce(self.store.arena)
 
     def _forked(self, side, tail):
         main = torch.cuda.current_stream()
@@ -74,48 +120,29 @@ class TrainStep:
         tail()
         main.wait_event(self.ev_join)
 
-    def _body(self, with_allreduce=True):
-        # (mml_gemm_set_wgrad_lds_pad can cap the wgrad GEMMs' residency so that the table optimizer co-resides; with
-        # the direct-to-LDS GEMMs the standalone speed of wgrad at 4 workgroups/CU wins, so the pad stays 0)
-        self._front()
-        if not self.overlap:
-            self._tail()
-            self._side(with_allreduce)
-            return
-        self._forked(lambda: self._side(with_allreduce), self._tail)
-
-    def _capture(self, fn):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn()
-        return g
-
     def run(self):
         """plan.X / plan.y must hold the batch. After the call plan.prob / plan.loss hold this step's outputs.
         The first call runs eagerly (HIP graph capture needs warmed-up state and does not execute what it records);
         the second call captures, then every call replays.
 
-        With two streams the step is THREE single-stream graphs (front, side, tail) forked and joined with events at
-        replay time, not one graph with two branches: hipGraphLaunch of a multi-branch graph walks past the end of the
-        exec's parallel-stream vector when one of those streams shares a hardware queue with the launch stream
-        (hip::Graph::UpdateStreams, ROCm 7.0 runtime bundled with torch 2.10) -- a sporadic segfault that depends on
-        how many streams the process has created.  Single-branch graphs never enter that loop."""
-        if not self.use_graph or self.calls == 0:
-            self._body()
-        elif not self.overlap:
-            if self.g_fb is None:
-                torch.cuda.synchronize()
-                self.g_fb = self._capture(self._body)
-            self.g_fb.replay()
+        With two streams the step is THREE single-stream graph sequences (front, side, tail) forked and joined with
+        events at replay time, not one graph with two branches: hipGraphLaunch of a multi-branch graph walks past the
+        end of the exec's parallel-stream vector when one of those streams shares a hardware queue with the launch
+        stream (hip::Graph::UpdateStreams, ROCm 7.0 runtime bundled with torch 2.10) -- a sporadic segfault that
+        depends on how many streams the process has created.  Single-branch graphs never enter that loop."""
+        if self.use_graph and self.calls == 1:
+            torch.cuda.synchronize()
+            for seg in (self.front, self.sideq, self.tail):
+                seg.capture()
+            torch.cuda.synchronize()
+        self.front.run()
+        if not self.overlap:
+            self.tail.run()
+            self.sideq.run()
         else:
-            if self.g_fb is None:
-                torch.cuda.synchronize()
-                self.g_fb = self._capture(self._front)
-                self.g_side = self._capture(self._side)
-                self.g_tail = self._capture(self._tail)
-                torch.cuda.synchronize()
-            self.g_fb.replay()
-            self._forked(self.g_side.replay, self.g_tail.replay)
+            self._forked(self.sideq.run, self.tail.run)
         self.calls += 1
         self.opt.steps_done += 1
         self.opt.dirty = True
+        if self.par is not None:
+            self.par.dirty = True

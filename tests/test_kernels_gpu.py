@@ -661,3 +661,112 @@ def test_batchnorm_fwd_bwd(ops, B, n, act):
     pre = (z64 - rm1.cpu().numpy()) / np.sqrt(rv1.cpu().numpy().astype(np.float64) + 1e-5) * gamma + beta
     assert rel(y.cpu().numpy(), np.maximum(pre, 0) if act == "relu" else pre) < 1e-5
     assert torch.equal(rm, rm1) and torch.equal(rv, rv1) and int(nbt.item()) == 4
+
+
+# ---------------------------------------------------------------------------------------------- row-sharded tables
+@pytest.mark.parametrize("E,B", [(8, 4000), (16, 555), (5, 300)])
+def test_scatter_idx32_and_unique_idx32(ops, E, B):
+    """Native-index variants (owner side of row-sharded tables, vocabularies past 2^24)."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(4)
+    vocab = [3, 500, 30000]
+    F = len(vocab)
+    idx = np.stack([np.minimum((v ** rng.random(B)).astype(np.int64), v - 1) for v in vocab], 1).astype(np.int32)
+    d_out = rng.standard_normal((B, F * E)).astype(np.float32)
+    gt = [torch.zeros(v, E, device=dev()) for v in vocab]
+    seen = [torch.zeros((v + 31) // 32, dtype=torch.int32, device=dev()) for v in vocab]
+    rowbase = np.concatenate([[0], np.cumsum(vocab)]).tolist()
+    touched = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    count = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.scatter_bwd_idx32(gt, T(idx), T(d_out), seen=seen, rowbase=rowbase, touched=touched, touched_count=count)
+    for f, v in enumerate(vocab):
+        g = np.zeros((v, E), np.float64)
+        np.add.at(g, idx[:, f], d_out[:, f * E:(f + 1) * E].astype(np.float64))
+        assert rel(gt[f].cpu().numpy(), g) < 1e-5
+    want = np.sort(np.concatenate([np.unique(idx[:, f]) + rowbase[f] for f in range(F)]))
+    assert np.array_equal(np.sort(touched[:int(count.item())].cpu().numpy()), want)
+    # index-only pass
+    seen2 = [torch.zeros_like(s) for s in seen]
+    t2 = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    c2 = torch.zeros(1, dtype=torch.int32, device=dev())
+    lib = L.load()
+    ii = T(idx)
+    L.check(lib.mml_index_unique_idx32((L.i64 * F)(*vocab), F, E if E <= 16 else 16, ii.data_ptr(), ii.stride(0), B,
+                                       ops._ptr_array(seen2), (L.i64 * (F + 1))(*rowbase), t2.data_ptr(), c2.data_ptr(),
+                                       t2.numel(), None, ops._stream()), "mml_index_unique_idx32")
+    assert np.array_equal(np.sort(t2[:int(c2.item())].cpu().numpy()), want)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("E,nd,B", [(8, 0, 3000), (4, 3, 257), (6, 0, 100)])
+def test_route_expand_permute(ops, world, E, nd, B):
+    """Routing of a batch to row owners (csrc/shard.hip) against the host arithmetic of parallel.RowSharding: counts,
+    owner-grouped keys, positions; expansion of the returned rows == the plain gather (bit-exact); mml_rows_permute is
+    its inverse; shard <-> table conversion round-trips."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd.parallel import RowSharding
+    rng = np.random.default_rng(5)
+    vocab = [1, 2, 7, 100, 1000, 50000, 3]
+    F = len(vocab)
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    idx[0, :] = 0
+    idx[1, :] = np.array(vocab) - 1
+    X = np.concatenate([idx.astype(np.float32), rng.random((B, nd), dtype=np.float32)], 1)
+    tabs = [rng.standard_normal((v, E)).astype(np.float32) for v in vocab]
+    shs = [RowSharding(vocab, E, world, r) for r in range(world)]
+    sh = shs[0]
+    counts, keys, pos = ops.route(T(X), list(range(F)), vocab, sh.keybase, world)
+    counts, keys, pos = counts.cpu().numpy(), keys.cpu().numpy(), pos.cpu().numpy()
+    own = (idx + np.arange(F)[None, :]) % world
+    key = np.array(sh.keybase[:F])[None, :] + idx // world
+    assert np.array_equal(counts, np.bincount(own.ravel(), minlength=world))
+    off = np.concatenate([[0], np.cumsum(counts)])
+    assert np.array_equal(np.sort(pos.ravel()), np.arange(B * F))  # a permutation of the send layout
+    assert np.array_equal(keys[pos], key)
+    seg_of_pos = np.searchsorted(off, pos, side="right") - 1
+    assert np.array_equal(seg_of_pos, own)
+    # int32 index input gives the same routing
+    c2, k2, p2 = ops.route(T(idx.astype(np.int32)), list(range(F)), vocab, sh.keybase, world)
+    assert np.array_equal(c2.cpu().numpy(), counts)
+    assert np.array_equal(k2.cpu().numpy()[p2.cpu().numpy()], key)
+    # owners: shards of the tables, gather of the received keys, rows back in the same order
+    dt = [T(t) for t in tabs]
+    shards = [s.tables_to_shard(dt) for s in shs]
+    for r, s in enumerate(shs):  # shard layout == host arithmetic
+        ref = np.zeros((s.R, E), np.float32)
+        for f, v in enumerate(vocab):
+            rows = np.arange(s.first(f), v, world)
+            assert len(rows) == s.owned_rows(f)
+            ref[s.keybase[f]:s.keybase[f] + len(rows)] = tabs[f][rows]
+        assert np.array_equal(shards[r].cpu().numpy(), ref)
+    rows_recv = torch.empty(B * F, E, device=dev())
+    for r in range(world):
+        seg = torch.from_numpy(keys[off[r]:off[r + 1]].astype(np.int32)).to(dev()).view(-1, 1)
+        if seg.numel():
+            rows_recv[off[r]:off[r + 1]] = ops.gather_fwd_idx32([shards[r]], seg)
+    out = ops.gather_fwd_idx32([rows_recv] * F, T(pos.astype(np.int32)), T(X[:, F:].copy()) if nd else None)
+    ref = np.concatenate([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # inverse: pack per-sample gradient pieces into the send order
+    d_out = rng.standard_normal((B, F * E + nd)).astype(np.float32)
+    packed = torch.zeros(B * F, E, device=dev())
+    ops.rows_permute(T(d_out), T(pos.astype(np.int32)), E, packed)
+    want = np.zeros((B * F, E), np.float32)
+    want[pos.ravel()] = d_out[:, :F * E].reshape(B * F, E)
+    assert np.array_equal(packed.cpu().numpy(), want)
+    # shards -> tables round trip
+    back = [torch.full_like(t, float("nan")) for t in dt]
+    for r, s in enumerate(shs):
+        s.shard_to_tables(shards[r], back, rank=r)
+    for f in range(F):
+        assert torch.equal(back[f], dt[f])
+
+
+def test_route_out_of_range_sets_status(ops):
+    status = ops.new_status(dev())
+    X = torch.tensor([[3.0], [10.0], [-1.0]], device=dev())
+    counts, keys, pos = ops.route(X, [0], [10], [0, 5], 2, status=status)
+    assert int(counts.sum().item()) == 3
+    with pytest.raises(IndexError):
+        ops.check_status(status)

@@ -165,9 +165,11 @@ def test_fused_train_steps(case, graph):
         assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL), (kind, losses)
 
 
-def test_sharded_path_world1_matches_golden():
-    """The table-sharded execution path (pack -> all_to_all -> owner gather/scatter -> unpack) on a 1-rank RCCL group
-    must reproduce the unsharded golden trajectory."""
+@pytest.mark.parametrize("mode", ["row_sharded", "replicated", "table_wise"])
+def test_sharded_path_world1_matches_golden(mode):
+    """The multi-GPU execution paths (parallel.MODES) on a 1-rank RCCL group -- route / pack -> all_to_all or
+    all_gather -> owner gather / scatter -> unpack, with the exchange-free segments replayed from HIP graphs -- must
+    reproduce the unsharded golden trajectory."""
     import os
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -178,14 +180,17 @@ def test_sharded_path_world1_matches_golden():
         created = True
     try:
         from mmlrec_amd import parallel
+        combos = [("adam", "dense_exact", 3), ("adagrad", "sparse_rows", 3)]
+        if mode != "table_wise":
+            combos.append(("adam", "lazy_exact", 3))
         for case_name in ("mmoe_ae30d", "pepnet_amazon"):
             g = load_golden(case_name)
-            for kind, tu, ck in (("adam", "dense_exact", 3), ("adagrad", "sparse_rows", 3)):
+            for kind, tu, ck in combos:
                 model, cfg = build(g, table_update=tu)
                 load_state(model, g)
                 model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
                 model.train()
-                parallel.shard_model(model, dist, 64)
+                par = parallel.shard_model(model, dist, 64, mode=mode)
                 losses = []
                 for i in range(3):
                     step = model.train_step_runner(64)
@@ -193,8 +198,12 @@ def test_sharded_path_world1_matches_golden():
                     step.plan.y.copy_(torch.from_numpy(g[f"y{i}"]).cuda())
                     step.run()
                     losses.append(float(step.plan.loss.item()))
+                assert step.front.n_graphs + step.sideq.n_graphs + step.tail.n_graphs >= 2  # segments were captured
                 assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL), (case_name, kind, losses)
+                if mode == "row_sharded":
+                    assert par.dirty
                 sd = model.state_dict()
+                assert not par.dirty
                 lr = cfg["optim_config"]["lr"]
                 for k in sd:
                     ref = g[f"{kind}{ck}/{k}"].astype(np.float64)

@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the table-wise sharded exchange (parallel.FieldSharding): the SAME segment tables and
-split sizes the GPU op feeds to mml_copy_cols / all_to_all_single, executed here with torch copies on CPU and the
-oracle's gather/scatter as the owner-side compute.  Contract: N ranks on a batch split N ways == 1 rank on the whole
-batch."""
+"""world_size-2 gloo tests of the multi-GPU exchanges (parallel.py) without a GPU: the host-side layout arithmetic the
+GPU ops share (RowSharding: owner / key / shard layout; FieldSharding: segment tables and split sizes) drives the same
+collectives (parallel.Comm over gloo), with torch index ops standing in for the owner-side kernels.  Contract: N ranks
+on a batch split N ways == 1 rank on the whole batch.  The kernels themselves are compared with this
+arithmetic in tests/test_kernels_gpu.py::test_route_expand_permute and end to end in tests/test_parallel_gpu.py."""
 import os
 import socket
 
@@ -111,6 +112,116 @@ def test_sharded_exchange_matches_single_process():
         owners = owners or owner
         assert owner == owners  # every rank derives the same placement
     assert set(owners) == {0, 1}
+
+
+def _row_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd.parallel import Comm, RowSharding
+    comm = Comm(dist)
+    F = len(VOCAB)
+    sh = RowSharding(VOCAB, E, world, rank)
+    tabs = _tables()
+    # this rank's flat shard, by the host arithmetic (the device version is mml_shard_rows)
+    shard = torch.zeros(sh.R, E)
+    for f, v in enumerate(VOCAB):
+        rows = torch.arange(sh.first(f), v, world)
+        assert len(rows) == sh.owned_rows(f)
+        shard[sh.keybase[f]:sh.keybase[f] + len(rows)] = tabs[f][rows]
+    X, d_out = _batch(rank)
+    idx = X[:, :F].long()
+    own = (idx + torch.arange(F)) % world
+    key = torch.tensor(sh.keybase[:F]) + idx // world
+    # route: keys grouped by owner (stable order here; the kernel's order inside a segment is unspecified)
+    order = torch.argsort(own.reshape(-1), stable=True)
+    send_keys = key.reshape(-1)[order].int()
+    pos = torch.empty(B * F, dtype=torch.long)
+    pos[order] = torch.arange(B * F)
+    send_cnt = torch.bincount(own.reshape(-1), minlength=world).int()
+    recv_cnt = torch.zeros(world, dtype=torch.int32)
+    comm.all_to_all_single(recv_cnt, send_cnt)
+    ss, rs = send_cnt.tolist(), recv_cnt.tolist()
+    recv_keys = torch.zeros(sum(rs), dtype=torch.int32)
+    comm.all_to_all_single(recv_keys, send_keys, rs, ss)
+    rows_send = shard[recv_keys.long()].reshape(-1).contiguous()       # owner gather
+    rows_recv = torch.zeros(B * F * E)
+    comm.all_to_all_single(rows_recv, rows_send, [c * E for c in ss], [c * E for c in rs])
+    out = torch.cat([rows_recv.view(B * F, E)[pos].view(B, F * E), X[:, F:]], 1)   # expand
+    ref = torch.cat([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
+    ok_fwd = bool(torch.equal(out, ref))
+    # backward: pack -> exchange -> owner scatter into the flat shard gradient
+    grad_send = torch.zeros(B * F, E)
+    grad_send[pos] = d_out[:, :F * E].reshape(B * F, E)
+    grad_recv = torch.zeros(sum(rs) * E)
+    comm.all_to_all_single(grad_recv, grad_send.reshape(-1), [c * E for c in rs], [c * E for c in ss])
+    gshard = torch.zeros(sh.R, E, dtype=torch.float64)
+    gshard.index_add_(0, recv_keys.long(), grad_recv.view(-1, E).double())
+    ok_bwd = True
+    for f, v in enumerate(VOCAB):
+        want = torch.zeros(v, E, dtype=torch.float64)
+        for r in range(world):  # one process over the concatenated batch
+            Xr, dr = _batch(r)
+            want.index_add_(0, Xr[:, f].long(), dr[:, f * E:(f + 1) * E].double())
+        rows = torch.arange(sh.first(f), v, world)
+        got = gshard[sh.keybase[f]:sh.keybase[f] + len(rows)]
+        ok_bwd = ok_bwd and bool(torch.allclose(got, want[rows], atol=1e-12))
+        pad = gshard[sh.keybase[f] + len(rows):sh.keybase[f + 1]]
+        ok_bwd = ok_bwd and bool((pad == 0).all())                      # padding rows never receive anything
+    # shards -> full tables on every rank (sync_tables): all-gather + inverse layout
+    allsh = torch.zeros(world, sh.R, E)
+    comm.all_gather_into_tensor(allsh, shard)
+    ok_sync = True
+    for f, v in enumerate(VOCAB):
+        full = torch.full((v, E), float("nan"))
+        for k in range(world):
+            rows = torch.arange(sh.first(f, k), v, world)
+            full[rows] = allsh[k, sh.keybase[f]:sh.keybase[f] + len(rows)]
+        ok_sync = ok_sync and bool(torch.equal(full, tabs[f]))
+    ret[rank] = (ok_fwd, ok_bwd, ok_sync, ss)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_row_sharded_exchange_matches_single_process():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_row_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        ok_fwd, ok_bwd, ok_sync, ss = ret[r]
+        assert ok_fwd, f"rank {r}: row-sharded forward exchange != local gather"
+        assert ok_bwd, f"rank {r}: owner-side scatter != single-process scatter restricted to the owned rows"
+        assert ok_sync, f"rank {r}: all-gathered shards do not rebuild the tables"
+        assert sum(ss) == B * len(VOCAB)
+
+
+def test_row_sharding_balances_rows_and_lookups():
+    """Dense-Adam rows per rank within +-5 % at N = 2 / 4 / 8, every row owned exactly once, and the
+    rotation by the field number keeps the Zipf heads of the 30 AE-30 fields off a single rank."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd.parallel import RowSharding
+    from mmlrec_amd.workloads import AE30_VOCAB, synth_batch
+    F = len(AE30_VOCAB)
+    for world in (1, 2, 4, 8):
+        shs = [RowSharding(AE30_VOCAB, 8, world, r) for r in range(world)]
+        for f, v in enumerate(AE30_VOCAB):
+            assert sum(s.owned_rows(f) for s in shs) == v
+        real = [sum(s.owned_rows(f) for f in range(F)) for s in shs]
+        mean = sum(AE30_VOCAB) / world
+        assert all(abs(r - mean) <= 0.05 * mean for r in real), (world, real)
+        assert all(s.R == shs[0].R for s in shs) and shs[0].R - mean <= F  # at most one padding row per field
+        if world > 1:
+            X, _ = synth_batch(AE30_VOCAB, 0, 4096, 2, seed=1)
+            own = (X.long() + torch.arange(F)) % world
+            cnt = torch.bincount(own.reshape(-1), minlength=world).double()
+            assert cnt.max() / cnt.mean() < 1.5, (world, cnt.tolist())
+            naive = torch.bincount((X.long() % world).reshape(-1), minlength=world).double()
+            assert cnt.max() <= naive.max()  # the plain r mod N rule piles every field's head on rank 0
 
 
 def test_field_sharding_balances_rows_and_lookups():
