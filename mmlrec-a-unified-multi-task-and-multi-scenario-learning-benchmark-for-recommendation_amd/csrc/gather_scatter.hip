@@ -9,6 +9,8 @@
 // atomics into dense [V,E] accumulators, shaped as E contiguous floats per row per wave-instruction.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace mml {
 
 struct FieldTable {
@@ -282,6 +284,237 @@ __global__ __launch_bounds__(256) void scatter_hash_kernel(const FieldTable ft, 
   if (bad && a.status) atomicOr(a.status, bad);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2, restructured (round 2).  Same idea as scatter_hash_kernel -- fold the duplicate rows of a sample chunk in LDS,
+// then E contiguous float atomics per distinct row -- rebuilt around what the MI355X measurements said
+// (tools/lab/micro/lds_atomic.hip, per wave-instruction and CU):  ds_add_f32 = 195 cycles whatever the address
+// pattern, ds_add_u64 = 15, ds_add_u32 = 9, ds_cmpst_rtn_b32 = 15; a same-address integer atomic costs ~4 cycles per
+// lane.  The fp32 LDS atomics were 94 us of the old kernel's 168 us, the single-address "occupied slots" counter
+// most of another 54 us.  So:
+//   * the duplicates of a chunk are summed in 64-bit FIXED POINT with integer LDS atomics: every gradient value is
+//     scaled by 2^(178 - emax), emax = the largest exponent the workgroup holds for this field, so the largest values
+//     keep their 24 mantissa bits 28 bits above the unit and 11 bits of headroom are left for 2048 addends.  Values
+//     down to 2^-28 of the largest are summed EXACTLY, smaller ones are rounded to 2^-52 of the largest -- the
+//     chunk sum is at least as accurate as an fp32 accumulation of the same rows, and independent of the order;
+//   * a lane owns one 16-byte piece of a gradient row (E/4 lanes per sample) and issues the index and gradient loads
+//     of ALL its samples before the first LDS operation (the old loop chained 16 dependent load -> LDS steps);
+//   * the occupied slots are listed with ONE counter atomic per wave (ballot), and the flush walks that list instead
+//     of all SLOTS x E cells;
+//   * tables with V <= SLOTS rows are direct-mapped (slot = row: no compare-and-swap, no probing) and one workgroup
+//     folds kDirectReps chunks before it flushes.
+// LDS accumulators are plane-major, acc[e][slot] with a (SLOTS + 1) pitch: the lanes of an insert differ in slot
+// (random banks) and the lanes of a flush in e (consecutive banks).
+// ------------------------------------------------------------------------------------------------
+struct ScatterPlan {
+  int32_t reps[MML_MAX_FIELDS];          // chunks folded per workgroup (direct-mapped fields: kDirectReps, others 1)
+  int32_t grp_base[MML_MAX_FIELDS + 1];  // prefix sum of per-field group counts (per XCD slot)
+};
+constexpr int kDirectReps = 4;
+
+__device__ __forceinline__ long long to_fixed(float x, int emax) {
+  const unsigned u = __float_as_uint(x);
+  int e = (int)((u >> 23) & 0xffu);
+  unsigned m = u & 0x7fffffu;
+  if (e) m |= 0x800000u; else e = 1;  // subnormal
+  const int sh = e - emax + 28;       // <= 28: x = m * 2^(e - 150) in units of 2^(emax - 178)
+  long long v;
+  if (sh >= 0) v = (long long)m << sh;
+  else if (sh > -25) v = ((long long)m + (1ll << (-sh - 1))) >> (-sh);
+  else v = 0;
+  return (u >> 31) ? -v : v;
+}
+
+__device__ __forceinline__ float from_fixed(long long v, int emax) {
+  return (float)ldexp((double)v, emax - 178);  // int64 -> f64 is exact below 2^53 and rounds once above; one rounding to f32
+}
+
+template <int SLOTS, int E>
+__global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, const ScatterArgs a,
+                                                           const ScatterPlan sp) {
+  constexpr int LPS = E / 4;                   // lanes per sample
+  constexpr int CHUNK = SLOTS / 2;             // samples per chunk (hash load factor <= 0.5)
+  constexpr int PER_PASS = 256 / LPS;          // samples per pass of the workgroup
+  constexpr int PASSES = CHUNK / PER_PASS;
+  constexpr int PITCH = SLOTS + 1;
+  extern __shared__ __attribute__((aligned(16))) long long smem64[];
+  long long* acc = smem64;                                   // [E][PITCH] fixed-point sums
+  int* keys = reinterpret_cast<int*>(acc + E * PITCH);       // [SLOTS]
+  unsigned short* occ = reinterpret_cast<unsigned short*>(keys + SLOTS);  // [SLOTS] occupied slots, first-claim order
+  int* newrows = reinterpret_cast<int*>(occ + SLOTS);        // [SLOTS] only when a.touched != null
+  __shared__ int n_occ, n_new, base_out;
+  __shared__ unsigned mx_bits;
+  // chunk group from the XCD slot, field from the position inside the XCD (see scatter_hash_kernel)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  int f = 0;
+  while (f + 1 < a.F && j >= sp.grp_base[f + 1]) ++f;
+  const int q = j - sp.grp_base[f];
+  const int reps = sp.reps[f];
+  const int64_t V = ft.vocab[f];
+  const bool direct = reps > 1;
+  const int64_t nchunks = (a.B + CHUNK - 1) / CHUNK;
+  if ((int64_t)xcd + 8 * (int64_t)q * reps >= nchunks) return;
+  const int colf = ft.col[f];
+  const int part = threadIdx.x % LPS;
+  const int s_in = threadIdx.x / LPS;
+  const int lane = threadIdx.x & 63;
+  int bad = 0;
+  // ---- every load of this lane in flight before the first LDS operation
+  int rows[kDirectReps][PASSES];
+  float4 g[kDirectReps][PASSES];
+  unsigned mx = 0;
+#pragma unroll
+  for (int r = 0; r < kDirectReps; ++r) {
+    const int64_t c = xcd + 8 * ((int64_t)q * reps + r);
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      rows[r][k] = -1;
+      g[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t b = c * CHUNK + k * PER_PASS + s_in;
+      if (r < reps && c < nchunks && b < a.B) {
+        const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + colf];
+        if (row < 0) bad |= 1;
+        else if (row >= V) bad |= 2;
+        else {
+          rows[r][k] = (int)row;
+          if (a.dOut) g[r][k] = *reinterpret_cast<const float4*>(a.dOut + b * a.ldo + f * E + part * 4);
+        }
+      }
+    }
+  }
+  if (a.dOut)
+    for (int i = threadIdx.x; i < E * PITCH / 2; i += 256)
+      *reinterpret_cast<float4*>(acc + i * 2) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < SLOTS; i += 256) keys[i] = -1;
+  if (threadIdx.x == 0) { n_occ = 0; n_new = 0; mx_bits = 0; }
+  __syncthreads();
+  if (a.dOut) {  // largest magnitude (as bit pattern) of the workgroup's gradient values -> the fixed-point scale
+#pragma unroll
+    for (int r = 0; r < kDirectReps; ++r)
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const unsigned m0 = __float_as_uint(g[r][k].x) & 0x7fffffffu, m1 = __float_as_uint(g[r][k].y) & 0x7fffffffu;
+        const unsigned m2 = __float_as_uint(g[r][k].z) & 0x7fffffffu, m3 = __float_as_uint(g[r][k].w) & 0x7fffffffu;
+        mx = max(mx, max(max(m0, m1), max(m2, m3)));
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if (lane == 0) atomicMax(&mx_bits, mx);
+    __syncthreads();
+  }
+  int emax = (int)(mx_bits >> 23);
+  emax = emax < 1 ? 1 : (emax > 254 ? 254 : emax);
+  // ---- insert
+#pragma unroll
+  for (int r = 0; r < kDirectReps; ++r) {
+    if (r >= reps) break;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int key = rows[r][k];
+      unsigned slot = 0;
+      bool is_new = false;
+      if (direct) {
+        if (key >= 0) {
+          slot = (unsigned)key;
+          if (part == 0 && keys[slot] != key) keys[slot] = key;  // racing writers store the same value
+        }
+      } else {
+        if (key >= 0 && part == 0) {  // one lane per sample claims the slot ...
+          slot = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
+          while (true) {
+            const int old = atomicCAS(&keys[slot], -1, key);
+            if (old == -1) { is_new = true; break; }
+            if (old == key) break;
+            slot = (slot + 1) & (SLOTS - 1);
+          }
+        }
+        // new slots of this wave join the occupied list with ONE counter atomic
+        const unsigned long long nm = __ballot(is_new);
+        if (nm) {
+          const int leader = __ffsll((long long)nm) - 1;
+          int base = 0;
+          if (lane == leader) base = atomicAdd(&n_occ, __popcll(nm));
+          base = __shfl(base, leader);
+          if (is_new) occ[base + __popcll(nm & ((1ull << lane) - 1ull))] = (unsigned short)slot;
+        }
+        if (LPS > 1) slot = (unsigned)__shfl((int)slot, lane & ~(LPS - 1));  // ... its lanes follow
+      }
+      if (a.dOut && key >= 0) {
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(acc) + (part * 4) * PITCH + slot;
+        atomicAdd(p, (unsigned long long)to_fixed(g[r][k].x, emax));
+        atomicAdd(p + PITCH, (unsigned long long)to_fixed(g[r][k].y, emax));
+        atomicAdd(p + 2 * PITCH, (unsigned long long)to_fixed(g[r][k].z, emax));
+        atomicAdd(p + 3 * PITCH, (unsigned long long)to_fixed(g[r][k].w, emax));
+      }
+    }
+  }
+  __syncthreads();
+  float* gt = a.gtab[f];
+  const int n_items = (direct ? (int)V : n_occ) * E;
+  for (int item = threadIdx.x; item < n_items; item += 256) {
+    const int i = item / E, e = item - i * E;
+    const int slot = direct ? i : (int)occ[i];
+    const int key = keys[slot];
+    if (key < 0) continue;  // (direct-mapped: a row no sample of these chunks touched)
+    if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
+    if (a.touched && e == 0) {
+      const uint32_t bit = 1u << (key & 31);
+      const uint32_t old = atomicOr(a.seen[f] + (key >> 5), bit);
+      if (!(old & bit)) newrows[atomicAdd(&n_new, 1)] = key;
+    }
+  }
+  if (a.touched) {  // ONE counter atomic per workgroup for the rows this launch sees for the first time
+    __syncthreads();
+    if (threadIdx.x == 0) base_out = n_new ? atomicAdd(a.touched_count, n_new) : 0;
+    __syncthreads();
+    const int base = base_out;
+    for (int i = threadIdx.x; i < n_new; i += 256)
+      if (base + i < a.touched_cap) a.touched[base + i] = (int32_t)(a.rowbase[f] + newrows[i]);
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+template <int SLOTS, int E>
+static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
+  constexpr int CHUNK = SLOTS / 2;
+  ScatterPlan sp{};
+  const int64_t nchunks = cdiv(a.B, (int64_t)CHUNK);
+  const int64_t per_xcd = cdiv(nchunks, 8);
+  int64_t total = 0;
+  for (int f = 0; f < a.F; ++f) {
+    sp.reps[f] = (ft.vocab[f] <= SLOTS) ? kDirectReps : 1;
+    sp.grp_base[f] = (int32_t)total;
+    total += cdiv(per_xcd, sp.reps[f]);
+  }
+  sp.grp_base[a.F] = (int32_t)total;
+  if (total * 8 > 0x7fffffff) return 1;  // caller falls back
+  const size_t lds = (size_t)E * (SLOTS + 1) * 8 + (size_t)SLOTS * 4 + (size_t)SLOTS * 2 +
+                     (a.touched ? (size_t)SLOTS * 4 : 0);
+  static bool attr_set = false;  // more than the 64 KiB a kernel may use by default
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (e != hipSuccess) {
+      set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+      return MML_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  MML_LAUNCH((scatter_fold_kernel<SLOTS, E>), dim3((unsigned)(total * 8)), dim3(256), lds, stream, ft, a, sp);
+  return check_launch(who);
+}
+
+// E in {4, 8, 16}, 16-byte aligned gradient rows: the restructured kernel; returns 1 when the shape is not covered
+static int try_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
+  if (a.dOut && (a.ldo % 4 != 0 || !aligned16(a.dOut))) return 1;
+  for (int f = 0; f < a.F; ++f)
+    if (ft.vocab[f] > 0x7fffffff) return 1;
+  if (a.E == 8) return launch_fold<1024, 8>(ft, a, stream, who);
+  if (a.E == 4) return launch_fold<1024, 4>(ft, a, stream, who);
+  if (a.E == 16) return launch_fold<512, 16>(ft, a, stream, who);
+  return 1;
+}
+
 }  // namespace mml
 
 using namespace mml;
@@ -354,6 +587,10 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
   a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
   const int threads = 256;
+  if (!getenv("MMLREC_SCATTER_OLD")) {
+    rc = try_fold(ft, a, to_stream(stream), "mml_scatter_bwd");
+    if (rc <= 0) return rc;
+  }
   if (E <= 16) {
     // dynamic LDS stays under the 64 KiB default limit: SLOTS * (1 + E) * 4 bytes = 36 KiB (4 workgroups per CU)
     const int slots = (E <= 8) ? 1024 : 512;
@@ -412,6 +649,10 @@ static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int3
   }
   a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = nullptr; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
+  if (!getenv("MMLREC_SCATTER_OLD")) {
+    const int rc = try_fold(ft, a, to_stream(stream), "mml_index_unique");
+    if (rc <= 0) return rc;
+  }
   const int slots = (E <= 8) ? 1024 : 512;
   const int chunk = slots / 2;
   const int64_t nblocks = (int64_t)F * 8 * cdiv(cdiv(B, chunk), 8);  // 8 XCD slots x F fields x chunk groups
