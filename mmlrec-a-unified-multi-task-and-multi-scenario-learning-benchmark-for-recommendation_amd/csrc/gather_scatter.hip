@@ -310,7 +310,11 @@ struct ScatterPlan {
   int32_t reps[MML_MAX_FIELDS];          // chunks folded per workgroup (direct-mapped fields: kDirectReps, others 1)
   int32_t grp_base[MML_MAX_FIELDS + 1];  // prefix sum of per-field group counts (per XCD slot)
 };
+#ifdef MML_LAB_SC_REPS
+constexpr int kDirectReps = MML_LAB_SC_REPS;
+#else
 constexpr int kDirectReps = 4;
+#endif
 
 __device__ __forceinline__ long long to_fixed(float x, int emax) {
   const unsigned u = __float_as_uint(x);
@@ -329,12 +333,16 @@ __device__ __forceinline__ float from_fixed(long long v, int emax) {
   return (float)ldexp((double)v, emax - 178);  // int64 -> f64 is exact below 2^53 and rounds once above; one rounding to f32
 }
 
-template <int SLOTS, int E>
-__global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, const ScatterArgs a,
+// NT threads per workgroup: the insert is a chain of LDS round trips (claim -> list -> shuffle -> add), so the kernel
+// wants every wave slot of the CU: 2 workgroups x 1024 threads at 76 KiB of LDS each (256 threads: 98 us, 512: 89 us,
+// 1024: 83 us on Zipf AE-30, B = 65 536)
+template <int SLOTS, int E, int NT>
+__global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, const ScatterArgs a,
                                                            const ScatterPlan sp) {
   constexpr int LPS = E / 4;                   // lanes per sample
   constexpr int CHUNK = SLOTS / 2;             // samples per chunk (hash load factor <= 0.5)
-  constexpr int PER_PASS = 256 / LPS;          // samples per pass of the workgroup
+  constexpr int PER_PASS = NT / LPS;
+  static_assert(CHUNK % PER_PASS == 0 && CHUNK >= PER_PASS, "workgroup size does not divide the chunk");          // samples per pass of the workgroup
   constexpr int PASSES = CHUNK / PER_PASS;
   constexpr int PITCH = SLOTS + 1;
   extern __shared__ __attribute__((aligned(16))) long long smem64[];
@@ -372,23 +380,32 @@ __global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, 
       g[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int64_t b = c * CHUNK + k * PER_PASS + s_in;
       if (r < reps && c < nchunks && b < a.B) {
+        // (the gradient load must not wait for the index: both are issued back to back, validity is applied later)
+#ifndef MML_LAB_SC_NOLOAD
+        if (a.dOut) g[r][k] = *reinterpret_cast<const float4*>(a.dOut + b * a.ldo + f * E + part * 4);
+#endif
         const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + colf];
         if (row < 0) bad |= 1;
         else if (row >= V) bad |= 2;
-        else {
-          rows[r][k] = (int)row;
-          if (a.dOut) g[r][k] = *reinterpret_cast<const float4*>(a.dOut + b * a.ldo + f * E + part * 4);
-        }
+        else rows[r][k] = (int)row;
       }
     }
   }
+#ifndef MML_LAB_SC_NOINIT
   if (a.dOut)
-    for (int i = threadIdx.x; i < E * PITCH / 2; i += 256)
+#else
+  if (a.dOut && blockIdx.x == 0xfffffff)
+#endif
+    for (int i = threadIdx.x; i < E * PITCH / 2; i += NT)
       *reinterpret_cast<float4*>(acc + i * 2) = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = threadIdx.x; i < SLOTS; i += 256) keys[i] = -1;
+  for (int i = threadIdx.x; i < SLOTS; i += NT) keys[i] = -1;
   if (threadIdx.x == 0) { n_occ = 0; n_new = 0; mx_bits = 0; }
   __syncthreads();
+#ifdef MML_LAB_SC_NOMX
+  if (a.dOut && blockIdx.x == 0xfffffff) {
+#else
   if (a.dOut) {  // largest magnitude (as bit pattern) of the workgroup's gradient values -> the fixed-point scale
+#endif
 #pragma unroll
     for (int r = 0; r < kDirectReps; ++r)
 #pragma unroll
@@ -421,6 +438,9 @@ __global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, 
       } else {
         if (key >= 0 && part == 0) {  // one lane per sample claims the slot ...
           slot = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
+#ifdef MML_LAB_SC_NOCLAIM
+          if (false)
+#endif
           while (true) {
             const int old = atomicCAS(&keys[slot], -1, key);
             if (old == -1) { is_new = true; break; }
@@ -439,7 +459,11 @@ __global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, 
         }
         if (LPS > 1) slot = (unsigned)__shfl((int)slot, lane & ~(LPS - 1));  // ... its lanes follow
       }
+#ifdef MML_LAB_SC_NOLDS
+      if (a.dOut && key == -12345) {
+#else
       if (a.dOut && key >= 0) {
+#endif
         unsigned long long* p = reinterpret_cast<unsigned long long*>(acc) + (part * 4) * PITCH + slot;
         atomicAdd(p, (unsigned long long)to_fixed(g[r][k].x, emax));
         atomicAdd(p + PITCH, (unsigned long long)to_fixed(g[r][k].y, emax));
@@ -451,12 +475,16 @@ __global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, 
   __syncthreads();
   float* gt = a.gtab[f];
   const int n_items = (direct ? (int)V : n_occ) * E;
-  for (int item = threadIdx.x; item < n_items; item += 256) {
+  for (int item = threadIdx.x; item < n_items; item += NT) {
     const int i = item / E, e = item - i * E;
     const int slot = direct ? i : (int)occ[i];
     const int key = keys[slot];
     if (key < 0) continue;  // (direct-mapped: a row no sample of these chunks touched)
+#ifdef MML_LAB_SC_NOFLUSH
+    if (a.dOut && acc[e * PITCH + slot] == 12345) gt[(int64_t)key * E + e] = 1.f;
+#else
     if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
+#endif
     if (a.touched && e == 0) {
       const uint32_t bit = 1u << (key & 31);
       const uint32_t old = atomicOr(a.seen[f] + (key >> 5), bit);
@@ -468,13 +496,13 @@ __global__ __launch_bounds__(256) void scatter_fold_kernel(const FieldTable ft, 
     if (threadIdx.x == 0) base_out = n_new ? atomicAdd(a.touched_count, n_new) : 0;
     __syncthreads();
     const int base = base_out;
-    for (int i = threadIdx.x; i < n_new; i += 256)
+    for (int i = threadIdx.x; i < n_new; i += NT)
       if (base + i < a.touched_cap) a.touched[base + i] = (int32_t)(a.rowbase[f] + newrows[i]);
   }
   if (bad && a.status) atomicOr(a.status, bad);
 }
 
-template <int SLOTS, int E>
+template <int SLOTS, int E, int NT>
 static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
   constexpr int CHUNK = SLOTS / 2;
   ScatterPlan sp{};
@@ -492,7 +520,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
                      (a.touched ? (size_t)SLOTS * 4 : 0);
   static bool attr_set = false;  // more than the 64 KiB a kernel may use by default
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
@@ -500,7 +528,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
     }
     attr_set = true;
   }
-  MML_LAUNCH((scatter_fold_kernel<SLOTS, E>), dim3((unsigned)(total * 8)), dim3(256), lds, stream, ft, a, sp);
+  MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
   return check_launch(who);
 }
 
@@ -509,9 +537,9 @@ static int try_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stre
   if (a.dOut && (a.ldo % 4 != 0 || !aligned16(a.dOut))) return 1;
   for (int f = 0; f < a.F; ++f)
     if (ft.vocab[f] > 0x7fffffff) return 1;
-  if (a.E == 8) return launch_fold<1024, 8>(ft, a, stream, who);
-  if (a.E == 4) return launch_fold<1024, 4>(ft, a, stream, who);
-  if (a.E == 16) return launch_fold<512, 16>(ft, a, stream, who);
+  if (a.E == 8) return launch_fold<1024, 8, 1024>(ft, a, stream, who);
+  if (a.E == 4) return launch_fold<1024, 4, 512>(ft, a, stream, who);
+  if (a.E == 16) return launch_fold<512, 16, 1024>(ft, a, stream, who);
   return 1;
 }
 
