@@ -240,6 +240,11 @@ def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
     return "gemm<%s>" % ("fwd", "dgrad", "wgrad")[epi]
 
 
+def scatter_symbol(E):
+    """Kernel symbol of a scatter / index-unique launch (csrc/gather_scatter.hip: scatter_impl's choice)."""
+    return "scatter_fold_kernel" if E in (4, 8, 16) else ("scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel")
+
+
 def _opt_dense_symbol(numel, ntensors):
     """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: mml_opt_step_dense's choice)."""
     return "opt_dense_kernel<true>" if (numel >= (1 << 24) and ntensors <= 4) else "opt_flat_kernel"
@@ -310,7 +315,7 @@ class GatherOp(Op):
             extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
         else:
             extra = (None, None, None, None, 0)
-        meta = dict(kernel="scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel",
+        meta = dict(kernel=scatter_symbol(E),
                     bytes=float(plan.B) * F * (4 + 12 * E), tail=True)  # idx + grad read + row RMW
         return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
                                        self.out.grad.data_ptr(), ops._ld(self.out.grad)) + extra +
@@ -1212,7 +1217,7 @@ class Optimizer:
         return gop.pre_index_calls(plan) + [
             (lib.mml_index_unique, (vocab, col, F, E, X.data_ptr(), ops._ld(X), nrows, ps, rb,
                                     rows.touched.data_ptr(), rows.count.data_ptr(), rows.touched.numel(),
-                                    plan.status.data_ptr()), dict(kernel="scatter_hash_kernel(index_unique)")),
+                                    plan.status.data_ptr()), dict(kernel=scatter_symbol(E) + "(index_unique)")),
             catchup,
         ]
 

@@ -468,7 +468,7 @@ class ShardedGatherOp(E.Op):
             calls.append((lib.mml_scatter_bwd, (gt, vocab, col, nfm, Em, self.recv_idx.data_ptr(), nfm, W * B,
                                                 self.grad_recv.data_ptr(), nfm * Em) + extra +
                           (plan.status.data_ptr(),),
-                          dict(kernel="scatter_hash_kernel", bytes=float(W * B) * nfm * (4 + 12 * Em), tail=True)))
+                          dict(kernel=E.scatter_symbol(Em), bytes=float(W * B) * nfm * (4 + 12 * Em), tail=True)))
         return calls
 
 

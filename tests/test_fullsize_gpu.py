@@ -124,3 +124,75 @@ def test_full_size_fused_step_matches_oracle(W):
     mask[rows] = False
     assert np.array_equal(got0[mask], c0_before[mask])
     assert np.abs(got0[rows] - c0_before[rows]).max() > 0.5 * lr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one full-size fused step against the oracle for the other BASELINE.json configurations (the shrunken
+# goldens run single-tile GEMMs; these run the persistent multi-tile paths of the real shapes)
+# ---------------------------------------------------------------------------------------------------------------
+def _randomize(model, seed):
+    """He-scaled weights / 0.05-scaled tables drawn on the host and copied into the model (and its unregistered STAR
+    tensors), so that logits are far from the 0.5 the reference's 1e-4 init gives."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("embedding_dict."):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(p.device))
+            elif p.dim() == 2:
+                fan_in = p.shape[0] if (".shared_weight" in n or ".specific_weight" in n) else p.shape[1]
+                scale = (2.0 / fan_in) ** 0.5
+                if ".specific_weight" in n:  # multiplies the shared weight elementwise: keep the product He-scaled
+                    p.copy_((1.0 + 0.25 * torch.randn(p.shape, generator=g)).to(p.device))
+                else:
+                    p.copy_((torch.randn(p.shape, generator=g) * scale).to(p.device))
+            elif not n.startswith("out."):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(p.device))
+        frozen = {}
+        for pfx in ("linears", "final_layers"):
+            for li, mod in enumerate(getattr(model, pfx, [])):
+                if not hasattr(mod, "specific_weights"):
+                    continue
+                for d in range(len(mod.specific_weights) - 1):  # the last one IS the registered parameter
+                    w, b = mod.specific_weights[d], mod.specific_biases[d]
+                    w.data.copy_((1.0 + 0.25 * torch.randn(w.shape, generator=g)).to(w.device))
+                    b.data.copy_((torch.randn(b.shape, generator=g) * 0.05).to(b.device))
+                    frozen[f"{pfx}.{li}.specific_weights.{d}"] = w.detach().cpu().numpy().copy()
+                    frozen[f"{pfx}.{li}.specific_biases.{d}"] = b.detach().cpu().numpy().copy()
+    return frozen
+
+
+@pytest.mark.parametrize("workload,B", [("mmoe_kuairec", 8192), ("ple_ijcai", 8192), ("star_amazon", 8192),
+                                        ("pepnet_amazon", 8192)])
+def test_full_size_fused_step_other_configs(W, workload, B):
+    """KuaiRec-32 MMoE (E = 16, experts 512 -> 512 -> 256), Ijcai-7 PLE (2 levels), Amazon-8 STAR and PepNet at their
+    full vocabularies and widths: loss, every MLP tensor and every table after one fused step (the config's own
+    optimizer, dense-exact / exact-rows table update) against oracle/mmlrec_oracle.py on the same batch."""
+    from oracle import mmlrec_oracle as orc
+    model, cfg, vocab, dense = W.build_model(workload, dev())
+    frozen = _randomize(model, 11)
+    names = [f.name for f in model._sparse_cols()]
+    spec = orc.Spec(cfg, names, vocab, dense)
+    params = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    T = W.num_tasks(cfg)
+    X, y = W.synth_batch(vocab, len(dense), B, T, seed=22)
+    kind, lr = cfg["optim_config"]["optimizer"], cfg["optim_config"]["lr"]
+    model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
+    model.train()
+    step = model.train_step_runner(B, use_graph=False)
+    step.plan.X.copy_(X.to(dev()))
+    step.plan.y.copy_(y.to(dev()))
+    step.run()
+    loss_gpu = float(step.plan.loss.item())
+    opt = orc.DenseOptimizer(kind, lr)
+    before = {k: v.copy() for k, v in params.items()}
+    loss_ref = orc.train_step(spec, params, opt, X.numpy(), y.numpy(), frozen or None)
+    assert abs(loss_gpu - loss_ref) / loss_ref < 1e-4, (loss_gpu, loss_ref)
+    sd = model.state_dict()
+    moved = 0
+    for k, ref in params.items():
+        got = sd[k].cpu().numpy().astype(np.float64)
+        dv = np.abs(got - ref)
+        assert dv.max() <= 2.5 * lr, k
+        assert (dv > 1e-4 * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, k
+        moved += int(np.abs(ref - before[k]).max() > 0)
+    assert moved >= len(params) // 2  # the step really updated the model (tables + MLP tensors)

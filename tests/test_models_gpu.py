@@ -18,6 +18,16 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def elem_rel(a, b, floor=1e-5):
+    """Element-wise check next to the tensor-max-normalised `rel`: max over elements of
+    |a - b| / (1e-4 |b| + floor * max|b|) -- <= 1 means every element is within 1e-4 of ITS OWN reference value, up to
+    an absolute floor of `floor` times the tensor's scale (fp32 summation-order noise on elements that cancel)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    return (np.abs(a - b) / (RTOL * np.abs(b) + floor * scale)).max()
+
+
 def build(g, device="cuda:0", **model_kw):
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd.model import AITM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
@@ -89,6 +99,7 @@ def test_forward_layers_mask(case):
     with torch.no_grad():
         y = model(X)
     assert rel(y.cpu().numpy(), g["y_pred"]) < RTOL
+    assert elem_rel(y.cpu().numpy(), g["y_pred"]) <= 1.0  # every probability within 1e-4 of its own value
     lo = model.layer_output_dict
     assert np.array_equal(lo["dnn_input"].cpu().numpy(), g["dnn_input"])  # gather is bit-exact
     for k in g.files:
@@ -122,6 +133,8 @@ def test_autograd_gradients(case):
                 assert float(p.grad.abs().max()) < 1e-5 * gscale, n
                 continue
             assert rel(p.grad.cpu().numpy(), g["grad/" + n]) < RTOL, n
+            if n.startswith("embedding_dict."):  # table gradients: element-wise as well (north_star names them)
+                assert elem_rel(p.grad.cpu().numpy(), g["grad/" + n]) <= 1.0, n
         else:
             assert "nograd/" + n in g.files
             assert p.grad is None, n
@@ -237,6 +250,63 @@ def test_bf16_operand_mode_kuairec():
         rms = np.sqrt(np.mean((y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))
         assert rms < 2e-2, rms
         assert rms > 1e-6  # (the mode really is in effect)
+    finally:
+        lib.mml_gemm_set_mode(mode0)
+
+
+def test_bf16_operand_mode_gradients_and_trajectory_kuairec():
+    """The opt-in bf16-operand GEMM mode (MMLREC_GEMM_MODE=1) beyond the forward pass: gradients and a
+    3-step dense-Adam trajectory on the KuaiRec fixture against the reference's fp32 goldens.  Stated tolerances (bf16
+    operands carry 8 significant bits, 2^-9 relative per product; the fp32 path sits at 1e-6 on all of these):
+      * summed BCE of each of the 3 steps within 1e-3 relative;
+      * every gradient tensor within 0.15 relative rms (measured worst: 0.093 on a first-layer expert weight);
+      * after 3 Adam steps (lr-sized moves whose SIGN follows noise-level gradients) per tensor: mean |dp| <= 10 % of
+        the 3*lr a parameter can travel, at most 8 % of the elements off by more than one lr, none by more than 6*lr."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib
+    lib = _lib.load()
+    g = load_golden("mmoe_kuairec")
+    mode0 = lib.mml_gemm_get_mode()
+    try:
+        lib.mml_gemm_set_mode(1)
+        model, cfg = build(g)
+        load_state(model, g)
+        model.train()
+        X = torch.from_numpy(g["X0"]).cuda()
+        y = torch.from_numpy(g["y0"]).cuda()
+        yp = model(X)
+        loss = sum(torch.nn.functional.binary_cross_entropy(yp[:, i], y[:, i], reduction="sum")
+                   for i in range(yp.shape[1]))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if "grad/" + n in g.files:
+                ref = g["grad/" + n].astype(np.float64)
+                got = p.grad.cpu().numpy().astype(np.float64)
+                r = np.sqrt(np.mean((got - ref) ** 2)) / max(np.sqrt(np.mean(ref ** 2)), 1e-30)
+                assert r < 0.15, (n, r)
+                worst = max(worst, r)
+        assert worst > 1e-5  # (the reduced-precision mode really is in effect)
+        model, cfg = build(g, table_update="dense_exact")
+        load_state(model, g)
+        model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+        model.train()
+        lr = cfg["optim_config"]["lr"]
+        losses = []
+        for i in range(3):
+            step = model.train_step_runner(64, use_graph=False)
+            step.plan.X.copy_(torch.from_numpy(g[f"X{i}"]).cuda())
+            step.plan.y.copy_(torch.from_numpy(g[f"y{i}"]).cuda())
+            step.run()
+            losses.append(float(step.plan.loss.item()))
+        assert np.allclose(losses, g["adam_losses"], rtol=1e-3), losses
+        sd = model.state_dict()
+        for k in sd:
+            dv = np.abs(sd[k].cpu().numpy().astype(np.float64) - g[f"adam3/{k}"].astype(np.float64))
+            assert dv.mean() <= 0.10 * 3 * lr, (k, dv.mean())
+            assert (dv > lr).mean() <= 0.08, (k, (dv > lr).mean())
+            assert dv.max() <= 6 * lr, (k, dv.max())
     finally:
         lib.mml_gemm_set_mode(mode0)
 
