@@ -424,6 +424,9 @@ typedef struct {
   float* state1;                   /* Adam m | Adagrad sum | RMSprop square_avg | SGD unused (NULL) */
   float* state2;                   /* Adam v | others NULL                                          */
   int64_t n;
+  /* regulariser of this tensor (BaseModel.get_regularization_loss, model/basemodel.py:524-540: total_loss +=
+   * sum(l1 |p|) + sum(l2 p^2)): the update sees grad + l1 * sign(p) + 2 * l2 * p.  0 = none. */
+  float l1, l2;
 } mml_opt_tensor;
 typedef struct {
   int32_t kind;      /* MML_OPT_* */

@@ -62,7 +62,8 @@ class HeadGroup(C.Structure):
 
 
 class OptTensor(C.Structure):
-    _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64)]
+    _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64), ("l1", C.c_float),
+                ("l2", C.c_float)]
 
 
 class Copy2dDesc(C.Structure):

@@ -65,6 +65,13 @@ __device__ __forceinline__ void opt_update(const mml_opt_hyper& h, const StepCon
   }
 }
 
+// Gradient of the regulariser folded into the update (model/basemodel.py:524-540): d/dp [l1 |p| + l2 p^2].
+__device__ __forceinline__ float reg_grad(float g, float p, float l1, float l2) {
+  if (l2 != 0.f) g += (2.f * l2) * p;
+  if (l1 != 0.f) g += l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));
+  return g;
+}
+
 // blockIdx.y = tensor, blockIdx.x strides over that tensor in float4 chunks.
 // STREAM only names the launch (profilers see two symbols): true = a launch that streams >= 2^24 parameters through
 // HBM (the dense table update), false = everything else (MLP parameters, small tables).  Same code.
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float* gw = const_cast<float*>(T.grad);
+  const bool reg = T.l1 != 0.f || T.l2 != 0.f;
   if (vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const bool nt = (L.variant & 1) != 0;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float pe = p[e], ae = a[e], be = b[e];
-        opt_update(h, c, pe, g[e], ae, be);
+        opt_update(h, c, pe, reg ? reg_grad(g[e], pe, T.l1, T.l2) : g[e], ae, be);
         p[e] = pe;
         a[e] = ae;
         b[e] = be;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   const int64_t tail0 = vec ? (n4 << 2) : 0;
   for (int64_t i = tail0 + tid; i < T.n; i += stride) {
     float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
-    opt_update(h, c, p, T.grad[i], a, b);
+    opt_update(h, c, p, reg_grad(T.grad[i], p, T.l1, T.l2), a, b);
     T.param[i] = p;
     if (T.state1) T.state1[i] = a;
     if (T.state2) T.state2[i] = b;
@@ -175,10 +183,10 @@ __global__ __launch_bounds__(256) void opt_flat_kernel(const OptLaunch L) {
       const float4 g = *reinterpret_cast<const float4*>(T.grad + e0);
       float4 a = T.state1 ? *reinterpret_cast<float4*>(T.state1 + e0) : make_float4(0, 0, 0, 0);
       float4 b = T.state2 ? *reinterpret_cast<float4*>(T.state2 + e0) : make_float4(0, 0, 0, 0);
-      opt_update(h, c, p.x, g.x, a.x, b.x);
-      opt_update(h, c, p.y, g.y, a.y, b.y);
-      opt_update(h, c, p.z, g.z, a.z, b.z);
-      opt_update(h, c, p.w, g.w, a.w, b.w);
+      opt_update(h, c, p.x, reg_grad(g.x, p.x, T.l1, T.l2), a.x, b.x);
+      opt_update(h, c, p.y, reg_grad(g.y, p.y, T.l1, T.l2), a.y, b.y);
+      opt_update(h, c, p.z, reg_grad(g.z, p.z, T.l1, T.l2), a.z, b.z);
+      opt_update(h, c, p.w, reg_grad(g.w, p.w, T.l1, T.l2), a.w, b.w);
       *reinterpret_cast<float4*>(T.param + e0) = p;
       if (T.state1) *reinterpret_cast<float4*>(T.state1 + e0) = a;
       if (T.state2) *reinterpret_cast<float4*>(T.state2 + e0) = b;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void opt_flat_kernel(const OptLaunch L) {
       for (int64_t i = e0; i < e0 + 4 && i < T.n; ++i) {
         float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
         const float g = T.grad[i];
-        opt_update(h, c, p, g, a, b);
+        opt_update(h, c, p, reg_grad(g, p, T.l1, T.l2), a, b);
         T.param[i] = p;
         if (T.state1) T.state1[i] = a;
         if (T.state2) T.state2[i] = b;

@@ -1093,6 +1093,8 @@ class Optimizer:
             raise NotImplementedError(kind)  # model/basemodel.py:581
         if table_update == "auto":
             table_update = "sparse_rows" if kind in ("sgd", "adagrad") else "dense_exact"
+            if self._table_reg(self._reg_map()):  # a regulariser on the tables moves every row every step
+                table_update = "dense_exact"
         if table_update == "lazy_exact" and kind in ("sgd", "adagrad"):
             table_update = "sparse_rows"  # nothing to replay: zero gradients do not move these optimizers
         if table_update not in ("dense_exact", "sparse_rows", "lazy_exact"):
@@ -1119,10 +1121,18 @@ class Optimizer:
         if self.table_update == "lazy_exact":
             pre += self._lazy_pre_calls(plan)
         calls = []
-        dense = [(pv, n) for n, pv in st.pvals.items() if not pv.is_table and pv.written]
-        entries = [(pv.data, pv.grad) + self.state[n] for pv, n in dense]
+        reg = self._reg_map()
+        # (a regularised parameter is updated even when no gradient reaches it -- the reference's dead PLE tensors,
+        # its arena slice stays zero, the update sees the regulariser's gradient alone)
+        dense = [(pv, n) for n, pv in st.pvals.items()
+                 if not pv.is_table and pv.grad is not None and (pv.written or pv.data.data_ptr() in reg)]
+        entries = [(pv.data, pv.grad) + self.state[n] + (reg.get(pv.data.data_ptr()),) for pv, n in dense]
         tabs = [st.pvals[n] for n in st.table_names if st.pvals[n].written]
         tnames = [n for n in st.table_names if st.pvals[n].written]
+        treg = self._table_reg(reg)
+        if treg and self.table_update != "dense_exact":
+            raise NotImplementedError("l2_reg_embedding / l1 on the tables makes every row's gradient non-zero: use "
+                                      "table_update='dense_exact' (the reference's own dense optimizer)")
         hyper = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=False)
         plan.keep.append(hyper)
         if entries:
@@ -1148,7 +1158,8 @@ class Optimizer:
                 small = [i for i in range(len(tabs)) if i not in big]
                 groups = [g_ for g_ in (big, small) if g_]
                 for grp in groups:
-                    arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] for i in grp])
+                    arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] + (treg,)
+                                                for i in grp])
                     plan.keep.append(arr)
                     numel = sum(tabs[i].data.numel() for i in grp)
                     calls.append((lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
@@ -1172,6 +1183,29 @@ class Optimizer:
                                                       C.byref(hyper)), dict(kernel="opt_rows_kernel")))
                 calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
         return {"pre": pre, "mlp": mlp_calls, "tables": calls}
+
+    # ---- regulariser (model/basemodel.py:524-540) ---------------------------------------------------------
+    def _reg_map(self):
+        """data_ptr -> (l1, l2) summed over the groups the model registered with add_regularization_weight."""
+        out = {}
+        for weight_list, l1, l2 in getattr(self.store.model, "regularization_weight", []):
+            if not (l1 > 0 or l2 > 0):
+                continue
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                a, b = out.get(p.data_ptr(), (0.0, 0.0))
+                out[p.data_ptr()] = (a + float(l1), b + float(l2))
+        return out
+
+    def _table_reg(self, reg):
+        """(l1, l2) of the embedding tables (one setting for all of them: l2_reg_embedding), or None."""
+        vals = {reg[p.data_ptr()] for n, p in self.store.model.named_parameters()
+                if n.startswith("embedding_dict.") and p.data_ptr() in reg}
+        if not vals:
+            return None
+        if len(vals) > 1:
+            raise NotImplementedError("different regularisers on different embedding tables")
+        return vals.pop()
 
     # ---- lazy_exact ----------------------------------------------------------------------------------
     def _lazy_pre_calls(self, plan):

@@ -440,9 +440,6 @@ class BaseModel(nn.Module):
         steps with the same batch sizes; `batch_size` is per rank (global batch = world * batch_size).  Loss and the
         per-step train metrics in the epoch log are averaged over ranks; validation runs on every rank (identical
         results), on the synchronised tables."""
-        if self._has_regularization():
-            raise NotImplementedError("non-zero l1/l2 regularisation is not in the fused step yet (every shipped "
-                                      "config sets l2_reg_* = 0)")
         X_all = self._as_matrix(x)
         n = X_all.shape[0]
         y = np.asarray(y, dtype=np.float32).reshape(n, self.num_tasks)

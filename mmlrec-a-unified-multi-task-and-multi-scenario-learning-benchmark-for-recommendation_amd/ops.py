@@ -368,10 +368,12 @@ def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False):
 
 
 def make_opt_tensors(entries):
-    """entries: (param, grad, state1 or None, state2 or None) with equal element counts, contiguous."""
+    """entries: (param, grad, state1 or None, state2 or None[, (l1, l2)]) with equal element counts, contiguous."""
     arr = (L.OptTensor * len(entries))()
-    for d, (p, g, s1, s2) in zip(arr, entries):
+    for d, ent in zip(arr, entries):
+        p, g, s1, s2 = ent[:4]
         d.param, d.grad, d.state1, d.state2, d.n = p.data_ptr(), g.data_ptr(), L.ptr(s1), L.ptr(s2), p.numel()
+        d.l1, d.l2 = ent[4] if len(ent) > 4 and ent[4] else (0.0, 0.0)
     return arr
 
 

@@ -1063,9 +1063,43 @@ class DenseOptimizer:
                 raise NotImplementedError(self.kind)  # basemodel.py:581
 
 
-def train_step(spec, params, opt, X, y, frozen=None):
-    """basemodel.py:268-313: forward, summed BCE, backward, dense optimizer step. Returns the loss."""
+def reg_map(spec, params):
+    """name -> (l1, l2) as the reference registers them (basemodel.py:129-130 for the tables; for sharedbottom / mmoe /
+    ple every sub-network's `'weight' in name and 'bn' not in name` parameters get l2_reg_dnn: sharedbottom.py:36-47,
+    mmoe.py:36-62, ple.py:57-103 -- including PLE's dead last-level shared-gate tensors).  The key
+    defaults are the reference's: 1e-5 for the tables when the key is absent, 0 for the DNNs."""
+    if spec.model_name not in ("sharedbottom", "mmoe", "pcg", "ple"):
+        raise NotImplementedError("reg_map restates sharedbottom / mmoe / ple only")
+    l2e, l2d = spec.mc.get("l2_reg_embedding", 1e-5), spec.mc.get("l2_reg_dnn", 0)
+    out = {}
+    for k in params:
+        if k.startswith("embedding_dict."):
+            if l2e > 0:
+                out[k] = (0.0, float(l2e))
+        elif "weight" in k and "bn" not in k and l2d > 0:
+            out[k] = (0.0, float(l2d))
+    return out
+
+
+def add_reg_grads(params, grads, reg):
+    """d/dp [l1 |p| + l2 p^2] added to (or creating) each regularised parameter's gradient (basemodel.py:524-540)."""
+    for k, (l1, l2) in reg.items():
+        p = params[k]
+        g = np.zeros_like(p)
+        if l2 > 0:
+            g = g + F32(2.0 * l2) * p
+        if l1 > 0:
+            g = g + F32(l1) * np.sign(p)
+        grads[k] = (grads[k] + g).astype(F32) if grads.get(k) is not None else g.astype(F32)
+    return grads
+
+
+def train_step(spec, params, opt, X, y, frozen=None, reg=None):
+    """basemodel.py:268-313: forward, summed BCE, backward (of loss + regulariser), dense optimizer step.
+    Returns the BCE loss (what the reference logs, :307)."""
     loss, grads, _ = loss_and_grads(spec, params, X, y, frozen)
+    if reg:
+        add_reg_grads(params, grads, reg)
     opt.step(params, grads)
     return loss
 

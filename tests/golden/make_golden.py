@@ -171,6 +171,13 @@ def make_cases():
                     task_types=["binary", "binary"], shared_hidden_unit=32, dnn_hidden_units=[32, 16],
                     tower_dnn_hidden_units=[16], dnn_use_bn=True)
     cases.append(dict(name="cross_stitch_bn", cls=CrossStitch, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=0))
+    # non-zero regulariser (model/basemodel.py:524-540; the code default for an absent l2_reg_embedding key is 1e-5):
+    # PLE, so that the dead last-level shared-gate tensors receive their regulariser-only gradient
+    c = base_config("mtl", "ple", ["l1", "l2"], 8, "adam", 0.005,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"],
+                    expert_dnn_hidden_units=[32], gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16],
+                    l2_reg_dnn=0.05, l2_reg_embedding=0.01)
+    cases.append(dict(name="ple_l2", cls=PLE, cfg=c, vocab=[9, 3, 96, 64, 64, 80, 48], nd=0))
     return cases
 
 

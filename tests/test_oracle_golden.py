@@ -20,6 +20,14 @@ def setup(g):
     return spec, params, frozen
 
 
+def reg_of(spec, params):
+    """The regulariser the fixture's config turns on (None for the l2 = 0 fixtures)."""
+    mc = spec.mc
+    if not (mc.get("l2_reg_dnn", 0) or mc.get("l2_reg_embedding", 0)):
+        return None
+    return orc.reg_map(spec, params)
+
+
 def test_gather_bit_exact(golden):
     name, g = golden
     spec, params, _ = setup(g)
@@ -46,6 +54,9 @@ def test_loss_and_grads(golden):
     spec, params, frozen = setup(g)
     loss, grads, _ = orc.loss_and_grads(spec, params, g["X0"], g["y0"], frozen)
     assert abs(loss - float(g["loss"])) / float(g["loss"]) < RTOL
+    reg = reg_of(spec, params)
+    if reg:  # the fixture's gradients are those of loss + regulariser (basemodel.py:300)
+        orc.add_reg_grads(params, grads, reg)
     gold_keys = {k[5:] for k in g.files if k.startswith("grad/")}
     nograd = {k[7:] for k in g.files if k.startswith("nograd/")}
     assert set(grads.keys()) == gold_keys, (set(grads) ^ gold_keys)
@@ -68,7 +79,7 @@ def test_optimizer_trajectories(golden):
         opt = orc.DenseOptimizer(kind, spec.cfg["optim_config"]["lr"])
         losses = []
         for i in range(3):
-            losses.append(orc.train_step(spec, params, opt, g[f"X{i}"], g[f"y{i}"], frozen))
+            losses.append(orc.train_step(spec, params, opt, g[f"X{i}"], g[f"y{i}"], frozen, reg_of(spec, params)))
             if (i + 1) in checkpoints:
                 noise_bias, noise_rm = bn_noise_keys(params.keys())
                 for k in params:
