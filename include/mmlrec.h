@@ -402,6 +402,16 @@ int mml_attn2_bwd(const mml_attn2_desc* d, mml_stream_t stream);
  * mml_head_bce_fwd_bwd as `dprob`.  Any of y, d_out, d_raw, loss may be null. */
 int mml_esmm_combine(const float* p_raw, int64_t ldr, const float* y, int64_t ldy, const float* d_out, int64_t lddo,
                      float* p_out, int64_t ldo, float* d_raw, int64_t lddr, float* loss, int64_t B, mml_stream_t stream);
+/* ESCM output stage and loss (model/escm.py:74-112 and the loss branch of BaseModel.fit, model/basemodel.py:284-292):
+ * p_out[b] = (ctr, cvr, ctr * cvr) from the two head probabilities p_raw[b] = (ctr, cvr).  With labels y [B,2]:
+ *   loss = BCE_sum(ctr, y0) + cf_w * L1 * S + global_w * BCE_sum(ctr * cvr, y1),   L1 = BCE_sum(cvr, y1),
+ *   S = sum_b y0_b * clip(1 / max(ctr_b * N, 1e-6), -15, 15),  N = sum_b y0_b      (counterfact_ipw, escm.py:98-112,
+ *   the mean over the batch cancels the factor batch_size; the gradient flows through the inverse propensity, as it
+ *   does in the reference), and d_raw = dLoss / d(ctr, cvr).  Without labels but with d_out (= dL / d p_out [B,3] from
+ *   autograd): d_raw by the chain rule.  Feed d_raw to mml_head_bce_fwd_bwd as `dprob`. */
+int mml_escm_combine(const float* p_raw, int64_t ldr, const float* y, int64_t ldy, const float* d_out, int64_t lddo,
+                     float* p_out, int64_t ldo, float* d_raw, int64_t lddr, float* loss, int64_t B, float cf_w,
+                     float global_w, mml_stream_t stream);
 /* ----------------------------------------------------------------------------------------------
  * Per-batch AUC on the device.  Replaces sklearn.metrics.roc_auc_score run on the host for every
  * training step (model/basemodel.py:316-331; the epoch log averages the per-step values, :335-337): for every segment

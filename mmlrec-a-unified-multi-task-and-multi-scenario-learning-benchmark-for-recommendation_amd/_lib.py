@@ -131,6 +131,7 @@ _SIGS = {
     "mml_attn2_fwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_attn2_bwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_esmm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp]),
+    "mml_escm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, C.c_float, C.c_float, fp]),
     "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),
     "mml_opt_step_dense": (C.c_int, [_PP(OptTensor), i32, _PP(OptHyper), fp]),

@@ -626,6 +626,13 @@ class EsmmHeadOp(HeadOp):
     """ESMM (reference model/esmm.py:46-62): two sigmoid heads (ctr, cvr) whose product is the second output.
     The heads run on a raw probability buffer; mml_esmm_combine turns it into [ctr, ctr*cvr], evaluates the summed BCE
     and hands dLoss/d(ctr, cvr) back to the head kernel's dprob path."""
+    N_OUT = 2
+    KERNEL = "esmm_combine_kernel"
+
+    def _group(self, plan, *a):
+        if plan.prob is None:
+            plan.prob = plan.empty(plan.B, self.N_OUT)
+        return super()._group(plan, *a)
 
     def _prob_buffers(self, plan, use_dprob):
         if getattr(self, "_raw", None) is None or self._raw.shape[0] != plan.B:
@@ -633,12 +640,16 @@ class EsmmHeadOp(HeadOp):
             self._draw = plan.empty(plan.B, 2)
         return self._raw, self._draw
 
+    def _fn_extra(self):
+        return L.load().mml_esmm_combine, ()
+
     def _combine(self, plan, y, dout, draw, loss):
-        return (L.load().mml_esmm_combine,
+        fn, extra = self._fn_extra()
+        return (fn,
                 (self._raw.data_ptr(), 2, L.ptr(y), 2 if y is not None else 0, L.ptr(dout),
                  ops._ld(dout) if dout is not None else 0, plan.prob.data_ptr(), ops._ld(plan.prob), L.ptr(draw),
-                 2 if draw is not None else 0, L.ptr(loss), plan.B),
-                dict(kernel="esmm_combine_kernel", bytes=4.0 * plan.B * 8))
+                 2 if draw is not None else 0, L.ptr(loss), plan.B) + extra,
+                dict(kernel=self.KERNEL, bytes=4.0 * plan.B * 8))
 
     def infer_calls(self, plan):
         calls = super().infer_calls(plan)
@@ -646,14 +657,14 @@ class EsmmHeadOp(HeadOp):
 
     def train_calls(self, plan, use_dprob, claim=True):
         lib = L.load()
-        if use_dprob:  # autograd hands dL/d[ctr, ctcvr]; the raw probabilities are those of the forward pass
+        if use_dprob:  # autograd hands dL/d(outputs); the raw probabilities are those of the forward pass
             if plan.dprob is None:
-                plan.dprob = plan.empty(plan.B, 2)
+                plan.dprob = plan.empty(plan.B, self.N_OUT)
             pre = [self._combine(plan, None, plan.dprob, self._prob_buffers(plan, True)[1], None)]
         else:
             fwd, _ = self._group(plan, False, False, False)
             if plan.y.stride(0) != 2:
-                raise L.MMLError("ESMM expects a contiguous [B, 2] label buffer")
+                raise L.MMLError("ESMM / ESCM expect a contiguous [B, 2] label buffer")
             pre = [(lib.mml_head_fwd, (C.byref(fwd),), dict(kernel="head_kernel")),
                    self._combine(plan, plan.y, None, self._draw, plan.loss)]
         grp, post = self._group(plan, True, True, claim)
@@ -662,6 +673,21 @@ class EsmmHeadOp(HeadOp):
         byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
         return pre + [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
                        dict(kernel="head_kernel", bytes=byts))] + post
+
+
+class EscmHeadOp(EsmmHeadOp):
+    """ESCM (reference model/escm.py:74-112): outputs [ctr, cvr, ctr*cvr]; the training loss is the reference's
+    special branch (model/basemodel.py:284-292: BCE(ctr) + 0.1 * counterfactual-IPW(cvr) + BCE(ctcvr)), evaluated with
+    its gradient by mml_escm_combine."""
+    N_OUT = 3
+    KERNEL = "escm_combine_kernel"
+
+    def __init__(self, heads, cf_w, global_w, mask_cols=None):
+        super().__init__(heads, mask_cols)
+        self.cf_w, self.global_w = float(cf_w), float(global_w)
+
+    def _fn_extra(self):
+        return L.load().mml_escm_combine, (self.cf_w, self.global_w)
 
 
 class BNOp(Op):

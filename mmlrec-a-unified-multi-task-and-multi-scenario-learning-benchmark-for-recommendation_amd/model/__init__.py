@@ -2,6 +2,7 @@
 from .aitm import AITM  # noqa: F401
 from .basemodel import BaseModel  # noqa: F401
 from .cross_stitch import CrossStitch  # noqa: F401
+from .escm import ESCM  # noqa: F401
 from .esmm import ESMM  # noqa: F401
 from .hmoe import HMOE  # noqa: F401
 from .mlp import MLP  # noqa: F401

@@ -74,6 +74,9 @@ class _PlanFunction(torch.autograd.Function):
 
 
 class BaseModel(nn.Module):
+    num_outputs = None      # columns of forward()'s result when that differs from num_tasks (ESCM: 3 for 2 tasks)
+    metric_columns = None   # ... and the output columns the metrics are computed on (basemodel.py:326-327)
+
     def __init__(self, linear_feature_columns, dnn_feature_columns, init_std=0.0001, device="cpu", gpus=None,
                  config=None):
         super().__init__()
@@ -474,7 +477,7 @@ class BaseModel(nn.Module):
             n_total, 0 if val_y is None else len(val_y), steps_per_epoch))
         best_auc, early_stop, best_model = 0, 0, None
         self.history = []
-        pred_epoch = torch.empty((n, self.num_tasks), dtype=torch.float32, device=dev)
+        pred_epoch = torch.empty((n, self.num_outputs or self.num_tasks), dtype=torch.float32, device=dev)
         for epoch in range(initial_epoch, epochs):
             start_time = time.time()
             perm = self._epoch_permutation(n_total, shuffle)
@@ -500,14 +503,15 @@ class BaseModel(nn.Module):
             epoch_logs = {"loss": float(loss_dev.item()) / (n * world), "cka_loss": 0.0}
             # per-batch train metrics, averaged over steps exactly like the reference (:316-337), computed once
             # per epoch on the host instead of once per step
-            dev_metrics = self._device_batch_metrics(pred_epoch, yd, perm_d, batch_size)
+            pred_m = pred_epoch if self.metric_columns is None else pred_epoch[:, list(self.metric_columns)]
+            dev_metrics = self._device_batch_metrics(pred_m, yd, perm_d, batch_size)
             pe = ye = None
             for name, fn in self.metrics.items():
                 if name in dev_metrics:
                     epoch_logs[name] = dev_metrics[name]
                     continue
                 if pe is None:
-                    pe = pred_epoch.cpu().numpy().astype("float64")
+                    pe = pred_m.cpu().numpy().astype("float64")
                     ye = y[perm.numpy()]
                 vals = []
                 for s in range(steps_per_epoch):
@@ -598,6 +602,8 @@ class BaseModel(nn.Module):
 
     def evaluate(self, x, y, batch_size=256, domain_mask=None):
         pred = self.predict(x, batch_size, domain_mask)
+        if self.metric_columns is not None:  # (the reference scores all columns here and raises for ESCM: model/escm.py)
+            pred = pred[:, list(self.metric_columns)]
         y = np.asarray(y).reshape(len(pred), -1)
         return {name: self._metric(fn, y, pred) for name, fn in self.metrics.items()}
 

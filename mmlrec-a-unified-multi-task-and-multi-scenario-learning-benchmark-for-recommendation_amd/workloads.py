@@ -63,7 +63,7 @@ def workload(name, vocab_scale=1.0):
                   mask_column="scene", scene_feature="scene")
         cfg["optim_config"].update(optimizer="adagrad", lr=0.01, loss=["binary_crossentropy"] * 4)
         names, dense = [f"s{i}" for i in range(7)] + ["scene"], []
-    elif name in ("mlp_ae30", "esmm_ae30", "cross_stitch_ae30", "hmoe_ae30", "aitm_ae30", "snr_trans_ae30",
+    elif name in ("mlp_ae30", "esmm_ae30", "escm_ae30", "cross_stitch_ae30", "hmoe_ae30", "aitm_ae30", "snr_trans_ae30",
                   "mssm_ae30"):
         # the wider zoo on the AliExpress-shaped tables, as two-task mtl models
         vocab = list(AE30_VOCAB)
@@ -79,13 +79,13 @@ def workload(name, vocab_scale=1.0):
 
 
 def build_model(name, device, vocab_scale=1.0, seed=0, **model_kw):
-    from .model import AITM, ESMM, HMOE, MLP, MMOE, MSSM, PLE, STAR, SNR_trans, CrossStitch, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from .model import AITM, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, PLE, STAR, SNR_trans, CrossStitch, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg, names, vocab, dense = workload(name, vocab_scale)
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(n, v, embedding_dim=emb) for n, v in zip(names, vocab)] + [DenseFeat(n, 1) for n in dense]
     cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP,
-           "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans,
+           "esmm": ESMM, "escm": ESCM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans,
            "mssm": MSSM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(seed)

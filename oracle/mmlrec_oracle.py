@@ -577,6 +577,55 @@ def esmm_bwd(spec, params, cache, dprob):
     return grads, dx.astype(F32)
 
 
+def escm_fwd(spec, params, x):
+    """ESCM.forward (model/escm.py:74-96): ESMM's towers, outputs [ctr, cvr, ctr * cvr]."""
+    p2, cache = esmm_fwd(spec, params, x)
+    c, v = cache["c"], cache["v"]
+    cache["layers"] = {}
+    return np.stack([c, v, c * v], 1).astype(F32), cache
+
+
+def escm_loss_and_dprob(p, y, cf_w=0.1, global_w=1.0):
+    """The ESCM branch of BaseModel.fit (model/basemodel.py:284-292) with counterfact_ipw (model/escm.py:98-112):
+    loss_0 = BCE_sum(ctr, y0); loss_1 = BCE_sum(cvr, y1) (a scalar); loss_2 = BCE_sum(ctcvr, y1);
+    ips = clip(1 / max(ctr * sum(y0), 1e-6), -15, 15) * B;  loss = loss_0 + cf_w * mean(loss_1 * ips * y0) + global_w * loss_2.
+    (`ips.stop_gradient = True` is a no-op in torch: the gradient flows through ips.)  Returns (loss, dLoss/d[ctr, cvr, ctcvr])
+    with the ctr / cvr entries holding ONLY the direct terms (the product's chain rule is esmm-style, done by the caller)."""
+    c, v, p2 = p[:, 0].astype(F32), p[:, 1].astype(F32), p[:, 2].astype(F32)
+    y0, y1 = y[:, 0].astype(F32), y[:, 1].astype(F32)
+    B = F32(len(c))
+    N = F32(y0.sum())
+    L0, L1, L2 = bce_sum(c, y0), bce_sum(v, y1), bce_sum(p2, y1)
+    ps = np.maximum(c * N, F32(1e-6))
+    r = (F32(1) / ps).astype(F32)
+    clip = np.clip(r, F32(-15), F32(15))
+    S = float((y0 * clip).sum())
+    loss = L0 + cf_w * (L1 * S) + global_w * L2
+    inside = (c * N > F32(1e-6)) & (r >= F32(-15)) & (r <= F32(15))
+    dclip = np.where(inside, -N * r * r, F32(0)).astype(F32)
+    d = np.zeros((len(c), 3), dtype=F32)
+    d[:, 0] = bce_prob_bwd(c, y0) + F32(cf_w * L1) * y0 * dclip
+    d[:, 1] = F32(cf_w * S) * bce_prob_bwd(v, y1)
+    d[:, 2] = F32(global_w) * bce_prob_bwd(p2, y1)
+    return float(loss), d
+
+
+def escm_bwd(spec, params, cache, dprob3):
+    c, v = cache["c"], cache["v"]
+    d2 = np.stack([dprob3[:, 0] + dprob3[:, 2] * v, dprob3[:, 1] + dprob3[:, 2] * c], 1).astype(F32)
+    # esmm_bwd expects d/d[ctr, ctcvr]: feed d/d ctr directly and fold d/d cvr through a unit "ctcvr" slot
+    dzc = (d2[:, 0] * c * (F32(1) - c)).astype(F32)[:, None]
+    dzv = (d2[:, 1] * v * (F32(1) - v)).astype(F32)[:, None]
+    grads = {}
+    _acc(grads, "out.bias", (dzc.sum(0) + dzv.sum(0)).astype(F32))
+    dhc, dW, _ = linear_bwd(cache["hc"], params["ctr_dnn_final_layer.weight"], dzc, has_bias=False)
+    _acc(grads, "ctr_dnn_final_layer.weight", dW)
+    dhv, dW, _ = linear_bwd(cache["hv"], params["cvr_dnn_final_layer.weight"], dzv, has_bias=False)
+    _acc(grads, "cvr_dnn_final_layer.weight", dW)
+    dx = dnn_bwd(params, "ctr_dnn", cache["ac"], dhc, grads) + dnn_bwd(params, "cvr_dnn", cache["av"], dhv, grads)
+    return grads, dx.astype(F32)
+
+
 def bce_prob_bwd(p, y):
     """d BCE / d p as PyTorch evaluates it: (p - y) / max(p (1 - p), 1e-12)."""
     return ((p - y) / np.maximum(p * (F32(1) - p), F32(1e-12))).astype(F32)
@@ -957,7 +1006,7 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_FWD = {"escm": escm_fwd, "aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
 _BWD = {"snr_trans": snr_trans_bwd, "mssm": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
@@ -991,6 +1040,12 @@ def loss_and_grads(spec, params, X, y, frozen=None):
         p, cache = forward(spec, params, X, None, frozen)
     finally:
         set_training(was)
+    if spec.model_name == "escm":
+        loss, d3 = escm_loss_and_dprob(p, y)
+        grads, dx = escm_bwd(spec, params, cache, d3)
+        grads.update(scatter_table_grads(spec, dx, cache["idx"], params))
+        cache["d_dnn_input"] = dx
+        return loss, grads, cache
     loss = sum(bce_sum(p[:, t], y[:, t]) for t in range(spec.T))
     dlogit = bce_sigmoid_bwd(p, y)
     if spec.model_name == "star":
@@ -1144,7 +1199,7 @@ def param_shapes(spec):
             shapes[f"cross_stitch.gate_{i}.cross_stitch_weight"] = (T * d, T * d)
             k = d
         towers(k)
-    elif name == "esmm":
+    elif name in ("esmm", "escm"):
         shapes["out.bias"] = (1,)
         for twr in ("ctr", "cvr"):
             h = dnn(f"{twr}_dnn", K0, mc.get("expert_dnn_hidden_units", [256, 128]))

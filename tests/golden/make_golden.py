@@ -41,6 +41,7 @@ from model.star import STAR  # noqa: E402
 from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
+from model.escm import ESCM  # noqa: E402
 from model.snr_trans import SNR_trans  # noqa: E402
 from model.mssm import MSSM  # noqa: E402
 from model.aitm import AITM  # noqa: E402
@@ -178,6 +179,10 @@ def make_cases():
                     expert_dnn_hidden_units=[32], gate_dnn_hidden_units=[16], tower_dnn_hidden_units=[16],
                     l2_reg_dnn=0.05, l2_reg_embedding=0.01)
     cases.append(dict(name="ple_l2", cls=PLE, cfg=c, vocab=[9, 3, 96, 64, 64, 80, 48], nd=0))
+    # ESCM (model/escm.py): three outputs for two tasks, the loss branch of basemodel.py:284-292
+    c = base_config("mtl", "escm", ["label2", "label3"], 8, "adam", 0.01,
+                    task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
+    cases.append(dict(name="escm_ml", cls=ESCM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=2))
     return cases
 
 
@@ -231,11 +236,24 @@ def frozen_star_tensors(model):
     return out
 
 
+def ref_loss(model, y_pred, y):
+    """The loss expression of the reference's training loop for an unmasked batch (basemodel.py:283-296), including
+    its ESCM branch (:284-292), assembled from the reference's own loss functions / counterfact_ipw."""
+    lf = model.loss_func
+    if model.model_config["model_name"] == "escm":
+        loss_0 = lf[0](y_pred[:, 0], y[:, 0], reduction="sum")
+        loss_1 = lf[1](y_pred[:, 1], y[:, 1], reduction="sum")
+        loss_2 = lf[1](y_pred[:, 2], y[:, 1], reduction="sum")
+        loss_1 = model.counterfact_ipw(loss_1, torch.sum(y[:, 0]), y[:, 0].float(), y_pred[:, 0])
+        return loss_0 + loss_1 * model.counterfactual_w + loss_2 * model.global_w
+    return sum(lf[i](y_pred[:, i], y[:, i], reduction="sum") for i in range(model.num_tasks))
+
+
 def ref_train_step(model, X, y):
     """The reference's pure step: basemodel.py:268-313 minus logging/metrics."""
     y_pred = model(X, None).squeeze()
     model.optim.zero_grad()
-    loss = sum(model.loss_func[i](y_pred[:, i], y[:, i], reduction="sum") for i in range(model.num_tasks))
+    loss = ref_loss(model, y_pred, y)
     total = loss + model.get_regularization_loss() + model.aux_loss
     total.backward()
     model.optim.step()
@@ -330,7 +348,7 @@ def run_case(case):
     model.compile(cfg["optim_config"]["optimizer"], cfg["optim_config"]["loss"], ["auc", "acc"])
     model.zero_grad()
     y_pred = model(X0, None).squeeze()
-    loss = sum(model.loss_func[i](y_pred[:, i], y0[:, i], reduction="sum") for i in range(T))
+    loss = ref_loss(model, y_pred, y0)
     (loss + model.get_regularization_loss() + model.aux_loss).backward()
     out["loss"] = np.array(loss.item(), dtype=np.float64)
     for k, p in model.named_parameters():

@@ -129,3 +129,92 @@ def test_device_batch_metrics_equal_host_loop(workload):
         vals = [model._metric(fn, ye[s * bs:(s + 1) * bs], pe[s * bs:(s + 1) * bs]) for s in range(steps)]
         want = np.sum(vals) / steps
         assert abs(got[name] - want) < 1e-9, (workload, name, got[name], want)
+
+
+@pytest.mark.gpu
+def test_main_run_writes_result_csv_and_layer_pickles(tmp_path):
+    """End to end through the driver (reference main.py:86-178): JSON config -> ctrdataset -> fit with validation ->
+    predict with save_layer_output -> layer-output pickles (main.py:115-122) and the result CSV (main.py:128-178:
+    one row per seed, columns type, log_loss_i, auc_i), appended on the second seed."""
+    import pickle
+    import pandas as pd
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import main as M
+    a, b = synth_csv.write_csvs(str(tmp_path), n_train=2048, n_test=512)
+    res = tmp_path / "res.csv"
+    cfg = synth_csv.config(a, b, str(res), "mmoe")
+    cfg["data_config"]["layer_output_path"] = str(tmp_path) + os.sep
+    cfg["save_config"]["save_layer_output"] = True
+    cfg["training_config"]["epochs"] = 1
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg))
+    args = M.build_parser().parse_args(["--config", str(p), "--run", "1", "--model_name", "mmoe", "--seeds", "0,2"])
+    rows = M.run(args)
+    assert [r["type"] for r in rows] == ["synthml_mtl_mmoe_0", "synthml_mtl_mmoe_2"]
+    df = pd.read_csv(res)
+    assert list(df.columns) == ["type", "log_loss_0", "auc_0", "log_loss_1", "auc_1"]  # reference row schema
+    assert len(df) == 2 and list(df["type"]) == [r["type"] for r in rows]
+    for r, (_, d) in zip(rows, df.iterrows()):
+        for k in ("log_loss_0", "auc_0", "log_loss_1", "auc_1"):
+            assert abs(r[k] - d[k]) < 1e-12 and round(r[k], 4) == r[k]        # rounded to 4 decimals like main.py
+        assert 0.5 < r["auc_0"] <= 1.0 and 0.0 < r["log_loss_0"] < 1.0          # the model learned something
+    # layer-output pickles: <path><model>_l2<l2_reg_dnn>_<key>.pkl, float64 arrays over the whole test set
+    want = {"dnn_input": (512, 56), "expert_outputs": (512, 4, 32), "gate_outputs": (512, 2, 4),
+            "mmoe_outputs": (512, 2, 32), "tower_outputs": (512, 2, 16)}
+    for key, shape in want.items():
+        fn = tmp_path / f"mmoe_l20_{key}.pkl"
+        assert fn.exists(), key
+        arr = pickle.load(open(fn, "rb"))
+        assert arr.shape == shape and arr.dtype == np.float64, (key, arr.shape)
+    gates = pickle.load(open(tmp_path / "mmoe_l20_gate_outputs.pkl", "rb"))
+    assert np.allclose(gates.sum(-1), 1.0, atol=1e-5)  # softmax rows
+
+
+@pytest.mark.gpu
+def test_state_dict_save_load_round_trip(tmp_path):
+    """On-disk format: torch.save(model.state_dict()) carries the reference's key names and shapes
+    (Appendix C), loads strict=True into a fresh model -- also after lazy_exact training, whose state_dict() first
+    replays the deferred table updates -- and reproduces the predictions bit for bit; a reference-keyed checkpoint
+    (the golden state) loads the same way."""
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import workloads as W
+    from conftest import load_golden
+    from test_models_gpu import build, load_state
+    dev = torch.device("cuda:0")
+    model, cfg, vocab, dense = W.build_model("mmoe_ae30", dev, vocab_scale=1e-4, seed=0, table_update="lazy_exact")
+    model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+    model.train()
+    T = W.num_tasks(cfg)
+    for i in range(3):
+        X, y = W.synth_batch(vocab, len(dense), 256, T, seed=30 + i)
+        step = model.train_step_runner(256)
+        step.plan.X.copy_(X.to(dev))
+        step.plan.y.copy_(y.to(dev))
+        step.run()
+    path = tmp_path / "ckpt.pt"
+    torch.save(model.state_dict(), path)
+    sd = torch.load(path, map_location="cpu")
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    assert all(k.startswith(("embedding_dict.", "out.", "expert_dnn.", "gate_dnn.", "gate_dnn_final_layer.",
+                             "tower_dnn.", "tower_dnn_final_layer.")) for k in sd)
+    fresh, _, _, _ = W.build_model("mmoe_ae30", dev, vocab_scale=1e-4, seed=123)
+    fresh.load_state_dict(sd, strict=True)
+    Xe, _ = W.synth_batch(vocab, len(dense), 512, T, seed=40)
+    model.eval()
+    fresh.eval()
+    with torch.no_grad():
+        a, b = model(Xe.to(dev)), fresh(Xe.to(dev))
+    assert torch.equal(a, b)
+    # a checkpoint written by the reference (the golden state carries its key names / layouts)
+    g = load_golden("ple_ijcai")
+    m2, _ = build(g)
+    load_state(m2, g)
+    p2 = tmp_path / "ref_ckpt.pt"
+    torch.save({k[6:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("state/")}, p2)
+    m3, _ = build(g)
+    m3.load_state_dict(torch.load(p2, map_location="cpu"), strict=True)
+    m3.eval()
+    with torch.no_grad():
+        yp = m3(torch.from_numpy(g["X0"]).cuda()).cpu().numpy()
+    assert np.abs(yp - g["y_pred"]).max() < 1e-4 * np.abs(g["y_pred"]).max()

@@ -30,13 +30,13 @@ def elem_rel(a, b, floor=1e-5):
 
 def build(g, device="cuda:0", **model_kw):
     import mmlrec_amd  # noqa: F401
-    from mmlrec_amd.model import AITM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from mmlrec_amd.model import AITM, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg = json.loads(str(g["cfg"]))
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(str(n), int(v), embedding_dim=emb) for n, v in zip(g["sparse_names"], g["vocab"])]
     cols += [DenseFeat(str(n), 1) for n in g["dense_names"]]
-    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}[
+    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "escm": ESCM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(0)
     model = cls(cols, device=device, config=cfg)
@@ -120,8 +120,14 @@ def test_autograd_gradients(case):
     X = torch.from_numpy(g["X0"]).cuda()
     y = torch.from_numpy(g["y0"]).cuda()
     yp = model(X)
-    loss = sum(torch.nn.functional.binary_cross_entropy(yp[:, i], y[:, i], reduction="sum")
-               for i in range(yp.shape[1]))
+    bce = torch.nn.functional.binary_cross_entropy
+    if cfg["model_config"]["model_name"] == "escm":  # the loss branch of basemodel.py:284-292 / escm.py:98-112
+        n_ctr = y[:, 0].sum()
+        ips = torch.clip(1.0 / torch.maximum(yp[:, 0] * n_ctr, torch.full_like(yp[:, 0], 1e-6)), -15, 15) * len(y)
+        ipw = (bce(yp[:, 1], y[:, 1], reduction="sum") * ips * y[:, 0]).mean()
+        loss = bce(yp[:, 0], y[:, 0], reduction="sum") + 0.1 * ipw + bce(yp[:, 2], y[:, 1], reduction="sum")
+    else:
+        loss = sum(bce(yp[:, i], y[:, i], reduction="sum") for i in range(yp.shape[1]))
     # the reference differentiates loss + regulariser (basemodel.py:300); zero for the l2 = 0 fixtures
     (loss + model.get_regularization_loss().sum()).backward()
     assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < RTOL
