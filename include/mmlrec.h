@@ -359,6 +359,19 @@ int mml_bn_fwd(const float* z, int64_t ldz, const float* gamma, const float* bet
 int mml_bn_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* gamma, const float* mean,
                const float* rstd, float* dz, int64_t lddz, float* dgamma, float* dbeta, int32_t accumulate, int64_t B,
                int32_t n, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
+/* DomainBatchNorm (model/utils.py:553-636; STAR applies it after its first star layer when forward() is given a domain
+ * mask, model/star.py:50-51).  gamma / beta are unregistered there, frozen at (1, 0).  Training mode normalises with
+ * the statistics of the WHOLE batch for every domain (= mml_bn_fwd with gamma 1 / beta 0; the caller issues that) and
+ * mml_domain_bn_update moves the per-domain population statistics:
+ *     pop_mean[d] = decay pop_mean[d] + (1 - decay) mean(x[argmax(mask) == d]),  pop_var[d] with the unbiased variance
+ * for EVERY domain, like the reference (a domain without samples gets NaN, one with a single sample a NaN variance).
+ * Eval mode: y[b] = sum_d mask[b, d] (x[b] - pop_mean[d]) / sqrt(pop_var[d] + eps)  (mml_domain_bn_eval).
+ * pop_mean / pop_var are [D, n] device arrays. */
+int mml_domain_bn_update(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t B, int32_t n, int32_t D,
+                         float* pop_mean, float* pop_var, float decay, mml_stream_t stream);
+int mml_domain_bn_eval(const float* x, int64_t ldx, const float* mask, int64_t ldm, const float* pop_mean,
+                       const float* pop_var, float* y, int64_t ldy, int64_t B, int32_t n, int32_t D, float eps,
+                       mml_stream_t stream);
 /* SNR-trans routing weights (model/snr_trans.py:38-50).  n_blocks = outputs x inputs blocks of `block` floats each:
  * fwd  W[b] = z(u[b], alpha) * M[b]  with the hard-concrete z = clamp(sigmoid(log u - log(1-u) + log(alpha)/beta)
  *      * (eps - gamma) + gamma, 0, 1);  the routing is then one [K,N] GEMM per output on the concatenated inputs;
@@ -402,6 +415,20 @@ int mml_attn2_bwd(const mml_attn2_desc* d, mml_stream_t stream);
  * mml_head_bce_fwd_bwd as `dprob`.  Any of y, d_out, d_raw, loss may be null. */
 int mml_esmm_combine(const float* p_raw, int64_t ldr, const float* y, int64_t ldy, const float* d_out, int64_t lddo,
                      float* p_out, int64_t ldo, float* d_raw, int64_t lddr, float* loss, int64_t B, mml_stream_t stream);
+/* APG (model/apg.py:9-118, the use_uv_shared / no-mf_p branch main.py builds).  The per-sample generated [k,k] weight
+ * W_b = reshape(Linear_kk(scene_b)) and bias c_b = Linear_bias(scene_b) applied to the low-rank activation o1_b
+ * (apg.py:77-80, :100-104) are ONE ordinary GEMM  o2 = z W_cat + bb  on
+ *     z_b = [ o1_b (x) s_b  (k*E, index i*E+e) | o1_b (k) | s_b (E) | zeros up to Kf ]
+ * against W_cat [Kf, k] ([K,N] layout): rows i*E+e = Wkk[(i*k+j), e], rows k*E+i = bkk[i*k+j], rows k*E+k+e = Wb[j, e].
+ *   mml_apg_features_fwd  writes z;  mml_apg_features_bwd  do1 (+)= dz contracted with s (the scene embedding is
+ *   detached in the reference: no gradient to s);  mml_apg_weights  dir 0: packs W_cat from (Wkk [k*k,E], bkk [k*k],
+ *   Wb [k,E]); dir 1: unpacks dW_cat into their gradients (accumulating where acc_* != 0). */
+int mml_apg_features_fwd(const float* o1, int64_t ldo1, const float* s, int64_t lds, float* z, int64_t ldz, int64_t B,
+                         int32_t k, int32_t E, int32_t Kf, mml_stream_t stream);
+int mml_apg_features_bwd(const float* dz, int64_t lddz, const float* s, int64_t lds, float* do1, int64_t lddo1,
+                         int64_t B, int32_t k, int32_t E, int32_t accumulate, mml_stream_t stream);
+int mml_apg_weights(float* Wkk, float* bkk, float* Wb, float* Wcat, int64_t ldw, int32_t k, int32_t E, int32_t dir,
+                    int32_t acc_kk, int32_t acc_bkk, int32_t acc_wb, mml_stream_t stream);
 /* ESCM output stage and loss (model/escm.py:74-112 and the loss branch of BaseModel.fit, model/basemodel.py:284-292):
  * p_out[b] = (ctr, cvr, ctr * cvr) from the two head probabilities p_raw[b] = (ctr, cvr).  With labels y [B,2]:
  *   loss = BCE_sum(ctr, y0) + cf_w * L1 * S + global_w * BCE_sum(ctr * cvr, y1),   L1 = BCE_sum(cvr, y1),

@@ -125,12 +125,17 @@ _SIGS = {
     "mml_bn_fwd": (C.c_int, [fp, i64, fp, fp, fp, fp, fp, fp, fp, fp, i64, i64, i32, i32, i32, C.c_float, C.c_float, fp,
                              i64, fp]),
     "mml_bn_bwd": (C.c_int, [fp, i64, fp, i64, fp, fp, fp, fp, i64, fp, fp, i32, i64, i32, fp, i64, fp]),
+    "mml_domain_bn_update": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp, C.c_float, fp]),
+    "mml_domain_bn_eval": (C.c_int, [fp, i64, fp, i64, fp, fp, fp, i64, i64, i32, i32, C.c_float, fp]),
     "mml_snr_gate_weights_fwd": (C.c_int, [fp, fp, fp, fp, i32, i64, i32, C.c_float, C.c_float, C.c_float, fp]),
     "mml_snr_gate_weights_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i64, i32, C.c_float, C.c_float,
                                            C.c_float, fp, fp]),
     "mml_attn2_fwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_attn2_bwd": (C.c_int, [_PP(Attn2Desc), fp]),
     "mml_esmm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp]),
+    "mml_apg_features_fwd": (C.c_int, [fp, i64, fp, i64, fp, i64, i64, i32, i32, i32, fp]),
+    "mml_apg_features_bwd": (C.c_int, [fp, i64, fp, i64, fp, i64, i64, i32, i32, i32, fp]),
+    "mml_apg_weights": (C.c_int, [fp, fp, fp, fp, i64, i32, i32, i32, i32, i32, i32, fp]),
     "mml_escm_combine": (C.c_int, [fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, fp, i64, C.c_float, C.c_float, fp]),
     "mml_act_bwd": (C.c_int, [fp, fp, fp, i64, i32, fp]),
     "mml_copy_cols": (C.c_int, [_PP(fp), _PP(i64), _PP(fp), _PP(i64), _PP(i32), i32, i64, i32, fp]),

@@ -13,8 +13,10 @@ namespace mml {
 
 constexpr int BN_CHUNK = 256;  // rows per partial
 
-// partial column sums of a [B, n] matrix: P0 = sum a, P1 = sum a * b   (b = a for the forward; a = dy, b = xhat backward)
-// MODE 0: b = a;  MODE 1: b = (z - mean) * rstd
+// partial column statistics of a [B, n] matrix over one chunk of rows.
+// MODE 0 (forward): P0 = mean of the chunk, P1 = sum of squared deviations from that mean (Welford in double: the
+//         E[z^2] - mu^2 form cancels catastrophically when |mean| >> std; torch uses Welford too);
+// MODE 1 (backward): P0 = sum a, P1 = sum a * xhat with xhat = (z - mean) * rstd   (a = dy).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* a, int64_t lda, const float* z, int64_t ldz,
                                                          const float* mean, const float* rstd, int64_t B, int n,
@@ -22,35 +24,52 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* a, int64_t
   const int64_t r0 = (int64_t)blockIdx.x * BN_CHUNK;
   const int64_t r1 = (r0 + BN_CHUNK < B) ? r0 + BN_CHUNK : B;
   for (int c = threadIdx.x; c < n; c += 256) {
-    float s0 = 0.f, s1 = 0.f;
-    const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float av = a[r * lda + c];
-      const float bv = MODE ? (z[r * ldz + c] - mu) * rs : av;
-      s0 += av;
-      s1 += av * bv;
+    if (MODE == 0) {
+      double mu = 0.0, m2 = 0.0;
+      int cnt = 0;
+      for (int64_t r = r0; r < r1; ++r) {
+        const double x = a[r * lda + c];
+        ++cnt;
+        const double d = x - mu;
+        mu += d / cnt;
+        m2 += d * (x - mu);
+      }
+      part[((int64_t)blockIdx.x * 2) * n + c] = (float)mu;
+      part[((int64_t)blockIdx.x * 2 + 1) * n + c] = (float)m2;
+    } else {
+      float s0 = 0.f, s1 = 0.f;
+      const float mu = mean[c], rs = rstd[c];
+      for (int64_t r = r0; r < r1; ++r) {
+        const float av = a[r * lda + c];
+        s0 += av;
+        s1 += av * ((z[r * ldz + c] - mu) * rs);
+      }
+      part[((int64_t)blockIdx.x * 2) * n + c] = s0;
+      part[((int64_t)blockIdx.x * 2 + 1) * n + c] = s1;
     }
-    part[((int64_t)blockIdx.x * 2) * n + c] = s0;
-    part[((int64_t)blockIdx.x * 2 + 1) * n + c] = s1;
   }
 }
 
+// chunk statistics -> batch statistics by Chan's parallel-variance merge, in chunk order, in double
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int nchunks, int64_t B, int n, float eps,
                                                              float momentum, float* mean, float* rstd,
                                                              float* running_mean, float* running_var, int64_t* nbt) {
   for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
-    double s0 = 0.0, s1 = 0.0;
+    double mu = 0.0, m2 = 0.0, cnt = 0.0;
     for (int k = 0; k < nchunks; ++k) {
-      s0 += part[((int64_t)k * 2) * n + c];
-      s1 += part[((int64_t)k * 2 + 1) * n + c];
+      const int64_t r0 = (int64_t)k * BN_CHUNK;
+      const double nk = (double)((r0 + BN_CHUNK < B ? r0 + BN_CHUNK : B) - r0);
+      const double mk = part[((int64_t)k * 2) * n + c], m2k = part[((int64_t)k * 2 + 1) * n + c];
+      const double d = mk - mu, tot = cnt + nk;
+      mu += d * nk / tot;
+      m2 += m2k + d * d * cnt * nk / tot;
+      cnt = tot;
     }
-    const double mu = s0 / (double)B;
-    double var = s1 / (double)B - mu * mu;
-    if (var < 0.0) var = 0.0;
+    const double var = m2 / (double)B;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
-      const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
+      const double unb = B > 1 ? m2 / (double)(B - 1) : var;
       running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
       running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
     }
@@ -111,6 +130,63 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int6
   }
 }
 
+// ---- DomainBatchNorm (reference model/utils.py:553-636; STAR's per-domain BN, model/star.py:32-33, :50-51) ----------
+// What the reference computes (probed): gamma / beta are unregistered lists frozen at (1, 0).
+//   training: every domain's branch normalises with the statistics of the WHOLE batch (F.batch_norm(..., training=True)
+//     ignores the tensors passed as running statistics), so  out = sum_d mask[:, d] * BN_batch(x) = BN_batch(x) for
+//     one-hot masks (mml_bn_fwd with gamma 1 / beta 0); side effect: for every domain d
+//         pop_mean[d] = decay pop_mean[d] + (1 - decay) mean(x[domain == d]),  pop_var likewise with the UNBIASED variance
+//     -- evaluated for EVERY domain (both arguments of the reference's torch.where are computed), so a domain with no
+//     sample in the batch turns its population statistics into NaN, and one with a single sample its variance.
+//   eval: out[b] = sum_d mask[b, d] * (x[b] - pop_mean[d]) / sqrt(pop_var[d] + 1e-5).
+// blockIdx.y = domain; a thread owns a column and walks the batch (Welford in double).
+__global__ __launch_bounds__(256) void domain_bn_update_kernel(const float* x, int64_t ldx, const float* mask,
+                                                               int64_t ldm, int64_t B, int n, int D, float* pop_mean,
+                                                               float* pop_var, float decay) {
+  const int d = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+    double mu = 0.0, m2 = 0.0;
+    int64_t cnt = 0;
+    for (int64_t b = 0; b < B; ++b) {
+      int arg = 0;  // torch.argmax: first maximal entry
+      float best = mask[b * ldm];
+      for (int j = 1; j < D; ++j) {
+        const float v = mask[b * ldm + j];
+        if (v > best) { best = v; arg = j; }
+      }
+      if (arg != d) continue;
+      const double v = x[b * ldx + c];
+      ++cnt;
+      const double dl = v - mu;
+      mu += dl / (double)cnt;
+      m2 += dl * (v - mu);
+    }
+    const float nanf_ = __int_as_float(0x7fc00000);
+    const float bm = cnt > 0 ? (float)mu : nanf_;
+    const float bv = cnt > 1 ? (float)(m2 / (double)(cnt - 1)) : nanf_;
+    pop_mean[(int64_t)d * n + c] = pop_mean[(int64_t)d * n + c] * decay + bm * (1.f - decay);
+    pop_var[(int64_t)d * n + c] = pop_var[(int64_t)d * n + c] * decay + bv * (1.f - decay);
+  }
+}
+
+__global__ __launch_bounds__(256) void domain_bn_eval_kernel(const float* x, int64_t ldx, const float* mask, int64_t ldm,
+                                                             const float* pop_mean, const float* pop_var, float* y,
+                                                             int64_t ldy, int64_t B, int n, int D, float eps) {
+  const int64_t total = B * n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / n;
+    const int c = (int)(i - b * n);
+    const float v = x[b * ldx + c];
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float m = mask[b * ldm + d];
+      acc += m * ((v - pop_mean[(int64_t)d * n + c]) / sqrtf(pop_var[(int64_t)d * n + c] + eps));
+    }
+    y[b * ldy + c] = acc;
+  }
+}
+
 static unsigned bn_grid(int64_t n) {
   int64_t b = cdiv(n, 256);
   if (b > 256 * 8) b = 256 * 8;
@@ -137,6 +213,8 @@ extern "C" int mml_bn_fwd(const float* z, int64_t ldz, const float* gamma, const
   MML_REQUIRE(act >= MML_ACT_NONE && act <= MML_ACT_SIGMOID2, "mml_bn_fwd: unknown activation");
   hipStream_t st = to_stream(stream);
   if (training) {
+    // torch: "Expected more than 1 value per channel when training" (a ragged last batch of one sample)
+    MML_REQUIRE(B > 1, "mml_bn_fwd: training-mode BatchNorm needs more than 1 sample per batch (got %lld)", (long long)B);
     MML_REQUIRE(workspace && workspace_bytes >= mml_bn_workspace_bytes(B, n), "mml_bn_fwd: workspace too small");
     const int nch = (int)cdiv(B, (int64_t)BN_CHUNK);
     float* part = static_cast<float*>(workspace);
@@ -169,4 +247,26 @@ extern "C" int mml_bn_bwd(const float* dy, int64_t lddy, const float* z, int64_t
   MML_LAUNCH(bn_bwd_apply_kernel, dim3(bn_grid(B * n)), dim3(256), 0, st, dy, lddy, z, ldz, mean, rstd, gamma, sums, dz,
              lddz, B, (int)n);
   return check_launch("mml_bn_bwd");
+}
+
+extern "C" int mml_domain_bn_update(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t B, int32_t n,
+                                    int32_t D, float* pop_mean, float* pop_var, float decay, mml_stream_t stream) {
+  MML_REQUIRE(B >= 0 && n >= 0 && D > 0, "mml_domain_bn_update: bad sizes");
+  if (n == 0) return MML_OK;
+  MML_REQUIRE(x && mask && pop_mean && pop_var && ldx >= n && ldm >= D, "mml_domain_bn_update: null argument or ld too small");
+  MML_LAUNCH(domain_bn_update_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)D), dim3(256), 0, to_stream(stream), x, ldx,
+             mask, ldm, B, (int)n, (int)D, pop_mean, pop_var, decay);
+  return check_launch("mml_domain_bn_update");
+}
+
+extern "C" int mml_domain_bn_eval(const float* x, int64_t ldx, const float* mask, int64_t ldm, const float* pop_mean,
+                                  const float* pop_var, float* y, int64_t ldy, int64_t B, int32_t n, int32_t D, float eps,
+                                  mml_stream_t stream) {
+  MML_REQUIRE(B >= 0 && n >= 0 && D > 0, "mml_domain_bn_eval: bad sizes");
+  if (B == 0 || n == 0) return MML_OK;
+  MML_REQUIRE(x && mask && pop_mean && pop_var && y && ldx >= n && ldy >= n && ldm >= D,
+              "mml_domain_bn_eval: null argument or ld too small");
+  MML_LAUNCH(domain_bn_eval_kernel, dim3(bn_grid(B * n)), dim3(256), 0, to_stream(stream), x, ldx, mask, ldm, pop_mean,
+             pop_var, y, ldy, B, (int)n, (int)D, eps);
+  return check_launch("mml_domain_bn_eval");
 }

@@ -745,6 +745,124 @@ class BNOp(Op):
                  dict(kernel="bn_bwd", bytes=4.0 * plan.B * n * 5))]
 
 
+class DomainBNOp(Op):
+    """DomainBatchNorm of STAR (reference model/utils.py:553-636, applied after the first star layer's activation when
+    forward() is given a domain mask, model/star.py:50-51): x (a post-activation value) -> y.  gamma / beta are the
+    reference's unregistered constants (1, 0).  Training mode = whole-batch statistics (mml_bn_fwd) plus the per-domain
+    population-statistics update; eval mode = per-domain normalisation with the population statistics."""
+    EPS, DECAY = 1e-5, 0.99
+
+    def __init__(self, x, y, module, mask):
+        self.x, self.y, self.m, self.mask = x, y, module, mask
+
+    def inputs(self):
+        return [self.x]
+
+    def outputs(self):
+        return [self.y]
+
+    def _ws(self, plan):
+        nbytes = int(L.load().mml_bn_workspace_bytes(plan.B, self.x.n))
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=plan.device)
+        plan.keep.append(ws)
+        return ws
+
+    def fwd_calls(self, plan):
+        lib, n, D = L.load(), self.x.n, self.mask.shape[1]
+        pm, pv = self.m.population(plan.device)
+        if pm.shape != (D, n):
+            raise L.MMLError(f"DomainBatchNorm holds {tuple(pm.shape)} statistics, the mask has {D} domains")
+        x, y = self.x.buf, self.y.buf
+        if not getattr(plan, "bn_training", plan.training):
+            return [(lib.mml_domain_bn_eval, (x.data_ptr(), ops._ld(x), self.mask.data_ptr(), ops._ld(self.mask),
+                                              pm.data_ptr(), pv.data_ptr(), y.data_ptr(), ops._ld(y), plan.B, n, D,
+                                              self.EPS), dict(kernel="domain_bn_eval_kernel"))]
+        self.ones, self.zeros = torch.ones(n, device=plan.device), torch.zeros(n, device=plan.device)
+        self.mean, self.rstd = plan.empty(n), plan.empty(n)
+        self.scratch = [plan.zeros(n), plan.zeros(n), plan.zeros(1, dtype=torch.int64)]  # F.batch_norm's discarded running stats
+        ws = self._ws(plan)
+        plan.keep += [self.ones, self.zeros]
+        return [(lib.mml_domain_bn_update, (x.data_ptr(), ops._ld(x), self.mask.data_ptr(), ops._ld(self.mask), plan.B, n,
+                                            D, pm.data_ptr(), pv.data_ptr(), self.DECAY),
+                 dict(kernel="domain_bn_update_kernel")),
+                (lib.mml_bn_fwd, (x.data_ptr(), ops._ld(x), self.ones.data_ptr(), self.zeros.data_ptr(),
+                                  self.scratch[0].data_ptr(), self.scratch[1].data_ptr(), self.scratch[2].data_ptr(),
+                                  self.mean.data_ptr(), self.rstd.data_ptr(), y.data_ptr(), ops._ld(y), plan.B, n,
+                                  L.ACT_NONE, 1, self.EPS, 0.1, ws.data_ptr(), ws.numel()), dict(kernel="bn_fwd"))]
+
+    def bwd_calls(self, plan):
+        if self.y.grad is None:
+            return []
+        if not getattr(plan, "bn_training", plan.training):
+            raise L.MMLError("backward through DomainBatchNorm in eval mode is not supported")
+        plan.grad_of(self.x)
+        if _claim(self.x):
+            raise NotImplementedError("DomainBatchNorm input with another consumer")
+        n = self.x.n
+        dscr = plan.empty(2 * n)
+        ws = self._ws(plan)
+        return [(L.load().mml_bn_bwd,
+                 (self.y.grad.data_ptr(), ops._ld(self.y.grad), self.x.buf.data_ptr(), ops._ld(self.x.buf),
+                  self.ones.data_ptr(), self.mean.data_ptr(), self.rstd.data_ptr(), self.x.grad.data_ptr(),
+                  ops._ld(self.x.grad), dscr.data_ptr(), dscr[n:].data_ptr(), 0, plan.B, n, ws.data_ptr(), ws.numel()),
+                 dict(kernel="bn_bwd"))]
+
+
+class ApgFeatOp(Op):
+    """z = [o1 (x) s | o1 | s | 0] (csrc/apg.hip): the feature row that turns APG's per-sample generated [k,k] weight
+    into one GEMM (reference model/apg.py:77-80, :100-104).  s is the detached scene embedding (a column slice of
+    dnn_input): no gradient flows into it."""
+
+    def __init__(self, o1, s, z, k, E):
+        self.o1, self.s, self.z, self.k, self.E = o1, s, z, k, E
+
+    def inputs(self):
+        return [self.o1]
+
+    def outputs(self):
+        return [self.z]
+
+    def fwd_calls(self, plan):
+        o1, z = self.o1.buf, self.z.buf
+        return [(L.load().mml_apg_features_fwd, (o1.data_ptr(), ops._ld(o1), self.s.data_ptr(), ops._ld(self.s),
+                                                 z.data_ptr(), ops._ld(z), plan.B, self.k, self.E, self.z.n),
+                 dict(kernel="apg_features_fwd_kernel", bytes=4.0 * plan.B * (self.z.n + self.k + self.E)))]
+
+    def bwd_calls(self, plan):
+        if self.z.grad is None or not self.o1.needs_grad:
+            return []
+        if self.o1.act != L.ACT_NONE:
+            raise NotImplementedError("ApgFeatOp input must be a plain linear output")
+        do1 = plan.grad_of(self.o1)
+        acc = _claim(self.o1)
+        dz = self.z.grad
+        return [(L.load().mml_apg_features_bwd, (dz.data_ptr(), ops._ld(dz), self.s.data_ptr(), ops._ld(self.s),
+                                                 do1.data_ptr(), ops._ld(do1), plan.B, self.k, self.E, acc),
+                 dict(kernel="apg_features_bwd_kernel", bytes=4.0 * plan.B * (self.z.n + self.k + self.E)))]
+
+
+class ApgWeightsOp(Op):
+    """Derived [Kf, k] weight of an APG layer's middle GEMM, re-laid-out from the generator Linear(E -> k*k) (weight
+    Wkk, bias bkk) and the weight of the generator Linear(E -> k) of the per-sample bias (csrc/apg.hip); backward
+    unpacks its gradient into theirs."""
+
+    def __init__(self, Wkk, bkk, Wb, Wcat, k, E):
+        self.Wkk, self.bkk, self.Wb, self.Wcat, self.k, self.E = Wkk, bkk, Wb, Wcat, k, E
+
+    def fwd_calls(self, plan):
+        return [(L.load().mml_apg_weights, (self.Wkk.data.data_ptr(), self.bkk.data.data_ptr(), self.Wb.data.data_ptr(),
+                                            self.Wcat.data.data_ptr(), self.k, self.k, self.E, 0, 0, 0, 0),
+                 dict(kernel="apg_weights_kernel"))]
+
+    def bwd_calls(self, plan):
+        if not self.Wcat.written:
+            return []
+        a, b, c = _claim(self.Wkk), _claim(self.bkk), _claim(self.Wb)
+        return [(L.load().mml_apg_weights, (self.Wkk.grad.data_ptr(), self.bkk.grad.data_ptr(), self.Wb.grad.data_ptr(),
+                                            self.Wcat.grad.data_ptr(), self.k, self.k, self.E, 1, a, b, c),
+                 dict(kernel="apg_weights_kernel", side=True))]
+
+
 class Attn2Op(Op):
     """Two-token attention of AITM (model/aitm.py:84-93): tokens = [(V0, K0, Q0), (V1, K1, Q1)] of [B, H] values -> out."""
 

@@ -16,11 +16,11 @@ import numpy as np
 import pandas as pd
 import torch
 
-from .model import AITM, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, PepNet, SharedBottom
+from .model import AITM, APG, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, PepNet, SharedBottom
 from .utils.data_utils import ctrdataset, unserialize
 
 MODELS = {"mmoe": MMOE, "pcg": MMOE, "sharedbottom": SharedBottom, "ple": PLE, "star": STAR, "pepnet": PepNet,
-          "mlp": MLP, "esmm": ESMM, "escm": ESCM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}
+          "mlp": MLP, "esmm": ESMM, "escm": ESCM, "apg": APG, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}
 
 
 def set_seed(seed, re=True):

@@ -1,5 +1,6 @@
 """Drop-in model zoo for the hot path: same class names / constructor signatures as the reference's model/*.py."""
 from .aitm import AITM  # noqa: F401
+from .apg import APG  # noqa: F401
 from .basemodel import BaseModel  # noqa: F401
 from .cross_stitch import CrossStitch  # noqa: F401
 from .escm import ESCM  # noqa: F401

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import engine as E
 from .basemodel import BaseModel
-from .utils import PredictionLayer, SharedSpecificLinear, activation_code
+from .utils import DomainBatchNorm, PredictionLayer, SharedSpecificLinear, activation_code
 
 
 class STAR(BaseModel):
@@ -20,7 +20,7 @@ class STAR(BaseModel):
         # dnn_use_bn (the shipped configs_msl/config_amazon.json): the reference builds a DomainBatchNorm whose tensors
         # are unregistered lists (no state_dict keys, ones / zeros: no random draws) and applies it only when forward()
         # is given a domain mask (model/star.py:50-51) -- which fit() and predict() never do.  The model
-        # therefore trains and predicts exactly like the one without the flag; the masked forward is rejected below.
+        # therefore trains and predicts exactly like the one without the flag; a direct forward(X, mask) runs it.
         self.dnn_hidden_units = mc.get("dnn_hidden_units", [256, 128])
         self.act_code = activation_code(mc.get("dnn_activation", "relu"))
         use_shared = mc.get("use_shared", True)
@@ -31,6 +31,8 @@ class STAR(BaseModel):
         self.linears = nn.ModuleList([SharedSpecificLinear(hidden_units[i], hidden_units[i + 1], T,
                                                            use_shared=use_shared, device=device)
                                       for i in range(len(hidden_units) - 1)])
+        if self.dnn_use_bn:
+            self.domain_bn = DomainBatchNorm(num_features=hidden_units[1], num_domains=T, device=device)
         self.final_layers = nn.ModuleList([SharedSpecificLinear(hidden_units[-1], 1, T, use_shared=use_shared,
                                                                 device=device) for _ in range(T)])
         self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
@@ -53,10 +55,11 @@ class STAR(BaseModel):
         return weff, beff
 
     def _build_graph(self, plan, store, x0):
-        if self.dnn_use_bn and plan.mask is not None:
-            raise NotImplementedError("STAR's DomainBatchNorm (forward with a domain mask and dnn_use_bn) is not on the "
-                                      "MI355X path; fit() / predict() never take it (SURVEY D3)")
         T, nl = self.num_tasks, len(self.dnn_hidden_units)
+        use_dbn = self.dnn_use_bn and plan.mask is not None
+        if use_dbn and plan.mask.shape[1] != T:
+            raise NotImplementedError("STAR's DomainBatchNorm indexes the mask with the HEAD number (model/utils.py:617-"
+                                      f"622): {T} heads against {plan.mask.shape[1]} mask columns fail in the reference")
         hs = [x0] * T
         per_layer = []
         for j in range(nl):
@@ -67,6 +70,13 @@ class STAR(BaseModel):
                 probs.append(dict(x=hs[i], W=weff, b=beff, out=o, w_kn=1))
             plan.add(E.LinearGroupOp(probs))
             hs = [q["out"] for q in probs]
+            if j == 0 and use_dbn:  # model/star.py:50-51: after the activation of the first layer, head by head
+                ys = []
+                for i in range(T):
+                    y = plan.val(self.dnn_hidden_units[j], name=f"star.{j}.{i}.dbn")
+                    plan.add(E.DomainBNOp(hs[i], y, self.domain_bn, plan.mask))
+                    ys.append(y)
+                hs = ys
             per_layer.append(hs)
             plan.layer_outputs[f"star_output_{j}"] = hs
         heads = []

@@ -215,6 +215,31 @@ def emit_blocks_into(plan, store, blocks, prefixes, ins, outs):
             plan.add(E.BNOp(q["out"], b["y"], b["gamma"], b["beta"], b["module"]))
 
 
+class DomainBatchNorm(nn.Module):
+    """STAR's per-domain BatchNorm (reference model/utils.py:553-636).  Like the reference's, its tensors are plain
+    attributes -- gamma / beta frozen at (1, 0), the population statistics (zeros / ones) outside state_dict and not
+    moved by .to(): they are created on the device of the first plan that uses them.  What it computes:
+    engine.DomainBNOp / csrc/bn.hip."""
+
+    def __init__(self, num_features, num_domains, decay=0.99, epsilon=1e-3, device=None, type=None):
+        super().__init__()
+        self.num_features, self.num_domains, self.decay, self.epsilon = num_features, num_domains, decay, epsilon
+        self._pop = None
+
+    def population(self, device):
+        """(pop_means, pop_vars) as [num_domains, num_features] device tensors."""
+        if self._pop is None or self._pop[0].device != device:
+            self._pop = (torch.zeros(self.num_domains, self.num_features, device=device),
+                         torch.ones(self.num_domains, self.num_features, device=device))
+        return self._pop
+
+    def __deepcopy__(self, memo):
+        new = DomainBatchNorm(self.num_features, self.num_domains, self.decay, self.epsilon)
+        if self._pop is not None:
+            new._pop = tuple(t.clone() for t in self._pop)
+        return new
+
+
 class PredictionLayer(nn.Module):
     """bias [1] + sigmoid for task == 'binary' (reference model/utils.py:225-248); fused into the head kernel."""
 

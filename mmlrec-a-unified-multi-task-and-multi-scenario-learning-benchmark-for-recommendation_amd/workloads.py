@@ -55,7 +55,7 @@ def workload(name, vocab_scale=1.0):
         mc.update(model_name="ple", expert_dnn_hidden_units=[128], gate_dnn_hidden_units=[64],
                   tower_dnn_hidden_units=[64], task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
         names, dense = [f"s{i}" for i in range(7)], []
-    elif name in ("star_amazon", "pepnet_amazon"):
+    elif name in ("star_amazon", "pepnet_amazon", "apg_amazon"):
         vocab = list(AMAZON8_VOCAB)
         mc.update(task_name="mtmsl", model_name=name.split("_")[0], dnn_hidden_units=[128, 128],
                   task_types=["binary"] * 4)
@@ -79,13 +79,13 @@ def workload(name, vocab_scale=1.0):
 
 
 def build_model(name, device, vocab_scale=1.0, seed=0, **model_kw):
-    from .model import AITM, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, PLE, STAR, SNR_trans, CrossStitch, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from .model import AITM, APG, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, PLE, STAR, SNR_trans, CrossStitch, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg, names, vocab, dense = workload(name, vocab_scale)
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(n, v, embedding_dim=emb) for n, v in zip(names, vocab)] + [DenseFeat(n, 1) for n in dense]
     cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP,
-           "esmm": ESMM, "escm": ESCM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans,
+           "esmm": ESMM, "escm": ESCM, "apg": APG, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans,
            "mssm": MSSM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(seed)

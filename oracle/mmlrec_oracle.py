@@ -626,6 +626,69 @@ def escm_bwd(spec, params, cache, dprob3):
     return grads, dx.astype(F32)
 
 
+def apg_fwd(spec, params, x):
+    """APG.forward (model/apg.py:146-193) with APGLayer.forward's use_uv_shared / no-mf_p branch (:100-106, :116-118):
+    per layer  o1 = x Wnk + bnk;  W_b = reshape(Linear_kk(s_b)) [k,k], c_b = Linear_bias(s_b);  o2_b = o1_b W_b + c_b;
+    out = relu(o2 Wkm + bkm).  s = the detached scene embedding (:152-153).  The per-sample weights ARE materialised
+    here (the checker follows the reference's formulation, not the GEMM rewrite of csrc/apg.hip)."""
+    E = spec.emb
+    pos = spec.sparse_names.index(spec.dc["scene_feature"])
+    s = x[:, pos * E:(pos + 1) * E]
+    h, acts, layers = x, [], {}
+    nl = len(spec.mc.get("dnn_hidden_units", [256, 128]))
+    for i in range(nl):
+        pf = f"apg_layers.{i}"
+        Wnk, bnk = params[f"{pf}.shared_weight_nk"], params[f"{pf}.shared_bias_nk"]
+        Wkm, bkm = params[f"{pf}.shared_weight_km"], params[f"{pf}.shared_bias_km"]
+        k = Wnk.shape[1]
+        Wg = linear_fwd(s, params[f"{pf}.specific_weight_kk.linears.0.weight"],
+                        params[f"{pf}.specific_weight_kk.linears.0.bias"]).reshape(-1, k, k)
+        cg = linear_fwd(s, params[f"{pf}.specific_bias_kk.linears.0.weight"],
+                        params[f"{pf}.specific_bias_kk.linears.0.bias"])
+        o1 = (h @ Wnk + bnk).astype(F32)
+        o2 = (np.einsum("bi,bij->bj", o1, Wg) + cg).astype(F32)
+        o3 = relu((o2 @ Wkm + bkm).astype(F32))
+        acts.append((h, o1, Wg, o2, o3))
+        layers[f"apg_output_{i}"] = o3
+        h = o3
+    ps = [sigmoid((linear_fwd(h, params[f"final_layer.{t}.weight"]) + params[f"out.{t}.bias"])[:, 0])
+          for t in range(spec.T)]
+    return np.stack(ps, 1).astype(F32), dict(acts=acts, s=s, h=h, layers=layers)
+
+
+def apg_bwd(spec, params, cache, dlogit):
+    grads = {}
+    h = cache["h"]
+    dh = np.zeros_like(h)
+    for t in range(spec.T):
+        dz = dlogit[:, t:t + 1]
+        _acc(grads, f"out.{t}.bias", dz.sum(0))
+        d, dW, _ = linear_bwd(h, params[f"final_layer.{t}.weight"], dz, has_bias=False)
+        _acc(grads, f"final_layer.{t}.weight", dW)
+        dh = dh + d
+    s = cache["s"]
+    for i in reversed(range(len(cache["acts"]))):
+        pf = f"apg_layers.{i}"
+        hin, o1, Wg, o2, o3 = cache["acts"][i]
+        k = o1.shape[1]
+        d3 = (dh * (o3 > 0)).astype(F32)
+        _acc(grads, f"{pf}.shared_weight_km", (o2.T @ d3).astype(F32))
+        _acc(grads, f"{pf}.shared_bias_km", d3.sum(0))
+        d2 = (d3 @ params[f"{pf}.shared_weight_km"].T).astype(F32)
+        dWg = np.einsum("bi,bj->bij", o1, d2).reshape(len(o1), k * k).astype(F32)   # d/d generated weights
+        _, dW, db = linear_bwd(s, params[f"{pf}.specific_weight_kk.linears.0.weight"], dWg)
+        _acc(grads, f"{pf}.specific_weight_kk.linears.0.weight", dW)
+        _acc(grads, f"{pf}.specific_weight_kk.linears.0.bias", db)
+        _, dW, db = linear_bwd(s, params[f"{pf}.specific_bias_kk.linears.0.weight"], d2)
+        _acc(grads, f"{pf}.specific_bias_kk.linears.0.weight", dW)
+        _acc(grads, f"{pf}.specific_bias_kk.linears.0.bias", db)
+        d1 = np.einsum("bj,bij->bi", d2, Wg).astype(F32)
+        _acc(grads, f"{pf}.shared_weight_nk", (hin.T @ d1).astype(F32))
+        _acc(grads, f"{pf}.shared_bias_nk", d1.sum(0))
+        dh = (d1 @ params[f"{pf}.shared_weight_nk"].T).astype(F32)
+    return grads, dh.astype(F32)
+
+
 def bce_prob_bwd(p, y):
     """d BCE / d p as PyTorch evaluates it: (p - y) / max(p (1 - p), 1e-12)."""
     return ((p - y) / np.maximum(p * (F32(1) - p), F32(1e-12))).astype(F32)
@@ -1006,8 +1069,8 @@ def pepnet_bwd(spec, params, cache, dlogit):
     return grads, dx
 
 
-_FWD = {"escm": escm_fwd, "aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
-_BWD = {"snr_trans": snr_trans_bwd, "mssm": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
+_FWD = {"apg": apg_fwd, "escm": escm_fwd, "aitm": aitm_fwd, "hmoe": hmoe_fwd, "cross_stitch": cross_stitch_fwd, "esmm": esmm_fwd, "mlp": mlp_fwd, "sharedbottom": sharedbottom_fwd, "mmoe": mmoe_fwd, "pcg": mmoe_fwd, "ple": ple_fwd, "pepnet": pepnet_fwd}
+_BWD = {"apg": apg_bwd, "snr_trans": snr_trans_bwd, "mssm": snr_trans_bwd, "aitm": aitm_bwd, "hmoe": hmoe_bwd, "cross_stitch": cross_stitch_bwd, "mlp": mlp_bwd, "sharedbottom": sharedbottom_bwd, "mmoe": mmoe_bwd, "pcg": mmoe_bwd, "ple": ple_bwd, "pepnet": pepnet_bwd}
 
 
 def forward(spec, params, X, mask=None, frozen=None):

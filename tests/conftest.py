@@ -13,7 +13,7 @@ GOLDEN_CASES = ["sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mm
                 "pepnet_amazon", "mlp_ml", "mlp_ae", "esmm_ml",
                 "cross_stitch_ae", "hmoe_ml", "aitm_ml", "snr_trans_ae",
                 "mssm_ml", "sharedbottom_bn", "mmoe_bn",
-                "mssm_bn", "cross_stitch_bn", "ple_l2", "escm_ml"]
+                "mssm_bn", "cross_stitch_bn", "ple_l2", "escm_ml", "apg_ae", "star_dbn"]
 
 
 def pytest_configure(config):

@@ -42,6 +42,7 @@ from model.pepnet import PepNet  # noqa: E402
 from model.mlp import MLP  # noqa: E402
 from model.esmm import ESMM  # noqa: E402
 from model.escm import ESCM  # noqa: E402
+from model.apg import APG  # noqa: E402
 from model.snr_trans import SNR_trans  # noqa: E402
 from model.mssm import MSSM  # noqa: E402
 from model.aitm import AITM  # noqa: E402
@@ -183,6 +184,21 @@ def make_cases():
     c = base_config("mtl", "escm", ["label2", "label3"], 8, "adam", 0.01,
                     task_names=["ctr", "ctcvr"], task_types=["binary", "binary"])
     cases.append(dict(name="escm_ml", cls=ESCM, cfg=c, vocab=[96, 64, 2, 7, 21, 64, 48], nd=2))
+    # APG (model/apg.py): per-sample generated [k,k] weights driven by the scene embedding, msl mode
+    c = base_config("msl", "apg", ["label", "label"], 8, "adam", 0.005, task_types=["binary", "binary"],
+                    dnn_hidden_units=[32, 16])
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="apg_ae", cls=APG, cfg=c, vocab=[96, 64, 48, 32, 24, 10, 2], nd=0, scene_last=True))
+    # STAR with its DomainBatchNorm (model/utils.py:553-636): msl mode (heads == domains, the only arrangement in which
+    # the reference's mask indexing works), forward / backward WITH a domain mask in training mode, then eval mode on
+    # the moved population statistics
+    c = base_config("msl", "star", ["label", "label"], 8, "adam", 0.005, task_types=["binary", "binary"],
+                    dnn_use_bn=True)
+    c["data_config"].update({"num_domains": 2, "mask_values": [0, 1], "mask_column": "scene",
+                             "scene_feature": "scene"})
+    cases.append(dict(name="star_dbn", cls=STAR, cfg=c, vocab=[2, 12, 23, 96, 64, 64, 48, 2], nd=0, scene_last=True,
+                      masked_train=True))
     return cases
 
 
@@ -356,6 +372,25 @@ def run_case(case):
             out[f"grad/{k}"] = p.grad.numpy().copy()
         else:
             out[f"nograd/{k}"] = np.array(1)
+
+    if case.get("masked_train"):  # forward(X, mask) in TRAINING mode + its gradients, then eval on the moved statistics
+        model.load_state_dict(state0)
+        model.train()
+        model.zero_grad()
+        ypm = model(X0, mask0)
+        lossm = sum(model.loss_func[i](ypm[:, i], y0[:, i], reduction="sum") for i in range(T))
+        lossm.backward()
+        out["mtrain/y_pred"] = ypm.detach().numpy().copy()
+        out["mtrain/loss"] = np.array(lossm.item(), dtype=np.float64)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out[f"mtrain/grad/{k}"] = p.grad.numpy().copy()
+        out["mtrain/pop_means"] = torch.stack([t.detach() for t in model.domain_bn.pop_means]).numpy().copy()
+        out["mtrain/pop_vars"] = torch.stack([t.detach() for t in model.domain_bn.pop_vars]).numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            out["mtrain/y_pred_eval_after"] = model(X0, mask0).numpy().copy()
+        model.train()
 
     # optimizer trajectories: 1 and 3 steps of Adam and Adagrad over batches 0,1,2
     for opt in ("adam", "adagrad"):

@@ -30,13 +30,13 @@ def elem_rel(a, b, floor=1e-5):
 
 def build(g, device="cuda:0", **model_kw):
     import mmlrec_amd  # noqa: F401
-    from mmlrec_amd.model import AITM, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
+    from mmlrec_amd.model import AITM, APG, ESCM, ESMM, HMOE, MLP, MMOE, MSSM, SNR_trans, CrossStitch, PLE, STAR, DenseFeat, PepNet, SharedBottom, SparseFeat
     cfg = json.loads(str(g["cfg"]))
     cfg["model_config"].update(model_kw)
     emb = cfg["model_config"]["emb"]
     cols = [SparseFeat(str(n), int(v), embedding_dim=emb) for n, v in zip(g["sparse_names"], g["vocab"])]
     cols += [DenseFeat(str(n), 1) for n in g["dense_names"]]
-    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "escm": ESCM, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}[
+    cls = {"sharedbottom": SharedBottom, "mmoe": MMOE, "ple": PLE, "star": STAR, "pepnet": PepNet, "mlp": MLP, "esmm": ESMM, "escm": ESCM, "apg": APG, "cross_stitch": CrossStitch, "hmoe": HMOE, "aitm": AITM, "snr_trans": SNR_trans, "mssm": MSSM}[
         cfg["model_config"]["model_name"]]
     torch.manual_seed(0)
     model = cls(cols, device=device, config=cfg)
@@ -328,8 +328,8 @@ def test_bf16_operand_mode_gradients_and_trajectory_kuairec():
 def test_star_with_dnn_use_bn_trains_like_without():
     """The shipped configs_msl/config_amazon.json sets dnn_use_bn for STAR: the reference's DomainBatchNorm is only applied
     when forward() receives a domain mask (model/star.py:50-51), which fit() / predict() never pass -- so
-    the flag must not change construction, state_dict, the unmasked forward or a training step; the masked forward is
-    rejected loudly."""
+    the flag must not change construction, state_dict, the unmasked forward or a training step.  (The masked forward
+    itself: test_star_domain_batchnorm_masked_forward_backward.)"""
     g = load_golden("star_amazon")
     outs, sds = [], []
     for flag in (False, True):
@@ -345,8 +345,41 @@ def test_star_with_dnn_use_bn_trains_like_without():
         with torch.no_grad():
             outs.append(model(torch.from_numpy(g["X1"]).cuda()).cpu())
         sds.append({k: v.cpu() for k, v in model.state_dict().items()})
-        if flag:
+        if flag:  # mtmsl: 4 heads against 2 mask columns -- the reference's DomainBatchNorm indexes out of range there
             with pytest.raises(NotImplementedError):
                 model(torch.from_numpy(g["X0"]).cuda(), torch.from_numpy(g["mask0"]).cuda())
     assert torch.equal(outs[0], outs[1])
     assert sds[0].keys() == sds[1].keys() and all(torch.equal(sds[0][k], sds[1][k]) for k in sds[0])
+
+
+def test_star_domain_batchnorm_masked_forward_backward():
+    """STAR's DomainBatchNorm (reference model/utils.py:553-636) against the reference's own tensors (golden star_dbn,
+    msl: heads == domains): forward(X, mask) in TRAINING mode (whole-batch statistics, per-domain population update
+    for every head), its gradients through loss.backward(), the population statistics it leaves behind, and the eval-
+    mode forward(X, mask) that normalises per domain with them."""
+    g = load_golden("star_dbn")
+    model, cfg = build(g)
+    load_state(model, g)
+    X = torch.from_numpy(g["X0"]).cuda()
+    mask = torch.from_numpy(g["mask0"]).cuda()
+    y = torch.from_numpy(g["y0"]).cuda()
+    model.eval()
+    with torch.no_grad():  # population statistics still (0, 1)
+        assert rel(model(X, mask).cpu().numpy(), g["y_pred_masked"]) < RTOL
+    model.train()
+    yp = model(X, mask)
+    assert rel(yp.detach().cpu().numpy(), g["mtrain/y_pred"]) < RTOL
+    loss = sum(torch.nn.functional.binary_cross_entropy(yp[:, i], y[:, i], reduction="sum") for i in range(yp.shape[1]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["mtrain/loss"])) / float(g["mtrain/loss"]) < RTOL
+    for n, p in model.named_parameters():
+        key = "mtrain/grad/" + n
+        if key in g.files:
+            assert p.grad is not None, n
+            assert rel(p.grad.cpu().numpy(), g[key]) < RTOL, n
+    pm, pv = model.domain_bn.population(X.device)
+    assert rel(pm.cpu().numpy(), g["mtrain/pop_means"]) < RTOL
+    assert rel(pv.cpu().numpy(), g["mtrain/pop_vars"]) < RTOL
+    model.eval()
+    with torch.no_grad():
+        assert rel(model(X, mask).cpu().numpy(), g["mtrain/y_pred_eval_after"]) < RTOL
