@@ -38,6 +38,9 @@ def parse():
                     help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
                          "--kernel-trace of this command reports stand-alone kernel durations")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary lazy_exact measurement")
+    ap.add_argument("--no-split-dense", action="store_true",
+                    help="dense table update as ONE launch after the scatter (round-1 schedule) instead of untouched "
+                         "rows beside the forward + touched rows after the scatter")
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -243,12 +246,14 @@ def main():
     results = {}
     for B in [args.batch] + ([args.alt_batch] if args.alt_batch and args.alt_batch != args.batch else []):
         batches = make_batches(B)
-        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=not args.serial)
+        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=not args.serial,
+                                         split_dense=not args.no_split_dense)
         steps = args.steps if B == args.batch else max(args.steps, 50)
         dt = timed_steps(runner, batches, steps, args.warmup, dist)
         results[B] = dict(dt=dt, steps=steps, value=world * B * steps / dt, ms=dt / steps * 1e3,
                           loss=float(runner.plan.loss.item()) / B)
         if B == args.batch:
+            runner0 = runner
             acc = kernel_breakdown(runner, batches, min(args.steps, 10))
             results[B]["acc"] = acc
             results[B]["bsteps"] = min(args.steps, 10)
@@ -321,8 +326,11 @@ def main():
         "vs_baseline": None, "dtype": gemm_dtype, "data": "synthetic",
         "config": {"workload": describe_workload(args.workload, cfg, vocab, dense),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
-                   "table_update": model.optimizer().table_update, "hip_graph": not args.no_graph,
-                   "streams": 1 if args.serial else 2,
+                   "table_update": model.optimizer().table_update,
+                   "dense_update_schedule": ("split: untouched rows beside the forward, touched rows after the scatter"
+                                             if getattr(runner0, "split_dense", False) else "one launch after the scatter"),
+                   "hip_graph": not args.no_graph,
+                   "streams": 1 if args.serial else (3 if getattr(runner0, "split_dense", False) else 2),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else
                              {"row_sharded": "row-wise sharded over ranks (owner = (row + field) mod N), one all-to-all "
                                              "per direction: keys / rows / row gradients",

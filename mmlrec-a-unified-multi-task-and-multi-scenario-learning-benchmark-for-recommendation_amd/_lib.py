@@ -63,7 +63,7 @@ class HeadGroup(C.Structure):
 
 class OptTensor(C.Structure):
     _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64), ("l1", C.c_float),
-                ("l2", C.c_float)]
+                ("l2", C.c_float), ("skip_rows", fp), ("row_elems", i32), ("zero_grads", i32)]
 
 
 class Copy2dDesc(C.Structure):
@@ -91,10 +91,10 @@ _SIGS = {
     "mml_gather_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
     "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
     "mml_scatter_bwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
-                                  fp, fp, i32, fp, fp]),
+                                  fp, fp, i32, fp, fp, fp]),
     "mml_scatter_bwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
-                                        fp, fp, i32, fp, fp]),
-    "mml_index_unique_idx32": (C.c_int, [_PP(i64), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp]),
+                                        fp, fp, i32, fp, fp, fp]),
+    "mml_index_unique_idx32": (C.c_int, [_PP(i64), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp, fp]),
     "mml_route_count": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), i32, i64, i32, fp, fp, fp]),
     "mml_route_place": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), _PP(i64), i32, i64, i32, fp, fp, fp, fp, fp]),
     "mml_rows_permute": (C.c_int, [fp, i64, fp, i32, i32, i64, fp, fp]),
@@ -145,7 +145,8 @@ _SIGS = {
     "mml_opt_catchup_rows": (C.c_int, [_PP(fp), _PP(fp), _PP(fp), _PP(fp), _PP(i64), i32, i32, fp, fp, i32,
                                        _PP(OptHyper), fp]),
     "mml_opt_catchup_dense": (C.c_int, [fp, fp, fp, fp, i64, i32, _PP(OptHyper), fp]),
-    "mml_index_unique": (C.c_int, [_PP(i64), _PP(i32), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp]),
+    "mml_index_unique": (C.c_int, [_PP(i64), _PP(i32), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp,
+                                   fp]),
     "mml_counter_update": (C.c_int, [fp, i32, i32, fp]),
 }
 EXPORTS = tuple(_SIGS)

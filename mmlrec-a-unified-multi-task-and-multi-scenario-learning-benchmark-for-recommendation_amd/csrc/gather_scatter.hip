@@ -167,6 +167,8 @@ struct ScatterArgs {
   int32_t* touched;
   int32_t* touched_count;
   int32_t touched_cap;
+  uint8_t* marks;  // optional byte per row (32-byte aligned per field, see mml_scatter_bwd): plain-store row marking
+  int64_t markbase[MML_MAX_FIELDS];
   int32_t* status;
 };
 
@@ -349,8 +351,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
   long long* acc = smem64;                                   // [E][PITCH] fixed-point sums
   int* keys = reinterpret_cast<int*>(acc + E * PITCH);       // [SLOTS]
   unsigned short* occ = reinterpret_cast<unsigned short*>(keys + SLOTS);  // [SLOTS] occupied slots, first-claim order
-  int* newrows = reinterpret_cast<int*>(occ + SLOTS);        // [SLOTS] only when a.touched != null
-  __shared__ int n_occ, n_new, base_out;
+  __shared__ int n_occ;
   __shared__ unsigned mx_bits;
   // chunk group from the XCD slot, field from the position inside the XCD (see scatter_hash_kernel)
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
     for (int i = threadIdx.x; i < E * PITCH / 2; i += NT)
       *reinterpret_cast<float4*>(acc + i * 2) = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = threadIdx.x; i < SLOTS; i += NT) keys[i] = -1;
-  if (threadIdx.x == 0) { n_occ = 0; n_new = 0; mx_bits = 0; }
+  if (threadIdx.x == 0) { n_occ = 0; mx_bits = 0; }
   __syncthreads();
 #ifdef MML_LAB_SC_NOMX
   if (a.dOut && blockIdx.x == 0xfffffff) {
@@ -485,21 +486,127 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
 #else
     if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
 #endif
+    // touched-row bookkeeping: only MARK the row here (a non-returning atomic: they run at the float-atomic request
+    // rate, while the returning form that told "first time seen" cost the index-only pass 0.5 ms); the list is built
+    // from the bitmaps by rows_compact_kernel
     if (a.touched && e == 0) {
-      const uint32_t bit = 1u << (key & 31);
-      const uint32_t old = atomicOr(a.seen[f] + (key >> 5), bit);
-      if (!(old & bit)) newrows[atomicAdd(&n_new, 1)] = key;
+      if (a.marks) a.marks[a.markbase[f] + key] = 1;  // plain store: hot rows cost nothing (see mark_rows_kernel)
+      else atomicOr(a.seen[f] + (key >> 5), 1u << (key & 31));
     }
   }
-  if (a.touched) {  // ONE counter atomic per workgroup for the rows this launch sees for the first time
-    __syncthreads();
-    if (threadIdx.x == 0) base_out = n_new ? atomicAdd(a.touched_count, n_new) : 0;
-    __syncthreads();
-    const int base = base_out;
-    for (int i = threadIdx.x; i < n_new; i += NT)
-      if (base + i < a.touched_cap) a.touched[base + i] = (int32_t)(a.rowbase[f] + newrows[i]);
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+// Index-only pass (mml_index_unique) with a mark map: one byte store per lookup, no LDS, no atomics.  Hot rows are
+// written by thousands of lanes -- plain same-value stores merge in L2, where same-address atomics serialise at the
+// memory side (the atomicOr form of this pass took 350 us at B = 65 536, 15 tiny tables hammering a few words each).
+__global__ __launch_bounds__(256) void mark_rows_kernel(const FieldTable ft, const ScatterArgs a) {
+  const int64_t total = a.B * a.F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / a.F;
+    const int f = (int)(i - b * a.F);
+    const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + ft.col[f]];
+    if (row < 0) bad |= 1;
+    else if (row >= ft.vocab[f]) bad |= 2;
+    else a.marks[a.markbase[f] + row] = 1;
   }
   if (bad && a.status) atomicOr(a.status, bad);
+}
+
+// touched list := every row whose bit is set in the per-field `seen` bitmaps (global row id rowbase[f] + row),
+// *count := their number.  One word per lane, one counter atomic per wave; 12.49 M rows = 1.56 MB of bitmap.
+struct CompactArgs {
+  uint32_t* seen[MML_MAX_FIELDS];
+  uint8_t* marks;  // or null: the bitmaps already hold the marks
+  int64_t wordbase[MML_MAX_FIELDS + 1];
+  int64_t rowbase[MML_MAX_FIELDS];
+  int64_t vocab[MML_MAX_FIELDS];
+  int32_t F;
+  int32_t* touched;
+  int32_t* count;
+  int32_t cap;
+};
+
+__global__ __launch_bounds__(256) void rows_compact_kernel(const CompactArgs a) {
+  const int64_t W = a.wordbase[a.F];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  for (int64_t w0 = (int64_t)blockIdx.x * blockDim.x; w0 < W; w0 += stride) {  // (whole waves stay in the loop)
+    const int64_t w = w0 + threadIdx.x;
+    uint32_t bits = 0;
+    int f = 0;
+    int64_t wi = 0;
+    if (w < W) {
+      while (f + 1 < a.F && w >= a.wordbase[f + 1]) ++f;
+      wi = w - a.wordbase[f];
+      if (a.marks) {  // 32 mark bytes -> one bitmap word (this lane is the word's only writer), marks cleared
+        uint4* m = reinterpret_cast<uint4*>(a.marks + w * 32);
+        const uint4 lo = m[0], hi = m[1];
+        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if ((q[k] >> (8 * j)) & 0xffu) bits |= 1u << (4 * k + j);
+          m[0] = make_uint4(0, 0, 0, 0);
+          m[1] = make_uint4(0, 0, 0, 0);
+          bits |= a.seen[f][wi];
+          a.seen[f][wi] = bits;
+        } else {
+          bits = a.seen[f][wi];
+        }
+      } else {
+        bits = a.seen[f][wi];
+      }
+    }
+    const int n = __popc(bits);
+    int pre = n;  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(pre, o);
+      if (lane >= o) pre += t;
+    }
+    const int total = __shfl(pre, 63);
+    int base = 0;
+    if (total) {
+      if (lane == 63) base = atomicAdd(a.count, total);
+      base = __shfl(base, 63);
+    }
+    int pos = base + pre - n;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      if (pos < a.cap) a.touched[pos] = (int32_t)(a.rowbase[f] + wi * 32 + b);
+      ++pos;
+    }
+  }
+}
+
+static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
+  CompactArgs c{};
+  int64_t words = 0;
+  for (int f = 0; f < a.F; ++f) {
+    c.seen[f] = a.seen[f];
+    c.wordbase[f] = words;  // (= a.markbase[f] / 32)
+    c.rowbase[f] = a.rowbase[f];
+    words += (ft.vocab[f] + 31) / 32;
+  }
+  c.wordbase[a.F] = words;
+  c.marks = a.marks;
+  c.F = a.F; c.touched = a.touched; c.count = a.touched_count; c.cap = a.touched_cap;
+  hipError_t e = hipMemsetAsync(a.touched_count, 0, sizeof(int32_t), stream);
+  if (e != hipSuccess) {
+    set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+    return MML_ERR_HIP;
+  }
+  int64_t blocks = cdiv(words, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  MML_LAUNCH(rows_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, c);
+  return check_launch(who);
 }
 
 template <int SLOTS, int E, int NT>
@@ -516,8 +623,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
   }
   sp.grp_base[a.F] = (int32_t)total;
   if (total * 8 > 0x7fffffff) return 1;  // caller falls back
-  const size_t lds = (size_t)E * (SLOTS + 1) * 8 + (size_t)SLOTS * 4 + (size_t)SLOTS * 2 +
-                     (a.touched ? (size_t)SLOTS * 4 : 0);
+  const size_t lds = (size_t)E * (SLOTS + 1) * 8 + (size_t)SLOTS * 4 + (size_t)SLOTS * 2;
   static bool attr_set = false;  // more than the 64 KiB a kernel may use by default
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E, NT>),
@@ -529,7 +635,9 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
     attr_set = true;
   }
   MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
-  return check_launch(who);
+  int rc = check_launch(who);
+  if (rc || !a.touched) return rc;
+  return launch_compact(ft, a, stream, who);
 }
 
 // E in {4, 8, 16}, 16-byte aligned gradient rows: the restructured kernel; returns 1 when the shape is not covered
@@ -592,11 +700,21 @@ extern "C" int mml_gather_fwd_idx32(const float* const* tables, const int64_t* v
   return launch_gather(ft, a, to_stream(stream));
 }
 
+// mark map layout: field f owns bytes [32 * wordbase_f, 32 * wordbase_f + V_f), wordbase = prefix sum of ceil(V_f / 32)
+static void set_marks(ScatterArgs& a, const FieldTable& ft, uint8_t* row_marks) {
+  a.marks = row_marks;
+  int64_t words = 0;
+  for (int f = 0; f < a.F; ++f) {
+    a.markbase[f] = words * 32;
+    words += (ft.vocab[f] + 31) / 32;
+  }
+}
+
 static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
                         int32_t E, const float* X, int64_t ldX, const int32_t* idx, int64_t ldi, int64_t B,
                         const float* dOut, int64_t ldo, uint32_t* const* seen, const int64_t* rowbase,
-                        int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
-                        mml_stream_t stream) {
+                        int32_t* touched, int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks,
+                        int32_t* status, mml_stream_t stream) {
   FieldTable ft;
   int rc = fill_fields(ft, (const float* const*)grad_tables, vocab, col, F, "mml_scatter_bwd");
   if (rc) return rc;
@@ -614,6 +732,7 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
   }
   a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
+  set_marks(a, ft, touched ? row_marks : nullptr);
   const int threads = 256;
   if (!getenv("MMLREC_SCATTER_OLD")) {
     rc = try_fold(ft, a, to_stream(stream), "mml_scatter_bwd");
@@ -642,24 +761,25 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
 extern "C" int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
                                int32_t E, const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
                                uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
-                               int32_t* touched_count, int32_t touched_cap, int32_t* status, mml_stream_t stream) {
+                               int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks, int32_t* status,
+                               mml_stream_t stream) {
   return scatter_impl(grad_tables, vocab, col, F, E, X, ldX, nullptr, 0, B, dOut, ldo, seen, rowbase, touched,
-                      touched_count, touched_cap, status, stream);
+                      touched_count, touched_cap, row_marks, status, stream);
 }
 
 extern "C" int mml_scatter_bwd_idx32(float* const* grad_tables, const int64_t* vocab, int32_t F, int32_t E,
                                      const int32_t* idx, int64_t ldi, int64_t B, const float* dOut, int64_t ldo,
                                      uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
-                                     int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                     int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks, int32_t* status,
                                      mml_stream_t stream) {
   return scatter_impl(grad_tables, vocab, nullptr, F, E, nullptr, 0, idx, ldi, B, dOut, ldo, seen, rowbase, touched,
-                      touched_count, touched_cap, status, stream);
+                      touched_count, touched_cap, row_marks, status, stream);
 }
 
 static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X, int64_t ldX,
                        const int32_t* idx, int64_t ldi, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
-                       int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
-                       mml_stream_t stream) {
+                       int32_t* touched, int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks,
+                       int32_t* status, mml_stream_t stream) {
   MML_REQUIRE(F >= 0 && F <= MML_MAX_FIELDS && vocab && seen && rowbase && touched && touched_count && touched_cap > 0,
               "mml_index_unique: bad arguments");
   MML_REQUIRE(E > 0 && E <= 16, "mml_index_unique: E must be in [1,16]");
@@ -677,6 +797,15 @@ static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int3
   }
   a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = nullptr; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
+  set_marks(a, ft, row_marks);
+  if (row_marks && !getenv("MMLREC_SCATTER_OLD")) {  // byte marks + bitmap compaction: no LDS, no atomics
+    int64_t blocks = cdiv(B * (int64_t)F, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    MML_LAUNCH(mark_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), ft, a);
+    int rc2 = check_launch("mml_index_unique");
+    if (rc2) return rc2;
+    return launch_compact(ft, a, to_stream(stream), "mml_index_unique");
+  }
   if (!getenv("MMLREC_SCATTER_OLD")) {
     const int rc = try_fold(ft, a, to_stream(stream), "mml_index_unique");
     if (rc <= 0) return rc;
@@ -695,16 +824,16 @@ static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int3
 
 extern "C" int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_t E, const float* X,
                                 int64_t ldX, int64_t B, uint32_t* const* seen, const int64_t* rowbase,
-                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, int32_t* status,
-                                mml_stream_t stream) {
+                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks,
+                                int32_t* status, mml_stream_t stream) {
   return unique_impl(vocab, col, F, E, X, ldX, nullptr, 0, B, seen, rowbase, touched, touched_count, touched_cap,
-                     status, stream);
+                     row_marks, status, stream);
 }
 
 extern "C" int mml_index_unique_idx32(const int64_t* vocab, int32_t F, int32_t E, const int32_t* idx, int64_t ldi,
                                       int64_t B, uint32_t* const* seen, const int64_t* rowbase, int32_t* touched,
-                                      int32_t* touched_count, int32_t touched_cap, int32_t* status,
+                                      int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks, int32_t* status,
                                       mml_stream_t stream) {
   return unique_impl(vocab, nullptr, F, E, nullptr, 0, idx, ldi, B, seen, rowbase, touched, touched_count,
-                     touched_cap, status, stream);
+                     touched_cap, row_marks, status, stream);
 }

@@ -111,8 +111,15 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         b[e] = be;
       }
     };
+    const uint32_t* skip = T.skip_rows;
+    const int re = T.row_elems > 0 ? T.row_elems : 1;
+    auto skipped = [&](int64_t c) {  // chunk c = elements [4c, 4c + 4): inside ONE row when row_elems % 4 == 0
+      const int64_t row = (c << 2) / re;
+      return (skip[row >> 5] >> (row & 31)) & 1u;
+    };
+    const bool zg = T.zero_grads != 0;
     int64_t i = tid;
-    if (unroll == 2) {
+    if (unroll == 2 && !skip) {
       for (; i + stride < n4; i += 2 * stride) {  // eight 16-byte loads in flight per thread
         const int64_t j = i + stride;
         f4 p0 = ld(P + i), p1 = ld(P + j);
@@ -130,8 +137,9 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
       }
     }
     for (; i < n4; i += stride) {
+      if (skip && skipped(i)) continue;
       f4 p = ld(P + i);
-      const f4 g = ld(G + i);
+      const f4 g = zg ? zero : ld(G + i);
       f4 a = S1 ? ld(S1 + i) : zero;
       f4 b = S2 ? ld(S2 + i) : zero;
       one(p, g, a, b);
@@ -144,8 +152,12 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   }
   const int64_t tail0 = vec ? (n4 << 2) : 0;
   for (int64_t i = tail0 + tid; i < T.n; i += stride) {
+    if (T.skip_rows) {
+      const int64_t row = i / (T.row_elems > 0 ? T.row_elems : 1);
+      if ((T.skip_rows[row >> 5] >> (row & 31)) & 1u) continue;
+    }
     float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
-    opt_update(h, c, p, reg_grad(T.grad[i], p, T.l1, T.l2), a, b);
+    opt_update(h, c, p, reg_grad(T.zero_grads ? 0.f : T.grad[i], p, T.l1, T.l2), a, b);
     T.param[i] = p;
     if (T.state1) T.state1[i] = a;
     if (T.state2) T.state2[i] = b;
@@ -176,11 +188,16 @@ __global__ __launch_bounds__(256) void opt_flat_kernel(const OptLaunch L) {
     const mml_opt_tensor T = ts[lo];
     const int64_t e0 = (ch - pre[lo]) << 2;
     float* gw = const_cast<float*>(T.grad);
+    const int re = T.row_elems > 0 ? T.row_elems : 1;
+    if (T.skip_rows && re % 4 == 0) {  // chunk inside one row
+      const int64_t row = e0 / re;
+      if ((T.skip_rows[row >> 5] >> (row & 31)) & 1u) continue;
+    }
     const bool vec = (e0 + 4 <= T.n) && aligned16(T.param) && aligned16(T.grad) && (!T.state1 || aligned16(T.state1)) &&
                      (!T.state2 || aligned16(T.state2));
     if (vec) {
       float4 p = *reinterpret_cast<float4*>(T.param + e0);
-      const float4 g = *reinterpret_cast<const float4*>(T.grad + e0);
+      const float4 g = T.zero_grads ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(T.grad + e0);
       float4 a = T.state1 ? *reinterpret_cast<float4*>(T.state1 + e0) : make_float4(0, 0, 0, 0);
       float4 b = T.state2 ? *reinterpret_cast<float4*>(T.state2 + e0) : make_float4(0, 0, 0, 0);
       opt_update(h, c, p.x, reg_grad(g.x, p.x, T.l1, T.l2), a.x, b.x);
@@ -194,8 +211,12 @@ __global__ __launch_bounds__(256) void opt_flat_kernel(const OptLaunch L) {
         *reinterpret_cast<float4*>(gw + e0) = make_float4(0, 0, 0, 0);
     } else {
       for (int64_t i = e0; i < e0 + 4 && i < T.n; ++i) {
+        if (T.skip_rows) {
+          const int64_t row = i / re;
+          if ((T.skip_rows[row >> 5] >> (row & 31)) & 1u) continue;
+        }
         float p = T.param[i], a = T.state1 ? T.state1[i] : 0.f, b = T.state2 ? T.state2[i] : 0.f;
-        const float g = T.grad[i];
+        const float g = T.zero_grads ? 0.f : T.grad[i];
         opt_update(h, c, p, reg_grad(g, p, T.l1, T.l2), a, b);
         T.param[i] = p;
         if (T.state1) T.state1[i] = a;
@@ -542,6 +563,8 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       MML_REQUIRE(t.param && t.grad && t.n >= 0, "mml_opt_step_dense: tensor %d malformed", i);
       MML_REQUIRE(hyper->kind == MML_OPT_SGD || t.state1, "mml_opt_step_dense: tensor %d needs state1", i);
       MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
+      MML_REQUIRE(!t.skip_rows || (t.row_elems > 0 && t.n % t.row_elems == 0),
+                  "mml_opt_step_dense: tensor %d: skip_rows needs row_elems dividing n", i);
       L.chunk0[L.n] = chunks;
       L.t[L.n++] = t;
       total += t.n;

@@ -312,9 +312,9 @@ class GatherOp(Op):
             seen = ops._ptr_array(sr.seen)
             rb = (L.i64 * (F + 1))(*sr.rowbase)
             plan.keep += [seen, rb]
-            extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
+            extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel(), sr.marks.data_ptr())
         else:
-            extra = (None, None, None, None, 0)
+            extra = (None, None, None, None, 0, None)
         meta = dict(kernel=scatter_symbol(E),
                     bytes=float(plan.B) * F * (4 + 12 * E), tail=True)  # idx + grad read + row RMW
         return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
@@ -1141,6 +1141,9 @@ class TableRows:
         for v in vocab:
             self.rowbase.append(self.rowbase[-1] + int(v))
         self.seen = [torch.zeros((int(v) + 31) // 32, dtype=torch.int32, device=device) for v in vocab]
+        # one byte per row, all-zero between launches: rows are marked with plain stores, a compaction pass turns the
+        # marks into the bitmaps + the list (include/mmlrec.h: row_marks)
+        self.marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=device)
         self.touched = torch.zeros(max(int(cap), 1), dtype=torch.int32, device=device)
         self.count = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -1254,16 +1257,31 @@ class Optimizer:
     def calls(self, plan):
         """Optimizer call list for one step (appended after a plan's backward)."""
         c = self.calls_split(plan)
-        return c["pre"] + c["mlp"] + c["tables"]
+        return c["pre"] + c["early"] + c["mlp"] + c["tables"]
 
-    def calls_split(self, plan):
-        """{'pre': step-counter bump (must run before anything reads it), 'mlp': dense MLP update, 'tables': table
-        update (+ touched-list reset)} so a trainer can put the two updates on different streams."""
+    def can_split_dense(self, plan):
+        """The dense table update may run as (untouched rows early, next to the forward) + (touched rows after the
+        scatter): needs the batch's row set before the forward (mml_index_unique: E <= 16, indices on this rank) and
+        an update that is the same function of (p, g, state) in both kernels (no regulariser on the tables)."""
+        if self.table_update != "dense_exact" or self._table_reg(self._reg_map()):
+            return False
+        gop = plan.ops[0] if plan.ops else None
+        if not isinstance(gop, GatherOp):
+            return False
+        return all(t.data.shape[1] <= 16 for t in gop.tables)
+
+    def calls_split(self, plan, split_dense=False):
+        """{'pre': step-counter bump (+ the index pre-pass), 'early': the untouched-rows half of a split dense table
+        update (may run beside the forward / backward), 'mlp': dense MLP update, 'tables': table update (+ touched-list
+        reset)} so a trainer can put them on different streams."""
         lib = L.load()
         st = self.store
         pre = [(lib.mml_counter_update, (self.step_dev.data_ptr(), 1, 0))]
         if self.table_update == "lazy_exact":
             pre += self._lazy_pre_calls(plan)
+        split_dense = bool(split_dense) and self.can_split_dense(plan)
+        if split_dense:
+            pre += self._unique_pre_calls(plan)
         calls = []
         reg = self._reg_map()
         # (a regularised parameter is updated even when no gradient reaches it -- the reference's dead PLE tensors,
@@ -1286,12 +1304,13 @@ class Optimizer:
             calls.append((lib.mml_opt_step_dense, (arr, len(entries), C.byref(hyper)),
                           dict(kernel=_opt_dense_symbol(sum(e[0].numel() for e in entries), len(entries)),
                                bytes=float(per) * sum(e[0].numel() for e in entries))))
-        mlp_calls, calls = calls, []
+        mlp_calls, calls, early = calls, [], []
         if tabs:
             if self.table_update == "dense_exact":
-                hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=True)
+                hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense)
                 plan.keep.append(hz)
-                per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind]  # p,g,m,v read + p,m,v written
+                # p, g, m, v read + p, m, v written; the split form never reads g
+                per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind] - (4 if split_dense else 0)
                 # one C call = one launch (the same size rule mml_opt_step_dense applies inside a call), so that a
                 # call's label is the kernel symbol a profiler reports
                 # the huge tables stream through opt_dense_kernel<true> (one call), every other table shares one
@@ -1301,14 +1320,18 @@ class Optimizer:
                     big = []
                 small = [i for i in range(len(tabs)) if i not in big]
                 groups = [g_ for g_ in (big, small) if g_]
+                seen_of = {}
+                if split_dense:
+                    seen_of = dict(zip(st.rows_names, st.rows.seen))
                 for grp in groups:
-                    arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] + (treg,)
-                                                for i in grp])
+                    arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] +
+                                                (treg, seen_of.get(tnames[i])) for i in grp])
                     plan.keep.append(arr)
                     numel = sum(tabs[i].data.numel() for i in grp)
-                    calls.append((lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
-                                  dict(kernel=_opt_dense_symbol(numel, len(grp)), bytes=float(per) * numel)))
-            else:
+                    (early if split_dense else calls).append(
+                        (lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
+                         dict(kernel=_opt_dense_symbol(numel, len(grp)), bytes=float(per) * numel)))
+            if self.table_update != "dense_exact" or split_dense:
                 rows = st.rows
                 lazy = self.table_update == "lazy_exact"
                 F = len(tabs)
@@ -1326,7 +1349,28 @@ class Optimizer:
                                                       rows.count.data_ptr(), rows.touched.numel(), pl,
                                                       C.byref(hyper)), dict(kernel="opt_rows_kernel")))
                 calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
-        return {"pre": pre, "mlp": mlp_calls, "tables": calls}
+        return {"pre": pre, "early": early, "mlp": mlp_calls, "tables": calls}
+
+    def _unique_pre_calls(self, plan):
+        """Index pre-pass of the split dense update: the batch's distinct rows -> `seen` bitmaps + touched list."""
+        lib, st = L.load(), self.store
+        gop = plan.ops[0]
+        names, rows = st.table_names, st.rows
+        if rows is None or list(st.rows_names) != list(names):
+            raise L.MMLError("split dense update needs ParamStore.ensure_rows over every table")
+        F = len(names)
+        E = st.pvals[names[0]].data.shape[1]
+        vocab = (L.i64 * F)(*[st.pvals[n].data.shape[0] for n in names])
+        ps = ops._ptr_array(rows.seen)
+        rb = (L.i64 * (F + 1))(*rows.rowbase)
+        X, nrows = gop.index_view(plan)
+        col = (L.i32 * F)(*gop.cols)
+        plan.keep += [vocab, ps, rb, col]
+        return gop.pre_index_calls(plan) + [
+            (lib.mml_index_unique, (vocab, col, F, E, X.data_ptr(), ops._ld(X), nrows, ps, rb,
+                                    rows.touched.data_ptr(), rows.count.data_ptr(), rows.touched.numel(),
+                                    rows.marks.data_ptr(), plan.status.data_ptr()),
+             dict(kernel="mark_rows_kernel+rows_compact_kernel", bytes=float(nrows) * F * 5))]
 
     # ---- regulariser (model/basemodel.py:524-540) ---------------------------------------------------------
     def _reg_map(self):
@@ -1383,7 +1427,8 @@ class Optimizer:
                 if n:
                     L.check(lib.mml_index_unique_idx32(vocab, 1, E, keys_ptr, 1, n, ps, rb, rows.touched.data_ptr(),
                                                        rows.count.data_ptr(), rows.touched.numel(),
-                                                       plan.status.data_ptr(), stream), "mml_index_unique_idx32")
+                                                       rows.marks.data_ptr(), plan.status.data_ptr(), stream),
+                            "mml_index_unique_idx32")
                     L.check(catchup[0](*catchup[1], stream), "mml_opt_catchup_rows")
             gop.lazy_launch = launch
             return []
@@ -1395,7 +1440,8 @@ class Optimizer:
         return gop.pre_index_calls(plan) + [
             (lib.mml_index_unique, (vocab, col, F, E, X.data_ptr(), ops._ld(X), nrows, ps, rb,
                                     rows.touched.data_ptr(), rows.count.data_ptr(), rows.touched.numel(),
-                                    plan.status.data_ptr()), dict(kernel=scatter_symbol(E) + "(index_unique)")),
+                                    rows.marks.data_ptr(), plan.status.data_ptr()),
+             dict(kernel="mark_rows_kernel+rows_compact_kernel", bytes=float(nrows) * F * 5)),
             catchup,
         ]
 

@@ -395,13 +395,16 @@ class BaseModel(nn.Module):
         return opt
 
     # ---- fused training step ---------------------------------------------------------------------
-    def train_step_runner(self, B, use_graph=None, allreduce=None, overlap=True):
-        """Returns a TrainStep for batch size B (cached)."""
+    def train_step_runner(self, B, use_graph=None, allreduce=None, overlap=True, split_dense=True):
+        """Returns a TrainStep for batch size B (cached).  split_dense: run the reference-exact dense table update as
+        (untouched rows beside the forward) + (touched rows after the scatter) when possible (trainer.TrainStep)."""
         from ..trainer import TrainStep
-        key = int(B)
+        key = (int(B), bool(self.training))  # BatchNorm follows the MODULE's mode: a step is recorded for one of them
         st = self._caches["steps"].get(key)
-        if st is None or st.store is not self._store() or st.overlap != bool(overlap):
-            st = TrainStep(self, B, self.use_hip_graph if use_graph is None else use_graph, allreduce, overlap)
+        if (st is None or st.store is not self._store() or st.overlap != bool(overlap) or
+                st.want_split != bool(split_dense)):
+            st = TrainStep(self, B, self.use_hip_graph if use_graph is None else use_graph, allreduce, overlap,
+                           split_dense)
             self._caches["steps"][key] = st
         return st
 
@@ -525,6 +528,10 @@ class BaseModel(nn.Module):
                 for m, v in zip(names, (t / world).tolist()):
                     epoch_logs[m] = v
             if do_validation:
+                # (Reference defect kept OUT: its predict() calls self.eval() and never restores train mode
+                # (basemodel.py:231 vs :397), so from the second epoch on the reference trains BatchNorm models with
+                # running statistics and returns best_model in eval mode.  Here every epoch trains in train mode; for
+                # models without BatchNorm -- every hot-path config -- the two are identical.)
                 eval_result = self.evaluate(val_x, val_y, batch_size)
                 print(eval_result)
                 if eval_result.get("auc", 0) > best_auc:

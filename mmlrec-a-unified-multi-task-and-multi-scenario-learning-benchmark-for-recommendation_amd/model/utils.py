@@ -128,7 +128,7 @@ def activation_layer(act_name, hidden_size=None, dice_dim=2):
 # ---- parameter containers -------------------------------------------------------------------------
 class DNN(nn.Module):
     """[Linear -> act] x L parameter stack (reference model/utils.py:92-161).  Weights N(0, init_std), biases keep
-    nn.Linear's default init.  BatchNorm / dropout are outside the accelerated path and rejected."""
+    nn.Linear's default init.  use_bn adds a BatchNorm1d after every Linear (engine.BNOp); dropout is rejected."""
 
     def __init__(self, inputs_dim, hidden_units, activation="relu", l2_reg=0, dropout_rate=0, use_bn=False,
                  init_std=0.0001, dice_dim=3, device="cpu"):

@@ -97,7 +97,13 @@ def gather_fwd_idx32(tables, idx, dense=None, out=None, status=None):
     return out
 
 
-def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None):
+def marks_bytes(vocab):
+    """Size of the row-mark scratch map of mml_scatter_bwd / mml_index_unique (include/mmlrec.h: row_marks)."""
+    return 32 * sum((int(v) + 31) // 32 for v in vocab)
+
+
+def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None,
+                marks=None):
     """grad_tables[f][X[:, cols[f]].long()] += d_out[:, f*E:(f+1)*E] (float atomics)."""
     lib = L.load()
     _need_gpu(X, d_out, *grad_tables)
@@ -108,11 +114,12 @@ def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=No
     rb = (L.i64 * (F + 1))(*rowbase) if rowbase is not None else None
     rc = lib.mml_scatter_bwd(_ptr_array(grad_tables), vocab, col, F, E, X.data_ptr(), _ld(X), B, d_out.data_ptr(),
                              _ld(d_out), seen_arr, rb, L.ptr(touched), L.ptr(touched_count),
-                             0 if touched is None else touched.numel(), L.ptr(status), _stream())
+                             0 if touched is None else touched.numel(), L.ptr(marks), L.ptr(status), _stream())
     L.check(rc, "mml_scatter_bwd")
 
 
-def scatter_bwd_idx32(grad_tables, idx, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None):
+def scatter_bwd_idx32(grad_tables, idx, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None,
+                      marks=None):
     """grad_tables[f][idx[:, f]] += d_out[:, f*E:(f+1)*E] with native int32 indices [B, F]."""
     lib = L.load()
     _need_gpu(idx, d_out, *grad_tables)
@@ -122,7 +129,7 @@ def scatter_bwd_idx32(grad_tables, idx, d_out, seen=None, rowbase=None, touched=
     rb = (L.i64 * (F + 1))(*rowbase) if rowbase is not None else None
     rc = lib.mml_scatter_bwd_idx32(_ptr_array(grad_tables), vocab, F, E, idx.data_ptr(), idx.stride(0), B,
                                    d_out.data_ptr(), _ld(d_out), seen_arr, rb, L.ptr(touched), L.ptr(touched_count),
-                                   0 if touched is None else touched.numel(), L.ptr(status), _stream())
+                                   0 if touched is None else touched.numel(), L.ptr(marks), L.ptr(status), _stream())
     L.check(rc, "mml_scatter_bwd_idx32")
 
 
@@ -368,12 +375,16 @@ def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False):
 
 
 def make_opt_tensors(entries):
-    """entries: (param, grad, state1 or None, state2 or None[, (l1, l2)]) with equal element counts, contiguous."""
+    """entries: (param, grad, state1 or None, state2 or None[, (l1, l2)[, skip bitmap]]) with equal element counts,
+    contiguous.  A skip bitmap (int32 words, one bit per table row) turns the entry into the untouched-rows half of the
+    split dense table update (include/mmlrec.h: mml_opt_tensor.skip_rows)."""
     arr = (L.OptTensor * len(entries))()
     for d, ent in zip(arr, entries):
         p, g, s1, s2 = ent[:4]
         d.param, d.grad, d.state1, d.state2, d.n = p.data_ptr(), g.data_ptr(), L.ptr(s1), L.ptr(s2), p.numel()
         d.l1, d.l2 = ent[4] if len(ent) > 4 and ent[4] else (0.0, 0.0)
+        if len(ent) > 5 and ent[5] is not None:
+            d.skip_rows, d.row_elems, d.zero_grads = ent[5].data_ptr(), p.shape[1], 1
     return arr
 
 
@@ -393,11 +404,11 @@ def opt_step_rows(tables, grad_tables, state1, state2, seen, rowbase, touched, t
                                        C.byref(hyper), _stream()), "mml_opt_step_rows")
 
 
-def index_unique(vocab, cols, E, X, seen, rowbase, touched, touched_count, status=None):
+def index_unique(vocab, cols, E, X, seen, rowbase, touched, touched_count, status=None, marks=None):
     F = len(vocab)
     L.check(L.load().mml_index_unique((L.i64 * F)(*vocab), (L.i32 * F)(*cols), F, E, X.data_ptr(), _ld(X), X.shape[0],
                                       _ptr_array(seen), (L.i64 * (F + 1))(*rowbase), touched.data_ptr(),
-                                      touched_count.data_ptr(), touched.numel(), L.ptr(status), _stream()),
+                                      touched_count.data_ptr(), touched.numel(), L.ptr(marks), L.ptr(status), _stream()),
             "mml_index_unique")
 
 

@@ -192,9 +192,10 @@ class RowShardedGatherOp(E.Op):
         if sr is not None:
             self.o_seen = ops._ptr_array(sr.seen)
             self.o_rb = (L.i64 * 2)(*sr.rowbase)
-            self.o_extra = (self.o_seen, self.o_rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
+            self.o_extra = (self.o_seen, self.o_rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel(),
+                            sr.marks.data_ptr())
         else:
-            self.o_extra = (None, None, None, None, 0)
+            self.o_extra = (None, None, None, None, 0, None)
         return [(E.PY, self._backward, (), dict(kernel="row_sharded_backward_exchange", tail=True))]
 
     # ---- run time ----------------------------------------------------------------------------------
@@ -462,9 +463,9 @@ class ShardedGatherOp(E.Op):
                 seen = ops._ptr_array(sr.seen)
                 rb = (L.i64 * (nfm + 1))(*sr.rowbase)
                 plan.keep += [seen, rb]
-                extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel())
+                extra = (seen, rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel(), sr.marks.data_ptr())
             else:
-                extra = (None, None, None, None, 0)
+                extra = (None, None, None, None, 0, None)
             calls.append((lib.mml_scatter_bwd, (gt, vocab, col, nfm, Em, self.recv_idx.data_ptr(), nfm, W * B,
                                                 self.grad_recv.data_ptr(), nfm * Em) + extra +
                           (plan.status.data_ptr(),),

@@ -65,10 +65,11 @@ class Segments:
 
 
 class TrainStep:
-    def __init__(self, model, B, use_graph=True, allreduce=None, overlap=True):
+    def __init__(self, model, B, use_graph=True, allreduce=None, overlap=True, split_dense=True):
         self.model = model
         self.store = model._store()
         self.opt = model.optimizer()
+        self.want_split = bool(split_dense)
         rows = None
         par = getattr(model, "_parallel", None)
         self.par = par
@@ -78,7 +79,14 @@ class TrainStep:
         lazy = self.opt.table_update == "lazy_exact"
         if lazy and par is not None and par.mode == "table_wise":
             raise NotImplementedError("lazy_exact table updates on the table-wise sharded path (use row_sharded)")
-        if self.opt.table_update in ("sparse_rows", "lazy_exact"):
+        # Split dense table update (engine.Optimizer.can_split_dense): the reference-exact dense optimizer as
+        #   early : every row the batch does NOT touch (zero gradient), streamed beside the forward / backward,
+        #   tables: the touched rows, with their gradients, after the scatter (mml_opt_step_rows)
+        # -- the same arithmetic on every row as one dense launch, but the 2.3 GB stream leaves the critical path.
+        split = (bool(split_dense) and self.opt.table_update == "dense_exact" and
+                 (par is None or par.mode == "replicated") and
+                 not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16)
+        if self.opt.table_update in ("sparse_rows", "lazy_exact") or split:
             if par is None:
                 rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))
             elif par.mode == "row_sharded":  # one flat table: at most every local row is touched
@@ -90,25 +98,40 @@ class TrainStep:
                 names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in par.sharding.mine]
                 rows = self.store.ensure_rows(par.world * int(B) * max(len(names), 1), names)
         # lazy_exact lists the batch's rows in a pre-pass (before the gather), so the scatter only accumulates
-        self.plan = model._record(B, True, False, self.store, sparse_rows=None if lazy else rows, lazy=lazy)
-        self.opt_split = self.opt.calls_split(self.plan)
-        self.opt_calls = self.opt_split["pre"] + self.opt_split["mlp"] + self.opt_split["tables"]
+        self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
+                                  lazy=lazy or split)
+        self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
+        self.split_dense = bool(self.opt_split["early"])
+        self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +
+                          self.opt_split["tables"])
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
+        self.side2 = torch.cuda.Stream(device=self.store.device) if (self.overlap and self.split_dense) else None
         # fork / join events live as long as the step
         self.ev_fork = torch.cuda.Event() if self.overlap else None
         self.ev_join = torch.cuda.Event() if self.overlap else None
+        self.ev_pre = torch.cuda.Event() if self.side2 is not None else None
+        self.ev_early = torch.cuda.Event() if self.side2 is not None else None
         p = self.plan
         ar = [(E.PY, self._allreduce, (), dict(kernel="all_reduce(mlp grads)"))] if allreduce is not None else []
-        self.front = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd, self.use_graph)
+        # the touched-row update clears the `seen` bits the early pass is still reading: it waits for that pass
+        wait = ([(E.PY, self._wait_early, (), dict(kernel="wait(early table pass)"))] if self.side2 is not None else [])
+        # (without an early pass the counter bump / lazy pre-pass simply lead the front graph)
+        self.pre = Segments(self.opt_split["pre"] if self.split_dense else [], self.use_graph)
+        self.early = Segments(self.opt_split["early"], self.use_graph, min_calls=1)
+        self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd + p.head_train + p.bwd,
+                              self.use_graph)
         self.sideq = Segments(p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
-        self.tail = Segments(p.bwd_tail + self.opt_split["tables"], self.use_graph)
+        self.tail = Segments(p.bwd_tail + wait + self.opt_split["tables"], self.use_graph)
         self.calls = 0
 
     def _allreduce(self):
         self.allreduce(self.store.arena)
+
+    def _wait_early(self):
+        torch.cuda.current_stream().wait_event(self.ev_early)
 
     def _forked(self, side, tail):
         main = torch.cuda.current_stream()
@@ -132,9 +155,19 @@ class TrainStep:
         depends on how many streams the process has created.  Single-branch graphs never enter that loop."""
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
-            for seg in (self.front, self.sideq, self.tail):
+            for seg in (self.pre, self.early, self.front, self.sideq, self.tail):
                 seg.capture()
             torch.cuda.synchronize()
+        self.pre.run()
+        if self.side2 is not None:  # untouched table rows: their own stream, beside everything up to the row update
+            main = torch.cuda.current_stream()
+            self.ev_pre.record(main)
+            self.side2.wait_event(self.ev_pre)
+            with torch.cuda.stream(self.side2):
+                self.early.run()
+                self.ev_early.record(self.side2)
+        else:
+            self.early.run()
         self.front.run()
         if not self.overlap:
             self.tail.run()

@@ -694,8 +694,30 @@ def test_scatter_idx32_and_unique_idx32(ops, E, B):
     ii = T(idx)
     L.check(lib.mml_index_unique_idx32((L.i64 * F)(*vocab), F, E if E <= 16 else 16, ii.data_ptr(), ii.stride(0), B,
                                        ops._ptr_array(seen2), (L.i64 * (F + 1))(*rowbase), t2.data_ptr(), c2.data_ptr(),
-                                       t2.numel(), None, ops._stream()), "mml_index_unique_idx32")
+                                       t2.numel(), None, None, ops._stream()), "mml_index_unique_idx32")
     assert np.array_equal(np.sort(t2[:int(c2.item())].cpu().numpy()), want)
+    # ... and with the byte-mark scratch map (plain stores + compaction instead of atomics): same set, marks left zero
+    seen3 = [torch.zeros_like(s) for s in seen]
+    t3 = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    c3 = torch.zeros(1, dtype=torch.int32, device=dev())
+    marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=dev())
+    L.check(lib.mml_index_unique_idx32((L.i64 * F)(*vocab), F, E if E <= 16 else 16, ii.data_ptr(), ii.stride(0), B,
+                                       ops._ptr_array(seen3), (L.i64 * (F + 1))(*rowbase), t3.data_ptr(), c3.data_ptr(),
+                                       t3.numel(), marks.data_ptr(), None, ops._stream()), "mml_index_unique_idx32")
+    assert np.array_equal(np.sort(t3[:int(c3.item())].cpu().numpy()), want)
+    assert int(marks.max().item()) == 0
+    for a_, b_ in zip(seen2, seen3):
+        assert torch.equal(a_, b_)
+    # scatter with marks: gradients and list as before
+    gt3 = [torch.zeros(v, E, device=dev()) for v in vocab]
+    seen4 = [torch.zeros_like(s) for s in seen]
+    t4 = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    c4 = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.scatter_bwd_idx32(gt3, T(idx), T(d_out), seen=seen4, rowbase=rowbase, touched=t4, touched_count=c4, marks=marks)
+    assert np.array_equal(np.sort(t4[:int(c4.item())].cpu().numpy()), want)
+    assert int(marks.max().item()) == 0
+    for f in range(F):
+        assert rel(gt3[f].cpu().numpy(), gt[f].cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
