@@ -74,6 +74,15 @@ int mml_device_caps(int device, int64_t* out6);
 int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
                    const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
                    float* out, int64_t ldo, int32_t* status, mml_stream_t stream);
+/* mml_gather_fwd that also marks every row it reads in row_marks (a byte per table row, layout and contract of
+ * mml_scatter_bwd's row_marks): the split dense table update (mml_opt_tensor.skip_rows) gets the batch's row set from
+ * the gather itself; mml_rows_compact then turns the marks into the `seen` bitmaps and the touched-row list
+ * (touched[] = every marked or already-seen row, *touched_count = their number; the marks are cleared). */
+int mml_gather_fwd_mark(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                        const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, float* out,
+                        int64_t ldo, uint8_t* row_marks, int32_t* status, mml_stream_t stream);
+int mml_rows_compact(uint32_t* const* seen, const int64_t* vocab, const int64_t* rowbase, int32_t F, int32_t* touched,
+                     int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks, mml_stream_t stream);
 /* same with native int32 indices idx[b*ldi + f] (additive API for vocabularies >= 2^24);
  * dense values come from dense[b*ldd + j] (may be null when Nd == 0). */
 int mml_gather_fwd_idx32(const float* const* tables, const int64_t* vocab, int32_t F, int32_t E,

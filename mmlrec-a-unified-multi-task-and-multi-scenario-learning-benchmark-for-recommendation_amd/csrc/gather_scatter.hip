@@ -29,6 +29,8 @@ struct GatherArgs {
   float* out;
   int64_t ldo;
   int32_t* status;
+  uint8_t* marks;  // optional: a byte per table row (layout of mml_scatter_bwd's row_marks), set for every row read
+  int64_t markbase[MML_MAX_FIELDS];
 };
 
 // Reference semantics of X[:, c].long(): truncation toward zero (model/basemodel.py:476).
@@ -88,6 +90,9 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, c
         if (b0 + i < a.B) {
           const int64_t row = load_index(a, b0 + i, f, ft, bad);
           v[i] = *reinterpret_cast<const float4*>(tab + row * a.E);
+          // the split dense table update needs the batch's row set before its early pass starts: the gather has every
+          // index in a register anyway (one byte store per lookup instead of a separate pass over X)
+          if (a.marks && part == 0) a.marks[a.markbase[f] + row] = 1;
         }
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256) void gather_scalar_kernel(const FieldTable ft,
       const int e = c - f * a.E;
       const int64_t row = load_index(a, b, f, ft, bad);
       v = ft.tab[f][row * a.E + e];
+      if (a.marks && e == 0) a.marks[a.markbase[f] + row] = 1;
     } else {
       const int j = c - a.F * a.E;
       v = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
@@ -529,23 +535,25 @@ struct CompactArgs {
   int32_t cap;
 };
 
-__global__ __launch_bounds__(256) void rows_compact_kernel(const CompactArgs a) {
-  const int64_t W = a.wordbase[a.F];
+__global__ __launch_bounds__(1024) void rows_compact_kernel(const CompactArgs a) {
+  // blockIdx.y = field (uniform per workgroup: the per-field pointers and bases stay in scalar registers; a per-lane
+  // search of the field tables made this pass 70 us), blockIdx.x strides over the field's bitmap words
+  const int f = blockIdx.y;
+  const int64_t W = a.wordbase[f + 1] - a.wordbase[f];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
+  uint32_t* seen = a.seen[f];
+  uint8_t* marks = a.marks ? a.marks + a.wordbase[f] * 32 : nullptr;
+  const int64_t rowbase = a.rowbase[f];
   for (int64_t w0 = (int64_t)blockIdx.x * blockDim.x; w0 < W; w0 += stride) {  // (whole waves stay in the loop)
-    const int64_t w = w0 + threadIdx.x;
+    const int64_t wi = w0 + threadIdx.x;
     uint32_t bits = 0;
-    int f = 0;
-    int64_t wi = 0;
-    if (w < W) {
-      while (f + 1 < a.F && w >= a.wordbase[f + 1]) ++f;
-      wi = w - a.wordbase[f];
-      if (a.marks) {  // 32 mark bytes -> one bitmap word (this lane is the word's only writer), marks cleared
-        uint4* m = reinterpret_cast<uint4*>(a.marks + w * 32);
+    if (wi < W) {
+      if (marks) {  // 32 mark bytes -> one bitmap word (this lane is the word's only writer), marks cleared
+        uint4* m = reinterpret_cast<uint4*>(marks + wi * 32);
         const uint4 lo = m[0], hi = m[1];
-        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) {
+          const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
           for (int k = 0; k < 8; ++k)
 #pragma unroll
@@ -553,13 +561,13 @@ __global__ __launch_bounds__(256) void rows_compact_kernel(const CompactArgs a) 
               if ((q[k] >> (8 * j)) & 0xffu) bits |= 1u << (4 * k + j);
           m[0] = make_uint4(0, 0, 0, 0);
           m[1] = make_uint4(0, 0, 0, 0);
-          bits |= a.seen[f][wi];
-          a.seen[f][wi] = bits;
+          bits |= seen[wi];
+          seen[wi] = bits;
         } else {
-          bits = a.seen[f][wi];
+          bits = seen[wi];
         }
       } else {
-        bits = a.seen[f][wi];
+        bits = seen[wi];
       }
     }
     const int n = __popc(bits);
@@ -569,17 +577,24 @@ __global__ __launch_bounds__(256) void rows_compact_kernel(const CompactArgs a) 
       const int t = __shfl_up(pre, o);
       if (lane >= o) pre += t;
     }
-    const int total = __shfl(pre, 63);
-    int base = 0;
-    if (total) {
-      if (lane == 63) base = atomicAdd(a.count, total);
-      base = __shfl(base, 63);
+    // ... over the workgroup, then ONE counter atomic per 1024 words (a returning atomic on a single address runs at
+    // ~88 per microsecond chip-wide: one per wave made this pass 70 us)
+    __shared__ int wsum[16], wbase[16], gbase;
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) wsum[wv] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int k = 0; k < 16; ++k) { wbase[k] = run; run += wsum[k]; }
+      gbase = run ? atomicAdd(a.count, run) : 0;
     }
-    int pos = base + pre - n;
+    __syncthreads();
+    int pos = gbase + wbase[wv] + pre - n;
     while (bits) {
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1;
-      if (pos < a.cap) a.touched[pos] = (int32_t)(a.rowbase[f] + wi * 32 + b);
+      if (pos < a.cap) a.touched[pos] = (int32_t)(rowbase + wi * 32 + b);
       ++pos;
     }
   }
@@ -602,10 +617,11 @@ static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_
     set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
     return MML_ERR_HIP;
   }
-  int64_t blocks = cdiv(words, 256);
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  if (blocks < 1) blocks = 1;
-  MML_LAUNCH(rows_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, c);
+  int64_t maxw = 1;
+  for (int f = 0; f < a.F; ++f) maxw = (c.wordbase[f + 1] - c.wordbase[f] > maxw) ? c.wordbase[f + 1] - c.wordbase[f] : maxw;
+  int64_t blocks = cdiv(maxw, 1024);
+  if (blocks > 256 * 4) blocks = 256 * 4;
+  MML_LAUNCH(rows_compact_kernel, dim3((unsigned)blocks, (unsigned)a.F), dim3(1024), 0, stream, c);
   return check_launch(who);
 }
 
@@ -681,6 +697,26 @@ extern "C" int mml_gather_fwd(const float* const* tables, const int64_t* vocab, 
   GatherArgs a{};
   a.X = X; a.ldX = ldX; a.F = F; a.E = E; a.dense_col0 = dense_col0; a.Nd = Nd; a.B = B;
   a.out = out; a.ldo = ldo; a.status = status;
+  return launch_gather(ft, a, to_stream(stream));
+}
+
+extern "C" int mml_gather_fwd_mark(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                                   int32_t E, const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
+                                   float* out, int64_t ldo, uint8_t* row_marks, int32_t* status, mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, tables, vocab, col, F, "mml_gather_fwd_mark");
+  if (rc) return rc;
+  MML_REQUIRE(B >= 0 && E > 0 && Nd >= 0, "mml_gather_fwd_mark: bad sizes");
+  MML_REQUIRE(B == 0 || (X && out), "mml_gather_fwd_mark: null X/out");
+  MML_REQUIRE(ldo >= (int64_t)F * E + Nd, "mml_gather_fwd_mark: ldo too small");
+  GatherArgs a{};
+  a.X = X; a.ldX = ldX; a.F = F; a.E = E; a.dense_col0 = dense_col0; a.Nd = Nd; a.B = B;
+  a.out = out; a.ldo = ldo; a.status = status; a.marks = row_marks;
+  int64_t words = 0;
+  for (int f = 0; f < F; ++f) {
+    a.markbase[f] = words * 32;
+    words += (vocab[f] + 31) / 32;
+  }
   return launch_gather(ft, a, to_stream(stream));
 }
 
@@ -836,4 +872,23 @@ extern "C" int mml_index_unique_idx32(const int64_t* vocab, int32_t F, int32_t E
                                       mml_stream_t stream) {
   return unique_impl(vocab, nullptr, F, E, nullptr, 0, idx, ldi, B, seen, rowbase, touched, touched_count,
                      touched_cap, row_marks, status, stream);
+}
+
+extern "C" int mml_rows_compact(uint32_t* const* seen, const int64_t* vocab, const int64_t* rowbase, int32_t F,
+                                int32_t* touched, int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks,
+                                mml_stream_t stream) {
+  MML_REQUIRE(F >= 1 && F <= MML_MAX_FIELDS && seen && vocab && rowbase && touched && touched_count && touched_cap > 0,
+              "mml_rows_compact: bad arguments");
+  FieldTable ft;
+  ScatterArgs a{};
+  a.F = F;
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(vocab[f] > 0 && seen[f], "mml_rows_compact: field %d malformed", f);
+    ft.vocab[f] = vocab[f];
+    a.seen[f] = seen[f];
+    a.rowbase[f] = rowbase[f];
+  }
+  a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap;
+  set_marks(a, ft, row_marks);
+  return launch_compact(ft, a, to_stream(stream), "mml_rows_compact");
 }

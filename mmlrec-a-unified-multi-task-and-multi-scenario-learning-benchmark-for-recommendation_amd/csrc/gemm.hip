@@ -533,6 +533,25 @@ __device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o) {
   }
 }
 
+// (ablation, tools/lab: what the kernel would run at if the COLUMN operand -- the weights in fwd / dgrad -- arrived
+// already cut into planes: its conversion is replaced by a free bit-cast; results are garbage)
+template <int EMU, bool RC>
+__device__ __forceinline__ void prep_frag_b(const RawFrag<RC>& r, Prep<EMU>& o) {
+#ifdef MML_LAB_NO_CONVERT_B
+  if constexpr (EMU != 0) {
+    float x[8];
+    r.get(x);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t0 = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    u4 t1 = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+#pragma unroll
+    for (int p = 0; p < EMU; ++p) o.p[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
+    return;
+  }
+#endif
+  prep_frag<EMU>(r, o);
+}
+
 // acc += rows(a) x cols(b); the COLUMN operand is the MFMA's A input (a lane then owns an output row, see epilogue)
 template <int EMU>
 __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const Prep<EMU>& b) {
@@ -1158,7 +1177,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       }
     }
     prep_frag<EMU>(a0, PA0[0]);
-    prep_frag<EMU>(b0, PB0[0]);
+    prep_frag_b<EMU>(b0, PB0[0]);
   }
 
   auto step = [&](auto par_c) __attribute__((always_inline)) {
@@ -1212,7 +1231,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     unsigned long long t3 = 0;
 #endif
     if (NI == 2) {
-      prep_frag<EMU>(RB1[P], PB1);
+      prep_frag_b<EMU>(RB1[P], PB1);
       mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
       interleave_hint<NMFMA, NVALU>();
       __builtin_amdgcn_sched_barrier(0);
@@ -1239,7 +1258,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           bs_next[1] = sum8(RB1[Q]);
         }
       }
-      prep_frag<EMU>(nb0, PB0[Q]);
+      prep_frag_b<EMU>(nb0, PB0[Q]);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
       pin_prep<EMU>(PB0[Q]);
       interleave_hint<NMFMA, NVALU>();
@@ -1267,7 +1286,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           bs_next[0] = sum8(nb0);
         }
       }
-      prep_frag<EMU>(nb0, PB0[Q]);
+      prep_frag_b<EMU>(nb0, PB0[Q]);
       prep_frag<EMU>(na0, PA0[Q]);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
       pin_prep<EMU>(PB0[Q]);

@@ -270,6 +270,7 @@ class GatherOp(Op):
     def __init__(self, tables, X, cols, dense_col0, nd, out, sparse_rows=None):
         self.tables, self.X, self.cols, self.dense_col0, self.nd, self.out = tables, X, cols, dense_col0, nd, out
         self.sparse_rows = sparse_rows  # TableRows bookkeeping (seen bitmaps, touched list) or None
+        self.mark_rows = None  # TableRows: the forward marks the rows it reads and lists them (split dense update)
 
     def outputs(self):
         return [self.out]
@@ -291,6 +292,17 @@ class GatherOp(Op):
         plan.keep += [tabs, vocab, col]
         meta = dict(kernel="gather_vec4_kernel" if E % 4 == 0 else "gather_scalar_kernel",
                     bytes=float(plan.B) * (F * (4 + 8 * E) + 8 * self.nd))  # index + row read + row write
+        mr = self.mark_rows
+        if mr is not None:
+            ps = ops._ptr_array(mr.seen)
+            rb = (L.i64 * (F + 1))(*mr.rowbase)
+            plan.keep += [ps, rb]
+            return [(lib.mml_gather_fwd_mark, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X),
+                                               self.dense_col0, self.nd, plan.B, self.out.buf.data_ptr(),
+                                               ops._ld(self.out.buf), mr.marks.data_ptr(), plan.status.data_ptr()), meta),
+                    (lib.mml_rows_compact, (ps, vocab, rb, F, mr.touched.data_ptr(), mr.count.data_ptr(),
+                                            mr.touched.numel(), mr.marks.data_ptr()),
+                     dict(kernel="rows_compact_kernel", bytes=float(mr.marks.numel())))]
         return [(lib.mml_gather_fwd, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), self.dense_col0,
                                       self.nd, plan.B, self.out.buf.data_ptr(), ops._ld(self.out.buf),
                                       plan.status.data_ptr()), meta)]
@@ -1280,7 +1292,7 @@ class Optimizer:
         if self.table_update == "lazy_exact":
             pre += self._lazy_pre_calls(plan)
         split_dense = bool(split_dense) and self.can_split_dense(plan)
-        if split_dense:
+        if split_dense and getattr(plan.ops[0], "mark_rows", None) is None:  # (else the gather itself lists the rows)
             pre += self._unique_pre_calls(plan)
         calls = []
         reg = self._reg_map()

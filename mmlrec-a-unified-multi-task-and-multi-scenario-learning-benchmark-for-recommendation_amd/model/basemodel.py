@@ -227,7 +227,7 @@ class BaseModel(nn.Module):
             self._caches["plans"][key] = plan
         return plan
 
-    def _record(self, B, training, masked, store, sparse_rows=None, lazy=False):
+    def _record(self, B, training, masked, store, sparse_rows=None, lazy=False, mark_rows=None):
         plan = E.Plan(store.device, B, training)
         plan.bn_training = bool(self.training)
         plan.generation = 0
@@ -267,7 +267,9 @@ class BaseModel(nn.Module):
             op.x_in_pre = bool(lazy)  # lazy_exact gathers the global index matrix before its catch-up pass
             plan.add(op)
         else:  # single GPU, and inference on the (synchronised) full tables of a row-sharded / replicated model
-            plan.add(E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
+            gop = E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)
+            gop.mark_rows = mark_rows
+            plan.add(gop)
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)
         head.mask_cols = self._head_mask_cols()

@@ -43,7 +43,11 @@ class Segments:
         for p in self.parts:
             if p[0] == "c" and len(p[1]) >= self.min_calls:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: only THIS thread's calls are checked during capture.  In the default global mode an
+                # event query of RCCL's watchdog thread (it polls while a process group exists) is an illegal call
+                # during capture: it invalidates the capture or aborts the process at teardown (seen as a sporadic
+                # "Fatal Python error: Aborted" in destroy_process_group).
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     E.Plan._run(p[1])
                 p[2] = g
         self.captured = True
@@ -98,8 +102,10 @@ class TrainStep:
                 names = [f"embedding_dict.{sp[f].embedding_name}.weight" for f in par.sharding.mine]
                 rows = self.store.ensure_rows(par.world * int(B) * max(len(names), 1), names)
         # lazy_exact lists the batch's rows in a pre-pass (before the gather), so the scatter only accumulates
+        # single GPU: the gather marks the rows it reads (no separate pass over X); replicated tables need the rows of
+        # the GLOBAL batch, listed by the index pre-pass
         self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
-                                  lazy=lazy or split)
+                                  lazy=lazy or split, mark_rows=rows if (split and par is None) else None)
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
         self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +
@@ -118,10 +124,13 @@ class TrainStep:
         ar = [(E.PY, self._allreduce, (), dict(kernel="all_reduce(mlp grads)"))] if allreduce is not None else []
         # the touched-row update clears the `seen` bits the early pass is still reading: it waits for that pass
         wait = ([(E.PY, self._wait_early, (), dict(kernel="wait(early table pass)"))] if self.side2 is not None else [])
-        # (without an early pass the counter bump / lazy pre-pass simply lead the front graph)
-        self.pre = Segments(self.opt_split["pre"] if self.split_dense else [], self.use_graph)
+        # (without an early pass the counter bump / lazy pre-pass simply lead the front graph; with one, `pre` is
+        # everything the early pass waits for: the counter, and the row list -- from the index pre-pass, or from the
+        # marking gather + compaction that open the forward)
+        n_lead = 2 if (self.split_dense and getattr(p.ops[0], "mark_rows", None) is not None) else 0
+        self.pre = Segments((self.opt_split["pre"] + p.fwd[:n_lead]) if self.split_dense else [], self.use_graph)
         self.early = Segments(self.opt_split["early"], self.use_graph, min_calls=1)
-        self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd + p.head_train + p.bwd,
+        self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd[n_lead:] + p.head_train + p.bwd,
                               self.use_graph)
         self.sideq = Segments(p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
         self.tail = Segments(p.bwd_tail + wait + self.opt_split["tables"], self.use_graph)

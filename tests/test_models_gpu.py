@@ -281,6 +281,7 @@ def test_sharded_path_world1_matches_golden(mode):
                     assert dv.max() <= 2.5 * lr * ck, (case_name, kind, k)
     finally:
         if created:
+            torch.cuda.synchronize()
             dist.destroy_process_group()
 
 
