@@ -336,6 +336,21 @@ int mml_ew_mul_bwd(const float* dout, const float* a, const float* b, float* da,
 int mml_ew_mul_bwd_act(const float* dout, const float* a, const float* b, float* da, float* db, int32_t acc_a,
                        int32_t acc_b, int64_t n, int32_t act_a, int32_t act_b, mml_stream_t stream);
 int mml_ew_add_n(const float* const* in, int32_t n_in, float* out, int64_t n, mml_stream_t stream);
+/* n independent items in one launch (16 per kernel-argument block): out[i] (+)= sum_k x_k[i] * (y_k ? y_k[i] : 1).
+ * STAR's derived parameters -- W_spec[d] * W_shared and b_spec[d] + b_shared of every head and layer
+ * (SharedSpecificLinear, model/utils.py:214-216) -- and their gradients (d W_shared = sum_d dW_eff[d] * W_spec[d], ...)
+ * as one call each way instead of one launch per tensor.  `d` is a HOST array. */
+#define MML_SUMPROD_TERMS 8
+#define MML_SUMPROD_BATCH 16
+typedef struct mml_sumprod_desc {
+  float* out;
+  const float* x[MML_SUMPROD_TERMS];
+  const float* y[MML_SUMPROD_TERMS]; /* NULL = 1 */
+  int64_t n;
+  int32_t n_terms;
+  int32_t accumulate;
+} mml_sumprod_desc;
+int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_stream_t stream);
 /* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,
  * model/pepnet.py:72, :139) */
 int mml_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate,

@@ -71,6 +71,10 @@ class Copy2dDesc(C.Structure):
                 ("accumulate", i32)]
 
 
+class SumProdDesc(C.Structure):
+    _fields_ = [("out", fp), ("x", fp * 8), ("y", fp * 8), ("n", i64), ("n_terms", i32), ("accumulate", i32)]
+
+
 class Attn2Desc(C.Structure):
     _fields_ = [("V", fp * 2), ("K", fp * 2), ("Q", fp * 2), ("ldv", i64 * 2), ("ldk", i64 * 2), ("ldq", i64 * 2),
                 ("out", fp), ("ldo", i64), ("A", fp), ("dout", fp), ("lddo", i64), ("dV", fp * 2), ("dK", fp * 2),
@@ -120,6 +124,7 @@ _SIGS = {
     "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
     "mml_ew_mul_bwd_act": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, i32, i32, fp]),
     "mml_ew_add_n": (C.c_int, [_PP(fp), i32, fp, i64, fp]),
+    "mml_sumprod_batch": (C.c_int, [_PP(SumProdDesc), i32, fp]),
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),

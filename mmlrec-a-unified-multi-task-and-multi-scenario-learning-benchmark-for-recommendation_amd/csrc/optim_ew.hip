@@ -244,29 +244,54 @@ struct RowsLaunch {
   mml_opt_hyper h;
 };
 
+// One lane = one 16-byte piece of a touched row (E % 4 == 0; else one float): four independent element updates per
+// lane, and the row / field decode once per piece instead of once per float.
+template <int VEC>
 __global__ __launch_bounds__(256) void opt_rows_kernel(const RowsLaunch L) {
   const mml_opt_hyper& h = L.h;
   const StepConsts c = step_consts(h);
   int32_t cnt = *L.touched_count;
   if (cnt > L.cap) cnt = L.cap;
-  const int64_t total = (int64_t)cnt * L.E;
+  const int per_row = L.E / VEC;
+  const int64_t total = (int64_t)cnt * per_row;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
-    const int32_t li = (int32_t)(item / L.E);
-    const int e = (int)(item - (int64_t)li * L.E);
+    const int32_t li = (int32_t)(item / per_row);
+    const int e = (int)(item - (int64_t)li * per_row) * VEC;
     const int64_t grow = L.touched[li];
     int f = 0;
     while (f + 1 < L.F && grow >= L.rowbase[f + 1]) ++f;  // F <= 64: short scan (binary search not worth it)
     const int64_t row = grow - L.rowbase[f];
     const int64_t o = row * L.E + e;
-    float p = L.tab[f][o];
-    const float g = L.grad[f][o];
-    float a = L.s1[f] ? L.s1[f][o] : 0.f, b = L.s2[f] ? L.s2[f][o] : 0.f;
-    opt_update(h, c, p, g, a, b);
-    L.tab[f][o] = p;
-    if (L.s1[f]) L.s1[f][o] = a;
-    if (L.s2[f]) L.s2[f][o] = b;
-    L.grad[f][o] = 0.f;
+    float p[VEC], g[VEC], a[VEC], b[VEC];
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(L.tab[f] + o);
+      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(L.grad[f] + o);
+      if (L.s1[f]) *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(L.s1[f] + o);
+      if (L.s2[f]) *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(L.s2[f] + o);
+    } else {
+      p[0] = L.tab[f][o];
+      g[0] = L.grad[f][o];
+      if (L.s1[f]) a[0] = L.s1[f][o];
+      if (L.s2[f]) b[0] = L.s2[f][o];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (!L.s1[f]) a[k] = 0.f;
+      if (!L.s2[f]) b[k] = 0.f;
+      opt_update(h, c, p[k], g[k], a[k], b[k]);
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(L.tab[f] + o) = *reinterpret_cast<float4*>(p);
+      if (L.s1[f]) *reinterpret_cast<float4*>(L.s1[f] + o) = *reinterpret_cast<float4*>(a);
+      if (L.s2[f]) *reinterpret_cast<float4*>(L.s2[f] + o) = *reinterpret_cast<float4*>(b);
+      *reinterpret_cast<float4*>(L.grad[f] + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      L.tab[f][o] = p[0];
+      if (L.s1[f]) L.s1[f][o] = a[0];
+      if (L.s2[f]) L.s2[f][o] = b[0];
+      L.grad[f][o] = 0.f;
+    }
     if (e == 0) {
       atomicAnd(L.seen[f] + (row >> 5), ~(1u << (row & 31)));
       if (L.last[f]) L.last[f][row] = h.step_dev ? *h.step_dev : h.step;
@@ -411,6 +436,22 @@ __global__ __launch_bounds__(256) void ew_add_n_kernel(const AddN A, float* out,
     float s = 0.f;
     for (int k = 0; k < A.n_in; ++k) s += A.in[k][i];
     out[i] = s;
+  }
+}
+
+// n independent items in ONE launch: out[i] (+)= sum_k x_k[i] * (y_k ? y_k[i] : 1).  STAR's derived parameters
+// (W_spec * W_shared, b_spec + b_shared for every head and layer, model/utils.py:214-216) and their gradients were
+// ~60 launches of a few KB each per step; they are two launches each way now.
+struct SumProdBatch {
+  mml_sumprod_desc d[MML_SUMPROD_BATCH];
+};
+__global__ __launch_bounds__(256) void sumprod_batch_kernel(const SumProdBatch Bt) {
+  const mml_sumprod_desc& D = Bt.d[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.n; i += stride) {
+    float s = D.accumulate ? D.out[i] : 0.f;
+    for (int k = 0; k < D.n_terms; ++k) s += D.x[k][i] * (D.y[k] ? D.y[k][i] : 1.f);
+    D.out[i] = s;
   }
 }
 
@@ -664,9 +705,13 @@ extern "C" int mml_opt_step_rows(float* const* tables, float* const* grad_tables
   L.rowbase[F] = rowbase[F];
   L.F = F; L.E = E; L.touched = touched; L.touched_count = touched_count; L.cap = touched_cap; L.h = *hyper;
   // the row count lives on the device: size the grid for the capacity, surplus workgroups exit at once
-  int64_t blocks = cdiv((int64_t)touched_cap * E, 256);
+  bool vec = (E % 4 == 0);
+  for (int f = 0; f < F && vec; ++f)
+    vec = aligned16(L.tab[f]) && aligned16(L.grad[f]) && (!L.s1[f] || aligned16(L.s1[f])) && (!L.s2[f] || aligned16(L.s2[f]));
+  int64_t blocks = cdiv((int64_t)touched_cap * (vec ? E / 4 : E), 256);
   if (blocks > 256 * 8) blocks = 256 * 8;
-  MML_LAUNCH(opt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
+  if (vec) MML_LAUNCH(opt_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
+  else MML_LAUNCH(opt_rows_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), L);
   return check_launch("mml_opt_step_rows");
 }
 
@@ -789,4 +834,25 @@ extern "C" int mml_act_bwd(const float* y, const float* dy, float* dst, int64_t 
   if (n == 0) return MML_OK;
   MML_LAUNCH(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), y, dy, dst, n, act);
   return check_launch("mml_act_bwd");
+}
+
+extern "C" int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_sumprod_batch: bad descriptor array");
+  for (int i0 = 0; i0 < n; i0 += MML_SUMPROD_BATCH) {
+    SumProdBatch Bt{};
+    const int m = (n - i0 < MML_SUMPROD_BATCH) ? n - i0 : MML_SUMPROD_BATCH;
+    int64_t nmax = 0;
+    for (int i = 0; i < m; ++i) {
+      const mml_sumprod_desc& D = d[i0 + i];
+      MML_REQUIRE(D.out && D.n >= 0 && D.n_terms >= 0 && D.n_terms <= MML_SUMPROD_TERMS, "mml_sumprod_batch: item %d malformed", i0 + i);
+      for (int k = 0; k < D.n_terms; ++k) MML_REQUIRE(D.x[k], "mml_sumprod_batch: item %d term %d is null", i0 + i, k);
+      Bt.d[i] = D;
+      nmax = D.n > nmax ? D.n : nmax;
+    }
+    if (nmax == 0) continue;
+    MML_LAUNCH(sumprod_batch_kernel, dim3(ew_grid(nmax), (unsigned)m), dim3(256), 0, to_stream(stream), Bt);
+    int rc = check_launch("mml_sumprod_batch");
+    if (rc) return rc;
+  }
+  return MML_OK;
 }

@@ -1083,6 +1083,51 @@ class PMulOp(Op):
                  dict(kernel="ew_mul_bwd_kernel", side=True))]
 
 
+class SumProdBatchOp(Op):
+    """Derived parameters as ONE launch each way: out_j = sum_k x_jk * y_jk (y optional).  STAR: W_eff = W_spec * W_shared
+    and b_eff = b_spec + b_shared for every head and layer (model/utils.py:214-216); the backward sums every factor's
+    gradient over the items it appears in (d W_shared = sum_heads dW_eff * W_spec) -- fixed order, no atomics.
+    items: (out PVal, [(x PVal, y PVal or None), ...])."""
+
+    def __init__(self, items):
+        self.items = items
+
+    @staticmethod
+    def _descs(plan, rows):
+        arr = (L.SumProdDesc * len(rows))()
+        for d, (out, terms, acc) in zip(arr, rows):
+            if len(terms) > 8:
+                raise NotImplementedError("more than 8 terms in one derived-parameter sum")
+            d.out, d.n, d.n_terms, d.accumulate = out.data_ptr(), out.numel(), len(terms), int(acc)
+            for k, (x, y) in enumerate(terms):
+                if x.numel() != out.numel() or (y is not None and y.numel() != out.numel()):
+                    raise L.MMLError("SumProdBatchOp: operand size mismatch")
+                d.x[k], d.y[k] = x.data_ptr(), (y.data_ptr() if y is not None else None)
+        plan.keep.append(arr)
+        return arr
+
+    def fwd_calls(self, plan):
+        rows = [(out.data, [(x.data, y.data if y is not None else None) for x, y in terms], 0)
+                for out, terms in self.items]
+        return [(L.load().mml_sumprod_batch, (self._descs(plan, rows), len(rows)),
+                 dict(kernel="sumprod_batch_kernel", bytes=12.0 * sum(o.data.numel() for o, _ in self.items)))]
+
+    def bwd_calls(self, plan):
+        grads = {}  # id(param) -> (param, [(dout, other factor or None)])
+        for out, terms in self.items:
+            if not out.written:
+                continue
+            for x, y in terms:
+                for p, other in ((x, y), (y, x)):
+                    if p is not None and p.needs_grad:
+                        grads.setdefault(id(p), (p, []))[1].append((out.grad, other.data if other is not None else None))
+        rows = [(p.grad, terms, _claim(p)) for p, terms in grads.values()]
+        if not rows:
+            return []
+        return [(L.load().mml_sumprod_batch, (self._descs(plan, rows), len(rows)),
+                 dict(kernel="sumprod_batch_kernel", side=True))]
+
+
 class SnrWeightsOp(Op):
     """Routing weights of an SNR-trans / MSSM gate (model/snr_trans.py:38-50, model/mssm.py:40-58): W[o][j] =
     M[o][j] scaled by the hard-concrete z(u, alpha) -- one coefficient per block (u: PVal [No, Ne], learned) or one per

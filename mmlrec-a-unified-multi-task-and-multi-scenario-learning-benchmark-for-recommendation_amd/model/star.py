@@ -50,8 +50,9 @@ class STAR(BaseModel):
         wsh, bsh = store.pvals[f"{prefix}.shared_weight"], store.pvals[f"{prefix}.shared_bias"]
         weff = E.PVal(plan.empty(*wsh.data.shape), plan.zeros(*wsh.data.shape), f"{prefix}.weff.{d}")
         beff = E.PVal(plan.empty(*bsh.data.shape), plan.zeros(*bsh.data.shape), f"{prefix}.beff.{d}")
-        plan.add(E.PMulOp(ws, wsh, weff))
-        plan.add(E.PAddOp([bs, bsh], beff))
+        # (collected: ALL derived parameters of the model are produced by one batched launch, see _build_graph)
+        self._derived.append((weff, [(ws, wsh)]))
+        self._derived.append((beff, [(bs, None), (bsh, None)]))
         return weff, beff
 
     def _build_graph(self, plan, store, x0):
@@ -62,10 +63,17 @@ class STAR(BaseModel):
                                       f"622): {T} heads against {plan.mask.shape[1]} mask columns fail in the reference")
         hs = [x0] * T
         per_layer = []
+        # K6: the Hadamard products / bias sums of every head and layer (and, on the way back, the sums of
+        # their gradients over the heads) are ONE batched launch each way, issued before the first GEMM
+        self._derived = []
+        eff = {(j, i): self._star_params(plan, store, f"linears.{j}", self.linears[j], i)
+               for j in range(nl) for i in range(T)}
+        eff_final = [self._star_params(plan, store, f"final_layers.{i}", self.final_layers[i], i) for i in range(T)]
+        plan.add(E.SumProdBatchOp(self._derived))
         for j in range(nl):
             probs = []
             for i in range(T):
-                weff, beff = self._star_params(plan, store, f"linears.{j}", self.linears[j], i)
+                weff, beff = eff[(j, i)]
                 o = plan.val(self.dnn_hidden_units[j], act=self.act_code, name=f"star.{j}.{i}")
                 probs.append(dict(x=hs[i], W=weff, b=beff, out=o, w_kn=1))
             plan.add(E.LinearGroupOp(probs))
@@ -81,6 +89,6 @@ class STAR(BaseModel):
             plan.layer_outputs[f"star_output_{j}"] = hs
         heads = []
         for i in range(T):
-            weff, beff = self._star_params(plan, store, f"final_layers.{i}", self.final_layers[i], i)
+            weff, beff = eff_final[i]
             heads.append(dict(Hin=hs[i], w=weff, bias=store.pvals[f"out.{i}.bias"], bias2=beff))
         return E.HeadOp(heads)
