@@ -254,9 +254,9 @@ def main():
                           loss=float(runner.plan.loss.item()) / B)
         if B == args.batch:
             runner0 = runner
-            acc = kernel_breakdown(runner, batches, min(args.steps, 10))
-            results[B]["acc"] = acc
-            results[B]["bsteps"] = min(args.steps, 10)
+        acc = kernel_breakdown(runner, batches, min(args.steps, 10))
+        results[B]["acc"] = acc
+        results[B]["bsteps"] = min(args.steps, 10)
 
     # forward-only path (predict / evaluate reuse the gather, GEMM, gate and head kernels):
     # model.forward in eval mode under no_grad, as predict() calls it -- includes the input copy, the output clone
@@ -351,6 +351,14 @@ def main():
         r = results[args.alt_batch]
         line["alt"] = {"batch_per_gpu": args.alt_batch, "value": round(r["value"], 1), "unit": "samples/s",
                        "ms_per_step": round(r["ms"], 4), "steps": r["steps"]}
+        try:  # the reference's own batch size is launch- / latency-bound: its dominant kernel and roofline fraction too
+            ra = roofline_of(r["acc"])
+            ra["launches_per_step"] = r["acc"][ra["kernel"]]["launches"] / r["bsteps"]
+            ra["traffic"] = None  # (the PMC summary under profiles/ is taken at the headline batch)
+            line["alt"]["roofline"] = ra
+            line["alt"]["launches_per_step"] = sum(v["launches"] for v in r["acc"].values()) / r["bsteps"]
+        except Exception:
+            pass
     if infer:
         line["inference"] = infer
     if lazy:

@@ -155,6 +155,23 @@ int mml_rows_permute(const float* src, int64_t lds, const int32_t* pos, int32_t 
                      mml_stream_t stream);
 int mml_shard_rows(float* table, int64_t V, float* shard, int64_t rows_local, int32_t E, int32_t world, int32_t first,
                    int32_t to_table, mml_stream_t stream);
+/* Requester-side de-duplication: route the batch's DISTINCT rows (the touched list of mml_index_unique: global row ids
+ * rowbase[f] + r, *count of them on the device, capacity cap) instead of its B*F lookups -- under Zipf a 65 536-sample
+ * AliExpress-shaped batch holds 209 k distinct rows against 1.97 M lookups.
+ *   mml_route_list_count / _place   as mml_route_count / _place, over the list; _place also writes
+ *                                   slot_of[global row id] = position of the row's key in send_keys
+ *   mml_lookup_slots                pos[b*F + f] = slot_of[rowbase[f] + trunc(X[b, col[f]])]  (indices validated / clamped)
+ *   mml_rows_clear                  clears the `seen` words of the listed rows (requester-side bitmaps)
+ * slot_of is a DEVICE int32 array of rowbase[F] entries (only the listed rows are written / read). */
+int mml_route_list_count(const int32_t* list, const int32_t* count, int32_t cap, const int64_t* vocab,
+                         const int64_t* rowbase, int32_t F, int32_t world, int32_t* counters, mml_stream_t stream);
+int mml_route_list_place(const int32_t* list, const int32_t* count, int32_t cap, const int64_t* vocab,
+                         const int64_t* rowbase, const int64_t* keybase, int32_t F, int32_t world, int32_t* counters,
+                         int32_t* send_keys, int32_t* slot_of, mml_stream_t stream);
+int mml_lookup_slots(const float* X, int64_t ldX, const int32_t* col, const int64_t* vocab, const int64_t* rowbase,
+                     int32_t F, int64_t B, const int32_t* slot_of, int32_t* pos, int32_t* status, mml_stream_t stream);
+int mml_rows_clear(const int32_t* list, const int32_t* count, int32_t cap, const int64_t* rowbase,
+                   uint32_t* const* seen, int32_t F, mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3  grouped GEMM family on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).

@@ -104,6 +104,10 @@ _SIGS = {
     "mml_route_count": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), i32, i64, i32, fp, fp, fp]),
     "mml_route_place": (C.c_int, [fp, i64, fp, i64, _PP(i32), _PP(i64), _PP(i64), i32, i64, i32, fp, fp, fp, fp, fp]),
     "mml_rows_permute": (C.c_int, [fp, i64, fp, i32, i32, i64, fp, fp]),
+    "mml_route_list_count": (C.c_int, [fp, fp, i32, _PP(i64), _PP(i64), i32, i32, fp, fp]),
+    "mml_route_list_place": (C.c_int, [fp, fp, i32, _PP(i64), _PP(i64), _PP(i64), i32, i32, fp, fp, fp, fp]),
+    "mml_lookup_slots": (C.c_int, [fp, i64, _PP(i32), _PP(i64), _PP(i64), i32, i64, fp, fp, fp, fp]),
+    "mml_rows_clear": (C.c_int, [fp, fp, i32, _PP(i64), _PP(fp), i32, fp]),
     "mml_shard_rows": (C.c_int, [fp, i64, fp, i64, i32, i32, i32, i32, fp]),
     "mml_gemm_set_mode": (C.c_int, [i32]),
     "mml_gemm_get_mode": (C.c_int, []),

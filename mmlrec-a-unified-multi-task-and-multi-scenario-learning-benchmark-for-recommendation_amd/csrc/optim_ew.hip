@@ -244,12 +244,37 @@ struct RowsLaunch {
   mml_opt_hyper h;
 };
 
+// field of a global row id: bisection of an LDS copy of rowbase (a per-lane scan of the kernel-argument array is a
+// chain of up to F dependent loads: it was most of the touched-row kernels' time)
+__device__ __forceinline__ int field_of_row(const int64_t* rb_lds, int F, int64_t grow) {
+  int lo = 0, hi = F;  // largest f with rb[f] <= grow
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rb_lds[mid] <= grow) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
 // One lane = one 16-byte piece of a touched row (E % 4 == 0; else one float): four independent element updates per
 // lane, and the row / field decode once per piece instead of once per float.
 template <int VEC>
 __global__ __launch_bounds__(256) void opt_rows_kernel(const RowsLaunch L) {
   const mml_opt_hyper& h = L.h;
-  const StepConsts c = step_consts(h);
+  // per-field descriptors in LDS: a per-lane index into the kernel-argument arrays is a memory load per use
+  __shared__ int64_t rb_lds[MML_MAX_FIELDS + 1];
+  __shared__ float* tab_l[MML_MAX_FIELDS];
+  __shared__ float* grad_l[MML_MAX_FIELDS];
+  __shared__ float* s1_l[MML_MAX_FIELDS];
+  __shared__ float* s2_l[MML_MAX_FIELDS];
+  __shared__ uint32_t* seen_l[MML_MAX_FIELDS];
+  __shared__ int32_t* last_l[MML_MAX_FIELDS];
+  for (int i = threadIdx.x; i <= L.F; i += 256) rb_lds[i] = L.rowbase[i];
+  for (int i = threadIdx.x; i < L.F; i += 256) {
+    tab_l[i] = L.tab[i]; grad_l[i] = L.grad[i]; s1_l[i] = L.s1[i]; s2_l[i] = L.s2[i]; seen_l[i] = L.seen[i];
+    last_l[i] = L.last[i];
+  }
+  const StepConsts c = step_consts(h);  // (contains the __syncthreads that publishes rb_lds)
   int32_t cnt = *L.touched_count;
   if (cnt > L.cap) cnt = L.cap;
   const int per_row = L.E / VEC;
@@ -259,42 +284,45 @@ __global__ __launch_bounds__(256) void opt_rows_kernel(const RowsLaunch L) {
     const int32_t li = (int32_t)(item / per_row);
     const int e = (int)(item - (int64_t)li * per_row) * VEC;
     const int64_t grow = L.touched[li];
-    int f = 0;
-    while (f + 1 < L.F && grow >= L.rowbase[f + 1]) ++f;  // F <= 64: short scan (binary search not worth it)
-    const int64_t row = grow - L.rowbase[f];
+    const int f = field_of_row(rb_lds, L.F, grow);
+    const int64_t row = grow - rb_lds[f];
     const int64_t o = row * L.E + e;
+    float* const T_ = tab_l[f];
+    float* const G_ = grad_l[f];
+    float* const S1 = s1_l[f];
+    float* const S2 = s2_l[f];
     float p[VEC], g[VEC], a[VEC], b[VEC];
     if (VEC == 4) {
-      *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(L.tab[f] + o);
-      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(L.grad[f] + o);
-      if (L.s1[f]) *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(L.s1[f] + o);
-      if (L.s2[f]) *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(L.s2[f] + o);
+      *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(T_ + o);
+      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(G_ + o);
+      if (S1) *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(S1 + o);
+      if (S2) *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(S2 + o);
     } else {
-      p[0] = L.tab[f][o];
-      g[0] = L.grad[f][o];
-      if (L.s1[f]) a[0] = L.s1[f][o];
-      if (L.s2[f]) b[0] = L.s2[f][o];
+      p[0] = T_[o];
+      g[0] = G_[o];
+      if (S1) a[0] = S1[o];
+      if (S2) b[0] = S2[o];
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      if (!L.s1[f]) a[k] = 0.f;
-      if (!L.s2[f]) b[k] = 0.f;
+      if (!S1) a[k] = 0.f;
+      if (!S2) b[k] = 0.f;
       opt_update(h, c, p[k], g[k], a[k], b[k]);
     }
     if (VEC == 4) {
-      *reinterpret_cast<float4*>(L.tab[f] + o) = *reinterpret_cast<float4*>(p);
-      if (L.s1[f]) *reinterpret_cast<float4*>(L.s1[f] + o) = *reinterpret_cast<float4*>(a);
-      if (L.s2[f]) *reinterpret_cast<float4*>(L.s2[f] + o) = *reinterpret_cast<float4*>(b);
-      *reinterpret_cast<float4*>(L.grad[f] + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(T_ + o) = *reinterpret_cast<float4*>(p);
+      if (S1) *reinterpret_cast<float4*>(S1 + o) = *reinterpret_cast<float4*>(a);
+      if (S2) *reinterpret_cast<float4*>(S2 + o) = *reinterpret_cast<float4*>(b);
+      *reinterpret_cast<float4*>(G_ + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      L.tab[f][o] = p[0];
-      if (L.s1[f]) L.s1[f][o] = a[0];
-      if (L.s2[f]) L.s2[f][o] = b[0];
-      L.grad[f][o] = 0.f;
+      T_[o] = p[0];
+      if (S1) S1[o] = a[0];
+      if (S2) S2[o] = b[0];
+      G_[o] = 0.f;
     }
     if (e == 0) {
-      atomicAnd(L.seen[f] + (row >> 5), ~(1u << (row & 31)));
-      if (L.last[f]) L.last[f][row] = h.step_dev ? *h.step_dev : h.step;
+      atomicAnd(seen_l[f] + (row >> 5), ~(1u << (row & 31)));
+      if (last_l[f]) last_l[f][row] = h.step_dev ? *h.step_dev : h.step;
     }
   }
 }
@@ -353,6 +381,11 @@ struct CatchupLaunch {
 };
 
 __global__ __launch_bounds__(256) void opt_catchup_kernel(const CatchupLaunch L) {
+  __shared__ int64_t rb_lds[MML_MAX_FIELDS + 1];
+  if (!L.dense) {
+    for (int i = threadIdx.x; i <= L.F; i += 256) rb_lds[i] = L.rowbase[i];
+    __syncthreads();
+  }
   const mml_opt_hyper& h = L.h;
   const int target = (h.step_dev ? *h.step_dev : h.step) - (L.dense ? 0 : 1);
   int64_t nrows;
@@ -371,8 +404,8 @@ __global__ __launch_bounds__(256) void opt_catchup_kernel(const CatchupLaunch L)
     int64_t row = li;
     if (!L.dense) {
       const int64_t grow = L.touched[li];
-      while (f + 1 < L.F && grow >= L.rowbase[f + 1]) ++f;
-      row = grow - L.rowbase[f];
+      f = field_of_row(rb_lds, L.F, grow);
+      row = grow - rb_lds[f];
     }
     const int from = L.last[f][row];
     if (from >= target) continue;

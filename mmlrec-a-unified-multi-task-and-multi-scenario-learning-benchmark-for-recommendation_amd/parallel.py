@@ -150,7 +150,11 @@ class RowShardedGatherOp(E.Op):
         self.shard, self.X, self.cols, self.dense_col0, self.nd, self.out = shard_pv, X, cols, dense_col0, nd, out
         self.sparse_rows = sparse_rows
         self.lazy_launch = None
-        self.stats = {"n_recv": 0, "steps": 0}
+        # requester-side de-duplication: the exchange carries every DISTINCT row of the local batch once (under Zipf a
+        # 65 536-sample AE-30 batch holds 209 k distinct rows against 1.97 M lookups), gradients of duplicates are
+        # summed locally before they travel
+        self.dedup = bool(getattr(par, "dedup", True))
+        self.stats = {"n_recv": 0, "n_sent": 0, "lookups": 0, "steps": 0}
 
     def outputs(self):
         return [self.out]
@@ -177,6 +181,11 @@ class RowShardedGatherOp(E.Op):
         self.x_tab = ops._ptr_array([self.rows_recv] * F)
         self.x_vocab = (L.i64 * F)(*([B * F] * F))
         self.status = plan.status
+        if self.dedup:
+            self.req = E.TableRows(sh.vocab, dev, B * F)   # requester-side row set of the LOCAL batch (full vocabulary)
+            self.req_seen = ops._ptr_array(self.req.seen)
+            self.req_rb = (L.i64 * (F + 1))(*self.req.rowbase)
+            self.slot_of = torch.empty(self.req.rowbase[-1], dtype=torch.int32, device=dev)
         plan.keep.append(self)
         return [(E.PY, self._forward, (), dict(kernel="row_sharded_forward_exchange"))]
 
@@ -187,6 +196,7 @@ class RowShardedGatherOp(E.Op):
             raise L.MMLError("row-sharded tables need the shard's gradient accumulator (ParamStore.ensure_table_grads)")
         E._claim(self.shard)
         self.grad_send = torch.empty(self.B * self.F, self.sh.emb, dtype=torch.float32, device=plan.device)
+        self.d_tab = ops._ptr_array([self.grad_send] * self.F)
         self.o_grad = ops._ptr_array([self.shard.grad])
         sr = self.sparse_rows
         if sr is not None:
@@ -213,27 +223,47 @@ class RowShardedGatherOp(E.Op):
         B, F, W, Em = self.B, self.F, sh.world, sh.emb
         Xp, ldX = self.X.data_ptr(), ops._ld(self.X)
         st = self.status.data_ptr()
-        L.check(lib.mml_route_count(Xp, ldX, None, 0, self.col, self.vocab, F, B, W, self.counters.data_ptr(), st, s),
-                "mml_route_count")
-        self.cnt_pair[0].copy_(self.counters[:W])  # (mml_route_place moves the cursors, not the counts)
-        L.check(lib.mml_route_place(Xp, ldX, None, 0, self.col, self.vocab, self.keybase, F, B, W,
-                                    self.counters.data_ptr(), self.send_keys.data_ptr(), self.pos.data_ptr(), st, s),
-                "mml_route_place")
+        cp = self.counters.data_ptr()
+        if self.dedup:
+            rq = self.req
+            tl, tc, cap = rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel()
+            L.check(lib.mml_index_unique(self.vocab, self.col, F, min(Em, 16), Xp, ldX, B, self.req_seen, self.req_rb, tl,
+                                         tc, cap, rq.marks.data_ptr(), st, s), "mml_index_unique(requester)")
+            L.check(lib.mml_route_list_count(tl, tc, cap, self.vocab, self.req_rb, F, W, cp, s), "mml_route_list_count")
+            self.cnt_pair[0].copy_(self.counters[:W])
+            L.check(lib.mml_route_list_place(tl, tc, cap, self.vocab, self.req_rb, self.keybase, F, W, cp,
+                                             self.send_keys.data_ptr(), self.slot_of.data_ptr(), s),
+                    "mml_route_list_place")
+        else:
+            L.check(lib.mml_route_count(Xp, ldX, None, 0, self.col, self.vocab, F, B, W, cp, st, s), "mml_route_count")
+            self.cnt_pair[0].copy_(self.counters[:W])  # (mml_route_place moves the cursors, not the counts)
+            L.check(lib.mml_route_place(Xp, ldX, None, 0, self.col, self.vocab, self.keybase, F, B, W, cp,
+                                        self.send_keys.data_ptr(), self.pos.data_ptr(), st, s), "mml_route_place")
         comm.all_to_all_single(self.cnt_pair[1], self.cnt_pair[0])
         pair = self.cnt_pair.cpu()  # the one host read of the step: split sizes of the three exchanges
         self.send_splits, self.recv_splits = pair[0].tolist(), pair[1].tolist()
         n = self.n_recv = int(sum(self.recv_splits))
+        u = self.n_send = int(sum(self.send_splits))  # == B * F without de-duplication
         self.stats["n_recv"] += n
+        self.stats["n_sent"] += u
+        self.stats["lookups"] += B * F
         self.stats["steps"] += 1
         self._grow(n)
-        comm.all_to_all_single(self.recv_keys[:n], self.send_keys, self.recv_splits, self.send_splits)
+        comm.all_to_all_single(self.recv_keys[:n], self.send_keys[:u], self.recv_splits, self.send_splits)
         if self.lazy_launch is not None:  # bring exactly the rows about to be read up to date (lazy-exact Adam)
             self.lazy_launch(self.recv_keys.data_ptr(), n, s)
         if n:
             L.check(lib.mml_gather_fwd_idx32(self.o_tab, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, None, 0, 0,
                                              n, self.rows_send.data_ptr(), Em, st, s), "mml_gather_fwd_idx32(owner)")
-        comm.all_to_all_single(self.rows_recv.view(-1), self.rows_send.view(-1)[:n * Em],
+        comm.all_to_all_single(self.rows_recv.view(-1)[:u * Em], self.rows_send.view(-1)[:n * Em],
                                [c * Em for c in self.send_splits], [c * Em for c in self.recv_splits])
+        if self.dedup:  # position of every lookup's row in the returned block, then the requester's bitmaps are reset
+            rq = self.req
+            L.check(lib.mml_lookup_slots(Xp, ldX, self.col, self.vocab, self.req_rb, F, B, self.slot_of.data_ptr(),
+                                         self.pos.data_ptr(), st, s), "mml_lookup_slots")
+            L.check(lib.mml_rows_clear(rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel(), self.req_rb,
+                                       self.req_seen, F, s), "mml_rows_clear")
+            L.check(lib.mml_counter_update(rq.count.data_ptr(), 0, 1, s), "mml_counter_update")
         dense = self.X[:, self.dense_col0:].data_ptr() if self.nd else None
         L.check(lib.mml_gather_fwd_idx32(self.x_tab, self.x_vocab, F, Em, self.pos.data_ptr(), F, dense, ldX, self.nd, B,
                                          self.out.buf.data_ptr(), ops._ld(self.out.buf), st, s),
@@ -242,11 +272,17 @@ class RowShardedGatherOp(E.Op):
     def _backward(self):
         lib, sh, comm = L.load(), self.sh, self.comm
         s = ops._stream()
-        B, F, Em, n = self.B, self.F, sh.emb, self.n_recv
+        B, F, Em, n, u = self.B, self.F, sh.emb, self.n_recv, self.n_send
         g = self.out.grad
-        L.check(lib.mml_rows_permute(g.data_ptr(), ops._ld(g), self.pos.data_ptr(), F, Em, B, self.grad_send.data_ptr(),
-                                     s), "mml_rows_permute")
-        comm.all_to_all_single(self.grad_recv.view(-1)[:n * Em], self.grad_send.view(-1),
+        if self.dedup:  # gradients of duplicate lookups are summed HERE, one row per distinct key travels
+            self.grad_send[:u].zero_()
+            L.check(lib.mml_scatter_bwd_idx32(self.d_tab, self.x_vocab, F, Em, self.pos.data_ptr(), F, B, g.data_ptr(),
+                                              ops._ld(g), None, None, None, None, 0, None, self.status.data_ptr(), s),
+                    "mml_scatter_bwd_idx32(requester)")
+        else:
+            L.check(lib.mml_rows_permute(g.data_ptr(), ops._ld(g), self.pos.data_ptr(), F, Em, B,
+                                         self.grad_send.data_ptr(), s), "mml_rows_permute")
+        comm.all_to_all_single(self.grad_recv.view(-1)[:n * Em], self.grad_send.view(-1)[:u * Em],
                                [c * Em for c in self.recv_splits], [c * Em for c in self.send_splits])
         if n:
             L.check(lib.mml_scatter_bwd_idx32(self.o_grad, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, n,
@@ -509,7 +545,7 @@ def _full_tables(model):
     return [model.embedding_dict[f.embedding_name].weight.data for f in model._sparse_cols()]
 
 
-def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded"):
+def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded", dedup=True):
     """Switch a model to multi-GPU execution on the current process group (collective: every rank calls it on an
     identically initialised model).  Returns the ParallelState (also stored as model._parallel)."""
     if mode not in MODES:
@@ -524,6 +560,7 @@ def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded"
     else:
         sharding = None
     par = ParallelState(comm, mode, sharding)
+    par.dedup = bool(dedup)  # row_sharded: exchange the batch's distinct rows instead of its lookups
     if mode == "row_sharded":
         tabs = _full_tables(model)
         if not tabs[0].is_cuda:

@@ -770,6 +770,58 @@ def test_route_expand_permute(ops, world, E, nd, B):
     out = ops.gather_fwd_idx32([rows_recv] * F, T(pos.astype(np.int32)), T(X[:, F:].copy()) if nd else None)
     ref = np.concatenate([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # ---- requester-side de-duplication: the distinct rows are routed, every lookup finds its row's slot
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    rowbase = np.concatenate([[0], np.cumsum(vocab)]).tolist()
+    seen = [torch.zeros((v + 31) // 32, dtype=torch.int32, device=dev()) for v in vocab]
+    marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=dev())
+    tl = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    tc = torch.zeros(1, dtype=torch.int32, device=dev())
+    Xd = T(X)
+    ops.index_unique(vocab, list(range(F)), min(E, 16), Xd, seen, rowbase, tl, tc, marks=marks)
+    uniq = np.unique(np.concatenate([idx[:, f] + rowbase[f] for f in range(F)]))
+    assert int(tc.item()) == len(uniq)
+    counters = torch.zeros(2 * world, dtype=torch.int32, device=dev())
+    voc, rb, kb = (L.i64 * F)(*vocab), (L.i64 * (F + 1))(*rowbase), (L.i64 * F)(*sh.keybase[:F])
+    st = ops._stream()
+    L.check(lib.mml_route_list_count(tl.data_ptr(), tc.data_ptr(), tl.numel(), voc, rb, F, world, counters.data_ptr(), st),
+            "mml_route_list_count")
+    cnt_d = counters[:world].cpu().numpy().copy()
+    keys_d = torch.full((B * F,), -1, dtype=torch.int32, device=dev())
+    slot_of = torch.full((rowbase[-1],), -1, dtype=torch.int32, device=dev())
+    L.check(lib.mml_route_list_place(tl.data_ptr(), tc.data_ptr(), tl.numel(), voc, rb, kb, F, world,
+                                     counters.data_ptr(), keys_d.data_ptr(), slot_of.data_ptr(), st), "mml_route_list_place")
+    pos_d = torch.empty(B, F, dtype=torch.int32, device=dev())
+    colv = (L.i32 * F)(*range(F))
+    L.check(lib.mml_lookup_slots(Xd.data_ptr(), Xd.stride(0), colv, voc, rb, F, B, slot_of.data_ptr(), pos_d.data_ptr(),
+                                 None, st), "mml_lookup_slots")
+    uf = np.searchsorted(np.array(rowbase), uniq, side="right") - 1       # field of every distinct row
+    ur = uniq - np.array(rowbase)[uf]
+    assert np.array_equal(cnt_d, np.bincount((ur + uf) % world, minlength=world))
+    u = len(uniq)
+    kd, pd = keys_d.cpu().numpy(), pos_d.cpu().numpy()
+    assert pd.min() >= 0 and pd.max() < u
+    assert np.array_equal(kd[pd], key)                                     # every lookup lands on its row's key
+    off_d = np.concatenate([[0], np.cumsum(cnt_d)])
+    assert np.array_equal(np.searchsorted(off_d, pd, side="right") - 1, own)
+    assert len(np.unique(pd)) == u                                         # one slot per distinct row
+    rows_d = torch.empty(u, E, device=dev())
+    for r in range(world):
+        seg = torch.from_numpy(kd[off_d[r]:off_d[r + 1]].astype(np.int32)).to(dev()).view(-1, 1)
+        if seg.numel():
+            rows_d[off_d[r]:off_d[r + 1]] = ops.gather_fwd_idx32([shards[r]], seg)
+    out_d = ops.gather_fwd_idx32([rows_d] * F, pos_d, T(X[:, F:].copy()) if nd else None)
+    assert np.array_equal(out_d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    L.check(lib.mml_rows_clear(tl.data_ptr(), tc.data_ptr(), tl.numel(), rb, ops._ptr_array(seen), F, st), "mml_rows_clear")
+    assert all(int(sn.abs().max().item()) == 0 for sn in seen) and int(marks.max().item()) == 0
+    # gradients of duplicates summed into the slot of their row (what travels in the de-duplicated exchange)
+    dg = rng.standard_normal((B, F * E)).astype(np.float32)
+    gsend = torch.zeros(u, E, device=dev())
+    ops.scatter_bwd_idx32([gsend] * F, pos_d, T(dg))
+    want_g = np.zeros((u, E), np.float64)
+    np.add.at(want_g, pd.ravel(), dg.reshape(B * F, E).astype(np.float64))
+    assert rel(gsend.cpu().numpy(), want_g) < 1e-5
     # inverse: pack per-sample gradient pieces into the send order
     d_out = rng.standard_normal((B, F * E + nd)).astype(np.float32)
     packed = torch.zeros(B * F, E, device=dev())

@@ -234,7 +234,7 @@ def test_dense_update_split_equals_single_launch(kind):
             assert np.array_equal(a[k][mask], b[k][mask]), k
 
 
-@pytest.mark.parametrize("mode", ["row_sharded", "replicated", "table_wise"])
+@pytest.mark.parametrize("mode", ["row_sharded", "row_sharded_nodedup", "replicated", "table_wise"])
 def test_sharded_path_world1_matches_golden(mode):
     """The multi-GPU execution paths (parallel.MODES) on a 1-rank RCCL group -- route / pack -> all_to_all or
     all_gather -> owner gather / scatter -> unpack, with the exchange-free segments replayed from HIP graphs -- must
@@ -249,6 +249,8 @@ def test_sharded_path_world1_matches_golden(mode):
         created = True
     try:
         from mmlrec_amd import parallel
+        dedup = not mode.endswith("_nodedup")
+        mode = mode.replace("_nodedup", "")
         combos = [("adam", "dense_exact", 3), ("adagrad", "sparse_rows", 3)]
         if mode != "table_wise":
             combos.append(("adam", "lazy_exact", 3))
@@ -259,7 +261,7 @@ def test_sharded_path_world1_matches_golden(mode):
                 load_state(model, g)
                 model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
                 model.train()
-                par = parallel.shard_model(model, dist, 64, mode=mode)
+                par = parallel.shard_model(model, dist, 64, mode=mode, dedup=dedup)
                 losses = []
                 for i in range(3):
                     step = model.train_step_runner(64)

@@ -55,7 +55,9 @@ def _worker(rank, world, port, jobs, ret):
             load_state(model, g)
             model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
             model.train()
-            par = parallel.shard_model(model, dist, 64 // world, mode=mode)
+            dedup = not mode.endswith("_nodedup")  # row_sharded: distinct rows (default) or every lookup travels
+            mode = mode.replace("_nodedup", "")
+            par = parallel.shard_model(model, dist, 64 // world, mode=mode, dedup=dedup)
             losses = []
             for i in range(3):
                 X = torch.from_numpy(g[f"X{i}"])[rank::world].contiguous().cuda()
@@ -103,6 +105,8 @@ def test_world2_steps_match_reference_trajectories():
             jobs.append((case_name, mode, "adam", "dense_exact", True))
             jobs.append((case_name, mode, "adagrad", "sparse_rows", False))
         jobs.append((case_name, "row_sharded", "adam", "lazy_exact", True))
+        jobs.append((case_name, "row_sharded_nodedup", "adam", "dense_exact", True))
+        jobs.append((case_name, "row_sharded_nodedup", "adagrad", "sparse_rows", False))
         jobs.append((case_name, "replicated", "adam", "lazy_exact", False))
     _spawn(jobs)
 
