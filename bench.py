@@ -191,6 +191,9 @@ def cpu_baseline(args):
     cores = os.cpu_count() or 1
     return {"value": round(args.cpu_batch * args.cpu_steps / dt, 1), "unit": "samples/s", "cores": cores,
             "kind": "port",
+            "note": "the oracle (numpy / BLAS + C/OpenMP restatement of the reference step, pinned to the reference by "
+                    "tests/golden), NOT the reference's PyTorch path: that one measured 8.1 k samples/s on 8 cores in "
+                    "the build container (BASELINE.md) and cannot travel to the GPU box",
             "sample": f"{args.cpu_steps} full train steps (fwd+BCE+bwd+dense {cfg['optim_config']['optimizer']}) of "
                       f"{args.workload} at batch {args.cpu_batch}, {args.dist} indices; oracle/mmlrec_oracle.py with "
                       f"multi-threaded BLAS GEMMs and " + ("C/OpenMP" if fast else "numpy (single-thread)") +

@@ -87,7 +87,10 @@ class TrainStep:
         #   early : every row the batch does NOT touch (zero gradient), streamed beside the forward / backward,
         #   tables: the touched rows, with their gradients, after the scatter (mml_opt_step_rows)
         # -- the same arithmetic on every row as one dense launch, but the 2.3 GB stream leaves the critical path.
-        split = (bool(split_dense) and self.opt.table_update == "dense_exact" and
+        # (pays only when the stream is long: with < 2^25 table parameters -- every workload but the AliExpress-shaped
+        # one -- the row bookkeeping costs more than the ~0.1 ms stream it moves; split_dense="force" overrides)
+        big = sum(self.store.pvals[n].data.numel() for n in self.store.table_names) >= (1 << 25)
+        split = (bool(split_dense) and (big or split_dense == "force") and self.opt.table_update == "dense_exact" and
                  (par is None or par.mode == "replicated") and
                  not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16)
         if self.opt.table_update in ("sparse_rows", "lazy_exact") or split:

@@ -20,7 +20,8 @@ def label(kernel_name, avg_bytes_hint=0):
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     for a, b in (("gather_vec4_kernel", "gather_vec4_kernel"), ("scatter_hash_kernel", "scatter_hash_kernel"),
-                 ("scatter_fold_kernel", "scatter_fold_kernel"),
+                 ("scatter_fold_kernel", "scatter_fold_kernel"), ("rows_compact_kernel", "rows_compact_kernel"),
+                 ("opt_rows_kernel", "opt_rows_kernel"), ("mark_rows_kernel", "mark_rows_kernel"),
                  ("gate_bwd_fast_kernel", "gate_bwd_kernel"), ("gate_fwd_fast_kernel", "gate_fwd_kernel"), ("gate_fwd_once_kernel", "gate_fwd_kernel"),
                  ("head_fast_kernel", "head_kernel"), ("opt_dense_kernel<true>", "opt_dense_kernel<true>"),
                  ("opt_flat_kernel", "opt_flat_kernel"),

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 traffic, prof = sys.argv[1], sys.argv[2]
-tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(os.path.join(out, f"{tag}_pmc"), exist_ok=True)
