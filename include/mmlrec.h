@@ -527,6 +527,11 @@ typedef struct {
   const int32_t* step_dev; /* optional device counter (hipGraph replay): the kernel reads *step_dev instead */
   float lr, beta1, beta2, eps, alpha;
   int32_t zero_grad; /* 1: write zeros over grad after use (keeps dense table-gradient accumulators clean) */
+  /* > 0: cap on the workgroups of a dense launch.  A streaming launch normally fills every wave slot of the chip (8
+   * workgroups per CU); the early half of the split table update runs BESIDE the forward / backward kernels and must
+   * leave them slots (uncapped, a B = 4 096 step's GEMMs waited 0.3 ms for a slot), and it has the whole forward +
+   * backward to finish in. */
+  int32_t max_blocks;
 } mml_opt_hyper;
 /* dense update of up to MML_MAX_OPT_TENSORS whole tensors in one launch (tables included: the reference's
  * optimizer touches every row of every table every step) */

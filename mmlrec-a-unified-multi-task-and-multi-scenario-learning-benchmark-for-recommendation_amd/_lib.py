@@ -84,7 +84,7 @@ class Attn2Desc(C.Structure):
 
 class OptHyper(C.Structure):
     _fields_ = [("kind", i32), ("step", i32), ("step_dev", fp), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("zero_grad", i32)]
+                ("beta2", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("zero_grad", i32), ("max_blocks", i32)]
 
 
 _PP = C.POINTER

@@ -136,6 +136,40 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         if (h.zero_grad && (g1.x != 0.f || g1.y != 0.f || g1.z != 0.f || g1.w != 0.f)) G[j] = zero;
       }
     }
+    if (skip) {
+      // early half of the split table update: it runs BESIDE other kernels with a capped grid (mml_opt_hyper.max_blocks),
+      // so the memory-level parallelism has to come from the thread: U independent chunks (3U 16-byte loads) in flight
+      constexpr int U = 4;
+      for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 p[U], a[U], b[U];
+        uint32_t w[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {  // the U bitmap words first ...
+          const int64_t row = ((i + k * stride) << 2) / re;
+          w[k] = (skip[row >> 5] >> (row & 31)) & 1u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {  // ... then every load of the live chunks
+          const int64_t j = i + k * stride;
+          if (!w[k]) {
+            p[k] = ld(P + j);
+            a[k] = S1 ? ld(S1 + j) : zero;
+            b[k] = S2 ? ld(S2 + j) : zero;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          if (w[k]) continue;
+          const int64_t j = i + k * stride;
+          const f4 g = zg ? zero : ld(G + j);
+          one(p[k], g, a[k], b[k]);
+          st(P + j, p[k]);
+          if (S1) st(S1 + j, a[k]);
+          if (S2) st(S2 + j, b[k]);
+          if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f)) G[j] = zero;
+        }
+      }
+    }
     for (; i < n4; i += stride) {
       if (skip && skipped(i)) continue;
       f4 p = ld(P + i);
@@ -661,10 +695,12 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
     if (total >= ((int64_t)1 << 24) && L.n <= 4) {
       int64_t bx = cdiv(cdiv(nmax, 4), 256);
       if (bx > 256 * 8) bx = 256 * 8;
+      if (hyper->max_blocks > 0 && bx * L.n > hyper->max_blocks) bx = cdiv(hyper->max_blocks, L.n);
       MML_LAUNCH(opt_dense_kernel<true>, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
     } else {
       int64_t bx = cdiv(chunks, 256);
       if (bx > 256 * 8) bx = 256 * 8;
+      if (hyper->max_blocks > 0 && bx > hyper->max_blocks) bx = hyper->max_blocks;
       MML_LAUNCH(opt_flat_kernel, dim3((unsigned)bx), dim3(256), 0, to_stream(stream), L);
     }
     rc = check_launch("mml_opt_step_dense");

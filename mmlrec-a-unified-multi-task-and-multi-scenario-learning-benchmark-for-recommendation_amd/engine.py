@@ -1364,7 +1364,12 @@ class Optimizer:
         mlp_calls, calls, early = calls, [], []
         if tabs:
             if self.table_update == "dense_exact":
-                hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense)
+                import os
+                # the early half of a split update shares the chip with the forward / backward: a few workgroups per
+                # CU instead of all eight (MMLREC_EARLY_BLOCKS: tuning knob; 1024 = 4 per CU measured best at B = 65 536 and 4 096)
+                cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "1024")) if split_dense else 0
+                hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense,
+                                    max_blocks=cap)
                 plan.keep.append(hz)
                 # p, g, m, v read + p, m, v written; the split form never reads g
                 per = {"sgd": 12, "adam": 28, "adagrad": 20, "rmsprop": 20}[self.kind] - (4 if split_dense else 0)

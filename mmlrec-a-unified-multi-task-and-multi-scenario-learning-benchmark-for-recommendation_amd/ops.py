@@ -361,7 +361,7 @@ def act_bwd(y, dy, dst, act):
 
 
 # ---------------------------------------------------------------------------------------------- K8
-def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False):
+def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False, max_blocks=0):
     h = L.OptHyper()
     h.kind = L.OPT_KINDS[kind] if isinstance(kind, str) else int(kind)
     h.step = int(step)
@@ -371,6 +371,7 @@ def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False):
     h.eps = {L.OPT_ADAM: 1e-8, L.OPT_ADAGRAD: 1e-10, L.OPT_RMSPROP: 1e-8}.get(h.kind, 0.0)
     h.alpha = 0.99
     h.zero_grad = int(zero_grad)
+    h.max_blocks = int(max_blocks)
     return h
 
 
