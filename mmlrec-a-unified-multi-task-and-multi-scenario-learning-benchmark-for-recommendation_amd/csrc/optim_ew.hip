@@ -11,7 +11,7 @@ namespace mml {
 struct OptLaunch {
   mml_opt_tensor t[MML_MAX_OPT_TENSORS];
   int32_t n;
-  int32_t variant;  // streaming form of the vector loop (tuning knob MMLREC_OPT_VARIANT): bit 0 = nontemporal, bit 1 = 2x unroll
+  int32_t variant;  // streaming form of the vector loop (tuning knob MMLREC_OPT_VARIANT): bit 0 = nontemporal, bit 1 = 2x unroll; bit 2 = capped grid (4 chunks in flight per thread)
   mml_opt_hyper h;
   int64_t chunk0[MML_MAX_OPT_TENSORS + 1];  // flat kernel: first 4-element chunk of tensor i in the concatenation
 };
@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         if (h.zero_grad && (g1.x != 0.f || g1.y != 0.f || g1.z != 0.f || g1.w != 0.f)) G[j] = zero;
       }
     }
-    if (skip) {
-      // early half of the split table update: it runs BESIDE other kernels with a capped grid (mml_opt_hyper.max_blocks),
-      // so the memory-level parallelism has to come from the thread: U independent chunks (3U 16-byte loads) in flight
+    if (skip && (L.variant & 4)) {
+      // early half of the split table update under a capped grid (mml_opt_hyper.max_blocks): it runs BESIDE other
+      // kernels with few waves, so the memory-level parallelism has to come from the thread: U independent chunks (3U
+      // 16-byte loads) in flight.  (With the full grid the plain loop below is faster: fewer registers, more waves.)
       constexpr int U = 4;
       for (; i + (U - 1) * stride < n4; i += U * stride) {
         f4 p[U], a[U], b[U];
@@ -686,7 +687,7 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       const char* e = getenv("MMLREC_OPT_VARIANT");
       variant = e ? atoi(e) : 0;
     }
-    L.variant = variant;
+    L.variant = variant | (hyper->max_blocks > 0 ? 4 : 0);
     // A group dominated by one huge tensor (the dense table update) streams with the per-tensor kernel (blockIdx.y =
     // tensor: no index search on the 2.7 GB stream); everything else (dozens of tensors from 64 B to a few MB) goes
     // through the flat kernel, where every workgroup has the same amount of work.

@@ -1365,9 +1365,11 @@ class Optimizer:
         if tabs:
             if self.table_update == "dense_exact":
                 import os
-                # the early half of a split update shares the chip with the forward / backward: a few workgroups per
-                # CU instead of all eight (MMLREC_EARLY_BLOCKS: tuning knob; 1024 = 4 per CU measured best at B = 65 536 and 4 096)
-                cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "1024")) if split_dense else 0
+                # the early half of a split update shares the chip with the forward / backward; its grid can be capped
+                # (mml_opt_hyper.max_blocks, MMLREC_EARLY_BLOCKS) so that it leaves them wave slots.  Same-box A/B runs
+                # (B = 65 536 and 4 096, caps 512 .. 2048) stayed inside the run-to-run noise, so the default is the
+                # full grid, at which the stream runs at its stand-alone bandwidth.
+                cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "0")) if split_dense else 0
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense,
                                     max_blocks=cap)
                 plan.keep.append(hz)
