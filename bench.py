@@ -55,6 +55,13 @@ def dist_setup(n):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # MMLREC_BENCH_SHARE_GPU=1: every rank on GPU 0 over gloo (parallel.Comm stages through the host) -- a smoke
+        # test of the N > 1 control flow on a one-GPU box, NOT a measurement (RCCL refuses two ranks on one device)
+        if os.environ.get("MMLREC_BENCH_SHARE_GPU") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            return rank, local, world, dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         return rank, local, world, dist

@@ -175,3 +175,26 @@ def test_world2_fit_with_validation(mode):
     # final ragged batch is padded by one repeated sample (DistributedSampler semantics)
     assert abs(h0[-1]["loss"] - h_ref[-1]["loss"]) < 2e-3 * abs(h_ref[-1]["loss"])
     assert np.abs(p0 - p_ref).max() < 5e-3
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_control_flow():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, rank 0 prints ONE JSON
+    line), here with both ranks sharing the test box's GPU over gloo (MMLREC_BENCH_SHARE_GPU=1: a control-flow smoke
+    test of the row-sharded benchmark path -- barriers, max-over-ranks timing, the instrumented pass with its
+    collectives -- not a measurement)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MMLREC_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--batch", "4096", "--alt-batch", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192
+    assert "row-wise sharded" in d["config"]["tables"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert any(k.startswith("row_sharded_") for k in d.get("collectives_ms_per_step", {}))
