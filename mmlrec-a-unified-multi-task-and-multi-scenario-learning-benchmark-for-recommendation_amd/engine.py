@@ -9,6 +9,7 @@ the ONLY consumer of a value folds the activation derivative into its own kernel
 kernels do this); otherwise consumers add raw contributions and one `mml_act_bwd` pass finalises the sum.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -1364,7 +1365,6 @@ class Optimizer:
         mlp_calls, calls, early = calls, [], []
         if tabs:
             if self.table_update == "dense_exact":
-                import os
                 # the early half of a split update shares the chip with the forward / backward; its grid can be capped
                 # (mml_opt_hyper.max_blocks, MMLREC_EARLY_BLOCKS) so that it leaves them wave slots.  Same-box A/B runs
                 # (B = 65 536 and 4 096, caps 512 .. 2048) stayed inside the run-to-run noise, so the default is the

@@ -13,7 +13,6 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .utils import DNN, PredictionLayer, activation_code

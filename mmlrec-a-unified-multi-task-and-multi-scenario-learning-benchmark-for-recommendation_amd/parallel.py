@@ -25,8 +25,6 @@ AE-30); in row_sharded mode they are stale while training and `sync_tables` (all
 BaseModel.flush_tables does that before anything outside the fused step reads a table.  All of these are collective
 calls: every rank must reach them.
 """
-import ctypes as C
-
 import torch
 
 from . import _lib as L
