@@ -87,9 +87,12 @@ class TrainStep:
         #   early : every row the batch does NOT touch (zero gradient), streamed beside the forward / backward,
         #   tables: the touched rows, with their gradients, after the scatter (mml_opt_step_rows)
         # -- the same arithmetic on every row as one dense launch, but the 2.3 GB stream leaves the critical path.
-        # (pays only when the stream is long: with < 2^25 table parameters -- every workload but the AliExpress-shaped
-        # one -- the row bookkeeping costs more than the ~0.1 ms stream it moves; split_dense="force" overrides)
-        big = sum(self.store.pvals[n].data.numel() for n in self.store.table_names) >= (1 << 25)
+        # When it pays (same-box A/B, AE-30): the stream has to be long -- with < 2^25 table parameters the row
+        # bookkeeping costs more than the ~0.1 ms stream it moves -- and the forward / backward short: at B = 4 096 the
+        # split step takes 0.70-0.76 ms against 0.77, at B = 65 536 it LOSES 2-4 % (1.95-2.01 against 1.92 ms: nothing
+        # co-resides with the GEMMs, so the early pass only adds its bookkeeping).  Default: batches up to 16 384;
+        # split_dense="force" overrides.
+        big = (sum(self.store.pvals[n].data.numel() for n in self.store.table_names) >= (1 << 25)) and int(B) <= 16384
         split = (bool(split_dense) and (big or split_dense == "force") and self.opt.table_update == "dense_exact" and
                  (par is None or par.mode == "replicated") and
                  not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16)

@@ -15,7 +15,7 @@ out = os.path.join(root, "profiles")
 os.makedirs(os.path.join(out, f"{tag}_pmc"), exist_ok=True)
 shutil.copy(os.path.join(traffic, "traffic.json"), os.path.join(out, "traffic.json"))
 for p, c in (("p_fetch", "FETCH_SIZE"), ("p_write", "WRITE_SIZE"), ("p_atomic", "TCC_EA0_ATOMIC")):
-    fs = glob.glob(f"{traffic}/{p}/**/*counter_collection.csv", recursive=True)
+    fs = sorted(glob.glob(f"{traffic}/{p}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]
     if not fs:
         continue
     d = collections.defaultdict(lambda: [0, 0.0])
@@ -29,9 +29,9 @@ for p, c in (("p_fetch", "FETCH_SIZE"), ("p_write", "WRITE_SIZE"), ("p_atomic", 
         w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Sum", "AvgPerDispatch"])
         for k, (n, s) in sorted(d.items(), key=lambda kv: -kv[1][1]):
             w.writerow([k, c, n, s, s / n])
-ks = glob.glob(f"{prof}/**/*kernel_stats.csv", recursive=True)
-if ks:
-    shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+ks = sorted(glob.glob(f"{prof}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+if ks:  # (gpurun merges new files next to old ones: take the newest)
+    shutil.copy(ks[-1], os.path.join(out, f"{tag}_kernel_stats.csv"))
 log = os.path.join(prof, "bench.log")
 if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
