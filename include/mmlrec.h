@@ -61,6 +61,12 @@ int mml_version(void);
 const char* mml_last_error(void);
 /* out[0]=CU count, [1]=LDS bytes/CU, [2]=total HBM bytes, [3]=wavefront size, [4]=max clock kHz, [5]=gfx arch number */
 int mml_device_caps(int device, int64_t* out6);
+/* A HIP stream whose kernels may only run on compute units [cu_lo, cu_hi) of `device` (bit i of the queue's CU mask;
+ * on gfx950 the driver deals mask bits round-robin over the 8 XCDs, so a contiguous range takes the same number of CUs
+ * from every XCD).  Lets an HBM-bound stream (the dense table optimizer) and an MFMA-bound one (the weight-gradient
+ * GEMMs) run side by side instead of alternating workgroup by workgroup.  mml_stream_destroy releases it. */
+int mml_stream_create_cu_range(int device, int cu_lo, int cu_hi, mml_stream_t* stream_out);
+int mml_stream_destroy(mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  fused multi-field gather + concat.

@@ -92,6 +92,8 @@ _SIGS = {
     "mml_version": (C.c_int, []),
     "mml_last_error": (C.c_char_p, []),
     "mml_device_caps": (C.c_int, [C.c_int, _PP(i64)]),
+    "mml_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _PP(C.c_void_p)]),
+    "mml_stream_destroy": (C.c_int, [C.c_void_p]),
     "mml_gather_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
     "mml_gather_fwd_mark": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp, fp]),
     "mml_rows_compact": (C.c_int, [_PP(fp), _PP(i64), _PP(i64), i32, fp, fp, i32, fp, fp]),

@@ -47,3 +47,40 @@ extern "C" int mml_device_caps(int device, int64_t* out6) {
   out6[5] = arch;
   return MML_OK;
 }
+
+extern "C" int mml_stream_create_cu_range(int device, int cu_lo, int cu_hi, mml_stream_t* stream_out) {
+  MML_REQUIRE(stream_out != nullptr, "mml_stream_create_cu_range: stream_out is null");
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, device);
+  if (e != hipSuccess) {
+    mml::set_error("hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+    return MML_ERR_HIP;
+  }
+  const int ncu = p.multiProcessorCount;
+  MML_REQUIRE(0 <= cu_lo && cu_lo < cu_hi && cu_hi <= ncu, "mml_stream_create_cu_range: need 0 <= lo < hi <= CU count");
+  uint32_t mask[32] = {0};
+  MML_REQUIRE(ncu <= 32 * 32, "mml_stream_create_cu_range: more than 1024 compute units");
+  for (int i = cu_lo; i < cu_hi; ++i) mask[i >> 5] |= 1u << (i & 31);
+  int prev = 0;
+  hipGetDevice(&prev);
+  if (prev != device) hipSetDevice(device);
+  hipStream_t s = nullptr;
+  e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((ncu + 31) / 32), mask);
+  if (prev != device) hipSetDevice(prev);
+  if (e != hipSuccess) {
+    mml::set_error("hipExtStreamCreateWithCUMask([%d, %d)): %s", cu_lo, cu_hi, hipGetErrorString(e));
+    return MML_ERR_HIP;
+  }
+  *stream_out = (mml_stream_t)s;
+  return MML_OK;
+}
+
+extern "C" int mml_stream_destroy(mml_stream_t stream) {
+  MML_REQUIRE(stream != nullptr, "mml_stream_destroy: null stream");
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    mml::set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return MML_ERR_HIP;
+  }
+  return MML_OK;
+}

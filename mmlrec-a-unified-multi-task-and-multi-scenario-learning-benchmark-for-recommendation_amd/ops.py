@@ -16,6 +16,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_masked_streams = {}
+
+
+def cu_range_stream(device, cu_lo, cu_hi):
+    """torch view of a HIP stream confined to compute units [cu_lo, cu_hi) (mml_stream_create_cu_range); one per
+    (device, range), kept for the life of the process."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, int(cu_lo), int(cu_hi))
+    st = _masked_streams.get(key)
+    if st is None:
+        h = C.c_void_p()
+        L.check(L.load().mml_stream_create_cu_range(idx, int(cu_lo), int(cu_hi), C.byref(h)))
+        st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+        _masked_streams[key] = st
+    return st
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -11,6 +11,8 @@ Multi-GPU steps (parallel.py) contain Python-issued entries (collectives, the ro
 sizes).  Those run eagerly; the runs of C-ABI calls between them -- static shapes, static pointers -- are still captured
 and replayed as HIP graphs (`Segments`).
 """
+import os
+
 import torch
 
 from . import engine as E
@@ -120,9 +122,23 @@ class TrainStep:
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
+        # CU partition of the forked tail (lab knob MMLREC_CU_TAIL = n: table scatter + table optimizer on compute
+        # units [0, n), weight-gradient GEMMs + MLP optimizer on [n, all))
+        self.tail_stream = None
+        n_tail = int(os.environ.get("MMLREC_CU_TAIL", "0"))
+        if self.overlap and n_tail > 0 and par is None:
+            from . import ops
+            ncu = torch.cuda.get_device_properties(self.store.device).multi_processor_count
+            self.tail_stream = ops.cu_range_stream(self.store.device, 0, n_tail)
+            self.side = ops.cu_range_stream(self.store.device, n_tail, ncu)
+            self.ev_tail = torch.cuda.Event()
         # (a high-priority stream, or more hardware queues (GPU_MAX_HW_QUEUES=8), for the early pass made a B = 4 096
         # step twice as slow: 0.82 -> 1.6 ms; the default priority it is)
         self.side2 = torch.cuda.Stream(device=self.store.device) if (self.overlap and self.split_dense) else None
+        n_early = int(os.environ.get("MMLREC_CU_EARLY", "0"))
+        if self.side2 is not None and n_early > 0:
+            from . import ops
+            self.side2 = ops.cu_range_stream(self.store.device, 0, n_early)
         # fork / join events live as long as the step
         self.ev_fork = torch.cuda.Event() if self.overlap else None
         self.ev_join = torch.cuda.Event() if self.overlap else None
@@ -157,7 +173,14 @@ class TrainStep:
         with torch.cuda.stream(self.side):
             side()
             self.ev_join.record(self.side)
-        tail()
+        if self.tail_stream is not None:
+            self.tail_stream.wait_event(self.ev_fork)
+            with torch.cuda.stream(self.tail_stream):
+                tail()
+                self.ev_tail.record(self.tail_stream)
+            main.wait_event(self.ev_tail)
+        else:
+            tail()
         main.wait_event(self.ev_join)
 
     def run(self):
