@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmmlrec_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+GEMM_SOURCES = ("gemm.hip", "gemm_planes.hip")  # kernels with hand-counted waits: resource / assembly checks below
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 
@@ -86,7 +87,7 @@ def _build_locked(force, verbose, jobs):
             obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             stderr = None
-            if os.path.basename(src) == "gemm.hip":
+            if os.path.basename(src) in GEMM_SOURCES:
                 # the pipelined GEMM counts its own VMEM operations (s_waitcnt vmcnt(N)): a register spill would add
                 # scratch traffic to that count and silently break the waits -> check the resource report
                 cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
@@ -102,7 +103,8 @@ def _build_locked(force, verbose, jobs):
             if os.path.exists(log):
                 sys.stderr.write("".join(l for l in open(log) if "remark:" not in l)[-4000:])
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    check_no_scratch(os.path.join(objdir, "gemm.o.log"))
+    for g in GEMM_SOURCES:
+        check_no_scratch(os.path.join(objdir, g[:-4] + ".o.log"))
     check_async_lds(objdir)
     tmp = LIBPATH + ".tmp.%d" % os.getpid()
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
@@ -121,7 +123,7 @@ def check_no_scratch(log):
     for line in open(log):
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split()[0]
-        elif "ScratchSize" in line and name and "gemm_pipe_kernel" in name:
+        elif "ScratchSize" in line and name and ("gemm_pipe_kernel" in name or "gemm_planes_kernel" in name):
             if int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
                 bad.append(name)
     if bad:
@@ -134,11 +136,16 @@ def check_async_lds(objdir):
     tool = os.path.join(os.path.dirname(HERE), "tools", "check_async_lds.py")
     if not asm or not os.path.exists(tool):
         return
-    r = subprocess.run([sys.executable, tool, asm[0]], capture_output=True, text=True)
-    for f in glob.glob(os.path.join(objdir, "gemm-*")) + glob.glob(os.path.join(objdir, "gemm.hip-*")):
+    out, bad = "", False
+    for a in asm:
+        r = subprocess.run([sys.executable, tool, a], capture_output=True, text=True)
+        out += r.stdout
+        bad = bad or r.returncode != 0
+    for f in set(glob.glob(os.path.join(objdir, "gemm*-hip-*")) + glob.glob(os.path.join(objdir, "gemm*-host-*")) +
+                 glob.glob(os.path.join(objdir, "gemm*.hip-*"))):
         os.remove(f)  # -save-temps leftovers (tens of MB that would travel with every snapshot)
-    if r.returncode != 0:
-        raise RuntimeError("pipelined GEMM reads an LDS-loaded register before its wait:\n" + r.stdout[-2000:])
+    if bad:
+        raise RuntimeError("pipelined GEMM reads an LDS-loaded register before its wait:\n" + out[-2000:])
 
 
 if __name__ == "__main__":

@@ -1,0 +1,111 @@
+// Pieces shared by the LDS-DMA GEMM kernels (gemm.hip, gemm_planes.hip): asynchronous LDS accesses as inline asm,
+// the global -> LDS DMA wave-instructions, the XCD-aware tile remap.
+#pragma once
+#include "common.hpp"
+
+namespace mml {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of
+// virtual tile ids: the n-tiles that re-read one 128-row A panel then hit the same 4 MiB L2.  Bijective for any
+// grid size (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// LDS accesses as inline asm: hipcc treats an LDS-DMA in flight as a pending LDS store and would put
+// s_waitcnt vmcnt(0) in front of every C++-level ds_read (draining the prefetch); asm accesses are invisible to that
+// pass, so the counted vmcnt(N) of the kernel is the only VMEM wait in the loop.  lgkmcnt waits are placed by hand.
+//
+// The price: to the compiler an asm ds_read has produced its value at once, so it feels free to COPY the destination
+// register before the data has landed (it did, to form register pairs for v_pk_add_f32).  Rule used throughout: a
+// value read this way is kept in a native vector type exactly as the instruction wrote it, is not touched until the
+// wait, and is passed through lds_landed() right after the wait; every real use hangs off lds_landed()'s output.
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_byte_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(const lds_f32_t*)p;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4_t ds_read128(uint32_t addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void ds_write128(uint32_t addr, const f32x4_t& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int U0, int U1>
+__device__ __forceinline__ f32x2_t ds_read2st64(uint32_t addr) {  // two dwords at addr + U0*256 B and addr + U1*256 B
+  f32x2_t v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(U0), "n"(U1) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_landed(f32x4_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void lds_landed(f32x2_t& v) { asm volatile("" : "+v"(v)); }
+
+// one LDS-DMA wave-instruction: every lane moves 16 bytes from its own global address to lds_dst + 16 * lane
+__device__ __forceinline__ void dma16(const float* g, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(g, lds_dst, 16, 0, 0);
+}
+// ... and the 4-byte form: lds_dst + 4 * lane
+__device__ __forceinline__ void dma4(const float* g, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(g, lds_dst, 4, 0, 0);
+}
+
+// fp32 value -> PL bf16 planes by mantissa slicing (h = top 8 significant bits, m = the next 8, l = the last 8; every
+// subtraction is exact, so h + m + l == x bit for bit when PL == 3).  Eight k-values of one operand row per lane,
+// packed as the 32x32x16 bf16 MFMA wants them.
+template <int PL>
+__device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&out)[PL]) {
+#ifdef MML_LAB_NO_CONVERT
+  {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t0 = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    u4 t1 = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+#pragma unroll
+    for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
+    return;
+  }
+#endif
+  uint32_t w[PL][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t u0 = __float_as_uint(x[2 * j]), u1 = __float_as_uint(x[2 * j + 1]);
+    if (PL == 1) {  // plain bf16 operands: round to nearest even (v_cvt_pk_bf16_f32)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 xx = {x[2 * j], x[2 * j + 1]};
+      w[0][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xx, bf16x2_t));
+      continue;
+    }
+    w[0][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {bf16 bits of x0, bf16 bits of x1}, truncated
+    if (PL > 1) {
+      const float r0 = x[2 * j] - __uint_as_float(u0 & 0xffff0000u);
+      const float r1 = x[2 * j + 1] - __uint_as_float(u1 & 0xffff0000u);
+      const uint32_t q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+      if (PL == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 r = {r0, r1};
+        w[1][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));  // RNE: 2^-17 |x| left over
+      } else {
+        w[1][j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(q0 & 0xffff0000u);
+        const float s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+        w[PL - 1][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PL; ++p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t = {w[p][0], w[p][1], w[p][2], w[p][3]};
+    out[p] = __builtin_bit_cast(bf16x8, t);
+  }
+}
+
+}  // namespace mml

@@ -10,7 +10,7 @@ import sys
 def check(path):
     txt = open(path).read()
     total = 0
-    for m in re.finditer(r"^(_ZN3mml16gemm_pipe_kernel\w+):.*?s_endpgm", txt, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3mml1[68]gemm_p(?:ipe|lanes)_kernel\w+):.*?s_endpgm", txt, re.S | re.M):
         name, pending, bad = m.group(1), set(), 0
         for ln in m.group(0).split("\n"):
             t = ln.strip()
