@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--table-update", default="dense_exact", choices=["dense_exact", "sparse_rows", "lazy_exact", "auto"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="emit roctx ranges (train_step / HIP-graph segment / kernel) for rocprofv3 --marker-trace")
     ap.add_argument("--parallel-mode", default="row_sharded", choices=["row_sharded", "replicated", "table_wise"],
                     help="how the tables are spread over the ranks when --gpus > 1 (mmlrec_amd/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,6 +234,9 @@ def main():
     dev = torch.device("cuda", local)
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd import workloads as W
+    if args.profile:
+        from mmlrec_amd import profiling
+        profiling.enable()
 
     model, cfg, vocab, dense = W.build_model(args.workload, dev, table_update=args.table_update,
                                              use_hip_graph=not args.no_graph)

@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import profiling
 from . import ops
 
 ACT = {"none": L.ACT_NONE, None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID,
@@ -123,6 +124,17 @@ class Plan:
     @staticmethod
     def _run(calls):
         s = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        if profiling.enabled:  # --profile: one roctx range per call, named after its kernel
+            for c in calls:
+                meta = c[3] if (c[0] is PY and len(c) > 3) else (c[2] if (c[0] is not PY and len(c) > 2) else {})
+                with profiling.range(meta.get("kernel") or getattr(c[1] if c[0] is PY else c[0], "__name__", "call")):
+                    if c[0] is PY:
+                        c[1](*c[2])
+                    else:
+                        rc = c[0](*c[1], s)
+                        if rc:
+                            L.check(rc, c[0].__name__)
+            return
         for c in calls:
             if c[0] is PY:
                 c[1](*c[2])

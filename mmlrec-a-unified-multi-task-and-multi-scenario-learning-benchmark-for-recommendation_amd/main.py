@@ -54,6 +54,8 @@ def build_parser():
     p.add_argument("--is_parallel", type=_bool, default=False)
     p.add_argument("--device", default="cuda")
     p.add_argument("--seeds", type=str, default="0,2,4,8", help="comma list (the reference hard-codes 0,2,4,8)")
+    p.add_argument("--profile", type=_bool, default=False,
+                   help="emit roctx ranges (epoch / train_step / kernel) for `rocprofv3 --marker-trace --kernel-trace`")
     return p
 
 
@@ -97,6 +99,10 @@ def evaluate_predictions(model, config, test, target, test_mask, pred_ans):
 
 def run(args):
     dist = None
+    if getattr(args, "profile", False):
+        from . import profiling
+        if not profiling.enable():
+            print("--profile: no roctx library found, ranges are not emitted")
     if args.is_parallel:
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -21,6 +21,7 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import engine as E
 from .. import ops
+from .. import profiling
 from .utils import (DenseFeat, PredictionLayer, SparseFeat, VarLenSparseFeat, build_input_features,
                     create_embedding_matrix, get_mask)
 
@@ -485,6 +486,7 @@ class BaseModel(nn.Module):
         pred_epoch = torch.empty((n, self.num_outputs or self.num_tasks), dtype=torch.float32, device=dev)
         for epoch in range(initial_epoch, epochs):
             start_time = time.time()
+            profiling.push("epoch %d" % epoch)
             perm = self._epoch_permutation(n_total, shuffle)
             if world > 1:
                 pad = n * world - n_total
@@ -545,6 +547,7 @@ class BaseModel(nn.Module):
                 for name, result in eval_result.items():
                     epoch_logs["val_" + name] = result
                 self.train()
+            profiling.pop()
             epoch_time = int(time.time() - start_time)
             print("Epoch {0}/{1}".format(epoch + 1, epochs))
             eval_str = "{0}s - loss: {1: .4f} - cka_loss: {2: .4f}".format(epoch_time, epoch_logs["loss"],

@@ -16,6 +16,7 @@ import os
 import torch
 
 from . import engine as E
+from . import profiling
 
 
 class Segments:
@@ -61,7 +62,12 @@ class Segments:
                     continue
                 item[1](*item[2])
             elif graph is not None:
-                graph.replay()
+                if profiling.enabled:
+                    with profiling.range("hip_graph[%d calls: %s ...]" % (len(item), (item[0][2] if len(item[0]) > 2 and
+                                         isinstance(item[0][2], dict) else {}).get("kernel", item[0][0].__name__))):
+                        graph.replay()
+                else:
+                    graph.replay()
             else:
                 E.Plan._run(item)
 
@@ -193,6 +199,7 @@ class TrainStep:
         end of the exec's parallel-stream vector when one of those streams shares a hardware queue with the launch
         stream (hip::Graph::UpdateStreams, ROCm 7.0 runtime bundled with torch 2.10) -- a sporadic segfault that
         depends on how many streams the process has created.  Single-branch graphs never enter that loop."""
+        profiling.push("train_step")
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
             for seg in (self.pre, self.early, self.front, self.sideq, self.tail):
@@ -214,6 +221,7 @@ class TrainStep:
             self.sideq.run()
         else:
             self._forked(self.sideq.run, self.tail.run)
+        profiling.pop()
         self.calls += 1
         self.opt.steps_done += 1
         self.opt.dirty = True

@@ -218,3 +218,36 @@ def test_state_dict_save_load_round_trip(tmp_path):
     with torch.no_grad():
         yp = m3(torch.from_numpy(g["X0"]).cuda()).cpu().numpy()
     assert np.abs(yp - g["y_pred"]).max() < 1e-4 * np.abs(g["y_pred"]).max()
+
+
+def test_profile_ranges_are_balanced_and_off_by_default():
+    """--profile (main.py / bench.py): roctx ranges around epochs, steps and C-ABI calls; host-side only.  Without the
+    flag nothing is emitted; with it every push has its pop (checked through a recording stub of the roctx calls)."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import profiling
+    assert not profiling.enabled
+    with profiling.range("not recorded"):
+        pass
+    events = []
+
+    class Stub:
+        @staticmethod
+        def roctxRangePushA(b):
+            events.append(("push", b.decode()))
+            return 0
+
+        @staticmethod
+        def roctxRangePop():
+            events.append(("pop", None))
+            return 0
+    old = profiling._lib
+    try:
+        profiling._lib, profiling.enabled = Stub, True
+        with profiling.range("epoch 0"):
+            profiling.push("train_step")
+            profiling.pop()
+    finally:
+        profiling._lib, profiling.enabled = old, False
+    assert events == [("push", "epoch 0"), ("push", "train_step"), ("pop", None), ("pop", None)]
+    from mmlrec_amd.main import build_parser
+    assert build_parser().parse_args(["--profile", "1"]).profile is True
