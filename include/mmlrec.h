@@ -406,6 +406,12 @@ typedef struct mml_sumprod_desc {
   int64_t n;
   int32_t n_terms;
   int32_t accumulate;
+  /* act != MML_ACT_NONE: the sum is multiplied by act'(.) taken from deriv_of[i], the OUTPUT of that activation (needs
+   * accumulate == 0): the gradient w.r.t. the pre-activation of a factor whose only consumer is this product --
+   * PepNet's h * 2*sigmoid(gate) products of all tasks of a layer in one launch each way (model/pepnet.py:72-78) */
+  const float* deriv_of;
+  int32_t act;
+  int32_t pad_;
 } mml_sumprod_desc;
 int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_stream_t stream);
 /* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,

@@ -513,12 +513,41 @@ __global__ __launch_bounds__(256) void ew_add_n_kernel(const AddN A, float* out,
 struct SumProdBatch {
   mml_sumprod_desc d[MML_SUMPROD_BATCH];
 };
+// (act_deriv_from_output is defined further up with the mul_bwd kernel; deriv_of = the OUTPUT of the activation whose
+// derivative multiplies the sum -- PepNet's gate products, where the factor is 2*sigmoid(.) or relu(.) and this product
+// its only consumer)
 __global__ __launch_bounds__(256) void sumprod_batch_kernel(const SumProdBatch Bt) {
   const mml_sumprod_desc& D = Bt.d[blockIdx.y];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.n; i += stride) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool vec = (D.n & 3) == 0 && aligned16(D.out) && (!D.deriv_of || aligned16(D.deriv_of));
+  for (int k = 0; k < D.n_terms; ++k) vec = vec && aligned16(D.x[k]) && (!D.y[k] || aligned16(D.y[k]));
+  if (vec) {  // 16 bytes per lane and operand
+    const int64_t n4 = D.n >> 2;
+    for (int64_t i = tid; i < n4; i += stride) {
+      float4 s = D.accumulate ? reinterpret_cast<const float4*>(D.out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < D.n_terms; ++k) {
+        const float4 x = reinterpret_cast<const float4*>(D.x[k])[i];
+        if (D.y[k]) {
+          const float4 y = reinterpret_cast<const float4*>(D.y[k])[i];
+          s.x += x.x * y.x; s.y += x.y * y.y; s.z += x.z * y.z; s.w += x.w * y.w;
+        } else {
+          s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+      }
+      if (D.act != MML_ACT_NONE) {
+        const float4 o = reinterpret_cast<const float4*>(D.deriv_of)[i];
+        s.x *= act_deriv_from_output(o.x, D.act); s.y *= act_deriv_from_output(o.y, D.act);
+        s.z *= act_deriv_from_output(o.z, D.act); s.w *= act_deriv_from_output(o.w, D.act);
+      }
+      reinterpret_cast<float4*>(D.out)[i] = s;
+    }
+    return;
+  }
+  for (int64_t i = tid; i < D.n; i += stride) {
     float s = D.accumulate ? D.out[i] : 0.f;
     for (int k = 0; k < D.n_terms; ++k) s += D.x[k][i] * (D.y[k] ? D.y[k][i] : 1.f);
+    if (D.act != MML_ACT_NONE) s *= act_deriv_from_output(D.deriv_of[i], D.act);
     D.out[i] = s;
   }
 }
@@ -916,6 +945,8 @@ extern "C" int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_strea
       const mml_sumprod_desc& D = d[i0 + i];
       MML_REQUIRE(D.out && D.n >= 0 && D.n_terms >= 0 && D.n_terms <= MML_SUMPROD_TERMS, "mml_sumprod_batch: item %d malformed", i0 + i);
       for (int k = 0; k < D.n_terms; ++k) MML_REQUIRE(D.x[k], "mml_sumprod_batch: item %d term %d is null", i0 + i, k);
+      MML_REQUIRE(D.act >= MML_ACT_NONE && D.act <= MML_ACT_SIGMOID2 && (D.act == MML_ACT_NONE || (D.deriv_of && !D.accumulate)),
+                  "mml_sumprod_batch: item %d: a folded activation derivative needs deriv_of and no accumulation", i0 + i);
       Bt.d[i] = D;
       nmax = D.n > nmax ? D.n : nmax;
     }

@@ -1059,6 +1059,66 @@ class MulOp(Op):
                  dict(kernel="ew_mul_bwd_kernel", bytes=4.0 * self.flat * (3 + (da is not None) + (db is not None))))]
 
 
+class MulBatchOp(Op):
+    """out_j = a_j * b_j for several independent [B, n] products in ONE launch each way (PepNet: the gate products of
+    every task of a layer, model/pepnet.py:72-78, :139-140; one launch per product before).  The backward writes each
+    operand's gradient once, summed over the products it appears in (the gated input feeds every task's first layer),
+    with the derivative of the activation that produced the operand folded in when this op is its only consumer.
+    items: (a Val, b Val, out Val)."""
+
+    def __init__(self, items):
+        self.items = items
+        self.flat = [MulOp._flat_numel(it) for it in items]
+
+    def inputs(self):
+        return [v for a, b, _ in self.items for v in (a, b)]
+
+    def outputs(self):
+        return [o for _, _, o in self.items]
+
+    @staticmethod
+    def _descs(plan, rows):
+        arr = (L.SumProdDesc * len(rows))()
+        for d, (out, n, terms, acc, act, deriv_of) in zip(arr, rows):
+            if len(terms) > 8:
+                raise NotImplementedError("more than 8 products share one operand")
+            d.out, d.n, d.n_terms, d.accumulate = out.data_ptr(), n, len(terms), int(acc)
+            d.act, d.deriv_of = int(act), (deriv_of.data_ptr() if act != L.ACT_NONE else None)
+            for k, (x, y) in enumerate(terms):
+                d.x[k], d.y[k] = x.data_ptr(), y.data_ptr()
+        plan.keep.append(arr)
+        return arr
+
+    def fwd_calls(self, plan):
+        rows = [(o.buf, n, [(a.buf, b.buf)], 0, L.ACT_NONE, None) for (a, b, o), n in zip(self.items, self.flat)]
+        return [(L.load().mml_sumprod_batch, (self._descs(plan, rows), len(rows)),
+                 dict(kernel="sumprod_batch_kernel", bytes=12.0 * sum(self.flat)))]
+
+    def bwd_calls(self, plan):
+        targets = {}  # id(operand) -> [operand, flat numel, [(dout, other factor)]]
+        for (a, b, o), n in zip(self.items, self.flat):
+            if o.grad is None:
+                continue
+            if o.grad.stride(0) != o.buf.stride(0):
+                raise L.MMLError("MulBatchOp: value / gradient pitch mismatch")
+            for v, other in ((a, b), (b, a)):
+                if v.needs_grad:
+                    targets.setdefault(id(v), [v, n, []])[2].append((o.grad, other.buf))
+        rows, nbytes = [], 0.0
+        for v, n, terms in targets.values():
+            g = plan.grad_of(v)
+            acc = _claim(v)
+            fold = (not acc and v.act != L.ACT_NONE and not v.deriv_applied and len(v.consumers) == 1)
+            if fold:
+                v.deriv_applied = True
+            rows.append((g, n, terms, acc, v.act if fold else L.ACT_NONE, v.buf))
+            nbytes += 4.0 * n * (2 * len(terms) + 1 + (1 if (acc or fold) else 0))
+        if not rows:
+            return []
+        return [(L.load().mml_sumprod_batch, (self._descs(plan, rows), len(rows)),
+                 dict(kernel="sumprod_batch_kernel", bytes=nbytes))]
+
+
 class CopyColsOp(Op):
     """dst[:, :] = src[:, :] for column-sliced views; no gradient flows (used for detached concatenations,
     model/pepnet.py:72, :139)."""

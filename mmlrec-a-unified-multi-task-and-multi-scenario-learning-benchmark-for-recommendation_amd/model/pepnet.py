@@ -101,18 +101,17 @@ class PepNet(BaseModel):
 
         fg = self._gate_nn(plan, store, "feature_gate", [("feature_gate", gate_input(x0, "epnet_in"))])[0]
         x2 = plan.val(K0, name="gated_input", pad_k=True)
-        plan.add(E.MulOp(fg, x0, x2))
+        plan.add(E.MulBatchOp([(fg, x0, x2)]))
         gin = gate_input(x2, "ppnet_in")
         gws = self._gate_nn(plan, store, "ppn", [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T)
                                                  for l in range(nl + 1)])
         hidden = [x2] * T
         heads = []
         for l in range(nl + 1):
-            hins = []
-            for t in range(T):
-                hin = plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True)
-                plan.add(E.MulOp(hidden[t], gws[t * (nl + 1) + l], hin))
-                hins.append(hin)
+            # the gate products of all tasks of this layer: one launch each way (K7 batched, not fused into the GEMMs:
+            # DESIGN 10)
+            hins = [plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True) for t in range(T)]
+            plan.add(E.MulBatchOp([(hidden[t], gws[t * (nl + 1) + l], hins[t]) for t in range(T)]))
             if l < nl:
                 probs = [dict(x=hins[t], W=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.weight"],
                               b=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.bias"],
