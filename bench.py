@@ -40,9 +40,11 @@ def parse():
                     help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
                          "--kernel-trace of this command reports stand-alone kernel durations")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary lazy_exact measurement")
-    ap.add_argument("--no-split-dense", action="store_true",
-                    help="dense table update as ONE launch after the scatter (round-1 schedule) instead of untouched "
-                         "rows beside the forward + touched rows after the scatter")
+    ap.add_argument("--split-dense", action="store_true",
+                    help="dense table update as untouched rows beside the forward + touched rows after the scatter, "
+                         "instead of ONE launch after the scatter that skips the gradient read of unmarked rows")
+    ap.add_argument("--no-split-dense", action="store_true", help="(default since the marked single launch; kept for "
+                                                                  "old command lines)")
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -262,7 +264,7 @@ def main():
     for B in [args.batch] + ([args.alt_batch] if args.alt_batch and args.alt_batch != args.batch else []):
         batches = make_batches(B)
         runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=not args.serial,
-                                         split_dense=not args.no_split_dense)
+                                         split_dense="force" if args.split_dense else False)
         steps = args.steps if B == args.batch else max(args.steps, 50)
         dt = timed_steps(runner, batches, steps, args.warmup, dist)
         results[B] = dict(dt=dt, steps=steps, value=world * B * steps / dt, ms=dt / steps * 1e3,
@@ -343,7 +345,9 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "index_dist": args.dist,
                    "table_update": model.optimizer().table_update,
                    "dense_update_schedule": ("split: untouched rows beside the forward, touched rows after the scatter"
-                                             if getattr(runner0, "split_dense", False) else "one launch after the scatter"),
+                                             if getattr(runner0, "split_dense", False) else
+                                             ("one launch after the scatter, gradients read for marked rows only"
+                                              if getattr(runner0, "grad_marks", False) else "one launch after the scatter")),
                    "hip_graph": not args.no_graph,
                    "streams": 1 if args.serial else (3 if getattr(runner0, "split_dense", False) else 2),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else

@@ -114,7 +114,11 @@ int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32
  * (field f owns the bytes from 32 * sum_{g<f} ceil(V_g / 32)).  With it the rows are marked by plain byte stores and
  * the list / bitmaps are rebuilt from the marks by a compaction pass (touched[] = every marked or already-seen row,
  * *touched_count = their number) instead of one same-address atomic per hot row: 350 us -> 30 us for the index-only
- * pass at B = 65 536 on the AliExpress-shaped tables. */
+ * pass at B = 65 536 on the AliExpress-shaped tables.
+ * row_marks WITHOUT a touched list (touched == NULL): the scatter only marks every row it adds to and leaves the bytes
+ * set -- the consumer is mml_opt_step_dense with mml_opt_tensor.grad_marks, which skips the gradient read of unmarked
+ * rows and clears the marks.  Needs the LDS-fold kernel (E in {4, 8, 16}, 16-byte aligned dOut, ldo % 4 == 0); other
+ * shapes are rejected (MML_ERR_ARG) rather than served by a kernel that would leave the marks unset. */
 
 /* Unique (field, row) list of a batch WITHOUT gradients: the scatter's LDS dedup run on the indices alone.  Appends
  * rowbase[f] + row for every distinct row of X[:, col[f]] to touched[] (first-seen order, `seen` bitmaps as above).
@@ -566,6 +570,12 @@ typedef struct {
   const uint32_t* skip_rows;
   int32_t row_elems;
   int32_t zero_grads;
+  /* Marked gradients (single-launch dense table update): grad_marks != NULL makes the tensor a [rows, row_elems] table
+   * with one byte per row; a row whose byte is 0 has an all-zero gradient (the accumulators are all-zero between steps
+   * and mml_scatter_bwd marks every row it adds to, see its row_marks) and `grad` is not read for it -- 4 of the 28
+   * bytes per parameter of a dense Adam step, for 99 % of the rows.  The kernel clears the bytes it finds set.
+   * Needs row_elems % 4 == 0 with row_elems / 4 a power of two <= 64, 16-byte aligned tensors, no skip_rows. */
+  uint8_t* grad_marks;
 } mml_opt_tensor;
 typedef struct {
   int32_t kind;      /* MML_OPT_* */

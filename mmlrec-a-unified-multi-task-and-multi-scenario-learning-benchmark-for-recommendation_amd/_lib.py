@@ -74,7 +74,7 @@ class HeadGroup(C.Structure):
 
 class OptTensor(C.Structure):
     _fields_ = [("param", fp), ("grad", fp), ("state1", fp), ("state2", fp), ("n", i64), ("l1", C.c_float),
-                ("l2", C.c_float), ("skip_rows", fp), ("row_elems", i32), ("zero_grads", i32)]
+                ("l2", C.c_float), ("skip_rows", fp), ("row_elems", i32), ("zero_grads", i32), ("grad_marks", fp)]
 
 
 class Copy2dDesc(C.Structure):

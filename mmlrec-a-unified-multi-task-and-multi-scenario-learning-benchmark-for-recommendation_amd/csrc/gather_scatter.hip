@@ -495,9 +495,9 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
     // touched-row bookkeeping: only MARK the row here (a non-returning atomic: they run at the float-atomic request
     // rate, while the returning form that told "first time seen" cost the index-only pass 0.5 ms); the list is built
     // from the bitmaps by rows_compact_kernel
-    if (a.touched && e == 0) {
+    if (e == 0) {
       if (a.marks) a.marks[a.markbase[f] + key] = 1;  // plain store: hot rows cost nothing (see mark_rows_kernel)
-      else atomicOr(a.seen[f] + (key >> 5), 1u << (key & 31));
+      else if (a.touched) atomicOr(a.seen[f] + (key >> 5), 1u << (key & 31));
     }
   }
   if (bad && a.status) atomicOr(a.status, bad);
@@ -768,12 +768,17 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
   }
   a.X = X; a.ldX = ldX; a.idx = idx; a.ldi = ldi; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E;
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap; a.status = status;
-  set_marks(a, ft, touched ? row_marks : nullptr);
+  set_marks(a, ft, row_marks);
   const int threads = 256;
   if (!getenv("MMLREC_SCATTER_OLD")) {
     rc = try_fold(ft, a, to_stream(stream), "mml_scatter_bwd");
     if (rc <= 0) return rc;
   }
+  // only the fold kernel writes marks: a caller that asked for marks alone (mml_opt_tensor.grad_marks: "unmarked rows
+  // have a zero gradient") must not be served by a kernel that leaves them unset
+  MML_REQUIRE(!row_marks || touched, "mml_scatter_bwd: row_marks without a touched list needs E in {4, 8, 16} and a "
+              "16-byte aligned dOut with ldo %% 4 == 0 (the LDS-fold kernel)");
+  if (!touched) set_marks(a, ft, nullptr);
   if (E <= 16) {
     // dynamic LDS stays under the 64 KiB default limit: SLOTS * (1 + E) * 4 bytes = 36 KiB (4 workgroups per CU)
     const int slots = (E <= 8) ? 1024 : 512;

@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
       return (skip[row >> 5] >> (row & 31)) & 1u;
     };
     const bool zg = T.zero_grads != 0;
+    // marked gradients: a row whose byte is 0 has a zero gradient, not read.  The chunks of a row sit in adjacent lanes
+    // of ONE wave (row_elems / 4 is a power of two <= 64, chunk index = lane + multiple of 64): every lane of the row
+    // reads the byte in the same wave-instruction, before the first chunk's lane clears it further down.
+    uint8_t* const gm = T.grad_marks;
     int64_t i = tid;
-    if (unroll == 2 && !skip) {
+    if (unroll == 2 && !skip && !gm) {
       for (; i + stride < n4; i += 2 * stride) {  // eight 16-byte loads in flight per thread
         const int64_t j = i + stride;
         f4 p0 = ld(P + i), p1 = ld(P + j);
@@ -173,8 +177,14 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
     }
     for (; i < n4; i += stride) {
       if (skip && skipped(i)) continue;
+      bool live = true;
+      int64_t row = 0;
+      if (gm) {
+        row = (i << 2) / re;
+        live = gm[row] != 0;
+      }
       f4 p = ld(P + i);
-      const f4 g = zg ? zero : ld(G + i);
+      const f4 g = (zg || !live) ? zero : ld(G + i);
       f4 a = S1 ? ld(S1 + i) : zero;
       f4 b = S2 ? ld(S2 + i) : zero;
       one(p, g, a, b);
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
       if (S2) st(S2 + i, b);
       // re-zero only what the scatter touched (~1 % of the rows): saves the 4 B/element store of a blind memset
       if (h.zero_grad && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f)) G[i] = zero;
+      if (gm && live && (i << 2) == row * re) gm[row] = 0;
     }
   }
   const int64_t tail0 = vec ? (n4 << 2) : 0;
@@ -703,6 +714,14 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
       MML_REQUIRE(!t.skip_rows || (t.row_elems > 0 && t.n % t.row_elems == 0),
                   "mml_opt_step_dense: tensor %d: skip_rows needs row_elems dividing n", i);
+      if (t.grad_marks) {
+        const int cpr = t.row_elems / 4;
+        MML_REQUIRE(t.row_elems > 0 && t.row_elems % 4 == 0 && cpr <= 64 && (cpr & (cpr - 1)) == 0 &&
+                        t.n % t.row_elems == 0 && !t.skip_rows && aligned16(t.param) && aligned16(t.grad) &&
+                        (!t.state1 || aligned16(t.state1)) && (!t.state2 || aligned16(t.state2)),
+                    "mml_opt_step_dense: tensor %d: grad_marks needs 16-byte aligned [rows, row_elems] tensors with "
+                    "row_elems / 4 a power of two <= 64 and no skip_rows", i);
+      }
       L.chunk0[L.n] = chunks;
       L.t[L.n++] = t;
       total += t.n;
@@ -728,6 +747,9 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       if (hyper->max_blocks > 0 && bx * L.n > hyper->max_blocks) bx = cdiv(hyper->max_blocks, L.n);
       MML_LAUNCH(opt_dense_kernel<true>, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
     } else {
+      for (int k = 0; k < L.n; ++k)
+        MML_REQUIRE(!L.t[k].grad_marks, "mml_opt_step_dense: grad_marks is only honoured by the streaming launch "
+                    "(>= 2^24 parameters in <= 4 tensors)");
       int64_t bx = cdiv(chunks, 256);
       if (bx > 256 * 8) bx = 256 * 8;
       if (hyper->max_blocks > 0 && bx > hyper->max_blocks) bx = hyper->max_blocks;

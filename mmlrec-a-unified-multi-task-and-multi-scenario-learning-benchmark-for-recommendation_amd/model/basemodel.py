@@ -228,7 +228,7 @@ class BaseModel(nn.Module):
             self._caches["plans"][key] = plan
         return plan
 
-    def _record(self, B, training, masked, store, sparse_rows=None, lazy=False, mark_rows=None):
+    def _record(self, B, training, masked, store, sparse_rows=None, lazy=False, mark_rows=None, grad_marks=False):
         plan = E.Plan(store.device, B, training)
         plan.bn_training = bool(self.training)
         plan.generation = 0
@@ -270,6 +270,11 @@ class BaseModel(nn.Module):
         else:  # single GPU, and inference on the (synchronised) full tables of a row-sharded / replicated model
             gop = E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)
             gop.mark_rows = mark_rows
+            # marked-gradient dense table update (trainer.TrainStep decides): needs the LDS-fold scatter (E in 4, 8, 16)
+            # and one table per field (a table shared by two fields would be marked in two maps)
+            if (grad_marks and training and sparse_rows is None and E_dim in (4, 8, 16) and
+                    len({id(t) for t in tables}) == len(tables)):
+                gop.grad_marks = store.ensure_grad_marks(tables)[0]
             plan.add(gop)
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)

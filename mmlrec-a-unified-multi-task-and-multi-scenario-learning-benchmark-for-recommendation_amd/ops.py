@@ -454,8 +454,8 @@ def make_hyper(kind, lr, step=1, step_dev=None, zero_grad=False, max_blocks=0):
 
 
 def make_opt_tensors(entries):
-    """entries: (param, grad, state1 or None, state2 or None[, (l1, l2)[, skip bitmap]]) with equal element counts,
-    contiguous.  A skip bitmap (int32 words, one bit per table row) turns the entry into the untouched-rows half of the
+    """entries: (param, grad, state1 or None, state2 or None[, (l1, l2)[, skip bitmap[, gradient marks]]]) with equal
+    element counts, contiguous.  A skip bitmap (int32 words, one bit per table row) turns the entry into the untouched-rows half of the
     split dense table update (include/mmlrec.h: mml_opt_tensor.skip_rows)."""
     arr = (L.OptTensor * len(entries))()
     for d, ent in zip(arr, entries):
@@ -464,6 +464,8 @@ def make_opt_tensors(entries):
         d.l1, d.l2 = ent[4] if len(ent) > 4 and ent[4] else (0.0, 0.0)
         if len(ent) > 5 and ent[5] is not None:
             d.skip_rows, d.row_elems, d.zero_grads = ent[5].data_ptr(), p.shape[1], 1
+        if len(ent) > 6 and ent[6] is not None:  # byte marks of the rows whose gradient is non-zero (uint8 view)
+            d.grad_marks, d.row_elems = ent[6].data_ptr(), p.shape[1]
     return arr
 
 

@@ -94,14 +94,13 @@ class TrainStep:
         # Split dense table update (engine.Optimizer.can_split_dense): the reference-exact dense optimizer as
         #   early : every row the batch does NOT touch (zero gradient), streamed beside the forward / backward,
         #   tables: the touched rows, with their gradients, after the scatter (mml_opt_step_rows)
-        # -- the same arithmetic on every row as one dense launch, but the 2.3 GB stream leaves the critical path.
-        # When it pays (same-box A/B, AE-30): the stream has to be long -- with < 2^25 table parameters the row
-        # bookkeeping costs more than the ~0.1 ms stream it moves -- and the forward / backward short: at B = 4 096 the
-        # split step takes 0.70-0.76 ms against 0.77, at B = 65 536 it LOSES 2-4 % (1.95-2.01 against 1.92 ms: nothing
-        # co-resides with the GEMMs, so the early pass only adds its bookkeeping).  Default: batches up to 16 384;
-        # split_dense="force" overrides.
-        big = (sum(self.store.pvals[n].data.numel() for n in self.store.table_names) >= (1 << 25)) and int(B) <= 16384
-        split = (bool(split_dense) and (big or split_dense == "force") and self.opt.table_update == "dense_exact" and
+        # -- the same arithmetic on every row as one dense launch.  Same-box A/B on AE-30: 0.70-0.76 against 0.77 ms at
+        # B = 4 096, 1.95-2.01 against 1.92 ms at B = 65 536 (nothing co-resides with the GEMMs: the early pass only
+        # adds its bookkeeping).  Since the single launch learnt to skip the gradient read of the rows the scatter did
+        # not mark (grad_marks below: 24 instead of 28 bytes per Adam parameter, no extra launch or stream) the two
+        # are level at B = 4 096 too (0.767 / 0.769 ms on one box), so the split form only runs on request
+        # (split_dense="force").
+        split = (split_dense == "force" and self.opt.table_update == "dense_exact" and
                  (par is None or par.mode == "replicated") and
                  not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16)
         if self.opt.table_update in ("sparse_rows", "lazy_exact") or split:
@@ -118,8 +117,14 @@ class TrainStep:
         # lazy_exact lists the batch's rows in a pre-pass (before the gather), so the scatter only accumulates
         # single GPU: the gather marks the rows it reads (no separate pass over X); replicated tables need the rows of
         # the GLOBAL batch, listed by the index pre-pass
+        # Single-launch dense update: the scatter marks the rows it adds to, the optimizer reads the gradient of those
+        # rows only (mml_opt_tensor.grad_marks): 24 instead of 28 bytes per Adam parameter, no extra launch.
+        marked = (self.opt.table_update == "dense_exact" and not split and par is None and
+                  os.environ.get("MMLREC_GRAD_MARKS", "1") != "0")
         self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
-                                  lazy=lazy or split, mark_rows=rows if (split and par is None) else None)
+                                  lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
+                                  grad_marks=marked)
+        self.grad_marks = getattr(self.plan.ops[0], "grad_marks", None) is not None
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
         self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +

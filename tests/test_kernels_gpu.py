@@ -391,6 +391,68 @@ def test_optimizer_dense_matches_oracle(ops, kind):
             assert float(tg[k].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind,E", [("adam", 8), ("adagrad", 16), ("adam", 4)])
+def test_optimizer_dense_marked_gradients(ops, kind, E):
+    """mml_opt_tensor.grad_marks: the scatter marks the rows it adds to (row_marks without a touched list), the
+    streaming dense launch does not read the gradient of unmarked rows and clears the marks -- bitwise the plain dense
+    step (an unmarked row's gradient IS zero), gradients re-zeroed, marks all-zero afterwards."""
+    rng = np.random.default_rng(12)
+    vocab = [(1 << 24) // E + 37, 1000]          # one streaming table (>= 2^24 parameters) and a small one
+    F, B = len(vocab), 5000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tabs = [torch.randn(v, E, generator=g).to(dev()) for v in vocab]
+    ref = [t.clone() for t in tabs]
+    st = [[torch.rand(v, E, generator=g).to(dev()) for v in vocab] for _ in range(2)]
+    st_ref = [[t.clone() for t in s_] for s_ in st]
+    grads = [torch.zeros(v, E, device=dev()) for v in vocab]
+    grads_ref = [torch.zeros(v, E, device=dev()) for v in vocab]
+    marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=dev())
+    base = [0, (vocab[0] + 31) // 32 * 32]
+    for step in (1, 2):
+        X = np.stack([np.r_[0, vocab[f] - 1, rng.integers(0, vocab[f], B - 2)] for f in range(F)], 1).astype(np.float32)
+        d_out = T(rng.standard_normal((B, F * E)).astype(np.float32))
+        ops.scatter_bwd(grads, T(X), list(range(F)), d_out, marks=marks)           # marks only: no touched list
+        ops.scatter_bwd(grads_ref, T(X), list(range(F)), d_out)
+        for f in range(F):
+            m = marks[base[f]:base[f] + vocab[f]].cpu().numpy().astype(bool)
+            want = np.zeros(vocab[f], bool)
+            want[X[:, f].astype(np.int64)] = True
+            assert np.array_equal(m, want)
+        hyper = ops.make_hyper(kind, 0.01, step=step, zero_grad=True)
+        s2 = (lambda s_, f: s_[1][f]) if kind == "adam" else (lambda s_, f: None)
+        ops.opt_step_dense([(tabs[0], grads[0], st[0][0], s2(st, 0), None, None, marks[base[0]:base[0] + vocab[0]])],
+                           hyper)
+        ops.opt_step_dense([(ref[0], grads_ref[0], st_ref[0][0], s2(st_ref, 0))], hyper)
+        # (scatter atomics land in a different order in the two accumulators: compare to atomic-order noise, and the
+        # rows no sample touched bit for bit)
+        hit = np.zeros(vocab[0], bool)
+        hit[X[:, 0].astype(np.int64)] = True
+        untouched = torch.from_numpy(~hit).to(dev())
+        assert torch.equal(tabs[0][untouched], ref[0][untouched])
+        assert rel(tabs[0].cpu().numpy(), ref[0].cpu().numpy()) < 1e-6
+        assert rel(st[0][0].cpu().numpy(), st_ref[0][0].cpu().numpy()) < 1e-6
+        assert float(grads[0].abs().max()) == 0.0
+        assert int(marks[base[0]:base[0] + vocab[0]].max()) == 0      # cleared by the optimizer
+        assert int(marks[base[1]:base[1] + vocab[1]].max()) == 1      # the small table's marks are not consumed here
+        marks[base[1]:].zero_()
+        grads[1].zero_()
+        grads_ref[1].zero_()
+
+
+def test_marks_only_needs_the_fold_scatter_and_the_streaming_launch(ops):
+    from mmlrec_amd import _lib as L
+    vocab, E, B = [100], 6, 64                    # E = 6: not served by the LDS-fold kernel
+    grads = [torch.zeros(vocab[0], E, device=dev())]
+    marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=dev())
+    X = torch.zeros(B, 1, device=dev())
+    with pytest.raises(L.MMLError):
+        ops.scatter_bwd(grads, X, [0], torch.zeros(B, E, device=dev()), marks=marks)
+    p = torch.zeros(1000, 8, device=dev())        # far below 2^24 parameters: the flat kernel ignores marks -> rejected
+    with pytest.raises(L.MMLError):
+        ops.opt_step_dense([(p, torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p), None, None,
+                             torch.zeros(1000, dtype=torch.uint8, device=dev()))], ops.make_hyper("adam", 0.01, step=1))
+
+
 @pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam"])
 def test_optimizer_rows(ops, kind):
     """Sparse-row update equals the dense update exactly for SGD/Adagrad (rows with zero gradient do not move);
