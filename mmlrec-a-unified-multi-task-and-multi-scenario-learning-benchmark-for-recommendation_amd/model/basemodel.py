@@ -260,12 +260,18 @@ class BaseModel(nn.Module):
             plan.add(ShardedGatherOp(par, tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
         elif par is not None and training and par.mode == "row_sharded":
             from ..parallel import RowShardedGatherOp
-            plan.add(RowShardedGatherOp(par, store.pvals["embedding_shard"], plan.X, cols, dense_col0, nd, x0,
-                                        sparse_rows=sparse_rows))
+            op = RowShardedGatherOp(par, store.pvals["embedding_shard"], plan.X, cols, dense_col0, nd, x0,
+                                    sparse_rows=sparse_rows)
+            if grad_marks and sparse_rows is None and E_dim in (4, 8, 16):
+                op.grad_marks = store.ensure_grad_marks(op.tables)[0]
+            plan.add(op)
         elif par is not None and training and par.mode == "replicated":
             from ..parallel import ReplicatedGatherOp
             op = ReplicatedGatherOp(par, tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)
             op.x_in_pre = bool(lazy)  # lazy_exact gathers the global index matrix before its catch-up pass
+            if (grad_marks and sparse_rows is None and E_dim in (4, 8, 16) and
+                    len({id(t) for t in tables}) == len(tables)):
+                op.grad_marks = store.ensure_grad_marks(tables)[0]
             plan.add(op)
         else:  # single GPU, and inference on the (synchronised) full tables of a row-sharded / replicated model
             gop = E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)

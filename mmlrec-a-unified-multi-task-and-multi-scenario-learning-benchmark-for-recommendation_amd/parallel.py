@@ -148,6 +148,8 @@ class RowShardedGatherOp(E.Op):
         self.shard, self.X, self.cols, self.dense_col0, self.nd, self.out = shard_pv, X, cols, dense_col0, nd, out
         self.sparse_rows = sparse_rows
         self.lazy_launch = None
+        self.tables = [shard_pv]   # (engine.Optimizer: the one table this op's scatter feeds)
+        self.grad_marks = None     # byte per shard row: marked-gradient dense update (engine.GatherOp.grad_marks)
         # requester-side de-duplication: the exchange carries every DISTINCT row of the local batch once (under Zipf a
         # 65 536-sample AE-30 batch holds 209 k distinct rows against 1.97 M lookups), gradients of duplicates are
         # summed locally before they travel
@@ -203,7 +205,7 @@ class RowShardedGatherOp(E.Op):
             self.o_extra = (self.o_seen, self.o_rb, sr.touched.data_ptr(), sr.count.data_ptr(), sr.touched.numel(),
                             sr.marks.data_ptr())
         else:
-            self.o_extra = (None, None, None, None, 0, None)
+            self.o_extra = (None, None, None, None, 0, L.ptr(self.grad_marks))
         return [(E.PY, self._backward, (), dict(kernel="row_sharded_backward_exchange", tail=True))]
 
     # ---- run time ----------------------------------------------------------------------------------
