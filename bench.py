@@ -349,7 +349,7 @@ def main():
                                              ("one launch after the scatter, gradients read for marked rows only"
                                               if getattr(runner0, "grad_marks", False) else "one launch after the scatter")),
                    "hip_graph": not args.no_graph,
-                   "streams": 1 if args.serial else (3 if getattr(runner0, "split_dense", False) else 2),
+                   "streams": 1 if not getattr(runner0, "overlap", True) else (3 if getattr(runner0, "split_dense", False) else 2),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else
                              {"row_sharded": "row-wise sharded over ranks (owner = (row + field) mod N), one all-to-all "
                                              "per direction: keys / rows / row gradients",

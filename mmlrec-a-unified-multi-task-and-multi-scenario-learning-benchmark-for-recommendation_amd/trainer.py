@@ -132,6 +132,12 @@ class TrainStep:
                           self.opt_split["tables"])
         self.allreduce = allreduce  # callable(flat dense-gradient arena) or None
         self.use_graph = bool(use_graph)
+        # Two streams pay when there is a long table stream to put beside the weight-gradient GEMMs.  The row-wise table
+        # updates have none, and at small batches the fork / join (two more graph seams, ~16 us each) costs more than
+        # the overlap returns -- same-box A/B, lazy_exact on AE-30: 0.374 forked vs 0.338 ms serial at B = 4 096, level
+        # at 16 384, 1.655 vs 1.682 at 65 536 (dense_exact: forked wins at every batch).
+        if overlap and self.opt.table_update != "dense_exact" and int(B) <= 8192 and par is None and allreduce is None:
+            overlap = False
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=self.store.device) if self.overlap else None
         # CU partition of the forked tail (lab knob MMLREC_CU_TAIL = n: table scatter + table optimizer on compute
