@@ -176,6 +176,12 @@ class TrainStep:
                               self.use_graph)
         self.sideq = Segments(p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
         self.tail = Segments(p.bwd_tail + wait + self.opt_split["tables"], self.use_graph)
+        # one stream: the whole step is ONE call list (one HIP graph when it holds no Python-issued entry) -- every graph
+        # seam is ~16 us of idle stream, a tenth of a small-batch step
+        self.whole = None
+        if not self.overlap and not self.split_dense:
+            self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
+                                  self.opt_split["tables"] + p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
         self.calls = 0
 
     def _allreduce(self):
@@ -214,9 +220,14 @@ class TrainStep:
         profiling.push("train_step")
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
-            for seg in (self.pre, self.early, self.front, self.sideq, self.tail):
+            for seg in ((self.whole,) if self.whole is not None else
+                        (self.pre, self.early, self.front, self.sideq, self.tail)):
                 seg.capture()
             torch.cuda.synchronize()
+        if self.whole is not None:
+            self.whole.run()
+            self._done()
+            return
         self.pre.run()
         if self.side2 is not None:  # untouched table rows: their own stream, beside everything up to the row update
             main = torch.cuda.current_stream()
@@ -233,6 +244,9 @@ class TrainStep:
             self.sideq.run()
         else:
             self._forked(self.sideq.run, self.tail.run)
+        self._done()
+
+    def _done(self):
         profiling.pop()
         self.calls += 1
         self.opt.steps_done += 1
