@@ -235,6 +235,40 @@ class Plan:
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
 
+    def merge_wgrad(self):
+        """Small batches: every weight-gradient GEMM of the step in ONE grouped launch (+ one reduction) instead of one
+        pair per layer.  At M = 4 096 a layer's launch fills a fraction of the chip for ~15 us; together they take the
+        time of the longest (lazy_exact step on AE-30: 0.327 -> see DESIGN 10.12).  Only when every problem writes its
+        own dW (a weight shared by two layers is written by two launches in order).  At large batches the per-layer
+        order stays: each launch fills the chip by itself and the reductions interleave with the next GEMM."""
+        lib = L.load()
+        fn = lib.mml_gemm_grouped_wgrad_phase
+        idx = [i for i, c in enumerate(self.bwd_side) if c[0] is fn]
+        if len(idx) <= 2:
+            return False
+        descs = []
+        for i in idx:
+            c = self.bwd_side[i]
+            if c[1][4] == 1:  # the partial-product phase carries the problems (phase 2 repeats them)
+                descs += [c[1][0][k] for k in range(c[1][1])]
+        targets = [d.dW for d in descs] + [d.dbias for d in descs if d.dbias]
+        if len(set(targets)) != len(targets) or any(d.accumulate for d in descs):
+            return False
+        arr = (L.GemmWgradDesc * len(descs))()
+        for k, d in enumerate(descs):
+            C.memmove(C.byref(arr[k]), C.byref(d), C.sizeof(L.GemmWgradDesc))
+        nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(descs))
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.keep += [arr, ws]
+        flops = sum(self.bwd_side[i][2].get("flops", 0.0) for i in idx)
+        merged = [(fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 1),
+                   dict(kernel=_gemm_symbol(False, False, [], 2), flops=flops, side=True, rank=0)),
+                  (fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 2),
+                   dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1))]
+        rest = [c for i, c in enumerate(self.bwd_side) if i not in set(idx)]  # (un-padding copies: after the reduction)
+        self.bwd_side = merged + rest
+        return True
+
     def _flat_numel(self, v):
         # act_bwd is a flat kernel: value and gradient must share the padded pitch (they do by construction)
         if v.buf.stride(0) != v.grad.stride(0):

@@ -126,6 +126,8 @@ class TrainStep:
                                   lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
                                   grad_marks=marked)
         self.grad_marks = getattr(self.plan.ops[0], "grad_marks", None) is not None
+        self.wgrad_merged = int(B) <= 8192 and os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0" and \
+            self.plan.merge_wgrad()
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
         self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +
