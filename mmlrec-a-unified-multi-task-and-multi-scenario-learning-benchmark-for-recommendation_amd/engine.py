@@ -498,10 +498,41 @@ class LinearGroupOp(Op):
             if q["x"].needs_grad:
                 by_x.setdefault(id(q["x"]), (q["x"], []))[1].append(q)
         waves = []  # chunk k of every input goes into launch k: chunks of ONE input must not run concurrently
+        post = []   # sums of split input gradients, after the launches
         for x, qs in by_x.values():
             plan.grad_of(x)
             chunks = [qs[i:i + L.MAX_SRC] for i in range(0, len(qs), L.MAX_SRC)]
             fuse = len(chunks) == 1 and len(x.consumers) == 1 and x.act != L.ACT_NONE
+            # Small batches: an input fed by many layers (dnn_input: every expert and gate) is ONE problem with a long
+            # reduction -- 128 tiles of 72 k-steps at B = 4 096 on AE-30, 41 us on a chip with 256 CUs.  Its sources are
+            # dealt to up to four problems of the same launch (partial sums into scratch, one add afterwards): 4x the
+            # tiles, a quarter of the steps.  Only without an activation derivative in the epilogue (input layers).
+            ktot = sum(q["out"].n for q in qs)
+            if (plan.B <= 8192 and len(chunks) == 1 and len(qs) >= 2 and x.act == L.ACT_NONE and ktot >= 512 and
+                    os.environ.get("MMLREC_SPLIT_DGRAD", "1") != "0"):
+                nparts = min(4, len(qs))
+                parts = [[] for _ in range(nparts)]
+                for q in sorted(qs, key=lambda q_: -q_["out"].n):  # longest first into the lightest part
+                    min(parts, key=lambda p_: sum(r["out"].n for r in p_)).append(q)
+                acc = _claim(x)
+                padded = x.kpad and all("Wp" in q for q in qs)
+                g0 = _padded_view(x.grad, x.kpad) if padded else x.grad
+                pitch = x.grad.stride(0)
+                targets = [g0]
+                for _ in parts[1:]:
+                    t_ = plan.zeros(plan.B, pitch)
+                    targets.append(t_.as_strided(g0.shape, (pitch, 1)))
+                while len(waves) < 1:
+                    waves.append([])
+                for part, dst in zip(parts, targets):
+                    waves[0].append(dict(dA=dst, Y=None, act=L.ACT_NONE, mask=None, accumulate=acc if dst is g0 else 0,
+                                         srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0))
+                                               for q in part]))
+                arr = ops._ptr_array([x.grad] + [t_ for t_ in targets[1:]])
+                plan.keep.append(arr)
+                post.append((lib.mml_ew_add_n, (arr, len(targets), x.grad.data_ptr(), plan.B * pitch),
+                             dict(kernel="ew_add_n_kernel", bytes=4.0 * plan.B * pitch * (len(targets) + 1))))
+                continue
             for ci, ch in enumerate(chunks):
                 acc = _claim(x)
                 while len(waves) <= ci:
@@ -526,7 +557,7 @@ class LinearGroupOp(Op):
                         flops=sum(2.0 * plan.B * q["dA"].shape[1] * sum(sr[0].shape[1] for sr in q["srcs"])
                                   for q in dg))
             calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg)), meta))
-        return calls
+        return calls + post
 
 
 class GateGroupOp(Op):
