@@ -359,6 +359,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
   unsigned short* occ = reinterpret_cast<unsigned short*>(keys + SLOTS);  // [SLOTS] occupied slots, first-claim order
   __shared__ int n_occ;
   __shared__ unsigned mx_bits;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.touched) *a.touched_count = 0;  // (the compaction that follows appends)
   // chunk group from the XCD slot, field from the position inside the XCD (see scatter_hash_kernel)
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   int f = 0;
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
 // written by thousands of lanes -- plain same-value stores merge in L2, where same-address atomics serialise at the
 // memory side (the atomicOr form of this pass took 350 us at B = 65 536, 15 tiny tables hammering a few words each).
 __global__ __launch_bounds__(256) void mark_rows_kernel(const FieldTable ft, const ScatterArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.touched_count) *a.touched_count = 0;  // (the compaction that follows appends)
   const int64_t total = a.B * a.F;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int bad = 0;
@@ -600,7 +602,10 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(const CompactArgs a)
   }
 }
 
-static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
+// count_zeroed: the kernel launched just before (mark_rows_kernel, scatter_fold_kernel) has already reset *touched_count
+// -- one fill launch less per step, ~5 us of a 300 us small-batch step
+static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who,
+                          bool count_zeroed = false) {
   CompactArgs c{};
   int64_t words = 0;
   for (int f = 0; f < a.F; ++f) {
@@ -612,10 +617,12 @@ static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_
   c.wordbase[a.F] = words;
   c.marks = a.marks;
   c.F = a.F; c.touched = a.touched; c.count = a.touched_count; c.cap = a.touched_cap;
-  hipError_t e = hipMemsetAsync(a.touched_count, 0, sizeof(int32_t), stream);
-  if (e != hipSuccess) {
-    set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
-    return MML_ERR_HIP;
+  if (!count_zeroed) {
+    hipError_t e = hipMemsetAsync(a.touched_count, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) {
+      set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+      return MML_ERR_HIP;
+    }
   }
   int64_t maxw = 1;
   for (int f = 0; f < a.F; ++f) maxw = (c.wordbase[f + 1] - c.wordbase[f] > maxw) ? c.wordbase[f + 1] - c.wordbase[f] : maxw;
@@ -653,7 +660,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
   MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
   int rc = check_launch(who);
   if (rc || !a.touched) return rc;
-  return launch_compact(ft, a, stream, who);
+  return launch_compact(ft, a, stream, who, true);
 }
 
 // E in {4, 8, 16}, 16-byte aligned gradient rows: the restructured kernel; returns 1 when the shape is not covered
@@ -845,7 +852,7 @@ static int unique_impl(const int64_t* vocab, const int32_t* col, int32_t F, int3
     MML_LAUNCH(mark_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), ft, a);
     int rc2 = check_launch("mml_index_unique");
     if (rc2) return rc2;
-    return launch_compact(ft, a, to_stream(stream), "mml_index_unique");
+    return launch_compact(ft, a, to_stream(stream), "mml_index_unique", true);
   }
   if (!getenv("MMLREC_SCATTER_OLD")) {
     const int rc = try_fold(ft, a, to_stream(stream), "mml_index_unique");

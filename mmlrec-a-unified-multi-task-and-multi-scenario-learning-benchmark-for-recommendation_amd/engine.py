@@ -1580,7 +1580,10 @@ class Optimizer:
                 calls.append((lib.mml_opt_step_rows, (pt, pg, p1, p2, ps, rb, F, E, rows.touched.data_ptr(),
                                                       rows.count.data_ptr(), rows.touched.numel(), pl,
                                                       C.byref(hyper)), dict(kernel="opt_rows_kernel")))
-                calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
+                # the list is REBUILT every step by the compaction that follows the marking kernels (E in 4, 8, 16: it
+                # resets the counter itself); only the appending atomic path needs the reset here
+                if E not in (4, 8, 16) or os.environ.get("MMLREC_SCATTER_OLD"):
+                    calls.append((lib.mml_counter_update, (rows.count.data_ptr(), 0, 1)))
         return {"pre": pre, "early": early, "mlp": mlp_calls, "tables": calls}
 
     def _unique_pre_calls(self, plan):
