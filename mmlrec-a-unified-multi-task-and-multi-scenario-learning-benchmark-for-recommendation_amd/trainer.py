@@ -126,8 +126,11 @@ class TrainStep:
                                   lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
                                   grad_marks=marked)
         self.grad_marks = getattr(self.plan.ops[0], "grad_marks", None) is not None
-        self.wgrad_merged = int(B) <= 8192 and os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0" and \
-            self.plan.merge_wgrad()
+        # every weight-gradient GEMM of the step in one launch: at small batches (a layer's launch does not fill the chip)
+        # and whenever no table stream runs beside them (same-box A/B at B = 65 536: lazy_exact 1.677 -> 1.628 ms, but
+        # dense_exact 1.94 -> 1.98: next to the dense table update the per-layer order shares the chip better)
+        self.wgrad_merged = (int(B) <= 8192 or self.opt.table_update != "dense_exact") and \
+            os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0" and self.plan.merge_wgrad()
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
         self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +
