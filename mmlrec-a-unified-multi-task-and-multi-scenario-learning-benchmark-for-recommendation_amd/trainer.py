@@ -121,7 +121,7 @@ class TrainStep:
         # rows only (mml_opt_tensor.grad_marks): 24 instead of 28 bytes per Adam parameter, no extra launch.
         marked = (self.opt.table_update == "dense_exact" and not split and
                   (par is None or par.mode in ("row_sharded", "replicated")) and
-                  os.environ.get("MMLREC_GRAD_MARKS", "1") != "0")
+                  os.environ.get("MMLREC_GRAD_MARKS", "1") != "0" and not os.environ.get("MMLREC_SCATTER_OLD"))
         self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
                                   lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
                                   grad_marks=marked)
