@@ -5,7 +5,6 @@ through a two-token attention over (g(feat[i-1]), feat[i]) with shared value / k
 import numpy as np
 import torch.nn as nn
 
-from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import emit_towers

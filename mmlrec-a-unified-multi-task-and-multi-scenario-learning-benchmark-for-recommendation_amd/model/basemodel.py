@@ -23,7 +23,7 @@ from .. import engine as E
 from .. import ops
 from .. import profiling
 from .utils import (DenseFeat, PredictionLayer, SparseFeat, VarLenSparseFeat, build_input_features,
-                    create_embedding_matrix, get_mask)
+                    create_embedding_matrix)
 
 
 class Linear(nn.Module):

@@ -5,7 +5,6 @@ AE-30 (headline): 30 sparse fields, vocab [1e7, 1e6 x2, 1e5 x4, 1e4 x8, 1e3 x8, 
 (model_config of configs_msl/config_AE.json:32-65 with model_name -> mmoe)."""
 import copy
 
-import numpy as np
 import torch
 
 AE30_VOCAB = [10_000_000] + [1_000_000] * 2 + [100_000] * 4 + [10_000] * 8 + [1_000] * 8 + [100] * 6 + [2]
