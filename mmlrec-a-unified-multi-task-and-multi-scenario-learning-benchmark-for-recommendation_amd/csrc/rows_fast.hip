@@ -15,10 +15,28 @@
 
 namespace mml {
 
+// Sum over the LPS lanes of a lane group, result in every lane.  Inside a row of 16 lanes the exchange is a DPP modifier
+// (quad permutes, then the two mirrors: VALU only); only the steps across rows go through the LDS crossbar
+// (ds_bpermute).  As five __shfl_xor per sum the PLE gate backward issued 384 LDS instructions and 2 055 VALU
+// instructions per pair of samples and was bound by exactly those (PMC: DESIGN 10.3).
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_sel) {
+  // (ctrl as a switch on a compile-time constant: the builtin wants an immediate)
+  const int x = __builtin_bit_cast(int, v);
+  int y = x;
+  if (ctrl_sel == 0) y = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+  else if (ctrl_sel == 1) y = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  else if (ctrl_sel == 2) y = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  else y = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);                     // row_mirror
+  return v + __builtin_bit_cast(float, y);
+}
 template <int LPS>
 __device__ __forceinline__ float group_sum(float v) {
+  if (LPS >= 2) v = dpp_add(v, 0);
+  if (LPS >= 4) v = dpp_add(v, 1);
+  if (LPS >= 8) v = dpp_add(v, 2);
+  if (LPS >= 16) v = dpp_add(v, 3);
 #pragma unroll
-  for (int off = LPS / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = 16; off < LPS; off <<= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
@@ -240,6 +258,13 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   const bool hcol = 4 * sub < g.H;
 
   float* myred = red + (wave * SPW + grp) * aux.wg_total;
+  // MODE 2: the (gate, expert) -> slot map in SGPRs (read through LDS + readfirstlane on every use it was 48 LDS reads
+  // per pair of samples)
+  int smap_s[NG * NE];
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < NG * NE; ++i) smap_s[i] = __builtin_amdgcn_readfirstlane(smap[i]);
+  }
 
   if constexpr (MODE == 1) {
   // every gate mixes experts 0..ne-1 in order (MMoE): one set of expert rows serves all gates and the final dE loop
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 #pragma unroll
       for (int x = 0; x < NE; ++x) {
         dl[x] = 0.f;
-        const int slot = __builtin_amdgcn_readfirstlane(smap[gi * NE + x]);
+        const int slot = smap_s[gi * NE + x];
         if (slot >= 0) {
           dl[x] = group_sum<LPS>(hcol ? dot4(dmv[gi], Ev[x]) : 0.f);
           dot += coef[gi * MML_MAX_EXPERTS + x] * dl[x];
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
         float4 dg = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < NE; ++x) {
-          const int slot = __builtin_amdgcn_readfirstlane(smap[gi * NE + x]);
+          const int slot = smap_s[gi * NE + x];
           if (slot >= 0) {
             fma4(dg, dl[x], ld4(W + slot * d.Gd + 4 * sub));
             float* r = myred + aux.wg_off[gi] + slot * d.Gd + 4 * sub;
