@@ -9,19 +9,27 @@ python3 - $out <<'PY'
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# the last full step: find the last occurrence of the counter kernel that opens a step
 names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "counter_kernel" in n]
-# steps open with a counter kernel; take the window between the 3rd-last and 2nd-last "opening" counters that are > 10 kernels apart
-opens = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 5]
-a, b = opens[-3], opens[-2]
+# replayed steps: the shortest window between two step-opening counter kernels that holds a whole step
+best = None
+for k in range(len(starts) - 1):
+    for nxt in (1, 2):
+        if k + nxt >= len(starts):
+            continue
+        a, b = starts[k], starts[k + nxt]
+        if b - a < 15 or b - a > 45:
+            continue
+        dur = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
+        if best is None or dur < best[0]:
+            best = (dur, a, b)
+dur, a, b = best
 t0 = int(rows[a]["Start_Timestamp"])
-prev_end = t0
-busy = 0
+prev, busy = t0, 0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:8.1f} us  +{(e - s) / 1e3:6.1f} us  gap {(s - prev_end) / 1e3:5.1f}  {r['Kernel_Name'][:70]}")
+    print(f"{(s - t0) / 1e3:8.1f} us  +{(e - s) / 1e3:6.1f} us  gap {(s - prev) / 1e3:7.1f}  q={r.get('Queue_Id', '?')}  {r['Kernel_Name'][:64]}")
     busy += e - s
-    prev_end = max(prev_end, e)
-print(f"step window {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us, kernels busy {busy / 1e3:.1f} us, {b - a} kernels")
+    prev = max(prev, e)
+print(f"step window {dur / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us, {b - a} kernels")
 PY
