@@ -55,7 +55,7 @@ __device__ __forceinline__ int64_t load_index(const GatherArgs& a, int64_t b, in
 }
 
 // One thread = one 16-byte piece of the output row (E % 4 == 0) or one dense scalar.
-// ITEMS independent (index -> row -> store) chains per thread keep several HBM requests in flight per lane.
+// ITEMS (index -> row -> store) chains per thread; launched with ITEMS = 1 (see launch_gather).
 template <int ITEMS>
 __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, const GatherArgs a) {
   const int e4 = a.E >> 2;
@@ -141,11 +141,23 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
   for (int f = 0; f < a.F && vec; ++f) vec = aligned16(ft.tab[f]);
   const int threads = 256;
   if (vec) {
-    constexpr int ITEMS = 4;
-    const int64_t total = cdiv(a.B, (int64_t)ITEMS) * ((int64_t)a.F * (a.E / 4) + a.Nd);
+    // ONE item per thread.  Round 1 gave a thread four consecutive samples ("four independent chains"); in the compiled
+    // kernel the chains run one after the other (every index load is followed by its range checks), so a thread's
+    // latency was four chains long and the grid four times smaller: 240 workgroups at B = 4 096.  Graph-replayed device
+    // times on AE-30 (tools/bench_rows.py --graph, Zipf), four items -> one: 30.8 -> 4.1 us at B = 4 096, 35 -> 8 us at
+    // 16 384, 35-46 -> 22.6 us at 65 536 (5.9 TB/s algorithmic), 541 -> 513 us at 1 048 576.  MMLREC_GATHER_ITEMS=4
+    // brings the old form back (lab).
+    static int items = -1;
+    if (items < 0) {
+      const char* e = getenv("MMLREC_GATHER_ITEMS");
+      items = (e && atoi(e) == 4) ? 4 : 1;
+    }
+    const int64_t per_sample = (int64_t)a.F * (a.E / 4) + a.Nd;
+    const int64_t total = cdiv(a.B, (int64_t)items) * per_sample;
     int64_t blocks = cdiv(total, (int64_t)threads);
-    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
-    MML_LAUNCH(gather_vec4_kernel<ITEMS>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;  // (grid-stride beyond that)
+    if (items == 4) MML_LAUNCH(gather_vec4_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    else MML_LAUNCH(gather_vec4_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
   } else {
     const int64_t total = a.B * ((int64_t)a.F * a.E + a.Nd);
     int64_t blocks = cdiv(total, threads);

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--dists", default="zipf,uniform")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--workload", default="mmoe_ae30")
+    ap.add_argument("--graph", action="store_true", help="time the launches replayed from ONE HIP graph (device time of "
+                                                         "small launches; eager calls are host-bound below ~20 us)")
     args = ap.parse_args()
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd import ops, workloads as W
@@ -42,6 +44,21 @@ def main():
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize()
+                if args.graph:
+                    g_ = torch.cuda.CUDAGraph()
+                    st_ = torch.cuda.Stream()
+                    with torch.cuda.stream(st_):
+                        with torch.cuda.graph(g_, stream=st_):
+                            for _ in range(args.reps):
+                                fn()
+                    g_.replay()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    g_.replay()
+                    b.record()
+                    torch.cuda.synchronize()
+                    return a.elapsed_time(b) / args.reps
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(args.reps):
