@@ -3,7 +3,7 @@
 indices, HIP-event timed; prints one JSON line per case with the achieved fraction of the 8 TB/s HBM roofline
 (algorithmic bytes: gather F*(4+8E), scatter F*(4+12E) per sample).
 
-    python tools/bench_rows.py [--batches 65536,1048576] [--dists zipf,uniform] [--reps 20] [--old-scatter]
+    python tools/bench_rows.py [--batches 65536,1048576] [--dists zipf,uniform] [--reps 20] [--graph]
 """
 import argparse
 import json
