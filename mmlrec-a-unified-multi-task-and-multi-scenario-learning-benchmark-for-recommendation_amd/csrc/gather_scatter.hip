@@ -11,6 +11,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 namespace mml {
 
 struct FieldTable {
@@ -330,15 +332,12 @@ struct ScatterPlan {
   int32_t reps[MML_MAX_FIELDS];          // chunks folded per workgroup (direct-mapped fields: kDirectReps, others 1)
   int32_t grp_base[MML_MAX_FIELDS + 1];  // prefix sum of per-field group counts (per XCD slot)
 };
-#ifdef MML_LAB_SC_REPS
-constexpr int kDirectReps = MML_LAB_SC_REPS;
-#else
 constexpr int kDirectReps = 4;
-#endif
 
 __device__ __forceinline__ long long to_fixed(float x, int emax) {
   const unsigned u = __float_as_uint(x);
   int e = (int)((u >> 23) & 0xffu);
+  if (e == 255) return 0;             // Inf / NaN: added to the table row directly (scatter_fold_kernel), not folded
   unsigned m = u & 0x7fffffu;
   if (e) m |= 0x800000u; else e = 1;  // subnormal
   const int sh = e - emax + 28;       // <= 28: x = m * 2^(e - 150) in units of 2^(emax - 178)
@@ -401,9 +400,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
       const int64_t b = c * CHUNK + k * PER_PASS + s_in;
       if (r < reps && c < nchunks && b < a.B) {
         // (the gradient load must not wait for the index: both are issued back to back, validity is applied later)
-#ifndef MML_LAB_SC_NOLOAD
         if (a.dOut) g[r][k] = *reinterpret_cast<const float4*>(a.dOut + b * a.ldo + f * E + part * 4);
-#endif
         const int64_t row = a.idx ? (int64_t)a.idx[b * a.ldi + f] : (int64_t)a.X[b * a.ldX + colf];
         if (row < 0) bad |= 1;
         else if (row >= V) bad |= 2;
@@ -411,21 +408,13 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
       }
     }
   }
-#ifndef MML_LAB_SC_NOINIT
   if (a.dOut)
-#else
-  if (a.dOut && blockIdx.x == 0xfffffff)
-#endif
     for (int i = threadIdx.x; i < E * PITCH / 2; i += NT)
       *reinterpret_cast<float4*>(acc + i * 2) = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = threadIdx.x; i < SLOTS; i += NT) keys[i] = -1;
   if (threadIdx.x == 0) { n_occ = 0; mx_bits = 0; }
   __syncthreads();
-#ifdef MML_LAB_SC_NOMX
-  if (a.dOut && blockIdx.x == 0xfffffff) {
-#else
   if (a.dOut) {  // largest magnitude (as bit pattern) of the workgroup's gradient values -> the fixed-point scale
-#endif
 #pragma unroll
     for (int r = 0; r < kDirectReps; ++r)
 #pragma unroll
@@ -440,6 +429,9 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
     __syncthreads();
   }
   int emax = (int)(mx_bits >> 23);
+  // A diverged backward (Inf / NaN in dOut) must reach the table like it does in the reference (index_add of a NaN is
+  // NaN), not be turned into a finite fixed-point value: such elements skip the fold and go to HBM as float atomics.
+  const bool nonfinite = emax >= 255;  // workgroup-uniform
   emax = emax < 1 ? 1 : (emax > 254 ? 254 : emax);
   // ---- insert
 #pragma unroll
@@ -458,9 +450,6 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
       } else {
         if (key >= 0 && part == 0) {  // one lane per sample claims the slot ...
           slot = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
-#ifdef MML_LAB_SC_NOCLAIM
-          if (false)
-#endif
           while (true) {
             const int old = atomicCAS(&keys[slot], -1, key);
             if (old == -1) { is_new = true; break; }
@@ -479,16 +468,19 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
         }
         if (LPS > 1) slot = (unsigned)__shfl((int)slot, lane & ~(LPS - 1));  // ... its lanes follow
       }
-#ifdef MML_LAB_SC_NOLDS
-      if (a.dOut && key == -12345) {
-#else
       if (a.dOut && key >= 0) {
-#endif
         unsigned long long* p = reinterpret_cast<unsigned long long*>(acc) + (part * 4) * PITCH + slot;
         atomicAdd(p, (unsigned long long)to_fixed(g[r][k].x, emax));
         atomicAdd(p + PITCH, (unsigned long long)to_fixed(g[r][k].y, emax));
         atomicAdd(p + 2 * PITCH, (unsigned long long)to_fixed(g[r][k].z, emax));
         atomicAdd(p + 3 * PITCH, (unsigned long long)to_fixed(g[r][k].w, emax));
+        if (nonfinite) {
+          float* dst = a.gtab[f] + (int64_t)key * E + part * 4;
+          const float gv[4] = {g[r][k].x, g[r][k].y, g[r][k].z, g[r][k].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if ((__float_as_uint(gv[i]) & 0x7f800000u) == 0x7f800000u) atomicAdd(dst + i, gv[i]);
+        }
       }
     }
   }
@@ -500,11 +492,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
     const int slot = direct ? i : (int)occ[i];
     const int key = keys[slot];
     if (key < 0) continue;  // (direct-mapped: a row no sample of these chunks touched)
-#ifdef MML_LAB_SC_NOFLUSH
-    if (a.dOut && acc[e * PITCH + slot] == 12345) gt[(int64_t)key * E + e] = 1.f;
-#else
     if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
-#endif
     // touched-row bookkeeping: only MARK the row here (a non-returning atomic: they run at the float-atomic request
     // rate, while the returning form that told "first time seen" cost the index-only pass 0.5 ms); the list is built
     // from the bitmaps by rows_compact_kernel
@@ -669,15 +657,18 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
   sp.grp_base[a.F] = (int32_t)total;
   if (total * 8 > 0x7fffffff) return 1;  // caller falls back
   const size_t lds = (size_t)E * (SLOTS + 1) * 8 + (size_t)SLOTS * 4 + (size_t)SLOTS * 2;
-  static bool attr_set = false;  // more than the 64 KiB a kernel may use by default
-  if (!attr_set) {
+  // more than the 64 KiB a kernel may use by default; the attribute is per DEVICE (a process may drive several)
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_relaxed) >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
       return MML_ERR_HIP;
     }
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_relaxed);
   }
   MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
   int rc = check_launch(who);
@@ -787,7 +778,16 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
   MML_REQUIRE(B == 0 || ((X || idx) && dOut), "mml_scatter_bwd: null X/dOut");
   MML_REQUIRE(!touched || (seen && rowbase && touched_count && touched_cap > 0),
               "mml_scatter_bwd: touched list needs seen/rowbase/touched_count/cap");
-  if (B == 0 || F == 0) return MML_OK;
+  if (B == 0 || F == 0) {  // an empty batch touches no row: the list of the previous call must not survive
+    if (touched) {
+      hipError_t e = hipMemsetAsync(touched_count, 0, sizeof(int32_t), to_stream(stream));
+      if (e != hipSuccess) {
+        set_error("mml_scatter_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        return MML_ERR_HIP;
+      }
+    }
+    return MML_OK;
+  }
   ScatterArgs a{};
   for (int f = 0; f < F; ++f) {
     a.gtab[f] = grad_tables[f];
@@ -808,6 +808,13 @@ static int scatter_impl(float* const* grad_tables, const int64_t* vocab, const i
   MML_REQUIRE(!row_marks || touched, "mml_scatter_bwd: row_marks without a touched list needs E in {4, 8, 16} and a "
               "16-byte aligned dOut with ldo %% 4 == 0 (the LDS-fold kernel)");
   if (!touched) set_marks(a, ft, nullptr);
+  if (touched) {  // the fold path resets the list itself; these kernels only append
+    hipError_t e = hipMemsetAsync(touched_count, 0, sizeof(int32_t), to_stream(stream));
+    if (e != hipSuccess) {
+      set_error("mml_scatter_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+      return MML_ERR_HIP;
+    }
+  }
   if (E <= 16) {
     // dynamic LDS stays under the 64 KiB default limit: SLOTS * (1 + E) * 4 bytes = 36 KiB (4 workgroups per CU)
     const int slots = (E <= 8) ? 1024 : 512;

@@ -712,8 +712,11 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       MML_REQUIRE(t.param && t.grad && t.n >= 0, "mml_opt_step_dense: tensor %d malformed", i);
       MML_REQUIRE(hyper->kind == MML_OPT_SGD || t.state1, "mml_opt_step_dense: tensor %d needs state1", i);
       MML_REQUIRE(hyper->kind != MML_OPT_ADAM || t.state2, "mml_opt_step_dense: tensor %d needs state2 (Adam)", i);
-      MML_REQUIRE(!t.skip_rows || (t.row_elems > 0 && t.n % t.row_elems == 0),
-                  "mml_opt_step_dense: tensor %d: skip_rows needs row_elems dividing n", i);
+      // (both kernels decide per 16-byte chunk by the row of its first element: a chunk must not straddle two rows)
+      MML_REQUIRE(!t.skip_rows || (t.row_elems > 0 && t.row_elems % 4 == 0 && t.n % t.row_elems == 0 &&
+                                   aligned16(t.param)),
+                  "mml_opt_step_dense: tensor %d: skip_rows needs row_elems %% 4 == 0 dividing n and a 16-byte aligned "
+                  "parameter (16-byte chunks must lie inside one row)", i);
       if (t.grad_marks) {
         const int cpr = t.row_elems / 4;
         MML_REQUIRE(t.row_elems > 0 && t.row_elems % 4 == 0 && cpr <= 64 && (cpr & (cpr - 1)) == 0 &&

@@ -842,7 +842,11 @@ class DomainBNOp(Op):
     """DomainBatchNorm of STAR (reference model/utils.py:553-636, applied after the first star layer's activation when
     forward() is given a domain mask, model/star.py:50-51): x (a post-activation value) -> y.  gamma / beta are the
     reference's unregistered constants (1, 0).  Training mode = whole-batch statistics (mml_bn_fwd) plus the per-domain
-    population-statistics update; eval mode = per-domain normalisation with the population statistics."""
+    population-statistics update; eval mode = per-domain normalisation with the population statistics.
+
+    Training mode assumes ONE-HOT mask rows (what get_mask, model/utils.py:639-645, produces): the reference's
+    sum_d mask[b, d] * BN_batch(x[b]) then equals BN_batch(x[b]).  A row whose mask is all zero (or holds several
+    ones) would need the factor sum_d mask[b, d]; such masks are outside the contract of this op."""
     EPS, DECAY = 1e-5, 0.99
 
     def __init__(self, x, y, module, mask):
@@ -1480,7 +1484,7 @@ class Optimizer:
         gop = plan.ops[0] if plan.ops else None
         if not isinstance(gop, GatherOp):
             return False
-        return all(t.data.shape[1] <= 16 for t in gop.tables)
+        return all(t.data.shape[1] <= 16 and t.data.shape[1] % 4 == 0 for t in gop.tables)
 
     def calls_split(self, plan, split_dense=False):
         """{'pre': step-counter bump (+ the index pre-pass), 'early': the untouched-rows half of a split dense table

@@ -284,10 +284,11 @@ class RowShardedGatherOp(E.Op):
                                          self.grad_send.data_ptr(), s), "mml_rows_permute")
         comm.all_to_all_single(self.grad_recv.view(-1)[:n * Em], self.grad_send.view(-1)[:u * Em],
                                [c * Em for c in self.recv_splits], [c * Em for c in self.send_splits])
-        if n:
-            L.check(lib.mml_scatter_bwd_idx32(self.o_grad, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, n,
-                                              self.grad_recv.data_ptr(), Em, *self.o_extra, self.status.data_ptr(), s),
-                    "mml_scatter_bwd_idx32(owner)")
+        # (n == 0 included: the entry point then resets the touched-row list, so the previous step's rows are not updated
+        # a second time)
+        L.check(lib.mml_scatter_bwd_idx32(self.o_grad, self.o_vocab, 1, Em, self.recv_keys.data_ptr(), 1, n,
+                                          self.grad_recv.data_ptr(), Em, *self.o_extra, self.status.data_ptr(), s),
+                "mml_scatter_bwd_idx32(owner)")
 
 
 class ReplicatedGatherOp(E.GatherOp):
@@ -550,6 +551,18 @@ def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded"
     identically initialised model).  Returns the ParallelState (also stored as model._parallel)."""
     if mode not in MODES:
         raise ValueError(f"mode must be one of {MODES}")
+    # The N-rank contract (an N-rank step on a batch split N ways == a 1-rank step on the whole batch) holds for steps
+    # that are per-sample sums.  Two model features are not: ESCM's IPW loss normalises by batch-wide sums (N = sum y0,
+    # L1, S: mml_escm_combine sees the local shard only) and BatchNorm / DomainBatchNorm use batch statistics (per-rank
+    # statistics would silently train a different model, and the running statistics would diverge across ranks).
+    if type(model).__name__ == "ESCM":
+        raise NotImplementedError("shard_model: ESCM's IPW loss is normalised over the whole batch (not a per-sample "
+                                  "sum): the multi-GPU step would optimise a different objective")
+    bn = (bool((getattr(model, "config", None) or {}).get("model_config", {}).get("dnn_use_bn", False)) or
+          any(type(m).__name__ in ("BatchNorm1d", "DomainBatchNorm") for m in model.modules()))
+    if bn:
+        raise NotImplementedError("shard_model: BatchNorm / DomainBatchNorm use batch statistics (per-rank statistics "
+                                  "differ from the whole-batch ones): not supported on the multi-GPU path")
     comm = Comm(dist, group)
     vocab = [f.vocabulary_size for f in model._sparse_cols()]
     Em = model.embedding_size

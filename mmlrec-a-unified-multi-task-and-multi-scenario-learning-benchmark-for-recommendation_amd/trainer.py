@@ -102,7 +102,8 @@ class TrainStep:
         # (split_dense="force").
         split = (split_dense == "force" and self.opt.table_update == "dense_exact" and
                  (par is None or par.mode == "replicated") and
-                 not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16)
+                 not self.opt._table_reg(self.opt._reg_map()) and model.embedding_size <= 16 and
+                 model.embedding_size % 4 == 0)
         if self.opt.table_update in ("sparse_rows", "lazy_exact") or split:
             if par is None:
                 rows = self.store.ensure_rows(int(B) * max(len(model._sparse_cols()), 1))

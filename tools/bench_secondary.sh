@@ -7,7 +7,7 @@ out=gpurun_out/secondary.jsonl
 run() {  # name, extra env, args...
   local tag=$1; shift
   local envs=$1; shift
-  env $envs timeout 600 python3 bench.py --no-cpu-baseline --no-lazy --alt-batch 0 --steps 50 "$@" 2> gpurun_out/secondary_$tag.err | tail -1 \
+  env $envs timeout 600 python3 bench.py --no-cpu-baseline --no-configs --no-lazy --alt-batch 0 --steps 50 "$@" 2> gpurun_out/secondary_$tag.err | tail -1 \
     | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); d['tag']='$tag'; print(json.dumps(d))" >> $out \
     || echo "{\"tag\": \"$tag\", \"failed\": true}" >> $out
 }

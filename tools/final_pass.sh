@@ -8,4 +8,4 @@ bash tools/prof_serial.sh gpurun_out/prof_serial > gpurun_out/prof_serial.log 2>
 python3 bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -1 gpurun_out/bench_default.json | cut -c1-300
 bash tools/bench_secondary.sh 2>&1 | tail -14
 python3 tools/bench_rows.py --graph > gpurun_out/rows.jsonl 2> gpurun_out/rows.err; cat gpurun_out/rows.jsonl
-MMLREC_BENCH_FORCE_SHARD=1 python3 bench.py --gpus 2 --no-cpu-baseline --no-lazy > gpurun_out/bench_forced_shard.json 2> gpurun_out/bench_forced_shard.err; tail -1 gpurun_out/bench_forced_shard.json | cut -c1-200
+MMLREC_BENCH_FORCE_SHARD=1 python3 bench.py --gpus 2 --no-cpu-baseline --no-configs --no-lazy > gpurun_out/bench_forced_shard.json 2> gpurun_out/bench_forced_shard.err; tail -1 gpurun_out/bench_forced_shard.json | cut -c1-200

@@ -4,7 +4,7 @@ out=${1:-gpurun_out/prof_overlap}
 shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --alt-batch 0 --no-lazy "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-configs --alt-batch 0 --no-lazy "$@" > $out/bench.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
