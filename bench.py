@@ -92,10 +92,10 @@ def spawn_ranks(args):
 
 def loss_tolerance(step):
     """Relative tolerance of the per-step loss against the oracle-made fixture (tests/golden/bench_losses_*.json).
-    Steps 0-7 stay at 2 ln 2 per sample (every probability ~0.5: 1e-4, the contract's tolerance); afterwards the model
+    Steps 0-11 stay near 2 ln 2 per sample: 1e-4, the contract's tolerance (measured <= 3e-6).  Afterwards the model
     memorises the four rotated batches and the trajectory amplifies fp32-level differences (Adam turns the sign of a
-    noise-level gradient into a full lr step), so the bound widens with the step."""
-    return 1e-4 if step < 8 else (5e-4 if step < 12 else 3e-3)
+    noise-level gradient into a full lr step): 1e-3 (measured <= 1.6e-4 up to step 24)."""
+    return 1e-4 if step < 12 else 1e-3
 
 
 def loss_fixture(args):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_tables
+from conftest import check_tables, check_update
 
 pytestmark = pytest.mark.gpu
 
@@ -247,12 +247,17 @@ def test_bench_configuration_steps_match_oracle(W, table_update):
     else:
         assert runner.whole.n_graphs >= 1
     sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}  # (lazy_exact: flushes every row first)
+    # From the reference's 1e-4-scale initialisation the first-layer weight gradients sit at Adam's eps (1e-8), where the
+    # update lr g / (|g| + eps) amplifies the fp32 summation-order noise of a 65 536-term sum (the oracle's own numpy sum
+    # carries the same noise): a max-normalised 1e-4 bound is not attainable there, the element-wise UPDATE criterion
+    # (5 % of the reference update, outliers < 0.2 %; measured: <= 0.03 % beyond 5 %) is -- for MLP tensors and tables
+    # alike.  Gross errors (a stale buffer in a replayed graph, a race between the two streams) move elements by ~lr.
     for k, ref in params.items():
         if k.startswith("embedding_dict."):
             continue
         dv = np.abs(sd[k].astype(np.float64) - ref)
         assert dv.max() <= 2.5 * lr * nsteps, k
-        assert (dv > 1e-4 * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, (k, float(dv.max()))
+        check_update(k, before[k], sd[k], ref)
     check_tables(vocab, names, np.concatenate(Xs), before, sd, params)
 
 

@@ -17,7 +17,7 @@ def test_table_update_checker_rejects_a_sign_flipped_scatter():
     ref = before.copy()
     ref[rows] -= upd
     good = ref.copy()
-    good[rows[:3], 0] = before[rows[:3], 0] + upd[:3, 0]  # three noise-level sign flips: inside the allowance
+    good[rows[:5], 0] = before[rows[:5], 0] + upd[:5, 0]  # five noise-level sign flips: inside the allowance
     share, _ = table_update_report(before, good, ref, rows)
     assert 0 < share < 2e-3
     flipped = before.copy()
