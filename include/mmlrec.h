@@ -42,6 +42,8 @@ extern "C" {
 #define MML_MAX_GATES 8     /* gates per gate group */
 #define MML_MAX_HEADS 8     /* prediction heads per head launch */
 #define MML_MAX_OPT_TENSORS 32
+#define MML_AMAX_WORDS 8    /* words of one operand-magnitude slot (see "operand magnitudes" at the GEMM family) */
+#define MML_MAX_AMAX 16     /* tensors per mml_amax_batch launch */
 
 typedef void* mml_stream_t; /* hipStream_t */
 
@@ -195,7 +197,13 @@ int mml_rows_clear(const int32_t* list, const int32_t* count, int32_t cap, const
  *       v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh; the dropped terms are <= 2^-24 |a b|) with fp32
  *       accumulation.  Max-norm error against float64 equals the fp32 MFMA's (4.7e-7 vs 4.3e-7 on a
  *       8192 x 256 x 240 product, tools/bench_gemm.py); the other launches use the fp32 MFMA;
- *   3 = the three-plane form on every launch of the LDS-DMA kernel;
+ *       When every operand of a launch comes with its magnitude (the amax fields of the descriptors below), auto runs
+ *       the TWO-PLANE fp16 form instead: each operand is scaled by a power of two that puts its largest magnitude below
+ *       2^15, cut into h = rne16(x s), l = rne16(x s - h) (x s = h + l to 22-23 significant bits), a 16-k block costs
+ *       three v_mfma_f32_32x32x16_f16 (hh, hl, lh) and the fp32 accumulators are scaled back exactly in the epilogue.
+ *       Max-norm error against float64 3.4e-7 (three bf16 planes 4.7e-7, fp32 MFMA 4.3e-7), 25-30 % faster;
+ *   2 = same as auto;
+ *   3 = the three-plane bf16 form on every launch of the LDS-DMA kernel (magnitudes ignored);
  *   1 = REDUCED precision, opt-in: operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per 16-k block,
  *       fp32 accumulation (~3e-3 relative per product; not covered by the 1e-4 parity contract).
  * Environment MMLREC_GEMM_MODE overrides the default. */
@@ -208,6 +216,22 @@ const char* mml_gemm_last_kernel(void);
  * wgrad GEMMs on a side stream next to an HBM-bound kernel (the dense table optimizer) sets ~17 KiB so that only three
  * wgrad workgroups fit a CU and the other kernel's waves can co-reside. */
 int mml_gemm_set_wgrad_lds_pad(int32_t bytes);
+
+/* Operand magnitudes.  A magnitude slot is MML_AMAX_WORDS consecutive uint32 words on the device; its value is the
+ * LARGEST of them, read as the bit pattern of a non-negative float: an upper bound of max |x| over a tensor (0 = the
+ * tensor is all zero).  Producers raise a slot with atomic max on any of its words (mml_amax_batch; the GEMM launches
+ * through amax_out: the magnitude of what they stored), nobody lowers it: mml_amax_reset zeroes slots at the start of a
+ * step.  A GEMM launch whose descriptors all carry the magnitudes of BOTH operands may run the two-plane fp16
+ * arithmetic (mml_gemm_set_mode); a stale-high bound costs precision only at 2^-39 of the bound, a too-LOW bound
+ * overflows fp16 -- so a slot must cover everything the tensor holds when the GEMM runs. */
+typedef struct {
+  const float* x;   /* [rows, cols], row pitch ld */
+  int64_t rows, ld;
+  int32_t cols, pad_;
+  uint32_t* slot;   /* MML_AMAX_WORDS words */
+} mml_amax_desc;
+int mml_amax_batch(const mml_amax_desc* descs, int32_t n, mml_stream_t stream);
+int mml_amax_reset(uint32_t* slots, int64_t n_slots, mml_stream_t stream);
 
 typedef struct {
   const float* A;    /* [M, K] input activations                                  */
@@ -224,6 +248,10 @@ typedef struct {
    * to apply relu'.  ldmask >= ceil(N / 32) words per row. */
   uint32_t* relu_mask;
   int64_t ldmask;
+  /* Optional operand magnitudes (see above): of A, of W; amax_out receives the magnitude of C. */
+  const uint32_t* amax_a;
+  const uint32_t* amax_w;
+  uint32_t* amax_out;
 } mml_gemm_fwd_desc;
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
@@ -278,6 +306,11 @@ typedef struct {
   /* Optional: the sign mask mml_gemm_grouped_fwd wrote for Y (act must be MML_ACT_RELU); used instead of Y. */
   const uint32_t* relu_mask;
   int64_t ldmask;
+  /* Optional operand magnitudes: of dC[s] and W[s] for every source; amax_out receives the magnitude of dA as stored
+   * (after the derivative and the accumulation). */
+  const uint32_t* amax_dc[MML_MAX_SRC];
+  const uint32_t* amax_w[MML_MAX_SRC];
+  uint32_t* amax_out;
 } mml_gemm_dgrad_desc;
 int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
 
@@ -291,6 +324,9 @@ typedef struct {
   int32_t accumulate; /* 1: dW/dbias += ; 0: overwrite               */
   int32_t w_kn;
   int32_t pad_;
+  /* Optional operand magnitudes of dC and A. */
+  const uint32_t* amax_dc;
+  const uint32_t* amax_a;
 } mml_gemm_wgrad_desc;
 /* The reduction over the batch is split across workgroups; partial tiles go to `workspace` and are
  * summed in a fixed order by a second kernel (bitwise reproducible). */
@@ -334,6 +370,12 @@ typedef struct {
   int32_t e_relu;                   /* experts end in ReLU (always true for DNN, model/utils.py:155-156) */
   int64_t B;
   mml_gate_desc gate[MML_MAX_GATES];
+  /* Optional operand-magnitude slots (see "operand magnitudes" at the GEMM family), each shared by all tensors of its
+   * kind: raised with max |mix| over every gate's mixture (forward), max |dE| over every expert gradient and max |dG|
+   * over every gate-input gradient (backward).  NULL = not wanted. */
+  uint32_t* amax_mix;
+  uint32_t* amax_dE;
+  uint32_t* amax_dG;
 } mml_gate_group;
 int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream);
 int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp);
@@ -374,6 +416,7 @@ typedef struct {
   const float* dprob; /* [B, lddprob] upstream dL/dprob used INSTEAD of the BCE gradient when y == NULL (autograd path) */
   int64_t lddprob;
   mml_head_desc head[MML_MAX_HEADS];
+  uint32_t* amax_dH;  /* optional operand-magnitude slot raised with max |dH| over all heads (training), or NULL */
 } mml_head_group;
 int64_t mml_head_workspace_bytes(const mml_head_group* grp);
 int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream);

@@ -22,7 +22,11 @@ i32, i64 = C.c_int32, C.c_int64
 class GemmFwdDesc(C.Structure):
     _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("lda", i64), ("ldw", i64), ("ldc", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32),
-                ("relu_mask", fp), ("ldmask", i64)]
+                ("relu_mask", fp), ("ldmask", i64), ("amax_a", fp), ("amax_w", fp), ("amax_out", fp)]
+
+
+class AmaxDesc(C.Structure):
+    _fields_ = [("x", fp), ("rows", i64), ("ld", i64), ("cols", i32), ("pad_", i32), ("slot", fp)]
 
 
 class PlanesCutDesc(C.Structure):
@@ -40,12 +44,14 @@ class GemmDgradDesc(C.Structure):
     _fields_ = [("dA", fp), ("Y", fp), ("ldda", i64), ("ldy", i64), ("M", i32), ("K", i32), ("act", i32),
                 ("n_src", i32), ("accumulate", i32), ("pad_", i32),
                 ("dC", fp * MAX_SRC), ("W", fp * MAX_SRC), ("lddc", i64 * MAX_SRC), ("ldw", i64 * MAX_SRC),
-                ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC), ("relu_mask", fp), ("ldmask", i64)]
+                ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC), ("relu_mask", fp), ("ldmask", i64),
+                ("amax_dc", fp * MAX_SRC), ("amax_w", fp * MAX_SRC), ("amax_out", fp)]
 
 
 class GemmWgradDesc(C.Structure):
     _fields_ = [("dC", fp), ("A", fp), ("dW", fp), ("dbias", fp), ("lddc", i64), ("lda", i64), ("lddw", i64),
-                ("M", i32), ("N", i32), ("K", i32), ("accumulate", i32), ("w_kn", i32), ("pad_", i32)]
+                ("M", i32), ("N", i32), ("K", i32), ("accumulate", i32), ("w_kn", i32), ("pad_", i32),
+                ("amax_dc", fp), ("amax_a", fp)]
 
 
 class GateDesc(C.Structure):
@@ -57,7 +63,7 @@ class GateDesc(C.Structure):
 class GateGroup(C.Structure):
     _fields_ = [("E", fp * MAX_EXPERTS), ("dE", fp * MAX_EXPERTS), ("lde", i64 * MAX_EXPERTS),
                 ("ldde", i64 * MAX_EXPERTS), ("n_experts", i32), ("n_gates", i32), ("H", i32), ("e_relu", i32),
-                ("B", i64), ("gate", GateDesc * MAX_GATES)]
+                ("B", i64), ("gate", GateDesc * MAX_GATES), ("amax_mix", fp), ("amax_dE", fp), ("amax_dG", fp)]
 
 
 class HeadDesc(C.Structure):
@@ -69,7 +75,7 @@ class HeadDesc(C.Structure):
 class HeadGroup(C.Structure):
     _fields_ = [("n_heads", i32), ("pad_", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
                 ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("dprob", fp), ("lddprob", i64),
-                ("head", HeadDesc * MAX_HEADS)]
+                ("head", HeadDesc * MAX_HEADS), ("amax_dH", fp)]
 
 
 class OptTensor(C.Structure):
@@ -125,6 +131,8 @@ _SIGS = {
     "mml_lookup_slots": (C.c_int, [fp, i64, _PP(i32), _PP(i64), _PP(i64), i32, i64, fp, fp, fp, fp]),
     "mml_rows_clear": (C.c_int, [fp, fp, i32, _PP(i64), _PP(fp), i32, fp]),
     "mml_shard_rows": (C.c_int, [fp, i64, fp, i64, i32, i32, i32, i32, fp]),
+    "mml_amax_batch": (C.c_int, [_PP(AmaxDesc), i32, fp]),
+    "mml_amax_reset": (C.c_int, [fp, i64, fp]),
     "mml_gemm_set_mode": (C.c_int, [i32]),
     "mml_gemm_get_mode": (C.c_int, []),
     "mml_gemm_last_kernel": (C.c_char_p, []),

@@ -3,6 +3,7 @@
 The .so is kept in-tree (git-ignored) so it travels to the GPU box with the snapshot.
 """
 import glob
+import time
 import os
 import subprocess
 import sys
@@ -57,6 +58,7 @@ def _build_locked(force, verbose, jobs):
     all_srcs = sources()
     if not all_srcs:
         raise RuntimeError("no HIP sources under " + CSRC)
+    t_build = time.time()  # (the library gets this time stamp: see the end of this function)
     hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(os.path.dirname(HERE), "include", "mmlrec.h")]
     hdr_time = _newest(hdrs)
 
@@ -73,13 +75,17 @@ def _build_locked(force, verbose, jobs):
 
     def reap(block):
         for item in list(procs):
-            p, src = item
+            p, src, t_start, obj = item
             if block:
                 p.wait()
             if p.poll() is not None:
                 procs.remove(item)
                 if p.returncode != 0:
                     failed.append(src)
+                elif os.path.exists(obj):
+                    # an object is as new as the moment its compile STARTED: a source edited while hipcc ran (minutes for
+                    # gemm.hip) must look newer than the object it did not go into
+                    os.utime(obj, (t_start, t_start))
 
     while pending or procs:
         while pending and len(procs) < jobs:
@@ -95,7 +101,8 @@ def _build_locked(force, verbose, jobs):
                 stderr = open(obj + ".log", "w")
             if verbose:
                 print("[mmlrec build]", " ".join(cmd), flush=True)
-            procs.append((subprocess.Popen(cmd, stderr=stderr), src))
+            t_start = time.time()
+            procs.append((subprocess.Popen(cmd, stderr=stderr), src, t_start, obj))
         reap(block=True)
     if failed:
         for src in failed:
@@ -111,6 +118,7 @@ def _build_locked(force, verbose, jobs):
     if verbose:
         print("[mmlrec build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.utime(tmp, (t_build, t_build))  # anything edited since the build began is newer than the library (needs_build)
     os.replace(tmp, LIBPATH)
     return LIBPATH
 

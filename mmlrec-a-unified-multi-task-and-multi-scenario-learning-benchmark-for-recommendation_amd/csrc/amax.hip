@@ -1,0 +1,96 @@
+// Operand magnitudes for the two-plane fp16 GEMM arithmetic (include/mmlrec.h, "operand magnitudes"): the largest |x|
+// of a tensor as a float bit pattern (for non-negative floats the unsigned order of the bits is the order of the
+// values), raised with atomic max.  The GEMM launches produce the magnitudes of their own outputs; this file serves
+// tensors that come from elsewhere (weights at the start of a step, outputs of the row kernels).  HBM-bound: one read.
+#include "common.hpp"
+
+namespace mml {
+
+struct AmaxLaunch {
+  mml_amax_desc t[MML_MAX_AMAX];
+  int32_t blk0[MML_MAX_AMAX + 1];  // first workgroup of tensor i in the 1-D grid
+  int32_t n;
+};
+
+__global__ __launch_bounds__(256) void amax_kernel(const AmaxLaunch L) {
+  int ti = 0;
+  while (ti + 1 < L.n && (int)blockIdx.x >= L.blk0[ti + 1]) ++ti;
+  const mml_amax_desc& T = L.t[ti];
+  const int bx = (int)blockIdx.x - L.blk0[ti], nb = L.blk0[ti + 1] - L.blk0[ti];
+  uint32_t am = 0;
+  const bool vec = (T.cols % 4 == 0) && (T.ld % 4 == 0) && aligned16(T.x);
+  if (vec) {
+    const int c4 = T.cols / 4;
+    const int64_t total = T.rows * c4;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+      const int64_t r = i / c4;
+      const int c = (int)(i - r * c4);
+      const float4 v = *reinterpret_cast<const float4*>(T.x + r * T.ld + 4 * c);
+      am = max(max(am, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+      am = max(max(am, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+    }
+  } else {
+    const int64_t total = T.rows * T.cols;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+      const int64_t r = i / T.cols;
+      am = max(am, __float_as_uint(T.x[r * T.ld + (i - r * T.cols)]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = max(am, (uint32_t)__shfl_xor((int)am, o));
+  __shared__ uint32_t wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    am = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (am) atomicMax(T.slot + (bx & (MML_AMAX_WORDS - 1)), am);
+  }
+}
+
+__global__ __launch_bounds__(256) void amax_reset_kernel(uint32_t* slots, int64_t words) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) slots[i] = 0u;
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_amax_batch: bad descriptor array");
+  int i = 0;
+  while (i < n) {
+    AmaxLaunch L{};
+    int total = 0;
+    while (i < n && L.n < MML_MAX_AMAX) {
+      const mml_amax_desc& q = d[i];
+      MML_REQUIRE(q.slot && q.rows >= 0 && q.cols >= 0 && q.ld >= q.cols && (q.x || q.rows * q.cols == 0),
+                  "mml_amax_batch: tensor %d malformed", i);
+      ++i;
+      if (q.rows * q.cols == 0) continue;
+      int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);  // >= 16 elements per thread, 4 workgroups per CU at most
+      if (nb > 1024) nb = 1024;
+      L.blk0[L.n] = total;
+      L.t[L.n++] = q;
+      total += (int)nb;
+    }
+    L.blk0[L.n] = total;
+    if (total == 0) continue;
+    MML_LAUNCH(amax_kernel, dim3((unsigned)total), dim3(256), 0, to_stream(stream), L);
+    int rc = check_launch("mml_amax_batch");
+    if (rc) return rc;
+  }
+  return MML_OK;
+}
+
+extern "C" int mml_amax_reset(uint32_t* slots, int64_t n_slots, mml_stream_t stream) {
+  MML_REQUIRE(n_slots >= 0 && (n_slots == 0 || slots), "mml_amax_reset: bad arguments");
+  if (n_slots == 0) return MML_OK;
+  // a kernel, not hipMemsetAsync: the step is replayed from HIP graphs, and a memset NODE captured in front of the
+  // kernels that raise the slots did not keep its place in the replayed order with the runtime of this image (the
+  // consumers then read zeros -> scale 2^110 -> Inf)
+  const int64_t words = n_slots * MML_AMAX_WORDS;
+  int64_t nb = cdiv(words, 256);
+  if (nb > 1024) nb = 1024;
+  MML_LAUNCH(amax_reset_kernel, dim3((unsigned)nb), dim3(256), 0, to_stream(stream), slots, words);
+  return check_launch("mml_amax_reset");
+}

@@ -22,6 +22,32 @@ __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_c
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// ---- operand magnitudes (include/mmlrec.h): per-lane running maximum of |x| bit patterns, published at kernel end ----
+__device__ __forceinline__ void amax_acc(uint32_t& am, float v) {
+  const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+  am = b > am ? b : am;
+}
+__device__ __forceinline__ void amax_acc(uint32_t& am, const float4& v) {
+  amax_acc(am, v.x); amax_acc(am, v.y); amax_acc(am, v.z); amax_acc(am, v.w);
+}
+// Call with the whole wave converged.  Wave maximum, then at most ONE atomic per wave -- and none when the slot word
+// already holds a value at least as large (slots only ever grow during a launch, so a stale read can only cost an
+// unnecessary atomic; thousands of waves hammering one address serialise at the memory side otherwise).
+__device__ __forceinline__ void amax_flush(uint32_t am, uint32_t* slot) {
+  if (!slot) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)am, o, 64);
+    am = t > am ? t : am;
+  }
+  if ((threadIdx.x & 63) == 0 && am) {
+    uint32_t* p = slot + (blockIdx.x & (MML_AMAX_WORDS - 1));
+    if (__atomic_load_n(p, __ATOMIC_RELAXED) < am) atomicMax(p, am);
+  }
+}
+#endif
+
 }  // namespace mml
 
 // hipGetLastError() is sticky per host thread: an error left behind by an unrelated earlier HIP call (e.g. a device

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_fwd_kernel(const mml_gate_
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * ROW_WAVES;
+  uint32_t am_mix = 0;
   for (int64_t b = wave0; b < g.B; b += nwaves) {
     for (int gi = 0; gi < g.n_gates; ++gi) {
       const mml_gate_desc& d = g.gate[gi];
@@ -71,9 +72,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_fwd_kernel(const mml_gate_
             acc += logit[e] * g.E[x][b * g.lde[x] + h];
           }
         d.mix[b * d.ldmix + h] = acc;
+        amax_acc(am_mix, acc);
       }
     }
   }
+  amax_flush(am_mix, g.amax_mix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_bwd_kernel(const mml_gate_
 
   const int64_t wave0 = (int64_t)blockIdx.x * ROW_WAVES + wave;
   const int64_t nwaves = (int64_t)gridDim.x * ROW_WAVES;
+  uint32_t am_dg = 0, am_de = 0;
   for (int64_t b = wave0; b < g.B; b += nwaves) {
     for (int i = lane; i < MML_MAX_GATES * MML_MAX_EXPERTS; i += 64) coef[i] = 0.f;
     // phase A: per gate softmax backward, dG, dWg
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_bwd_kernel(const mml_gate_
           }
         if (d.g_relu && !(gk > 0.f)) dg = 0.f;
         d.dG[b * d.lddg + k] = dg;
+        amax_acc(am_dg, dg);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -158,10 +163,13 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_bwd_kernel(const mml_gate_
           for (int gi = 0; gi < MML_MAX_GATES; ++gi) acc += coef[gi * MML_MAX_EXPERTS + x] * dmv[gi];
           if (g.e_relu && !(g.E[x][b * g.lde[x] + h] > 0.f)) acc = 0.f;
           g.dE[x][b * g.ldde[x] + h] = acc;
+          amax_acc(am_de, acc);
         }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  amax_flush(am_dg, g.amax_dG);
+  amax_flush(am_de, g.amax_dE);
   __syncthreads();
   float* out = aux.slab + (int64_t)blockIdx.x * aux.wg_total;
   for (int i = threadIdx.x; i < aux.wg_total; i += ROW_BLOCK) out[i] = wacc[i];
@@ -186,6 +194,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void head_kernel(const mml_head_group g,
   float dwacc[MML_MAX_HEADS][HEAD_SLOTS];
   float dbacc[MML_MAX_HEADS];
   float lossacc = 0.f;
+  uint32_t am_dh = 0;
 #pragma unroll
   for (int t = 0; t < MML_MAX_HEADS; ++t) {
     dbacc[t] = 0.f;
@@ -242,12 +251,14 @@ __global__ __launch_bounds__(ROW_BLOCK) void head_kernel(const mml_head_group g,
             float dh = dlogit * wv[s];
             if (d.h_relu && !(hv[s] > 0.f)) dh = 0.f;
             d.dH[b * d.lddh + h] = dh;
+            amax_acc(am_dh, dh);
           }
         }
       }
     }
   }
   if (!aux.train) return;
+  amax_flush(am_dh, g.amax_dH);
   // workgroup reduction: waves -> LDS -> fixed-order sum by wave 0 -> slab
   const int per_head = HEAD_SLOTS * 64 + 1;
 #pragma unroll

@@ -37,6 +37,10 @@ struct Source {
   int64_t lda, ldb;
   int32_t Kred;    // reduction extent of this source
   int32_t vecA, vecB;  // 16-byte vector loads legal
+  // magnitudes of the two operands (MML_AMAX_WORDS words each: the largest is the bit pattern of an upper bound of
+  // max |x|), or null: the two-plane fp16 arithmetic needs both for every source of a launch
+  const uint32_t* amaxA;
+  const uint32_t* amaxB;
 };
 
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_SLAB = 2 };
@@ -62,7 +66,37 @@ struct Problem {
   int32_t bias_cols;   // 0: bias partials are sums of the ROW operand (rows = n); 1: of the COL operand (w_kn)
   float* bias_slab;    // [S][n] partial sums over the batch of dC, or null
   int64_t slab_off;    // float offset of this problem's slab in the workspace
+  uint32_t* amax_out;  // fwd / dgrad: MML_AMAX_WORDS words that receive max |C| (atomic max of bit patterns), or null
 };
+
+// ---- operand magnitudes (mml_amax_*, the amax fields of the GEMM descriptors) ----
+// A magnitude slot is MML_AMAX_WORDS consecutive words; producers atomicMax the bit pattern of |x| into ANY of them
+// (which one is picked from the workgroup / wave number, so that thousands of same-address atomics do not serialise
+// at the memory side), consumers take the largest.
+__device__ __forceinline__ uint32_t amax_load(const uint32_t* p) {
+  if (!p) return 0x3f800000u;  // (no magnitude given: scale 2^14; the host only selects the fp16 form when all are there)
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < MML_AMAX_WORDS; ++i) m = p[i] > m ? p[i] : m;
+  return m;
+}
+// power-of-two exponent k with |x| 2^k < 2^15 for every |x| <= the slot's value (fp16: largest finite 65504)
+__device__ __forceinline__ int amax_scale_exp(uint32_t bits) {
+  int e = (int)((bits >> 23) & 0xffu);  // |x| < 2^(e - 126)
+  if (e == 255) return 0;               // Inf / NaN in the operand: they propagate whatever the scale
+  int k = 141 - e;
+  return k > 110 ? 110 : (k < -110 ? -110 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+// wave-wide maximum of a per-lane bit pattern, then ONE atomic per wave into the slot
+__device__ __forceinline__ void amax_publish(uint32_t am, uint32_t* slot, int salt) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ o) << 2), (int)am);
+    am = t > am ? t : am;
+  }
+  if ((threadIdx.x & 63) == 0 && am) atomicMax(slot + (salt & (MML_AMAX_WORDS - 1)), am);
+}
 
 struct Launch {
   Source src[MAX_SOURCES];
@@ -302,6 +336,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
     return;
   }
 
+  uint32_t am = 0;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -331,8 +366,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void gemm_kernel(const Lau
           if (P.accumulate) v += *dst;
         }
         *dst = v;
+        am = max(am, __float_as_uint(v) & 0x7fffffffu);
       }
     }
+  if (P.amax_out) amax_publish(am, P.amax_out, blockIdx.x * 4 + wave);
 }
 
 // ====================================================================================================
@@ -424,11 +461,20 @@ template <>
 struct Prep<0> {
   float x[8];
 };
+// EMU 2: two fp16 planes of the scaled operand (three v_mfma_f32_32x32x16_f16 per 16-k block: hh, hl, lh)
+template <>
+struct Prep<2> {
+  f16x8 h, l;
+};
 
 template <int EMU, bool RC>
-__device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o) {
+__device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o, const float scale = 1.f) {
   if constexpr (EMU == 0) {
     r.get(o.x);
+  } else if constexpr (EMU == 2) {
+    float x[8];
+    r.get(x);
+    split_f16_planes(x, scale, o.h, o.l);
   } else {
     float x[8];
     r.get(x);
@@ -439,7 +485,11 @@ __device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o) {
 // (ablation, tools/lab: what the kernel would run at if the COLUMN operand -- the weights in fwd / dgrad -- arrived
 // already cut into planes: its conversion is replaced by a free bit-cast; results are garbage)
 template <int EMU, bool RC>
-__device__ __forceinline__ void prep_frag_b(const RawFrag<RC>& r, Prep<EMU>& o) {
+__device__ __forceinline__ void prep_frag_b(const RawFrag<RC>& r, Prep<EMU>& o, const float scale = 1.f) {
+  if constexpr (EMU == 2) {
+    prep_frag<EMU>(r, o, scale);
+    return;
+  }
 #ifdef MML_LAB_NO_CONVERT_B
   if constexpr (EMU != 0) {
     float x[8];
@@ -461,6 +511,10 @@ __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const
   if constexpr (EMU == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x[k], a.x[k], acc, 0, 0, 0);
+  } else if constexpr (EMU == 2) {  // smallest products first; l x l (<= 2^-22 of the product) is dropped
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
   } else {
 #pragma unroll
     for (int lvl = EMU - 1; lvl >= 0; --lvl)  // smallest products first
@@ -475,6 +529,40 @@ __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const
   }
 }
 
+// EMU 2: one product block (three dependent MFMAs, ~32 cycles each) with the cut of ONE raw fragment dealt into their
+// shadows by hand: 8 + 8 + 4 VALU instructions.
+#ifdef MML_LAB_F16_AUTO  // (tools/lab A/B: leave the placement of the fp16 cuts to the compiler)
+constexpr bool kF16Manual = false;
+#else
+constexpr bool kF16Manual = true;
+#endif
+template <bool RC>
+__device__ __forceinline__ void mma_prep_f16(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
+                                             const float scale, Prep<2>& o) {
+  float x[8];
+  r.get(x);
+  F16Cut c;
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_hr(x, scale, c, 0);
+  f16_cut_hr(x, scale, c, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_hr(x, scale, c, 2);
+  f16_cut_hr(x, scale, c, 3);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_l(c, 0);
+  f16_cut_l(c, 1);
+  f16_cut_l(c, 2);
+  f16_cut_l(c, 3);
+  f16_cut_done(c, o.h, o.l);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Keeps a prepared operand's conversion where it was written: without a use in the same block hipcc sinks the VALU
 // work of an operand that is only consumed by the NEXT step out of the MFMA shadow it was placed in.
 template <int EMU>
@@ -482,6 +570,9 @@ __device__ __forceinline__ void pin_prep(Prep<EMU>& o) {
   if constexpr (EMU == 0) {
     asm volatile("" : "+v"(o.x[0]), "+v"(o.x[1]), "+v"(o.x[2]), "+v"(o.x[3]));
     asm volatile("" : "+v"(o.x[4]), "+v"(o.x[5]), "+v"(o.x[6]), "+v"(o.x[7]));
+  } else if constexpr (EMU == 2) {
+    asm volatile("" : "+v"(o.h));
+    asm volatile("" : "+v"(o.l));
   } else {
 #pragma unroll
     for (int p = 0; p < EMU; ++p) asm volatile("" : "+v"(o.p[p]));
@@ -522,7 +613,9 @@ __device__ __forceinline__ float act_bwd_t(float y) {
 // BCOLS (weight-gradient launches only): the bias partials are batch sums of the COLUMN operand ([K,N] weights) instead
 // of the row operand; uniform per launch (the host groups problems by layout), so the per-step sums carry no branch.
 template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false>
-__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
+// (128 x 64 input-gradient kernels: two workgroups per CU like the wide tiles -- their epilogue (mask words, Y, the
+// accumulate target) does not fit the 168 registers three would leave)
+__global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
   typedef const __attribute__((address_space(4))) Launch KLaunch;
   KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();  // see gemm_glds_kernel
   constexpr int NI = BN / 64;
@@ -532,9 +625,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
   constexpr int NSTORE = 8 * NI;     // 16-byte epilogue stores per wave of an interior tile
   constexpr int NBIAS = (EPI == EPI_FWD) ? 1 : 0;  // the next tile's bias DMA follows the stores
   constexpr int AFTER_EPI = (LOADS + NSTORE + NBIAS < 63) ? LOADS + NSTORE + NBIAS : 63;
-  constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 1 ? 1 : 6);  // MFMAs per block
+  constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 1 ? 1 : (EMU == 2 ? 3 : 6));  // MFMAs per block
   constexpr int NVALU = EMU == 0 ? 0 : 8;  // VALU slots per MFMA of a block with one prepare (EMU 1: 4 cvt_pk)
-  __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256];  // + one 64-float bias slot per wave
+  // + one 64-float bias slot per wave + one word per problem: the largest |output| this workgroup stored for it
+  __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256 + MML_MAX_GROUP];
   const int tid = threadIdx.x;
   // wave as a SCALAR: the LDS destinations of the DMA (wave-dependent) then live in SGPRs; as a VGPR expression every
   // DMA needed v_readfirstlane -> s_mov m0 inside the loop, a VALU -> SALU hand-over that waits for the wave's MFMAs
@@ -552,6 +646,38 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     bool want_bias, bias_cols;  // wgrad: this tile also sums the bias partials (of the row / column operand)
     bool short_tile;            // fewer than three k-steps: the bias DMA may still be in flight at the epilogue
     bool counted;               // interior tile with 16-byte stores: its epilogue leaves exactly NSTORE stores in flight
+    float sA, sB, inv;          // EMU 2: power-of-two scales of the row / column operand of this problem, 1 / (sA sB)
+  };
+  // EMU 2: ONE scale pair per problem (the smallest over its sources: accumulation across sources needs a common unit)
+  auto problem_scales = [&](const int pi, float& sA, float& sB, float& inv) __attribute__((always_inline)) {
+    int kA = 110, kB = 110;
+    const int s0 = L.p[pi].src0, ns = L.p[pi].nsrc;
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const int ka = amax_scale_exp(amax_load(L.src[s0 + s2].amaxA));
+      const int kb = amax_scale_exp(amax_load(L.src[s0 + s2].amaxB));
+      kA = ka < kA ? ka : kA;
+      kB = kb < kB ? kb : kB;
+    }
+    // 1 / (sA sB) must be ONE fp32 number (the epilogue multiplies once): where the exponents add up beyond its range
+    // -- two operands below 2^-48, whose products fp32 can barely hold -- both scales give way equally
+    const int over = kA + kB - 126, under = -126 - (kA + kB);
+    if (over > 0) { kA -= (over + 1) >> 1; kB -= over >> 1; }
+    if (under > 0) { kA += (under + 1) >> 1; kB += under >> 1; }
+    kA = __builtin_amdgcn_readfirstlane(kA);
+    kB = __builtin_amdgcn_readfirstlane(kB);
+    sA = pow2f(kA);
+    sB = pow2f(kB);
+    inv = pow2f(-(kA + kB));
+  };
+  // ... of the tile a virtual id names (the look-ahead of the last step of a tile)
+  auto scales_of_vid = [&](const int64_t vid, float& sA, float& sB) __attribute__((always_inline)) {
+    if (vid >= total) return;
+    const int outer = (int)(vid / L.total_ntiles);
+    const int j = (int)(vid - (int64_t)outer * L.total_ntiles);
+    int pi = 0;
+    while (pi + 1 < L.n && j >= L.p[pi + 1].tile0) ++pi;
+    float inv_unused;
+    problem_scales(pi, sA, sB, inv_unused);
   };
   auto decode = [&](Cursor& c) __attribute__((always_inline)) {
     c.ok = c.vid < total;
@@ -587,6 +713,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     c.want_bias = (EPI == EPI_SLAB) && L.p[pi].bias_slab != nullptr && (c.bias_cols ? c.row0 == 0 : c.col0 == 0);
     c.short_tile = (EPI != EPI_SLAB) && (c.nsrc == 1) && (c.kend - c.k0 < 3 * GK);
     c.counted = c.row0 + BM <= c.M && c.col0 + BN <= c.N && (EPI == EPI_SLAB || L.p[pi].vec_out != 0);
+    if constexpr (EMU == 2) problem_scales(pi, c.sA, c.sB, c.inv);
+    else c.sA = c.sB = c.inv = 1.f;
   };
   auto last_step = [&](const Cursor& c) __attribute__((always_inline)) {
     return c.k0 + GK >= c.kend && (EPI == EPI_SLAB || c.s + 1 >= c.nsrc);
@@ -722,6 +850,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
 
   // ---- epilogue: lane = output row, registers = four runs of 4 consecutive columns.  The activation is dispatched ONCE
   // per tile (a per-element `switch` made this 10 000 instructions of branchy code that cost as much as 14 k-steps).
+  // EMU 2: the accumulators hold sum (a sA)(b sB); one exact power-of-two multiplication brings them back
+  auto unscale = [&](const float v, const Cursor& c) __attribute__((always_inline)) -> float {
+    if constexpr (EMU == 2) return v * c.inv;
+    else return v;
+  };
+  // largest |stored output| of this lane's part of the current tile (fwd / dgrad with amax_out): v_max_f32 with an |x|
+  // source modifier, one instruction per element (a NaN does not register; it reaches the consumer as a NaN anyway)
+  float am_f = 0.f;
   auto epilogue_slab = [&](const Cursor& c) __attribute__((always_inline)) {
     const int pi = c.pi;
     const int row0 = c.row0, col0 = c.col0, PM = c.M, PN = c.N;
@@ -752,7 +888,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
           if (row < PM && col < PN)
             *reinterpret_cast<float4*>(slab + (int64_t)row * PN + col) =
-                make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+                make_float4(unscale(acc[mi][ni][4 * g], c), unscale(acc[mi][ni][4 * g + 1], c),
+                            unscale(acc[mi][ni][4 * g + 2], c), unscale(acc[mi][ni][4 * g + 3], c));
         }
     }
   };
@@ -823,7 +960,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           for (int g = 0; g < 4; ++g) {
             const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
             if (!row_ok || col >= PN) continue;
-            float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+            float4 v = make_float4(unscale(acc[mi][ni][4 * g], c), unscale(acc[mi][ni][4 * g + 1], c),
+                                   unscale(acc[mi][ni][4 * g + 2], c), unscale(acc[mi][ni][4 * g + 3], c));
             float* dst = C + (int64_t)row * ldc + col;
             if (EPI == EPI_FWD) {
               if (bias) {
@@ -851,6 +989,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
               }
             }
             *reinterpret_cast<float4*>(dst) = v;
+            am_f = fmaxf(fmaxf(am_f, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
           }
         if (EPI == EPI_FWD && mask) {  // the two half-waves hold the odd / even 4-column groups of the same rows
 #pragma unroll
@@ -897,7 +1036,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4_t v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            const f32x4_t v = {unscale(acc[mi][ni][4 * g], c), unscale(acc[mi][ni][4 * g + 1], c),
+                               unscale(acc[mi][ni][4 * g + 2], c), unscale(acc[mi][ni][4 * g + 3], c)};
             ds_write128(tb + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) * 16), v);
           }
           f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
@@ -963,6 +1103,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
               x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
             }
             *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;
+            am_f = fmaxf(fmaxf(am_f, fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
           }
         }
       }
@@ -980,7 +1121,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
             const int bit = 8 * (r >> 2) + 4 * h + (r & 3);
             const int col = cg + bit;
             if (row >= PM || col >= PN) continue;
-            float x = acc[mi][ni][r];
+            float x = unscale(acc[mi][ni][r], c);
             float* dst = C + (int64_t)row * ldc + col;
             if (EPI == EPI_FWD) {
               x = act_fwd_t<ACT>(x + (bias ? bias[col] : 0.f));
@@ -994,6 +1135,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
               if (accumulate) x += *dst;
             }
             *dst = x;
+            am_f = fmaxf(am_f, fabsf(x));
           }
           if (EPI == EPI_FWD && mask) {
             const uint32_t w = mw | xor_lane(mw, 32);
@@ -1017,6 +1159,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
       case MML_ACT_SIGMOID2: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_SIGMOID2>{}); break;
       default: epilogue_act(c, so_epi, std::integral_constant<int, MML_ACT_NONE>{}); break;
     }
+    // The output's magnitude for the GEMMs that will read it: wave maximum -> the workgroup's word of this problem in
+    // LDS (ds_max_u32, asm like every LDS access of this kernel); ONE global atomic per workgroup and problem follows at
+    // the end of the kernel.  (A global atomic per tile stalled the pipeline: the counted waits make every younger
+    // load wait for it -- +0.1 ms per launch at M = 65 536.)
+    // (every lane issues the LDS atomic on the same word: ~2 cycles per lane once per tile, and no registers for a wave
+    // reduction -- the 128 x 64 input-gradient kernels sit at their 168-VGPR limit)
+    if (L.p[c.pi].amax_out) {
+      const uint32_t a = lds0 + (uint32_t)(PSTAGES * STG + 256 + c.pi) * 4u;
+      const uint32_t am_bits = __float_as_uint(am_f);
+      asm volatile("ds_max_u32 %0, %1" ::"v"(a), "v"(am_bits) : "memory");
+    }
+    am_f = 0.f;
   };
 
   // ---- fragment reads of one stage: the stage's byte offset is a run-time VGPR add (the reads are inline asm, so the
@@ -1040,6 +1194,11 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
   RawFrag<ARC> RA1[2];
   RawFrag<BRC> RB1[2];
 
+  if (EPI != EPI_SLAB && tid < MML_MAX_GROUP) {  // (ordered before the first epilogue by the barriers of the k-steps)
+    const uint32_t a = lds0 + (uint32_t)(PSTAGES * STG + 256 + tid) * 4u;
+    const uint32_t z = 0u;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(z) : "memory");
+  }
   Cursor cur;
   cur.vid = xcd_remap(blockIdx.x, gridDim.x);
   decode(cur);
@@ -1081,12 +1240,19 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
         if (NI == 2) bs_cur[1] = sum8(RB1[0]);
       }
     }
-    prep_frag<EMU>(a0, PA0[0]);
-    prep_frag_b<EMU>(b0, PB0[0]);
+    prep_frag<EMU>(a0, PA0[0], cur.sA);
+    prep_frag_b<EMU>(b0, PB0[0], cur.sB);
   }
 
   auto step = [&](auto par_c) __attribute__((always_inline)) {
     constexpr int P = decltype(par_c)::value, Q = P ^ 1;
+    // The operands of step i + 1 are prepared in the shadow of this step's MFMAs; at the end of a tile they belong to
+    // the NEXT tile (possibly another problem, with other scales), so the cursor is advanced HERE and installed below.
+    const bool tile_end = last_step(cur);
+    float nsA = cur.sA, nsB = cur.sB;
+    if constexpr (EMU == 2) {
+      if (__builtin_expect(tile_end, 0)) scales_of_vid(cur.vid + gridDim.x, nsA, nsB);
+    }
     const int sidx = i & (PSTAGES - 1);
     const uint32_t so_cur = (uint32_t)sidx * (STG * 4);
     const uint32_t so_next = (uint32_t)((sidx + 1) & (PSTAGES - 1)) * (STG * 4);
@@ -1136,14 +1302,19 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     unsigned long long t3 = 0;
 #endif
     if (NI == 2) {
-      prep_frag_b<EMU>(RB1[P], PB1);
-      mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
-      interleave_hint<NMFMA, NVALU>();
-      __builtin_amdgcn_sched_barrier(0);
-      prep_frag<EMU>(RA1[P], PA1);
-      mma_block<EMU>(acc[0][NI - 1], PA0[P], PB1);
-      interleave_hint<NMFMA, NVALU>();
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EMU == 2 && kF16Manual) {
+        mma_prep_f16(acc[0][0], PA0[P], PB0[P], RB1[P], cur.sB, PB1);
+        mma_prep_f16(acc[0][NI - 1], PA0[P], PB1, RA1[P], cur.sA, PA1);
+      } else {
+        prep_frag_b<EMU>(RB1[P], PB1, cur.sB);
+        mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
+        interleave_hint<NMFMA, NVALU>();
+        __builtin_amdgcn_sched_barrier(0);
+        prep_frag<EMU>(RA1[P], PA1, cur.sA);
+        mma_block<EMU>(acc[0][NI - 1], PA0[P], PB1);
+        interleave_hint<NMFMA, NVALU>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       nb0.landed();
       na0.landed();
@@ -1163,18 +1334,23 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           bs_next[1] = sum8(RB1[Q]);
         }
       }
-      prep_frag_b<EMU>(nb0, PB0[Q]);
-      mma_block<EMU>(acc[1][0], PA1, PB0[P]);
-      pin_prep<EMU>(PB0[Q]);
-      interleave_hint<NMFMA, NVALU>();
-      __builtin_amdgcn_sched_barrier(0);
-      prep_frag<EMU>(na0, PA0[Q]);
-      mma_block<EMU>(acc[1][NI - 1], PA1, PB1);
-      pin_prep<EMU>(PA0[Q]);
-      interleave_hint<NMFMA, NVALU>();
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EMU == 2 && kF16Manual) {
+        mma_prep_f16(acc[1][0], PA1, PB0[P], nb0, nsB, PB0[Q]);
+        mma_prep_f16(acc[1][NI - 1], PA1, PB1, na0, nsA, PA0[Q]);
+      } else {
+        prep_frag_b<EMU>(nb0, PB0[Q], nsB);
+        mma_block<EMU>(acc[1][0], PA1, PB0[P]);
+        pin_prep<EMU>(PB0[Q]);
+        interleave_hint<NMFMA, NVALU>();
+        __builtin_amdgcn_sched_barrier(0);
+        prep_frag<EMU>(na0, PA0[Q], nsA);
+        mma_block<EMU>(acc[1][NI - 1], PA1, PB1);
+        pin_prep<EMU>(PA0[Q]);
+        interleave_hint<NMFMA, NVALU>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
-      prep_frag<EMU>(RA1[P], PA1);
+      prep_frag<EMU>(RA1[P], PA1, cur.sA);
       mma_block<EMU>(acc[0][0], PA0[P], PB0[P]);
       interleave_hint<NMFMA, NVALU>();
       __builtin_amdgcn_sched_barrier(0);
@@ -1191,15 +1367,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
           bs_next[0] = sum8(nb0);
         }
       }
-      prep_frag_b<EMU>(nb0, PB0[Q]);
-      prep_frag<EMU>(na0, PA0[Q]);
+      prep_frag_b<EMU>(nb0, PB0[Q], nsB);
+      prep_frag<EMU>(na0, PA0[Q], nsA);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
       pin_prep<EMU>(PB0[Q]);
       pin_prep<EMU>(PA0[Q]);
       interleave_hint<NMFMA, 2 * NVALU>();
       __builtin_amdgcn_sched_barrier(0);
     }
-    const bool tile_end = last_step(cur);
 #ifdef MML_LAB_TIMES
     const bool lab_last = tile_end;
 #endif
@@ -1270,6 +1445,19 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_pipe_kernel(cons
     if (!cur.ok) break;
     step(I1{});
   }
+  if (EPI != EPI_SLAB) {  // the workgroup's magnitudes -> the slots (every wave left the loop at the same step)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < L.n) {
+      uint32_t* const amo = L.p[tid].amax_out;
+      if (amo) {
+        const uint32_t a = lds0 + (uint32_t)(PSTAGES * STG + 256 + tid) * 4u;
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        if (v) atomicMax(amo + (blockIdx.x & (MML_AMAX_WORDS - 1)), v);
+      }
+    }
+  }
 }
 
 // host-side eligibility of a whole launch for the direct-to-LDS path
@@ -1307,7 +1495,7 @@ static int g_wgrad_pad = -1;  // unused dynamic LDS requested by wgrad launches 
 static int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("MMLREC_GEMM_MODE");
-    g_gemm_mode = (e && (e[0] == '0' || e[0] == '1' || e[0] == '3')) ? e[0] - '0' : 4;
+    g_gemm_mode = (e && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4;
   }
   return g_gemm_mode;
 }
@@ -1336,7 +1524,14 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     return MML_ERR_ARG;
   }
   dim3 g((unsigned)nblocks), b(256);
-  const int emu = tc.emu;  // 0 = fp32 MFMA, 1 = bf16 operands, 3 = three bf16 planes
+  int emu = tc.emu;  // 0 = fp32 MFMA, 1 = bf16 operands, 2 = two scaled fp16 planes, 3 = three bf16 planes
+  if (emu == 3 && gemm_mode() != 3) {  // every operand of the launch comes with its magnitude: two fp16 planes
+    bool all = true;
+    for (int i = 0; i < L.n && all; ++i)
+      for (int s = 0; s < L.p[i].nsrc && all; ++s)
+        all = L.src[L.p[i].src0 + s].amaxA != nullptr && L.src[L.p[i].src0 + s].amaxB != nullptr;
+    if (all) emu = 2;
+  }
   const bool bcols = (EPI == EPI_SLAB) && L.n > 0 && L.p[0].bias_cols != 0;  // (uniform per launch: see the wgrad entry)
   (void)bcols;
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  An unused
@@ -1357,7 +1552,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
         n = 256;
       cus = n;
     }
-    const int64_t slots = (int64_t)cus * (bn == 64 ? 3 : 2);
+    const int64_t slots = (int64_t)cus * ((bn == 64 && EPI != EPI_DGRAD) ? 3 : 2);
     if (nblocks > slots) g = dim3((unsigned)slots);
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
 #define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU, false>), g, b, dyn, st, L)
@@ -1366,6 +1561,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   do {                                                                                       \
     if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);       \
     else if (emu == 1) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 1, C_>), g, b, dyn, st, L);  \
+    else if (emu == 2) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2, C_>), g, b, dyn, st, L);  \
     else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, C_>), g, b, dyn, st, L);                \
   } while (0)
 #define MML_GL2(A_, B_, N_)                                  \
@@ -1441,7 +1637,7 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
   tc.bn = (pad128 * 100 <= pad64 * 150) ? 128 : 64;  // wide tiles unless > 1/3 of their columns would be padding
   if (row_tiles * (pad128 / 128) < 1024) tc.bn = 64;  // ... or they would not fill the 512 resident slots twice
   if (force == 64 || force == 128) tc.bn = force;
-  tc.emu = (mode == 0) ? 0 : (mode == 1 ? 1 : 3);
+  tc.emu = (mode == 0) ? 0 : (mode == 1 ? 1 : 3);  // (3 becomes 2 in launch_tiles when the magnitudes are there)
   (void)kind;
   (void)kred;
   return tc;
@@ -1452,9 +1648,10 @@ static TileChoice pick_tiles(const int32_t* Ns, int n, int kind, int64_t kred, i
 using namespace mml;
 
 extern "C" int mml_gemm_set_mode(int32_t mode) {
-  MML_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 4,
-              "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16 operands, reduced precision), 3 (fp32 emulated "
-              "from three bf16 planes on every LDS-DMA launch) or 4 (auto)");
+  MML_REQUIRE(mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 4,
+              "mml_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16 operands, reduced precision), 2 / 4 (auto: fp32 "
+              "emulated from two scaled fp16 planes where the operand magnitudes are given, else from three bf16 "
+              "planes) or 3 (three bf16 planes on every LDS-DMA launch)");
   g_gemm_mode = mode;
   return MML_OK;
 }
@@ -1500,6 +1697,8 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       Source& S0 = L.src[j - i];
       S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
       S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
+      S0.amaxA = q.amax_a; S0.amaxB = q.amax_w;
+      P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
       MML_REQUIRE(!q.relu_mask || q.ldmask * 32 >= q.N, "mml_gemm_grouped_fwd: ldmask too small in problem %d", j);
       P.mask = (q.act == MML_ACT_RELU) ? q.relu_mask : nullptr; P.ldmask = q.ldmask;
@@ -1555,7 +1754,9 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
         S.A = q.dC[s]; S.lda = q.lddc[s]; S.B = q.W[s]; S.ldb = q.ldw[s];
         S.Kred = q.N[s];
         S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
+        S.amaxA = q.amax_dc[s]; S.amaxB = q.amax_w[s];
       }
+      P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
       MML_REQUIRE(!q.relu_mask || (q.act == MML_ACT_RELU && q.ldmask * 32 >= q.K),
                   "mml_gemm_grouped_dgrad: relu_mask needs act == RELU and ldmask >= K/32 (problem %d)", j);
@@ -1682,9 +1883,11 @@ extern "C" int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* d, int32_
       // batch-major in memory, i.e. NOT reduction-contiguous.
       if (!q.w_kn) {
         S.A = q.dC; S.lda = q.lddc; S.B = q.A; S.ldb = q.lda;
+        S.amaxA = q.amax_dc; S.amaxB = q.amax_a;
         P.M = q.N; P.N = q.K;
       } else {
         S.A = q.A; S.lda = q.lda; S.B = q.dC; S.ldb = q.lddc;
+        S.amaxA = q.amax_a; S.amaxB = q.amax_dc;
         P.M = q.K; P.N = q.N;
       }
       S.Kred = q.M;

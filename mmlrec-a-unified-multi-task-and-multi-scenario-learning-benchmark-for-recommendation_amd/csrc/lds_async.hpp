@@ -108,4 +108,56 @@ __device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&out)[
   }
 }
 
+// fp32 value -> TWO fp16 planes of the scaled value: h = rne16(x s), l = rne16(x s - h).  The residual is exact in fp32
+// (h agrees with x s in its leading 11 bits), so h + l carries 22-23 significant bits of x s as long as l stays a
+// normal fp16 number; s is a power of two chosen per operand tensor from its largest magnitude (see gemm.hip).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_f16_planes(const float (&x)[8], float s, f16x8& hi, f16x8& lo) {
+  // Five VALU instructions per PAIR of values, the scale folded in (mixed-precision FMAs: fp32 sources, fp16 result /
+  // an fp16 addend): h = rne16(x s) into the low / high half, r = x s - h exactly, l = rne16(r) packed.  Written as asm
+  // because hipcc forms v_pk_mul_f32 + v_cvt_pk + 2 v_cvt_f32_f16 + v_pk_fma_f32 + v_cvt_pk from the C expression
+  // (8 issue slots per pair: packed fp32 ops run at half rate), which made the kernel VALU-bound again.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t hw[4], lw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t h, l;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x[2 * j]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x[2 * j + 1]), "v"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x[2 * j]), "v"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x[2 * j + 1]), "v"(s), "v"(h));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+    hw[j] = h;
+    lw[j] = l;
+  }
+  const u32x4 a = {hw[0], hw[1], hw[2], hw[3]}, b = {lw[0], lw[1], lw[2], lw[3]};
+  hi = __builtin_bit_cast(f16x8, a);
+  lo = __builtin_bit_cast(f16x8, b);
+}
+
+// The same cut, piecewise: the pipelined GEMM places the pieces by hand in the shadows of the three MFMAs of a product
+// block (asm statements are invisible to sched_group_barrier, which arranges the bf16 forms)
+struct F16Cut {
+  uint32_t h[4], l[4];
+  float r0[4], r1[4];
+};
+__device__ __forceinline__ void f16_cut_hr(const float (&x)[8], const float s, F16Cut& c, const int j) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h[j]) : "v"(x[2 * j]), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h[j]) : "v"(x[2 * j + 1]), "v"(s));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.r0[j]) : "v"(x[2 * j]), "v"(s), "v"(c.h[j]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=v"(c.r1[j])
+      : "v"(x[2 * j + 1]), "v"(s), "v"(c.h[j]));
+}
+__device__ __forceinline__ void f16_cut_l(F16Cut& c, const int j) {
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.l[j]) : "v"(c.r0[j]), "v"(c.r1[j]));
+}
+__device__ __forceinline__ void f16_cut_done(const F16Cut& c, f16x8& hi, f16x8& lo) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 a = {c.h[0], c.h[1], c.h[2], c.h[3]}, b = {c.l[0], c.l[1], c.l[2], c.l[3]};
+  hi = __builtin_bit_cast(f16x8, a);
+  lo = __builtin_bit_cast(f16x8, b);
+}
+
 }  // namespace mml

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
+  uint32_t am_mix = 0;
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -124,10 +125,14 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
         float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < NE; ++e) fma4(acc, p[e], Ev[e]);  // p[e] == 0 beyond the gate's expert count
-        if (valid) st4(d.mix + b * d.ldmix + 4 * sub, acc);
+        if (valid) {
+          st4(d.mix + b * d.ldmix + 4 * sub, acc);
+          amax_acc(am_mix, acc);
+        }
       }
     }
   }
+  amax_flush(am_mix, g.amax_mix);
 }
 
 // Load-once forward (at most NE experts in the group, any membership): the softmax of every gate first, its
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
+  uint32_t am_mix = 0;
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -211,11 +217,15 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
         float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < NE; ++x) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], Ev[x]);
-        if (valid) st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 4 * sub, acc);
+        if (valid) {
+          st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 4 * sub, acc);
+          amax_acc(am_mix, acc);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  amax_flush(am_mix, g.amax_mix);
 }
 
 // ------------------------------------------------------------------------------------------------ gate backward
@@ -258,6 +268,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   const bool hcol = 4 * sub < g.H;
 
   float* myred = red + (wave * SPW + grp) * aux.wg_total;
+  uint32_t am_dg = 0, am_de = 0;  // operand magnitudes of everything this lane stores (mml_gate_group.amax_dG / amax_dE)
   // MODE 2: the (gate, expert) -> slot map in SGPRs (read through LDS + readfirstlane on every use it was 48 LDS reads
   // per pair of samples)
   int smap_s[NG * NE];
@@ -331,7 +342,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv[gi].z > 0.f)) dg.z = 0.f;
           if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
         }
-        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+        if (valid) {
+          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          amax_acc(am_dg, dg);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -348,7 +362,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev[x].z > 0.f)) acc.z = 0.f;
           if (!(Ev[x].w > 0.f)) acc.w = 0.f;
         }
-        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+        if (valid) {
+          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          amax_acc(am_de, acc);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -418,7 +435,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv[gi].z > 0.f)) dg.z = 0.f;
           if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
         }
-        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+        if (valid) {
+          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          amax_acc(am_dg, dg);
+        }
       }
     }
     if (hcol) {
@@ -434,7 +454,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev[x].z > 0.f)) acc.z = 0.f;
           if (!(Ev[x].w > 0.f)) acc.w = 0.f;
         }
-        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+        if (valid) {
+          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          amax_acc(am_de, acc);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -498,7 +521,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv.z > 0.f)) dg.z = 0.f;
           if (!(Gv.w > 0.f)) dg.w = 0.f;
         }
-        if (valid) st4(d.dG + b * d.lddg + 4 * sub, dg);
+        if (valid) {
+          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          amax_acc(am_dg, dg);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -515,12 +541,17 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev.z > 0.f)) acc.z = 0.f;
           if (!(Ev.w > 0.f)) acc.w = 0.f;
         }
-        if (valid) st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+        if (valid) {
+          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          amax_acc(am_de, acc);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
   }
+  amax_flush(am_dg, g.amax_dG);
+  amax_flush(am_de, g.amax_dE);
   // combine: fixed-order sum over the lane-group regions -> slab
   __syncthreads();
   float* out = aux.slab + (int64_t)blockIdx.x * aux.wg_total;
@@ -544,6 +575,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
   float4 dwacc[NT];
   float dbacc[NT];
   float lossacc = 0.f;
+  uint32_t am_dh = 0;
   float4 wv[NT];
   float bias[NT];
 #pragma unroll
@@ -602,12 +634,16 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
             if (!(hv.z > 0.f)) dh.z = 0.f;
             if (!(hv.w > 0.f)) dh.w = 0.f;
           }
-          if (valid) st4(d.dH + b * d.lddh + 4 * sub, dh);
+          if (valid) {
+            st4(d.dH + b * d.lddh + 4 * sub, dh);
+            amax_acc(am_dh, dh);
+          }
         }
       }
     }
   }
   if (!aux.train) return;
+  amax_flush(am_dh, g.amax_dH);
   constexpr int PH = 4 * LPS + 1;  // per head: dw (4*LPS slots) + dbias
 #pragma unroll
   for (int t = 0; t < NT; ++t) {

@@ -29,6 +29,10 @@ class PVal:
         self.needs_grad = needs_grad and grad is not None
         self.is_table = is_table
         self.written = 0  # build-time counter: first writer overwrites, later writers accumulate
+        # True: a trained parameter (ParamStore) that changes only in the optimizer -- its magnitude is measured ONCE at
+        # the start of a step.  False: a tensor some op of the step produces (STAR's effective weights, APG's generated
+        # ones): measured where it is used.
+        self.stable = False
 
 
 class Val:
@@ -45,6 +49,11 @@ class Val:
         # never written -- a GEMM may then read it as a [B, kpad] operand (LinearGroupOp: reduction lengths that
         # are not a multiple of the 16-wide k-step, e.g. 30 x 8 embedding columns + 63 dense columns = 303)
         self.kpad = 0
+        # operand magnitudes for the two-plane fp16 GEMMs (include/mmlrec.h): slot of the value, slot of its gradient,
+        # and how many of the gradient's writers raised that slot (valid iff it equals `written`)
+        self.amax = None
+        self.gamax = None
+        self.gamax_writers = 0
 
     @property
     def n(self):
@@ -80,6 +89,19 @@ class Plan:
         self.dprob = None
         self.X = None
         self.layer_outputs = {}
+        # operand magnitudes (ops.amax_slots): one pool per plan, zeroed at the start of every forward; the magnitudes of
+        # the stable weights are measured by ONE launch right after (amax_pre, put in front of `fwd` by finish())
+        # Batches of 16 384 and more: the GEMMs are throughput-bound and the two-plane fp16 form pays (AE-30 at 65 536:
+        # GEMM family 1.14 -> 1.0 ms).  Below, a step is a chain of ~25 short launches: the three extra ones (slot reset,
+        # weight magnitudes, dnn_input) and the per-tile magnitude loads cost more than the arithmetic saves
+        # (lazy_exact AE-30 at 4 096: 0.27 -> 0.35 ms), so the three-plane bf16 form stays.  MMLREC_AMAX=0 / 1 forces.
+        env = os.environ.get("MMLREC_AMAX", "")
+        self.use_amax = (env != "0") and (env == "1" or self.B >= 16384)
+        self.amax_pool = ops.amax_slots(1024, device) if (device.type == "cuda" and self.use_amax) else None
+        self.amax_next = 0
+        self.amax_weights = {}   # (data_ptr, shape) -> slot
+        self.amax_wlist = []     # (tensor, slot) of the stable weights
+        self.n_pre = 0           # entries of `fwd` that precede the first op's calls
 
     # ---- buffers -----------------------------------------------------------------------------
     def empty(self, *shape, dtype=torch.float32):
@@ -119,6 +141,60 @@ class Plan:
                 ld = (v.n + 3) // 4 * 4
                 v.grad = self.empty(self.B, ld)[:, :v.n] if ld != v.n else self.empty(self.B, v.n)
         return v.grad
+
+    # ---- operand magnitudes --------------------------------------------------------------------
+    def new_amax(self):
+        if self.amax_pool is None:
+            return None
+        if self.amax_next >= self.amax_pool.shape[0]:
+            raise L.MMLError("operand-magnitude pool exhausted")
+        self.amax_next += 1
+        return self.amax_pool[self.amax_next - 1]
+
+    def weight_amax(self, pv, tensor, need):
+        """Slot of a GEMM weight operand.  `tensor` may be a zero-padded copy of pv.data (same magnitude).  Stable
+        parameters join the start-of-step launch; anything else is appended to `need` (measured before the launch that
+        is being recorded)."""
+        if self.amax_pool is None:
+            return None
+        key = (pv.data.data_ptr(), tuple(pv.data.shape))
+        if key in self.amax_weights:
+            return self.amax_weights[key]
+        slot = self.new_amax()
+        if getattr(pv, "stable", False):
+            self.amax_weights[key] = slot
+            self.amax_wlist.append((pv.data, slot))
+        else:
+            need.append((pv.data, slot))  # (not cached: re-measured by every launch that reads it -- it may change)
+        return slot
+
+    def value_amax(self, v, view, need):
+        """Slot of a forward value used as a GEMM operand: the producer's, or measured now (once)."""
+        if self.amax_pool is None:
+            return None
+        if v.amax is None:
+            v.amax = self.new_amax()
+            need.append((view, v.amax))
+        return v.amax
+
+    def grad_amax(self, v, need):
+        """Slot of v.grad as a GEMM operand, called when every writer of the gradient has been recorded: the slot the
+        writers raised if ALL of them did, else measured now."""
+        if self.amax_pool is None:
+            return None
+        if v.gamax is not None and v.gamax_writers == v.written and v.written > 0:
+            return v.gamax
+        v.gamax = self.new_amax()
+        v.gamax_writers = v.written
+        need.append((v.grad, v.gamax))
+        return v.gamax
+
+    def amax_call(self, need, **meta):
+        arr = ops.make_amax_descs(need)
+        self.keep.append(arr)
+        m = dict(kernel="amax_kernel", bytes=4.0 * sum(t.numel() for t, _ in need))
+        m.update(meta)
+        return (L.load().mml_amax_batch, (arr, len(need)), m)
 
     # ---- execution ---------------------------------------------------------------------------
     @staticmethod
@@ -213,6 +289,7 @@ class Plan:
                 v.consumers.append(head_op)
         self.head_infer = head_op.infer_calls(self)
         if not self.training:
+            self._amax_prologue()
             return
         self.head_train = head_op.train_calls(self, use_dprob=False)
         self.head_bwd = head_op.train_calls(self, use_dprob=True, claim=False)
@@ -230,10 +307,23 @@ class Plan:
                     self.bwd_tail.append(c)
                 else:
                     self.bwd.append(c)
+        self._amax_prologue()
         # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
         # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
+
+    def _amax_prologue(self):
+        """Zero EVERY magnitude slot of the plan (forward and backward ones: the producers only ever raise them) and
+        measure the stable weights, as the first entries of `fwd`.  Called when the whole plan has been recorded."""
+        if self.amax_pool is None or not self.amax_next or self.n_pre:
+            return
+        pre = [(L.load().mml_amax_reset, (self.amax_pool.data_ptr(), self.amax_next),
+                dict(kernel="amax_reset", bytes=32.0 * self.amax_next))]
+        if self.amax_wlist:
+            pre.append(self.amax_call(self.amax_wlist))
+        self.fwd = pre + self.fwd
+        self.n_pre = len(pre)
 
     def merge_wgrad(self):
         """Small batches: every weight-gradient GEMM of the step in ONE grouped launch (+ one reduction) instead of one
@@ -439,10 +529,21 @@ class LinearGroupOp(Op):
                 q["Wp"] = plan.zeros(q["W"].data.shape[0], kp)
                 pads.append((q["W"].data, q["Wp"]))
         pre = [_copy2d_batch_call(plan, pads)] if pads else []
+        # operand magnitudes: the input's (its producer's, or measured here), the weight's (start of the step), and the
+        # output's is produced by this launch for the GEMMs that read it
+        need = []
+        for q in self.p:
+            q["amax_a"] = plan.value_amax(q["x"], q.get("Ap", q["x"].buf), need)
+            q["amax_w"] = plan.weight_amax(q["W"], q.get("Wp", q["W"].data), need)
+            if q["out"].amax is None:
+                q["out"].amax = plan.new_amax()
+        if need:
+            pre.append(plan.amax_call(need))
         descs = ops.make_fwd_descs([dict(A=q.get("Ap", q["x"].buf), W=q.get("Wp", q["W"].data),
                                          bias=q["b"].data if q.get("b") else None,
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
-                                         mask=q["out"].mask) for q in self.p])
+                                         mask=q["out"].mask, amax_a=q["amax_a"], amax_w=q["amax_w"],
+                                         amax_out=q["out"].amax) for q in self.p])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
         meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
@@ -457,6 +558,15 @@ class LinearGroupOp(Op):
         lib = L.load()
         calls = []
         live = [q for q in self.p if q["out"].grad is not None]
+        # magnitudes of the incoming gradients (every writer of out.grad has been recorded by now): raised by the GEMM
+        # that wrote them, else measured here, on the main chain, before the input-gradient and weight-gradient launches
+        need = []
+        for q in live:
+            q["amax_dc"] = plan.grad_amax(q["out"], need)
+            if q.get("amax_w") is None:
+                q["amax_w"] = plan.weight_amax(q["W"], q.get("Wp", q["W"].data), need)
+        if need:
+            calls.append(plan.amax_call(need))
         # weight / bias gradients
         wg = []
         for q in live:
@@ -470,10 +580,11 @@ class LinearGroupOp(Op):
             if "Ap" in q and not acc:
                 q["dWp"] = plan.empty(W.data.shape[0], q["Ap"].shape[1])
                 wg.append(dict(dC=q["out"].grad, A=q["Ap"], dW=q["dWp"], dbias=b.grad if (b and b.needs_grad) else None,
-                               accumulate=0, w_kn=0, unpad=(q["dWp"], W.grad)))
+                               accumulate=0, w_kn=0, unpad=(q["dWp"], W.grad), amax_dc=q["amax_dc"],
+                               amax_a=q.get("amax_a")))
                 continue
             wg.append(dict(dC=q["out"].grad, A=q["x"].buf, dW=W.grad, dbias=b.grad if (b and b.needs_grad) else None,
-                           accumulate=acc, w_kn=q.get("w_kn", 0)))
+                           accumulate=acc, w_kn=q.get("w_kn", 0), amax_dc=q["amax_dc"], amax_a=q.get("amax_a")))
         if wg:
             descs = ops.make_wgrad_descs(wg)
             nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(descs, len(wg))
@@ -526,8 +637,8 @@ class LinearGroupOp(Op):
                     waves.append([])
                 for part, dst in zip(parts, targets):
                     waves[0].append(dict(dA=dst, Y=None, act=L.ACT_NONE, mask=None, accumulate=acc if dst is g0 else 0,
-                                         srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0))
-                                               for q in part]))
+                                         srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0),
+                                                q["amax_dc"], q["amax_w"]) for q in part]))
                 arr = ops._ptr_array([x.grad] + [t_ for t_ in targets[1:]])
                 plan.keep.append(arr)
                 post.append((lib.mml_ew_add_n, (arr, len(targets), x.grad.data_ptr(), plan.B * pitch),
@@ -538,12 +649,20 @@ class LinearGroupOp(Op):
                 while len(waves) <= ci:
                     waves.append([])
                 padded = x.kpad and all("Wp" in q for q in ch)  # every source reads the zero-padded weight copy
+                # this launch raises the magnitude slot of x.grad with what it stores (after derivative / accumulation)
+                if x.gamax is None and plan.amax_pool is not None:
+                    x.gamax = plan.new_amax()
+                if x.gamax is not None and x.gamax_writers == x.written - 1:
+                    x.gamax_writers += 1
+                    out_slot = x.gamax
+                else:
+                    out_slot = None
                 waves[ci].append(dict(dA=_padded_view(x.grad, x.kpad) if padded else x.grad,
                                       Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
                                       mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
-                                      accumulate=acc,
-                                      srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0))
-                                            for q in ch]))
+                                      accumulate=acc, amax_out=out_slot,
+                                      srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0),
+                                             q["amax_dc"], q["amax_w"]) for q in ch]))
             if fuse:
                 x.deriv_applied = True
         for dg in waves:
@@ -579,6 +698,11 @@ class GateGroupOp(Op):
         grp = ops.make_gate_group([e.buf for e in self.experts],
                                   [dict(G=g["G"].buf, Wg=g["Wg"].data, P=g["P"], mix=g["mix"].buf, expert=g["expert"])
                                    for g in self.gates], plan.B, self.H)
+        slot = plan.new_amax()  # ONE magnitude slot for all mixtures (an upper bound for each of them)
+        if slot is not None:
+            grp.amax_mix = slot.data_ptr()
+            for g in self.gates:
+                g["mix"].amax = slot
         plan.keep.append(grp)
         byts = 4.0 * plan.B * (len(self.experts) * self.H + sum(g["G"].n + len(g["expert"]) + self.H for g in self.gates))
         return [(L.load().mml_gate_mix_fwd, (C.byref(grp),), dict(kernel="gate_fwd_kernel", bytes=byts))]
@@ -615,6 +739,16 @@ class GateGroupOp(Op):
             _claim(e)
             e.deriv_applied = True
         grp = ops.make_gate_group([e.buf for e in self.experts], gl, plan.B, self.H, d_experts=dE, e_relu=e_relu)
+        # magnitudes of what the kernel stores: one slot for every expert gradient, one for every gate-input gradient
+        # (this op is the only writer of each of them: checked above)
+        s_de, s_dg = plan.new_amax(), plan.new_amax()
+        if s_de is not None:
+            grp.amax_dE, grp.amax_dG = s_de.data_ptr(), s_dg.data_ptr()
+            for e in self.experts:
+                e.gamax, e.gamax_writers = s_de, e.written
+            for g in self.gates:
+                if g["mix"].grad is not None:
+                    g["G"].gamax, g["G"].gamax_writers = s_dg, g["G"].written
         ws = ops.workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)), plan.device)
         plan.keep += [grp, ws]
         act = [g for g in self.gates if g["mix"].grad is not None]
@@ -656,6 +790,10 @@ class HeadOp(Op):
                     if claim:
                         _claim(Hin)
                         Hin.deriv_applied = True
+                        if Hin.written == 1 and plan.amax_pool is not None:  # the kernel raises ONE slot for all dH
+                            if getattr(self, "_amax_dH", None) is None:
+                                self._amax_dH = plan.new_amax()
+                            Hin.gamax, Hin.gamax_writers = self._amax_dH, 1
                 else:
                     tmp = h.setdefault("_dH_tmp", plan.empty(plan.B, Hin.n))
                     q["dH"], q["h_relu"] = tmp, 0
@@ -691,6 +829,8 @@ class HeadOp(Op):
         grp = ops.make_head_group(hl, prob_buf, y=plan.y if (train and not use_dprob) else None, mask=plan.mask,
                                   loss=plan.loss if (train and not use_dprob) else None,
                                   dprob=dprob_buf if use_dprob else None)
+        if train and getattr(self, "_amax_dH", None) is not None:
+            grp.amax_dH = self._amax_dH.data_ptr()
         plan.keep.append(grp)
         return grp, post
 
@@ -1372,6 +1512,7 @@ class ParamStore:
             g = self.arena[off:off + p.numel()].view(p.shape)
             off += p.numel()
             self.pvals[name] = PVal(p.data, g, name)
+            self.pvals[name].stable = True
         self.table_names = [n for n, _ in tables]
         for name, p in tables:
             self.pvals[name] = PVal(p.data, None, name, is_table=True)

@@ -198,11 +198,60 @@ def make_fwd_descs(problems):
         m = p.get("mask")
         d.relu_mask = L.ptr(m)
         d.ldmask = _ld(m) if m is not None else 0
+        d.amax_a, d.amax_w, d.amax_out = L.ptr(p.get("amax_a")), L.ptr(p.get("amax_w")), L.ptr(p.get("amax_out"))
     return arr
 
 
-def gemm_fwd(problems):
+# ---- operand magnitudes (include/mmlrec.h): slots of MML_AMAX_WORDS words --------------------------------------
+AMAX_WORDS = 8
+
+
+def amax_slots(n, device):
+    """n zeroed magnitude slots as an int32 [n, AMAX_WORDS] tensor (row i = slot i)."""
+    return torch.zeros(n, AMAX_WORDS, dtype=torch.int32, device=device)
+
+
+def make_amax_descs(pairs):
+    """pairs: (tensor [rows, cols] with unit column stride, slot) -- one mml_amax_batch call raises every slot."""
+    arr = (L.AmaxDesc * len(pairs))()
+    for d, (x, slot) in zip(arr, pairs):
+        if x.dim() == 1:
+            x = x.view(1, -1)
+        d.x, d.rows, d.cols, d.ld, d.slot = x.data_ptr(), x.shape[0], x.shape[1], _ld(x), slot.data_ptr()
+    return arr
+
+
+def amax_batch(pairs):
+    arr = make_amax_descs(pairs)
+    L.check(L.load().mml_amax_batch(arr, len(pairs), _stream()), "mml_amax_batch")
+
+
+def amax_value(slot):
+    """The slot's value as a Python float (host read: tests / diagnostics)."""
+    return float(slot.view(-1).max().view(1).view(torch.float32).item())
+
+
+def _measured(tensors, cache):
+    """slot per tensor (by storage pointer + shape), measured now with the stand-alone kernel"""
+    todo = []
+    for t in tensors:
+        key = (t.data_ptr(), tuple(t.shape), t.stride(0) if t.dim() > 1 else 0)
+        if key not in cache:
+            cache[key] = amax_slots(1, t.device)[0]
+            todo.append((t, cache[key]))
+    if todo:
+        amax_batch(todo)
+    return cache
+
+
+def gemm_fwd(problems, amax=False):
+    """amax=True: measure both operands of every problem first (stand-alone mml_amax_batch launches), which lets the
+    launch run the two-plane fp16 arithmetic -- what engine.py arranges with magnitudes produced along the way."""
     lib = L.load()
+    if amax:
+        cache = _measured([p["A"] for p in problems] + [p["W"] for p in problems], {})
+        problems = [dict(p, amax_a=cache[(p["A"].data_ptr(), tuple(p["A"].shape), p["A"].stride(0))],
+                         amax_w=cache[(p["W"].data_ptr(), tuple(p["W"].shape), p["W"].stride(0))]) for p in problems]
     arr = make_fwd_descs(problems)
     L.check(lib.mml_gemm_grouped_fwd(arr, len(problems), _stream()), "mml_gemm_grouped_fwd")
 
@@ -283,19 +332,29 @@ def make_dgrad_descs(problems):
         d.accumulate = int(p.get("accumulate", 0))
         srcs = p["srcs"]
         d.n_src = len(srcs)
-        for s, (dC, W, w_kn) in enumerate(srcs):
+        for s, src in enumerate(srcs):
+            dC, W, w_kn = src[:3]
             d.dC[s], d.W[s] = dC.data_ptr(), W.data_ptr()
             d.lddc[s], d.ldw[s] = _ld(dC), _ld(W)
             d.N[s] = dC.shape[1]
             d.w_kn[s] = int(w_kn)
+            if len(src) > 3:  # (dC, W, w_kn, magnitude slot of dC, magnitude slot of W)
+                d.amax_dc[s], d.amax_w[s] = L.ptr(src[3]), L.ptr(src[4])
         m = p.get("mask")
         d.relu_mask = L.ptr(m)
         d.ldmask = _ld(m) if m is not None else 0
+        d.amax_out = L.ptr(p.get("amax_out"))
     return arr
 
 
-def gemm_dgrad(problems):
+def gemm_dgrad(problems, amax=False):
     lib = L.load()
+    if amax:
+        ts = [t for p in problems for src in p["srcs"] for t in src[:2]]
+        cache = _measured(ts, {})
+        k = lambda t: (t.data_ptr(), tuple(t.shape), t.stride(0))  # noqa: E731
+        problems = [dict(p, srcs=[(dC, W, kn, cache[k(dC)], cache[k(W)]) for dC, W, kn in
+                                  [src[:3] for src in p["srcs"]]]) for p in problems]
     arr = make_dgrad_descs(problems)
     L.check(lib.mml_gemm_grouped_dgrad(arr, len(problems), _stream()), "mml_gemm_grouped_dgrad")
 
@@ -312,11 +371,16 @@ def make_wgrad_descs(problems):
         d.K = A.shape[1]
         d.accumulate = int(p.get("accumulate", 0))
         d.w_kn = int(p.get("w_kn", 0))
+        d.amax_dc, d.amax_a = L.ptr(p.get("amax_dc")), L.ptr(p.get("amax_a"))
     return arr
 
 
-def gemm_wgrad(problems):
+def gemm_wgrad(problems, amax=False):
     lib = L.load()
+    if amax:
+        cache = _measured([p["dC"] for p in problems] + [p["A"] for p in problems], {})
+        k = lambda t: (t.data_ptr(), tuple(t.shape), t.stride(0))  # noqa: E731
+        problems = [dict(p, amax_dc=cache[k(p["dC"])], amax_a=cache[k(p["A"])]) for p in problems]
     arr = make_wgrad_descs(problems)
     dev = problems[0]["dC"].device
     nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(problems))

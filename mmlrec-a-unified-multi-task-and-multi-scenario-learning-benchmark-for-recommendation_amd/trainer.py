@@ -176,6 +176,7 @@ class TrainStep:
         # everything the early pass waits for: the counter, and the row list -- from the index pre-pass, or from the
         # marking gather + compaction that open the forward)
         n_lead = 2 if (self.split_dense and getattr(p.ops[0], "mark_rows", None) is not None) else 0
+        n_lead += getattr(p, "n_pre", 0) if self.split_dense else 0  # (the magnitude reset / weight pass open `fwd`)
         self.pre = Segments((self.opt_split["pre"] + p.fwd[:n_lead]) if self.split_dense else [], self.use_graph)
         self.early = Segments(self.opt_split["early"], self.use_graph, min_calls=1)
         self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd[n_lead:] + p.head_train + p.bwd,

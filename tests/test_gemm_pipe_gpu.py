@@ -52,7 +52,7 @@ def dact_ref(torch, y, act, L):
     return torch.ones_like(y)
 
 
-@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("mode", [0, 3, 2])
 @pytest.mark.parametrize("M,K,Ns", [
     (128, 16, [64]),            # one k-step per tile
     (300, 32, [128, 4]),        # two k-steps, ragged M, a 4-column problem in the group
@@ -73,7 +73,9 @@ def test_pipe_fwd(env, mode, M, K, Ns):
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
         b = torch.randn(N, generator=g).to(dev) if i % 2 == 0 else None
         probs.append(dict(A=A, W=W, bias=b, C=torch.full((M, N), float("nan"), device=dev), act=acts[i % 4]))
-    ops.gemm_fwd(probs)
+    ops.gemm_fwd(probs, amax=(mode == 2))  # mode 2: two scaled fp16 planes (needs the operand magnitudes)
+    if mode == 2:
+        assert ", 2, " in lib.mml_gemm_last_kernel().decode()
     torch.cuda.synchronize()
     assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
     for p in probs:
@@ -83,7 +85,7 @@ def test_pipe_fwd(env, mode, M, K, Ns):
         assert rel(p["C"], act_ref(torch, z, p["act"], L)) < RTOL
 
 
-@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("mode", [0, 3, 2])
 @pytest.mark.parametrize("M,K,srcNs,w_kn,act,accumulate", [
     (128, 64, [16], 0, "relu", 0),            # one k-step, Y read in the epilogue
     (515, 256, [128], 0, "relu", 0),          # the layer-2 shape: 8 k-steps + Y
@@ -112,13 +114,14 @@ def test_pipe_dgrad(env, mode, M, K, srcNs, w_kn, act, accumulate):
     dA = old.clone() if accumulate else torch.full((M, K), float("nan"), device=dev)
     if accumulate:
         ref = ref + old.double()
-    ops.gemm_dgrad([dict(dA=dA, Y=Y if act != L.ACT_NONE else None, act=act, accumulate=accumulate, srcs=srcs)])
+    ops.gemm_dgrad([dict(dA=dA, Y=Y if act != L.ACT_NONE else None, act=act, accumulate=accumulate, srcs=srcs)],
+                   amax=(mode == 2))
     torch.cuda.synchronize()
     assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
     assert rel(dA, ref) < RTOL
 
 
-@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("mode", [0, 3, 2])
 @pytest.mark.parametrize("M,shapes,w_kn", [
     (4096, [(64, 16)], 0),
     (4096 + 16, [(256, 240), (64, 240)], 0),     # batch not a multiple of the chunk
@@ -139,7 +142,7 @@ def test_pipe_wgrad(env, mode, M, shapes, w_kn):
         dC = torch.randn(M, N, generator=g).to(dev)
         dW = torch.full((K, N) if w_kn else (N, K), float("nan"), device=dev)
         probs.append(dict(dC=dC, A=As[K], dW=dW, dbias=torch.full((N,), float("nan"), device=dev), w_kn=w_kn))
-    ops.gemm_wgrad(probs)
+    ops.gemm_wgrad(probs, amax=(mode == 2))
     torch.cuda.synchronize()
     assert "gemm_pipe_kernel" in lib.mml_gemm_last_kernel().decode()
     for p in probs:
@@ -166,7 +169,7 @@ def test_pipe_is_bitwise_repeatable(env):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("mode", [0, 3, 2])
 @pytest.mark.parametrize("M,K,N", [
     (300, 64, 128),      # 128 x 64 tiles (few row tiles): per-lane-row epilogue
     (70000, 128, 256),   # 128 x 128 tiles: row-major epilogue through LDS
@@ -186,7 +189,7 @@ def test_relu_sign_mask_round_trip(env, mode, M, K, N):
     Cc = torch.empty(M, N, device=dev)
     words = (N + 31) // 32
     mask = torch.full((M, words), -1, dtype=torch.int32, device=dev)
-    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=Cc, act=L.ACT_RELU, mask=mask)])
+    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=Cc, act=L.ACT_RELU, mask=mask)], amax=(mode == 2))
     torch.cuda.synchronize()
     bits = ((mask.cpu().numpy().astype(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, words * 32)
     assert np.array_equal(bits[:, :N].astype(bool), (Cc > 0).cpu().numpy())
@@ -195,9 +198,66 @@ def test_relu_sign_mask_round_trip(env, mode, M, K, N):
     dC = torch.randn(M, N2, generator=g).to(dev)
     W2 = (torch.randn(N2, N, generator=g) / N ** 0.5).to(dev)
     d_y, d_m = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
-    ops.gemm_dgrad([dict(dA=d_y, Y=Cc, act=L.ACT_RELU, srcs=[(dC, W2, 0)])])
-    ops.gemm_dgrad([dict(dA=d_m, Y=Cc, act=L.ACT_RELU, mask=mask, srcs=[(dC, W2, 0)])])
+    ops.gemm_dgrad([dict(dA=d_y, Y=Cc, act=L.ACT_RELU, srcs=[(dC, W2, 0)])], amax=(mode == 2))
+    ops.gemm_dgrad([dict(dA=d_m, Y=Cc, act=L.ACT_RELU, mask=mask, srcs=[(dC, W2, 0)])], amax=(mode == 2))
     torch.cuda.synchronize()
     assert torch.equal(d_y, d_m)
     ref = (dC.double() @ W2.double()) * (Cc > 0).double()
     assert rel(d_m, ref) < RTOL
+
+
+@pytest.mark.parametrize("scale_a,scale_w", [(1e-4, 1e-4), (3e-9, 2e3), (5e4, 1e-7), (1.0, 1e-30), (2e20, 1e-20)])
+def test_two_plane_fp16_is_scale_invariant(env, scale_a, scale_w):
+    """The two-plane fp16 arithmetic (auto mode with operand magnitudes) scales every operand by a power of two taken
+    from its magnitude slot: operands far outside fp16's range (the reference initialises weights at 1e-4, gradients
+    reach 1e-9) give the same relative accuracy as O(1) ones, and the produced magnitude (amax_out) bounds |C|."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, K, N = 1000, 240, 256
+    A = (torch.randn(M, K, generator=g) * scale_a).to(dev)
+    W = (torch.randn(N, K, generator=g) * scale_w).to(dev)
+    Cc = torch.empty(M, N, device=dev)
+    slots = ops.amax_slots(3, dev)
+    ops.amax_batch([(A, slots[0]), (W, slots[1])])
+    assert ops.amax_value(slots[0]) == float(A.abs().max()) and ops.amax_value(slots[1]) == float(W.abs().max())
+    ops.gemm_fwd([dict(A=A, W=W, bias=None, C=Cc, act=L.ACT_NONE, amax_a=slots[0], amax_w=slots[1], amax_out=slots[2])])
+    torch.cuda.synchronize()
+    assert ", 2, " in lib.mml_gemm_last_kernel().decode()
+    ref = A.double() @ W.double().t()
+    assert rel(Cc, ref) < 2e-6
+    assert ops.amax_value(slots[2]) == float(Cc.abs().max())
+    # a stale-HIGH magnitude (a bound 2^20 above the truth) only costs precision far below the tolerance
+    slots[0].fill_(int(np.float32(float(A.abs().max()) * 2.0 ** 20).view(np.int32)))
+    ops.gemm_fwd([dict(A=A, W=W, bias=None, C=Cc, act=L.ACT_NONE, amax_a=slots[0], amax_w=slots[1])])
+    assert rel(Cc, ref) < 1e-5
+    # without magnitudes the same call runs the three-plane bf16 form
+    ops.gemm_fwd([dict(A=A, W=W, bias=None, C=Cc, act=L.ACT_NONE)])
+    assert ", 3, " in lib.mml_gemm_last_kernel().decode()
+    assert rel(Cc, ref) < 2e-6
+
+
+def test_amax_of_fallback_kernel_and_nonfinite(env):
+    """K % 16 != 0 runs the register-staged fp32 kernel: it must still publish amax_out.  Inf in an operand: scale 1,
+    the Inf propagates."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn(200, 24, generator=g).to(dev)
+    W = torch.randn(96, 24, generator=g).to(dev)
+    Cc = torch.empty(200, 96, device=dev)
+    slots = ops.amax_slots(3, dev)
+    ops.amax_batch([(A, slots[0]), (W, slots[1])])
+    ops.gemm_fwd([dict(A=A, W=W, bias=None, C=Cc, act=L.ACT_RELU, amax_a=slots[0], amax_w=slots[1], amax_out=slots[2])])
+    assert "gemm_kernel" in lib.mml_gemm_last_kernel().decode()
+    assert ops.amax_value(slots[2]) == float(Cc.abs().max())
+    A2 = torch.randn(256, 64, generator=g).to(dev)
+    A2[3, 5] = float("inf")
+    W2 = torch.randn(64, 64, generator=g).to(dev)
+    C2 = torch.empty(256, 64, device=dev)
+    s2 = ops.amax_slots(2, dev)
+    ops.amax_batch([(A2, s2[0]), (W2, s2[1])])
+    ops.gemm_fwd([dict(A=A2, W=W2, bias=None, C=C2, act=L.ACT_NONE, amax_a=s2[0], amax_w=s2[1])])
+    assert not torch.isfinite(C2[3]).all() and torch.isfinite(C2[4]).all()

@@ -68,6 +68,13 @@ def case(request):
     return request.param, g
 
 
+@pytest.fixture(params=["fp16x2", "bf16x3"])
+def arith(request, monkeypatch):
+    """GEMM arithmetic of the recorded plans: two scaled fp16 planes (operand magnitudes on) or three bf16 planes."""
+    monkeypatch.setenv("MMLREC_AMAX", "1" if request.param == "fp16x2" else "0")
+    return request.param
+
+
 def test_state_dict_keys_match_reference(case):
     name, g = case
     model, _ = build(g)
@@ -111,7 +118,7 @@ def test_forward_layers_mask(case):
         assert rel(ym.cpu().numpy(), g["y_pred_masked"]) < RTOL
 
 
-def test_autograd_gradients(case):
+def test_autograd_gradients(case, arith):
     """loss.backward() through the drop-in forward() gives the reference's gradients (dense [V,E] for tables)."""
     name, g = case
     model, cfg = build(g)
@@ -147,8 +154,65 @@ def test_autograd_gradients(case):
             assert p.grad is None, n
 
 
+def gpu_state(model):
+    """(parameters, optimizer moments, steps done) of a model between two fused steps, as numpy -- what the oracle
+    needs to take the NEXT step from exactly where the MI355X stands (state_dict() flushes a lazy_exact optimizer first,
+    so every row and its moments are current)."""
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    opt = model.optimizer()
+    mom = {}
+    for k in sd:
+        if k in opt.store.pvals and k in opt.state:
+            s1, s2 = opt.state[k]
+            mom[k] = (None if s1 is None else s1.cpu().numpy().copy(), None if s2 is None else s2.cpu().numpy().copy())
+    return sd, mom, opt.steps_done
+
+
+def oracle_step_from(g, state, kind, lr, X, y, frozen=None):
+    """One reference step (oracle) from a captured MI355X state; returns the oracle's parameters after it."""
+    from oracle import mmlrec_oracle as orc
+    sd, mom, t = state
+    spec = orc.Spec.from_golden(g)
+    params = {k: v.copy() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    opt = orc.DenseOptimizer(kind, lr)
+    opt.t = t
+    key = {"adam": ("m", "v"), "adagrad": ("sum", None), "rmsprop": ("sq", None), "sgd": (None, None)}[kind]
+    for k, (s1, s2) in mom.items():
+        st = {}
+        if key[0] and s1 is not None:
+            st[key[0]] = s1.copy()
+        if key[1] and s2 is not None:
+            st[key[1]] = s2.copy()
+        if st:
+            opt.state[k] = st
+    orc.train_step(spec, params, opt, X, y, frozen)
+    return params
+
+
+def step_is_consistent(g, before, after_sd, kind, lr, X, y):
+    """Chaos-free form of the trajectory check: the step the MI355X just took, against the oracle's step FROM THE SAME
+    STATE (free-running trajectories amplify fp32-level differences: one weight moved by 1e-5 can flip a ReLU of one of
+    the 64 samples and change that expert's gradient by 1/64 in the next step -- measured on mmoe_ae30 with the
+    two-plane fp16 GEMMs: every gradient agreed to 1e-6 at every oracle state, the free-running step 3 did not).
+    Element-wise update criterion of conftest.table_update_report on every tensor."""
+    from conftest import table_update_report
+    ref = oracle_step_from(g, before, kind, lr, X, y)
+    worst = 0.0
+    for k, r in ref.items():
+        b, a = before[0][k], after_sd[k]
+        if np.abs(r - b).max() == 0 and np.abs(a - b).max() == 0:
+            continue
+        b2 = b.reshape(b.shape[0], -1) if b.ndim > 1 else b.reshape(1, -1)
+        rows = np.nonzero(np.abs(r.reshape(b2.shape) - b2).max(1) + np.abs(a.reshape(b2.shape) - b2).max(1))[0]
+        share, rel = table_update_report(b2, a.reshape(b2.shape), r.reshape(b2.shape), rows)
+        if share >= 2e-3:
+            return False, (k, share, rel)
+        worst = max(worst, share)
+    return True, worst
+
+
 @pytest.mark.parametrize("graph", [False, True])
-def test_fused_train_steps(case, graph):
+def test_fused_train_steps(case, graph, arith):
     """Fused step (fwd + BCE + bwd + optimizer) reproduces the reference's parameters after 1 and 3 steps."""
     name, g = case
     combos = (("adam", (1, 3), "dense_exact"), ("adagrad", (3,), "sparse_rows"), ("adam", (1, 3), "lazy_exact"))
@@ -167,19 +231,28 @@ def test_fused_train_steps(case, graph):
         model.train()
         lr = cfg["optim_config"]["lr"]
         losses = []
+        # models the oracle can step (no BatchNorm / unregistered tensors): every step after the first is ALSO taken by
+        # the oracle from the MI355X's own state, the arbiter when the free-running comparison below trips
+        can_force = name in ("sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "pepnet_amazon")
+        forced_ok = {}
         for i in range(3):
             X = torch.from_numpy(g[f"X{i}"]).cuda()
             y = torch.from_numpy(g[f"y{i}"]).cuda()
             # (graph=True also forces the split schedule of the dense table update, which the trainer picks by itself
             # only for tables of >= 2^25 parameters: both schedules meet every fixture)
             step = model.train_step_runner(X.shape[0], use_graph=graph, split_dense="force" if graph else True)
+            before = gpu_state(model) if (can_force and i > 0) else None
             step.plan.X.copy_(X)
             step.plan.y.copy_(y)
             step.run()
             losses.append(float(step.plan.loss.item()))
+            if before is not None:
+                after = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+                forced_ok[i] = step_is_consistent(g, before, after, kind, lr, g[f"X{i}"], g[f"y{i}"])
             if (i + 1) in checkpoints:
                 sd = model.state_dict()
                 noise_bias, noise_rm = bn_noise_keys(sd.keys())
+                free_running = None
                 for k in sd:
                     ref = g[f"{kind}{i + 1}/{k}"].astype(np.float64)
                     got = sd[k].cpu().numpy().astype(np.float64)
@@ -189,9 +262,15 @@ def test_fused_train_steps(case, graph):
                         continue
                     # Adam/Adagrad divide by sqrt(sum g^2): gradients at fp32-noise level may flip a whole lr-sized
                     # update, hence outlier share + absolute bound instead of a pure max-relative test
-                    assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, (kind, i + 1, k)
+                    if (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() >= 2e-3 and free_running is None:
+                        free_running = (kind, i + 1, k)
                     assert dv.max() <= 2.5 * lr * (i + 1), (kind, i + 1, k)
+                if free_running is not None:
+                    # the free-running trajectory left the reference's: legitimate only as amplified rounding noise,
+                    # i.e. when EVERY step since the first checkpoint is the oracle's step from the MI355X's own state
+                    assert i > 0 and forced_ok and all(ok for ok, _ in forced_ok.values()), (free_running, forced_ok)
         assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL), (kind, losses)
+        assert all(ok for ok, _ in forced_ok.values()), forced_ok  # (checked whether or not the free run tripped)
 
 
 @pytest.mark.parametrize("kind", ["adam", "rmsprop", "adagrad", "sgd"])

@@ -26,6 +26,9 @@ def timeit(fn, rounds=7, inner=5):
     return ts[len(ts) // 2]
 
 
+AMAX = os.environ.get("GEMM_AMAX", "1") != "0"  # measure the operand magnitudes first -> two-plane fp16 arithmetic in auto mode
+
+
 def accuracy(dev):
     """max-norm relative error of fwd / dgrad / wgrad against float64 torch on one L1-like problem."""
     torch.manual_seed(0)
@@ -34,16 +37,16 @@ def accuracy(dev):
     W = torch.randn(N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev)
     C = torch.empty(M, N, device=dev)
-    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=C, act=L.ACT_NONE)])
+    ops.gemm_fwd([dict(A=A, W=W, bias=b, C=C, act=L.ACT_NONE)], amax=AMAX)
     ref = A.double() @ W.double().t() + b.double()
     e_f = float((C.double() - ref).abs().max() / ref.abs().max())
     dC = torch.randn(M, N, device=dev)
     dA = torch.empty(M, K, device=dev)
-    ops.gemm_dgrad([dict(dA=dA, Y=None, act=L.ACT_NONE, srcs=[(dC, W, 0)])])
+    ops.gemm_dgrad([dict(dA=dA, Y=None, act=L.ACT_NONE, srcs=[(dC, W, 0)])], amax=AMAX)
     ref = dC.double() @ W.double()
     e_d = float((dA.double() - ref).abs().max() / ref.abs().max())
     dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
-    ops.gemm_wgrad([dict(dC=dC, A=A, dW=dW, dbias=db)])
+    ops.gemm_wgrad([dict(dC=dC, A=A, dW=dW, dbias=db)], amax=AMAX)
     ref = dC.double().t() @ A.double()
     e_w = float((dW.double() - ref).abs().max() / ref.abs().max())
     print(f"accuracy vs float64 (max |err| / max |ref|): fwd {e_f:.2e}  dgrad {e_d:.2e}  wgrad {e_w:.2e}")
@@ -75,19 +78,33 @@ def main():
             probs_f.append(dict(A=A[K], W=W, bias=torch.zeros(N, device=dev), C=Cc, act=L.ACT_RELU))
             probs_w.append(dict(dC=Cc, A=A[K], dW=torch.empty(N, K, device=dev), dbias=torch.empty(N, device=dev)))
             flops += 2.0 * M * N * K
+        key = lambda t_: (t_.data_ptr(), tuple(t_.shape), t_.stride(0))  # noqa: E731
+        cache = {}
+        if AMAX:  # magnitudes measured ONCE, outside the timed launches (the step gets them from the producers)
+            ops.gemm_fwd(probs_f)  # (C as the timed launches will leave it: the dgrad / wgrad read it as dC)
+            ops._measured([p["A"] for p in probs_f] + [p["W"] for p in probs_f] + [p["C"] for p in probs_f], cache)
+            for p, q in zip(probs_f, probs_w):
+                p.update(amax_a=cache[key(p["A"])], amax_w=cache[key(p["W"])])
+                q.update(amax_dc=cache[key(q["dC"])], amax_a=cache[key(q["A"])])
+        amx = lambda p: ((cache[key(p["C"])], cache[key(p["W"])]) if AMAX else ())  # noqa: E731
+        AOUT = os.environ.get("GEMM_AMAX_OUT", "0") == "1"  # the launches also produce the magnitude of their output
+        if AOUT:
+            for p in probs_f:
+                p["amax_out"] = ops.amax_slots(1, dev)[0]
         t = timeit(lambda: ops.gemm_fwd(probs_f))
         print(f"{name:22s} fwd   {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
         t = timeit(lambda: ops.gemm_wgrad(probs_w))
         print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
         K0 = shapes[0][1]
         if name.startswith("L2"):  # one dgrad problem per expert (single source each), as the step runs them
-            pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0)])
-                  for p in probs_f]
+            pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx(p)],
+                       amax_out=ops.amax_slots(1, dev)[0] if AOUT else None) for p in probs_f]
             t = timeit(lambda: ops.gemm_dgrad(pd))
             print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s  (one problem per expert)")
         elif all(k == K0 for _, k in shapes):
             dA = torch.empty(M, K0, device=dev)
-            pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) for p in probs_f[:8]])]
+            pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx(p) for p in probs_f[:8]],
+                       amax_out=ops.amax_slots(1, dev)[0] if AOUT else None)]
             fl = sum(2.0 * M * n * k for n, k in shapes[:8])
             t = timeit(lambda: ops.gemm_dgrad(pd))
             print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s")
