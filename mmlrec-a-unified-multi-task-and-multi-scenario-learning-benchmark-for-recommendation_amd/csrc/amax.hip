@@ -17,34 +17,34 @@ __global__ __launch_bounds__(256) void amax_kernel(const AmaxLaunch L) {
   while (ti + 1 < L.n && (int)blockIdx.x >= L.blk0[ti + 1]) ++ti;
   const mml_amax_desc& T = L.t[ti];
   const int bx = (int)blockIdx.x - L.blk0[ti], nb = L.blk0[ti + 1] - L.blk0[ti];
-  uint32_t am = 0;
+  float amf = 0.f;
   const bool vec = (T.cols % 4 == 0) && (T.ld % 4 == 0) && aligned16(T.x);
   if (vec) {
+    // four independent 16-byte loads in flight per thread (a plain grid-stride loop issues them one at a time: 2 TB/s)
     const int c4 = T.cols / 4;
     const int64_t total = T.rows * c4;
-    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
-      const int64_t r = i / c4;
-      const int c = (int)(i - r * c4);
-      const float4 v = *reinterpret_cast<const float4*>(T.x + r * T.ld + 4 * c);
-      am = max(max(am, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
-      am = max(max(am, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+    const int64_t step = (int64_t)nb * 256;
+    const bool flat = T.ld == T.cols;  // contiguous rows: no index arithmetic (a 64-bit division per load otherwise)
+    auto at = [&](int64_t i) __attribute__((always_inline)) {
+      if (flat) return reinterpret_cast<const float4*>(T.x)[i];
+      const int64_t r = (total < 0x7fffffff) ? (int64_t)((uint32_t)i / (uint32_t)c4) : i / c4;
+      return *reinterpret_cast<const float4*>(T.x + r * T.ld + 4 * (i - r * c4));
+    };
+    int64_t i = (int64_t)bx * 256 + threadIdx.x;
+    for (; i + 3 * step < total; i += 4 * step) {
+      const float4 v0 = at(i), v1 = at(i + step), v2 = at(i + 2 * step), v3 = at(i + 3 * step);
+      amax_acc(amf, v0); amax_acc(amf, v1); amax_acc(amf, v2); amax_acc(amf, v3);
     }
+    for (; i < total; i += step) amax_acc(amf, at(i));
   } else {
     const int64_t total = T.rows * T.cols;
     for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
       const int64_t r = i / T.cols;
-      am = max(am, __float_as_uint(T.x[r * T.ld + (i - r * T.cols)]) & 0x7fffffffu);
+      amax_acc(amf, T.x[r * T.ld + (i - r * T.cols)]);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) am = max(am, (uint32_t)__shfl_xor((int)am, o));
-  __shared__ uint32_t wmax[4];
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    am = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    if (am) atomicMax(T.slot + (bx & (MML_AMAX_WORDS - 1)), am);
-  }
+  // (Inf / NaN: the integer pattern of an Inf is what the consumers test for; a NaN does not register -- see amax_acc)
+  amax_flush(amf, T.slot);
 }
 
 __global__ __launch_bounds__(256) void amax_reset_kernel(uint32_t* slots, int64_t words) {
@@ -67,8 +67,8 @@ extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t st
                   "mml_amax_batch: tensor %d malformed", i);
       ++i;
       if (q.rows * q.cols == 0) continue;
-      int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);  // >= 16 elements per thread, 4 workgroups per CU at most
-      if (nb > 1024) nb = 1024;
+      int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);  // >= 16 elements per thread, 8 workgroups per CU at most
+      if (nb > 2048) nb = 2048;
       L.blk0[L.n] = total;
       L.t[L.n++] = q;
       total += (int)nb;

@@ -24,27 +24,31 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 #ifdef __HIPCC__
 // ---- operand magnitudes (include/mmlrec.h): per-lane running maximum of |x| bit patterns, published at kernel end ----
-__device__ __forceinline__ void amax_acc(uint32_t& am, float v) {
-  const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
-  am = b > am ? b : am;
+__device__ __forceinline__ void amax_acc(float& am, float v) { am = fmaxf(am, fabsf(v)); }  // one v_max_f32 (|x| modifier)
+__device__ __forceinline__ void amax_acc(float& am, const float4& v) {
+  am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
-__device__ __forceinline__ void amax_acc(uint32_t& am, const float4& v) {
-  amax_acc(am, v.x); amax_acc(am, v.y); amax_acc(am, v.z); amax_acc(am, v.w);
-}
-// Call with the whole wave converged.  Wave maximum, then at most ONE atomic per wave -- and none when the slot word
-// already holds a value at least as large (slots only ever grow during a launch, so a stale read can only cost an
-// unnecessary atomic; thousands of waves hammering one address serialise at the memory side otherwise).
-__device__ __forceinline__ void amax_flush(uint32_t am, uint32_t* slot) {
-  if (!slot) return;
+// End of a kernel, every thread of the workgroup converged (<= 16 waves): wave maxima -> LDS -> ONE atomic per workgroup
+// on the slot word the workgroup number picks.  Kernels that use it run a few thousand workgroups at most; same-address
+// atomics serialise at the memory side (~11 ns each), and a device-coherent "is it larger already?" read per wave is no
+// cheaper than the atomic it would save (measured on the gather: 15 000 workgroups -> +0.1 ms either way, so the
+// gather's output is measured by the stand-alone pass instead).
+// (A NaN never registers in the running maximum; it reaches the consumer as a NaN whatever the scale.)
+__device__ __forceinline__ void amax_flush(float amf, uint32_t* slot) {
+  if (!slot) return;  // (uniform)
+  __shared__ float amax_wg[16];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = (uint32_t)__shfl_xor((int)am, o, 64);
-    am = t > am ? t : am;
+  for (int o = 32; o > 0; o >>= 1) amf = fmaxf(amf, __shfl_xor(amf, o, 64));
+  if ((threadIdx.x & 63) == 0) amax_wg[threadIdx.x >> 6] = amf;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    float m = amax_wg[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, amax_wg[w]);
+    const uint32_t am = __float_as_uint(m);
+    if (am) atomicMax(slot + (blockIdx.x & (MML_AMAX_WORDS - 1)), am);
   }
-  if ((threadIdx.x & 63) == 0 && am) {
-    uint32_t* p = slot + (blockIdx.x & (MML_AMAX_WORDS - 1));
-    if (__atomic_load_n(p, __ATOMIC_RELAXED) < am) atomicMax(p, am);
-  }
+  __syncthreads();  // (the array may be reused by the next flush of the same kernel)
 }
 #endif
 

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_fwd_kernel(const mml_gate_
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * ROW_WAVES;
-  uint32_t am_mix = 0;
+  float am_mix = 0.f;
   for (int64_t b = wave0; b < g.B; b += nwaves) {
     for (int gi = 0; gi < g.n_gates; ++gi) {
       const mml_gate_desc& d = g.gate[gi];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void gate_mix_bwd_kernel(const mml_gate_
 
   const int64_t wave0 = (int64_t)blockIdx.x * ROW_WAVES + wave;
   const int64_t nwaves = (int64_t)gridDim.x * ROW_WAVES;
-  uint32_t am_dg = 0, am_de = 0;
+  float am_dg = 0.f, am_de = 0.f;
   for (int64_t b = wave0; b < g.B; b += nwaves) {
     for (int i = lane; i < MML_MAX_GATES * MML_MAX_EXPERTS; i += 64) coef[i] = 0.f;
     // phase A: per gate softmax backward, dG, dWg
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void head_kernel(const mml_head_group g,
   float dwacc[MML_MAX_HEADS][HEAD_SLOTS];
   float dbacc[MML_MAX_HEADS];
   float lossacc = 0.f;
-  uint32_t am_dh = 0;
+  float am_dh = 0.f;
 #pragma unroll
   for (int t = 0; t < MML_MAX_HEADS; ++t) {
     dbacc[t] = 0.f;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
-  uint32_t am_mix = 0;
+  float am_mix = 0.f;
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
-  uint32_t am_mix = 0;
+  float am_mix = 0.f;
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   const bool hcol = 4 * sub < g.H;
 
   float* myred = red + (wave * SPW + grp) * aux.wg_total;
-  uint32_t am_dg = 0, am_de = 0;  // operand magnitudes of everything this lane stores (mml_gate_group.amax_dG / amax_dE)
+  float am_dg = 0.f, am_de = 0.f;  // operand magnitudes of everything this lane stores (mml_gate_group.amax_dG / amax_dE)
   // MODE 2: the (gate, expert) -> slot map in SGPRs (read through LDS + readfirstlane on every use it was 48 LDS reads
   // per pair of samples)
   int smap_s[NG * NE];
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
   float4 dwacc[NT];
   float dbacc[NT];
   float lossacc = 0.f;
-  uint32_t am_dh = 0;
+  float am_dh = 0.f;
   float4 wv[NT];
   float bias[NT];
 #pragma unroll
