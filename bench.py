@@ -140,11 +140,18 @@ def barrier(dist):
 def timed_steps(runner, batches, steps, warmup, dist, flush=None, warm_losses=None):
     nb = len(batches)
 
+    # row-sharded tables: batch i + 1 is handed over while step i is in flight (trainer.TrainStep.prefetch), so its
+    # routing -- incl. the count exchange and the host read of the split sizes -- is off the step's critical path
+    ahead = getattr(getattr(runner, "par", None), "mode", None) == "row_sharded"
+
     def one(i):
-        X, y = batches[i % nb]
-        runner.plan.X.copy_(X)
-        runner.plan.y.copy_(y)
+        if not runner._has_next:
+            X, y = batches[i % nb]
+            runner.plan.X.copy_(X)
+            runner.plan.y.copy_(y)
         runner.run()
+        if ahead:
+            runner.prefetch(*batches[(i + 1) % nb])
 
     for i in range(warmup):
         one(i)
@@ -169,6 +176,7 @@ def timed_steps(runner, batches, steps, warmup, dist, flush=None, warm_losses=No
     barrier(dist)
     dt = time.perf_counter() - t0
     gc.enable()
+    runner.drop_prefetch()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

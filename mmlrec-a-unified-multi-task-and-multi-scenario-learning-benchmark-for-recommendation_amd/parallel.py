@@ -137,6 +137,27 @@ class RowSharding:
                                        self.emb, self.world, self.first(f, rank), 1, s), "mml_shard_rows")
 
 
+class _RouteSet:
+    """Index-only state of one batch on the row-sharded path (see RowShardedGatherOp.fwd_calls)."""
+
+    def __init__(self, op, plan, k):
+        sh, dev = op.sh, plan.device
+        F, W, B = len(sh.vocab), sh.world, plan.B
+        self.counters = torch.zeros(2 * W, dtype=torch.int32, device=dev)
+        self.cnt_pair = torch.zeros(2, W, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(2, W, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.host = self.host.pin_memory()
+        self.ready = torch.cuda.Event() if dev.type == "cuda" else None
+        self.send_keys = torch.empty(B * F, dtype=torch.int32, device=dev)
+        self.pos = torch.empty(B, F, dtype=torch.int32, device=dev)
+        if op.dedup:
+            self.req = E.TableRows(sh.vocab, dev, B * F)      # requester-side row set of the batch (full vocabulary)
+            self.req_seen = ops._ptr_array(self.req.seen)
+            self.req_rb = (L.i64 * (F + 1))(*self.req.rowbase)
+            self.slot_of = torch.empty(self.req.rowbase[-1], dtype=torch.int32, device=dev)
+
+
 class RowShardedGatherOp(E.Op):
     """K1/K2 over row-sharded tables.  The exchange sizes are only known at run time, so forward and backward are one
     Python-issued entry each (engine.PY): kernels + collectives launched eagerly; everything between them has static
@@ -167,10 +188,15 @@ class RowShardedGatherOp(E.Op):
         self.col = (L.i32 * F)(*self.cols)
         self.vocab = (L.i64 * F)(*sh.vocab)
         self.keybase = (L.i64 * F)(*sh.keybase[:F])
-        self.counters = torch.zeros(2 * W, dtype=torch.int32, device=dev)
-        self.cnt_pair = torch.zeros(2, W, dtype=torch.int32, device=dev)
-        self.send_keys = torch.empty(B * F, dtype=torch.int32, device=dev)
-        self.pos = torch.empty(B, F, dtype=torch.int32, device=dev)
+        # Everything that depends only on the batch's INDICES -- the distinct rows, their owners, the send order, the
+        # per-owner counts (exchanged and read by the host: the split sizes of the all-to-alls) and the position of
+        # every lookup in the returned row block -- lives in a route set.  There are two: while step k runs, the trainer
+        # routes batch k + 1 on a side stream (prefetch_route), so the step itself starts at all_to_all(keys) and never
+        # waits for a device -> host read.
+        self.routes = [_RouteSet(self, plan, k) for k in range(2)]
+        self.cur = self.routes[0]     # the set the forward / backward exchange of the current step uses
+        self.staged = None            # a set routed ahead of time for the NEXT step, or None
+        self.route_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.rows_recv = torch.empty(B * F, sh.emb, dtype=torch.float32, device=dev)
         self.recv_keys = self.rows_send = self.grad_recv = None
         self.n_recv = 0
@@ -181,11 +207,6 @@ class RowShardedGatherOp(E.Op):
         self.x_tab = ops._ptr_array([self.rows_recv] * F)
         self.x_vocab = (L.i64 * F)(*([B * F] * F))
         self.status = plan.status
-        if self.dedup:
-            self.req = E.TableRows(sh.vocab, dev, B * F)   # requester-side row set of the LOCAL batch (full vocabulary)
-            self.req_seen = ops._ptr_array(self.req.seen)
-            self.req_rb = (L.i64 * (F + 1))(*self.req.rowbase)
-            self.slot_of = torch.empty(self.req.rowbase[-1], dtype=torch.int32, device=dev)
         plan.keep.append(self)
         return [(E.PY, self._forward, (), dict(kernel="row_sharded_forward_exchange"))]
 
@@ -212,35 +233,73 @@ class RowShardedGatherOp(E.Op):
     def _grow(self, n):
         if self.recv_keys is None or self.recv_keys.numel() < n:
             cap = max(int(n * 1.25) + 1024, 1)
-            dev, Em = self.send_keys.device, self.sh.emb
+            dev, Em = self.rows_recv.device, self.sh.emb
             self.recv_keys = torch.empty(cap, dtype=torch.int32, device=dev)
             self.rows_send = torch.empty(cap, Em, dtype=torch.float32, device=dev)
             self.grad_recv = torch.empty(cap, Em, dtype=torch.float32, device=dev)
+
+    def _route(self, rs, X):
+        """Index-only half of the exchange for the batch in X ([B, ldX] fp32-encoded indices) into route set rs, on the
+        CURRENT stream: distinct rows -> owners -> send order + counts -> all_to_all(counts) -> pinned host copy (an
+        event marks it), position of every lookup in the row block that will come back."""
+        lib, sh, comm = L.load(), self.sh, self.comm
+        s = ops._stream()
+        B, F, W, Em = self.B, self.F, sh.world, sh.emb
+        Xp, ldX = X.data_ptr(), ops._ld(X)
+        st = self.status.data_ptr()
+        cp = rs.counters.data_ptr()
+        if self.dedup:
+            rq = rs.req
+            tl, tc, cap = rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel()
+            L.check(lib.mml_index_unique(self.vocab, self.col, F, min(Em, 16), Xp, ldX, B, rs.req_seen, rs.req_rb, tl,
+                                         tc, cap, rq.marks.data_ptr(), st, s), "mml_index_unique(requester)")
+            L.check(lib.mml_route_list_count(tl, tc, cap, self.vocab, rs.req_rb, F, W, cp, s), "mml_route_list_count")
+            rs.cnt_pair[0].copy_(rs.counters[:W])
+            L.check(lib.mml_route_list_place(tl, tc, cap, self.vocab, rs.req_rb, self.keybase, F, W, cp,
+                                             rs.send_keys.data_ptr(), rs.slot_of.data_ptr(), s),
+                    "mml_route_list_place")
+            # position of every lookup's row in the returned block, then the requester's bitmaps are reset
+            L.check(lib.mml_lookup_slots(Xp, ldX, self.col, self.vocab, rs.req_rb, F, B, rs.slot_of.data_ptr(),
+                                         rs.pos.data_ptr(), st, s), "mml_lookup_slots")
+            L.check(lib.mml_rows_clear(rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel(), rs.req_rb,
+                                       rs.req_seen, F, s), "mml_rows_clear")
+            L.check(lib.mml_counter_update(rq.count.data_ptr(), 0, 1, s), "mml_counter_update")
+        else:
+            L.check(lib.mml_route_count(Xp, ldX, None, 0, self.col, self.vocab, F, B, W, cp, st, s), "mml_route_count")
+            rs.cnt_pair[0].copy_(rs.counters[:W])  # (mml_route_place moves the cursors, not the counts)
+            L.check(lib.mml_route_place(Xp, ldX, None, 0, self.col, self.vocab, self.keybase, F, B, W, cp,
+                                        rs.send_keys.data_ptr(), rs.pos.data_ptr(), st, s), "mml_route_place")
+        comm.all_to_all_single(rs.cnt_pair[1], rs.cnt_pair[0])
+        rs.host.copy_(rs.cnt_pair, non_blocking=True)
+        rs.ready.record(torch.cuda.current_stream())
+        rs.splits = None
+
+    def prefetch_route(self, X_next):
+        """Route the NEXT step's batch now, on the side stream, beside whatever the current step still has queued
+        (collective: every rank calls it at the same point of its program).  The next forward exchange then finds
+        its counts on the host already.  X_next: a buffer the caller keeps unchanged until that step has started
+        (trainer.TrainStep.prefetch owns one), holding the batch that step will find in plan.X."""
+        if self.route_stream is None:
+            return
+        rs = self.routes[1] if self.cur is self.routes[0] else self.routes[0]
+        with torch.cuda.stream(self.route_stream):  # (TrainStep.prefetch already runs on it: X_next is written there)
+            self._route(rs, X_next)
+        self.staged = rs
 
     def _forward(self):
         lib, sh, comm = L.load(), self.sh, self.comm
         s = ops._stream()
         B, F, W, Em = self.B, self.F, sh.world, sh.emb
-        Xp, ldX = self.X.data_ptr(), ops._ld(self.X)
         st = self.status.data_ptr()
-        cp = self.counters.data_ptr()
-        if self.dedup:
-            rq = self.req
-            tl, tc, cap = rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel()
-            L.check(lib.mml_index_unique(self.vocab, self.col, F, min(Em, 16), Xp, ldX, B, self.req_seen, self.req_rb, tl,
-                                         tc, cap, rq.marks.data_ptr(), st, s), "mml_index_unique(requester)")
-            L.check(lib.mml_route_list_count(tl, tc, cap, self.vocab, self.req_rb, F, W, cp, s), "mml_route_list_count")
-            self.cnt_pair[0].copy_(self.counters[:W])
-            L.check(lib.mml_route_list_place(tl, tc, cap, self.vocab, self.req_rb, self.keybase, F, W, cp,
-                                             self.send_keys.data_ptr(), self.slot_of.data_ptr(), s),
-                    "mml_route_list_place")
-        else:
-            L.check(lib.mml_route_count(Xp, ldX, None, 0, self.col, self.vocab, F, B, W, cp, st, s), "mml_route_count")
-            self.cnt_pair[0].copy_(self.counters[:W])  # (mml_route_place moves the cursors, not the counts)
-            L.check(lib.mml_route_place(Xp, ldX, None, 0, self.col, self.vocab, self.keybase, F, B, W, cp,
-                                        self.send_keys.data_ptr(), self.pos.data_ptr(), st, s), "mml_route_place")
-        comm.all_to_all_single(self.cnt_pair[1], self.cnt_pair[0])
-        pair = self.cnt_pair.cpu()  # the one host read of the step: split sizes of the three exchanges
+        if self.staged is not None:   # routed while the previous step ran: the counts are (about to be) on the host
+            rs, self.staged = self.staged, None
+            torch.cuda.current_stream().wait_event(rs.ready)  # (the kernels below read rs.send_keys / rs.pos)
+        else:                         # first step / no prefetch: route here; the host read below waits for the device
+            rs = self.cur
+            self._route(rs, self.X)
+        self.cur = rs
+        rs.ready.synchronize()
+        pair = rs.host
         self.send_splits, self.recv_splits = pair[0].tolist(), pair[1].tolist()
         n = self.n_recv = int(sum(self.recv_splits))
         u = self.n_send = int(sum(self.send_splits))  # == B * F without de-duplication
@@ -249,7 +308,7 @@ class RowShardedGatherOp(E.Op):
         self.stats["lookups"] += B * F
         self.stats["steps"] += 1
         self._grow(n)
-        comm.all_to_all_single(self.recv_keys[:n], self.send_keys[:u], self.recv_splits, self.send_splits)
+        comm.all_to_all_single(self.recv_keys[:n], rs.send_keys[:u], self.recv_splits, self.send_splits)
         if self.lazy_launch is not None:  # bring exactly the rows about to be read up to date (lazy-exact Adam)
             self.lazy_launch(self.recv_keys.data_ptr(), n, s)
         if n:
@@ -257,15 +316,9 @@ class RowShardedGatherOp(E.Op):
                                              n, self.rows_send.data_ptr(), Em, st, s), "mml_gather_fwd_idx32(owner)")
         comm.all_to_all_single(self.rows_recv.view(-1)[:u * Em], self.rows_send.view(-1)[:n * Em],
                                [c * Em for c in self.send_splits], [c * Em for c in self.recv_splits])
-        if self.dedup:  # position of every lookup's row in the returned block, then the requester's bitmaps are reset
-            rq = self.req
-            L.check(lib.mml_lookup_slots(Xp, ldX, self.col, self.vocab, self.req_rb, F, B, self.slot_of.data_ptr(),
-                                         self.pos.data_ptr(), st, s), "mml_lookup_slots")
-            L.check(lib.mml_rows_clear(rq.touched.data_ptr(), rq.count.data_ptr(), rq.touched.numel(), self.req_rb,
-                                       self.req_seen, F, s), "mml_rows_clear")
-            L.check(lib.mml_counter_update(rq.count.data_ptr(), 0, 1, s), "mml_counter_update")
+        ldX = ops._ld(self.X)
         dense = self.X[:, self.dense_col0:].data_ptr() if self.nd else None
-        L.check(lib.mml_gather_fwd_idx32(self.x_tab, self.x_vocab, F, Em, self.pos.data_ptr(), F, dense, ldX, self.nd, B,
+        L.check(lib.mml_gather_fwd_idx32(self.x_tab, self.x_vocab, F, Em, rs.pos.data_ptr(), F, dense, ldX, self.nd, B,
                                          self.out.buf.data_ptr(), ops._ld(self.out.buf), st, s),
                 "mml_gather_fwd_idx32(expand)")
 
@@ -276,11 +329,11 @@ class RowShardedGatherOp(E.Op):
         g = self.out.grad
         if self.dedup:  # gradients of duplicate lookups are summed HERE, one row per distinct key travels
             self.grad_send[:u].zero_()
-            L.check(lib.mml_scatter_bwd_idx32(self.d_tab, self.x_vocab, F, Em, self.pos.data_ptr(), F, B, g.data_ptr(),
+            L.check(lib.mml_scatter_bwd_idx32(self.d_tab, self.x_vocab, F, Em, self.cur.pos.data_ptr(), F, B, g.data_ptr(),
                                               ops._ld(g), None, None, None, None, 0, None, self.status.data_ptr(), s),
                     "mml_scatter_bwd_idx32(requester)")
         else:
-            L.check(lib.mml_rows_permute(g.data_ptr(), ops._ld(g), self.pos.data_ptr(), F, Em, B,
+            L.check(lib.mml_rows_permute(g.data_ptr(), ops._ld(g), self.cur.pos.data_ptr(), F, Em, B,
                                          self.grad_send.data_ptr(), s), "mml_rows_permute")
         comm.all_to_all_single(self.grad_recv.view(-1)[:n * Em], self.grad_send.view(-1)[:u * Em],
                                [c * Em for c in self.recv_splits], [c * Em for c in self.send_splits])

@@ -190,6 +190,42 @@ class TrainStep:
             self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
                                   self.opt_split["tables"] + p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
         self.calls = 0
+        self._nX = self._ny = None  # staging buffers of a prefetched batch
+        self._has_next = False
+
+    def prefetch(self, X, y, fence=None):
+        """Hand over the NEXT step's batch while this one is still in flight: it is copied into staging buffers (the
+        next run() moves it into plan.X / plan.y itself -- do not copy it there as well) and, on row-sharded tables, its
+        index-only routing work (distinct rows, owners, per-owner counts incl. their exchange and the host read of the
+        split sizes) starts at once on a side stream.  Collective on the multi-GPU paths: every rank calls it at the
+        same point.  Optional: a step whose batch was simply copied into plan.X / plan.y routes it itself."""
+        p = self.plan
+        if self._nX is None:
+            self._nX, self._ny = torch.empty_like(p.X), torch.empty_like(p.y)
+            self._stage_stream = torch.cuda.Stream(device=p.device)
+            self._ev_staged, self._ev_consumed = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_consumed.record(torch.cuda.current_stream())
+        op = p.ops[0] if p.ops else None
+        side = getattr(op, "route_stream", None) or self._stage_stream
+        # X / y must be complete when this is called (resident batches, or `fence` = an event recorded after the work
+        # that produces them): the copies are NOT queued behind the step that is in flight on the caller's stream --
+        # that is the point -- only behind the previous staged batch having been moved into the plan
+        if fence is not None:
+            side.wait_event(fence)
+        side.wait_event(self._ev_consumed)
+        with torch.cuda.stream(side):
+            self._nX.copy_(X, non_blocking=True)
+            self._ny.copy_(y, non_blocking=True)
+            if hasattr(op, "prefetch_route"):
+                op.prefetch_route(self._nX)
+            self._ev_staged.record(side)
+        self._has_next = True
+
+    def drop_prefetch(self):
+        self._has_next = False
+        op = self.plan.ops[0] if self.plan.ops else None
+        if getattr(op, "staged", None) is not None:
+            op.staged = None
 
     def _allreduce(self):
         self.allreduce(self.store.arena)
@@ -225,6 +261,13 @@ class TrainStep:
         stream (hip::Graph::UpdateStreams, ROCm 7.0 runtime bundled with torch 2.10) -- a sporadic segfault that
         depends on how many streams the process has created.  Single-branch graphs never enter that loop."""
         profiling.push("train_step")
+        if self._has_next:  # the batch handed over by prefetch()
+            main = torch.cuda.current_stream()
+            main.wait_event(self._ev_staged)
+            self.plan.X.copy_(self._nX)
+            self.plan.y.copy_(self._ny)
+            self._ev_consumed.record(main)
+            self._has_next = False
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
             for seg in ((self.whole,) if self.whole is not None else

@@ -368,6 +368,56 @@ def test_sharded_path_world1_matches_golden(mode):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dedup", [True, False])
+def test_row_sharded_prefetch_matches_golden(dedup):
+    """trainer.TrainStep.prefetch on row-sharded tables: batch i + 1 is routed on a side stream while step i runs (its
+    count exchange and the host read of the split sizes leave the step's critical path); the step then starts at
+    all_to_all(keys).  Same golden trajectory as the unsharded step, HIP-graph segments on, 1-rank RCCL group."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        from mmlrec_amd import parallel
+        g = load_golden("mmoe_ae30d")
+        for kind, tu in (("adam", "dense_exact"), ("adam", "lazy_exact"), ("adagrad", "sparse_rows")):
+            model, cfg = build(g, table_update=tu)
+            load_state(model, g)
+            model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
+            model.train()
+            parallel.shard_model(model, dist, 64, mode="row_sharded", dedup=dedup)
+            step = model.train_step_runner(64)
+            Xs = [torch.from_numpy(g[f"X{i}"]).cuda() for i in range(3)]
+            ys = [torch.from_numpy(g[f"y{i}"]).cuda() for i in range(3)]
+            losses = []
+            step.plan.X.copy_(Xs[0])
+            step.plan.y.copy_(ys[0])
+            for i in range(3):
+                step.run()
+                if i + 1 < 3:
+                    step.prefetch(Xs[i + 1], ys[i + 1])  # routed beside the step that was just issued
+                    Xs[i + 1] = None                     # (the runner owns a copy: the caller's tensor may go away)
+                losses.append(float(step.plan.loss.item()))
+            gop = step.plan.ops[0]
+            assert gop.staged is None and gop.stats["steps"] == 3
+            assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL), (kind, tu, losses)
+            sd = model.state_dict()
+            lr = cfg["optim_config"]["lr"]
+            for k in sd:
+                ref = g[f"{kind}3/{k}"].astype(np.float64)
+                dv = np.abs(sd[k].cpu().numpy().astype(np.float64) - ref)
+                assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, (kind, tu, k)
+                assert dv.max() <= 2.5 * lr * 3, (kind, tu, k)
+    finally:
+        if created:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+
+
 def test_bf16_operand_mode_kuairec():
     """BASELINE configs[1] (MMoE / KuaiRec-shaped, E = 16) names bf16: the opt-in GEMM mode 1 rounds the operands to
     bf16 in registers (fp32 accumulate, everything else fp32).  The reference has no bf16 path; SURVEY section 8 (A5)
