@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--alt-batch", type=int, default=4096, help="also report this per-GPU batch (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--scatter-mode", default="atomic", choices=["atomic", "deterministic"],
+                    help="deterministic: table gradients as order-independent integer fixed-point sums (bitwise repeatable)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` block (BASELINE.json's other configurations, a few steps each)")
     ap.add_argument("--no-loss-check", action="store_true")
@@ -369,7 +371,7 @@ def main():
         profiling.enable()
 
     model, cfg, vocab, dense = W.build_model(args.workload, dev, table_update=args.table_update,
-                                             use_hip_graph=not args.no_graph)
+                                             use_hip_graph=not args.no_graph, scatter_mode=args.scatter_mode)
     model.compile(cfg["optim_config"]["optimizer"], cfg["optim_config"]["loss"], cfg["optim_config"]["metrics"])
     model.train()
     T = W.num_tasks(cfg)
@@ -477,7 +479,7 @@ def main():
                                              if getattr(runner0, "split_dense", False) else
                                              ("one launch after the scatter, gradients read for marked rows only"
                                               if getattr(runner0, "grad_marks", False) else "one launch after the scatter")),
-                   "hip_graph": not args.no_graph,
+                   "hip_graph": not args.no_graph, "scatter_mode": args.scatter_mode,
                    "streams": 1 if not getattr(runner0, "overlap", True) else (3 if getattr(runner0, "split_dense", False) else 2),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else
                              {"row_sharded": "row-wise sharded over ranks (owner = (row + field) mod N), one all-to-all "

@@ -131,6 +131,19 @@ int mml_index_unique(const int64_t* vocab, const int32_t* col, int32_t F, int32_
                      int32_t* touched_count, int32_t touched_cap, uint8_t* row_marks, int32_t* status,
                      mml_stream_t stream);
 
+/* Deterministic form of mml_scatter_bwd ("mode: sorted" of SURVEY 8(b), without the sort): the same LDS fold, but
+ * every addend is turned into 64-bit fixed point with ONE unit for the whole launch (taken from max |dOut|, which the call
+ * measures into amax_slot: MML_AMAX_WORDS words) and the chunk sums are added to 64-bit integer row accumulators
+ * acc64[f] ([V_f, E] int64, all zero between calls) with integer atomics; a second launch turns the totals of the
+ * marked rows into fp32, adds them to grad_tables and zeroes them again.  Integer sums do not depend on the order of
+ * the addends, so the result is BITWISE repeatable and independent of the order of the samples in the batch (a sorted
+ * fp32 sum would still depend on it); accuracy: addends down to 2^-(62 - 24 - ceil(log2 B)) of the largest |dOut| are
+ * summed exactly.  row_marks: the byte map of mml_scatter_bwd (required: the second launch walks it); clear_marks = 0
+ * leaves the marks for mml_opt_tensor.grad_marks / mml_rows_compact.  E in {4, 8, 16}, dOut 16-byte aligned. */
+int mml_scatter_bwd_det(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                        const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo, int64_t* const* acc64,
+                        uint32_t* amax_slot, uint8_t* row_marks, int32_t clear_marks, int32_t* status,
+                        mml_stream_t stream);
 /* Native-index variants (int32 idx[b*ldi + f], fields in array order): vocabularies >= 2^24 and the
  * owner side of row-sharded tables, which sees lookups as keys into its flat row space (F = 1). */
 int mml_scatter_bwd_idx32(float* const* grad_tables, const int64_t* vocab, int32_t F, int32_t E, const int32_t* idx,

@@ -120,6 +120,8 @@ _SIGS = {
     "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
     "mml_scatter_bwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
                                   fp, fp, i32, fp, fp, fp]),
+    "mml_scatter_bwd_det": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i64, fp, i64, _PP(fp), fp, fp, i32,
+                                      fp, fp]),
     "mml_scatter_bwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, i64, fp, i64, _PP(fp), _PP(i64),
                                         fp, fp, i32, fp, fp, fp]),
     "mml_index_unique_idx32": (C.c_int, [_PP(i64), i32, i32, fp, i64, i64, _PP(fp), _PP(i64), fp, fp, i32, fp, fp, fp]),

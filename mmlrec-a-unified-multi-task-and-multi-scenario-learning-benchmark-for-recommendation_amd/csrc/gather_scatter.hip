@@ -190,6 +190,11 @@ struct ScatterArgs {
   uint8_t* marks;  // optional byte per row (32-byte aligned per field, see mml_scatter_bwd): plain-store row marking
   int64_t markbase[MML_MAX_FIELDS];
   int32_t* status;
+  // deterministic mode (mml_scatter_bwd_det): ONE fixed-point unit for the whole launch, taken from the magnitude slot
+  // of dOut, and 64-bit integer accumulators per table row -- integer sums do not depend on the order of the addends
+  long long* acc64[MML_MAX_FIELDS];
+  const uint32_t* amax_dout;
+  int32_t fix_shift;
 };
 
 // One lane = one gradient float: lanes run over e fastest, so every wave-instruction reads 256 contiguous
@@ -334,13 +339,13 @@ struct ScatterPlan {
 };
 constexpr int kDirectReps = 4;
 
-__device__ __forceinline__ long long to_fixed(float x, int emax) {
+__device__ __forceinline__ long long to_fixed(float x, int emax, const int shift = 28) {
   const unsigned u = __float_as_uint(x);
   int e = (int)((u >> 23) & 0xffu);
   if (e == 255) return 0;             // Inf / NaN: added to the table row directly (scatter_fold_kernel), not folded
   unsigned m = u & 0x7fffffu;
   if (e) m |= 0x800000u; else e = 1;  // subnormal
-  const int sh = e - emax + 28;       // <= 28: x = m * 2^(e - 150) in units of 2^(emax - 178)
+  const int sh = e - emax + shift;    // <= shift: x = m * 2^(e - 150) in units of 2^(emax - 150 - shift)
   long long v;
   if (sh >= 0) v = (long long)m << sh;
   else if (sh > -25) v = ((long long)m + (1ll << (-sh - 1))) >> (-sh);
@@ -348,14 +353,18 @@ __device__ __forceinline__ long long to_fixed(float x, int emax) {
   return (u >> 31) ? -v : v;
 }
 
-__device__ __forceinline__ float from_fixed(long long v, int emax) {
-  return (float)ldexp((double)v, emax - 178);  // int64 -> f64 is exact below 2^53 and rounds once above; one rounding to f32
+__device__ __forceinline__ float from_fixed(long long v, int emax, const int shift = 28) {
+  return (float)ldexp((double)v, emax - 150 - shift);  // int64 -> f64 is exact below 2^53 and rounds once above; one rounding to f32
 }
 
 // NT threads per workgroup: the insert is a chain of LDS round trips (claim -> list -> shuffle -> add), so the kernel
 // wants every wave slot of the CU: 2 workgroups x 1024 threads at 76 KiB of LDS each (256 threads: 98 us, 512: 89 us,
 // 1024: 83 us on Zipf AE-30, B = 65 536)
-template <int SLOTS, int E, int NT>
+// DET: deterministic mode -- the fixed-point unit comes from the launch-wide magnitude of dOut (a.amax_dout) instead of
+// the workgroup's own maximum, and the flush adds the 64-bit chunk sums to 64-bit row accumulators (a.acc64) with INTEGER
+// atomics: every row total is an exact integer sum, whatever the order -- bitwise repeatable, and independent of the
+// order of the samples in the batch (scatter_det_finalize_kernel turns the totals into the fp32 gradient).
+template <int SLOTS, int E, int NT, bool DET = false>
 __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, const ScatterArgs a,
                                                            const ScatterPlan sp) {
   constexpr int LPS = E / 4;                   // lanes per sample
@@ -414,7 +423,14 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
   for (int i = threadIdx.x; i < SLOTS; i += NT) keys[i] = -1;
   if (threadIdx.x == 0) { n_occ = 0; mx_bits = 0; }
   __syncthreads();
-  if (a.dOut) {  // largest magnitude (as bit pattern) of the workgroup's gradient values -> the fixed-point scale
+  if (DET) {
+    if (threadIdx.x == 0) {
+      uint32_t m = 0;
+      for (int i = 0; i < MML_AMAX_WORDS; ++i) m = a.amax_dout[i] > m ? a.amax_dout[i] : m;
+      mx_bits = m;
+    }
+    __syncthreads();
+  } else if (a.dOut) {  // largest magnitude (as bit pattern) of the workgroup's gradient values -> the fixed-point scale
 #pragma unroll
     for (int r = 0; r < kDirectReps; ++r)
 #pragma unroll
@@ -433,6 +449,7 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
   // NaN), not be turned into a finite fixed-point value: such elements skip the fold and go to HBM as float atomics.
   const bool nonfinite = emax >= 255;  // workgroup-uniform
   emax = emax < 1 ? 1 : (emax > 254 ? 254 : emax);
+  const int shift = DET ? a.fix_shift : 28;
   // ---- insert
 #pragma unroll
   for (int r = 0; r < kDirectReps; ++r) {
@@ -470,10 +487,10 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
       }
       if (a.dOut && key >= 0) {
         unsigned long long* p = reinterpret_cast<unsigned long long*>(acc) + (part * 4) * PITCH + slot;
-        atomicAdd(p, (unsigned long long)to_fixed(g[r][k].x, emax));
-        atomicAdd(p + PITCH, (unsigned long long)to_fixed(g[r][k].y, emax));
-        atomicAdd(p + 2 * PITCH, (unsigned long long)to_fixed(g[r][k].z, emax));
-        atomicAdd(p + 3 * PITCH, (unsigned long long)to_fixed(g[r][k].w, emax));
+        atomicAdd(p, (unsigned long long)to_fixed(g[r][k].x, emax, shift));
+        atomicAdd(p + PITCH, (unsigned long long)to_fixed(g[r][k].y, emax, shift));
+        atomicAdd(p + 2 * PITCH, (unsigned long long)to_fixed(g[r][k].z, emax, shift));
+        atomicAdd(p + 3 * PITCH, (unsigned long long)to_fixed(g[r][k].w, emax, shift));
         if (nonfinite) {
           float* dst = a.gtab[f] + (int64_t)key * E + part * 4;
           const float gv[4] = {g[r][k].x, g[r][k].y, g[r][k].z, g[r][k].w};
@@ -492,7 +509,12 @@ __global__ __launch_bounds__(NT) void scatter_fold_kernel(const FieldTable ft, c
     const int slot = direct ? i : (int)occ[i];
     const int key = keys[slot];
     if (key < 0) continue;  // (direct-mapped: a row no sample of these chunks touched)
-    if (a.dOut) atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
+    if (DET) {
+      const long long v = acc[e * PITCH + slot];
+      if (v) atomicAdd(reinterpret_cast<unsigned long long*>(a.acc64[f]) + (int64_t)key * E + e, (unsigned long long)v);
+    } else if (a.dOut) {
+      atomicAdd(gt + (int64_t)key * E + e, from_fixed(acc[e * PITCH + slot], emax));
+    }
     // touched-row bookkeeping: only MARK the row here (a non-returning atomic: they run at the float-atomic request
     // rate, while the returning form that told "first time seen" cost the index-only pass 0.5 ms); the list is built
     // from the bitmaps by rows_compact_kernel
@@ -642,7 +664,7 @@ static int launch_compact(const FieldTable& ft, const ScatterArgs& a, hipStream_
   return check_launch(who);
 }
 
-template <int SLOTS, int E, int NT>
+template <int SLOTS, int E, int NT, bool DET = false>
 static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stream, const char* who) {
   constexpr int CHUNK = SLOTS / 2;
   ScatterPlan sp{};
@@ -662,7 +684,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_relaxed) >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_fold_kernel<SLOTS, E, NT, DET>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
@@ -670,7 +692,7 @@ static int launch_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t s
     }
     if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_relaxed);
   }
-  MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
+  MML_LAUNCH((scatter_fold_kernel<SLOTS, E, NT, DET>), dim3((unsigned)(total * 8)), dim3(NT), lds, stream, ft, a, sp);
   int rc = check_launch(who);
   if (rc || !a.touched) return rc;
   return launch_compact(ft, a, stream, who, true);
@@ -685,6 +707,42 @@ static int try_fold(const FieldTable& ft, const ScatterArgs& a, hipStream_t stre
   if (a.E == 4) return launch_fold<1024, 4, 512>(ft, a, stream, who);
   if (a.E == 16) return launch_fold<512, 16, 1024>(ft, a, stream, who);
   return 1;
+}
+
+// Deterministic mode, second launch: every marked row's 64-bit totals -> fp32, added to the gradient accumulator (one
+// thread owns a row: no atomics), the totals zeroed again.  One field per workgroup range like rows_compact_kernel.
+struct DetFinalArgs {
+  float* gtab[MML_MAX_FIELDS];
+  long long* acc64[MML_MAX_FIELDS];
+  int64_t vocab[MML_MAX_FIELDS];
+  int64_t markbase[MML_MAX_FIELDS];
+  int32_t blk0[MML_MAX_FIELDS + 1];
+  uint8_t* marks;
+  const uint32_t* amax_dout;
+  int32_t F, E, fix_shift, clear_marks;
+};
+__global__ __launch_bounds__(256) void scatter_det_finalize_kernel(const DetFinalArgs a) {
+  int f = 0;
+  while (f + 1 < a.F && (int)blockIdx.x >= a.blk0[f + 1]) ++f;
+  const int bx = (int)blockIdx.x - a.blk0[f], nb = a.blk0[f + 1] - a.blk0[f];
+  uint32_t m = 0;
+  for (int i = 0; i < MML_AMAX_WORDS; ++i) m = a.amax_dout[i] > m ? a.amax_dout[i] : m;
+  int emax = (int)(m >> 23);
+  emax = emax < 1 ? 1 : (emax > 254 ? 254 : emax);  // (as scatter_fold_kernel clamps it; Inf / NaN went to the table directly)
+  uint8_t* marks = a.marks + a.markbase[f];
+  for (int64_t row = (int64_t)bx * 256 + threadIdx.x; row < a.vocab[f]; row += (int64_t)nb * 256) {
+    if (!marks[row]) continue;
+    long long* src = a.acc64[f] + row * a.E;
+    float* dst = a.gtab[f] + row * a.E;
+    for (int e = 0; e < a.E; ++e) {
+      const long long v = src[e];
+      if (v) {
+        dst[e] += from_fixed(v, emax, a.fix_shift);
+        src[e] = 0;
+      }
+    }
+    if (a.clear_marks) marks[row] = 0;
+  }
 }
 
 }  // namespace mml
@@ -932,4 +990,63 @@ extern "C" int mml_rows_compact(uint32_t* const* seen, const int64_t* vocab, con
   a.touched = touched; a.touched_count = touched_count; a.touched_cap = touched_cap;
   set_marks(a, ft, row_marks);
   return launch_compact(ft, a, to_stream(stream), "mml_rows_compact");
+}
+
+extern "C" int mml_scatter_bwd_det(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                                   int32_t E, const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo,
+                                   int64_t* const* acc64, uint32_t* amax_slot, uint8_t* row_marks, int32_t clear_marks,
+                                   int32_t* status, mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, (const float* const*)grad_tables, vocab, col, F, "mml_scatter_bwd_det");
+  if (rc) return rc;
+  MML_REQUIRE(B >= 0 && (E == 4 || E == 8 || E == 16), "mml_scatter_bwd_det: E must be 4, 8 or 16");
+  MML_REQUIRE(B == 0 || (X && dOut), "mml_scatter_bwd_det: null X/dOut");
+  MML_REQUIRE(acc64 && amax_slot && row_marks, "mml_scatter_bwd_det: acc64, amax_slot and row_marks are required");
+  MML_REQUIRE(ldo % 4 == 0 && aligned16(dOut), "mml_scatter_bwd_det: dOut must be 16-byte aligned with ldo %% 4 == 0");
+  if (B == 0 || F == 0) return MML_OK;
+  hipStream_t st = to_stream(stream);
+  // the launch-wide magnitude of dOut (a maximum does not depend on the order either)
+  rc = mml_amax_reset(amax_slot, 1, stream);
+  if (rc) return rc;
+  mml_amax_desc ad{};
+  ad.x = dOut; ad.rows = B; ad.ld = ldo; ad.cols = F * E; ad.slot = amax_slot;
+  rc = mml_amax_batch(&ad, 1, stream);
+  if (rc) return rc;
+  ScatterArgs a{};
+  DetFinalArgs fa{};
+  for (int f = 0; f < F; ++f) {
+    MML_REQUIRE(acc64[f], "mml_scatter_bwd_det: acc64[%d] is null", f);
+    MML_REQUIRE(vocab[f] <= 0x7fffffff, "mml_scatter_bwd_det: table %d too large", f);
+    a.gtab[f] = grad_tables[f];
+    a.acc64[f] = reinterpret_cast<long long*>(acc64[f]);
+    fa.gtab[f] = grad_tables[f];
+    fa.acc64[f] = a.acc64[f];
+    fa.vocab[f] = vocab[f];
+  }
+  a.X = X; a.ldX = ldX; a.B = B; a.dOut = dOut; a.ldo = ldo; a.F = F; a.E = E; a.status = status;
+  a.amax_dout = amax_slot;
+  // headroom: a row may receive all B addends at the launch-wide maximum: 24 significand bits + shift + log2(B) < 63
+  int lg = 1;
+  while (((int64_t)1 << lg) < B) ++lg;
+  int shift = 62 - 24 - lg;
+  shift = shift > 28 ? 28 : (shift < 4 ? 4 : shift);
+  a.fix_shift = shift;
+  set_marks(a, ft, row_marks);
+  if (E == 8) rc = launch_fold<1024, 8, 1024, true>(ft, a, st, "mml_scatter_bwd_det");
+  else if (E == 4) rc = launch_fold<1024, 4, 512, true>(ft, a, st, "mml_scatter_bwd_det");
+  else rc = launch_fold<512, 16, 1024, true>(ft, a, st, "mml_scatter_bwd_det");
+  if (rc) return rc < 0 ? rc : MML_ERR_UNSUPPORTED;
+  int total = 0;
+  for (int f = 0; f < F; ++f) {
+    fa.markbase[f] = a.markbase[f];
+    int64_t nb = cdiv(vocab[f], 256 * 8);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    fa.blk0[f] = total;
+    total += (int)nb;
+  }
+  fa.blk0[F] = total;
+  fa.marks = row_marks; fa.amax_dout = amax_slot; fa.F = F; fa.E = E; fa.fix_shift = shift; fa.clear_marks = clear_marks;
+  MML_LAUNCH(scatter_det_finalize_kernel, dim3((unsigned)total), dim3(256), 0, st, fa);
+  return check_launch("mml_scatter_bwd_det");
 }

@@ -411,6 +411,9 @@ class GatherOp(Op):
         # uint8 map (ops.marks_bytes layout): the scatter marks every row it adds to, the dense table optimizer skips
         # the gradient read of unmarked rows and clears the marks (mml_opt_tensor.grad_marks)
         self.grad_marks = None
+        # True: the backward is mml_scatter_bwd_det -- order-independent integer fixed-point sums, bitwise repeatable
+        # (BaseModel.scatter_mode = "deterministic"); needs store.ensure_det(tables)
+        self.deterministic = None
 
     def outputs(self):
         return [self.out]
@@ -469,6 +472,24 @@ class GatherOp(Op):
             extra = (None, None, None, None, 0, L.ptr(self.grad_marks))
         meta = dict(kernel=scatter_symbol(E),
                     bytes=float(plan.B) * F * (4 + 12 * E), tail=True)  # idx + grad read + row RMW
+        det = self.deterministic
+        if det is not None:
+            # deterministic scatter: 64-bit integer row totals, then fp32 (two launches + the magnitude of d(dnn_input));
+            # the marks feed the marked dense update (left set) or the touched-row list (compaction, which clears them)
+            acc = ops._ptr_array(det["acc64"])
+            marks = self.grad_marks if self.grad_marks is not None else (sr.marks if sr is not None else det["marks"])
+            keep_marks = self.grad_marks is not None or sr is not None
+            slot = det["slot"]
+            plan.keep += [acc]
+            calls = [(lib.mml_scatter_bwd_det, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
+                                                self.out.grad.data_ptr(), ops._ld(self.out.grad), acc, slot.data_ptr(),
+                                                marks.data_ptr(), 0 if keep_marks else 1, plan.status.data_ptr()),
+                      dict(meta, kernel="scatter_fold_kernel<det>"))]
+            if sr is not None:
+                calls.append((lib.mml_rows_compact, (seen, vocab, rb, F, sr.touched.data_ptr(), sr.count.data_ptr(),
+                                                     sr.touched.numel(), sr.marks.data_ptr()),
+                              dict(kernel="rows_compact_kernel", bytes=float(sr.marks.numel()), tail=True)))
+            return calls
         return [(lib.mml_scatter_bwd, (gt, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), plan.B,
                                        self.out.grad.data_ptr(), ops._ld(self.out.grad)) + extra +
                  (plan.status.data_ptr(),), meta)]
@@ -1556,6 +1577,21 @@ class ParamStore:
             base.append(off)
             off += (v + 31) // 32 * 32
         return self.grad_marks, base
+
+    def ensure_det(self, tables):
+        """Buffers of the deterministic scatter for `tables` (a gather's field order): int64 [V, E] totals per table (kept
+        all zero between steps by the scatter's second launch), a mark map of its own and a magnitude slot."""
+        key = tuple(t.data.data_ptr() for t in tables)
+        if getattr(self, "_det_key", None) != key:
+            uniq = {}
+            for t in tables:
+                uniq.setdefault(t.data.data_ptr(), torch.zeros(t.data.shape, dtype=torch.int64, device=self.device))
+            self._det = dict(acc64=[uniq[t.data.data_ptr()] for t in tables],
+                             marks=torch.zeros(ops.marks_bytes([int(t.data.shape[0]) for t in tables]), dtype=torch.uint8,
+                                               device=self.device),
+                             slot=ops.amax_slots(1, self.device)[0])
+            self._det_key = key
+        return self._det
 
     def stale(self):
         return self.sig != tuple(p.data_ptr() for _, p in self.model.named_parameters())

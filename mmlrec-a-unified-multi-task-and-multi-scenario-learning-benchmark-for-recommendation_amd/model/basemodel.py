@@ -272,6 +272,7 @@ class BaseModel(nn.Module):
             if (grad_marks and sparse_rows is None and E_dim in (4, 8, 16) and
                     len({id(t) for t in tables}) == len(tables)):
                 op.grad_marks = store.ensure_grad_marks(tables)[0]
+            self._maybe_deterministic(op, store, tables, training, E_dim)
             plan.add(op)
         else:  # single GPU, and inference on the (synchronised) full tables of a row-sharded / replicated model
             gop = E.GatherOp(tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows)
@@ -281,12 +282,25 @@ class BaseModel(nn.Module):
             if (grad_marks and training and sparse_rows is None and E_dim in (4, 8, 16) and
                     len({id(t) for t in tables}) == len(tables)):
                 gop.grad_marks = store.ensure_grad_marks(tables)[0]
+            self._maybe_deterministic(gop, store, tables, training, E_dim)
             plan.add(gop)
         plan.layer_outputs["dnn_input"] = x0
         head = self._build_graph(plan, store, x0)
         head.mask_cols = self._head_mask_cols()
         plan.finish(head)
         return plan
+
+    def _maybe_deterministic(self, gop, store, tables, training, E_dim):
+        """model.scatter_mode = "deterministic" (or model_config["scatter_mode"]): the table gradients of the step are
+        summed in order-independent integer fixed point (mml_scatter_bwd_det) -- bitwise repeatable runs, and replicated
+        tables that stay bitwise equal on every rank without re-broadcasts.  Default "atomic" (float atomics: faster)."""
+        mode = getattr(self, "scatter_mode", None) or (self.config or {}).get("model_config", {}).get("scatter_mode", "atomic")
+        if mode not in ("atomic", "deterministic"):
+            raise ValueError("scatter_mode must be 'atomic' or 'deterministic'")
+        if mode == "deterministic" and training:
+            if E_dim not in (4, 8, 16) or len({id(t) for t in tables}) != len(tables):
+                raise NotImplementedError("deterministic scatter: embedding size 4, 8 or 16 and one table per field")
+            gop.deterministic = store.ensure_det(tables)
 
     def _head_mask_cols(self):
         """Column of domain_mask that multiplies head i (e.g. model/mmoe.py:101-106), or None for unmasked heads."""

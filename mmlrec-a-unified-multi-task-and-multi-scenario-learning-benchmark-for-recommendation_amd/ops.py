@@ -135,6 +135,22 @@ def scatter_bwd(grad_tables, X, cols, d_out, seen=None, rowbase=None, touched=No
     L.check(rc, "mml_scatter_bwd")
 
 
+def scatter_bwd_det(grad_tables, X, cols, d_out, acc64, marks, amax_slot=None, clear_marks=True, status=None):
+    """Deterministic scatter (mml_scatter_bwd_det): acc64 = per-table int64 [V, E] accumulators (all zero between calls),
+    marks = the byte map of marks_bytes(vocab).  Bitwise repeatable, independent of the order of the samples."""
+    lib = L.load()
+    _need_gpu(X, d_out, *grad_tables)
+    F, E, B = len(grad_tables), grad_tables[0].shape[1], X.shape[0]
+    vocab = (L.i64 * F)(*[t.shape[0] for t in grad_tables])
+    col = (L.i32 * F)(*cols)
+    if amax_slot is None:
+        amax_slot = amax_slots(1, X.device)[0]
+    rc = lib.mml_scatter_bwd_det(_ptr_array(grad_tables), vocab, col, F, E, X.data_ptr(), _ld(X), B, d_out.data_ptr(),
+                                 _ld(d_out), _ptr_array(acc64), amax_slot.data_ptr(), marks.data_ptr(),
+                                 int(bool(clear_marks)), L.ptr(status), _stream())
+    L.check(rc, "mml_scatter_bwd_det")
+
+
 def scatter_bwd_idx32(grad_tables, idx, d_out, seen=None, rowbase=None, touched=None, touched_count=None, status=None,
                       marks=None):
     """grad_tables[f][idx[:, f]] += d_out[:, f*E:(f+1)*E] with native int32 indices [B, F]."""

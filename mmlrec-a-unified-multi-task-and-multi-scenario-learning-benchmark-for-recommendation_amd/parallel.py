@@ -639,6 +639,11 @@ def shard_model(model, dist, batch_per_rank=4096, group=None, mode="row_sharded"
     return par
 
 
+def _scatter_mode(model):
+    return getattr(model, "scatter_mode", None) or (getattr(model, "config", None) or {}).get("model_config", {}).get(
+        "scatter_mode", "atomic")
+
+
 def sync_tables(model):
     """Make every rank's full embedding_dict tables equal to the trained state (collective).
     row_sharded: all-gather of the flat shards; table_wise: broadcast from each owner; replicated: rank 0's copy."""
@@ -656,6 +661,10 @@ def sync_tables(model):
     elif par.mode == "table_wise":
         for f, w in enumerate(tabs):
             comm.broadcast(w, src=par.sharding.owner[f])
+    elif _scatter_mode(model) == "deterministic":
+        # replicated tables + deterministic scatter: every rank applied bitwise the same update to its copy (identical
+        # all-gathered inputs, order-independent integer sums, the all-reduced MLP gradients): nothing to reconcile
+        pass
     else:
         for w in tabs:
             comm.broadcast(w, src=0)

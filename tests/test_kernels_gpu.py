@@ -980,3 +980,47 @@ def test_route_out_of_range_sets_status(ops):
     assert int(counts.sum().item()) == 3
     with pytest.raises(IndexError):
         ops.check_status(status)
+
+
+@pytest.mark.parametrize("E", [4, 8, 16])
+def test_scatter_det_is_bitwise_repeatable_and_order_independent(E):
+    """mml_scatter_bwd_det (SURVEY 8(b) "mode: sorted", 5 "deterministic variant for bit-stable debugging"): integer
+    fixed-point row totals.  Two runs agree BIT FOR BIT; so does a run on the same batch in another sample order (a
+    sorted fp32 sum would not); the result is the float64 index_add to 1e-6; the 64-bit totals are zero again afterwards
+    and the marks cleared.  Tables: a hot tiny one (every sample hits 2 rows), direct-mapped, hashed and a large one."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import ops
+    dev = torch.device("cuda:0")
+    vocab = [2, 100, 1000, 5000, 300000]
+    F, B = len(vocab), 20000
+    g = torch.Generator().manual_seed(E)
+    X = torch.stack([(torch.rand(B, generator=g) ** 3 * v).floor().clamp_(0, v - 1) for v in vocab], 1).contiguous()
+    d = torch.randn(B, F * E, generator=g) * torch.logspace(-6, 2, B).unsqueeze(1)[torch.randperm(B, generator=g)]
+    marks_n = ops.marks_bytes(vocab)
+
+    def run(Xh, dh):
+        gt = [torch.zeros(v, E, device=dev) for v in vocab]
+        acc = [torch.zeros(v, E, dtype=torch.int64, device=dev) for v in vocab]
+        marks = torch.zeros(marks_n, dtype=torch.uint8, device=dev)
+        ops.scatter_bwd_det(gt, Xh.to(dev), list(range(F)), dh.to(dev), acc, marks)
+        torch.cuda.synchronize()
+        assert all(int(a.abs().max()) == 0 for a in acc) and int(marks.max()) == 0
+        return gt
+
+    g1, g2 = run(X, d), run(X, d)
+    perm = torch.randperm(B, generator=g)
+    g3 = run(X[perm].contiguous(), d[perm].contiguous())
+    for f in range(F):
+        assert torch.equal(g1[f].view(torch.int32), g2[f].view(torch.int32)), f
+        assert torch.equal(g1[f].view(torch.int32), g3[f].view(torch.int32)), f
+        ref = torch.zeros(vocab[f], E, dtype=torch.float64, device=dev)
+        ref.index_add_(0, X[:, f].long().to(dev), d[:, f * E:(f + 1) * E].double().to(dev))
+        err = (g1[f].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-6, (f, err)
+    # second call ADDS to the accumulators (like mml_scatter_bwd): 2 x the first result, exactly (powers of two)
+    gt = [t.clone() for t in g1]
+    acc = [torch.zeros(v, E, dtype=torch.int64, device=dev) for v in vocab]
+    marks = torch.zeros(marks_n, dtype=torch.uint8, device=dev)
+    ops.scatter_bwd_det(gt, X.to(dev), list(range(F)), d.to(dev), acc, marks)
+    for f in range(F):
+        assert torch.allclose(gt[f], 2 * g1[f], rtol=1e-6, atol=0)

@@ -418,6 +418,38 @@ def test_row_sharded_prefetch_matches_golden(dedup):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("tu,kind", [("dense_exact", "adam"), ("sparse_rows", "adagrad"), ("lazy_exact", "adam")])
+def test_deterministic_scatter_mode_is_bitwise_repeatable(tu, kind):
+    """model.scatter_mode = "deterministic": two independent 3-step runs of the fused step (HIP graphs, two streams) end
+    in BITWISE identical parameters -- tables and MLP (everything else in the step is fixed-order already) -- and in the
+    reference's trajectory like the default mode."""
+    g = load_golden("mmoe_ae30d")
+    finals = []
+    for rep_ in range(2):
+        model, cfg = build(g, table_update=tu)
+        load_state(model, g)
+        model.scatter_mode = "deterministic"
+        model.compile(kind, cfg["optim_config"]["loss"], ["auc"])
+        model.train()
+        losses = []
+        for i in range(3):
+            step = model.train_step_runner(64, use_graph=True)
+            step.plan.X.copy_(torch.from_numpy(g[f"X{i}"]).cuda())
+            step.plan.y.copy_(torch.from_numpy(g[f"y{i}"]).cuda())
+            step.run()
+            losses.append(float(step.plan.loss.item()))
+        assert step.plan.ops[0].deterministic is not None
+        assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL), (tu, losses)
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    lr = cfg["optim_config"]["lr"]
+    for k in finals[0]:
+        assert torch.equal(finals[0][k].view(torch.int32), finals[1][k].view(torch.int32)), (tu, k)
+        ref = g[f"{kind}3/{k}"].astype(np.float64)
+        dv = np.abs(finals[0][k].numpy().astype(np.float64) - ref)
+        assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, (tu, k)
+        assert dv.max() <= 2.5 * lr * 3, (tu, k)
+
+
 def test_bf16_operand_mode_kuairec():
     """BASELINE configs[1] (MMoE / KuaiRec-shaped, E = 16) names bf16: the opt-in GEMM mode 1 rounds the operands to
     bf16 in registers (fp32 accumulate, everything else fp32).  The reference has no bf16 path; SURVEY section 8 (A5)
