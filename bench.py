@@ -217,13 +217,14 @@ def roofline_of(acc):
         planes = 0
         import re
         m = re.match(r"gemm_pipe_kernel<\w+, \w+, \d+, \d+, (\d+)", name)
-        if m and int(m.group(1)) in (1, 3):
+        if m and int(m.group(1)) in (1, 2, 3):
             planes = int(m.group(1))
-        if planes:  # fp32 emulated on the bf16 MFMA pipe: 3 (two planes) or 6 (three planes) MFMAs per product block
+        if planes:  # fp32 emulated on the 16-bit MFMA pipe: 3 (two fp16 planes) or 6 (three bf16 planes) MFMAs per block
             per = {1: 1, 2: 3, 3: 6}[planes]
             peak = 2500.0 / per
-            note = (f"algorithmic fp32 FLOP/s; the kernel issues {per} v_mfma_f32_32x32x16_bf16 per 32x32x16 product "
-                    f"block, so peak = dense bf16 MFMA peak (2.5 PFLOP/s) / {per}; frac = bf16 MFMA pipe utilisation. "
+            ins = "v_mfma_f32_32x32x16_f16" if planes == 2 else "v_mfma_f32_32x32x16_bf16"
+            note = (f"algorithmic fp32 FLOP/s; the kernel issues {per} {ins} per 32x32x16 product "
+                    f"block, so peak = dense 16-bit MFMA peak (2.5 PFLOP/s) / {per}; frac = MFMA pipe utilisation. "
                     f"The fp32 MFMA peak (v_mfma_f32_32x32x2_f32) is 157.3 TFLOP/s.")
         else:
             peak = 157.3
@@ -458,7 +459,10 @@ def main():
         return
     from mmlrec_amd import _lib
     gmode = _lib.load().mml_gemm_get_mode()
-    gemm_dtype = {0: "f32", 4: "f32 (GEMMs: fp32 MFMA, or fp32-equivalent 3-plane bf16 MFMA emulation with f32 accumulate where faster)",
+    gemm_dtype = {0: "f32", 4: "f32 (GEMMs: fp32-equivalent emulation on the 16-bit MFMA pipe with f32 accumulate -- two scaled fp16 planes "
+                                "per operand where the operand magnitudes travel with the tensors (batches >= 16 384), else three bf16 planes; "
+                                "max-norm error vs float64 3.3e-7 / 4.7e-7, fp32 MFMA 4.3e-7)",
+                  2: "f32 (GEMMs: as mode 4)",
                   3: "f32 (GEMMs: fp32-equivalent 3-plane bf16 MFMA emulation, f32 accumulate)",
                   1: "bf16 GEMM operands (rounded in registers), f32 accumulate, f32 everywhere else"}.get(
         gmode, "f32 operands, GEMM products from 2 bf16 planes (~1e-5 rel), f32 accumulate")

@@ -472,6 +472,7 @@ typedef struct mml_sumprod_desc {
   const float* deriv_of;
   int32_t act;
   int32_t pad_;
+  uint32_t* amax_out; /* optional operand-magnitude slot (see the GEMM family) raised with max |out|, or NULL */
 } mml_sumprod_desc;
 int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_stream_t stream);
 /* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,

@@ -90,7 +90,7 @@ class Copy2dDesc(C.Structure):
 
 class SumProdDesc(C.Structure):
     _fields_ = [("out", fp), ("x", fp * 8), ("y", fp * 8), ("n", i64), ("n_terms", i32), ("accumulate", i32),
-                ("deriv_of", fp), ("act", i32), ("pad_", i32)]
+                ("deriv_of", fp), ("act", i32), ("pad_", i32), ("amax_out", fp)]
 
 
 class Attn2Desc(C.Structure):

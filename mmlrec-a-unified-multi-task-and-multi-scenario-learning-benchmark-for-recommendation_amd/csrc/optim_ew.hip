@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void sumprod_batch_kernel(const SumProdBatch B
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool vec = (D.n & 3) == 0 && aligned16(D.out) && (!D.deriv_of || aligned16(D.deriv_of));
   for (int k = 0; k < D.n_terms; ++k) vec = vec && aligned16(D.x[k]) && (!D.y[k] || aligned16(D.y[k]));
+  float am = 0.f;  // operand magnitude of what this thread stores (D.amax_out)
   if (vec) {  // 16 bytes per lane and operand
     const int64_t n4 = D.n >> 2;
     for (int64_t i = tid; i < n4; i += stride) {
@@ -552,7 +553,9 @@ __global__ __launch_bounds__(256) void sumprod_batch_kernel(const SumProdBatch B
         s.z *= act_deriv_from_output(o.z, D.act); s.w *= act_deriv_from_output(o.w, D.act);
       }
       reinterpret_cast<float4*>(D.out)[i] = s;
+      amax_acc(am, s);
     }
+    amax_flush(am, D.amax_out);
     return;
   }
   for (int64_t i = tid; i < D.n; i += stride) {
@@ -560,7 +563,9 @@ __global__ __launch_bounds__(256) void sumprod_batch_kernel(const SumProdBatch B
     for (int k = 0; k < D.n_terms; ++k) s += D.x[k][i] * (D.y[k] ? D.y[k][i] : 1.f);
     if (D.act != MML_ACT_NONE) s *= act_deriv_from_output(D.deriv_of[i], D.act);
     D.out[i] = s;
+    amax_acc(am, s);
   }
+  amax_flush(am, D.amax_out);
 }
 
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows,
@@ -976,7 +981,12 @@ extern "C" int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_strea
       nmax = D.n > nmax ? D.n : nmax;
     }
     if (nmax == 0) continue;
-    MML_LAUNCH(sumprod_batch_kernel, dim3(ew_grid(nmax), (unsigned)m), dim3(256), 0, to_stream(stream), Bt);
+    // about 2048 workgroups in all (8 per CU: every wave slot) walking their item grid-stride: items that publish their
+    // magnitude end with one atomic per workgroup, and 30 000 of those on eight words cost more than the pass itself
+    unsigned gx = ew_grid(nmax);
+    const unsigned cap = (unsigned)(2048 / m > 64 ? 2048 / m : 64);
+    if (gx > cap) gx = cap;
+    MML_LAUNCH(sumprod_batch_kernel, dim3(gx, (unsigned)m), dim3(256), 0, to_stream(stream), Bt);
     int rc = check_launch("mml_sumprod_batch");
     if (rc) return rc;
   }

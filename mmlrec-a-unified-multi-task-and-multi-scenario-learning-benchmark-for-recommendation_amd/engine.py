@@ -1312,10 +1312,12 @@ class MulBatchOp(Op):
     @staticmethod
     def _descs(plan, rows):
         arr = (L.SumProdDesc * len(rows))()
-        for d, (out, n, terms, acc, act, deriv_of) in zip(arr, rows):
+        for d, row in zip(arr, rows):
+            out, n, terms, acc, act, deriv_of = row[:6]
             if len(terms) > 8:
                 raise NotImplementedError("more than 8 products share one operand")
             d.out, d.n, d.n_terms, d.accumulate = out.data_ptr(), n, len(terms), int(acc)
+            d.amax_out = L.ptr(row[6]) if len(row) > 6 else None
             d.act, d.deriv_of = int(act), (deriv_of.data_ptr() if act != L.ACT_NONE else None)
             for k, (x, y) in enumerate(terms):
                 d.x[k], d.y[k] = x.data_ptr(), y.data_ptr()
@@ -1323,7 +1325,13 @@ class MulBatchOp(Op):
         return arr
 
     def fwd_calls(self, plan):
-        rows = [(o.buf, n, [(a.buf, b.buf)], 0, L.ACT_NONE, None) for (a, b, o), n in zip(self.items, self.flat)]
+        rows = []
+        for (a, b, o), n in zip(self.items, self.flat):
+            # the product's magnitude for the GEMMs that read it (only when the flat launch covers no padding columns)
+            slot = plan.new_amax() if (o.amax is None and o.buf.stride(0) == o.n) else None
+            if slot is not None:
+                o.amax = slot
+            rows.append((o.buf, n, [(a.buf, b.buf)], 0, L.ACT_NONE, None, slot))
         return [(L.load().mml_sumprod_batch, (self._descs(plan, rows), len(rows)),
                  dict(kernel="sumprod_batch_kernel", bytes=12.0 * sum(self.flat)))]
 
@@ -1344,7 +1352,14 @@ class MulBatchOp(Op):
             fold = (not acc and v.act != L.ACT_NONE and not v.deriv_applied and len(v.consumers) == 1)
             if fold:
                 v.deriv_applied = True
-            rows.append((g, n, terms, acc, v.act if fold else L.ACT_NONE, v.buf))
+            slot = None  # magnitude of the gradient as stored (tracked like a dgrad GEMM's amax_out)
+            if plan.amax_pool is not None and g.stride(0) == v.n:
+                if v.gamax is None:
+                    v.gamax = plan.new_amax()
+                if v.gamax_writers == v.written - 1:
+                    v.gamax_writers += 1
+                    slot = v.gamax
+            rows.append((g, n, terms, acc, v.act if fold else L.ACT_NONE, v.buf, slot))
             nbytes += 4.0 * n * (2 * len(terms) + 1 + (1 if (acc or fold) else 0))
         if not rows:
             return []
