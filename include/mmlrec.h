@@ -268,39 +268,6 @@ typedef struct {
 } mml_gemm_fwd_desc;
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------------
- * K3p  Linear forward on operands that are already cut into bf16 planes.
- * mml_gemm_grouped_fwd emulates the fp32 product with three bf16 planes per operand and cuts every fragment in
- * registers, in every wave that uses it; the cuts bound that kernel.  Here a matrix X[R, C] is cut ONCE into
- * "plane panels": bf16 [ldp / 8 panels][R rows][3 planes][8] -- a panel holds eight consecutive columns of every row,
- * the h, m and l chunks of a row side by side (h, m, l = the top / middle / bottom 8 bits of the significand:
- * h + m + l == X bit for bit for normal numbers above 2^-100), ldp a multiple of 16, columns [C, ldp) zero
- * (mml_planes_cut; transpose = 1 cuts X^T, i.e. output rows = columns of X) -- and the GEMM only moves planes: a
- * 256-row piece of a panel is 12 KiB of contiguous memory, whole cache lines for every DMA instruction.
- * Same contract as mml_gemm_grouped_fwd with w_kn = 0:  C = act(A W^T + bias), optional ReLU sign mask.
- * Requirements (else MML_ERR_ARG): N % 4 == 0, C / bias 16-byte aligned, ldc % 4 == 0.
- * ---------------------------------------------------------------------------------------------- */
-typedef struct {
-  const float* src;      /* [rows, cols], row pitch ld */
-  uint16_t* planes;      /* 3 * ldp * (output rows) elements */
-  int64_t ld, ldp;
-  int32_t rows, cols;
-  int32_t transpose, pad_;
-} mml_planes_cut_desc;
-int mml_planes_cut(const mml_planes_cut_desc* descs, int32_t n, mml_stream_t stream);
-
-typedef struct {
-  const uint16_t* A;   /* planes of the [M, K] input                          */
-  const uint16_t* W;   /* planes of the [N, K] weight (nn.Linear layout)      */
-  const float* bias;   /* [N] or NULL                                         */
-  float* C;            /* [M, N]                                              */
-  uint32_t* relu_mask; /* as mml_gemm_fwd_desc.relu_mask (act == RELU) or NULL */
-  int64_t ldpa, ldpw;  /* padded column counts (ldp) the two matrices were cut with */
-  int64_t ldc, ldmask;
-  int32_t M, N, K;
-  int32_t act;
-} mml_gemm_planes_fwd_desc;
-int mml_gemm_planes_fwd(const mml_gemm_planes_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
 typedef struct {
   float* dA;           /* [M, K] = sum_s dC_s W_s  (then * act'(Y) if act != NONE)            */

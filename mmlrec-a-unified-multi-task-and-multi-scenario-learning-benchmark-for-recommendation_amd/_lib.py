@@ -29,17 +29,6 @@ class AmaxDesc(C.Structure):
     _fields_ = [("x", fp), ("rows", i64), ("ld", i64), ("cols", i32), ("pad_", i32), ("slot", fp)]
 
 
-class PlanesCutDesc(C.Structure):
-    _fields_ = [("src", fp), ("planes", fp), ("ld", i64), ("ldp", i64), ("rows", i32),
-                ("cols", i32), ("transpose", i32), ("pad_", i32)]
-
-
-class GemmPlanesFwdDesc(C.Structure):
-    _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("relu_mask", fp), ("ldpa", i64), ("ldpw", i64),
-                ("ldc", i64), ("ldmask", i64), ("M", i32), ("N", i32), ("K", i32),
-                ("act", i32)]
-
-
 class GemmDgradDesc(C.Structure):
     _fields_ = [("dA", fp), ("Y", fp), ("ldda", i64), ("ldy", i64), ("M", i32), ("K", i32), ("act", i32),
                 ("n_src", i32), ("accumulate", i32), ("pad_", i32),
@@ -112,8 +101,6 @@ _SIGS = {
     "mml_device_caps": (C.c_int, [C.c_int, _PP(i64)]),
     "mml_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _PP(C.c_void_p)]),
     "mml_stream_destroy": (C.c_int, [C.c_void_p]),
-    "mml_planes_cut": (C.c_int, [_PP(PlanesCutDesc), i32, fp]),
-    "mml_gemm_planes_fwd": (C.c_int, [_PP(GemmPlanesFwdDesc), i32, fp]),
     "mml_gather_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
     "mml_gather_fwd_mark": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp, fp]),
     "mml_rows_compact": (C.c_int, [_PP(fp), _PP(i64), _PP(i64), i32, fp, fp, i32, fp, fp]),

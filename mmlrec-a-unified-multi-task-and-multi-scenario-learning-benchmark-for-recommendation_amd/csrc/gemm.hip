@@ -444,14 +444,6 @@ __device__ __forceinline__ void read_frag_nrc(uint32_t a, RawFrag<false>& r) {
 // ====================================================================================================
 constexpr int PSTAGES = 4;
 
-#ifdef MML_LAB_TIMES  // per-phase cycle sums of wave 0 of workgroup 0 (tools/lab): [0] wait+barrier [1] issue+scalar
-                      // [2] reads + blocks 1-2 [3] blocks 3-4 (+epilogue) [4] steps [5] epilogue-bearing steps' [3]
-__device__ unsigned long long g_lab_t[16];
-#define LAB_T(var) unsigned long long var = __builtin_readcyclecounter()
-#else
-#define LAB_T(var)
-#endif
-
 
 template <int EMU>
 struct Prep {
@@ -482,26 +474,12 @@ __device__ __forceinline__ void prep_frag(const RawFrag<RC>& r, Prep<EMU>& o, co
   }
 }
 
-// (ablation, tools/lab: what the kernel would run at if the COLUMN operand -- the weights in fwd / dgrad -- arrived
-// already cut into planes: its conversion is replaced by a free bit-cast; results are garbage)
 template <int EMU, bool RC>
 __device__ __forceinline__ void prep_frag_b(const RawFrag<RC>& r, Prep<EMU>& o, const float scale = 1.f) {
   if constexpr (EMU == 2) {
     prep_frag<EMU>(r, o, scale);
     return;
   }
-#ifdef MML_LAB_NO_CONVERT_B
-  if constexpr (EMU != 0) {
-    float x[8];
-    r.get(x);
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 t0 = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-    u4 t1 = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-#pragma unroll
-    for (int p = 0; p < EMU; ++p) o.p[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
-    return;
-  }
-#endif
   prep_frag<EMU>(r, o);
 }
 
@@ -520,22 +498,13 @@ __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const
     for (int lvl = EMU - 1; lvl >= 0; --lvl)  // smallest products first
 #pragma unroll
       for (int ia = 0; ia <= lvl; ++ia) {
-#ifdef MML_LAB_NO_MFMA
-        acc[(lvl + ia) & 15] += __builtin_bit_cast(float4, a.p[ia]).x * __builtin_bit_cast(float4, b.p[lvl - ia]).y;
-#else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[lvl - ia], a.p[ia], acc, 0, 0, 0);
-#endif
       }
   }
 }
 
 // EMU 2: one product block (three dependent MFMAs, ~32 cycles each) with the cut of ONE raw fragment dealt into their
 // shadows by hand: 8 + 8 + 4 VALU instructions.
-#ifdef MML_LAB_F16_AUTO  // (tools/lab A/B: leave the placement of the fp16 cuts to the compiler)
-constexpr bool kF16Manual = false;
-#else
-constexpr bool kF16Manual = true;
-#endif
 template <bool RC>
 __device__ __forceinline__ void mma_prep_f16(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
                                              const float scale, Prep<2>& o) {
@@ -582,9 +551,6 @@ __device__ __forceinline__ void pin_prep(Prep<EMU>& o) {
 // interleave hint for one block: NM MFMAs, each followed by NV VALU instructions of the neighbouring prepare
 template <int NM, int NV>
 __device__ __forceinline__ void interleave_hint() {
-#ifdef MML_LAB_NO_HINT
-  return;
-#endif
 #pragma unroll
   for (int t = 0; t < NM; ++t) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -779,7 +745,6 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     incB = BRC ? GK : GK * ldb;
   };
   auto issue = [&](const int stage) __attribute__((always_inline)) {
-#ifndef MML_LAB_NO_GLOBAL
     float* sa = lds + stage * STG;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -787,7 +752,6 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
 #pragma unroll
     for (int j = 0; j < NI; ++j)
       dma16(pb[j], sa + GA + (wave + 4 * j) * 256);
-#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j) pa[j] += incA;
 #pragma unroll
@@ -1146,9 +1110,6 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     }
   };
   auto epilogue = [&](const Cursor& c, const uint32_t so_epi) __attribute__((always_inline)) {
-#ifdef MML_LAB_NO_EPI
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
     if (EPI == EPI_SLAB) {
       epilogue_slab(c);
       return;
@@ -1256,7 +1217,6 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     const int sidx = i & (PSTAGES - 1);
     const uint32_t so_cur = (uint32_t)sidx * (STG * 4);
     const uint32_t so_next = (uint32_t)((sidx + 1) & (PSTAGES - 1)) * (STG * 4);
-    LAB_T(t0);
     // Stage i+1 (read below) was issued two steps ago: in steady state at most the loads of step i+2 are younger.
     // Off the hot path: for two steps after a counted epilogue its stores are younger too; once the prefetch cursor
     // has run out of work, drain.
@@ -1270,39 +1230,22 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
       epi_left = 0;
     }
     __builtin_amdgcn_s_barrier();
-    LAB_T(t1);
     if (pf.ok) {
       issue((sidx + 3) & (PSTAGES - 1));
-#ifdef MML_LAB_TIMES
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long tp0 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-      const bool sw = advance(pf);
-      if (sw) setup_ptrs(pf);
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long tp1 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-      if (blockIdx.x == 0 && tid == 0 && sw) { g_lab_t[11] += tp1 - tp0; g_lab_t[12] += 1; }
-#else
       if (advance(pf)) setup_ptrs(pf);
-#endif
       ++issued;
     }
     // next step's fragments -> the other register set (in flight during blocks 1-2)
     RawFrag<ARC> na0;
     RawFrag<BRC> nb0;
-    LAB_T(t2);
     read_b(so_next, I0{}, nb0);
     read_a(so_next, I0{}, na0);
     read_a(so_next, I1{}, RA1[Q]);
     if (NI == 2) read_b(so_next, I1{}, RB1[Q]);
     __builtin_amdgcn_sched_barrier(0);
     Prep<EMU> PA1, PB1;
-#ifdef MML_LAB_TIMES
-    unsigned long long t3 = 0;
-#endif
     if (NI == 2) {
-      if constexpr (EMU == 2 && kF16Manual) {
+      if constexpr (EMU == 2) {
         mma_prep_f16(acc[0][0], PA0[P], PB0[P], RB1[P], cur.sB, PB1);
         mma_prep_f16(acc[0][NI - 1], PA0[P], PB1, RA1[P], cur.sA, PA1);
       } else {
@@ -1321,10 +1264,6 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
       RA1[Q].landed();
       RB1[Q].landed();
       __builtin_amdgcn_sched_barrier(0);
-#ifdef MML_LAB_TIMES
-      t3 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       if (EPI == EPI_SLAB) {
         if (!BCOLS) {
           bs_next[0] = sum8(na0);
@@ -1334,7 +1273,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
           bs_next[1] = sum8(RB1[Q]);
         }
       }
-      if constexpr (EMU == 2 && kF16Manual) {
+      if constexpr (EMU == 2) {
         mma_prep_f16(acc[1][0], PA1, PB0[P], nb0, nsB, PB0[Q]);
         mma_prep_f16(acc[1][NI - 1], PA1, PB1, na0, nsA, PA0[Q]);
       } else {
@@ -1375,25 +1314,8 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
       interleave_hint<NMFMA, 2 * NVALU>();
       __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef MML_LAB_TIMES
-    const bool lab_last = tile_end;
-#endif
     if (__builtin_expect(tile_end, 0)) {
-#ifdef MML_LAB_TIMES
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long te0 = __builtin_readcyclecounter();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned long long te1 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-      if (blockIdx.x == 0 && tid == 0) { g_lab_t[7] += te1 - te0; }
-#endif
       epilogue(cur, so_cur);
-#ifdef MML_LAB_TIMES
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long te2 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-      if (blockIdx.x == 0 && tid == 0) { g_lab_t[8] += te2 - te1; }
-#endif
       // every load of the epilogue (bias, Y, accumulate target) was consumed before its store issued, so a counted
       // tile leaves exactly NSTORE (or more: bias partials) stores in flight and nothing else
       epi_left = cur.counted ? 2 : 0;
@@ -1401,42 +1323,14 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
       zero_acc();
       bs_cur[0] = 0.f;
       bs_cur[1] = 0.f;
-#ifdef MML_LAB_TIMES
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long te3 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-      if (blockIdx.x == 0 && tid == 0) { g_lab_t[9] += te3 - te2; }
-#endif
     }
-#ifdef MML_LAB_TIMES
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned long long ta0 = __builtin_readcyclecounter();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     if (EPI == EPI_SLAB) {  // the fragments read in this step belong to the next one
       bs_cur[0] += bs_next[0];
       bs_cur[1] += bs_next[1];
     }
     advance(cur);
     if (__builtin_expect(tile_end, 0)) bias_dma(cur);
-#ifdef MML_LAB_TIMES
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned long long ta1 = __builtin_readcyclecounter();
-    __builtin_amdgcn_sched_barrier(0);
-    if (blockIdx.x == 0 && tid == 0 && lab_last) { g_lab_t[10] += ta1 - ta0; }
-#endif
     ++i;
-#ifdef MML_LAB_TIMES
-    {
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long t4 = __builtin_readcyclecounter();
-      if (blockIdx.x == 0 && tid == 0) {
-        g_lab_t[0] += t1 - t0; g_lab_t[1] += t2 - t1; g_lab_t[2] += t3 - t2;
-        if (lab_last) { g_lab_t[5] += t4 - t3; g_lab_t[6] += 1; } else { g_lab_t[3] += t4 - t3; }
-        g_lab_t[4] += 1;
-      }
-    }
-#endif
   };
 
   while (true) {
@@ -1660,16 +1554,6 @@ extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
 
 extern "C" const char* mml_gemm_last_kernel(void) { return g_last_kernel; }
 
-#ifdef MML_LAB_TIMES
-extern "C" int mml_lab_times(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_t), sizeof(g_lab_t)) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lab_t), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
 
 extern "C" int mml_gemm_set_wgrad_lds_pad(int32_t bytes) {
   MML_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, "mml_gemm_set_wgrad_lds_pad: bytes outside [0, 65536]");

@@ -63,16 +63,6 @@ __device__ __forceinline__ void dma4(const float* g, float* lds_dst) {
 // packed as the 32x32x16 bf16 MFMA wants them.
 template <int PL>
 __device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&out)[PL]) {
-#ifdef MML_LAB_NO_CONVERT
-  {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 t0 = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-    u4 t1 = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-#pragma unroll
-    for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(bf16x8, (p & 1) ? t1 : t0);
-    return;
-  }
-#endif
   uint32_t w[PL][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

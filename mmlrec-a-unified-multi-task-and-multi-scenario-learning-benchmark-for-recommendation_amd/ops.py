@@ -272,67 +272,6 @@ def gemm_fwd(problems, amax=False):
     L.check(lib.mml_gemm_grouped_fwd(arr, len(problems), _stream()), "mml_gemm_grouped_fwd")
 
 
-class Planes:
-    """The three bf16 planes of an fp32 matrix in the panel layout of include/mmlrec.h (K3p): 16-bit storage
-    [ldp / 8, rows, 3, 8], ldp a multiple of 16, columns beyond the matrix zero.  `rows x cols` is the shape of the
-    matrix the planes stand for (the TRANSPOSE of the source when cut with transpose=True)."""
-
-    def __init__(self, rows, cols, device):
-        self.rows, self.cols = int(rows), int(cols)
-        self.ldp = (self.cols + 15) // 16 * 16
-        self.buf = torch.zeros(self.ldp // 8, self.rows, 3, 8, dtype=torch.int16, device=device)
-
-    def plane(self, p):
-        """Plane p as fp32 [rows, cols] (test helper)."""
-        f = (self.buf[:, :, p, :].to(torch.int32) << 16).view(torch.float32)
-        return f.permute(1, 0, 2).reshape(self.rows, self.ldp)[:, :self.cols]
-
-    def to_float(self):
-        """h + m + l as fp32 [rows, cols] (test helper: exact)."""
-        return (self.plane(0) + self.plane(1)) + self.plane(2)
-
-
-def make_cut_descs(items):
-    """items: (src fp32 2-D tensor, Planes, transpose)."""
-    arr = (L.PlanesCutDesc * len(items))()
-    for d, (src, pl, tr) in zip(arr, items):
-        _need_gpu(src, pl.buf)
-        _f32_2d(src, "planes_cut src")
-        rows, cols = src.shape
-        if (pl.rows, pl.cols) != ((cols, rows) if tr else (rows, cols)):
-            raise L.MMLError(f"planes_cut: planes are {pl.rows}x{pl.cols}, source {rows}x{cols}, transpose={bool(tr)}")
-        d.src, d.planes, d.ld, d.ldp = src.data_ptr(), pl.buf.data_ptr(), _ld(src), pl.ldp
-        d.rows, d.cols, d.transpose = rows, cols, 1 if tr else 0
-    return arr
-
-
-def planes_cut(items):
-    arr = make_cut_descs(items)
-    L.check(L.load().mml_planes_cut(arr, len(items), _stream()), "mml_planes_cut")
-
-
-def make_planes_fwd_descs(problems):
-    """problems: dicts with A (Planes of [M, K]), W (Planes of [N, K]), bias or None, C [M, N], act, mask."""
-    arr = (L.GemmPlanesFwdDesc * len(problems))()
-    for d, p in zip(arr, problems):
-        A, W, Cc = p["A"], p["W"], p["C"]
-        if A.cols != W.cols or Cc.shape != (A.rows, W.rows):
-            raise L.MMLError(f"planes fwd: A {A.rows}x{A.cols}, W {W.rows}x{W.cols}, C {tuple(Cc.shape)}")
-        d.A, d.W, d.C, d.bias = A.buf.data_ptr(), W.buf.data_ptr(), Cc.data_ptr(), L.ptr(p.get("bias"))
-        d.ldpa, d.ldpw, d.ldc = A.ldp, W.ldp, _ld(Cc)
-        d.M, d.N, d.K = A.rows, W.rows, A.cols
-        d.act = int(p.get("act", L.ACT_NONE))
-        m = p.get("mask")
-        d.relu_mask = L.ptr(m)
-        d.ldmask = _ld(m) if m is not None else 0
-    return arr
-
-
-def gemm_planes_fwd(problems):
-    arr = make_planes_fwd_descs(problems)
-    L.check(L.load().mml_gemm_planes_fwd(arr, len(problems), _stream()), "mml_gemm_planes_fwd")
-
-
 def make_dgrad_descs(problems):
     """problems: dicts with dA [M,K], Y (or None), act, accumulate, srcs = [(dC [M,N], W, w_kn), ...]."""
     arr = (L.GemmDgradDesc * len(problems))()

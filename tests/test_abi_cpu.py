@@ -35,7 +35,6 @@ def test_struct_sizes_match_header():
              "mml_gate_group": _lib.GateGroup, "mml_head_desc": _lib.HeadDesc, "mml_head_group": _lib.HeadGroup,
              "mml_opt_tensor": _lib.OptTensor, "mml_opt_hyper": _lib.OptHyper,
              "mml_copy2d_desc": _lib.Copy2dDesc, "mml_sumprod_desc": _lib.SumProdDesc, "mml_attn2_desc": _lib.Attn2Desc,
-             "mml_planes_cut_desc": _lib.PlanesCutDesc, "mml_gemm_planes_fwd_desc": _lib.GemmPlanesFwdDesc,
              "mml_amax_desc": _lib.AmaxDesc}
     src = '#include <stdio.h>\n#include "mmlrec.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"

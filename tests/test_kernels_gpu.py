@@ -132,80 +132,6 @@ def test_gemm_fwd(ops, M, shapes):
         assert rel(p["C"].cpu().numpy(), r) < 2e-5
 
 
-@pytest.mark.parametrize("rows,cols,ld", [(257, 240, 240), (64, 33, 36), (5, 16, 16), (1000, 303, 304)])
-def test_planes_cut_is_exact(ops, rows, cols, ld):
-    """x == h + m + l bit for bit, each plane has 8 significant bits, pad columns are zero; transposed cut likewise."""
-    rng = np.random.default_rng(3)
-    src = (rng.standard_normal((rows, ld)) * np.exp(rng.uniform(-20, 20, (rows, ld)))).astype(np.float32)
-    src[0, :3] = [0.0, -0.0, np.float32(1e-30)]
-    x = T(src)[:, :cols]
-    pl, plt = ops.Planes(rows, cols, dev()), ops.Planes(cols, rows, dev())
-    pl.buf.fill_(0x7f7f)
-    plt.buf.fill_(0x7f7f)  # stale contents must be overwritten, pads included
-    ops.planes_cut([(x, pl, False), (x, plt, True)])
-    assert np.array_equal(pl.to_float().cpu().numpy(), src[:, :cols])
-    assert np.array_equal(plt.to_float().cpu().numpy(), src[:, :cols].T)
-    for q, n in ((pl, cols), (plt, rows)):  # pad columns are zero in every plane
-        pads = q.buf.permute(1, 2, 0, 3).reshape(q.rows, 3, q.ldp)[:, :, n:]
-        assert pads.numel() == 0 or int(pads.abs().max().item()) == 0
-    h = pl.plane(0).cpu().numpy()
-    assert np.array_equal(h.view(np.uint32), src[:, :cols].view(np.uint32) & 0xffff0000)  # top plane = truncation
-
-
-@pytest.mark.parametrize("M,shapes", [
-    (1000, [(256, 240), (64, 240), (256, 240)]),   # AE-30 layer-1 experts + gates, ragged M, half-filled column tile
-    (512, [(128, 256)] * 4),                       # expert layer 2
-    (300, [(132, 303), (4, 303)]),                 # reduction length padded to 304, ragged N
-    (64, [(64, 16)]),                              # a single k-step
-    (8192, [(256, 240)] * 4 + [(64, 240)] * 2),    # persistent workgroups take several tiles each
-])
-def test_gemm_planes_fwd(ops, M, shapes):
-    """Forward GEMM on pre-cut operands: against float64, against the in-register-cut kernel (same planes and products:
-    agreement to accumulation-order noise), and the ReLU sign mask."""
-    from mmlrec_amd import _lib as L
-    rng = np.random.default_rng(4)
-    probs, olds, refs = [], [], []
-    A0 = {}
-    for i, (N, K) in enumerate(shapes):
-        if K not in A0:
-            a = T(rng.standard_normal((M, K)).astype(np.float32))
-            pa = ops.Planes(M, K, dev())
-            ops.planes_cut([(a, pa, False)])
-            A0[K] = (a, pa)
-        a, pa = A0[K]
-        W = T((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
-        b = T(rng.standard_normal(N).astype(np.float32)) if i % 3 != 2 else None
-        pw = ops.Planes(N, K, dev())
-        ops.planes_cut([(W, pw, False)])
-        act = [L.ACT_RELU, L.ACT_NONE, L.ACT_SIGMOID, L.ACT_SIGMOID2][i % 4]
-        mask = torch.zeros(M, (N + 31) // 32, dtype=torch.int32, device=dev()) if act == L.ACT_RELU else None
-        C1, C2 = torch.full((M, N), 7.0, device=dev()), torch.empty(M, N, device=dev())
-        probs.append(dict(A=pa, W=pw, bias=b, C=C1, act=act, mask=mask))
-        olds.append(dict(A=a, W=W, bias=b, C=C2, act=act))
-        z = a.cpu().numpy().astype(np.float64) @ W.cpu().numpy().T.astype(np.float64)
-        if b is not None:
-            z = z + b.cpu().numpy()
-        refs.append({L.ACT_RELU: np.maximum(z, 0), L.ACT_NONE: z, L.ACT_SIGMOID: 1 / (1 + np.exp(-z)),
-                     L.ACT_SIGMOID2: 2 / (1 + np.exp(-z))}[act])
-    ops.gemm_planes_fwd(probs)
-    ops.gemm_fwd(olds)
-    for p, o, r in zip(probs, olds, refs):
-        got = p["C"].cpu().numpy()
-        assert rel(got, r) < 2e-6
-        assert rel(got, o["C"].cpu().numpy()) < 2e-6
-        if p["mask"] is not None:
-            N = got.shape[1]
-            bits = np.unpackbits(p["mask"].cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :N]
-            assert np.array_equal(bits.astype(bool), got > 0)
-
-
-def test_gemm_planes_fwd_rejects_unaligned(ops):
-    from mmlrec_amd import _lib as L
-    a, w = ops.Planes(64, 32, dev()), ops.Planes(6, 32, dev())  # N = 6: not a multiple of 4
-    with pytest.raises(L.MMLError):
-        ops.gemm_planes_fwd([dict(A=a, W=w, bias=None, C=torch.empty(64, 6, device=dev()), act=0)])
-
-
 def test_gemm_fwd_kn_layout_and_strided_output(ops):
     from mmlrec_amd import _lib as L
     rng = np.random.default_rng(3)
