@@ -112,6 +112,50 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, c
   if (bad && a.status) atomicOr(a.status, bad);
 }
 
+// north_star's "LDS-staged index dedup", measured rather than argued: the tables with at most kLdsRows rows
+// (AE-30: 6 x 100 + 2 rows = 19 KiB at E = 8) are copied into LDS once per PERSISTENT workgroup and their lookups served
+// from there; the other fields read HBM / L2 as in gather_vec4_kernel.  Opt-in (MMLREC_GATHER_LDS=1); not the default:
+// see DESIGN 10.14 for the numbers (the one-item-per-thread kernel above wins at every batch size).
+constexpr int kLdsRows = 128;
+constexpr int kLdsFloats = 12 * 1024;  // 48 KiB
+struct SmallTabs {
+  int32_t off[MML_MAX_FIELDS];  // float offset of field f's copy in LDS, or -1
+  int32_t total;                // floats
+};
+__global__ __launch_bounds__(256) void gather_lds_kernel(const FieldTable ft, const GatherArgs a, const SmallTabs st) {
+  __shared__ __attribute__((aligned(16))) float small[kLdsFloats];
+  for (int f = 0; f < a.F; ++f) {
+    if (st.off[f] < 0) continue;
+    const int n4 = (int)(ft.vocab[f] * a.E) >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256)
+      reinterpret_cast<float4*>(small + st.off[f])[i] = reinterpret_cast<const float4*>(ft.tab[f])[i];
+  }
+  __syncthreads();
+  const int e4 = a.E >> 2;
+  const int nvec = a.F * e4;
+  const int per_sample = nvec + a.Nd;
+  const int64_t total = a.B * per_sample;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < total; base += stride) {
+    const int64_t b = base / per_sample;
+    const int c = (int)(base - b * per_sample);
+    if (c < nvec) {
+      const int f = c / e4;
+      const int part = c - f * e4;
+      const int64_t row = load_index(a, b, f, ft, bad);
+      float4 v;
+      if (st.off[f] >= 0) v = *reinterpret_cast<const float4*>(small + st.off[f] + row * a.E + part * 4);
+      else v = *reinterpret_cast<const float4*>(ft.tab[f] + row * a.E + part * 4);
+      *reinterpret_cast<float4*>(a.out + b * a.ldo + (int64_t)c * 4) = v;
+    } else {
+      const int j = c - nvec;
+      a.out[b * a.ldo + (int64_t)a.F * a.E + j] = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+    }
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
 // Generic path (E not a multiple of 4, or misaligned buffers): one thread per output float.
 __global__ __launch_bounds__(256) void gather_scalar_kernel(const FieldTable ft, const GatherArgs a) {
   const int per_sample = a.F * a.E + a.Nd;
@@ -153,6 +197,26 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
     if (items < 0) {
       const char* e = getenv("MMLREC_GATHER_ITEMS");
       items = (e && atoi(e) == 4) ? 4 : 1;
+    }
+    static int use_lds = -1;
+    if (use_lds < 0) {
+      const char* e = getenv("MMLREC_GATHER_LDS");
+      use_lds = e ? atoi(e) : 0;  // n > 0: the persistent LDS-staged variant with n workgroups per CU (measurement knob)
+    }
+    if (use_lds > 0 && !a.marks) {
+      SmallTabs st{};
+      int off = 0;
+      for (int f = 0; f < a.F; ++f) {
+        st.off[f] = -1;
+        const int64_t fl = ft.vocab[f] * a.E;
+        if (ft.vocab[f] <= kLdsRows && off + fl <= kLdsFloats) {
+          st.off[f] = off;
+          off += (int)((fl + 3) / 4 * 4);
+        }
+      }
+      st.total = off;
+      MML_LAUNCH(gather_lds_kernel, dim3(256u * (unsigned)use_lds), dim3(threads), 0, stream, ft, a, st);
+      return check_launch("mml_gather_fwd(lds)");
     }
     const int64_t per_sample = (int64_t)a.F * (a.E / 4) + a.Nd;
     const int64_t total = cdiv(a.B, (int64_t)items) * per_sample;
