@@ -520,12 +520,21 @@ class BaseModel(nn.Module):
                 perm = perm[rank::world].contiguous()
             perm_d = perm.to(dev)
             loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+            # row-sharded tables: the next batch is staged and ROUTED (distinct rows, owners, count exchange, host read of
+            # the split sizes) on a side stream while the current step runs (trainer.TrainStep.prefetch)
+            ahead = par is not None and par.mode == "row_sharded"
             for s in range(steps_per_epoch):
                 idx = perm_d[s * batch_size:(s + 1) * batch_size]
                 step = self.train_step_runner(idx.numel())
-                torch.index_select(Xd, 0, idx, out=step.plan.X)
-                torch.index_select(yd, 0, idx, out=step.plan.y)
+                if not step._has_next:
+                    torch.index_select(Xd, 0, idx, out=step.plan.X)
+                    torch.index_select(yd, 0, idx, out=step.plan.y)
                 step.run()
+                if ahead and s + 1 < steps_per_epoch:
+                    nxt = perm_d[(s + 1) * batch_size:(s + 2) * batch_size]
+                    if nxt.numel() == idx.numel():  # (a ragged last batch runs on another plan: it routes itself)
+                        step.prefetch(fill=lambda bx, by, nxt=nxt: (torch.index_select(Xd, 0, nxt, out=bx),
+                                                                   torch.index_select(yd, 0, nxt, out=by)))
                 pred_epoch[s * batch_size:s * batch_size + idx.numel()] = step.plan.prob
                 loss_dev += step.plan.loss
             for st in self._caches["steps"].values():

@@ -193,12 +193,14 @@ class TrainStep:
         self._nX = self._ny = None  # staging buffers of a prefetched batch
         self._has_next = False
 
-    def prefetch(self, X, y, fence=None):
+    def prefetch(self, X=None, y=None, fence=None, fill=None):
         """Hand over the NEXT step's batch while this one is still in flight: it is copied into staging buffers (the
         next run() moves it into plan.X / plan.y itself -- do not copy it there as well) and, on row-sharded tables, its
         index-only routing work (distinct rows, owners, per-owner counts incl. their exchange and the host read of the
         split sizes) starts at once on a side stream.  Collective on the multi-GPU paths: every rank calls it at the
-        same point.  Optional: a step whose batch was simply copied into plan.X / plan.y routes it itself."""
+        same point.  Optional: a step whose batch was simply copied into plan.X / plan.y routes it itself.
+        fill(X_buf, y_buf): instead of X / y, a callable that writes the staging buffers (it runs on the side stream;
+        whatever it reads must be complete and must stay alive until the next run())."""
         p = self.plan
         if self._nX is None:
             self._nX, self._ny = torch.empty_like(p.X), torch.empty_like(p.y)
@@ -214,8 +216,11 @@ class TrainStep:
             side.wait_event(fence)
         side.wait_event(self._ev_consumed)
         with torch.cuda.stream(side):
-            self._nX.copy_(X, non_blocking=True)
-            self._ny.copy_(y, non_blocking=True)
+            if fill is not None:   # the caller writes the staging buffers itself (e.g. index_select from a resident set)
+                fill(self._nX, self._ny)
+            else:
+                self._nX.copy_(X, non_blocking=True)
+                self._ny.copy_(y, non_blocking=True)
             if hasattr(op, "prefetch_route"):
                 op.prefetch_route(self._nX)
             self._ev_staged.record(side)
