@@ -1,0 +1,370 @@
+/* CPU restatement of the hot-path subset of include/mmlrec.h under the SAME symbols and signatures -- TEST
+ * INFRASTRUCTURE, NOT PRODUCT CODE (same status as mmlrec_oracle.py: only tests may load the library built from this
+ * file; the shipped package never does and fails loudly without the HIP library).
+ *
+ * SURVEY 8(b), last sentence: "The same symbols are provided by the CPU restatement library so tests run in both
+ * containers."  Plain C loops over HOST memory (the mml_stream_t argument is ignored), float64 accumulation inside
+ * the dot products, no tiling, no atomics; every function restates the reference lines its HIP counterpart names:
+ *   mml_gather_fwd            BaseModel.input_from_feature_columns + combined_dnn_input (model/basemodel.py:461-487, utils.py:434-446)
+ *   mml_scatter_bwd           aten::embedding_dense_backward, sparse=False (model/basemodel.py:122), batch order
+ *   mml_gemm_grouped_*        DNN.forward Linear + activation and its autograd pair (model/utils.py:146-161)
+ *   mml_gate_mix_fwd / _bwd   gate softmax + expert mix (model/mmoe.py:80-88, model/ple.py:127-152)
+ *   mml_head_fwd / mml_head_bce_fwd_bwd   final layer + PredictionLayer + summed BCE (model/utils.py:242-248, basemodel.py:294-296)
+ *   mml_opt_step_dense        torch.optim.{SGD,Adam,Adagrad,RMSprop}.step over dense tensors (model/basemodel.py:313, :569-584)
+ *   mml_amax_batch / _reset   operand magnitudes (a contract of ours, see include/mmlrec.h)
+ * tests/test_cabi_cpu.py drives one full MMoE training step of a reference-made golden fixture through these entry
+ * points (the call sequence of mmlrec_amd/engine.py) in the CPU container.
+ * Build: oracle/build_fast.py (gcc -O2 -shared -fPIC), output oracle/_build/libmmlrec_cpu.so. */
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mmlrec.h"
+
+static __thread char g_err[256] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return MML_ERR_ARG;
+}
+#define REQUIRE(c, ...) do { if (!(c)) return fail(__VA_ARGS__); } while (0)
+
+const char* mml_last_error(void) { return g_err; }
+int mml_version(void) { return 100; }
+
+static float act_fwd(float v, int act) {
+  if (act == MML_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == MML_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (act == MML_ACT_SIGMOID2) return 2.f / (1.f + expf(-v));
+  return v;
+}
+static float act_bwd_from_output(float y, int act) {
+  if (act == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MML_ACT_SIGMOID2) return y * (1.f - 0.5f * y);
+  return 1.f;
+}
+static void amax_raise(uint32_t* slot, float v) {
+  union { float f; uint32_t u; } c;
+  c.f = fabsf(v);
+  if (slot && c.u > slot[0] && c.u <= 0x7f800000u) slot[0] = c.u;
+}
+
+/* ------------------------------------------------------------------------------------------------ K1 / K2 */
+int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                   const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, float* out, int64_t ldo,
+                   int32_t* status, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(F >= 0 && F <= MML_MAX_FIELDS && E > 0 && B >= 0 && Nd >= 0, "mml_gather_fwd: bad sizes");
+  REQUIRE(B == 0 || (X && out && tables && vocab), "mml_gather_fwd: null argument");
+  REQUIRE(ldo >= (int64_t)F * E + Nd, "mml_gather_fwd: ldo too small");
+  for (int64_t b = 0; b < B; ++b) {
+    for (int f = 0; f < F; ++f) {
+      int64_t i = (int64_t)X[b * ldX + (col ? col[f] : f)]; /* .long(): truncation (model/basemodel.py:476) */
+      if (i < 0) { if (status) *status |= 1; i = 0; }
+      if (i >= vocab[f]) { if (status) *status |= 2; i = vocab[f] - 1; }
+      memcpy(out + b * ldo + (int64_t)f * E, tables[f] + i * E, sizeof(float) * E);
+    }
+    for (int j = 0; j < Nd; ++j) out[b * ldo + (int64_t)F * E + j] = X[b * ldX + dense_col0 + j];
+  }
+  return MML_OK;
+}
+
+int mml_scatter_bwd(float* const* grad_tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                    const float* X, int64_t ldX, int64_t B, const float* dOut, int64_t ldo, uint32_t* const* seen,
+                    const int64_t* rowbase, int32_t* touched, int32_t* touched_count, int32_t touched_cap,
+                    uint8_t* row_marks, int32_t* status, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(F >= 0 && F <= MML_MAX_FIELDS && E > 0 && B >= 0, "mml_scatter_bwd: bad sizes");
+  REQUIRE(B == 0 || (X && dOut && grad_tables && vocab), "mml_scatter_bwd: null argument");
+  REQUIRE(!touched || (seen && rowbase && touched_count && touched_cap > 0), "mml_scatter_bwd: touched list malformed");
+  if (touched) *touched_count = 0;
+  int64_t markbase = 0;
+  for (int f = 0; f < F; ++f) {
+    for (int64_t b = 0; b < B; ++b) {
+      const int64_t i = (int64_t)X[b * ldX + (col ? col[f] : f)];
+      if (i < 0) { if (status) *status |= 1; continue; }
+      if (i >= vocab[f]) { if (status) *status |= 2; continue; }
+      for (int e = 0; e < E; ++e) grad_tables[f][i * E + e] += dOut[b * ldo + (int64_t)f * E + e];
+      if (row_marks && !touched) row_marks[markbase + i] = 1;
+      if (touched && !((seen[f][i >> 5] >> (i & 31)) & 1u)) {
+        seen[f][i >> 5] |= 1u << (i & 31);
+        if (*touched_count < touched_cap) touched[*touched_count] = (int32_t)(rowbase[f] + i);
+        ++*touched_count;
+      }
+    }
+    markbase += (vocab[f] + 31) / 32 * 32;
+  }
+  return MML_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ operand magnitudes */
+int mml_amax_reset(uint32_t* slots, int64_t n_slots, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n_slots >= 0 && (n_slots == 0 || slots), "mml_amax_reset: bad arguments");
+  memset(slots, 0, (size_t)n_slots * MML_AMAX_WORDS * sizeof(uint32_t));
+  return MML_OK;
+}
+int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_amax_batch: bad descriptor array");
+  for (int i = 0; i < n; ++i) {
+    REQUIRE(d[i].slot && d[i].ld >= d[i].cols, "mml_amax_batch: tensor %d malformed", i);
+    for (int64_t r = 0; r < d[i].rows; ++r)
+      for (int c = 0; c < d[i].cols; ++c) amax_raise(d[i].slot, d[i].x[r * d[i].ld + c]);
+  }
+  return MML_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ K3 */
+int mml_gemm_set_mode(int32_t mode) { (void)mode; return MML_OK; }
+int mml_gemm_get_mode(void) { return 0; }
+const char* mml_gemm_last_kernel(void) { return "cpu"; }
+
+int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");
+  for (int p = 0; p < n; ++p) {
+    const mml_gemm_fwd_desc* q = d + p;
+    REQUIRE(q->A && q->W && q->C && q->M >= 0 && q->N > 0 && q->K > 0, "mml_gemm_grouped_fwd: problem %d malformed", p);
+    for (int64_t m = 0; m < q->M; ++m)
+      for (int nn = 0; nn < q->N; ++nn) {
+        double s = q->bias ? q->bias[nn] : 0.0;
+        for (int k = 0; k < q->K; ++k)
+          s += (double)q->A[m * q->lda + k] * (q->w_kn ? q->W[(int64_t)k * q->ldw + nn] : q->W[(int64_t)nn * q->ldw + k]);
+        const float v = act_fwd((float)s, q->act);
+        q->C[m * q->ldc + nn] = v;
+        amax_raise(q->amax_out, v);
+        if (q->relu_mask && q->act == MML_ACT_RELU) {
+          uint32_t* w = q->relu_mask + m * q->ldmask + (nn >> 5);
+          if (v > 0.f) *w |= 1u << (nn & 31); else *w &= ~(1u << (nn & 31));
+        }
+      }
+  }
+  return MML_OK;
+}
+
+int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_dgrad: bad descriptor array");
+  for (int p = 0; p < n; ++p) {
+    const mml_gemm_dgrad_desc* q = d + p;
+    REQUIRE(q->dA && q->n_src >= 1 && q->n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", p);
+    REQUIRE(q->act == MML_ACT_NONE || q->Y || q->relu_mask, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", p);
+    for (int64_t m = 0; m < q->M; ++m)
+      for (int k = 0; k < q->K; ++k) {
+        double s = 0.0;
+        for (int sidx = 0; sidx < q->n_src; ++sidx)
+          for (int nn = 0; nn < q->N[sidx]; ++nn)
+            s += (double)q->dC[sidx][m * q->lddc[sidx] + nn] *
+                 (q->w_kn[sidx] ? q->W[sidx][(int64_t)k * q->ldw[sidx] + nn] : q->W[sidx][(int64_t)nn * q->ldw[sidx] + k]);
+        float v = (float)s;
+        if (q->relu_mask) {
+          if (!((q->relu_mask[m * q->ldmask + (k >> 5)] >> (k & 31)) & 1u)) v = 0.f;
+        } else if (q->act != MML_ACT_NONE) {
+          v *= act_bwd_from_output(q->Y[m * q->ldy + k], q->act);
+        }
+        if (q->accumulate) v += q->dA[m * q->ldda + k];
+        q->dA[m * q->ldda + k] = v;
+        amax_raise(q->amax_out, v);
+      }
+  }
+  return MML_OK;
+}
+
+int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_desc* d, int32_t n) { (void)d; (void)n; return 256; }
+int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes,
+                                 int32_t phase, mml_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_wgrad: bad descriptor array");
+  REQUIRE(phase >= 0 && phase <= 2, "mml_gemm_grouped_wgrad_phase: bad phase");
+  if (phase == 2) return MML_OK; /* (the partial-product phase already wrote the results: there are no slabs here) */
+  for (int p = 0; p < n; ++p) {
+    const mml_gemm_wgrad_desc* q = d + p;
+    REQUIRE(q->dC && q->A && q->dW, "mml_gemm_grouped_wgrad: null pointer in problem %d", p);
+    for (int nn = 0; nn < q->N; ++nn) {
+      for (int k = 0; k < q->K; ++k) {
+        double s = 0.0;
+        for (int64_t m = 0; m < q->M; ++m) s += (double)q->dC[m * q->lddc + nn] * q->A[m * q->lda + k];
+        float* dst = q->w_kn ? q->dW + (int64_t)k * q->lddw + nn : q->dW + (int64_t)nn * q->lddw + k;
+        *dst = (q->accumulate ? *dst : 0.f) + (float)s;
+      }
+      if (q->dbias) {
+        double s = 0.0;
+        for (int64_t m = 0; m < q->M; ++m) s += q->dC[m * q->lddc + nn];
+        q->dbias[nn] = (q->accumulate ? q->dbias[nn] : 0.f) + (float)s;
+      }
+    }
+  }
+  return MML_OK;
+}
+int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes,
+                           mml_stream_t stream) {
+  return mml_gemm_grouped_wgrad_phase(d, n, workspace, workspace_bytes, 0, stream);
+}
+
+/* ------------------------------------------------------------------------------------------------ K4 */
+int mml_gate_mix_fwd(const mml_gate_group* g, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(g && g->n_experts >= 1 && g->n_gates >= 1 && g->H > 0, "mml_gate_mix_fwd: bad group");
+  for (int64_t b = 0; b < g->B; ++b)
+    for (int gi = 0; gi < g->n_gates; ++gi) {
+      const mml_gate_desc* d = &g->gate[gi];
+      double logit[MML_MAX_EXPERTS], mx = -1e300, den = 0.0;
+      for (int e = 0; e < d->ne; ++e) {
+        double s = 0.0;
+        for (int k = 0; k < d->Gd; ++k) s += (double)d->G[b * d->ldg + k] * d->Wg[(int64_t)e * d->Gd + k];
+        logit[e] = (float)s;
+        if (logit[e] > mx) mx = logit[e];
+      }
+      for (int e = 0; e < d->ne; ++e) { logit[e] = expf((float)(logit[e] - mx)); den += logit[e]; }
+      for (int e = 0; e < d->ne; ++e) d->P[b * d->ldp + e] = (float)(logit[e] / den);
+      for (int h = 0; h < g->H; ++h) {
+        double s = 0.0;
+        for (int e = 0; e < d->ne; ++e) s += (double)d->P[b * d->ldp + e] * g->E[d->expert[e]][b * g->lde[d->expert[e]] + h];
+        d->mix[b * d->ldmix + h] = (float)s;
+        amax_raise(g->amax_mix, (float)s);
+      }
+    }
+  return MML_OK;
+}
+
+int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* g) { (void)g; return 256; }
+int mml_gate_mix_bwd(const mml_gate_group* g, void* workspace, int64_t workspace_bytes, mml_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  REQUIRE(g && g->n_experts >= 1 && g->n_gates >= 1 && g->H > 0, "mml_gate_mix_bwd: bad group");
+  for (int gi = 0; gi < g->n_gates; ++gi)
+    if (g->gate[gi].active)
+      memset(g->gate[gi].dWg, 0, sizeof(float) * (size_t)g->gate[gi].ne * g->gate[gi].Gd);
+  for (int64_t b = 0; b < g->B; ++b) {
+    for (int x = 0; x < g->n_experts; ++x)
+      for (int h = 0; h < g->H; ++h) g->dE[x][b * g->ldde[x] + h] = 0.f;
+    for (int gi = 0; gi < g->n_gates; ++gi) {
+      const mml_gate_desc* d = &g->gate[gi];
+      if (!d->active) continue;
+      double dp[MML_MAX_EXPERTS], dot = 0.0;
+      for (int e = 0; e < d->ne; ++e) {
+        const int x = d->expert[e];
+        double s = 0.0;
+        for (int h = 0; h < g->H; ++h) s += (double)d->dmix[b * d->lddmix + h] * g->E[x][b * g->lde[x] + h];
+        dp[e] = s;
+        dot += d->P[b * d->ldp + e] * s;
+      }
+      for (int e = 0; e < d->ne; ++e) dp[e] = d->P[b * d->ldp + e] * (dp[e] - dot); /* dlogit */
+      for (int k = 0; k < d->Gd; ++k) {
+        const float gk = d->G[b * d->ldg + k];
+        double dg = 0.0;
+        for (int e = 0; e < d->ne; ++e) {
+          dg += dp[e] * d->Wg[(int64_t)e * d->Gd + k];
+          d->dWg[(int64_t)e * d->Gd + k] += (float)(dp[e] * gk);
+        }
+        if (d->g_relu && !(gk > 0.f)) dg = 0.0;
+        d->dG[b * d->lddg + k] = (float)dg;
+        amax_raise(g->amax_dG, (float)dg);
+      }
+      for (int e = 0; e < d->ne; ++e) {
+        const int x = d->expert[e];
+        for (int h = 0; h < g->H; ++h) g->dE[x][b * g->ldde[x] + h] += d->P[b * d->ldp + e] * d->dmix[b * d->lddmix + h];
+      }
+    }
+    for (int x = 0; x < g->n_experts; ++x)
+      for (int h = 0; h < g->H; ++h) {
+        float* v = &g->dE[x][b * g->ldde[x] + h];
+        if (g->e_relu && !(g->E[x][b * g->lde[x] + h] > 0.f)) *v = 0.f;
+        amax_raise(g->amax_dE, *v);
+      }
+  }
+  return MML_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ K5 */
+static int heads(const mml_head_group* g, int train) {
+  REQUIRE(g && g->n_heads >= 1 && g->n_heads <= MML_MAX_HEADS && g->prob, "mml_head_*: bad group");
+  double loss = 0.0;
+  if (train)
+    for (int t = 0; t < g->n_heads; ++t) {
+      const mml_head_desc* d = &g->head[t];
+      if (d->dw) memset(d->dw, 0, sizeof(float) * (size_t)d->H);
+      if (d->dbias) d->dbias[0] = 0.f;
+    }
+  for (int64_t b = 0; b < g->B; ++b)
+    for (int t = 0; t < g->n_heads; ++t) {
+      const mml_head_desc* d = &g->head[t];
+      double s = d->bias[0];
+      for (int i = 0; i < d->n_bias2; ++i) s += d->bias2[i];
+      for (int h = 0; h < d->H; ++h) s += (double)d->Hin[b * d->ldh + h] * d->w[h] * (d->w2 ? d->w2[h] : 1.f);
+      const float p = 1.f / (1.f + expf(-(float)s));
+      const float m = (d->mask_col >= 0 && g->mask) ? g->mask[b * g->ldmask + d->mask_col] : 1.f;
+      const float pm = p * m;
+      g->prob[b * g->ldprob + t] = pm;
+      if (!train) continue;
+      float dpm;
+      if (g->y) {
+        const float y = g->y[b * g->ldy + t];
+        const float lp = fmaxf(logf(pm), -100.f), l1p = fmaxf(log1pf(-pm), -100.f); /* F.binary_cross_entropy clamps */
+        loss += -(y * lp + (1.f - y) * l1p);
+        dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
+      } else {
+        dpm = g->dprob[b * g->lddprob + t];
+      }
+      const float dlogit = dpm * m * p * (1.f - p);
+      if (d->dbias) d->dbias[0] += dlogit;
+      for (int h = 0; h < d->H; ++h) {
+        const float hv = d->Hin[b * d->ldh + h];
+        if (d->dw) d->dw[h] += dlogit * hv;
+        float dh = dlogit * d->w[h] * (d->w2 ? d->w2[h] : 1.f);
+        if (d->h_relu && !(hv > 0.f)) dh = 0.f;
+        if (d->dH) { d->dH[b * d->lddh + h] = dh; amax_raise(g->amax_dH, dh); }
+      }
+    }
+  if (train && g->loss) g->loss[0] = (float)loss;
+  return MML_OK;
+}
+int64_t mml_head_workspace_bytes(const mml_head_group* g) { (void)g; return 256; }
+int mml_head_fwd(const mml_head_group* g, mml_stream_t stream) { (void)stream; return heads(g, 0); }
+int mml_head_bce_fwd_bwd(const mml_head_group* g, void* workspace, int64_t workspace_bytes, mml_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  return heads(g, 1);
+}
+
+/* ------------------------------------------------------------------------------------------------ K8 */
+int mml_opt_step_dense(const mml_opt_tensor* t, int32_t n, const mml_opt_hyper* h, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(h && h->kind >= MML_OPT_SGD && h->kind <= MML_OPT_RMSPROP, "mml_opt_step_dense: bad hyper");
+  REQUIRE(n >= 0 && (n == 0 || t), "mml_opt_step_dense: bad tensor array");
+  const int step = h->step_dev ? ((const int32_t*)h->step_dev)[0] : h->step;
+  const double bc1 = 1.0 - pow(h->beta1, step), bc2 = 1.0 - pow(h->beta2, step);
+  for (int i = 0; i < n; ++i) {
+    REQUIRE(t[i].param && t[i].grad, "mml_opt_step_dense: tensor %d malformed", i);
+    for (int64_t j = 0; j < t[i].n; ++j) {
+      float p = t[i].param[j], gr = t[i].grad[j];
+      if (t[i].l2 != 0.f) gr += 2.f * t[i].l2 * p;
+      if (t[i].l1 != 0.f) gr += t[i].l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));
+      if (h->kind == MML_OPT_SGD) {
+        p -= h->lr * gr;
+      } else if (h->kind == MML_OPT_ADAM) { /* torch.optim.Adam: betas (0.9, 0.999), eps 1e-8 */
+        float* m = t[i].state1 + j; float* v = t[i].state2 + j;
+        *m = h->beta1 * *m + (1.f - h->beta1) * gr;
+        *v = h->beta2 * *v + (1.f - h->beta2) * gr * gr;
+        const float denom = sqrtf(*v) / (float)sqrt(bc2) + h->eps;
+        p -= (float)(h->lr / bc1) * (*m / denom);
+      } else if (h->kind == MML_OPT_ADAGRAD) {
+        float* s = t[i].state1 + j;
+        *s += gr * gr;
+        p -= h->lr * gr / (sqrtf(*s) + h->eps);
+      } else { /* RMSprop: alpha 0.99 */
+        float* s = t[i].state1 + j;
+        *s = h->alpha * *s + (1.f - h->alpha) * gr * gr;
+        p -= h->lr * gr / (sqrtf(*s) + h->eps);
+      }
+      t[i].param[j] = p;
+      if (h->zero_grad || t[i].zero_grads) ((float*)t[i].grad)[j] = 0.f;
+    }
+    if (t[i].grad_marks && t[i].row_elems > 0) memset(t[i].grad_marks, 0, (size_t)(t[i].n / t[i].row_elems));
+  }
+  return MML_OK;
+}

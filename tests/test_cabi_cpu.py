@@ -1,0 +1,211 @@
+"""The C ABI of include/mmlrec.h, exercised in the CPU container ("the same symbols are provided by the CPU
+restatement library so tests run in both containers").
+
+oracle/_build/libmmlrec_cpu.so (oracle/cabi_cpu.c -- test infrastructure, never loaded by the package) exports the
+hot-path subset of the header under the same symbols and signatures.  Here it is bound with the SAME ctypes signature
+table and descriptor structs the package uses for the HIP library (mmlrec_amd/_lib.py) and driven through the call
+sequence mmlrec_amd/engine.py records for MMoE -- gather, grouped Linear(+ReLU) launches, gate mix, head + summed BCE,
+the backward launches, scatter, dense Adam -- on a fixture the unmodified reference produced
+(tests/golden/mmoe_ae30.npz): probabilities, loss, every gradient and the parameters after one Adam step.
+What this pins on CPU: the descriptor layouts and argument meaning of the header (a layout or stride mistake in
+_lib.py / ops.py shows up here without a GPU), and the semantics each entry point documents."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    from oracle import build_fast
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib as L
+    lib = C.CDLL(build_fast.build_cabi())
+    for name, (res, args) in L._SIGS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib, L
+
+
+def test_cpu_library_symbols_are_a_subset_of_the_header_with_matching_signatures(cpu):
+    lib, L = cpu
+    import re
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib._name]).decode()
+    syms = sorted(set(re.findall(r"\bT (mml_[a-z0-9_]+)", out)))
+    assert len(syms) >= 18
+    hdr = open(os.path.join(ROOT, "include", "mmlrec.h")).read()
+    for s in syms:
+        assert re.search(r"\b%s\s*\(" % s, hdr), f"{s} exported by the CPU library but not declared in include/mmlrec.h"
+        assert s in L._SIGS, s
+    assert lib.mml_version() == 100
+    assert lib.mml_gemm_grouped_fwd(None, 3, None) == -1 and b"descriptor" in lib.mml_last_error()
+
+
+def ptr(a):
+    return a.ctypes.data
+
+
+def ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def test_mmoe_training_step_through_the_cpu_cabi_matches_the_reference_golden(cpu):
+    lib, L = cpu
+    g = load_golden("mmoe_ae30")
+    P = {k[6:]: np.array(g[k], dtype=np.float32) for k in g.files if k.startswith("state/")}
+    X, y = np.ascontiguousarray(g["X0"], dtype=np.float32), np.ascontiguousarray(g["y0"], dtype=np.float32)
+    vocab = [int(v) for v in g["vocab"]]
+    names = [str(s) for s in g["sparse_names"]]
+    B, F, E, T, Ne = X.shape[0], len(vocab), 8, 2, 4
+    K0 = F * E
+    f32 = lambda *s: np.zeros(s, dtype=np.float32)  # noqa: E731
+    amax = np.zeros((64, 8), dtype=np.uint32)  # operand-magnitude slots (raised by every producer below)
+    slot = iter(range(64))
+    new_slot = lambda: amax[next(slot)]  # noqa: E731
+
+    # ---- K1 gather
+    tabs = [P[f"embedding_dict.{n}.weight"] for n in names]
+    x0 = f32(B, K0)
+    status = np.zeros(1, dtype=np.int32)
+    rc = lib.mml_gather_fwd(ptr_array(tabs), (C.c_int64 * F)(*vocab), (C.c_int32 * F)(*range(F)), F, E, ptr(X), X.shape[1],
+                            0, 0, B, ptr(x0), K0, ptr(status), None)
+    assert rc == 0 and status[0] == 0
+    assert np.array_equal(x0, g["dnn_input"])  # index work: bit-exact
+
+    def linear_group(probs):
+        """probs: (A, W, b, act) -> outputs, relu masks; one mml_gemm_grouped_fwd call."""
+        arr = (L.GemmFwdDesc * len(probs))()
+        outs, masks = [], []
+        for d, (A, W, b, act) in zip(arr, probs):
+            out = f32(A.shape[0], W.shape[0])
+            m = np.zeros((A.shape[0], (W.shape[0] + 31) // 32), dtype=np.uint32)
+            d.A, d.W, d.bias, d.C = ptr(A), ptr(W), (ptr(b) if b is not None else None), ptr(out)
+            d.lda, d.ldw, d.ldc = A.shape[1], W.shape[1], out.shape[1]
+            d.M, d.N, d.K, d.act, d.w_kn = A.shape[0], W.shape[0], A.shape[1], act, 0
+            d.relu_mask, d.ldmask = ptr(m), m.shape[1]
+            d.amax_out = ptr(new_slot())
+            outs.append(out)
+            masks.append(m)
+        assert lib.mml_gemm_grouped_fwd(arr, len(probs), None) == 0
+        return outs, masks
+
+    W_ = lambda k: P[k + ".weight"]  # noqa: E731
+    b_ = lambda k: P[k + ".bias"]  # noqa: E731
+    # ---- experts (two ReLU layers) and gate DNNs (one), as ONE grouped launch per layer like engine.LinearGroupOp
+    l1, m1 = linear_group([(x0, W_(f"expert_dnn.{e}.linears.0"), b_(f"expert_dnn.{e}.linears.0"), L.ACT_RELU) for e in range(Ne)] +
+                          [(x0, W_(f"gate_dnn.{t}.linears.0"), b_(f"gate_dnn.{t}.linears.0"), L.ACT_RELU) for t in range(T)])
+    h1, G, mG = l1[:Ne], l1[Ne:], m1[Ne:]
+    h2, m2 = linear_group([(h1[e], W_(f"expert_dnn.{e}.linears.1"), b_(f"expert_dnn.{e}.linears.1"), L.ACT_RELU) for e in range(Ne)])
+    H = h2[0].shape[1]
+    # ---- K4 gates
+    grp = L.GateGroup()
+    grp.n_experts, grp.n_gates, grp.H, grp.B, grp.e_relu = Ne, T, H, B, 1
+    dE = [f32(B, H) for _ in range(Ne)]
+    for e in range(Ne):
+        grp.E[e], grp.lde[e], grp.dE[e], grp.ldde[e] = ptr(h2[e]), H, ptr(dE[e]), H
+    Pg, mix, dmix, dG, dWg = [], [], [], [], []
+    for t in range(T):
+        d = grp.gate[t]
+        Wg = W_(f"gate_dnn_final_layer.{t}")
+        Pg.append(f32(B, Ne)); mix.append(f32(B, H)); dmix.append(f32(B, H)); dG.append(f32(B, G[t].shape[1])); dWg.append(f32(*Wg.shape))
+        d.G, d.Wg, d.P, d.mix, d.dmix, d.dG, d.dWg = ptr(G[t]), ptr(Wg), ptr(Pg[t]), ptr(mix[t]), ptr(dmix[t]), ptr(dG[t]), ptr(dWg[t])
+        d.ldg, d.ldp, d.ldmix, d.lddmix, d.lddg = G[t].shape[1], Ne, H, H, G[t].shape[1]
+        d.Gd, d.ne, d.g_relu, d.active = G[t].shape[1], Ne, 1, 1
+        for e in range(Ne):
+            d.expert[e] = e
+    s_mix, s_dE, s_dG, s_dH = new_slot(), new_slot(), new_slot(), new_slot()
+    grp.amax_mix, grp.amax_dE, grp.amax_dG = ptr(s_mix), ptr(s_dE), ptr(s_dG)
+    assert lib.mml_gate_mix_fwd(C.byref(grp), None) == 0
+    assert float(s_mix.view(np.float32).max()) == float(max(np.abs(m).max() for m in mix))
+    # ---- towers + heads (+ summed BCE and its backward)
+    tw, mt = linear_group([(mix[t], W_(f"tower_dnn.{t}.linears.0"), b_(f"tower_dnn.{t}.linears.0"), L.ACT_RELU) for t in range(T)])
+    hg = L.HeadGroup()
+    prob, loss = f32(B, T), f32(1)
+    hg.n_heads, hg.B, hg.prob, hg.ldprob, hg.y, hg.ldy, hg.loss = T, B, ptr(prob), T, ptr(y), T, ptr(loss)
+    dH, dw, dbias = [], [], []
+    for t in range(T):
+        d = hg.head[t]
+        w = W_(f"tower_dnn_final_layer.{t}")
+        dH.append(f32(B, tw[t].shape[1])); dw.append(f32(w.size)); dbias.append(f32(1))
+        d.Hin, d.w, d.bias, d.dH, d.dw, d.dbias = ptr(tw[t]), ptr(w), ptr(P[f"out.{t}.bias"]), ptr(dH[t]), ptr(dw[t]), ptr(dbias[t])
+        d.ldh, d.lddh, d.H, d.h_relu, d.n_bias2, d.mask_col = tw[t].shape[1], tw[t].shape[1], tw[t].shape[1], 1, 0, -1
+    hg.amax_dH = ptr(s_dH)
+    assert lib.mml_head_bce_fwd_bwd(C.byref(hg), None, 0, None) == 0
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))  # noqa: E731
+    assert rel(prob, g["y_pred"]) < RTOL
+    assert abs(float(loss[0]) - float(g["loss"])) / float(g["loss"]) < RTOL
+
+    # ---- backward: weight gradients (one grouped launch per layer) and input gradients
+    grads = {}
+
+    def wgrad(items):
+        arr = (L.GemmWgradDesc * len(items))()
+        for d, (dCm, A, key) in zip(arr, items):
+            grads[key + ".weight"], grads[key + ".bias"] = f32(dCm.shape[1], A.shape[1]), f32(dCm.shape[1])
+            d.dC, d.A, d.dW, d.dbias = ptr(dCm), ptr(A), ptr(grads[key + ".weight"]), ptr(grads[key + ".bias"])
+            d.lddc, d.lda, d.lddw, d.M, d.N, d.K = dCm.shape[1], A.shape[1], A.shape[1], A.shape[0], dCm.shape[1], A.shape[1]
+        ws = np.zeros(lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(items)), dtype=np.uint8)
+        assert lib.mml_gemm_grouped_wgrad(arr, len(items), ptr(ws), ws.size, None) == 0
+
+    def dgrad(problems):
+        """problems: (dA, mask or None, [(dC, W)]) -- relu' from the sign mask the forward wrote."""
+        arr = (L.GemmDgradDesc * len(problems))()
+        for d, (dA, mask, srcs) in zip(arr, problems):
+            d.dA, d.ldda, d.M, d.K, d.n_src = ptr(dA), dA.shape[1], dA.shape[0], dA.shape[1], len(srcs)
+            d.act = L.ACT_RELU if mask is not None else L.ACT_NONE
+            if mask is not None:
+                d.relu_mask, d.ldmask = ptr(mask), mask.shape[1]
+            for s, (dCm, Wm) in enumerate(srcs):
+                d.dC[s], d.W[s], d.lddc[s], d.ldw[s], d.N[s], d.w_kn[s] = ptr(dCm), ptr(Wm), dCm.shape[1], Wm.shape[1], dCm.shape[1], 0
+        assert lib.mml_gemm_grouped_dgrad(arr, len(problems), None) == 0
+
+    for t in range(T):
+        grads[f"tower_dnn_final_layer.{t}.weight"] = dw[t].reshape(W_(f"tower_dnn_final_layer.{t}").shape)
+        grads[f"out.{t}.bias"] = dbias[t]
+    wgrad([(dH[t], mix[t], f"tower_dnn.{t}.linears.0") for t in range(T)])
+    dgrad([(dmix[t], None, [(dH[t], W_(f"tower_dnn.{t}.linears.0"))]) for t in range(T)])
+    ws = np.zeros(max(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)), 8), dtype=np.uint8)
+    assert lib.mml_gate_mix_bwd(C.byref(grp), ptr(ws), ws.size, None) == 0
+    for t in range(T):
+        grads[f"gate_dnn_final_layer.{t}.weight"] = dWg[t]
+    wgrad([(dE[e], h1[e], f"expert_dnn.{e}.linears.1") for e in range(Ne)])
+    dh1 = [f32(B, h1[e].shape[1]) for e in range(Ne)]
+    dgrad([(dh1[e], m1[e], [(dE[e], W_(f"expert_dnn.{e}.linears.1"))]) for e in range(Ne)])
+    wgrad([(dh1[e], x0, f"expert_dnn.{e}.linears.0") for e in range(Ne)] + [(dG[t], x0, f"gate_dnn.{t}.linears.0") for t in range(T)])
+    dx0 = f32(B, K0)
+    dgrad([(dx0, None, [(dh1[e], W_(f"expert_dnn.{e}.linears.0")) for e in range(Ne)] +
+            [(dG[t], W_(f"gate_dnn.{t}.linears.0")) for t in range(T)])])
+    # ---- K2 scatter
+    gt = [np.zeros_like(t) for t in tabs]
+    rc = lib.mml_scatter_bwd(ptr_array(gt), (C.c_int64 * F)(*vocab), (C.c_int32 * F)(*range(F)), F, E, ptr(X), X.shape[1], B,
+                             ptr(dx0), K0, None, None, None, None, 0, None, ptr(status), None)
+    assert rc == 0
+    for n, t in zip(names, gt):
+        grads[f"embedding_dict.{n}.weight"] = t
+    for k in P:
+        assert rel(grads[k], g["grad/" + k].astype(np.float64)) < RTOL, k
+
+    # ---- K8 dense Adam, step 1 (torch.optim defaults), every tensor in one call
+    keys = list(P)
+    arr = (L.OptTensor * len(keys))()
+    mom = {k: (np.zeros_like(P[k]), np.zeros_like(P[k])) for k in keys}
+    for d, k in zip(arr, keys):
+        grads[k] = np.ascontiguousarray(grads[k], dtype=np.float32)
+        d.param, d.grad, d.state1, d.state2, d.n = ptr(P[k]), ptr(grads[k]), ptr(mom[k][0]), ptr(mom[k][1]), P[k].size
+    hy = L.OptHyper()
+    cfg_lr = 0.005
+    hy.kind, hy.step, hy.lr, hy.beta1, hy.beta2, hy.eps, hy.alpha = L.OPT_ADAM, 1, cfg_lr, 0.9, 0.999, 1e-8, 0.99
+    assert lib.mml_opt_step_dense(arr, len(keys), C.byref(hy), None) == 0
+    for k in keys:
+        ref = g["adam1/" + k].astype(np.float64)
+        dv = np.abs(P[k].astype(np.float64) - ref)
+        # first-step Adam turns a noise-level gradient's sign into an lr-sized move: outlier share + absolute bound
+        assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, k
+        assert dv.max() <= 2.5 * cfg_lr, k
