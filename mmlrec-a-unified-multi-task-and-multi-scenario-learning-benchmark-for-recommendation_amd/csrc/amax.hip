@@ -67,8 +67,10 @@ extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t st
                   "mml_amax_batch: tensor %d malformed", i);
       ++i;
       if (q.rows * q.cols == 0) continue;
-      int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);  // >= 16 elements per thread, 8 workgroups per CU at most
-      if (nb > 2048) nb = 2048;
+      // 16 elements (four 16-byte loads, all in flight at once) per thread where the tensor is large enough to give
+      // every CU work that way; beyond 8192 workgroups the threads loop
+      int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);
+      if (nb > 8192) nb = 8192;
       L.blk0[L.n] = total;
       L.t[L.n++] = q;
       total += (int)nb;

@@ -47,21 +47,37 @@ class Comm:
     def _stage(self, t):
         return t.detach().cpu() if (self.staged and t.is_cuda) else t
 
+    def _call(self, what, fn, *a, **k):
+        """A failed collective leaves the ranks out of step: every later exchange would hang or mix batches.  Say which
+        rank failed in what, then take the whole job down (failure detection; the launcher reaps the others)."""
+        try:
+            return fn(*a, **k)
+        except Exception as e:  # RCCL / gloo errors surface as RuntimeError / DistBackendError
+            import os
+            import sys
+            import traceback
+            sys.stderr.write(f"[mmlrec rank {self.rank}/{self.world}] collective {what} failed: {e!r}\n")
+            traceback.print_exc()
+            sys.stderr.flush()
+            if os.environ.get("MMLREC_COMM_RAISE") == "1":  # (tests: observe the error instead of dying)
+                raise
+            os._exit(70)
+
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         o, i = self._stage(out), self._stage(inp)
-        self.dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+        self._call("all_to_all_single", self.dist.all_to_all_single, o, i, out_splits, in_splits, group=self.group)
         if o is not out:
             out.copy_(o)
 
     def all_reduce(self, t):
         s = self._stage(t)
-        self.dist.all_reduce(s, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._call("all_reduce(sum)", self.dist.all_reduce, s, op=self.dist.ReduceOp.SUM, group=self.group)
         if s is not t:
             t.copy_(s)
 
     def all_reduce_max(self, t):
         s = self._stage(t)
-        self.dist.all_reduce(s, op=self.dist.ReduceOp.MAX, group=self.group)
+        self._call("all_reduce(max)", self.dist.all_reduce, s, op=self.dist.ReduceOp.MAX, group=self.group)
         if s is not t:
             t.copy_(s)
 
@@ -69,20 +85,20 @@ class Comm:
         o, i = self._stage(out), self._stage(inp)
         if self.staged:
             parts = list(o.view(self.world, -1).unbind(0))
-            self.dist.all_gather(parts, i.reshape(-1).contiguous(), group=self.group)
+            self._call("all_gather", self.dist.all_gather, parts, i.reshape(-1).contiguous(), group=self.group)
         else:
-            self.dist.all_gather_into_tensor(o, i, group=self.group)
+            self._call("all_gather_into_tensor", self.dist.all_gather_into_tensor, o, i, group=self.group)
         if o is not out:
             out.copy_(o)
 
     def broadcast(self, t, src):
         s = self._stage(t)
-        self.dist.broadcast(s, src=src, group=self.group)
+        self._call("broadcast", self.dist.broadcast, s, src=src, group=self.group)
         if s is not t:
             t.copy_(s)
 
     def barrier(self):
-        self.dist.barrier(group=self.group)
+        self._call("barrier", self.dist.barrier, group=self.group)
 
 
 # ======================================================================================================

@@ -238,3 +238,39 @@ def test_field_sharding_balances_rows_and_lookups():
         big = shs[0].owner[0]
         if world >= 4:
             assert all(shs[0].owner[f] != big for f in (1, 2))
+
+
+def test_failed_collective_names_the_rank(monkeypatch, capsys):
+    """A collective that fails is reported with the rank and its name (and takes the process down unless
+    MMLREC_COMM_RAISE=1 asks for the exception): SURVEY section 5, failure detection."""
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import parallel
+
+    class FakeDist:
+        class ReduceOp:
+            SUM, MAX = 0, 1
+
+        @staticmethod
+        def get_world_size(group=None):
+            return 2
+
+        @staticmethod
+        def get_rank(group=None):
+            return 1
+
+        @staticmethod
+        def get_backend(group=None):
+            return "gloo"
+
+        @staticmethod
+        def all_reduce(t, op=None, group=None):
+            raise RuntimeError("NCCL error: unhandled system error")
+
+    monkeypatch.setenv("MMLREC_COMM_RAISE", "1")
+    comm = parallel.Comm(FakeDist)
+    import pytest
+    with pytest.raises(RuntimeError):
+        comm.all_reduce(torch.zeros(4))
+    err = capsys.readouterr().err
+    assert "rank 1/2" in err and "all_reduce(sum)" in err and "unhandled system error" in err
