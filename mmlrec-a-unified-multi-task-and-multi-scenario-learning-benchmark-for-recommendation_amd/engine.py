@@ -91,12 +91,13 @@ class Plan:
         self.layer_outputs = {}
         # operand magnitudes (ops.amax_slots): one pool per plan, zeroed at the start of every forward; the magnitudes of
         # the stable weights are measured by ONE launch right after (amax_pre, put in front of `fwd` by finish())
-        # Batches of 16 384 and more: the GEMMs are throughput-bound and the two-plane fp16 form pays (AE-30 at 65 536:
-        # GEMM family 1.14 -> 1.0 ms).  Below, a step is a chain of ~25 short launches: the three extra ones (slot reset,
-        # weight magnitudes, dnn_input) and the per-tile magnitude loads cost more than the arithmetic saves
-        # (lazy_exact AE-30 at 4 096: 0.27 -> 0.35 ms), so the three-plane bf16 form stays.  MMLREC_AMAX=0 / 1 forces.
+        # Large batches: the GEMMs are throughput-bound and the two-plane fp16 form pays (AE-30 at 65 536: GEMM family
+        # 1.14 -> 1.0 ms, step -5 %).  Same-box A/B at smaller batches: level at 32 768 and 16 384 (+-2 %: the ~50 us of
+        # magnitude launches per step against the arithmetic saved), a loss below (8 192: 0.839 -> 0.854 ms; lazy_exact at
+        # 4 096: 0.27 -> 0.35 ms -- a step there is a chain of ~25 short launches).  So: on from 49 152 samples per step,
+        # the three-plane bf16 form below.  MMLREC_AMAX=0 / 1 forces.
         env = os.environ.get("MMLREC_AMAX", "")
-        self.use_amax = (env != "0") and (env == "1" or self.B >= 16384)
+        self.use_amax = (env != "0") and (env == "1" or self.B >= 49152)
         self.amax_pool = ops.amax_slots(1024, device) if (device.type == "cuda" and self.use_amax) else None
         self.amax_next = 0
         self.amax_weights = {}   # (data_ptr, shape) -> slot
