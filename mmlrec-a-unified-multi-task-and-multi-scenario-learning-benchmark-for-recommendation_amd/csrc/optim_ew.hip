@@ -175,6 +175,40 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         }
       }
     }
+    if (gm && !skip && (L.variant & 4)) {
+      // marked single-launch update under a capped grid (mml_opt_hyper.max_blocks: it runs beside the weight-gradient
+      // GEMMs and leaves them their wave slots): the memory-level parallelism comes from the thread -- U chunks, 3U
+      // 16-byte loads in flight
+      constexpr int U = 4;
+      for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 p[U], a[U], b[U], g[U];
+        bool lv[U];
+        int64_t rw[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          rw[k] = ((i + k * stride) << 2) / re;
+          lv[k] = gm[rw[k]] != 0;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int64_t j = i + k * stride;
+          p[k] = ld(P + j);
+          a[k] = S1 ? ld(S1 + j) : zero;
+          b[k] = S2 ? ld(S2 + j) : zero;
+          g[k] = (zg || !lv[k]) ? zero : ld(G + j);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int64_t j = i + k * stride;
+          one(p[k], g[k], a[k], b[k]);
+          st(P + j, p[k]);
+          if (S1) st(S1 + j, a[k]);
+          if (S2) st(S2 + j, b[k]);
+          if (h.zero_grad && (g[k].x != 0.f || g[k].y != 0.f || g[k].z != 0.f || g[k].w != 0.f)) G[j] = zero;
+          if (lv[k] && (j << 2) == rw[k] * re) gm[rw[k]] = 0;
+        }
+      }
+    }
     for (; i < n4; i += stride) {
       if (skip && skipped(i)) continue;
       bool live = true;

@@ -1720,7 +1720,13 @@ class Optimizer:
                 # (mml_opt_hyper.max_blocks, MMLREC_EARLY_BLOCKS) so that it leaves them wave slots.  Same-box A/B runs
                 # (B = 65 536 and 4 096, caps 512 .. 2048) stayed inside the run-to-run noise, so the default is the
                 # full grid, at which the stream runs at its stand-alone bandwidth.
-                cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "0")) if split_dense else 0
+                # Round 3: the single marked launch runs beside the weight-gradient GEMMs of the side stream.  A capped
+                # grid (3072 workgroups = 12 per CU) whose threads keep four chunks -- twelve 16-byte loads -- in flight
+                # streams faster than the full grid of one-chunk threads even alone (0.57 -> 0.48 ms on a slow box) and
+                # leaves the GEMMs more wave slots: same-box A/B of the step 1.948 -> 1.850-1.861 ms (caps 1536 .. 4096
+                # and the uncapped four-chunk form all land between 1.86 and 1.89).  MMLREC_TAIL_BLOCKS overrides.
+                cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "0")) if split_dense else \
+                    int(os.environ.get("MMLREC_TAIL_BLOCKS", "3072"))
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense,
                                     max_blocks=cap)
                 plan.keep.append(hz)
