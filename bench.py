@@ -487,6 +487,7 @@ def main():
                                               if getattr(runner0, "grad_marks", False) else "one launch after the scatter")),
                    "hip_graph": not args.no_graph, "scatter_mode": args.scatter_mode,
                    "streams": 1 if not getattr(runner0, "overlap", True) else (3 if getattr(runner0, "split_dense", False) else 2),
+                   "early_fork": int(getattr(runner0, "early_fork", 0) or 0),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else
                              {"row_sharded": "row-wise sharded over ranks (owner = (row + field) mod N), one all-to-all "
                                              "per direction: keys / rows / row gradients",

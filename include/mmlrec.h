@@ -442,6 +442,20 @@ typedef struct mml_sumprod_desc {
   uint32_t* amax_out; /* optional operand-magnitude slot (see the GEMM family) raised with max |out|, or NULL */
 } mml_sumprod_desc;
 int mml_sumprod_batch(const mml_sumprod_desc* d, int32_t n, mml_stream_t stream);
+/* Dropout after a DNN layer's activation (reference model/utils.py:121 `self.dropout = nn.Dropout(dropout_rate)`,
+ * :159 `fc = self.dropout(fc)`; training mode only -- evaluation is the identity and launches nothing):
+ *   out[r, c] (+)= x[r, c] * (keep(r, c) ? 1 / (1 - p) : 0),  r < rows, c < cols (row pitches ldx / ldo; out may be x).
+ * keep() is a pure function of (seed, step, site, row0 + r, c): word (c mod 4) of Philox4x32-10 with counter
+ * (row0 + r, c / 4, step, site) and key (seed low, seed high), kept iff word >= floor(p * 2^32).  row0 = the position
+ * of this buffer's first row in the GLOBAL batch (rank * local batch on a data-parallel rank, else 0): N ranks on a
+ * split batch draw the mask one rank draws on the whole batch.  No mask is stored: the
+ * backward is the SAME call on dL/d(out) (same seed / step / site).  step_dev (device int32, read by the kernel: a
+ * replayed HIP graph draws a new mask every step) overrides step when not NULL.  `site` tells the layers of a model
+ * apart.  The stream of masks is this library's, not torch's generator: a reference run with the same torch seed drops
+ * different elements (same distribution, same arithmetic). */
+int mml_dropout(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int32_t cols, int64_t row0, float p,
+                uint64_t seed, uint32_t site, const int32_t* step_dev, int32_t step, int32_t accumulate,
+                mml_stream_t stream);
 /* strided 2-D copy / accumulate: dst[r, c] (+)= src[r, c], r < rows, c < cols (concat / split of feature blocks,
  * model/pepnet.py:72, :139) */
 int mml_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate,

@@ -143,6 +143,7 @@ _SIGS = {
     "mml_ew_add_n": (C.c_int, [_PP(fp), i32, fp, i64, fp]),
     "mml_sumprod_batch": (C.c_int, [_PP(SumProdDesc), i32, fp]),
     "mml_copy2d": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp]),
+    "mml_dropout": (C.c_int, [fp, i64, fp, i64, i64, i32, i64, C.c_float, C.c_uint64, C.c_uint32, fp, i32, i32, fp]),
     "mml_copy2d_batch": (C.c_int, [_PP(Copy2dDesc), i32, fp]),
     "mml_auc_segments": (C.c_int, [fp, i64, fp, i64, i64, i32, i32, fp, fp]),
     "mml_bn_workspace_bytes": (C.c_int64, [i64, i32]),

@@ -80,6 +80,12 @@ class Plan:
         # chain has already produced).  Sequential order bwd -> bwd_tail -> bwd_side is always valid.
         self.bwd_tail, self.bwd_side = [], []
         self.keep = []  # ctypes descriptor blocks + buffers referenced by raw pointer
+        # dropout (DropoutOp): on iff the MODULE is in training mode; the step word of its mask stream is read from
+        # `step_dev` (the optimizer's device step counter when the model has one, else a counter of the plan's own)
+        self.dropout_on = False
+        self.row0 = 0  # first row of this plan's batch in the global batch (data-parallel ranks: rank * B)
+        self.dropout_seed = 0
+        self.step_dev = None
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.vals = {}
         self.prob = None
@@ -300,14 +306,20 @@ class Plan:
                     self.bwd.append((L.load().mml_act_bwd, (v.buf.data_ptr(), v.grad.data_ptr(), v.grad.data_ptr(),
                                                             self._flat_numel(v), v.act)))
                     v.deriv_applied = True
+            mine = []
             for c in op.bwd_calls(self):
                 meta = c[-1] if isinstance(c[-1], dict) else {}
                 if meta.get("side"):
                     self.bwd_side.append(c)
+                    mine.append(c)
                 elif meta.get("tail"):
                     self.bwd_tail.append(c)
                 else:
                     self.bwd.append(c)
+            # a side call reads dL/d(this op's outputs) and forward values only: it may start once the chain has issued
+            # everything up to and including this op's own entries (TrainStep's early fork of the side stream)
+            for c in mine:
+                c[-1]["ready"] = len(self.bwd)
         self._amax_prologue()
         # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
         # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
@@ -998,6 +1010,44 @@ class BNOp(Op):
                   ops._ld(self.z.grad), self.gamma.grad.data_ptr(), self.beta.grad.data_ptr(), acc, plan.B, n,
                   ws.data_ptr(), ws.numel()),
                  dict(kernel="bn_bwd", bytes=4.0 * plan.B * n * 5))]
+
+
+class DropoutOp(Op):
+    """nn.Dropout after a DNN layer's activation (reference model/utils.py:121, :159): x -> y = x * keep / (1 - p) while
+    the module is in training mode (`plan.dropout_on`, recorded like BatchNorm's mode; in eval mode the model does not
+    add the op).  The mask is regenerated, not stored (mml_dropout): the backward is the same call on dL/dy with the
+    step counter the forward read -- the optimizer's device counter, bumped at the start of a fused step."""
+
+    def __init__(self, x, y, p, seed, site):
+        self.x, self.y, self.p, self.seed, self.site = x, y, float(p), int(seed) & ((1 << 64) - 1), int(site) & 0xffffffff
+
+    def inputs(self):
+        return [self.x]
+
+    def outputs(self):
+        return [self.y]
+
+    def _call(self, plan, src, dst, acc):
+        return (L.load().mml_dropout,
+                (src.data_ptr(), ops._ld(src), dst.data_ptr(), ops._ld(dst), plan.B, self.x.n, plan.row0, self.p, self.seed,
+                 self.site, plan.step_dev.data_ptr(), 0, int(acc)),
+                dict(kernel="dropout_kernel", bytes=4.0 * plan.B * self.x.n * (3 if acc else 2)))
+
+    def fwd_calls(self, plan):
+        return [self._call(plan, self.x.buf, self.y.buf, 0)]
+
+    def bwd_calls(self, plan):
+        if self.y.grad is None or not self.x.needs_grad:
+            return []
+        g = plan.grad_of(self.x)
+        return [self._call(plan, self.y.grad, g, _claim(self.x))]
+
+
+def dropout_site(name):
+    """The `site` word of a dropout layer's mask stream: CRC-32 of the layer's name (prefix.layer), so that the engine
+    and the CPU restatement (oracle/mmlrec_oracle.py) agree without sharing a counter."""
+    import zlib
+    return zlib.crc32(name.encode()) & 0xffffffff
 
 
 class DomainBNOp(Op):

@@ -93,6 +93,9 @@ class BaseModel(nn.Module):
             raise NotImplementedError("use_cka_loss: the reference imports a module that does not exist (SURVEY D14)")
         self.device = device
         self.gpus = gpus
+        # key of the dropout mask stream (engine.DropoutOp): the seed torch's global generator was given, so that a
+        # seeded run (main.set_seed) repeats; the masks themselves are not torch's (include/mmlrec.h: mml_dropout)
+        self.dropout_seed = int(torch.initial_seed()) & ((1 << 64) - 1)
         if gpus and str(self.gpus[0]) not in str(self.device):
             raise ValueError("`gpus[0]` should be the same gpu with `device`")
 
@@ -231,6 +234,14 @@ class BaseModel(nn.Module):
     def _record(self, B, training, masked, store, sparse_rows=None, lazy=False, mark_rows=None, grad_marks=False):
         plan = E.Plan(store.device, B, training)
         plan.bn_training = bool(self.training)
+        plan.dropout_on = bool(self.training)
+        plan.dropout_seed = int(getattr(self, "dropout_seed", 0))
+        par0 = getattr(self, "_parallel", None)
+        # data-parallel ranks hold consecutive blocks of the global batch (rank r: rows [r B, (r + 1) B)) and must have
+        # been built under the same torch seed: together they then draw the dropout mask of a one-rank step
+        plan.row0 = par0.rank * int(B) if (par0 is not None and training) else 0
+        plan.step_dev = (self.optimizer().step_dev if getattr(self, "optim_name", None) is not None else
+                         torch.zeros(1, dtype=torch.int32, device=store.device))
         plan.generation = 0
         sp, de = self._sparse_cols(), self._dense_cols()
         ftot = max(e for _, e in self.feature_index.values())

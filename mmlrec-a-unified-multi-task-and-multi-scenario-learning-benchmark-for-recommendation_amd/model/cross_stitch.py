@@ -10,7 +10,7 @@ from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import build_tower_modules, emit_towers
-from .utils import DNN, emit_blocks_into, emit_dnn_stacks
+from .utils import DNN, blocks_out_act, emit_blocks_into, emit_dnn_stacks
 
 
 class CrossStitchLayer(nn.Module):
@@ -55,8 +55,9 @@ class CrossStitch(BaseModel):
         for i, d in enumerate(self.dnn_hidden_units):
             if d % 4:
                 raise NotImplementedError("cross-stitch widths must be multiples of 4 (16-byte column slices)")
-            cat = plan.val(T * d, act=L.ACT_RELU, name=f"cross_stitch.{i}.cat")
-            parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], L.ACT_RELU, name=f"cross_stitch.{i}.task.{j}")
+            act = blocks_out_act(plan, self.cross_stitch[f"task_layer_{i}"])
+            cat = plan.val(T * d, act=act, name=f"cross_stitch.{i}.cat")
+            parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], act, name=f"cross_stitch.{i}.task.{j}")
                      for j in range(T)]
             pfx = f"cross_stitch.task_layer_{i}"
             emit_blocks_into(plan, store, self.cross_stitch[f"task_layer_{i}"], [f"{pfx}.{j}" for j in range(T)], ins,

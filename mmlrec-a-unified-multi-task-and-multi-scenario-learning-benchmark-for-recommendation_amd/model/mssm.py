@@ -49,13 +49,15 @@ class MSSM(SNR_trans):
         if self.num_experts <= 1:
             raise ValueError("num_experts must be greater than 1")
         act, bn = mc.get("dnn_activation", "relu"), mc.get("dnn_use_bn", False)
+        drop = mc.get("dnn_dropout", 0)  # experts and towers (reference model/mssm.py:76, :89, :127)
         units, Ne, T = self.expert_dnn_hidden_units, self.num_experts, self.num_tasks
         self.mssm = nn.ModuleDict()
         for i, d in enumerate(units):
             k = self.input_dim if i == 0 else units[i - 1]
             self.mssm[f"expert{i + 1}"] = nn.ModuleList(
-                DNN(k, [d], activation=act, use_bn=bn, init_std=init_std, device=device) for _ in range(Ne))
+                DNN(k, [d], activation=act, dropout_rate=drop, use_bn=bn, init_std=init_std, device=device)
+                for _ in range(Ne))
             self.mssm[f"gate{i + 1}"] = gate(Ne, T if i == len(units) - 1 else Ne, d, device=device)
-        build_tower_modules(self, units[-1], self.tower_dnn_hidden_units, act, mc.get("l2_reg_dnn", 0), 0, bn,
+        build_tower_modules(self, units[-1], self.tower_dnn_hidden_units, act, mc.get("l2_reg_dnn", 0), drop, bn,
                             init_std, device)
         self.to(device)

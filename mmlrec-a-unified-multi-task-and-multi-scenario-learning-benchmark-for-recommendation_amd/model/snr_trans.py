@@ -13,7 +13,7 @@ from .. import _lib as L
 from .. import engine as E
 from .basemodel import BaseModel
 from .towers import build_tower_modules, emit_towers
-from .utils import DNN, dnn_options, emit_blocks_into
+from .utils import DNN, blocks_out_act, dnn_options, emit_blocks_into
 
 
 class gate(nn.Module):  # (lower-case class name of the reference: it shows in nothing but repr)
@@ -70,8 +70,9 @@ class SNR_trans(BaseModel):
                 raise NotImplementedError("routing widths must be multiples of 4 (16-byte column slices)")
             g = mods[f"gate{i + 1}"]
             No = g.output_dim
-            cat = plan.val(Ne * d, act=L.ACT_RELU, name=f"snr.{i}.cat")
-            parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], L.ACT_RELU, name=f"snr.{i}.expert.{j}") for j in range(Ne)]
+            act = blocks_out_act(plan, mods[f"{self._EXPERT}{i + 1}"])
+            cat = plan.val(Ne * d, act=act, name=f"snr.{i}.cat")
+            parts = [E.Val(cat.buf[:, j * d:(j + 1) * d], act, name=f"snr.{i}.expert.{j}") for j in range(Ne)]
             pfx = f"{stem}{i + 1}"
             emit_blocks_into(plan, store, mods[f"{self._EXPERT}{i + 1}"], [f"{pfx}.{j}" for j in range(Ne)], ins, parts)
             plan.add(E.JoinOp(parts, cat))

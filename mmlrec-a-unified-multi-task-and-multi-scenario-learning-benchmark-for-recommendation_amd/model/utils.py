@@ -128,15 +128,16 @@ def activation_layer(act_name, hidden_size=None, dice_dim=2):
 # ---- parameter containers -------------------------------------------------------------------------
 class DNN(nn.Module):
     """[Linear -> act] x L parameter stack (reference model/utils.py:92-161).  Weights N(0, init_std), biases keep
-    nn.Linear's default init.  use_bn adds a BatchNorm1d after every Linear (engine.BNOp); dropout is rejected."""
+    nn.Linear's default init.  use_bn adds a BatchNorm1d after every Linear (engine.BNOp); dropout_rate > 0 adds an
+    engine.DropoutOp after every activation while the model is in training mode (reference :159)."""
 
     def __init__(self, inputs_dim, hidden_units, activation="relu", l2_reg=0, dropout_rate=0, use_bn=False,
                  init_std=0.0001, dice_dim=3, device="cpu"):
         super().__init__()
         if len(hidden_units) == 0:
             raise ValueError("hidden_units is empty!!")
-        if dropout_rate:
-            raise NotImplementedError("dropout inside DNN is not on the MI355X hot path (every shipped config uses 0)")
+        if not 0 <= dropout_rate < 1:
+            raise ValueError("dropout_rate must be in [0, 1)")  # (reference docstring, model/utils.py:109)
         self.l2_reg, self.use_bn, self.dropout_rate, self.activation = l2_reg, use_bn, dropout_rate, activation
         self.act_code = activation_code(activation)
         dims = [inputs_dim] + list(hidden_units)
@@ -167,6 +168,10 @@ class DNN(nn.Module):
                 h = q["bn"]["y"]
             else:
                 q["out"] = h = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}")
+            if self.dropout_rate and plan.dropout_on:  # act -> dropout (reference :156-159); emit_dnn_stacks adds the op
+                q["drop"] = dict(x=h, y=plan.val(lin.out_features, name=f"{prefix}.{l}.drop"), p=self.dropout_rate,
+                                 site=E.dropout_site(f"{prefix}.{l}"))
+                h = q["drop"]["y"]
             out.append(q)
         return out
 
@@ -174,6 +179,8 @@ class DNN(nn.Module):
         from ..functional import linear_act
         if self.use_bn:
             raise NotImplementedError("stand-alone DNN.forward with BatchNorm: use the model's forward")
+        if self.dropout_rate and self.training:
+            raise NotImplementedError("stand-alone DNN.forward with dropout in training mode: use the model's forward")
         h = inputs
         for lin in self.linears:
             h = linear_act(h, lin.weight, lin.bias, self.act_code)
@@ -191,7 +198,19 @@ def emit_dnn_stacks(plan, stacks):
             if "bn" in q:
                 b = q["bn"]
                 plan.add(E.BNOp(q["out"], b["y"], b["gamma"], b["beta"], b["module"]))
-    return [s[-1]["bn"]["y"] if "bn" in s[-1] else s[-1]["out"] for s in stacks]
+            if "drop" in q:
+                d = q["drop"]
+                plan.add(E.DropoutOp(d["x"], d["y"], d["p"], plan.dropout_seed, d["site"]))
+    return [s[-1]["drop"]["y"] if "drop" in s[-1] else (s[-1]["bn"]["y"] if "bn" in s[-1] else s[-1]["out"])
+            for s in stacks]
+
+
+def blocks_out_act(plan, blocks):
+    """Activation code the GIVEN outputs of emit_blocks_into must carry: the blocks' own, or none when dropout sits
+    between the activation and the output (training mode)."""
+    if plan.dropout_on and any(b.dropout_rate for b in blocks):
+        return L.ACT_NONE
+    return L.ACT_RELU
 
 
 def emit_blocks_into(plan, store, blocks, prefixes, ins, outs):
@@ -201,18 +220,29 @@ def emit_blocks_into(plan, store, blocks, prefixes, ins, outs):
     probs = []
     for blk, pfx, x, o in zip(blocks, prefixes, ins, outs):
         q = dict(x=x, W=store.pvals[f"{pfx}.linears.0.weight"], b=store.pvals[f"{pfx}.linears.0.bias"])
+        drop = bool(blk.dropout_rate) and plan.dropout_on
+        # with dropout the activation's output is a scratch value and the dropout op produces the given one
+        if drop and o.act != L.ACT_NONE:
+            raise L.MMLError("emit_blocks_into: the given output of a block with dropout must carry no activation "
+                             "(blocks_out_act)")
+        a = plan.val(o.n, act=blk.act_code, name=o.name + ".a") if drop else o
         if blk.use_bn:
             q["out"] = plan.val(o.n, name=o.name + ".z")
-            q["bn"] = dict(y=o, gamma=store.pvals[f"{pfx}.bn.0.weight"], beta=store.pvals[f"{pfx}.bn.0.bias"],
+            q["bn"] = dict(y=a, gamma=store.pvals[f"{pfx}.bn.0.weight"], beta=store.pvals[f"{pfx}.bn.0.bias"],
                            module=blk.bn[0])
         else:
-            q["out"] = o
+            q["out"] = a
+        if drop:
+            q["drop"] = dict(x=a, y=o, p=blk.dropout_rate, site=E.dropout_site(f"{pfx}.0"))
         probs.append(q)
     plan.add(E.LinearGroupOp(probs))
     for q in probs:
         if "bn" in q:
             b = q["bn"]
             plan.add(E.BNOp(q["out"], b["y"], b["gamma"], b["beta"], b["module"]))
+        if "drop" in q:
+            d = q["drop"]
+            plan.add(E.DropoutOp(d["x"], d["y"], d["p"], plan.dropout_seed, d["site"]))
 
 
 class DomainBatchNorm(nn.Module):

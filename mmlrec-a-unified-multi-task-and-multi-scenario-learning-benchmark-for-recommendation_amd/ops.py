@@ -446,6 +446,14 @@ def ew_add_n(inputs, out):
             "mml_ew_add_n")
 
 
+def dropout(x, out, p, seed, site=0, step=0, step_dev=None, accumulate=False, row0=0):
+    """out (+)= x * keep / (1 - p) on [rows, cols] views (row pitches may differ; out may be x); the backward is the same
+    call on the gradient (include/mmlrec.h: mml_dropout; reference model/utils.py:159)."""
+    L.check(L.load().mml_dropout(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), x.shape[0], x.shape[1], int(row0), float(p),
+                                 int(seed) & ((1 << 64) - 1), int(site) & 0xffffffff, L.ptr(step_dev), int(step),
+                                 int(accumulate), _stream()), "mml_dropout")
+
+
 def copy2d(src, dst, accumulate=False):
     """dst[:, :] (+)= src[:, :] for 2-D row-strided views (column slices of wider buffers are fine)."""
     rows, cols = src.shape

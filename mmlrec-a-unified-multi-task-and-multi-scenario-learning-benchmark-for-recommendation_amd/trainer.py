@@ -179,9 +179,19 @@ class TrainStep:
         n_lead += getattr(p, "n_pre", 0) if self.split_dense else 0  # (the magnitude reset / weight pass open `fwd`)
         self.pre = Segments((self.opt_split["pre"] + p.fwd[:n_lead]) if self.split_dense else [], self.use_graph)
         self.early = Segments(self.opt_split["early"], self.use_graph, min_calls=1)
-        self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd[n_lead:] + p.head_train + p.bwd,
-                              self.use_graph)
-        self.sideq = Segments(p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
+        # Early fork of the side stream: when no long table stream waits in the tail to hide the weight-gradient GEMMs
+        # behind (row-wise table updates, small tables), the GEMMs whose operands the backward chain has already produced
+        # start beside the REST of the chain instead -- worth it where that rest holds HBM-bound launches (PepNet's gate
+        # products, the gate / head row kernels) that leave the matrix pipe idle.  One more graph seam on each stream.
+        k = self._early_fork(p, int(B)) if self.overlap and not self.split_dense else 0
+        self.front = Segments(([] if self.split_dense else self.opt_split["pre"]) + p.fwd[n_lead:] + p.head_train +
+                              (p.bwd[:k] if k else p.bwd), self.use_graph)
+        self.front_b = Segments(p.bwd[k:], self.use_graph, min_calls=1) if k else None
+        side_a = [c for c in p.bwd_side if c[-1].get("ready", 1 << 30) <= k] if k else []
+        self.side_a = Segments(side_a, self.use_graph, min_calls=1) if k else None
+        self.ev_fork_a = torch.cuda.Event() if k else None
+        self.early_fork = k
+        self.sideq = Segments(p.bwd_side[len(side_a):] + ar + self.opt_split["mlp"], self.use_graph)
         self.tail = Segments(p.bwd_tail + wait + self.opt_split["tables"], self.use_graph)
         # one stream: the whole step is ONE call list (one HIP graph when it holds no Python-issued entry) -- every graph
         # seam is ~16 us of idle stream, a tenth of a small-batch step
@@ -192,6 +202,42 @@ class TrainStep:
         self.calls = 0
         self._nX = self._ny = None  # staging buffers of a prefetched batch
         self._has_next = False
+
+    @staticmethod
+    def _cost(c):
+        meta = c[-1] if isinstance(c[-1], dict) else {}
+        return 4e-6 + meta.get("flops", 0.0) / 5e14 + meta.get("bytes", 0.0) / 4e12
+
+    def _early_fork(self, p, B):
+        """Index into plan.bwd at which the side stream forks early (0 = only at the end of the chain).
+        MMLREC_EARLY_WGRAD: 0 off, n > 0 that index, unset / "auto": where the side calls that are ready by then take
+        about as long as the rest of the chain -- but only when the tail has no dense table stream of the same length
+        to put them beside."""
+        env = os.environ.get("MMLREC_EARLY_WGRAD", "0")
+        ready = [c[-1].get("ready") for c in p.bwd_side]
+        if env == "0" or not p.bwd_side or any(r is None for r in ready) or any(c[0] is E.PY for c in p.bwd):
+            return 0
+        if ready != sorted(ready):  # (program order: a later side call is never ready before an earlier one)
+            return 0
+        if env != "auto":
+            return max(0, min(int(env), len(p.bwd) - 1))
+        side_t = sum(self._cost(c) for c in p.bwd_side)
+        table_t = sum(self._cost(c) for c in self.opt_split["tables"])
+        if os.environ.get("MMLREC_EARLY_WGRAD_DEBUG"):
+            import sys
+            print("early fork: side %.0f us, tables %.0f us, chain %.0f us, ready %s of %d" % (
+                side_t * 1e6, table_t * 1e6, sum(self._cost(c) for c in p.bwd) * 1e6, ready, len(p.bwd)), file=sys.stderr)
+        if B < 16384 or table_t > 0.5 * side_t:
+            return 0
+        best, best_k = 0.0, 0
+        for k in sorted(set(ready)):
+            if k <= 0 or k >= len(p.bwd):
+                continue
+            a = sum(self._cost(c) for c, r in zip(p.bwd_side, ready) if r <= k)
+            rest = sum(self._cost(c) for c in p.bwd[k:])
+            if min(a, rest) > best:
+                best, best_k = min(a, rest), k
+        return best_k if best > 40e-6 else 0
 
     def prefetch(self, X=None, y=None, fence=None, fill=None):
         """Hand over the NEXT step's batch while this one is still in flight: it is copied into staging buffers (the
@@ -276,8 +322,9 @@ class TrainStep:
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
             for seg in ((self.whole,) if self.whole is not None else
-                        (self.pre, self.early, self.front, self.sideq, self.tail)):
-                seg.capture()
+                        (self.pre, self.early, self.front, self.front_b, self.side_a, self.sideq, self.tail)):
+                if seg is not None:
+                    seg.capture()
             torch.cuda.synchronize()
         if self.whole is not None:
             self.whole.run()
@@ -294,6 +341,13 @@ class TrainStep:
         else:
             self.early.run()
         self.front.run()
+        if self.front_b is not None:  # early fork: ready weight-gradient GEMMs beside the rest of the backward chain
+            main = torch.cuda.current_stream()
+            self.ev_fork_a.record(main)
+            self.side.wait_event(self.ev_fork_a)
+            with torch.cuda.stream(self.side):
+                self.side_a.run()
+            self.front_b.run()
         if not self.overlap:
             self.tail.run()
             self.sideq.run()

@@ -12,6 +12,7 @@
  *   mml_head_fwd / mml_head_bce_fwd_bwd   final layer + PredictionLayer + summed BCE (model/utils.py:242-248, basemodel.py:294-296)
  *   mml_opt_step_dense        torch.optim.{SGD,Adam,Adagrad,RMSprop}.step over dense tensors (model/basemodel.py:313, :569-584)
  *   mml_amax_batch / _reset   operand magnitudes (a contract of ours, see include/mmlrec.h)
+ *   mml_dropout               nn.Dropout after a DNN layer (model/utils.py:121, :159) under this build's Philox mask stream
  * tests/test_cabi_cpu.py drives one full MMoE training step of a reference-made golden fixture through these entry
  * points (the call sequence of mmlrec_amd/engine.py) in the CPU container.
  * Build: oracle/build_fast.py (gcc -O2 -shared -fPIC), output oracle/_build/libmmlrec_cpu.so. */
@@ -121,6 +122,41 @@ int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t stream) {
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
+/* Philox4x32-10 (Salmon et al., SC'11), one block; the mask contract of mml_dropout in include/mmlrec.h */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+int mml_dropout(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int32_t cols, int64_t row0, float p,
+                uint64_t seed, uint32_t site, const int32_t* step_dev, int32_t step, int32_t accumulate,
+                mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(rows >= 0 && cols >= 0, "mml_dropout: negative size");
+  REQUIRE(p >= 0.f && p < 1.f, "mml_dropout: p must be in [0, 1)");
+  if (rows == 0 || cols == 0) return MML_OK;
+  REQUIRE(x && out && ldx >= cols && ldo >= cols, "mml_dropout: bad arguments");
+  const double t = (double)p * 4294967296.0;
+  const uint32_t thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+  const float scale = 1.0f / (1.0f - p);
+  const uint32_t st = step_dev ? (uint32_t)*step_dev : (uint32_t)step;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int32_t q = 0; 4 * q < cols; ++q) {
+      uint32_t w[4] = {(uint32_t)(row0 + r), (uint32_t)q, st, site};
+      philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));
+      for (int j = 0; j < 4 && 4 * q + j < cols; ++j) {
+        float o = x[r * ldx + 4 * q + j] * (w[j] < thr ? 0.f : scale);
+        if (accumulate) o += out[r * ldo + 4 * q + j];
+        out[r * ldo + 4 * q + j] = o;
+      }
+    }
+  return MML_OK;
+}
+
 int mml_gemm_set_mode(int32_t mode) { (void)mode; return MML_OK; }
 int mml_gemm_get_mode(void) { return 0; }
 const char* mml_gemm_last_kernel(void) { return "cpu"; }

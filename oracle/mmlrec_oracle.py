@@ -81,8 +81,7 @@ class Spec:
             self.T = len(self.dc["label_columns"])
         else:
             self.T = len(self.mc.get("task_names", ["ctr", "ctcvr"]))
-        if self.mc.get("dnn_dropout", 0) != 0:
-            raise NotImplementedError("oracle covers dropout 0 only (every shipped config)")
+        self.dropout = float(self.mc.get("dnn_dropout", 0))  # applied when set_dropout() gives the mask stream a key
         if self.mc.get("dnn_activation", "relu") != "relu":
             raise NotImplementedError("oracle covers relu towers only")
 
@@ -184,8 +183,51 @@ def set_training(flag):
     _MODE["training"] = bool(flag)
 
 
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the published
+    algorithm, pinned by its known-answer vectors in tests/test_dropout_cpu.py) on arrays of counters: four uint32
+    words out per (c0, c1, c2, c3) under the key (k0, k1)."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & 0xffffffff for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xffffffff, int(k1) & 0xffffffff
+    for _ in range(rounds):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0), p1 & np.uint64(0xffffffff),
+                          (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1), p0 & np.uint64(0xffffffff))
+        k0, k1 = (k0 + 0x9E3779B9) & 0xffffffff, (k1 + 0xBB67AE85) & 0xffffffff
+    return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
+
+
+def dropout_scale(rows, cols, p, seed, step, site, row0=0):
+    """The factor nn.Dropout multiplies a [rows, cols] activation with (model/utils.py:159; torch: input * noise with
+    noise = bernoulli(1 - p) / (1 - p)), under this build's mask stream (include/mmlrec.h, mml_dropout): element
+    (r, c) is kept iff word c % 4 of philox4x32(counter = (row0 + r, c // 4, step, site), key = seed) >= floor(p * 2^32)
+    (row0: position of the first row in the global batch of a data-parallel step)."""
+    c4 = (cols + 3) // 4
+    r = np.repeat(np.arange(row0, row0 + rows, dtype=np.uint64), c4)
+    q = np.tile(np.arange(c4, dtype=np.uint64), rows)
+    w = philox4x32(r, q, np.full(r.shape, step, dtype=np.uint64), np.full(r.shape, site, dtype=np.uint64),
+                   seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+    words = np.stack(w, axis=1).reshape(rows, 4 * c4)[:, :cols]
+    thr = min(int(float(np.float32(p)) * 4294967296.0), 0xffffffff)
+    scale = F32(1.0) / (F32(1.0) - F32(p))
+    return np.where(words < np.uint32(thr), F32(0), scale).astype(F32)
+
+
+def set_dropout(p=0.0, seed=0, step=0):
+    """Key of the dropout mask stream for the next forward (p = 0 switches dropout off): the model's dnn_dropout, the
+    seed the engine holds (BaseModel.dropout_seed) and the optimizer's step counter as the forward reads it (1 in the
+    first fused step)."""
+    _MODE["dropout"] = dict(p=float(p), seed=int(seed), step=int(step)) if p else None
+
+
+def _layer_site(name):
+    import zlib
+    return zlib.crc32(name.encode()) & 0xffffffff
+
+
 def dnn_fwd(params, prefix, x):
-    """DNN.forward (model/utils.py:146-161): [Linear -> (BatchNorm1d) -> ReLU]* (dropout 0 in the shipped configs).
+    """DNN.forward (model/utils.py:146-161): [Linear -> (BatchNorm1d) -> ReLU -> Dropout]* (dropout only in training
+    mode and when set_dropout() armed it; the reference's MLP model builds its blocks without it, model/mlp.py).
     BatchNorm1d as torch does it: batch mean / biased variance in training mode, with the running statistics moved by
     momentum 0.1 (unbiased variance) and num_batches_tracked incremented IN `params`; running statistics in eval mode.
     Returns output and the per-layer records for backward."""
@@ -218,6 +260,11 @@ def dnn_fwd(params, prefix, x):
             z = (xhat * g + be).astype(F32)
         y = relu(z)
         acts.append((h, y, bn))
+        dr = _MODE.get("dropout")
+        if dr and _MODE["training"] and not prefix.startswith("mlp_layers."):
+            ms = dropout_scale(y.shape[0], y.shape[1], dr["p"], dr["seed"], dr["step"], _layer_site(f"{prefix}.{l}"))
+            acts[-1] = (h, y, bn, ms)
+            y = (y * ms).astype(F32)
         h = y
         l += 1
     if l == 0:
@@ -228,7 +275,10 @@ def dnn_fwd(params, prefix, x):
 def dnn_bwd(params, prefix, acts, dy, grads):
     """Backward of dnn_fwd; accumulates into grads[key]; returns d(input)."""
     for l in range(len(acts) - 1, -1, -1):
-        x, y, bn = acts[l] if len(acts[l]) == 3 else (*acts[l], None)
+        ms = acts[l][3] if len(acts[l]) == 4 else None
+        x, y, bn = acts[l][:3] if len(acts[l]) >= 3 else (*acts[l], None)
+        if ms is not None:  # dropout backward: the same factor on the gradient
+            dy = (dy * ms).astype(F32)
         dz = (dy * (y > 0)).astype(F32)
         if bn is not None:  # BatchNorm backward with batch statistics
             xhat, rstd = bn

@@ -48,6 +48,24 @@ def test_cpu_library_symbols_are_a_subset_of_the_header_with_matching_signatures
     assert lib.mml_gemm_grouped_fwd(None, 3, None) == -1 and b"descriptor" in lib.mml_last_error()
 
 
+def test_cpu_library_dropout_is_the_oracle_mask(cpu):
+    """Two independent restatements of the mask contract of mml_dropout (C here, numpy in the oracle) agree bit for bit
+    -- and with the HIP kernel (tests/test_dropout_gpu.py compares it with the numpy one)."""
+    lib, L = cpu
+    from oracle import mmlrec_oracle as orc
+    rng = np.random.default_rng(5)
+    rows, cols, p, seed, site, step = 300, 37, 0.3, 0xfeedfacecafebeef, 0x9e3779b9, 5
+    x = rng.standard_normal((rows, cols + 3)).astype(np.float32)
+    out = np.ones((rows, cols), dtype=np.float32)
+    sd = np.array([step], dtype=np.int32)
+    assert lib.mml_dropout(x.ctypes.data, cols + 3, out.ctypes.data, cols, rows, cols, 11, p, seed, site, sd.ctypes.data,
+                           99, 1, None) == 0
+    want = x[:, :cols] * orc.dropout_scale(rows, cols, p, seed, step, site, row0=11) + np.float32(1.0)
+    assert np.array_equal(out, want.astype(np.float32))
+    assert lib.mml_dropout(x.ctypes.data, cols + 3, out.ctypes.data, cols, rows, cols, 0, 1.0, seed, site, None, 0, 0,
+                           None) == -1
+
+
 def ptr(a):
     return a.ctypes.data
 

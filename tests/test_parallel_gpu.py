@@ -97,6 +97,82 @@ def _spawn(jobs, world=2):
             assert not bad, (r, case_name, mode, kind, tu, bad)
 
 
+def _dropout_worker(rank, world, port, ret):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import mmlrec_amd  # noqa: F401
+        from mmlrec_amd import parallel
+        from conftest import load_golden, table_update_report
+        from oracle import mmlrec_oracle as orc
+        from test_dropout_gpu import P, _spec
+        from test_models_gpu import build, load_state
+        out = []
+        for mode in ("row_sharded", "replicated"):
+            g = load_golden("mmoe_ae30d")
+            model, cfg = build(g, dnn_dropout=P, table_update="dense_exact")
+            load_state(model, g)
+            model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+            model.train()
+            B = 64 // world
+            par = parallel.shard_model(model, dist, B, mode=mode)
+            before = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+            X = torch.from_numpy(g["X0"])[rank * B:(rank + 1) * B].contiguous().cuda()  # consecutive blocks
+            y = torch.from_numpy(g["y0"])[rank * B:(rank + 1) * B].contiguous().cuda()
+            step = model.train_step_runner(B, use_graph=True)
+            step.plan.X.copy_(X)
+            step.plan.y.copy_(y)
+            step.run()
+            lt = step.plan.loss.detach().clone().double()
+            par.comm.all_reduce(lt)
+            after = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+            # the one-rank step on the WHOLE batch under the same mask stream (oracle)
+            params = {k: v.copy() for k, v in before.items()}
+            orc.set_dropout(P, seed=model.dropout_seed, step=1)
+            try:
+                ref_loss = orc.train_step(_spec(g, P), params, orc.DenseOptimizer("adam", cfg["optim_config"]["lr"]),
+                                          g["X0"], g["y0"])
+            finally:
+                orc.set_dropout(0)
+            bad = []
+            if abs(float(lt.item()) - ref_loss) / ref_loss >= RTOL:
+                bad.append(("loss", float(lt.item()), ref_loss))
+            for k, r in params.items():
+                b, a = before[k], after[k]
+                b2 = b.reshape(b.shape[0], -1) if b.ndim > 1 else b.reshape(1, -1)
+                rows = np.nonzero(np.abs(r.reshape(b2.shape) - b2).max(1) + np.abs(a.reshape(b2.shape) - b2).max(1))[0]
+                if len(rows) and table_update_report(b2, a.reshape(b2.shape), r.reshape(b2.shape), rows)[0] >= 2e-3:
+                    bad.append((k,))
+            out.append((mode, bad))
+        ret[rank] = ("ok", out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = ("error", traceback.format_exc())
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_world2_dropout_step_is_the_one_rank_step():
+    """Dropout on two data-parallel ranks: the ranks' masks are the two halves of the one-rank mask (mml_dropout row0),
+    so the summed loss and the parameters after a fused step equal the oracle's step on the whole batch."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dropout_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in range(2):
+        status, out = ret[r]
+        assert status == "ok", out
+        for mode, bad in out:
+            assert not bad, (r, mode, bad)
+
+
 @pytest.mark.timeout(900)
 def test_world2_steps_match_reference_trajectories():
     jobs = []

@@ -18,7 +18,7 @@ for k in range(len(starts) - 1):
         if k + nxt >= len(starts):
             continue
         a, b = starts[k], starts[k + nxt]
-        if b - a < 15 or b - a > 45:
+        if b - a < 15 or b - a > 160:
             continue
         dur = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
         if best is None or dur < best[0]:
