@@ -75,7 +75,12 @@ __device__ __forceinline__ float reg_grad(float g, float p, float l1, float l2) 
 // blockIdx.y = tensor, blockIdx.x strides over that tensor in float4 chunks.
 // STREAM only names the launch (profilers see two symbols): true = a launch that streams >= 2^24 parameters through
 // HBM (the dense table update), false = everything else (MLP parameters, small tables).  Same code.
-template <bool STREAM>
+// PATH = the form of the vector loop, one instantiation each so that each keeps ITS register count (all forms in one
+// kernel: 170 VGPRs, two waves per SIMD -- and the plain loop, which needs 40, ran at that occupancy too):
+//   0 plain grid-stride loop (also the remainder loop of every other form)   1 two chunks per iteration
+//   2 split update, untouched rows, U chunks in flight per thread            3 marked gradients, U chunks in flight
+enum { OPT_PLAIN = 0, OPT_UNROLL2 = 1, OPT_SKIP_U = 2, OPT_MARK_U = 3 };
+template <bool STREAM, int PATH, int U>
 __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   const mml_opt_tensor& T = L.t[blockIdx.y];
   const mml_opt_hyper& h = L.h;
@@ -90,7 +95,6 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
   if (vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const bool nt = (L.variant & 1) != 0;
-    const int unroll = (L.variant & 2) ? 2 : 1;
     f4* P = reinterpret_cast<f4*>(T.param);
     f4* G = reinterpret_cast<f4*>(gw);
     f4* S1 = reinterpret_cast<f4*>(T.state1);
@@ -113,8 +117,13 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
     };
     const uint32_t* skip = T.skip_rows;
     const int re = T.row_elems > 0 ? T.row_elems : 1;
-    auto skipped = [&](int64_t c) {  // chunk c = elements [4c, 4c + 4): inside ONE row when row_elems % 4 == 0
-      const int64_t row = (c << 2) / re;
+    // row of chunk c = elements [4c, 4c + 4) (inside ONE row when row_elems % 4 == 0): a shift for the usual power-of-two
+    // embedding widths (a 64-bit division is ~100 VALU instructions per chunk, issue slots the GEMM waves beside this
+    // kernel want)
+    const int rsh = (re & (re - 1)) == 0 ? __builtin_ctz((unsigned)re) : -1;
+    auto row_of = [&](int64_t c) { return rsh >= 0 ? ((c << 2) >> rsh) : ((c << 2) / re); };
+    auto skipped = [&](int64_t c) {
+      const int64_t row = row_of(c);
       return (skip[row >> 5] >> (row & 31)) & 1u;
     };
     const bool zg = T.zero_grads != 0;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
     // reads the byte in the same wave-instruction, before the first chunk's lane clears it further down.
     uint8_t* const gm = T.grad_marks;
     int64_t i = tid;
-    if (unroll == 2 && !skip && !gm) {
+    if (PATH == OPT_UNROLL2 && !skip && !gm) {
       for (; i + stride < n4; i += 2 * stride) {  // eight 16-byte loads in flight per thread
         const int64_t j = i + stride;
         f4 p0 = ld(P + i), p1 = ld(P + j);
@@ -140,17 +149,16 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         if (h.zero_grad && (g1.x != 0.f || g1.y != 0.f || g1.z != 0.f || g1.w != 0.f)) G[j] = zero;
       }
     }
-    if (skip && (L.variant & 4)) {
+    if (PATH == OPT_SKIP_U && skip) {
       // early half of the split table update under a capped grid (mml_opt_hyper.max_blocks): it runs BESIDE other
       // kernels with few waves, so the memory-level parallelism has to come from the thread: U independent chunks (3U
       // 16-byte loads) in flight.  (With the full grid the plain loop below is faster: fewer registers, more waves.)
-      constexpr int U = 4;
       for (; i + (U - 1) * stride < n4; i += U * stride) {
         f4 p[U], a[U], b[U];
         uint32_t w[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {  // the U bitmap words first ...
-          const int64_t row = ((i + k * stride) << 2) / re;
+          const int64_t row = row_of(i + k * stride);
           w[k] = (skip[row >> 5] >> (row & 31)) & 1u;
         }
 #pragma unroll
@@ -175,18 +183,17 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
         }
       }
     }
-    if (gm && !skip && (L.variant & 4)) {
+    if (PATH == OPT_MARK_U && gm && !skip) {
       // marked single-launch update under a capped grid (mml_opt_hyper.max_blocks: it runs beside the weight-gradient
       // GEMMs and leaves them their wave slots): the memory-level parallelism comes from the thread -- U chunks, 3U
       // 16-byte loads in flight
-      constexpr int U = 4;
       for (; i + (U - 1) * stride < n4; i += U * stride) {
         f4 p[U], a[U], b[U], g[U];
         bool lv[U];
         int64_t rw[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-          rw[k] = ((i + k * stride) << 2) / re;
+          rw[k] = row_of(i + k * stride);
           lv[k] = gm[rw[k]] != 0;
         }
 #pragma unroll
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
       bool live = true;
       int64_t row = 0;
       if (gm) {
-        row = (i << 2) / re;
+        row = row_of(i);
         live = gm[row] != 0;
       }
       f4 p = ld(P + i);
@@ -787,7 +794,31 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       int64_t bx = cdiv(cdiv(nmax, 4), 256);
       if (bx > 256 * 8) bx = 256 * 8;
       if (hyper->max_blocks > 0 && bx * L.n > hyper->max_blocks) bx = cdiv(hyper->max_blocks, L.n);
-      MML_LAUNCH(opt_dense_kernel<true>, dim3((unsigned)bx, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
+      // the loop form (see opt_dense_kernel): decided for the launch, so every tensor of it must qualify
+      bool all_gm = true, all_skip = true, none = true;
+      for (int k = 0; k < L.n; ++k) {
+        all_gm = all_gm && L.t[k].grad_marks && !L.t[k].skip_rows;
+        all_skip = all_skip && L.t[k].skip_rows;
+        none = none && !L.t[k].grad_marks && !L.t[k].skip_rows;
+      }
+      static int u_mark = -1;
+      if (u_mark < 0) {
+        const char* e = getenv("MMLREC_OPT_U");  // lab knob: chunks in flight per thread of the marked form (2, 4, 8)
+        u_mark = e ? atoi(e) : 4;
+      }
+      const dim3 grid((unsigned)bx, (unsigned)L.n);
+      hipStream_t st = to_stream(stream);
+      if ((L.variant & 4) && all_gm) {
+        if (u_mark == 2) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 2>), grid, dim3(256), 0, st, L);
+        else if (u_mark == 8) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 8>), grid, dim3(256), 0, st, L);
+        else MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 4>), grid, dim3(256), 0, st, L);
+      } else if ((L.variant & 4) && all_skip) {
+        MML_LAUNCH((opt_dense_kernel<true, OPT_SKIP_U, 4>), grid, dim3(256), 0, st, L);
+      } else if ((L.variant & 2) && none) {
+        MML_LAUNCH((opt_dense_kernel<true, OPT_UNROLL2, 1>), grid, dim3(256), 0, st, L);
+      } else {
+        MML_LAUNCH((opt_dense_kernel<true, OPT_PLAIN, 1>), grid, dim3(256), 0, st, L);
+      }
     } else {
       for (int k = 0; k < L.n; ++k)
         MML_REQUIRE(!L.t[k].grad_marks, "mml_opt_step_dense: grad_marks is only honoured by the streaming launch "

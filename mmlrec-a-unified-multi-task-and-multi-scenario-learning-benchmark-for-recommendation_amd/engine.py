@@ -395,9 +395,14 @@ def scatter_symbol(E):
     return "scatter_fold_kernel" if E in (4, 8, 16) else ("scatter_hash_kernel" if E <= 16 else "scatter_atomic_kernel")
 
 
-def _opt_dense_symbol(numel, ntensors):
-    """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: mml_opt_step_dense's choice)."""
-    return "opt_dense_kernel<true>" if (numel >= (1 << 24) and ntensors <= 4) else "opt_flat_kernel"
+def _opt_dense_symbol(numel, ntensors, form=0):
+    """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: mml_opt_step_dense's choice).  form: the loop form
+    of the streaming kernel -- 0 plain, 1 two chunks per iteration (MMLREC_OPT_VARIANT bit 1), 2 untouched rows of the
+    split update under a capped grid, 3 marked gradients under a capped grid."""
+    if not (numel >= (1 << 24) and ntensors <= 4):
+        return "opt_flat_kernel"
+    u = {0: 1, 1: 1, 2: 4, 3: int(os.environ.get("MMLREC_OPT_U", "4"))}[form]
+    return "opt_dense_kernel<true, %d, %d>" % (form, u)
 
 
 class Op:
@@ -1771,10 +1776,12 @@ class Optimizer:
                 # (B = 65 536 and 4 096, caps 512 .. 2048) stayed inside the run-to-run noise, so the default is the
                 # full grid, at which the stream runs at its stand-alone bandwidth.
                 # Round 3: the single marked launch runs beside the weight-gradient GEMMs of the side stream.  A capped
-                # grid (3072 workgroups = 12 per CU) whose threads keep four chunks -- twelve 16-byte loads -- in flight
-                # streams faster than the full grid of one-chunk threads even alone (0.57 -> 0.48 ms on a slow box) and
-                # leaves the GEMMs more wave slots: same-box A/B of the step 1.948 -> 1.850-1.861 ms (caps 1536 .. 4096
-                # and the uncapped four-chunk form all land between 1.86 and 1.89).  MMLREC_TAIL_BLOCKS overrides.
+                # grid (3072 workgroups) whose threads keep four chunks -- twelve 16-byte loads -- in flight holds two
+                # waves per SIMD (172 VGPRs) and leaves the GEMMs their register file: same-box A/B of the step, every
+                # loop form its own kernel (csrc/optim_ew.hip: the plain loop at 54 VGPRs / 8 waves, two chunks at 100
+                # / 4): plain 1.928, two chunks uncapped 1.912, four chunks / 3072 1.883 ms; alone the two-chunk form is
+                # the fastest (0.44 against 0.49 plain and 0.50), eight chunks (256 VGPRs, one wave) the slowest (0.85).
+                # MMLREC_TAIL_BLOCKS / MMLREC_OPT_U override.
                 cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "0")) if split_dense else \
                     int(os.environ.get("MMLREC_TAIL_BLOCKS", "3072"))
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense,
@@ -1811,11 +1818,14 @@ class Optimizer:
                     plan.keep.append(arr)
                     numel = sum(tabs[i].data.numel() for i in grp)
                     nbytes = float(per) * numel
+                    v = int(os.environ.get("MMLREC_OPT_VARIANT", "0"))
+                    form = (3 if (cap > 0 and marked) else 2 if (cap > 0 and split_dense) else
+                            1 if (v & 2 and not marked and not split_dense) else 0)
                     if marked:  # g is read for the touched rows only (~1 %): count the mark bytes instead
                         nbytes += sum(tabs[i].data.shape[0] - 4.0 * tabs[i].data.numel() for i in grp)
                     (early if split_dense else calls).append(
                         (lib.mml_opt_step_dense, (arr, len(grp), C.byref(hz)),
-                         dict(kernel=_opt_dense_symbol(numel, len(grp)), bytes=nbytes)))
+                         dict(kernel=_opt_dense_symbol(numel, len(grp), form), bytes=nbytes)))
             if self.table_update != "dense_exact" or split_dense:
                 rows = st.rows
                 lazy = self.table_update == "lazy_exact"

@@ -16,14 +16,14 @@ import sys
 
 def label(kernel_name, avg_bytes_hint=0):
     k = kernel_name.replace("void ", "").replace("mml::", "")
-    m = re.match(r"(gemm_pipe_kernel|gemm_glds_kernel|gemm_kernel)<([^>]+)>", k)
+    m = re.match(r"(gemm_pipe_kernel|gemm_glds_kernel|gemm_kernel|opt_dense_kernel)<([^>]+)>", k)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     for a, b in (("gather_vec4_kernel", "gather_vec4_kernel"), ("scatter_hash_kernel", "scatter_hash_kernel"),
                  ("scatter_fold_kernel", "scatter_fold_kernel"), ("rows_compact_kernel", "rows_compact_kernel"),
                  ("opt_rows_kernel", "opt_rows_kernel"), ("mark_rows_kernel", "mark_rows_kernel"),
                  ("gate_bwd_fast_kernel", "gate_bwd_kernel"), ("gate_fwd_fast_kernel", "gate_fwd_kernel"), ("gate_fwd_once_kernel", "gate_fwd_kernel"),
-                 ("head_fast_kernel", "head_kernel"), ("opt_dense_kernel<true>", "opt_dense_kernel<true>"),
+                 ("head_fast_kernel", "head_kernel"),
                  ("opt_flat_kernel", "opt_flat_kernel"),
                  ("slab_reduce", "slab_reduce")):
         if k.startswith(a):
