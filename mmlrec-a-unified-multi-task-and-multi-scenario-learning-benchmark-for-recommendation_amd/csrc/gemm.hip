@@ -504,7 +504,7 @@ __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const
 }
 
 // EMU 2: one product block (three dependent MFMAs, ~32 cycles each) with the cut of ONE raw fragment dealt into their
-// shadows by hand: 8 + 8 + 4 VALU instructions.
+// shadows by hand: 10 + 10 + 4 VALU instructions.
 template <bool RC>
 __device__ __forceinline__ void mma_prep_f16(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
                                              const float scale, Prep<2>& o) {
@@ -514,13 +514,11 @@ __device__ __forceinline__ void mma_prep_f16(f32x16& acc, const Prep<2>& a, cons
   __builtin_amdgcn_sched_barrier(0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  f16_cut_hr(x, scale, c, 0);
-  f16_cut_hr(x, scale, c, 1);
+  f16_cut_hr2(x, scale, c, 0);
   __builtin_amdgcn_sched_barrier(0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  f16_cut_hr(x, scale, c, 2);
-  f16_cut_hr(x, scale, c, 3);
+  f16_cut_hr2(x, scale, c, 2);
   __builtin_amdgcn_sched_barrier(0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);

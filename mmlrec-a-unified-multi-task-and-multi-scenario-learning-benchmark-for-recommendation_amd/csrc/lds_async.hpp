@@ -140,6 +140,31 @@ __device__ __forceinline__ void f16_cut_hr(const float (&x)[8], const float s, F
       : "=v"(c.r1[j])
       : "v"(x[2 * j + 1]), "v"(s), "v"(c.h[j]));
 }
+// Two pairs (j, j + 1) at once, the form the pipelined GEMM uses since round 3's instruction-rate measurements
+// (tools/lab/micro/valu_rate.hip, mfma_mix.hip): v_fma_mixlo/hi_f16 issue at a quarter of the plain fp32 rate (7.1 ns
+// per instruction pair of two waves against 2.3 for v_mul_f32 and 3.7 for v_cvt_pk_f16_f32) and do not overlap the
+// MFMA pipe, so h = rne16(x s) is two multiplications and one packed conversion instead (x s is exact: s is a power of
+// two); and the instructions of the two pairs alternate, so that a wave does not issue an instruction right behind the
+// one it depends on (a SIMD holds two waves of this kernel: dependent issue is not hidden).
+__device__ __forceinline__ void f16_cut_hr2(const float (&x)[8], const float s, F16Cut& c, const int j) {
+  float y0, y1, y2, y3;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x[2 * j]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x[2 * j + 1]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y2) : "v"(x[2 * j + 2]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y3) : "v"(x[2 * j + 3]), "s"(s));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.h[j]) : "v"(y0), "v"(y1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.h[j + 1]) : "v"(y2), "v"(y3));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.r0[j]) : "v"(x[2 * j]), "s"(s), "v"(c.h[j]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=v"(c.r1[j])
+      : "v"(x[2 * j + 1]), "s"(s), "v"(c.h[j]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+      : "=v"(c.r0[j + 1])
+      : "v"(x[2 * j + 2]), "s"(s), "v"(c.h[j + 1]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=v"(c.r1[j + 1])
+      : "v"(x[2 * j + 3]), "s"(s), "v"(c.h[j + 1]));
+}
 __device__ __forceinline__ void f16_cut_l(F16Cut& c, const int j) {
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.l[j]) : "v"(c.r0[j]), "v"(c.r1[j]));
 }
