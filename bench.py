@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 second, instrumented pass over the same batches) and `cpu_baseline` (the oracle timed on the host, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -194,13 +195,23 @@ def kernel_breakdown(runner, batches, steps):
     """Second, instrumented pass: every C-ABI call bracketed by HIP events on the launch stream."""
     from mmlrec_amd import engine as E
     acc = {}
-    for i in range(steps):
-        X, y = batches[i % len(batches)]
-        runner.plan.X.copy_(X)
-        runner.plan.y.copy_(y)
-        for calls in (runner.plan.fwd, runner.plan.head_train, runner.plan.bwd, runner.plan.bwd_tail,
-                      runner.plan.bwd_side, runner.opt_calls):
+    # ONE call list per step and no garbage collection while it is issued: the bracket of the first call after a
+    # synchronisation starts on an idle stream, so any host hiccup (a generation-2 collection over the thousands of event
+    # objects of a large plan) lands in it -- with one list per phase that was the table scatter, first of `bwd_tail`
+    # (snr_trans_ae30 once reported 4 ms for an 87 us kernel)
+    calls = (list(runner.plan.fwd) + list(runner.plan.head_train) + list(runner.plan.bwd) + list(runner.plan.bwd_tail) +
+             list(runner.plan.bwd_side) + list(runner.opt_calls))
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for i in range(steps):
+            X, y = batches[i % len(batches)]
+            runner.plan.X.copy_(X)
+            runner.plan.y.copy_(y)
             E.Plan.run_timed(calls, acc)
+    finally:
+        if was:
+            gc.enable()
     return acc
 
 
