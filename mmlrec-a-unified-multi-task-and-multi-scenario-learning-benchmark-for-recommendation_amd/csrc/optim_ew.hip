@@ -804,14 +804,14 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       static int u_mark = -1;
       if (u_mark < 0) {
         const char* e = getenv("MMLREC_OPT_U");  // lab knob: chunks in flight per thread of the marked form (2, 4, 8)
-        u_mark = e ? atoi(e) : 4;
+        u_mark = e ? atoi(e) : 2;
       }
       const dim3 grid((unsigned)bx, (unsigned)L.n);
       hipStream_t st = to_stream(stream);
       if ((L.variant & 4) && all_gm) {
-        if (u_mark == 2) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 2>), grid, dim3(256), 0, st, L);
+        if (u_mark == 4) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 4>), grid, dim3(256), 0, st, L);
         else if (u_mark == 8) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 8>), grid, dim3(256), 0, st, L);
-        else MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 4>), grid, dim3(256), 0, st, L);
+        else MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 2>), grid, dim3(256), 0, st, L);
       } else if ((L.variant & 4) && all_skip) {
         MML_LAUNCH((opt_dense_kernel<true, OPT_SKIP_U, 4>), grid, dim3(256), 0, st, L);
       } else if ((L.variant & 2) && none) {

@@ -401,7 +401,7 @@ def _opt_dense_symbol(numel, ntensors, form=0):
     split update under a capped grid, 3 marked gradients under a capped grid."""
     if not (numel >= (1 << 24) and ntensors <= 4):
         return "opt_flat_kernel"
-    u = {0: 1, 1: 1, 2: 4, 3: int(os.environ.get("MMLREC_OPT_U", "4"))}[form]
+    u = {0: 1, 1: 1, 2: 4, 3: int(os.environ.get("MMLREC_OPT_U", "2"))}[form]
     return "opt_dense_kernel<true, %d, %d>" % (form, u)
 
 
@@ -1775,15 +1775,16 @@ class Optimizer:
                 # (mml_opt_hyper.max_blocks, MMLREC_EARLY_BLOCKS) so that it leaves them wave slots.  Same-box A/B runs
                 # (B = 65 536 and 4 096, caps 512 .. 2048) stayed inside the run-to-run noise, so the default is the
                 # full grid, at which the stream runs at its stand-alone bandwidth.
-                # Round 3: the single marked launch runs beside the weight-gradient GEMMs of the side stream.  A capped
-                # grid (3072 workgroups) whose threads keep four chunks -- twelve 16-byte loads -- in flight holds two
-                # waves per SIMD (172 VGPRs) and leaves the GEMMs their register file: same-box A/B of the step, every
-                # loop form its own kernel (csrc/optim_ew.hip: the plain loop at 54 VGPRs / 8 waves, two chunks at 100
-                # / 4): plain 1.928, two chunks uncapped 1.912, four chunks / 3072 1.883 ms; alone the two-chunk form is
-                # the fastest (0.44 against 0.49 plain and 0.50), eight chunks (256 VGPRs, one wave) the slowest (0.85).
-                # MMLREC_TAIL_BLOCKS / MMLREC_OPT_U override.
+                # Round 3: the single marked launch runs beside the weight-gradient GEMMs of the side stream.  Every loop
+                # form is its own kernel (csrc/optim_ew.hip: the plain loop at 54 VGPRs / 8 waves per SIMD, two chunks per
+                # thread at 100 / 4, four at 172 / 2, eight at 256 / 1).  Alone (same box, ms): two chunks 0.39-0.44, plain
+                # 0.43-0.49, four chunks 0.47-0.50, eight 0.85.  In the step (three interleaved repetitions on a quiet box):
+                # plain 1.928, two chunks 1.912, four chunks under a 3072-workgroup cap 1.883 -- the two-wave form leaves
+                # the GEMMs their registers -- but on other boxes the three are level within the +-3 % drift of a run.
+                # Default: two chunks on the full grid, the best stream by itself (0.66-0.74 of 8 TB/s) and level in the
+                # step; MMLREC_TAIL_BLOCKS (workgroup cap, 0 = plain loop) / MMLREC_OPT_U override.
                 cap = int(os.environ.get("MMLREC_EARLY_BLOCKS", "0")) if split_dense else \
-                    int(os.environ.get("MMLREC_TAIL_BLOCKS", "3072"))
+                    int(os.environ.get("MMLREC_TAIL_BLOCKS", str(1 << 20)))
                 hz = ops.make_hyper(self.kind, self.lr, step=0, step_dev=self.step_dev, zero_grad=not split_dense,
                                     max_blocks=cap)
                 plan.keep.append(hz)
