@@ -265,6 +265,11 @@ typedef struct {
   const uint32_t* amax_a;
   const uint32_t* amax_w;
   uint32_t* amax_out;
+  /* Optional pre-cut weight (mml_gemm_planes_cut, layout MML_PLANES_ROWS for w_kn = 0): the two fp16 planes of W in a
+   * buffer of W's own shape and pitch, and the exponent they were scaled with.  When every problem of a launch that runs
+   * the two-plane arithmetic carries them, the kernel reads the planes instead of cutting W's fragments (same bits). */
+  const uint32_t* w_planes;
+  const int32_t* w_kexp;
 } mml_gemm_fwd_desc;
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
@@ -291,8 +296,36 @@ typedef struct {
   const uint32_t* amax_dc[MML_MAX_SRC];
   const uint32_t* amax_w[MML_MAX_SRC];
   uint32_t* amax_out;
+  /* Optional pre-cut weights of the sources (mml_gemm_planes_cut, layout MML_PLANES_COLS for w_kn = 0), all sources of
+   * a problem cut as ONE group (one common exponent): honoured when every source of every problem of the launch has them. */
+  const uint32_t* w_planes[MML_MAX_SRC];
+  const int32_t* w_kexp[MML_MAX_SRC];
 } mml_gemm_dgrad_desc;
 int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
+
+/* Pre-cut weights for the two-plane fp16 arithmetic.  The GEMM kernels cut every fp32 operand fragment into its planes
+ * h = rne16(x 2^k), l = rne16(x 2^k - h) in registers, once per wave that reads it; a weight matrix is read by every row
+ * tile of the batch, so it can be cut ONCE per step instead: `planes` has W's shape and pitch and holds, per aligned
+ * block of 16 values along the reduction, the 32 bytes of h and the 32 bytes of l in the order the kernel's fragment
+ * reads deliver them (so the planes travel through the same LDS image as the floats would).
+ *   MML_PLANES_ROWS: the reduction runs along a ROW of W ([N, K] read by the forward: K % 16 == 0);
+ *   MML_PLANES_COLS: the reduction runs down the ROWS of W ([N, K] read by the input gradient: N % 16 == 0).
+ * k = the largest exponent that keeps every |w| 2^k below 2^15 for the LARGEST of the n_amax magnitude slots given
+ * (the weights that feed one input-gradient problem share their exponent); it is written to *kexp.  Bit-identical to
+ * the in-kernel cut with the same magnitudes. */
+#define MML_PLANES_ROWS 0
+#define MML_PLANES_COLS 1
+#define MML_MAX_PLANES 64
+typedef struct {
+  const float* W;     /* [rows, cols], row pitch ld (floats) */
+  uint32_t* planes;   /* same shape and pitch, 4-byte words */
+  int64_t rows, ld;
+  int32_t cols, layout;
+  int32_t n_amax, pad_;
+  const uint32_t* amax[MML_MAX_SRC];
+  int32_t* kexp;
+} mml_planes_desc;
+int mml_gemm_planes_cut(const mml_planes_desc* descs, int32_t n, mml_stream_t stream);
 
 typedef struct {
   const float* dC;  /* [M, N] gradient w.r.t. pre-activation output */

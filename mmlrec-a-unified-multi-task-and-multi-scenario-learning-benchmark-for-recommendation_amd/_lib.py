@@ -22,7 +22,8 @@ i32, i64 = C.c_int32, C.c_int64
 class GemmFwdDesc(C.Structure):
     _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("lda", i64), ("ldw", i64), ("ldc", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32),
-                ("relu_mask", fp), ("ldmask", i64), ("amax_a", fp), ("amax_w", fp), ("amax_out", fp)]
+                ("relu_mask", fp), ("ldmask", i64), ("amax_a", fp), ("amax_w", fp), ("amax_out", fp),
+                ("w_planes", fp), ("w_kexp", fp)]
 
 
 class AmaxDesc(C.Structure):
@@ -34,7 +35,13 @@ class GemmDgradDesc(C.Structure):
                 ("n_src", i32), ("accumulate", i32), ("pad_", i32),
                 ("dC", fp * MAX_SRC), ("W", fp * MAX_SRC), ("lddc", i64 * MAX_SRC), ("ldw", i64 * MAX_SRC),
                 ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC), ("relu_mask", fp), ("ldmask", i64),
-                ("amax_dc", fp * MAX_SRC), ("amax_w", fp * MAX_SRC), ("amax_out", fp)]
+                ("amax_dc", fp * MAX_SRC), ("amax_w", fp * MAX_SRC), ("amax_out", fp),
+                ("w_planes", fp * MAX_SRC), ("w_kexp", fp * MAX_SRC)]
+
+
+class PlanesDesc(C.Structure):
+    _fields_ = [("W", fp), ("planes", fp), ("rows", i64), ("ld", i64), ("cols", i32), ("layout", i32),
+                ("n_amax", i32), ("pad_", i32), ("amax", fp * MAX_SRC), ("kexp", fp)]
 
 
 class GemmWgradDesc(C.Structure):
@@ -122,6 +129,7 @@ _SIGS = {
     "mml_shard_rows": (C.c_int, [fp, i64, fp, i64, i32, i32, i32, i32, fp]),
     "mml_amax_batch": (C.c_int, [_PP(AmaxDesc), i32, fp]),
     "mml_amax_reset": (C.c_int, [fp, i64, fp]),
+    "mml_gemm_planes_cut": (C.c_int, [C.POINTER(PlanesDesc), i32, fp]),
     "mml_gemm_set_mode": (C.c_int, [i32]),
     "mml_gemm_get_mode": (C.c_int, []),
     "mml_gemm_last_kernel": (C.c_char_p, []),

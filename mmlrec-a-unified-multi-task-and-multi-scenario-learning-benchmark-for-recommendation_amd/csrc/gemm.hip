@@ -98,6 +98,77 @@ __device__ __forceinline__ void amax_publish(uint32_t am, uint32_t* slot, int sa
   if ((threadIdx.x & 63) == 0 && am) atomicMax(slot + (salt & (MML_AMAX_WORDS - 1)), am);
 }
 
+// ---- pre-cut weights (mml_gemm_planes_cut): the two fp16 planes of a weight matrix, laid out so that they travel through
+// the SAME global -> LDS image and fragment reads as the floats (see planes_of) ----
+constexpr int PLANES_PER_LAUNCH = 20;
+struct PlanesLaunch {
+  mml_planes_desc d[PLANES_PER_LAUNCH];
+  int32_t item0[PLANES_PER_LAUNCH + 1];  // first work item of matrix i (one item = one block of 16 along the reduction)
+  int32_t n;
+};
+// the lane's eight k of a 16-block, in fragment order: S_h = {4h .. 4h+3, 8+4h .. 8+4h+3} (RawFrag::get)
+__device__ __forceinline__ int planes_k(int h, int e) { return 4 * h + (e & 3) + 8 * (e >> 2); }
+__global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
+  const mml_planes_desc& D = L.d[blockIdx.y];
+  // the group's exponent, once per workgroup: lane w of the first n_amax * MML_AMAX_WORDS threads reads one slot word
+  __shared__ uint32_t mx;
+  if (threadIdx.x == 0) mx = 0u;
+  __syncthreads();
+  if ((int)threadIdx.x < D.n_amax * MML_AMAX_WORDS) {
+    const uint32_t* sl = D.amax[threadIdx.x / MML_AMAX_WORDS];
+    atomicMax(&mx, sl[threadIdx.x % MML_AMAX_WORDS]);
+  }
+  __syncthreads();
+  // (amax_scale_exp is monotone: the exponent of the largest magnitude is the smallest exponent of the group; an
+  // Inf / NaN pattern gives 0 like the in-kernel cut of the operand that holds it)
+  int k = amax_scale_exp(mx);
+  if (D.n_amax > 1 && (mx >> 23) >= 255u) {  // a non-finite slot must not hide the finite ones' exponents: redo per slot
+    k = 110;
+    for (int a = 0; a < D.n_amax; ++a) {
+      const int ka = amax_scale_exp(amax_load(D.amax[a]));
+      k = ka < k ? ka : k;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.kexp = k;
+  const float s = pow2f(k);
+  const int64_t total = L.item0[blockIdx.y + 1] - L.item0[blockIdx.y];
+  for (int64_t loc = (int64_t)blockIdx.x * 256 + threadIdx.x; loc < total; loc += (int64_t)gridDim.x * 256) {
+    float x[16];
+    int64_t base, stride;  // element e of the block sits at base + e * stride (floats / words)
+    if (D.layout == MML_PLANES_ROWS) {
+      const int nb = D.cols / 16;
+      const int64_t r = loc / nb;
+      base = r * D.ld + 16 * (loc - r * nb);
+      stride = 1;
+    } else {
+      const int64_t rb = loc / D.cols;
+      base = 16 * rb * D.ld + (loc - rb * D.cols);
+      stride = D.ld;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = D.W[base + e * stride];
+    uint32_t hp[16], lp[16];  // half bit patterns
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float y = x[e] * s;            // exact: s is a power of two
+      const _Float16 h = (_Float16)y;      // round to nearest even
+      const float r = y - (float)h;        // exact
+      const _Float16 l = (_Float16)r;
+      hp[e] = (uint32_t)__builtin_bit_cast(uint16_t, h);
+      lp[e] = (uint32_t)__builtin_bit_cast(uint16_t, l);
+    }
+    // word 4h + i = halves (S_h[2i], S_h[2i+1]) of the h plane, word 8 + 4h + i the same of the l plane
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k0 = planes_k(h, 2 * i), k1 = planes_k(h, 2 * i + 1);
+        D.planes[base + (4 * h + i) * stride] = hp[k0] | (hp[k1] << 16);
+        D.planes[base + (8 + 4 * h + i) * stride] = lp[k0] | (lp[k1] << 16);
+      }
+  }
+}
+
 struct Launch {
   Source src[MAX_SOURCES];
   Problem p[MML_MAX_GROUP];
@@ -483,6 +554,19 @@ __device__ __forceinline__ void prep_frag_b(const RawFrag<RC>& r, Prep<EMU>& o, 
   prep_frag<EMU>(r, o);
 }
 
+// BPL: a fragment of the pre-cut column operand IS its two planes (mml_gemm_planes_cut wrote the 8 halves of h where the
+// first four floats of the lane's 8 values would be, the 8 halves of l in place of the last four)
+__device__ __forceinline__ void planes_of(const RawFrag<true>& r, Prep<2>& o) {
+  o.h = __builtin_bit_cast(f16x8, r.q0);
+  o.l = __builtin_bit_cast(f16x8, r.q1);
+}
+__device__ __forceinline__ void planes_of(const RawFrag<false>& r, Prep<2>& o) {
+  const f32x4_t hh = __builtin_shufflevector(r.p0, r.p1, 0, 1, 2, 3);
+  const f32x4_t ll = __builtin_shufflevector(r.p2, r.p3, 0, 1, 2, 3);
+  o.h = __builtin_bit_cast(f16x8, hh);
+  o.l = __builtin_bit_cast(f16x8, ll);
+}
+
 // acc += rows(a) x cols(b); the COLUMN operand is the MFMA's A input (a lane then owns an output row, see epilogue)
 template <int EMU>
 __device__ __forceinline__ void mma_block(f32x16& acc, const Prep<EMU>& a, const Prep<EMU>& b) {
@@ -527,6 +611,49 @@ __device__ __forceinline__ void mma_prep_f16(f32x16& acc, const Prep<2>& a, cons
   f16_cut_l(c, 2);
   f16_cut_l(c, 3);
   f16_cut_done(c, o.h, o.l);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// BPL (the column operand arrives pre-cut): the cut of the ONE fragment a pair of product blocks has to prepare, dealt over
+// the six MFMAs of the pair: first block 6 + 4 + 6, second block 4 + 4 + 0 instructions.
+template <bool RC>
+__device__ __forceinline__ void mma_cut_first(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
+                                              const float scale, F16Cut& c) {
+  float x[8];
+  r.get(x);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_a2(x, scale, c, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_b2(x, scale, c, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_a2(x, scale, c, 2);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <bool RC>
+__device__ __forceinline__ void mma_cut_second(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
+                                               const float scale, F16Cut& c, Prep<2>& o) {
+  float x[8];
+  r.get(x);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_b2(x, scale, c, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  f16_cut_l(c, 0);
+  f16_cut_l(c, 1);
+  f16_cut_l(c, 2);
+  f16_cut_l(c, 3);
+  f16_cut_done(c, o.h, o.l);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -576,7 +703,10 @@ __device__ __forceinline__ float act_bwd_t(float y) {
 
 // BCOLS (weight-gradient launches only): the bias partials are batch sums of the COLUMN operand ([K,N] weights) instead
 // of the row operand; uniform per launch (the host groups problems by layout), so the per-step sums carry no branch.
-template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false>
+// BPL (EMU 2, forward / input-gradient launches): the column operand (the weights) arrives PRE-CUT -- Source::B points at
+// the plane image mml_gemm_planes_cut wrote (same shape, pitch and LDS image as the floats), Source::amaxB at the
+// exponent it was scaled with -- so its fragments are used as they land, without the in-register cut.
+template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false, bool BPL = false>
 // (128 x 64 input-gradient kernels: two workgroups per CU like the wide tiles -- their epilogue (mask words, Y, the
 // accumulate target) does not fit the 168 registers three would leave)
 __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
@@ -618,9 +748,17 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     const int s0 = L.p[pi].src0, ns = L.p[pi].nsrc;
     for (int s2 = 0; s2 < ns; ++s2) {
       const int ka = amax_scale_exp(amax_load(L.src[s0 + s2].amaxA));
-      const int kb = amax_scale_exp(amax_load(L.src[s0 + s2].amaxB));
       kA = ka < kA ? ka : kA;
-      kB = kb < kB ? kb : kB;
+      if constexpr (!BPL) {
+        const int kb = amax_scale_exp(amax_load(L.src[s0 + s2].amaxB));
+        kB = kb < kB ? kb : kB;
+      }
+    }
+    if constexpr (BPL) {  // the exponent the planes were cut with (one per problem: its sources were cut as a group)
+      kB = *reinterpret_cast<const int32_t*>(L.src[s0].amaxB);
+      // (the planes are what they are: where the exponents add up beyond fp32's range the row operand alone gives way)
+      if (kA + kB > 126) kA = 126 - kB;
+      if (kA + kB < -126) kA = -126 - kB;
     }
     // 1 / (sA sB) must be ONE fp32 number (the epilogue multiplies once): where the exponents add up beyond its range
     // -- two operands below 2^-48, whose products fp32 can barely hold -- both scales give way equally
@@ -1200,7 +1338,8 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
       }
     }
     prep_frag<EMU>(a0, PA0[0], cur.sA);
-    prep_frag_b<EMU>(b0, PB0[0], cur.sB);
+    if constexpr (BPL) planes_of(b0, PB0[0]);
+    else prep_frag_b<EMU>(b0, PB0[0], cur.sB);
   }
 
   auto step = [&](auto par_c) __attribute__((always_inline)) {
@@ -1243,7 +1382,12 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     __builtin_amdgcn_sched_barrier(0);
     Prep<EMU> PA1, PB1;
     if (NI == 2) {
-      if constexpr (EMU == 2) {
+      if constexpr (EMU == 2 && BPL) {
+        planes_of(RB1[P], PB1);
+        F16Cut c1;
+        mma_cut_first(acc[0][0], PA0[P], PB0[P], RA1[P], cur.sA, c1);
+        mma_cut_second(acc[0][NI - 1], PA0[P], PB1, RA1[P], cur.sA, c1, PA1);
+      } else if constexpr (EMU == 2) {
         mma_prep_f16(acc[0][0], PA0[P], PB0[P], RB1[P], cur.sB, PB1);
         mma_prep_f16(acc[0][NI - 1], PA0[P], PB1, RA1[P], cur.sA, PA1);
       } else {
@@ -1271,7 +1415,12 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
           bs_next[1] = sum8(RB1[Q]);
         }
       }
-      if constexpr (EMU == 2) {
+      if constexpr (EMU == 2 && BPL) {
+        planes_of(nb0, PB0[Q]);
+        F16Cut c2;
+        mma_cut_first(acc[1][0], PA1, PB0[P], na0, nsA, c2);
+        mma_cut_second(acc[1][NI - 1], PA1, PB1, na0, nsA, c2, PA0[Q]);
+      } else if constexpr (EMU == 2) {
         mma_prep_f16(acc[1][0], PA1, PB0[P], nb0, nsB, PB0[Q]);
         mma_prep_f16(acc[1][NI - 1], PA1, PB1, na0, nsA, PA0[Q]);
       } else {
@@ -1304,7 +1453,8 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
           bs_next[0] = sum8(nb0);
         }
       }
-      prep_frag_b<EMU>(nb0, PB0[Q], nsB);
+      if constexpr (BPL) planes_of(nb0, PB0[Q]);
+      else prep_frag_b<EMU>(nb0, PB0[Q], nsB);
       prep_frag<EMU>(na0, PA0[Q], nsA);
       mma_block<EMU>(acc[1][0], PA1, PB0[P]);
       pin_prep<EMU>(PB0[Q]);
@@ -1397,18 +1547,26 @@ struct TileChoice {
 };
 
 static thread_local char g_last_kernel[96] = "";
-static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, int mode, int bcols = -1) {
+static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, int mode, int bcols = -1,
+                        bool bpl = false) {
   if (bcols < 0)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d>", fam, arc ? "true" : "false",
              brc ? "true" : "false", bn, epi);
+  else if (bpl)  // (the symbol a profiler prints: trailing default template arguments are omitted, BPL = true is not)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s, true>", fam, arc ? "true" : "false",
+             brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false");
   else
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s>", fam, arc ? "true" : "false",
              brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false");
 }
 
+// planes / kexps (or null): per source of the launch, the pre-cut image of its column operand and the exponent slot
+// (mml_gemm_planes_cut); used when EVERY source has them and the launch runs the two-plane arithmetic on the LDS-DMA path
 template <int EPI>
-static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int64_t nblocks, hipStream_t st,
-                        const char* who) {
+static int launch_tiles(const Launch& Lin, bool arc, bool brc, TileChoice tc, int64_t nblocks, hipStream_t st,
+                        const char* who, const uint32_t* const* planes = nullptr, const int32_t* const* kexps = nullptr) {
+  Launch Lcopy;
+  const Launch* Lp = &Lin;
   const int bn = tc.bn;
   if (nblocks <= 0) return MML_OK;
   if (nblocks > 0x7fffffff) {
@@ -1419,11 +1577,37 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   int emu = tc.emu;  // 0 = fp32 MFMA, 1 = bf16 operands, 2 = two scaled fp16 planes, 3 = three bf16 planes
   if (emu == 3 && gemm_mode() != 3) {  // every operand of the launch comes with its magnitude: two fp16 planes
     bool all = true;
-    for (int i = 0; i < L.n && all; ++i)
-      for (int s = 0; s < L.p[i].nsrc && all; ++s)
-        all = L.src[L.p[i].src0 + s].amaxA != nullptr && L.src[L.p[i].src0 + s].amaxB != nullptr;
+    for (int i = 0; i < Lin.n && all; ++i)
+      for (int s = 0; s < Lin.p[i].nsrc && all; ++s)
+        all = Lin.src[Lin.p[i].src0 + s].amaxA != nullptr && Lin.src[Lin.p[i].src0 + s].amaxB != nullptr;
     if (all) emu = 2;
   }
+  bool bpl = false;
+  if (EPI != EPI_SLAB && emu == 2 && planes && kexps && pipe_ok(Lin, arc, brc, bn, EPI)) {
+    static int use = -1;
+    if (use < 0) {
+      const char* e = getenv("MMLREC_GEMM_PLANES");  // 0: ignore pre-cut weights (A/B switch)
+      use = e ? atoi(e) : 1;
+    }
+    bpl = use != 0;
+    for (int i = 0; i < Lin.n && bpl; ++i)
+      for (int s = 0; s < Lin.p[i].nsrc && bpl; ++s) {
+        const int si = Lin.p[i].src0 + s;
+        // (one exponent per problem: the kernel reads the first source's)
+        bpl = planes[si] && kexps[si] && aligned16(planes[si]) && kexps[si] == kexps[Lin.p[i].src0];
+      }
+    if (bpl) {
+      Lcopy = Lin;
+      for (int i = 0; i < Lin.n; ++i)
+        for (int s = 0; s < Lin.p[i].nsrc; ++s) {
+          const int si = Lin.p[i].src0 + s;
+          Lcopy.src[si].B = reinterpret_cast<const float*>(planes[si]);
+          Lcopy.src[si].amaxB = reinterpret_cast<const uint32_t*>(kexps[si]);
+        }
+      Lp = &Lcopy;
+    }
+  }
+  const Launch& L = *Lp;
   const bool bcols = (EPI == EPI_SLAB) && L.n > 0 && L.p[0].bias_cols != 0;  // (uniform per launch: see the wgrad entry)
   (void)bcols;
   // The weight-gradient GEMMs run on a side stream next to the HBM-bound table optimizer (trainer.py).  An unused
@@ -1434,7 +1618,7 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
   }
   const size_t dyn = (EPI == EPI_SLAB) ? (size_t)g_wgrad_pad : 0;
   if (pipe_ok(L, arc, brc, bn, EPI)) {
-    note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, emu, bcols ? 1 : 0);
+    note_kernel("gemm_pipe_kernel", arc, brc, bn, EPI, emu, bcols ? 1 : 0, bpl);
     // persistent workgroups: one per resident slot (128 x 128 tiles: 2 per CU; 128 x 64: 3), each loops over tiles
     static int cus = 0;
     if (cus == 0) {
@@ -1447,12 +1631,19 @@ static int launch_tiles(const Launch& L, bool arc, bool brc, TileChoice tc, int6
     const int64_t slots = (int64_t)cus * ((bn == 64 && EPI != EPI_DGRAD) ? 3 : 2);
     if (nblocks > slots) g = dim3((unsigned)slots);
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
-#define MML_GL(A_, B_) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU, false>), g, b, dyn, st, L)
+#define MML_GL(A_, B_)                                                                                            \
+  do {                                                                                                            \
+    if (bpl) MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU, false, (EPI != EPI_SLAB && MML_LAB_EMU == 2)>), \
+                        g, b, dyn, st, L);                                                                        \
+    else MML_LAUNCH((gemm_pipe_kernel<A_, B_, MML_LAB_BN, EPI, MML_LAB_EMU, false>), g, b, dyn, st, L);           \
+  } while (0)
 #else
 #define MML_GL3(A_, B_, N_, C_)                                                              \
   do {                                                                                       \
     if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);       \
     else if (emu == 1) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 1, C_>), g, b, dyn, st, L);  \
+    else if (emu == 2 && bpl)                                                                     \
+      MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2, C_, (EPI != EPI_SLAB)>), g, b, dyn, st, L); \
     else if (emu == 2) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2, C_>), g, b, dyn, st, L);  \
     else MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, C_>), g, b, dyn, st, L);                \
   } while (0)
@@ -1550,6 +1741,43 @@ extern "C" int mml_gemm_set_mode(int32_t mode) {
 
 extern "C" int mml_gemm_get_mode(void) { return gemm_mode(); }
 
+extern "C" int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_planes_cut: bad descriptor array");
+  int i = 0;
+  while (i < n) {
+    PlanesLaunch L{};
+    int64_t items = 0;
+    while (i < n && L.n < PLANES_PER_LAUNCH) {
+      const mml_planes_desc& q = d[i];
+      MML_REQUIRE(q.W && q.planes && q.kexp && q.rows >= 0 && q.cols >= 0 && q.ld >= q.cols,
+                  "mml_gemm_planes_cut: matrix %d malformed", i);
+      MML_REQUIRE(q.layout == MML_PLANES_ROWS || q.layout == MML_PLANES_COLS, "mml_gemm_planes_cut: layout of matrix %d", i);
+      MML_REQUIRE(q.layout == MML_PLANES_ROWS ? q.cols % 16 == 0 : q.rows % 16 == 0,
+                  "mml_gemm_planes_cut: the reduction extent of matrix %d is not a multiple of 16", i);
+      MML_REQUIRE(q.n_amax >= 1 && q.n_amax <= MML_MAX_SRC, "mml_gemm_planes_cut: matrix %d needs 1..%d magnitude slots", i,
+                  MML_MAX_SRC);
+      for (int a = 0; a < q.n_amax; ++a) MML_REQUIRE(q.amax[a], "mml_gemm_planes_cut: null magnitude slot (matrix %d)", i);
+      const int64_t it = q.layout == MML_PLANES_ROWS ? q.rows * (q.cols / 16) : (q.rows / 16) * q.cols;
+      MML_REQUIRE(items + it < 0x7fffffff, "mml_gemm_planes_cut: too many blocks");
+      L.item0[L.n] = (int32_t)items;
+      L.d[L.n++] = q;
+      items += it;
+      ++i;
+    }
+    L.item0[L.n] = (int32_t)items;
+    if (items == 0) continue;
+    int64_t most = 0;
+    for (int k = 0; k < L.n; ++k) most = (L.item0[k + 1] - L.item0[k]) > most ? (L.item0[k + 1] - L.item0[k]) : most;
+    int64_t nb = cdiv(most, 256);
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    MML_LAUNCH(planes_cut_kernel, dim3((unsigned)nb, (unsigned)L.n), dim3(256), 0, to_stream(stream), L);
+    int rc = check_launch("mml_gemm_planes_cut");
+    if (rc) return rc;
+  }
+  return MML_OK;
+}
+
 extern "C" const char* mml_gemm_last_kernel(void) { return g_last_kernel; }
 
 
@@ -1567,6 +1795,8 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     int j = i;
     int32_t Ns[MML_MAX_GROUP];
     Launch L{};
+    const uint32_t* planes[MAX_SOURCES] = {};
+    const int32_t* kexps[MAX_SOURCES] = {};
     while (j < n && j - i < MML_MAX_GROUP && d[j].w_kn == d[i].w_kn && d[j].M == d[i].M) {
       const mml_gemm_fwd_desc& q = d[j];
       MML_REQUIRE(q.A && q.W && q.C, "mml_gemm_grouped_fwd: null pointer in problem %d", j);
@@ -1580,6 +1810,8 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
       S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
       S0.amaxA = q.amax_a; S0.amaxB = q.amax_w;
+      planes[j - i] = q.w_kn == 0 ? q.w_planes : nullptr;
+      kexps[j - i] = q.w_kn == 0 ? q.w_kexp : nullptr;
       P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
       MML_REQUIRE(!q.relu_mask || q.ldmask * 32 >= q.N, "mml_gemm_grouped_fwd: ldmask too small in problem %d", j);
@@ -1602,7 +1834,7 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     L.total_ntiles = t;
     L.tiles_m = (int)cdiv(d[i].M, BM);
     int rc = launch_tiles<EPI_FWD>(L, true, d[i].w_kn == 0, tc, (int64_t)L.tiles_m * t, to_stream(stream),
-                                   "mml_gemm_grouped_fwd");
+                                   "mml_gemm_grouped_fwd", planes, kexps);
     if (rc) return rc;
     i = j;
   }
@@ -1618,6 +1850,8 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     Launch L{};
     const int32_t lay = d[i].n_src > 0 ? d[i].w_kn[0] : 0;
     int nsources = 0;
+    const uint32_t* planes[MAX_SOURCES] = {};
+    const int32_t* kexps[MAX_SOURCES] = {};
     while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) {
       const mml_gemm_dgrad_desc& q = d[j];
       MML_REQUIRE(q.dA && q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", j);
@@ -1637,6 +1871,8 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
         S.Kred = q.N[s];
         S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
         S.amaxA = q.amax_dc[s]; S.amaxB = q.amax_w[s];
+        planes[nsources - 1] = lay == 0 ? q.w_planes[s] : nullptr;
+        kexps[nsources - 1] = lay == 0 ? q.w_kexp[s] : nullptr;
       }
       P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
@@ -1667,7 +1903,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     L.tiles_m = (int)cdiv(d[i].M, BM);
     // col operand = W: reduction index is W's row for [N,K] (not contiguous) and contiguous for [K,N]
     int rc = launch_tiles<EPI_DGRAD>(L, true, lay == 1, tc, (int64_t)L.tiles_m * t, to_stream(stream),
-                                     "mml_gemm_grouped_dgrad");
+                                     "mml_gemm_grouped_dgrad", planes, kexps);
     if (rc) return rc;
     i = j;
   }

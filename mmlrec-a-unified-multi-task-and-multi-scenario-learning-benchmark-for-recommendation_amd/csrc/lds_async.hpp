@@ -165,6 +165,30 @@ __device__ __forceinline__ void f16_cut_hr2(const float (&x)[8], const float s, 
       : "=v"(c.r1[j + 1])
       : "v"(x[2 * j + 3]), "s"(s), "v"(c.h[j + 1]));
 }
+// The same two pairs in two pieces, for launches whose column operand arrives pre-cut (gemm.hip: BPL): the cut of the
+// one remaining fragment is spread over the six MFMAs of TWO product blocks, 6 + 4 + 6 | 4 + 4 instructions -- about what
+// one wave can issue in the shadow of an MFMA (one VALU instruction per ~6 clocks, tools/lab/micro/valu_rate.hip).
+__device__ __forceinline__ void f16_cut_a2(const float (&x)[8], const float s, F16Cut& c, const int j) {
+  float y0, y1, y2, y3;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x[2 * j]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x[2 * j + 1]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y2) : "v"(x[2 * j + 2]), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y3) : "v"(x[2 * j + 3]), "s"(s));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.h[j]) : "v"(y0), "v"(y1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.h[j + 1]) : "v"(y2), "v"(y3));
+}
+__device__ __forceinline__ void f16_cut_b2(const float (&x)[8], const float s, F16Cut& c, const int j) {
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.r0[j]) : "v"(x[2 * j]), "s"(s), "v"(c.h[j]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=v"(c.r1[j])
+      : "v"(x[2 * j + 1]), "s"(s), "v"(c.h[j]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+      : "=v"(c.r0[j + 1])
+      : "v"(x[2 * j + 2]), "s"(s), "v"(c.h[j + 1]));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=v"(c.r1[j + 1])
+      : "v"(x[2 * j + 3]), "s"(s), "v"(c.h[j + 1]));
+}
 __device__ __forceinline__ void f16_cut_l(F16Cut& c, const int j) {
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(c.l[j]) : "v"(c.r0[j]), "v"(c.r1[j]));
 }

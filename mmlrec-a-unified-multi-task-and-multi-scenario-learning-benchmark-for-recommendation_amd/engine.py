@@ -108,6 +108,10 @@ class Plan:
         self.amax_next = 0
         self.amax_weights = {}   # (data_ptr, shape) -> slot
         self.amax_wlist = []     # (tensor, slot) of the stable weights
+        # pre-cut weights (mml_gemm_planes_cut): the two fp16 planes of every stable weight the forward / input-gradient
+        # GEMMs read, cut once at the start of a step instead of by every wave that stages a fragment of it
+        self.planes_items = []   # (W, planes, layout, [slots], kexp)
+        self.planes_cache = {}
         self.n_pre = 0           # entries of `fwd` that precede the first op's calls
 
     # ---- buffers -----------------------------------------------------------------------------
@@ -174,6 +178,34 @@ class Plan:
         else:
             need.append((pv.data, slot))  # (not cached: re-measured by every launch that reads it -- it may change)
         return slot
+
+    def weight_planes(self, q, layout, group=None):
+        """(planes, kexp) of problem q's weight for the forward (layout ROWS: its own exponent) or as one source of an
+        input-gradient problem (layout COLS: `group` = the problems whose weights feed the same output, ONE exponent), or
+        (None, None): only stable weights in nn.Linear layout whose magnitude is taken at the start of the step, with a
+        reduction extent the plane image can hold, and not the zero-padded copies."""
+        if (self.amax_pool is None or os.environ.get("MMLREC_GEMM_PLANES", "1") == "0" or q.get("w_kn", 0) or "Wp" in q):
+            return None, None
+        qs = [q] if group is None else group
+        slots = []
+        for g in qs:
+            W = g["W"]
+            key = (W.data.data_ptr(), tuple(W.data.shape))
+            if (g.get("w_kn", 0) or "Wp" in g or not getattr(W, "stable", False) or key not in self.amax_weights or
+                    W.data.dim() != 2 or W.data.stride(1) != 1 or W.data.shape[layout == ops.PLANES_ROWS] % 16 or
+                    W.data.data_ptr() % 16 or W.data.stride(0) % 4):
+                return None, None
+            slots.append(self.amax_weights[key])
+        W = q["W"].data
+        ck = (W.data_ptr(), tuple(W.shape), layout, tuple(sl.data_ptr() for sl in slots))
+        if ck not in self.planes_cache:
+            gk = ("kexp", layout, tuple(sl.data_ptr() for sl in slots))  # one exponent word per group
+            if gk not in self.planes_cache:
+                self.planes_cache[gk] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            planes = torch.zeros(W.shape[0], W.stride(0), dtype=torch.int32, device=self.device)[:, :W.shape[1]]
+            self.planes_cache[ck] = (planes, self.planes_cache[gk])
+            self.planes_items.append((W, planes, layout, slots, self.planes_cache[gk]))
+        return self.planes_cache[ck]
 
     def value_amax(self, v, view, need):
         """Slot of a forward value used as a GEMM operand: the producer's, or measured now (once)."""
@@ -335,6 +367,11 @@ class Plan:
                 dict(kernel="amax_reset", bytes=32.0 * self.amax_next))]
         if self.amax_wlist:
             pre.append(self.amax_call(self.amax_wlist))
+        if self.planes_items:  # (after the magnitudes of the weights: the cut reads them)
+            arr = ops.make_planes_descs(self.planes_items)
+            self.keep.append(arr)
+            pre.append((L.load().mml_gemm_planes_cut, (arr, len(self.planes_items)),
+                        dict(kernel="planes_cut_kernel", bytes=8.0 * sum(it[0].numel() for it in self.planes_items))))
         self.fwd = pre + self.fwd
         self.n_pre = len(pre)
 
@@ -578,11 +615,16 @@ class LinearGroupOp(Op):
                 q["out"].amax = plan.new_amax()
         if need:
             pre.append(plan.amax_call(need))
+        # pre-cut weights: all problems of the launch or none (the kernel takes the planes form per launch)
+        wp = [plan.weight_planes(q, ops.PLANES_ROWS) for q in self.p]
+        if any(pl is None for pl, _ in wp):
+            wp = [(None, None)] * len(self.p)
         descs = ops.make_fwd_descs([dict(A=q.get("Ap", q["x"].buf), W=q.get("Wp", q["W"].data),
                                          bias=q["b"].data if q.get("b") else None,
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
                                          mask=q["out"].mask, amax_a=q["amax_a"], amax_w=q["amax_w"],
-                                         amax_out=q["out"].amax) for q in self.p])
+                                         amax_out=q["out"].amax, w_planes=pl, w_kexp=kx)
+                                    for q, (pl, kx) in zip(self.p, wp)])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
         meta = dict(kernel=_gemm_symbol(True, not kn, [q["out"].n for q in self.p], 0,
@@ -696,12 +738,17 @@ class LinearGroupOp(Op):
                     out_slot = x.gamax
                 else:
                     out_slot = None
+                # the weights that feed this input gradient, cut as one group (common exponent)
+                gp = [plan.weight_planes(q, ops.PLANES_COLS, ch) for q in ch] if not padded else [(None, None)]
+                if any(pl is None for pl, _ in gp):
+                    gp = [(None, None)] * len(ch)
                 waves[ci].append(dict(dA=_padded_view(x.grad, x.kpad) if padded else x.grad,
                                       Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
                                       mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
                                       accumulate=acc, amax_out=out_slot,
                                       srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0),
-                                             q["amax_dc"], q["amax_w"]) for q in ch]))
+                                             q["amax_dc"], q["amax_w"]) + ((pl, kx) if pl is not None else ())
+                                            for q, (pl, kx) in zip(ch, gp)]))
             if fuse:
                 x.deriv_applied = True
         for dg in waves:

@@ -215,11 +215,37 @@ def make_fwd_descs(problems):
         d.relu_mask = L.ptr(m)
         d.ldmask = _ld(m) if m is not None else 0
         d.amax_a, d.amax_w, d.amax_out = L.ptr(p.get("amax_a")), L.ptr(p.get("amax_w")), L.ptr(p.get("amax_out"))
+        d.w_planes, d.w_kexp = L.ptr(p.get("w_planes")), L.ptr(p.get("w_kexp"))  # pre-cut weight (planes_cut)
     return arr
 
 
 # ---- operand magnitudes (include/mmlrec.h): slots of MML_AMAX_WORDS words --------------------------------------
 AMAX_WORDS = 8
+PLANES_ROWS, PLANES_COLS = 0, 1
+
+
+def make_planes_descs(items):
+    """items: (W [rows, cols] view, planes int32 tensor of W's shape and pitch, layout, [magnitude slots], kexp int32
+    [1] tensor) -> the descriptor block of mml_gemm_planes_cut."""
+    arr = (L.PlanesDesc * len(items))()
+    for d, (W, planes, layout, slots, kexp) in zip(arr, items):
+        if planes.shape != W.shape or _ld(planes) != _ld(W):
+            raise L.MMLError("planes buffer must have the weight's shape and pitch")
+        d.W, d.planes = W.data_ptr(), planes.data_ptr()
+        d.rows, d.cols = W.shape
+        d.ld = _ld(W)
+        d.layout = int(layout)
+        d.n_amax = len(slots)
+        for a, sl in enumerate(slots):
+            d.amax[a] = sl.data_ptr()
+        d.kexp = kexp.data_ptr()
+    return arr
+
+
+def planes_cut(items):
+    """Cut weight matrices into their two fp16 planes once (include/mmlrec.h: mml_gemm_planes_cut)."""
+    arr = make_planes_descs(items)
+    L.check(L.load().mml_gemm_planes_cut(arr, len(items), _stream()), "mml_gemm_planes_cut")
 
 
 def amax_slots(n, device):
@@ -293,8 +319,10 @@ def make_dgrad_descs(problems):
             d.lddc[s], d.ldw[s] = _ld(dC), _ld(W)
             d.N[s] = dC.shape[1]
             d.w_kn[s] = int(w_kn)
-            if len(src) > 3:  # (dC, W, w_kn, magnitude slot of dC, magnitude slot of W)
+            if len(src) > 3:  # (dC, W, w_kn, magnitude slot of dC, magnitude slot of W[, planes of W, their exponent])
                 d.amax_dc[s], d.amax_w[s] = L.ptr(src[3]), L.ptr(src[4])
+            if len(src) > 5:
+                d.w_planes[s], d.w_kexp[s] = L.ptr(src[5]), L.ptr(src[6])
         m = p.get("mask")
         d.relu_mask = L.ptr(m)
         d.ldmask = _ld(m) if m is not None else 0

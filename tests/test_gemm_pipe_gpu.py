@@ -261,3 +261,135 @@ def test_amax_of_fallback_kernel_and_nonfinite(env):
     ops.amax_batch([(A2, s2[0]), (W2, s2[1])])
     ops.gemm_fwd([dict(A=A2, W=W2, bias=None, C=C2, act=L.ACT_NONE, amax_a=s2[0], amax_w=s2[1])])
     assert not torch.isfinite(C2[3]).all() and torch.isfinite(C2[4]).all()
+
+
+def _cut_ref(W, k):
+    """numpy restatement of the two-plane cut (csrc/lds_async.hpp, csrc/gemm.hip: planes_cut_kernel): h = rne16(w 2^k),
+    l = rne16(w 2^k - h), as uint16 bit patterns."""
+    y = W.astype(np.float32) * np.float32(2.0 ** k)
+    h = y.astype(np.float16)
+    l = (y - h.astype(np.float32)).astype(np.float16)
+    return h.view(np.uint16).astype(np.uint32), l.view(np.uint16).astype(np.uint32)
+
+
+def _planes_ref(W, k, layout):
+    """Expected plane image (include/mmlrec.h: mml_gemm_planes_cut): per block of 16 along the reduction, word 4h + i =
+    h-plane halves (S_h[2i], S_h[2i+1]), word 8 + 4h + i = the same of the l plane, S_h = (4h..4h+3, 8+4h..8+4h+3)."""
+    hb, lb = _cut_ref(W, k)
+    if layout == 1:
+        hb, lb = hb.T, lb.T  # reduction down the rows: work on the transpose, transpose back
+    R, Cn = hb.shape
+    out = np.zeros((R, Cn), dtype=np.uint32)
+    S = [[4 * h + (e & 3) + 8 * (e >> 2) for e in range(8)] for h in range(2)]
+    for b in range(Cn // 16):
+        blk_h, blk_l = hb[:, 16 * b:16 * b + 16], lb[:, 16 * b:16 * b + 16]
+        for h in range(2):
+            for i in range(4):
+                k0, k1 = S[h][2 * i], S[h][2 * i + 1]
+                out[:, 16 * b + 4 * h + i] = blk_h[:, k0] | (blk_h[:, k1] << 16)
+                out[:, 16 * b + 8 + 4 * h + i] = blk_l[:, k0] | (blk_l[:, k1] << 16)
+    return out.T.copy() if layout == 1 else out
+
+
+def _kexp(amax):
+    e = (np.float32(amax).view(np.uint32) >> 23) & 0xff
+    return int(np.clip(141 - int(e), -110, 110))
+
+
+@pytest.mark.parametrize("scale_w", [1e-4, 1.0, 3e5])
+def test_planes_cut_image_and_exponent(env, scale_w):
+    """mml_gemm_planes_cut against the numpy restatement: both layouts, a pitched weight, a group of two magnitudes."""
+    torch, L, ops, lib = env
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, K = 96, 80
+    buf = torch.zeros(N, K + 16, device=dev)
+    W = buf[:, :K]
+    W.copy_((torch.randn(N, K, generator=g) * scale_w).to(dev))
+    W2 = (torch.randn(48, 64, generator=g) * scale_w * 8).to(dev)
+    slots = ops.amax_slots(2, dev)
+    ops.amax_batch([(W, slots[0]), (W2, slots[1])])
+    pr = torch.zeros(N, K + 16, dtype=torch.int32, device=dev)[:, :K]
+    pc = torch.zeros(N, K + 16, dtype=torch.int32, device=dev)[:, :K]
+    p2 = torch.zeros(48, 64, dtype=torch.int32, device=dev)
+    kx = torch.full((3,), 12345, dtype=torch.int32, device=dev)
+    ops.planes_cut([(W, pr, ops.PLANES_ROWS, [slots[0]], kx[0:1]),
+                    (W, pc, ops.PLANES_COLS, [slots[0], slots[1]], kx[1:2]),   # group of two: the larger magnitude rules
+                    (W2, p2, ops.PLANES_COLS, [slots[1], slots[0]], kx[2:3])])
+    torch.cuda.synchronize()
+    k_own = _kexp(float(W.abs().max()))
+    k_grp = min(k_own, _kexp(float(W2.abs().max())))
+    assert kx.tolist() == [k_own, k_grp, k_grp]
+    Wn = W.cpu().numpy()
+    assert np.array_equal(pr.cpu().numpy().view(np.uint32), _planes_ref(Wn, k_own, 0))
+    assert np.array_equal(pc.cpu().numpy().view(np.uint32), _planes_ref(Wn, k_grp, 1))
+    assert np.array_equal(p2.cpu().numpy().view(np.uint32), _planes_ref(W2.cpu().numpy(), k_grp, 1))
+    with pytest.raises(L.MMLError):  # reduction extent not a multiple of 16
+        ops.planes_cut([(W[:, :72], pr[:, :72], ops.PLANES_ROWS, [slots[0]], kx[0:1])])
+
+
+@pytest.mark.parametrize("M,K,Ns", [(1000, 240, [256, 256, 64]), (70000, 128, [128, 128]), (300, 32, [128, 4]),
+                                    (4096 + 37, 48, [100])])
+def test_pipe_fwd_with_precut_weights_is_bitwise_the_in_kernel_cut(env, M, K, Ns, monkeypatch):
+    """Forward launches whose weights arrive as pre-cut planes give the SAME bits as the launches that cut the weight
+    fragments in registers (same planes, same products, same order), and run the planes kernel."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    A = (torch.randn(M, K, generator=g) * 3e-3).to(dev)
+    Ws = [(torch.randn(n, K, generator=g) * 1e-4).to(dev) for n in Ns]
+    bs = [torch.randn(n, generator=g).to(dev) * 1e-6 for n in Ns]
+    slots = ops.amax_slots(1 + len(Ns), dev)
+    ops.amax_batch([(A, slots[0])] + [(w, slots[1 + i]) for i, w in enumerate(Ws)])
+    planes = [torch.zeros(w.shape, dtype=torch.int32, device=dev) for w in Ws]
+    kx = torch.zeros(len(Ns), dtype=torch.int32, device=dev)
+    ops.planes_cut([(w, p, ops.PLANES_ROWS, [slots[1 + i]], kx[i:i + 1]) for i, (w, p) in enumerate(zip(Ws, planes))])
+    outs = []
+    for use in (False, True):
+        Cs = [torch.empty(M, n, device=dev) for n in Ns]
+        probs = [dict(A=A, W=w, bias=b, C=c, act=L.ACT_RELU, amax_a=slots[0], amax_w=slots[1 + i])
+                 for i, (w, b, c) in enumerate(zip(Ws, bs, Cs))]
+        if use:
+            for i, p in enumerate(probs):
+                p.update(w_planes=planes[i], w_kexp=kx[i:i + 1])
+        ops.gemm_fwd(probs)
+        torch.cuda.synchronize()
+        name = lib.mml_gemm_last_kernel().decode()
+        assert ", 2, false" in name and name.endswith(", true>") == use, name
+        outs.append([c.cpu().numpy() for c in Cs])
+    for a, b, w, bias in zip(outs[0], outs[1], Ws, bs):
+        assert np.array_equal(a, b)
+        ref = torch.relu(A.double() @ w.double().t() + bias.double())
+        assert rel(torch.from_numpy(b).to(dev), ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,srcNs,accumulate", [(1000, 240, [256, 256, 64, 64], 0), (70000, 256, [128], 1),
+                                                  (300, 64, [48, 16], 0)])
+def test_pipe_dgrad_with_precut_weights_is_bitwise_the_in_kernel_cut(env, M, K, srcNs, accumulate):
+    """The same for the input gradient: the weights of a problem's sources are cut as ONE group (common exponent)."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + K + 1)
+    dCs = [(torch.randn(M, n, generator=g) * 1e-6).to(dev) for n in srcNs]
+    Ws = [(torch.randn(n, K, generator=g) * (1e-4 * (1 + 3 * i))).to(dev) for i, n in enumerate(srcNs)]
+    ns = len(srcNs)
+    slots = ops.amax_slots(2 * ns, dev)
+    ops.amax_batch([(t, slots[i]) for i, t in enumerate(dCs + Ws)])
+    planes = [torch.zeros(w.shape, dtype=torch.int32, device=dev) for w in Ws]
+    kx = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.planes_cut([(w, p, ops.PLANES_COLS, [slots[ns + i] for i in range(ns)], kx) for w, p in zip(Ws, planes)])
+    base = torch.randn(M, K, generator=g).to(dev) * 1e-9
+    outs = []
+    for use in (False, True):
+        dA = base.clone()
+        srcs = [(dCs[i], Ws[i], 0, slots[i], slots[ns + i]) + ((planes[i], kx) if use else ()) for i in range(ns)]
+        ops.gemm_dgrad([dict(dA=dA, Y=None, act=L.ACT_NONE, accumulate=accumulate, srcs=srcs)])
+        torch.cuda.synchronize()
+        name = lib.mml_gemm_last_kernel().decode()
+        assert ", 2, false" in name and name.endswith(", true>") == use, name
+        outs.append(dA.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    ref = sum(dc.double() @ w.double() for dc, w in zip(dCs, Ws)) + (base.double() if accumulate else 0)
+    assert rel(torch.from_numpy(outs[1]).to(dev), ref) < 2e-6

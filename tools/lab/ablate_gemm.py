@@ -61,6 +61,34 @@ def nomfma(s):
     return s
 
 
+NOCUT_FN = '''
+template <bool RC>
+__device__ __forceinline__ void mma_prep_f16_nocut(f32x16& acc, const Prep<2>& a, const Prep<2>& b, const RawFrag<RC>& r,
+                                                   const float scale, Prep<2>& o) {
+  float x[8];
+  r.get(x);
+  __builtin_amdgcn_sched_barrier(0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l, a.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h, a.h, acc, 0, 0, 0);
+  { typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ a_ = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    const u32x4_ b_ = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+    o.h = __builtin_bit_cast(f16x8, a_); o.l = __builtin_bit_cast(f16x8, b_); }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Keeps a prepared operand's conversion where it was written'''
+
+
+def nocut_b(s):
+    """what pre-cut weight planes could give at best: the column operand's fragments arrive as planes (no cut)"""
+    s = sub(s, "\n// Keeps a prepared operand's conversion where it was written", NOCUT_FN)
+    s = sub(s, "mma_prep_f16(acc[0][0], PA0[P], PB0[P], RB1[P], cur.sB, PB1);", "mma_prep_f16_nocut(acc[0][0], PA0[P], PB0[P], RB1[P], cur.sB, PB1);")
+    s = sub(s, "mma_prep_f16(acc[1][0], PA1, PB0[P], nb0, nsB, PB0[Q]);", "mma_prep_f16_nocut(acc[1][0], PA1, PB0[P], nb0, nsB, PB0[Q]);")
+    return s
+
+
 VARIANTS = {
     "base": lambda s: s,
     "nobar": lambda s: sub(s, STEP_BARRIER, STEP_BARRIER.replace("    __builtin_amdgcn_s_barrier();\n", "")),
@@ -70,6 +98,7 @@ VARIANTS = {
     "noreads": lambda s: sub(s, READS, ""),
     "nocut": lambda s: sub(sub(sub(s, CUT_HR, ""), CUT_HR2, ""), CUT_L, NOCUT_DONE),
     "nomfma": nomfma,
+    "nocutB": nocut_b,
     "nocut_noreads": lambda s: VARIANTS["nocut"](VARIANTS["noreads"](s)),
     "nocut_nobar_nowait": lambda s: VARIANTS["nocut"](VARIANTS["nobar_nowait"](s)),
 }
