@@ -76,7 +76,16 @@ extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t st
       // 16 elements (four 16-byte loads, all in flight at once) per thread where the tensor is large enough to give
       // every CU work that way; beyond 8192 workgroups the threads loop
       int64_t nb = cdiv(q.rows * (int64_t)q.cols, 256 * 16);
-      if (nb > 2048) nb = 2048;  // (8192 workgroups with a quarter of the work each: 58 us instead of 40 -- their atomics)
+      static int cap = 0;
+      if (!cap) {
+        const char* e = getenv("MMLREC_AMAX_BLOCKS");  // lab knob
+        cap = e ? atoi(e) : 256;
+      }
+      // One atomic per workgroup ends the kernel, all of them on the slot's one 32-byte line (~8 ns each, serialised):
+      // the input of the first layer ([65 536, 240]) took 54 us with 4 096 workgroups, 35 with 2 048, 29 with 1 024, 20-21
+      // with 128 .. 384 (warm caches, eager launch included; tools/lab/bench_amax.py).  One workgroup per CU streams
+      // enough (eight 16-byte loads in flight per thread).
+      if (nb > cap) nb = cap;
       L.blk0[L.n] = total;
       L.t[L.n++] = q;
       total += (int)nb;
