@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const AmaxLaunch L) {
     }
   }
   // (Inf / NaN: the integer pattern of an Inf is what the consumers test for; a NaN does not register -- see amax_acc)
-  amax_flush(amf, T.slot);
+  amax_flush<true>(amf, T.slot);
 }
 
 __global__ __launch_bounds__(256) void amax_reset_kernel(uint32_t* slots, int64_t words) {
@@ -79,12 +79,12 @@ extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t st
       static int cap = 0;
       if (!cap) {
         const char* e = getenv("MMLREC_AMAX_BLOCKS");  // lab knob
-        cap = e ? atoi(e) : 256;
+        cap = e ? atoi(e) : 1024;
       }
-      // One atomic per workgroup ends the kernel, all of them on the slot's one 32-byte line (~8 ns each, serialised):
-      // the input of the first layer ([65 536, 240]) took 54 us with 4 096 workgroups, 35 with 2 048, 29 with 1 024, 20-21
-      // with 128 .. 384 (warm caches, eager launch included; tools/lab/bench_amax.py).  One workgroup per CU streams
-      // enough (eight 16-byte loads in flight per thread).
+      // One atomic per workgroup ended the kernel, all of them on the slot's one 32-byte line (~8 ns each, serialised):
+      // the input of the first layer ([65 536, 240]) took 54 us with 4 096 workgroups, 35 with 2 048, 20-21 with 128 .. 384
+      // (warm caches, eager launch included; tools/lab/bench_amax.py).  Since the workgroups look at the slot before the
+      // atomic (amax_flush<true>) the count no longer matters: 20 us at 256, 2 048 and 4 096.
       if (nb > cap) nb = cap;
       L.blk0[L.n] = total;
       L.t[L.n++] = q;

@@ -34,6 +34,7 @@ __device__ __forceinline__ void amax_acc(float& am, const float4& v) {
 // cheaper than the atomic it would save (measured on the gather: 15 000 workgroups -> +0.1 ms either way, so the
 // gather's output is measured by the stand-alone pass instead).
 // (A NaN never registers in the running maximum; it reaches the consumer as a NaN whatever the scale.)
+template <bool LOOK = false>
 __device__ __forceinline__ void amax_flush(float amf, uint32_t* slot) {
   if (!slot) return;  // (uniform)
   __shared__ float amax_wg[16];
@@ -46,7 +47,17 @@ __device__ __forceinline__ void amax_flush(float amf, uint32_t* slot) {
     float m = amax_wg[0];
     for (int w = 1; w < nw; ++w) m = fmaxf(m, amax_wg[w]);
     const uint32_t am = __float_as_uint(m);
-    if (am) atomicMax(slot + (blockIdx.x & (MML_AMAX_WORDS - 1)), am);
+    // LOOK before the atomic: the words only ever rise, so a workgroup whose maximum is not above what it reads has
+    // nothing to add (a stale-low read costs one needless atomic, never a wrong slot) -- the atomics of a launch all
+    // land on the slot's one 32-byte line and serialise there (~8 ns each).  Only for kernels whose workgroups live
+    // long (the stand-alone magnitude pass: 35 -> 20 us at 2 048 workgroups): in the row kernels the extra memory round
+    // trip at the end of every short-lived workgroup cost more than the atomics it saved (gate backward 96 -> 121 us).
+    uint32_t* const w = slot + (blockIdx.x & (MML_AMAX_WORDS - 1));
+    if (LOOK) {
+      if (am && am > __builtin_nontemporal_load(w)) atomicMax(w, am);
+    } else if (am) {
+      atomicMax(w, am);
+    }
   }
   __syncthreads();  // (the array may be reused by the next flush of the same kernel)
 }
