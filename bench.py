@@ -419,6 +419,11 @@ def main():
         acc = kernel_breakdown(runner, batches, min(args.steps, 10))
         results[B]["acc"] = acc
         results[B]["bsteps"] = min(args.steps, 10)
+        # did the run stay a training run?  (the summed-BCE kernel clamps log p at -100 with fmaxf, which also swallows a
+        # NaN: a diverged model keeps reporting a finite loss.  snr_trans_ae30 on two alternating batches overfits to
+        # loss 0.004 by step 31 and has all-NaN input gradients by step 41 -- and a scatter that takes 4 ms for them)
+        gin = runner.plan.layer_outputs.get("dnn_input") if hasattr(runner.plan, "layer_outputs") else None
+        results[B]["finite"] = bool(gin is None or gin.grad is None or torch.isfinite(gin.grad).all().item())
 
     # forward-only path (predict / evaluate reuse the gather, GEMM, gate and head kernels):
     # model.forward in eval mode under no_grad, as predict() calls it -- includes the input copy, the output clone
@@ -510,7 +515,11 @@ def main():
         "kernels_ms_per_step": {k: round(v["ms"] / main_r["bsteps"], 4) for k, v in
                                 sorted(main_r["acc"].items(), key=lambda kv: -kv[1]["ms"])},
         "mean_loss_per_sample": round(main_r["loss"], 5),
+        "gradients_finite": main_r.get("finite", True),
     }
+    if not line["gradients_finite"]:
+        sys.stderr.write("bench: the input gradients of the last step are not finite -- the model diverged on this "
+                         "synthetic stream; the timing is that of a diverged run\n")
     if world > 1 or forced:
         line["rccl_ranks"] = world if os.environ.get("MMLREC_BENCH_SHARE_GPU") != "1" else 0
     # parity of the measured run itself: the losses of the untimed warm-up steps and of the LAST timed step against the

@@ -65,6 +65,14 @@ __device__ __forceinline__ void amax_flush(float amf, uint32_t* slot) {
 
 }  // namespace mml
 
+namespace mml {
+#if defined(__HIPCC__)
+// torch.clamp(x, min = -100) of F.binary_cross_entropy's log terms: a NaN stays a NaN (fmaxf alone returns the other
+// operand, and a diverged model would keep reporting a finite loss)
+__device__ __forceinline__ float bce_log_clamp(float x) { return x != x ? x : fmaxf(x, -100.f); }
+#endif
+}  // namespace mml
+
 // hipGetLastError() is sticky per host thread: an error left behind by an unrelated earlier HIP call (e.g. a device
 // probe before the runtime was initialised) must not be blamed on our launch, so clear it first.
 #define MML_LAUNCH(...)          \

@@ -22,8 +22,8 @@ __global__ __launch_bounds__(ESMM_THREADS) void esmm_combine_kernel(const float*
     float g0 = 0.f, g1 = 0.f;
     if (y) {
       const float y0 = y[b * ldy], y1 = y[b * ldy + 1];
-      acc += -(y0 * fmaxf(logf(p0), -100.f) + (1.f - y0) * fmaxf(log1pf(-p0), -100.f));
-      acc += -(y1 * fmaxf(logf(p1), -100.f) + (1.f - y1) * fmaxf(log1pf(-p1), -100.f));
+      acc += -(y0 * bce_log_clamp(logf(p0)) + (1.f - y0) * bce_log_clamp(log1pf(-p0)));
+      acc += -(y1 * bce_log_clamp(logf(p1)) + (1.f - y1) * bce_log_clamp(log1pf(-p1)));
       g0 = (p0 - y0) / fmaxf((1.f - p0) * p0, 1e-12f);
       g1 = (p1 - y1) / fmaxf((1.f - p1) * p1, 1e-12f);
     } else if (dout) {
@@ -64,7 +64,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 __device__ __forceinline__ float bce_term(float p, float y) {
-  return -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(log1pf(-p), -100.f));
+  return -(y * bce_log_clamp(logf(p)) + (1.f - y) * bce_log_clamp(log1pf(-p)));
 }
 
 __global__ __launch_bounds__(ESMM_THREADS) void escm_combine_kernel(const float* praw, int64_t ldr, const float* y,

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(ROW_BLOCK) void head_kernel(const mml_head_group g,
         if (g.y) {
           const float y = g.y[b * g.ldy + t];
           // F.binary_cross_entropy: log terms clamped at -100; backward divides by max(p(1-p), 1e-12)
-          const float lp = fmaxf(logf(pm), -100.f);
-          const float l1p = fmaxf(log1pf(-pm), -100.f);
+          const float lp = bce_log_clamp(logf(pm));
+          const float l1p = bce_log_clamp(log1pf(-pm));
           if (lane == 0) lossacc += -(y * lp + (1.f - y) * l1p);
           dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
         } else {

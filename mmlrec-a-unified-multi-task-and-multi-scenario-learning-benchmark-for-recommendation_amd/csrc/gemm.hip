@@ -1552,12 +1552,9 @@ static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, in
   if (bcols < 0)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d>", fam, arc ? "true" : "false",
              brc ? "true" : "false", bn, epi);
-  else if (bpl)  // (the symbol a profiler prints: trailing default template arguments are omitted, BPL = true is not)
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s, true>", fam, arc ? "true" : "false",
-             brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false");
-  else
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s>", fam, arc ? "true" : "false",
-             brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false");
+  else  // (the symbol as a profiler prints it: every template argument, the defaulted ones too)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s, %s, %d, %d, %d, %s, %s>", fam, arc ? "true" : "false",
+             brc ? "true" : "false", bn, epi, mode, bcols ? "true" : "false", bpl ? "true" : "false");
 }
 
 // planes / kexps (or null): per source of the launch, the pre-cut image of its column operand and the exponent slot

@@ -616,8 +616,8 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
         float dpm;
         if (g.y) {
           const float y = g.y[b * g.ldy + t];
-          const float lp = fmaxf(logf(pm), -100.f);
-          const float l1p = fmaxf(log1pf(-pm), -100.f);
+          const float lp = bce_log_clamp(logf(pm));
+          const float l1p = bce_log_clamp(log1pf(-pm));
           if (valid && sub == 0) lossacc += -(y * lp + (1.f - y) * l1p);
           dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
         } else {

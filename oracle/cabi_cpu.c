@@ -341,7 +341,9 @@ static int heads(const mml_head_group* g, int train) {
       float dpm;
       if (g->y) {
         const float y = g->y[b * g->ldy + t];
-        const float lp = fmaxf(logf(pm), -100.f), l1p = fmaxf(log1pf(-pm), -100.f); /* F.binary_cross_entropy clamps */
+        /* F.binary_cross_entropy: torch.clamp(log p, min = -100) -- a NaN stays a NaN (fmaxf alone would drop it) */
+        const float lg = logf(pm), lg1 = log1pf(-pm);
+        const float lp = lg != lg ? lg : fmaxf(lg, -100.f), l1p = lg1 != lg1 ? lg1 : fmaxf(lg1, -100.f);
         loss += -(y * lp + (1.f - y) * l1p);
         dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
       } else {

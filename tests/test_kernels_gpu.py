@@ -292,6 +292,29 @@ def test_head_bce(ops, B, H, T_, masked):
     assert torch.equal(prob, prob2)
 
 
+@pytest.mark.parametrize("H", [64, 200])
+def test_head_bce_loss_propagates_nan(ops, H):
+    """F.binary_cross_entropy clamps its log terms with torch.clamp(.., min=-100), which keeps a NaN (the oracle's
+    np.maximum does too); fmaxf alone returned -100 and a diverged model kept reporting a finite loss.  Both head kernels
+    (the row-fast one for H <= 128 multiples of 16, the generic one)."""
+    B = 256
+    rng = np.random.default_rng(3)
+    Hin = np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32)
+    Hin[17, 3] = np.nan
+    w = (rng.standard_normal(H) / np.sqrt(H)).astype(np.float32)
+    y = (rng.random((B, 1)) < 0.4).astype(np.float32)
+    prob = torch.empty(B, 1, device=dev())
+    loss = torch.zeros(1, device=dev())
+    heads = [dict(Hin=T(Hin), w=T(w), bias=T(np.zeros(1, np.float32)), dH=torch.empty(B, H, device=dev()),
+                  dw=torch.empty(H, device=dev()), dbias=torch.empty(1, device=dev()), h_relu=1, mask_col=-1)]
+    ops.head_bce_fwd_bwd(ops.make_head_group(heads, prob, y=T(y), mask=None, loss=loss), dev())
+    assert np.isnan(float(loss.item()))
+    p = prob.cpu().numpy()[:, 0]
+    assert np.isnan(p[17]) and np.isfinite(np.delete(p, 17)).all()
+    logit = (Hin.astype(np.float64) @ w).astype(np.float32)
+    assert np.isnan(orc.bce_sum(orc.sigmoid(logit), y[:, 0]))  # the oracle agrees
+
+
 @pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "rmsprop"])
 def test_optimizer_dense_matches_oracle(ops, kind):
     rng = np.random.default_rng(9)

@@ -19,9 +19,12 @@ for B in 4096 65536; do
   run pepnet_amazon_b$B "MMLREC_GEMM_MODE=4" --workload pepnet_amazon --batch $B
   run ae30d_b$B        "MMLREC_GEMM_MODE=4" --workload mmoe_ae30d --batch $B
 done
-for w in mlp_ae30 esmm_ae30 cross_stitch_ae30 hmoe_ae30 aitm_ae30 snr_trans_ae30 mssm_ae30; do
+for w in mlp_ae30 esmm_ae30 cross_stitch_ae30 hmoe_ae30 aitm_ae30 mssm_ae30; do
   run ${w}_b65536 "MMLREC_GEMM_MODE=4" --workload $w --batch 65536
 done
+# SNR-trans on two alternating batches overfits (loss 0.004 by step 31) and then diverges (all-NaN input gradients by step
+# 41: every run() above takes 5 + 50 + 10 steps): 12 timed steps keep the measurement inside the training regime
+run snr_trans_ae30_b65536 "MMLREC_GEMM_MODE=4" --workload snr_trans_ae30 --batch 65536 --steps 12 --warmup 3
 python3 - <<'PY'
 import json
 for l in open('gpurun_out/secondary.jsonl'):
@@ -29,5 +32,5 @@ for l in open('gpurun_out/secondary.jsonl'):
     if d.get('failed'):
         print(d['tag'], 'FAILED'); continue
     r = d['roofline']
-    print(f"{d['tag']:22s} {d['value']/1e6:8.2f} M samples/s  {d['ms_per_step']:.3f} ms  dominant {r['kernel'][:48]} frac {r['frac']}")
+    print(f"{d['tag']:22s} {d['value']/1e6:8.2f} M samples/s  {d['ms_per_step']:.3f} ms  dominant {r['kernel'][:48]} frac {r['frac']}" + ("" if d.get("gradients_finite", True) else "  DIVERGED (non-finite gradients)"))
 PY

@@ -32,12 +32,12 @@ a = gr.abs()
 e = torch.frexp(a[a > 0])[1] if (a > 0).any() else None
 if e is not None:
     print("exponent range of nonzero |g|:", int(e.min()), "..", int(e.max()))
-for it in range(40):
-    Xb, yb = W.synth_batch(vocab, len(dense), B, W.num_tasks(cfg), seed=2 + it)
+for it in range(int(os.environ.get('STEPS', '40'))):
+    Xb, yb = W.synth_batch(vocab, len(dense), B, W.num_tasks(cfg), seed=(1 + it % 2) if os.environ.get('REPEAT') else 2 + it)
     step.plan.X.copy_(Xb.to(dev))
     step.plan.y.copy_(yb.to(dev))
     step.run()
-    if it % 5 == 4:
+    if it % 10 == 9:
         torch.cuda.synchronize()
         gr = x0.grad
         a = gr.abs()
@@ -45,7 +45,8 @@ for it in range(40):
         den = int(((a > 0) & (a < 1.1754944e-38)).sum())
         print("step", it + 2, "loss/sample %.5f" % (float(step.plan.loss) / B), "zeros %.4f" % float((gr == 0).float().mean()),
               "nonfinite", int((~torch.isfinite(gr)).sum()), "denormal", den, "max %.3e" % float(a.max()),
-              "min nz %.3e" % (float(nz.min()) if nz.numel() else 0.0))
+              "min nz %.3e" % (float(nz.min()) if nz.numel() else 0.0), "rows with max<1e-30: %d" % int((a.max(1).values < 1e-30).sum()),
+              "col-block (field) max range: %.2e .. %.2e" % (float(a.view(B, -1, 8).amax((0, 2)).min()), float(a.view(B, -1, 8).amax((0, 2)).max())))
 import time
 from mmlrec_amd import engine as E
 torch.cuda.synchronize()
