@@ -87,6 +87,25 @@ def main():
                 p.update(amax_a=cache[key(p["A"])], amax_w=cache[key(p["W"])])
                 q.update(amax_dc=cache[key(q["dC"])], amax_a=cache[key(q["A"])])
         amx = lambda p: ((cache[key(p["C"])], cache[key(p["W"])]) if AMAX else ())  # noqa: E731
+        # pre-cut weight planes (as the step has them): own exponent for the forward, one exponent per input-gradient
+        # problem (GEMM_PLANES=0: the kernels cut the weight fragments themselves)
+        PLANES = AMAX and os.environ.get("GEMM_PLANES", "1") != "0" and all(k % 16 == 0 and n % 16 == 0 for n, k in shapes)
+        pl_f, pl_d = {}, {}
+        if PLANES:
+            items = []
+            one_group = not name.startswith("L2") and all(k == shapes[0][1] for _, k in shapes)
+            kx_grp = torch.zeros(1, dtype=torch.int32, device=dev)
+            for p in probs_f:
+                Wt, sl = p["W"], cache[key(p["W"])]
+                pf, kf = torch.zeros(Wt.shape, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+                items.append((Wt, pf, ops.PLANES_ROWS, [sl], kf))
+                p.update(w_planes=pf, w_kexp=kf)
+                pd_, kd = torch.zeros(Wt.shape, dtype=torch.int32, device=dev), (kx_grp if one_group else torch.zeros(1, dtype=torch.int32, device=dev))
+                grp = [cache[key(q["W"])] for q in probs_f[:8]] if one_group else [sl]
+                items.append((Wt, pd_, ops.PLANES_COLS, grp, kd))
+                pl_d[id(p)] = (pd_, kd)
+            ops.planes_cut(items)
+        amx_p = lambda p: (amx(p) + pl_d[id(p)]) if PLANES else amx(p)  # noqa: E731
         AOUT = os.environ.get("GEMM_AMAX_OUT", "0") == "1"  # the launches also produce the magnitude of their output
         if AOUT:
             for p in probs_f:
@@ -97,13 +116,13 @@ def main():
         print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
         K0 = shapes[0][1]
         if name.startswith("L2"):  # one dgrad problem per expert (single source each), as the step runs them
-            pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx(p)],
+            pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx_p(p)],
                        amax_out=ops.amax_slots(1, dev)[0] if AOUT else None) for p in probs_f]
             t = timeit(lambda: ops.gemm_dgrad(pd))
             print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s  (one problem per expert)")
         elif all(k == K0 for _, k in shapes):
             dA = torch.empty(M, K0, device=dev)
-            pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx(p) for p in probs_f[:8]],
+            pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx_p(p) for p in probs_f[:8]],
                        amax_out=ops.amax_slots(1, dev)[0] if AOUT else None)]
             fl = sum(2.0 * M * n * k for n, k in shapes[:8])
             t = timeit(lambda: ops.gemm_dgrad(pd))
