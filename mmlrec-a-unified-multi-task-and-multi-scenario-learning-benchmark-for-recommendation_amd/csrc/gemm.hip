@@ -100,12 +100,13 @@ __device__ __forceinline__ void amax_publish(uint32_t am, uint32_t* slot, int sa
 
 // ---- pre-cut weights (mml_gemm_planes_cut): the two fp16 planes of a weight matrix, laid out so that they travel through
 // the SAME global -> LDS image and fragment reads as the floats (see planes_of) ----
-constexpr int PLANES_PER_LAUNCH = 20;
+constexpr int PLANES_PER_LAUNCH = 32;  // (kernel-argument block: 32 x 120 B + 136 B < 4 KiB)
 struct PlanesLaunch {
   mml_planes_desc d[PLANES_PER_LAUNCH];
   int32_t item0[PLANES_PER_LAUNCH + 1];  // first work item of matrix i (one item = one block of 16 along the reduction)
   int32_t n;
 };
+static_assert(sizeof(PlanesLaunch) <= 4096, "PlanesLaunch must fit the kernel-argument block");
 // the lane's eight k of a 16-block, in fragment order: S_h = {4h .. 4h+3, 8+4h .. 8+4h+3} (RawFrag::get)
 __device__ __forceinline__ int planes_k(int h, int e) { return 4 * h + (e & 3) + 8 * (e >> 2); }
 __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
