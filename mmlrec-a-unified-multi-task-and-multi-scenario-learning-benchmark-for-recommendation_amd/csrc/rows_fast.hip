@@ -726,10 +726,11 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
   static int fwd_per_cu = -1;
   if (fwd_per_cu < 0) {
     const char* e = getenv("MMLREC_GATE_FWD_WGS");
-    fwd_per_cu = e ? atoi(e) : 8;
+    fwd_per_cu = e ? atoi(e) : 6;
   }
-  // the forward kernel writes no per-workgroup partials and needs 34 VGPRs: eight workgroups (32 waves) per CU hide
-  // the dependent G -> expert-row loads of a sample behind other samples
+  // the forward kernel writes no per-workgroup partials; since it tracks the magnitude of its output it holds 73-94
+  // VGPRs (five or six waves per SIMD), so six workgroups per CU are ONE round of resident workgroups (eight were a round
+  // and a third: 67-68 us against 64 at B = 65 536 on AE-30; twelve 72)
   aux.grid = fast_row_grid(g->B, aux.lps, bwd ? 4 : fwd_per_cu);
   return aux.lps;
 }
