@@ -308,7 +308,7 @@ int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stre
  * tile of the batch, so it can be cut ONCE per step instead: `planes` has W's shape and pitch and holds, per aligned
  * block of 16 values along the reduction, the 32 bytes of h and the 32 bytes of l in the order the kernel's fragment
  * reads deliver them (so the planes travel through the same LDS image as the floats would).
- *   MML_PLANES_ROWS: the reduction runs along a ROW of W ([N, K] read by the forward: K % 16 == 0);
+ *   MML_PLANES_ROWS: the reduction runs along a ROW of W ([N, K] read by the forward: K % 16 == 0, or any K with ldp);
  *   MML_PLANES_COLS: the reduction runs down the ROWS of W ([N, K] read by the input gradient: N % 16 == 0).
  * k = the largest exponent that keeps every |w| 2^k below 2^15 for the LARGEST of the n_amax magnitude slots given
  * (the weights that feed one input-gradient problem share their exponent); it is written to *kexp.  Bit-identical to
@@ -318,12 +318,18 @@ int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stre
 #define MML_MAX_PLANES 64
 typedef struct {
   const float* W;     /* [rows, cols], row pitch ld (floats) */
-  uint32_t* planes;   /* same shape and pitch, 4-byte words */
+  uint32_t* planes;   /* [rows, cols] 4-byte words at row pitch ldp */
   int64_t rows, ld;
   int32_t cols, layout;
   int32_t n_amax, pad_;
   const uint32_t* amax[MML_MAX_SRC];
   int32_t* kexp;
+  /* Row pitch of `planes` in words; 0 = ld.  A wider pitch serves the zero-padded operand a GEMM reads when the
+   * reduction extent is not a multiple of 16 (K0 = 303 -> 304): with MML_PLANES_ROWS, cols may then be ANY length and
+   * the last, partial block is cut as if the missing columns were zero (ldp >= cols rounded up to 16; the words of the
+   * missing columns are written as zero planes); with MML_PLANES_COLS the columns beyond `cols` are not touched (the
+   * caller zeroes the buffer once). */
+  int64_t ldp;
 } mml_planes_desc;
 int mml_gemm_planes_cut(const mml_planes_desc* descs, int32_t n, mml_stream_t stream);
 

@@ -41,7 +41,7 @@ class GemmDgradDesc(C.Structure):
 
 class PlanesDesc(C.Structure):
     _fields_ = [("W", fp), ("planes", fp), ("rows", i64), ("ld", i64), ("cols", i32), ("layout", i32),
-                ("n_amax", i32), ("pad_", i32), ("amax", fp * MAX_SRC), ("kexp", fp)]
+                ("n_amax", i32), ("pad_", i32), ("amax", fp * MAX_SRC), ("kexp", fp), ("ldp", i64)]
 
 
 class GemmWgradDesc(C.Structure):

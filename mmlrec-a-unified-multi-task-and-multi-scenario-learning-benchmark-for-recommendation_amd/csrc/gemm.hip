@@ -100,7 +100,7 @@ __device__ __forceinline__ void amax_publish(uint32_t am, uint32_t* slot, int sa
 
 // ---- pre-cut weights (mml_gemm_planes_cut): the two fp16 planes of a weight matrix, laid out so that they travel through
 // the SAME global -> LDS image and fragment reads as the floats (see planes_of) ----
-constexpr int PLANES_PER_LAUNCH = 32;  // (kernel-argument block: 32 x 120 B + 136 B < 4 KiB)
+constexpr int PLANES_PER_LAUNCH = 30;  // (kernel-argument block: 30 x 128 B + 128 B < 4 KiB)
 struct PlanesLaunch {
   mml_planes_desc d[PLANES_PER_LAUNCH];
   int32_t item0[PLANES_PER_LAUNCH + 1];  // first work item of matrix i (one item = one block of 16 along the reduction)
@@ -135,19 +135,26 @@ __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
   const int64_t total = L.item0[blockIdx.y + 1] - L.item0[blockIdx.y];
   for (int64_t loc = (int64_t)blockIdx.x * 256 + threadIdx.x; loc < total; loc += (int64_t)gridDim.x * 256) {
     float x[16];
-    int64_t base, stride;  // element e of the block sits at base + e * stride (floats / words)
+    int64_t base, stride, pbase, pstride;  // element e of the block: W[base + e stride], word e: planes[pbase + e pstride]
+    int live = 16;                           // (ROWS with a partial last block: the missing columns count as zeros)
+    const int64_t ldp = D.ldp ? D.ldp : D.ld;
     if (D.layout == MML_PLANES_ROWS) {
-      const int nb = D.cols / 16;
+      const int nb = (D.cols + 15) / 16;
       const int64_t r = loc / nb;
-      base = r * D.ld + 16 * (loc - r * nb);
-      stride = 1;
+      const int c0 = 16 * (int)(loc - r * nb);
+      base = r * D.ld + c0;
+      pbase = r * ldp + c0;
+      stride = pstride = 1;
+      live = D.cols - c0 < 16 ? D.cols - c0 : 16;
     } else {
       const int64_t rb = loc / D.cols;
       base = 16 * rb * D.ld + (loc - rb * D.cols);
+      pbase = 16 * rb * ldp + (loc - rb * D.cols);
       stride = D.ld;
+      pstride = ldp;
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = D.W[base + e * stride];
+    for (int e = 0; e < 16; ++e) x[e] = e < live ? D.W[base + e * stride] : 0.f;
     uint32_t hp[16], lp[16];  // half bit patterns
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -164,8 +171,8 @@ __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k0 = planes_k(h, 2 * i), k1 = planes_k(h, 2 * i + 1);
-        D.planes[base + (4 * h + i) * stride] = hp[k0] | (hp[k1] << 16);
-        D.planes[base + (8 + 4 * h + i) * stride] = lp[k0] | (lp[k1] << 16);
+        D.planes[pbase + (4 * h + i) * pstride] = hp[k0] | (hp[k1] << 16);
+        D.planes[pbase + (8 + 4 * h + i) * pstride] = lp[k0] | (lp[k1] << 16);
       }
   }
 }
@@ -1750,12 +1757,14 @@ extern "C" int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stre
       MML_REQUIRE(q.W && q.planes && q.kexp && q.rows >= 0 && q.cols >= 0 && q.ld >= q.cols,
                   "mml_gemm_planes_cut: matrix %d malformed", i);
       MML_REQUIRE(q.layout == MML_PLANES_ROWS || q.layout == MML_PLANES_COLS, "mml_gemm_planes_cut: layout of matrix %d", i);
-      MML_REQUIRE(q.layout == MML_PLANES_ROWS ? q.cols % 16 == 0 : q.rows % 16 == 0,
-                  "mml_gemm_planes_cut: the reduction extent of matrix %d is not a multiple of 16", i);
+      const int64_t ldp = q.ldp ? q.ldp : q.ld;
+      MML_REQUIRE(q.layout == MML_PLANES_ROWS ? ldp >= (q.cols + 15) / 16 * 16 : (q.rows % 16 == 0 && ldp >= q.cols),
+                  "mml_gemm_planes_cut: matrix %d: the planes pitch cannot hold the reduction extent rounded up to 16 "
+                  "(ROWS), or the row count is not a multiple of 16 (COLS)", i);
       MML_REQUIRE(q.n_amax >= 1 && q.n_amax <= MML_MAX_SRC, "mml_gemm_planes_cut: matrix %d needs 1..%d magnitude slots", i,
                   MML_MAX_SRC);
       for (int a = 0; a < q.n_amax; ++a) MML_REQUIRE(q.amax[a], "mml_gemm_planes_cut: null magnitude slot (matrix %d)", i);
-      const int64_t it = q.layout == MML_PLANES_ROWS ? q.rows * (q.cols / 16) : (q.rows / 16) * q.cols;
+      const int64_t it = q.layout == MML_PLANES_ROWS ? q.rows * ((q.cols + 15) / 16) : (q.rows / 16) * q.cols;
       MML_REQUIRE(items + it < 0x7fffffff, "mml_gemm_planes_cut: too many blocks");
       L.item0[L.n] = (int32_t)items;
       L.d[L.n++] = q;

@@ -179,30 +179,36 @@ class Plan:
             need.append((pv.data, slot))  # (not cached: re-measured by every launch that reads it -- it may change)
         return slot
 
-    def weight_planes(self, q, layout, group=None):
+    def weight_planes(self, q, layout, group=None, padded=False):
         """(planes, kexp) of problem q's weight for the forward (layout ROWS: its own exponent) or as one source of an
         input-gradient problem (layout COLS: `group` = the problems whose weights feed the same output, ONE exponent), or
-        (None, None): only stable weights in nn.Linear layout whose magnitude is taken at the start of the step, with a
-        reduction extent the plane image can hold, and not the zero-padded copies."""
-        if (self.amax_pool is None or os.environ.get("MMLREC_GEMM_PLANES", "1") == "0" or q.get("w_kn", 0) or "Wp" in q):
+        (None, None): only stable weights in nn.Linear layout whose magnitude is taken at the start of the step.
+        padded: the launch reads the zero-padded operand (q["Wp"], reduction extent rounded up to 16): the planes are cut
+        from the weight itself into a zero-initialised buffer of the padded shape."""
+        if self.amax_pool is None or os.environ.get("MMLREC_GEMM_PLANES", "1") == "0":
             return None, None
         qs = [q] if group is None else group
         slots = []
         for g in qs:
             W = g["W"]
             key = (W.data.data_ptr(), tuple(W.data.shape))
-            if (g.get("w_kn", 0) or "Wp" in g or not getattr(W, "stable", False) or key not in self.amax_weights or
-                    W.data.dim() != 2 or W.data.stride(1) != 1 or W.data.shape[layout == ops.PLANES_ROWS] % 16 or
-                    W.data.data_ptr() % 16 or W.data.stride(0) % 4):
+            red = W.data.shape[1] if layout == ops.PLANES_ROWS else W.data.shape[0]
+            if (g.get("w_kn", 0) or ("Wp" in g) != bool(padded) or not getattr(W, "stable", False) or
+                    key not in self.amax_weights or W.data.dim() != 2 or W.data.stride(1) != 1 or
+                    (red % 16 and not (padded and layout == ops.PLANES_ROWS)) or
+                    W.data.data_ptr() % 16 or (W.data.stride(0) % 4 and not padded)):
                 return None, None
             slots.append(self.amax_weights[key])
         W = q["W"].data
-        ck = (W.data_ptr(), tuple(W.shape), layout, tuple(sl.data_ptr() for sl in slots))
+        shape = tuple(q["Wp"].shape) if padded else (W.shape[0], W.stride(0))
+        ck = (W.data_ptr(), tuple(W.shape), layout, bool(padded), tuple(sl.data_ptr() for sl in slots))
         if ck not in self.planes_cache:
-            gk = ("kexp", layout, tuple(sl.data_ptr() for sl in slots))  # one exponent word per group
+            gk = ("kexp", layout, bool(padded), tuple(sl.data_ptr() for sl in slots))  # one exponent word per group
             if gk not in self.planes_cache:
                 self.planes_cache[gk] = torch.zeros(1, dtype=torch.int32, device=self.device)
-            planes = torch.zeros(W.shape[0], W.stride(0), dtype=torch.int32, device=self.device)[:, :W.shape[1]]
+            planes = torch.zeros(shape, dtype=torch.int32, device=self.device)
+            if not padded:
+                planes = planes[:, :W.shape[1]]
             self.planes_cache[ck] = (planes, self.planes_cache[gk])
             self.planes_items.append((W, planes, layout, slots, self.planes_cache[gk]))
         return self.planes_cache[ck]
@@ -616,7 +622,7 @@ class LinearGroupOp(Op):
         if need:
             pre.append(plan.amax_call(need))
         # pre-cut weights: all problems of the launch or none (the kernel takes the planes form per launch)
-        wp = [plan.weight_planes(q, ops.PLANES_ROWS) for q in self.p]
+        wp = [plan.weight_planes(q, ops.PLANES_ROWS, padded="Wp" in q) for q in self.p]
         if any(pl is None for pl, _ in wp):
             wp = [(None, None)] * len(self.p)
         descs = ops.make_fwd_descs([dict(A=q.get("Ap", q["x"].buf), W=q.get("Wp", q["W"].data),
@@ -739,7 +745,7 @@ class LinearGroupOp(Op):
                 else:
                     out_slot = None
                 # the weights that feed this input gradient, cut as one group (common exponent)
-                gp = [plan.weight_planes(q, ops.PLANES_COLS, ch) for q in ch] if not padded else [(None, None)]
+                gp = [plan.weight_planes(q, ops.PLANES_COLS, ch, padded=bool(padded)) for q in ch]
                 if any(pl is None for pl, _ in gp):
                     gp = [(None, None)] * len(ch)
                 waves[ci].append(dict(dA=_padded_view(x.grad, x.kpad) if padded else x.grad,

@@ -229,11 +229,14 @@ def make_planes_descs(items):
     [1] tensor) -> the descriptor block of mml_gemm_planes_cut."""
     arr = (L.PlanesDesc * len(items))()
     for d, (W, planes, layout, slots, kexp) in zip(arr, items):
-        if planes.shape != W.shape or _ld(planes) != _ld(W):
-            raise L.MMLError("planes buffer must have the weight's shape and pitch")
+        # planes: the weight's shape (pitch may differ), or -- for the zero-padded operand of a reduction that is not a
+        # multiple of 16 -- the same rows with the columns rounded up (a zero-initialised buffer)
+        if planes.shape[0] != W.shape[0] or planes.shape[1] < W.shape[1]:
+            raise L.MMLError("planes buffer must have the weight's rows and at least its columns")
         d.W, d.planes = W.data_ptr(), planes.data_ptr()
         d.rows, d.cols = W.shape
         d.ld = _ld(W)
+        d.ldp = _ld(planes)
         d.layout = int(layout)
         d.n_amax = len(slots)
         for a, sl in enumerate(slots):

@@ -324,8 +324,20 @@ def test_planes_cut_image_and_exponent(env, scale_w):
     assert np.array_equal(pr.cpu().numpy().view(np.uint32), _planes_ref(Wn, k_own, 0))
     assert np.array_equal(pc.cpu().numpy().view(np.uint32), _planes_ref(Wn, k_grp, 1))
     assert np.array_equal(p2.cpu().numpy().view(np.uint32), _planes_ref(W2.cpu().numpy(), k_grp, 1))
-    with pytest.raises(L.MMLError):  # reduction extent not a multiple of 16
-        ops.planes_cut([(W[:, :72], pr[:, :72], ops.PLANES_ROWS, [slots[0]], kx[0:1])])
+    with pytest.raises(L.MMLError):  # reduction extent not a multiple of 16 and no room for the rounded-up block
+        ops.planes_cut([(W[:, :72], torch.zeros(N, 72, dtype=torch.int32, device=dev), ops.PLANES_ROWS, [slots[0]], kx[0:1])])
+    with pytest.raises(L.MMLError):  # reduction down the rows: the row count must be a multiple of 16
+        ops.planes_cut([(W[:40], pc[:40], ops.PLANES_COLS, [slots[0]], kx[0:1])])
+    # the zero-padded operand of a ragged reduction (K = 72 -> 80): planes of the padded shape cut from the weight itself
+    Wr = W[:, :72]
+    pp = torch.zeros(N, 80, dtype=torch.int32, device=dev)
+    pq = torch.full((N, 80), 0, dtype=torch.int32, device=dev)
+    ops.planes_cut([(Wr, pp, ops.PLANES_ROWS, [slots[0]], kx[0:1]), (Wr, pq, ops.PLANES_COLS, [slots[0]], kx[1:2])])
+    torch.cuda.synchronize()
+    Wpad = np.zeros((N, 80), dtype=np.float32)
+    Wpad[:, :72] = Wr.cpu().numpy()
+    assert np.array_equal(pp.cpu().numpy().view(np.uint32), _planes_ref(Wpad, k_own, 0))
+    assert np.array_equal(pq.cpu().numpy().view(np.uint32), _planes_ref(Wpad, k_own, 1))
 
 
 @pytest.mark.parametrize("M,K,Ns", [(1000, 240, [256, 256, 64]), (70000, 128, [128, 128]), (300, 32, [128, 4]),
@@ -362,6 +374,46 @@ def test_pipe_fwd_with_precut_weights_is_bitwise_the_in_kernel_cut(env, M, K, Ns
         assert np.array_equal(a, b)
         ref = torch.relu(A.double() @ w.double().t() + bias.double())
         assert rel(torch.from_numpy(b).to(dev), ref) < 2e-6
+
+
+def test_pipe_fwd_dgrad_with_precut_padded_weights(env):
+    """Ragged reduction (K = 72, the operands zero-padded to 80 as engine.LinearGroupOp does): planes of the padded shape,
+    cut from the unpadded weight, give the bits of the launches that read the padded float copy."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, K, KP, N = 3000, 72, 80, 128
+    Ap = torch.zeros(M, KP, device=dev)
+    Ap[:, :K] = (torch.randn(M, K, generator=g) * 2e-3).to(dev)
+    W = (torch.randn(N, K, generator=g) * 1e-4).to(dev)
+    Wp = torch.zeros(N, KP, device=dev)
+    Wp[:, :K] = W
+    dC = (torch.randn(M, N, generator=g) * 1e-6).to(dev)
+    slots = ops.amax_slots(3, dev)
+    ops.amax_batch([(Ap, slots[0]), (W, slots[1]), (dC, slots[2])])
+    pr = torch.zeros(N, KP, dtype=torch.int32, device=dev)
+    pc = torch.zeros(N, KP, dtype=torch.int32, device=dev)
+    kx = torch.zeros(2, dtype=torch.int32, device=dev)
+    ops.planes_cut([(W, pr, ops.PLANES_ROWS, [slots[1]], kx[0:1]), (W, pc, ops.PLANES_COLS, [slots[1]], kx[1:2])])
+    outs = []
+    for use in (False, True):
+        Cc = torch.empty(M, N, device=dev)
+        p = dict(A=Ap, W=Wp, bias=None, C=Cc, act=L.ACT_NONE, amax_a=slots[0], amax_w=slots[1])
+        if use:
+            p.update(w_planes=pr, w_kexp=kx[0:1])
+        ops.gemm_fwd([p])
+        torch.cuda.synchronize()
+        assert lib.mml_gemm_last_kernel().decode().endswith(", true>") == use
+        dA = torch.zeros(M, KP, device=dev)
+        ops.gemm_dgrad([dict(dA=dA, Y=None, act=L.ACT_NONE, accumulate=0,
+                             srcs=[(dC, Wp, 0, slots[2], slots[1]) + ((pc, kx[1:2]) if use else ())])])
+        torch.cuda.synchronize()
+        assert lib.mml_gemm_last_kernel().decode().endswith(", true>") == use
+        outs.append((Cc.cpu().numpy(), dA.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert rel(torch.from_numpy(outs[1][0]).to(dev), Ap.double() @ Wp.double().t()) < 2e-6
+    assert float(np.abs(outs[1][1][:, K:]).max()) == 0.0  # the padding columns of the input gradient stay zero
 
 
 @pytest.mark.parametrize("M,K,srcNs,accumulate", [(1000, 240, [256, 256, 64, 64], 0), (70000, 256, [128], 1),
