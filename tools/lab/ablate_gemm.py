@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Timing ablations of gemm_pipe_kernel (results are garbage, only the time is read): each variant is a PATCHED COPY of
 csrc/gemm.hip (the product source carries no switches) compiled for one tile width / arithmetic (-DMML_LAB) and linked
-with the regular objects of the other sources into tools/lab/lib_<name>.so (tools/lab/run.sh times them all).
+with the regular objects of the other sources into tools/lab/lib_<name>.so (tools/lab/run.sh times them all; the patches
+address the form that cuts BOTH operands in registers: run.sh sets GEMM_PLANES=0 so that tools/bench_gemm.py does not
+hand the launches pre-cut weights).
 usage: ablate_gemm.py [BN [EMU]]"""
 import glob
 import os
@@ -49,7 +51,8 @@ NOCUT_DONE = '''  { typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
 
 
 def sub(s, old, new, count=1):
-    assert s.count(old) == count, (old[:50], s.count(old))
+    """count = None: every occurrence (at least one)"""
+    assert (s.count(old) >= 1) if count is None else (s.count(old) == count), (old[:50], s.count(old))
     return s.replace(old, new)
 
 
@@ -57,7 +60,7 @@ def nomfma(s):
     # the three MFMAs of mma_prep_f16 -> one cheap dependent VALU op each on the accumulator's first word
     for op in ("b.l, a.h", "b.h, a.l", "b.h, a.h"):
         s = sub(s, "  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(%s, acc, 0, 0, 0);\n  __builtin_amdgcn_sched_barrier(0);\n  f16_cut" % op,
-                "  acc[0] += __builtin_bit_cast(float, ((__attribute__((ext_vector_type(4))) uint32_t)__builtin_bit_cast(__attribute__((ext_vector_type(4))) uint32_t, %s))[0]);\n  __builtin_amdgcn_sched_barrier(0);\n  f16_cut" % op.split(",")[0])
+                "  acc[0] += __builtin_bit_cast(float, ((__attribute__((ext_vector_type(4))) uint32_t)__builtin_bit_cast(__attribute__((ext_vector_type(4))) uint32_t, %s))[0]);\n  __builtin_amdgcn_sched_barrier(0);\n  f16_cut" % op.split(",")[0], count=None)
     return s
 
 
