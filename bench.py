@@ -478,7 +478,7 @@ def main():
     from mmlrec_amd import _lib
     gmode = _lib.load().mml_gemm_get_mode()
     gemm_dtype = {0: "f32", 4: "f32 (GEMMs: fp32-equivalent emulation on the 16-bit MFMA pipe with f32 accumulate -- two scaled fp16 planes "
-                                "per operand where the operand magnitudes travel with the tensors (batches >= 49 152), else three bf16 planes; "
+                                "per operand where the operand magnitudes travel with the tensors (batches >= 32 768), else three bf16 planes; "
                                 "max-norm error vs float64 3.3e-7 / 4.7e-7, fp32 MFMA 4.3e-7)",
                   2: "f32 (GEMMs: as mode 4)",
                   3: "f32 (GEMMs: fp32-equivalent 3-plane bf16 MFMA emulation, f32 accumulate)",

@@ -100,10 +100,12 @@ class Plan:
         # Large batches: the GEMMs are throughput-bound and the two-plane fp16 form pays (AE-30 at 65 536: GEMM family
         # 1.14 -> 1.0 ms, step -5 %).  Same-box A/B at smaller batches: level at 32 768 and 16 384 (+-2 %: the ~50 us of
         # magnitude launches per step against the arithmetic saved), a loss below (8 192: 0.839 -> 0.854 ms; lazy_exact at
-        # 4 096: 0.27 -> 0.35 ms -- a step there is a chain of ~25 short launches).  So: on from 49 152 samples per step,
-        # the three-plane bf16 form below.  MMLREC_AMAX=0 / 1 forces.
+        # 4 096: 0.27 -> 0.35 ms -- a step there is a chain of ~25 short launches).  With the cheaper cut and the pre-cut
+        # weights of the end of round 3: 32 768: 1.272 -> 1.244 ms (lazy_exact 0.927 -> 0.894), 16 384: 0.994 -> 1.036,
+        # 8 192: 0.760 -> 0.802, 4 096: 0.696 -> 0.720.  So: on from 32 768 samples per step, the three-plane bf16 form
+        # below.  MMLREC_AMAX=0 / 1 forces.
         env = os.environ.get("MMLREC_AMAX", "")
-        self.use_amax = (env != "0") and (env == "1" or self.B >= 49152)
+        self.use_amax = (env != "0") and (env == "1" or self.B >= 32768)
         self.amax_pool = ops.amax_slots(1024, device) if (device.type == "cuda" and self.use_amax) else None
         self.amax_next = 0
         self.amax_weights = {}   # (data_ptr, shape) -> slot

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The engine gives GEMM launches their operand magnitudes (two-plane fp16 arithmetic) only for batches >= 49 152, where
+# The engine gives GEMM launches their operand magnitudes (two-plane fp16 arithmetic) only for batches >= 32 768, where
 # it pays; the fixtures hold 64 samples, so the suite switches it on for every batch -- the tests that name an `arith`
 # parameter run both forms.
 os.environ.setdefault("MMLREC_AMAX", "1")
