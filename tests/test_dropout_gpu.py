@@ -70,7 +70,10 @@ def _spec(g, p):
 
 
 CASES = ["sharedbottom_ml", "mmoe_ae30", "ple_ijcai", "cross_stitch_ae", "hmoe_ml", "aitm_ml", "esmm_ml", "mssm_ml",
-         "snr_trans_ae"]
+         "snr_trans_ae",
+         # Linear -> BatchNorm -> ReLU -> Dropout (model/utils.py:153-159), stacked and as blocks writing into a
+         # concatenation buffer
+         "sharedbottom_bn", "mmoe_bn", "cross_stitch_bn", "mssm_bn"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -89,7 +92,7 @@ def test_model_gradients_with_dropout_match_the_oracle_under_the_same_mask(name)
     bce = torch.nn.functional.binary_cross_entropy
     loss = sum(bce(yp[:, i], y[:, i], reduction="sum") for i in range(yp.shape[1]))
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) > 1e-6  # (the mask did something)
+    assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) > 1e-6  # (the mask did something)
     spec = _spec(g, P)
     params = orc.params_from_golden(g)
     frozen = orc.params_from_golden(g, "frozen/")
@@ -98,9 +101,13 @@ def test_model_gradients_with_dropout_match_the_oracle_under_the_same_mask(name)
         ref_loss, ref_grads, _ = orc.loss_and_grads(spec, params, g["X0"], g["y0"], frozen or None)
     finally:
         orc.set_dropout(0)
-    assert abs(float(loss) - ref_loss) / ref_loss < RTOL
+    assert abs(float(loss.detach()) - ref_loss) / ref_loss < RTOL
     checked = 0
+    from conftest import bn_noise_keys
+    noise_bias, _ = bn_noise_keys(model.state_dict().keys())
     for n, p in model.named_parameters():
+        if n in noise_bias:  # bias in front of a BatchNorm: structurally zero gradient, rounding noise on both sides
+            continue
         if n in ref_grads and p.grad is not None:
             assert rel(p.grad.cpu().numpy(), ref_grads[n]) < RTOL, n
             if n.startswith("embedding_dict."):
