@@ -591,3 +591,41 @@ def test_star_domain_batchnorm_masked_forward_backward():
     model.eval()
     with torch.no_grad():
         assert rel(model(X, mask).cpu().numpy(), g["mtrain/y_pred_eval_after"]) < RTOL
+
+
+def test_step_uses_precut_weight_planes(monkeypatch):
+    """The recorded step cuts every stable nn.Linear weight once (mml_gemm_planes_cut in the prologue of the forward) and
+    its forward / input-gradient launches run the planes form of the kernel; MMLREC_GEMM_PLANES=0 records the step
+    without them and gives the same parameters bit for bit (the cut is the same arithmetic either way)."""
+    from mmlrec_amd import _lib as L
+    g = load_golden("mmoe_ae30")
+    outs = []
+    for planes in ("1", "0"):
+        monkeypatch.setenv("MMLREC_GEMM_PLANES", planes)
+        model, cfg = build(g, table_update="dense_exact")
+        load_state(model, g)
+        model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+        model.train()
+        step = model.train_step_runner(64, use_graph=False)
+        lib = L.load()
+        has = any(c[0] is lib.mml_gemm_planes_cut for c in step.plan.fwd)
+        assert has == (planes == "1")
+        if planes == "1":
+            # 4 experts x 2 layers + 2 gate DNNs + 2 towers, one image for the forward and one for the input gradient
+            # (the first layer's six weights feed ONE input-gradient problem: one exponent word for the group)
+            assert len(step.plan.planes_items) >= 20
+            names = []
+            for c in step.plan.fwd:
+                if c[0] is lib.mml_gemm_grouped_fwd:
+                    c[0](*c[1], torch.cuda.current_stream().cuda_stream)
+                    names.append(lib.mml_gemm_last_kernel().decode())
+        step.plan.X.copy_(torch.from_numpy(g["X0"]).cuda())
+        step.plan.y.copy_(torch.from_numpy(g["y0"]).cuda())
+        step.run()
+        if planes == "1":
+            assert names and all(n.endswith(", true>") for n in names), names
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+    for k in outs[0]:
+        if k.startswith("embedding_dict."):
+            continue  # (the table scatter's float atomics are order-dependent run to run)
+        assert np.array_equal(outs[0][k], outs[1][k]), k
