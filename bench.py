@@ -151,9 +151,7 @@ def timed_steps(runner, batches, steps, warmup, dist, flush=None, warm_losses=No
 
     def one(i):
         if not runner._has_next:
-            X, y = batches[i % nb]
-            runner.plan.X.copy_(X)
-            runner.plan.y.copy_(y)
+            runner.load(*batches[i % nb])  # (one launch for both tensors)
         runner.run()
         if ahead:
             runner.prefetch(*batches[(i + 1) % nb])

@@ -272,6 +272,22 @@ class TrainStep:
             self._ev_staged.record(side)
         self._has_next = True
 
+    def load(self, X, y):
+        """plan.X / plan.y <- the batch (device tensors of the plan's shapes) in ONE launch on the current stream: two
+        tensor copies are two launches in front of every step (6 us each at the head of a 1.8 ms step)."""
+        from . import _lib as L
+        p = self.plan
+        if (X.shape != p.X.shape or y.shape != p.y.shape or X.dtype != torch.float32 or y.dtype != torch.float32 or
+                X.stride(1) != 1 or y.stride(1) != 1 or X.device != p.X.device or y.device != p.y.device):
+            p.X.copy_(X)
+            p.y.copy_(y)
+            return
+        arr = (L.Copy2dDesc * 2)()
+        for d, (src, dst) in zip(arr, ((X, p.X), (y, p.y))):
+            d.src, d.lds, d.dst, d.ldd = src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)
+            d.rows, d.cols, d.accumulate = src.shape[0], src.shape[1], 0
+        L.check(L.load().mml_copy2d_batch(arr, 2, torch.cuda.current_stream().cuda_stream), "mml_copy2d_batch")
+
     def drop_prefetch(self):
         self._has_next = False
         op = self.plan.ops[0] if self.plan.ops else None
@@ -315,8 +331,7 @@ class TrainStep:
         if self._has_next:  # the batch handed over by prefetch()
             main = torch.cuda.current_stream()
             main.wait_event(self._ev_staged)
-            self.plan.X.copy_(self._nX)
-            self.plan.y.copy_(self._ny)
+            self.load(self._nX, self._ny)
             self._ev_consumed.record(main)
             self._has_next = False
         if self.use_graph and self.calls == 1:
