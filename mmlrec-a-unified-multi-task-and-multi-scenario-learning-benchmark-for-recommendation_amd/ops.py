@@ -5,6 +5,8 @@ All functions require CUDA(HIP) tensors and raise MMLError otherwise -- there is
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -48,6 +50,54 @@ def _f32_2d(t, name):
 
 def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def concurrent_stream(device, tries=6):
+    """A stream whose kernels really run beside those of the current stream.  HIP hands streams one of a few
+    hardware queues round-robin (four by default); a process that also holds RCCL's streams and the routing stream of
+    the row-sharded tables can find its side stream on the SAME queue as the main stream, and the forked tail then
+    runs one launch after the other (seen in the kernel trace of the forced row-sharded step: weight-gradient GEMMs
+    and table update on one queue, 2.10 ms where the unsharded step takes 1.88).  So: probe -- a spin kernel on each
+    stream, concurrent if the pair takes the time of one -- and keep the first candidate that passes.
+    MMLREC_SIDE_PROBE=0 takes the first stream unprobed."""
+    main = torch.cuda.current_stream(device)
+    first = torch.cuda.Stream(device=device)
+    if os.environ.get("MMLREC_SIDE_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+        return first
+    try:
+        spin = 400_000  # cycles: ~0.2 ms
+
+        def pair_ms(s):
+            torch.cuda.synchronize(device)
+            a, b, j = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                       torch.cuda.Event())
+            a.record(main)
+            s.wait_event(a)
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(spin)
+                j.record(s)
+            torch.cuda._sleep(spin)
+            main.wait_event(j)
+            b.record(main)
+            torch.cuda.synchronize(device)
+            return a.elapsed_time(b)
+
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(spin)  # (warm-up of the spin kernel itself)
+        a.record(main)
+        torch.cuda._sleep(spin)
+        b.record(main)
+        torch.cuda.synchronize(device)
+        one = a.elapsed_time(b)
+        cand = first
+        for _ in range(tries):
+            if min(pair_ms(cand), pair_ms(cand)) < 1.5 * one:
+                return cand
+            cand = torch.cuda.Stream(device=device)
+    except Exception:  # (a probe must never cost the step)
+        pass
+    return first
 
 
 def workspace(nbytes, device):

@@ -212,7 +212,8 @@ class RowShardedGatherOp(E.Op):
         self.routes = [_RouteSet(self, plan, k) for k in range(2)]
         self.cur = self.routes[0]     # the set the forward / backward exchange of the current step uses
         self.staged = None            # a set routed ahead of time for the NEXT step, or None
-        self.route_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # (a stream that really runs beside the step's: ops.concurrent_stream probes the hardware-queue assignment)
+        self.route_stream = ops.concurrent_stream(dev) if dev.type == "cuda" else None
         self.rows_recv = torch.empty(B * F, sh.emb, dtype=torch.float32, device=dev)
         self.recv_keys = self.rows_send = self.grad_recv = None
         self.n_recv = 0

@@ -16,6 +16,7 @@ import os
 import torch
 
 from . import engine as E
+from .ops import concurrent_stream as ops_concurrent_stream
 from . import profiling
 
 
@@ -145,7 +146,7 @@ class TrainStep:
         if overlap and self.opt.table_update != "dense_exact" and int(B) <= 8192 and par is None and allreduce is None:
             overlap = False
         self.overlap = bool(overlap)
-        self.side = self._concurrent_stream(self.store.device) if self.overlap else None
+        self.side = ops_concurrent_stream(self.store.device) if self.overlap else None
         # CU partition of the forked tail (lab knob MMLREC_CU_TAIL = n: table scatter + table optimizer on compute
         # units [0, n), weight-gradient GEMMs + MLP optimizer on [n, all))
         self.tail_stream = None
@@ -204,54 +205,6 @@ class TrainStep:
         self._has_next = False
 
     @staticmethod
-    def _concurrent_stream(device, tries=6):
-        """A stream whose kernels really run beside those of the current stream.  HIP hands streams one of a few
-        hardware queues round-robin (four by default); a process that also holds RCCL's streams and the routing stream of
-        the row-sharded tables can find its side stream on the SAME queue as the main stream, and the forked tail then
-        runs one launch after the other (seen in the kernel trace of the forced row-sharded step: weight-gradient GEMMs
-        and table update on one queue, 2.10 ms where the unsharded step takes 1.88).  So: probe -- a spin kernel on each
-        stream, concurrent if the pair takes the time of one -- and keep the first candidate that passes.
-        MMLREC_SIDE_PROBE=0 takes the first stream unprobed."""
-        main = torch.cuda.current_stream(device)
-        first = torch.cuda.Stream(device=device)
-        if os.environ.get("MMLREC_SIDE_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
-            return first
-        try:
-            spin = 400_000  # cycles: ~0.2 ms
-
-            def pair_ms(s):
-                torch.cuda.synchronize(device)
-                a, b, j = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                           torch.cuda.Event())
-                a.record(main)
-                s.wait_event(a)
-                with torch.cuda.stream(s):
-                    torch.cuda._sleep(spin)
-                    j.record(s)
-                torch.cuda._sleep(spin)
-                main.wait_event(j)
-                b.record(main)
-                torch.cuda.synchronize(device)
-                return a.elapsed_time(b)
-
-            torch.cuda.synchronize(device)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(spin)  # (warm-up of the spin kernel itself)
-            a.record(main)
-            torch.cuda._sleep(spin)
-            b.record(main)
-            torch.cuda.synchronize(device)
-            one = a.elapsed_time(b)
-            cand = first
-            for _ in range(tries):
-                if min(pair_ms(cand), pair_ms(cand)) < 1.5 * one:
-                    return cand
-                cand = torch.cuda.Stream(device=device)
-        except Exception:  # (a probe must never cost the step)
-            pass
-        return first
-
-    @staticmethod
     def _cost(c):
         meta = c[-1] if isinstance(c[-1], dict) else {}
         return 4e-6 + meta.get("flops", 0.0) / 5e14 + meta.get("bytes", 0.0) / 4e12
@@ -298,7 +251,7 @@ class TrainStep:
         p = self.plan
         if self._nX is None:
             self._nX, self._ny = torch.empty_like(p.X), torch.empty_like(p.y)
-            self._stage_stream = torch.cuda.Stream(device=p.device)
+            self._stage_stream = ops_concurrent_stream(p.device)
             self._ev_staged, self._ev_consumed = torch.cuda.Event(), torch.cuda.Event()
             self._ev_consumed.record(torch.cuda.current_stream())
         op = p.ops[0] if p.ops else None
