@@ -13,6 +13,8 @@
  *   mml_opt_step_dense        torch.optim.{SGD,Adam,Adagrad,RMSprop}.step over dense tensors (model/basemodel.py:313, :569-584)
  *   mml_amax_batch / _reset   operand magnitudes (a contract of ours, see include/mmlrec.h)
  *   mml_dropout               nn.Dropout after a DNN layer (model/utils.py:121, :159) under this build's Philox mask stream
+ *   mml_gemm_planes_cut       the pre-cut weight planes of the two-plane GEMM arithmetic (a contract of ours; the CPU GEMMs
+ *                             here ignore w_planes / w_kexp and read the float weights)
  * tests/test_cabi_cpu.py drives one full MMoE training step of a reference-made golden fixture through these entry
  * points (the call sequence of mmlrec_amd/engine.py) in the CPU container.
  * Build: oracle/build_fast.py (gcc -O2 -shared -fPIC), output oracle/_build/libmmlrec_cpu.so. */
@@ -154,6 +156,90 @@ int mml_dropout(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t ro
         out[r * ldo + 4 * q + j] = o;
       }
     }
+  return MML_OK;
+}
+
+/* mml_gemm_planes_cut: the two fp16 planes of a weight matrix in the operand-image layout of include/mmlrec.h.  The
+ * conversions are spelled out (round to nearest even, like the device's v_cvt_pk_f16_f32). */
+static int amax_exp(const uint32_t* slot) {
+  uint32_t m = 0;
+  for (int i = 0; i < MML_AMAX_WORDS; ++i) m = slot[i] > m ? slot[i] : m;
+  const int e = (int)((m >> 23) & 0xffu);
+  if (e == 255) return 0;
+  const int k = 141 - e;
+  return k > 110 ? 110 : (k < -110 ? -110 : k);
+}
+/* fp32 -> fp16 bit pattern, round to nearest even (the gcc of this image has no _Float16 on x86-64), and back */
+static uint32_t half_bits(float xf) {
+  uint32_t f;
+  memcpy(&f, &xf, 4);
+  const uint32_t sign = (f >> 16) & 0x8000u, x = f & 0x7fffffffu;
+  if (x >= 0x7f800000u) return sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u);  /* Inf / NaN */
+  if (x >= 0x477ff000u) return sign | 0x7c00u;                                     /* >= 65520 rounds to Inf */
+  if (x < 0x38800000u) {                                                           /* below 2^-14: subnormal or zero */
+    float a;
+    memcpy(&a, &x, 4);
+    return sign | (uint32_t)lrintf(a * 16777216.0f);  /* |x| 2^24, ties to even (1024 = the smallest normal) */
+  }
+  uint32_t h = ((((x >> 23) - 127u + 15u)) << 10) | ((x & 0x7fffffu) >> 13);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return sign | h;
+}
+static float half_value(uint32_t h) {
+  const uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else {
+    const uint32_t b = ((e - 15u + 127u) << 23) | (m << 13);
+    memcpy(&v, &b, 4);
+  }
+  return (h & 0x8000u) ? -v : v;
+}
+int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_planes_cut: bad descriptor array");
+  for (int i = 0; i < n; ++i) {
+    const mml_planes_desc* q = &d[i];
+    const int64_t ldp = q->ldp ? q->ldp : q->ld;
+    REQUIRE(q->W && q->planes && q->kexp && q->n_amax >= 1 && q->n_amax <= MML_MAX_SRC, "mml_gemm_planes_cut: matrix %d malformed", i);
+    REQUIRE(q->layout == MML_PLANES_ROWS ? ldp >= (q->cols + 15) / 16 * 16 : (q->rows % 16 == 0 && ldp >= q->cols),
+            "mml_gemm_planes_cut: matrix %d: pitch / reduction extent", i);
+    int k = 110;
+    for (int a = 0; a < q->n_amax; ++a) {
+      const int ka = amax_exp(q->amax[a]);
+      k = ka < k ? ka : k;
+    }
+    *q->kexp = k;
+    const float s = ldexpf(1.f, k);
+    const int rows_k = q->layout == MML_PLANES_ROWS;  /* reduction along a row */
+    const int64_t outer = rows_k ? q->rows : q->cols, blocks = rows_k ? (q->cols + 15) / 16 : q->rows / 16;
+    for (int64_t o = 0; o < outer; ++o)
+      for (int64_t b = 0; b < blocks; ++b) {
+        uint32_t hp[16], lp[16];
+        for (int e = 0; e < 16; ++e) {
+          const int64_t kk = 16 * b + e;
+          const int live = rows_k ? kk < q->cols : 1;
+          const float x = live ? (rows_k ? q->W[o * q->ld + kk] : q->W[kk * q->ld + o]) : 0.f;
+          const float y = x * s;
+          hp[e] = half_bits(y);
+          lp[e] = half_bits(y - half_value(hp[e]));
+        }
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 4; ++j) {
+            const int k0 = 4 * h + ((2 * j) & 3) + 8 * ((2 * j) >> 2), k1 = 4 * h + ((2 * j + 1) & 3) + 8 * ((2 * j + 1) >> 2);
+            const int64_t wh = 16 * b + 4 * h + j, wl = 16 * b + 8 + 4 * h + j;
+            if (rows_k) {
+              q->planes[o * ldp + wh] = hp[k0] | (hp[k1] << 16);
+              q->planes[o * ldp + wl] = lp[k0] | (lp[k1] << 16);
+            } else {
+              q->planes[wh * ldp + o] = hp[k0] | (hp[k1] << 16);
+              q->planes[wl * ldp + o] = lp[k0] | (lp[k1] << 16);
+            }
+          }
+      }
+  }
   return MML_OK;
 }
 

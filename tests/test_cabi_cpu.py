@@ -66,6 +66,65 @@ def test_cpu_library_dropout_is_the_oracle_mask(cpu):
                            None) == -1
 
 
+def test_cpu_library_planes_cut_layout(cpu):
+    """The plane image of mml_gemm_planes_cut (include/mmlrec.h) from the C restatement against a numpy one: both layouts,
+    a ragged reduction with a wider planes pitch, a group of two magnitudes.  (tests/test_gemm_pipe_gpu.py pins the HIP
+    kernel to the same numpy image.)"""
+    lib, L = cpu
+    rng = np.random.default_rng(4)
+
+    def slot(v):
+        s = np.zeros(8, dtype=np.uint32)
+        s[3] = np.float32(v).view(np.uint32)
+        return s
+
+    def kexp(v):
+        e = (np.float32(v).view(np.uint32) >> 23) & 0xff
+        return int(np.clip(141 - int(e), -110, 110))
+
+    def image(W, k, layout):
+        y = W.astype(np.float32) * np.float32(2.0 ** k)
+        h = y.astype(np.float16)
+        lo = (y - h.astype(np.float32)).astype(np.float16)
+        hb, lb = h.view(np.uint16).astype(np.uint32), lo.view(np.uint16).astype(np.uint32)
+        if layout == 1:
+            hb, lb = hb.T, lb.T
+        out = np.zeros(hb.shape, dtype=np.uint32)
+        S = [[4 * hh + (e & 3) + 8 * (e >> 2) for e in range(8)] for hh in range(2)]
+        for b in range(hb.shape[1] // 16):
+            bh, bl = hb[:, 16 * b:16 * b + 16], lb[:, 16 * b:16 * b + 16]
+            for hh in range(2):
+                for i in range(4):
+                    k0, k1 = S[hh][2 * i], S[hh][2 * i + 1]
+                    out[:, 16 * b + 4 * hh + i] = bh[:, k0] | (bh[:, k1] << 16)
+                    out[:, 16 * b + 8 + 4 * hh + i] = bl[:, k0] | (bl[:, k1] << 16)
+        return out.T.copy() if layout == 1 else out
+
+    N, K, KP = 48, 72, 80
+    W = (rng.standard_normal((N, K)) * 3e-4).astype(np.float32)
+    s_own, s_big = slot(np.abs(W).max()), slot(7.5)
+    arr = (L.PlanesDesc * 3)()
+    outs = [np.zeros((N, KP), dtype=np.uint32) for _ in range(3)]
+    kx = np.zeros(3, dtype=np.int32)
+    for i, (layout, slots) in enumerate(((0, [s_own]), (1, [s_own]), (1, [s_own, s_big]))):
+        d = arr[i]
+        d.W, d.planes, d.rows, d.ld, d.cols, d.layout, d.ldp = W.ctypes.data, outs[i].ctypes.data, N, K, K, layout, KP
+        d.n_amax = len(slots)
+        for a, sl in enumerate(slots):
+            d.amax[a] = sl.ctypes.data
+        d.kexp = kx[i:i + 1].ctypes.data
+    assert lib.mml_gemm_planes_cut(arr, 3, None) == 0
+    Wpad = np.zeros((N, KP), dtype=np.float32)
+    Wpad[:, :K] = W
+    k_own, k_grp = kexp(np.abs(W).max()), min(kexp(np.abs(W).max()), kexp(7.5))
+    assert kx.tolist() == [k_own, k_own, k_grp]
+    assert np.array_equal(outs[0], image(Wpad, k_own, 0))
+    assert np.array_equal(outs[1], image(Wpad, k_own, 1))
+    assert np.array_equal(outs[2], image(Wpad, k_grp, 1))
+    arr[0].ldp = K  # no room for the rounded-up block of the ragged reduction
+    assert lib.mml_gemm_planes_cut(arr, 1, None) == -1
+
+
 def ptr(a):
     return a.ctypes.data
 
