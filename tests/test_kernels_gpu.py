@@ -973,3 +973,38 @@ def test_scatter_det_is_bitwise_repeatable_and_order_independent(E):
     ops.scatter_bwd_det(gt, X.to(dev), list(range(F)), d.to(dev), acc, marks)
     for f in range(F):
         assert torch.allclose(gt[f], 2 * g1[f], rtol=1e-6, atol=0)
+
+
+def test_concurrent_stream_runs_beside_the_current_stream(ops):
+    """ops.concurrent_stream: the stream it returns executes a kernel WHILE the current stream executes another (the
+    trainer's forked tail and the routing prefetch depend on it; HIP's round-robin hardware-queue assignment does not
+    guarantee it for an arbitrary new stream)."""
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("no spin kernel in this torch build")
+    d = dev()
+    main = torch.cuda.current_stream(d)
+    side = ops.concurrent_stream(d)
+    assert side != main
+    spin = 400_000
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main)
+        fn()
+        b.record(main)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    def pair():
+        j = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(spin)
+            j.record(side)
+        torch.cuda._sleep(spin)
+        main.wait_event(j)
+
+    torch.cuda._sleep(spin)
+    one = min(timed(lambda: torch.cuda._sleep(spin)) for _ in range(3))
+    both = min(timed(pair) for _ in range(3))
+    assert both < 1.5 * one, (one, both)
