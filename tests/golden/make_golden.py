@@ -14,7 +14,9 @@ What is captured per case:
   dnn_input, layer/<name> (reference save_layer_output hooks, e.g. mmoe.py:110-118),
   y_pred, y_pred_masked, loss, grad/<key> (dense [V,E] table grads: sparse=False, basemodel.py:122),
   adam1/, adam3/, adagrad3/ (parameters after 1 and 3 reference train steps over batches 0..2,
-  basemodel.py:268-313), init_y_pred for the as-constructed (std=1e-4) weights.
+  basemodel.py:268-313), init_y_pred for the as-constructed (std=1e-4) weights;
+  rmsprop1/, rmsprop3/, sgd1/, sgd3/ + their losses for the cases in EXTRA_OPTIMIZER_CASES (the other two optimizers
+  basemodel.py:569-584 builds: torch.optim.RMSprop / SGD with the config's lr and torch's defaults).
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -51,6 +53,10 @@ from model.cross_stitch import CrossStitch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 B = 64
+# cases that also carry 3-step RMSprop and SGD trajectories (the two optimizers of basemodel.py:569-584 that
+# no fixture pinned)
+EXTRA_OPTIMIZER_CASES = ("sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "star_amazon",
+                         "pepnet_amazon")
 
 
 def base_config(task_name, model_name, label_columns, emb, optimizer, lr, **model_kw):
@@ -393,13 +399,14 @@ def run_case(case):
         model.train()
 
     # optimizer trajectories: 1 and 3 steps of Adam and Adagrad over batches 0,1,2
-    for opt in ("adam", "adagrad"):
+    opts = ("adam", "adagrad") + (("rmsprop", "sgd") if name in EXTRA_OPTIMIZER_CASES else ())
+    for opt in opts:
         model.load_state_dict(state0)
         model.compile(opt, cfg["optim_config"]["loss"], ["auc", "acc"])
         losses = []
         for i, (X, y) in enumerate(batches):
             losses.append(ref_train_step(model, X, y))
-            if (opt == "adam" and i in (0, 2)) or (opt == "adagrad" and i == 2):
+            if (opt in ("adam", "rmsprop", "sgd") and i in (0, 2)) or (opt == "adagrad" and i == 2):
                 for k, v in model.state_dict().items():
                     out[f"{opt}{i + 1}/{k}"] = v.numpy().copy()
         out[f"{opt}_losses"] = np.array(losses, dtype=np.float64)

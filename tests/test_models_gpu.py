@@ -216,6 +216,9 @@ def test_fused_train_steps(case, graph, arith):
     """Fused step (fwd + BCE + bwd + optimizer) reproduces the reference's parameters after 1 and 3 steps."""
     name, g = case
     combos = (("adam", (1, 3), "dense_exact"), ("adagrad", (3,), "sparse_rows"), ("adam", (1, 3), "lazy_exact"))
+    if "rmsprop_losses" in g.files:  # fixtures that pin torch.optim.RMSprop / SGD too (basemodel.py:569-584)
+        combos += (("rmsprop", (1, 3), "dense_exact"), ("rmsprop", (1, 3), "lazy_exact"), ("sgd", (1, 3), "auto"),
+                   ("sgd", (1, 3), "dense_exact"))
     if json.loads(str(g["cfg"]))["model_config"].get("l2_reg_embedding", 0):
         # a regulariser on the tables moves every row every step: only the dense table update is the reference's
         combos = (("adam", (1, 3), "dense_exact"), ("adagrad", (3,), "auto"))
@@ -262,9 +265,13 @@ def test_fused_train_steps(case, graph, arith):
                         continue
                     # Adam/Adagrad divide by sqrt(sum g^2): gradients at fp32-noise level may flip a whole lr-sized
                     # update, hence outlier share + absolute bound instead of a pure max-relative test
-                    if (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() >= 2e-3 and free_running is None:
+                    # (RMSprop: a gradient at the level of eps / 0.1 moves its element by a value-dependent share of
+                    # 10 lr, so one element per tensor is tolerated -- tests/test_oracle_golden.py has the same rule)
+                    few = max(2e-3 * dv.size, 1.5 if kind == "rmsprop" else 0.0)
+                    if (dv > RTOL * max(np.abs(ref).max(), 1e-30)).sum() >= few and free_running is None:
                         free_running = (kind, i + 1, k)
-                    assert dv.max() <= 2.5 * lr * (i + 1), (kind, i + 1, k)
+                    # (an RMSprop step is up to 10 lr per element: g / sqrt(0.01 g^2))
+                    assert dv.max() <= (25.0 if kind == "rmsprop" else 2.5) * lr * (i + 1), (kind, i + 1, k)
                 if free_running is not None:
                     # the free-running trajectory left the reference's: legitimate only as amplified rounding noise,
                     # i.e. when EVERY step since the first checkpoint is the oracle's step from the MI355X's own state

@@ -74,7 +74,10 @@ def test_loss_and_grads(golden):
 def test_optimizer_trajectories(golden):
     name, g = golden
     spec, _, frozen = setup(g)
-    for kind, checkpoints in (("adam", (1, 3)), ("adagrad", (3,))):
+    kinds = (("adam", (1, 3)), ("adagrad", (3,)))
+    if "rmsprop_losses" in g.files:  # the fixtures that also pin torch.optim.RMSprop / SGD (basemodel.py:569-584)
+        kinds += (("rmsprop", (1, 3)), ("sgd", (1, 3)))
+    for kind, checkpoints in kinds:
         params = orc.params_from_golden(g)
         opt = orc.DenseOptimizer(kind, spec.cfg["optim_config"]["lr"])
         losses = []
@@ -96,6 +99,19 @@ def test_optimizer_trajectories(golden):
                     bad = (np.abs(upd - upd_ref) > 0.05 * scale).mean()
                     assert bad < 1e-3, (kind, i + 1, k, bad)
                     dv = np.abs(params[k].astype(np.float64) - ref)
-                    assert (dv > RTOL * np.abs(ref).max()).mean() < 1e-3, (kind, i + 1, k)
-                    assert dv.max() <= 2.5 * float(opt.lr) * (i + 1), (kind, i + 1, k)
+                    # (RMSprop's first steps are lr * 10 * sign(g) whatever |g| is, later ones depend on RATIOS of
+                    # successive gradients, and PepNet's loss goes 184 -> 290 -> 175 in the reference's own run: there
+                    # the value criterion is 1e-3 of the UPDATE scale where that is larger than 1e-4 of the tensor's)
+                    vtol = RTOL * np.abs(ref).max()
+                    if kind == "rmsprop" and i > 0:  # (the first step is held to the strict criterion)
+                        vtol = max(vtol, 1e-3 * scale)
+                    # a gradient at the level of RMSprop's eps / 0.1 = 1e-7 moves its element by a value-dependent
+                    # fraction of 10 lr already in step 1: one such element is tolerated per tensor; after three of
+                    # PepNet's chaotic steps 0.5 % of the elements
+                    allowed = max(1e-3 * dv.size, 1.5) if kind == "rmsprop" else 1e-3 * dv.size
+                    if kind == "rmsprop" and i > 0:
+                        allowed = max(allowed, 5e-3 * dv.size)
+                    assert (dv > vtol).sum() < allowed, (kind, i + 1, k)
+                    # (an RMSprop step is up to 10 lr per element: g / sqrt(0.01 g^2))
+                    assert dv.max() <= (25.0 if kind == "rmsprop" else 2.5) * float(opt.lr) * (i + 1), (kind, i + 1, k)
         assert np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL)
