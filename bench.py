@@ -61,15 +61,40 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT a HIP call (torch.cuda.device_count() can fall through to hipGetDeviceCount
+    on builds without amdsmi, which initialises the runtime in the parent of the ranks: ADVICE r3): the KFD topology
+    nodes with SIMDs, cut down by HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES.  None when sysfs says nothing (the ranks then
+    fail with their own message)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(ln.split(None, 1) for ln in f.read().splitlines() if " " in ln)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (no
-    GPU call has happened in this process), relay its output -- the JSON line of rank 0 stays the last stdout line --
+    GPU call happens in this process: the device count comes from sysfs), relay its output -- the JSON line of rank 0 stays the last stdout line --
     and return its exit code."""
     import socket
     import subprocess
     share = os.environ.get("MMLREC_BENCH_SHARE_GPU") == "1"
-    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-    if ndev < args.gpus and not share:
+    ndev = visible_gpu_count()  # (from sysfs: nothing in THIS process may initialise the HIP runtime)
+    if ndev is not None and ndev < args.gpus and not share:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -590,4 +615,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:  # a rank that lost a collective must end the whole job: the launcher reaps the others
+        if type(e).__name__ == "CollectiveError":
+            import traceback
+            traceback.print_exc()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(70)
+        raise

@@ -266,6 +266,10 @@ class BaseModel(nn.Module):
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
         cols = [self.feature_index[f.name][0] for f in sp]
         par = getattr(self, "_parallel", None)
+        if par is not None and training and par.mode in ("table_wise", "row_sharded"):
+            # the owner-side scatter of these modes is the float-atomic kernel: a deterministic request must not be
+            # dropped silently
+            self._reject_deterministic(par.mode)
         if par is not None and par.mode == "table_wise":
             from ..parallel import ShardedGatherOp
             plan.add(ShardedGatherOp(par, tables, plan.X, cols, dense_col0, nd, x0, sparse_rows=sparse_rows))
@@ -299,19 +303,37 @@ class BaseModel(nn.Module):
         head = self._build_graph(plan, store, x0)
         head.mask_cols = self._head_mask_cols()
         plan.finish(head)
+        if (getattr(self, "optim_name", None) is None and plan.dropout_on and
+                any(isinstance(o, E.DropoutOp) for o in plan.ops)):
+            # an uncompiled model in a custom training loop: the plan owns its step counter, and nothing else would ever
+            # move it -- every forward would draw the SAME dropout mask.  The forward bumps it first; the
+            # backward of that forward regenerates the mask from the same value.
+            plan.fwd.insert(0, (L.load().mml_counter_update, (plan.step_dev.data_ptr(), 1, 0),
+                                dict(kernel="mml_counter_update", bytes=4.0)))
+            plan.n_pre += 1
         return plan
 
     def _maybe_deterministic(self, gop, store, tables, training, E_dim):
         """model.scatter_mode = "deterministic" (or model_config["scatter_mode"]): the table gradients of the step are
         summed in order-independent integer fixed point (mml_scatter_bwd_det) -- bitwise repeatable runs, and replicated
         tables that stay bitwise equal on every rank without re-broadcasts.  Default "atomic" (float atomics: faster)."""
-        mode = getattr(self, "scatter_mode", None) or (self.config or {}).get("model_config", {}).get("scatter_mode", "atomic")
-        if mode not in ("atomic", "deterministic"):
-            raise ValueError("scatter_mode must be 'atomic' or 'deterministic'")
+        mode = self._scatter_mode()
         if mode == "deterministic" and training:
             if E_dim not in (4, 8, 16) or len({id(t) for t in tables}) != len(tables):
                 raise NotImplementedError("deterministic scatter: embedding size 4, 8 or 16 and one table per field")
             gop.deterministic = store.ensure_det(tables)
+
+    def _scatter_mode(self):
+        mode = getattr(self, "scatter_mode", None) or (self.config or {}).get("model_config", {}).get("scatter_mode", "atomic")
+        if mode not in ("atomic", "deterministic"):
+            raise ValueError("scatter_mode must be 'atomic' or 'deterministic'")
+        return mode
+
+    def _reject_deterministic(self, where):
+        if self._scatter_mode() == "deterministic":
+            raise NotImplementedError(
+                f"scatter_mode='deterministic' is not available with {where} tables (their owner-side scatter sums with "
+                "float atomics); use mode='replicated' or a single GPU for bitwise-repeatable table gradients")
 
     def _head_mask_cols(self):
         """Column of domain_mask that multiplies head i (e.g. model/mmoe.py:101-106), or None for unmasked heads."""

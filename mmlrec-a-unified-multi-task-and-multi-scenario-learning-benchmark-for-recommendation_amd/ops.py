@@ -52,6 +52,9 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+_SPIN_CAL = {}  # device index -> (spin ticks for ~0.2 ms, measured ms of one such spin)
+
+
 def concurrent_stream(device, tries=6):
     """A stream whose kernels really run beside those of the current stream.  HIP hands streams one of a few
     hardware queues round-robin (four by default); a process that also holds RCCL's streams and the routing stream of
@@ -65,31 +68,42 @@ def concurrent_stream(device, tries=6):
     if os.environ.get("MMLREC_SIDE_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
         return first
     try:
-        spin = 400_000  # cycles: ~0.2 ms
-
-        def pair_ms(s):
+        def timed(fn):
             torch.cuda.synchronize(device)
-            a, b, j = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                       torch.cuda.Event())
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(main)
-            s.wait_event(a)
-            with torch.cuda.stream(s):
-                torch.cuda._sleep(spin)
-                j.record(s)
-            torch.cuda._sleep(spin)
-            main.wait_event(j)
+            fn()
             b.record(main)
             torch.cuda.synchronize(device)
             return a.elapsed_time(b)
 
-        torch.cuda.synchronize(device)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(spin)  # (warm-up of the spin kernel itself)
-        a.record(main)
-        torch.cuda._sleep(spin)
-        b.record(main)
-        torch.cuda.synchronize(device)
-        one = a.elapsed_time(b)
+        # torch.cuda._sleep counts s_memtime ticks (a 100 MHz constant clock on gfx9, not shader cycles): the spin length
+        # for ~0.2 ms is MEASURED once per device and cached (400 000 ticks were ~4 ms per probe)
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        cal = _SPIN_CAL.get(key)
+        if cal is None:
+            torch.cuda._sleep(1000)  # (loads the spin kernel)
+            probe = 20_000
+            ms = max(timed(lambda: torch.cuda._sleep(probe)), 1e-3)
+            spin = int(min(max(probe * 0.2 / ms, 2_000), 2_000_000))
+            one = timed(lambda: torch.cuda._sleep(spin))
+            cal = _SPIN_CAL[key] = (spin, one)
+        spin, one = cal
+
+        def pair_ms(s):
+            j = torch.cuda.Event()
+
+            def both():
+                a0 = torch.cuda.Event()
+                a0.record(main)
+                s.wait_event(a0)
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(spin)
+                    j.record(s)
+                torch.cuda._sleep(spin)
+                main.wait_event(j)
+            return timed(both)
+
         cand = first
         for _ in range(tries):
             if min(pair_ms(cand), pair_ms(cand)) < 1.5 * one:

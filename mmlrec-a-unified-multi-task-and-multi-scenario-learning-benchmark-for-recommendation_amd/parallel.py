@@ -32,6 +32,10 @@ from . import engine as E
 from . import ops
 
 
+class CollectiveError(RuntimeError):
+    """A collective failed on this rank: the ranks are out of step and the job has to end."""
+
+
 class Comm:
     """The few collectives the step needs, on one process group.  RCCL ("nccl") moves device buffers directly; under
     "gloo" (the world-2 tests: two processes on one GPU or on CPU) device buffers are staged through the host."""
@@ -49,19 +53,25 @@ class Comm:
 
     def _call(self, what, fn, *a, **k):
         """A failed collective leaves the ranks out of step: every later exchange would hang or mix batches.  Say which
-        rank failed in what, then take the whole job down (failure detection; the launcher reaps the others)."""
+        rank failed in what and re-raise as CollectiveError; launcher scripts (bench.py, main.run) turn that into a
+        non-zero exit of the whole job (failure detection; the launcher reaps the others).  Errors that never
+        left this rank (a bad split list, a dtype mismatch: TypeError / ValueError) pass through unchanged.  With
+        MMLREC_COMM_EXIT=1 a backend failure ends the process at once (for jobs without such a launcher)."""
         try:
             return fn(*a, **k)
+        except (TypeError, ValueError):
+            raise
         except Exception as e:  # RCCL / gloo errors surface as RuntimeError / DistBackendError
             import os
             import sys
             import traceback
             sys.stderr.write(f"[mmlrec rank {self.rank}/{self.world}] collective {what} failed: {e!r}\n")
             traceback.print_exc()
+            sys.stdout.flush()
             sys.stderr.flush()
-            if os.environ.get("MMLREC_COMM_RAISE") == "1":  # (tests: observe the error instead of dying)
-                raise
-            os._exit(70)
+            if os.environ.get("MMLREC_COMM_EXIT") == "1":
+                os._exit(70)
+            raise CollectiveError(f"rank {self.rank}/{self.world}: collective {what} failed: {e!r}") from e
 
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         o, i = self._stage(out), self._stage(inp)

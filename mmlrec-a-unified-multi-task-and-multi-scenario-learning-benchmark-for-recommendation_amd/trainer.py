@@ -211,9 +211,9 @@ class TrainStep:
 
     def _early_fork(self, p, B):
         """Index into plan.bwd at which the side stream forks early (0 = only at the end of the chain).
-        MMLREC_EARLY_WGRAD: 0 off, n > 0 that index, unset / "auto": where the side calls that are ready by then take
-        about as long as the rest of the chain -- but only when the tail has no dense table stream of the same length
-        to put them beside."""
+        MMLREC_EARLY_WGRAD: unset or 0 = off (the default: measured a loss or level on every workload),
+        n > 0 = that index, "auto" = where the side calls that are ready by then take about as long as the rest of the
+        chain -- but only when the tail has no dense table stream of the same length to put them beside."""
         env = os.environ.get("MMLREC_EARLY_WGRAD", "0")
         ready = [c[-1].get("ready") for c in p.bwd_side]
         if env == "0" or not p.bwd_side or any(r is None for r in ready) or any(c[0] is E.PY for c in p.bwd):

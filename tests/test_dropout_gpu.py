@@ -96,7 +96,8 @@ def test_model_gradients_with_dropout_match_the_oracle_under_the_same_mask(name)
     spec = _spec(g, P)
     params = orc.params_from_golden(g)
     frozen = orc.params_from_golden(g, "frozen/")
-    orc.set_dropout(P, seed=model.dropout_seed, step=0)  # (no optimizer: the plan's own step counter stays 0)
+    # (no optimizer: the plan owns its step counter and every training-mode forward bumps it first -- this was forward 1)
+    orc.set_dropout(P, seed=model.dropout_seed, step=1)
     try:
         ref_loss, ref_grads, _ = orc.loss_and_grads(spec, params, g["X0"], g["y0"], frozen or None)
     finally:
@@ -114,6 +115,17 @@ def test_model_gradients_with_dropout_match_the_oracle_under_the_same_mask(name)
                 assert elem_rel(p.grad.cpu().numpy(), ref_grads[n]) <= 1.0, n
             checked += 1
     assert checked >= 4
+    # a second forward of the uncompiled model draws ANOTHER mask (the counter used to stay at 0), the
+    # oracle's for step word 2
+    with torch.no_grad():
+        yp2 = model(X).cpu().numpy()
+    assert np.abs(yp2 - yp.detach().cpu().numpy()).max() > 1e-6
+    orc.set_dropout(P, seed=model.dropout_seed, step=2)
+    try:
+        _, _, cache2 = orc.loss_and_grads(spec, params, g["X0"], g["y0"], frozen or None)
+    finally:
+        orc.set_dropout(0)
+    assert rel(yp2, cache2["p"]) < RTOL
 
 
 @pytest.mark.parametrize("name,graph", [("sharedbottom_ml", False), ("mmoe_ae30", True), ("ple_ijcai", True)])

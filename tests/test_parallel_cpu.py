@@ -241,8 +241,9 @@ def test_field_sharding_balances_rows_and_lookups():
 
 
 def test_failed_collective_names_the_rank(monkeypatch, capsys):
-    """A collective that fails is reported with the rank and its name (and takes the process down unless
-    MMLREC_COMM_RAISE=1 asks for the exception): SURVEY section 5, failure detection."""
+    """A collective that fails is reported with the rank and its name and raises CollectiveError (launchers turn it into
+    a non-zero exit; MMLREC_COMM_EXIT=1 ends the process at once); an argument error that never left the rank passes
+    through unchanged: SURVEY section 5, failure detection; ADVICE r3."""
     import torch
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd import parallel
@@ -267,10 +268,18 @@ def test_failed_collective_names_the_rank(monkeypatch, capsys):
         def all_reduce(t, op=None, group=None):
             raise RuntimeError("NCCL error: unhandled system error")
 
-    monkeypatch.setenv("MMLREC_COMM_RAISE", "1")
+        @staticmethod
+        def all_to_all_single(o, i, out_splits=None, in_splits=None, group=None):
+            raise ValueError("split sizes do not add up")
+
+    monkeypatch.delenv("MMLREC_COMM_EXIT", raising=False)
     comm = parallel.Comm(FakeDist)
     import pytest
-    with pytest.raises(RuntimeError):
+    with pytest.raises(parallel.CollectiveError):
         comm.all_reduce(torch.zeros(4))
     err = capsys.readouterr().err
     assert "rank 1/2" in err and "all_reduce(sum)" in err and "unhandled system error" in err
+    with pytest.raises(ValueError) as ei:
+        comm.all_to_all_single(torch.zeros(4), torch.zeros(4), [1, 2], [2, 2])
+    assert not isinstance(ei.value, parallel.CollectiveError)
+    assert capsys.readouterr().err == ""
