@@ -222,6 +222,14 @@ int mml_rows_clear(const int32_t* list, const int32_t* count, int32_t cap, const
  * Environment MMLREC_GEMM_MODE overrides the default. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);
+/* The activation-stationary forward kernel (csrc/gemm_panel.hip; round 4).  A grouped forward launch whose problems ALL
+ * read one input A [M, K] (the first DNN layer of every expert / gate tower: reference model/mmoe.py:69-79) with
+ * 160 <= K <= 240, K % 16 == 0, M >= 8 192, N % 64 == 0, nn.Linear weights with pre-cut planes, the magnitude of A,
+ * activation relu or none, 16-byte aligned operands, and relu sign masks on all problems or on none, is served by a
+ * persistent workgroup per 128-row block that keeps the block's fp16 planes in LDS and sweeps every N-tile from it
+ * (bitwise the results of the tile kernel).  on = 0 switches it off (process-wide; default on; environment
+ * MMLREC_GEMM_PANEL=0 does the same). */
+int mml_gemm_set_panel(int32_t on);
 /* Kernel symbol (as rocprofv3 prints it, without the mml:: prefix) of the calling thread's most recent GEMM launch;
  * "" before the first one.  For profilers / benchmark labels. */
 const char* mml_gemm_last_kernel(void);

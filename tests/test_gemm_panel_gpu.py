@@ -1,0 +1,124 @@
+"""The activation-stationary forward kernel (csrc/gemm_panel.hip) against float64 and, bit for bit, against the tile
+kernel it replaces for the shared-input first layers (reference model/mmoe.py:69-79, model/utils.py:146-161)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-6  # max-norm, against float64 (the two-plane fp16 arithmetic measures 3.3e-7)
+
+
+@pytest.fixture()
+def env():
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib as L, ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    lib = L.load()
+    mode0 = lib.mml_gemm_get_mode()
+    yield torch, L, ops, lib
+    lib.mml_gemm_set_mode(mode0)
+    lib.mml_gemm_set_panel(1)
+
+
+def make_launch(torch, L, ops, M, K, Ns, masks=True, bias=True, acts=None, seed=0, scale=1.0):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = (torch.randn(M, K, generator=g) * scale).to(dev)
+    slots = ops.amax_slots(1 + 2 * len(Ns), dev)
+    ops.amax_batch([(A, slots[0])])
+    probs, items = [], []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev) if (bias and i % 3 != 2) else None
+        ops.amax_batch([(W, slots[1 + 2 * i])])
+        planes = torch.zeros(W.shape, dtype=torch.int32, device=dev)
+        kexp = torch.zeros(1, dtype=torch.int32, device=dev)
+        items.append((W, planes, ops.PLANES_ROWS, [slots[1 + 2 * i]], kexp))
+        act = (acts[i] if acts else L.ACT_RELU)
+        p = dict(A=A, W=W, bias=b, act=act, amax_a=slots[0], amax_w=slots[1 + 2 * i], w_planes=planes, w_kexp=kexp,
+                 amax_out=slots[2 + 2 * i])
+        probs.append(p)
+    ops.planes_cut(items)
+    return A, probs, slots
+
+
+def run(torch, ops, lib, probs, M, panel, masks):
+    dev = torch.device("cuda:0")
+    lib.mml_gemm_set_panel(1 if panel else 0)
+    out = []
+    for p in probs:
+        N = p["W"].shape[0]
+        p["C"] = torch.full((M, N), float("nan"), device=dev)
+        if masks:
+            p["mask"] = torch.full((M, (N + 31) // 32), 0x55555555, dtype=torch.int32, device=dev)
+        p["amax_out"].zero_()
+    ops.gemm_fwd(probs)
+    torch.cuda.synchronize()
+    name = lib.mml_gemm_last_kernel().decode()
+    for p in probs:
+        out.append((p["C"].clone(), p["mask"].clone() if masks else None, p["amax_out"].clone()))
+    return name, out
+
+
+@pytest.mark.parametrize("M,K,Ns,masks", [
+    (8192, 240, [256, 256, 256, 256, 64, 64], True),     # AE-30's first layer: 4 experts + 2 gates, two gates in one tile
+    (8192, 240, [256, 64, 64, 64], False),               # odd number of half tiles (inference: no masks)
+    (8192 + 77, 160, [128, 64], True),                   # ragged last panel, the shortest reduction the kernel takes
+    (40000, 208, [64], True),                            # one half tile only; more panels than workgroups
+])
+def test_panel_fwd_matches_float64_and_the_tile_kernel(env, M, K, Ns, masks):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=masks, seed=M + K)
+    name_p, out_p = run(torch, ops, lib, probs, M, True, masks)
+    assert name_p == "gemm_panel_kernel", name_p
+    name_t, out_t = run(torch, ops, lib, probs, M, False, masks)
+    assert "gemm_pipe_kernel" in name_t and ", 2, " in name_t, name_t
+    for p, (C, mk, am), (Ct, mkt, amt) in zip(probs, out_p, out_t):
+        z = A.double() @ p["W"].double().t()
+        if p["bias"] is not None:
+            z = z + p["bias"].double()
+        ref = torch.relu(z) if p["act"] == L.ACT_RELU else z
+        err = float((C.double() - ref).abs().max() / ref.abs().max())
+        assert err < RTOL, err
+        assert torch.equal(C, Ct)                       # same planes, same product and k order: same bits
+        if masks:
+            N = p["W"].shape[0]
+            bits = (C > 0).cpu().numpy()
+            words = mk.cpu().numpy().view(np.uint32)
+            got = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, -1)[:, :N].astype(bool)
+            assert np.array_equal(got, bits)
+            assert torch.equal(mk, mkt)
+        # the published magnitude bounds what was stored
+        amax = float(torch.max(am.view(torch.float32)))
+        assert amax >= float(C.abs().max()) and amax <= float(C.abs().max()) * (1 + 1e-6)
+
+
+def test_panel_fwd_is_scale_invariant(env):
+    """Operands far outside fp16's own range (the reference initialises weights at 1e-4; activations of 3e-9 or 2e20)."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    for scale in (3e-9, 1.0, 2e20):
+        A, probs, _ = make_launch(torch, L, ops, 8192, 240, [128, 64], masks=False, bias=False, seed=3, scale=scale,
+                                  acts=[L.ACT_NONE, L.ACT_RELU])
+        name, out = run(torch, ops, lib, probs, 8192, True, False)
+        assert name == "gemm_panel_kernel"
+        for p, (C, _, _) in zip(probs, out):
+            z = A.double() @ p["W"].double().t()
+            ref = torch.relu(z) if p["act"] == L.ACT_RELU else z
+            err = float((C.double() - ref).abs().max() / ref.abs().max())
+            assert err < RTOL, (scale, err)
+
+
+def test_launches_the_panel_kernel_does_not_serve_fall_back(env):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    # K beyond the LDS panel, a batch below the threshold, a sigmoid, a problem with another input
+    for M, K, Ns, acts in ((8192, 256, [128], None), (4096, 240, [128], None), (8192, 240, [128], [L.ACT_SIGMOID])):
+        A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=False, acts=acts)
+        name, out = run(torch, ops, lib, probs, M, True, False)
+        assert "gemm_pipe_kernel" in name, (M, K, name)
+        z = A.double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
+        ref = torch.sigmoid(z) if acts else torch.relu(z)
+        assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL

@@ -76,6 +76,8 @@ def main():
             W = torch.randn(N, K, device=dev) / K ** 0.5
             Cc = torch.empty(M, N, device=dev)
             probs_f.append(dict(A=A[K], W=W, bias=torch.zeros(N, device=dev), C=Cc, act=L.ACT_RELU))
+            if os.environ.get("GEMM_MASK", "0") == "1":  # the training step's forward also writes the relu sign masks
+                probs_f[-1]["mask"] = torch.zeros(M, (N + 31) // 32, dtype=torch.int32, device=dev)
             probs_w.append(dict(dC=Cc, A=A[K], dW=torch.empty(N, K, device=dev), dbias=torch.empty(N, device=dev)))
             flops += 2.0 * M * N * K
         key = lambda t_: (t_.data_ptr(), tuple(t_.shape), t_.stride(0))  # noqa: E731
@@ -111,7 +113,9 @@ def main():
             for p in probs_f:
                 p["amax_out"] = ops.amax_slots(1, dev)[0]
         t = timeit(lambda: ops.gemm_fwd(probs_f))
-        print(f"{name:22s} fwd   {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
+        print(f"{name:22s} fwd   {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s   [{L.load().mml_gemm_last_kernel().decode()}]")
+        if os.environ.get("FWD_ONLY") == "1":
+            continue
         t = timeit(lambda: ops.gemm_wgrad(probs_w))
         print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
         K0 = shapes[0][1]
