@@ -5,14 +5,18 @@
 // gemm_pipe_kernel (gemm.hip) treats the N-tiles of such a launch as unrelated tiles: the 128 x K activation panel is
 // fetched, staged and cut into its two fp16 planes once per N-TILE -- nine times for AE-30's 4 x 256 + 2 x 64 output
 // columns -- and every tile pays its own prologue.  Here a persistent workgroup owns a 128-row panel:
-//   * the panel (K <= 240: <= 120 KB) is moved into LDS ONCE, cut in place into the two fp16 planes of the scaled values
-//     (same bits as the in-register cut of gemm.hip: h = rne16(x s), l = rne16(x s - h)), and stays there while the
-//     workgroup sweeps every N-tile of the row block;
-//   * the weights arrive pre-cut (mml_gemm_planes_cut, MML_PLANES_ROWS) through a three-stage LDS-DMA ring, so the k-loop
-//     holds no VALU work at all: LDS-DMA issue, fragment reads one step ahead, twelve v_mfma_f32_32x32x16_f16 per wave;
-//   * one wave per SIMD (256 threads, up to 512 VGPRs): the finished tile leaves the k-loop in a second register set
-//     (the last MFMA of every product block writes there) and its epilogue -- unscale, bias, ReLU, sign mask, row-major
-//     turn through LDS, whole-line stores -- is dealt in eight pieces into the k-steps of the NEXT tile, so stores
+//   * one wave per SIMD (256 threads, 512 VGPRs each): a wave keeps the MFMA fragments of ITS 32 rows of the panel -- all
+//     K <= 240 of them, already cut into the two fp16 planes of the scaled values (same bits as the in-register cut of
+//     gemm.hip: h = rne16(x s), l = rne16(x s - h)) -- in 8 K / 16 registers while the workgroup sweeps every N-tile of
+//     the row block: the activations are read and cut ONCE per panel and never touch LDS;
+//   * the whole LDS is a twelve-stage ring for the pre-cut weights (mml_gemm_planes_cut, MML_PLANES_ROWS): ten k-steps
+//     of LDS-DMA in flight.  The depth is not a luxury: vector-memory operations of a wave retire IN ORDER, so a weight
+//     tile issued behind an epilogue store cannot count as landed before that store has been acknowledged (~1.5 us under
+//     load); the first form of this kernel (panel in LDS, three stages) ran 1.7x SLOWER than the tile kernel for it;
+//   * the k-loop holds no VALU work: LDS-DMA issue, weight fragment reads one step ahead, twelve
+//     v_mfma_f32_32x32x16_f16 per wave and step; the finished tile leaves the loop in a second register set (the last
+//     MFMA of every product block writes there) and its epilogue -- unscale, bias, ReLU, sign mask, row-major turn
+//     through LDS, whole-line stores -- is dealt in eight pieces into k-steps 1..8 of the NEXT tile, so the stores
 //     trickle out beside the MFMAs instead of arriving as one burst per tile;
 //   * a tile is a PAIR of 64-column half tiles, each with its own problem: two 64-wide gate layers share one tile.
 // Results are bitwise those of gemm_pipe_kernel<.., EMU = 2, BPL> on the same operands (same planes, same product
@@ -23,23 +27,22 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace mml {
 
 using pf32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int PN_BM = 128;               // panel rows
-constexpr int PN_KB_MAX = 15;            // 16-k blocks of a panel (K <= 240)
-constexpr int PN_KB_MIN = 10;            // (eight epilogue pieces need eight middle k-steps)
-constexpr int PN_STAGE = 8192;           // bytes of one 128-row x 16-k image
-constexpr int PN_NST = 3;                // weight ring stages
-constexpr int PN_SCR = 2048;             // bytes of a wave's row-major turn area (16 rows x 128 B)
+constexpr int PN_BM = 128;               // panel rows (four waves x 32)
+constexpr int PN_STAGE = 8192;           // bytes of one 128-column x 16-k weight image
+constexpr int PN_D = 12;                 // weight ring stages
+constexpr int PN_W = PN_D - 2;           // k-steps between the issue of a stage and the wait for it
+constexpr int PN_SCR = 4096;             // bytes of a wave's row-major turn area (32 rows x 128 B)
 constexpr int PN_MAXH = 64;              // half tiles per launch
-constexpr int PN_PANEL_OFF = 0;
-constexpr int PN_RING_OFF = PN_KB_MAX * PN_STAGE;
-constexpr int PN_SCR_OFF = PN_RING_OFF + PN_NST * PN_STAGE;
-constexpr int PN_BIAS_OFF = PN_SCR_OFF + 4 * PN_SCR;            // two buffers x four waves x 64 floats
-constexpr int PN_AMAX_OFF = PN_BIAS_OFF + 2 * 4 * 256;          // one word per problem
+constexpr int PN_RING_OFF = 0;
+constexpr int PN_SCR_OFF = PN_RING_OFF + PN_D * PN_STAGE;
+constexpr int PN_BIAS_OFF = PN_SCR_OFF + 4 * PN_SCR;            // two buffers x 128 floats
+constexpr int PN_AMAX_OFF = PN_BIAS_OFF + 2 * 512;              // one word per problem
 constexpr int PN_INVB_OFF = PN_AMAX_OFF + MML_MAX_GROUP * 4;    // 2^-kB per problem (read once from the exponent words)
 constexpr int PN_LDS_BYTES = PN_INVB_OFF + MML_MAX_GROUP * 4;
 static_assert(PN_LDS_BYTES <= 160 * 1024, "panel kernel LDS budget");
@@ -64,8 +67,7 @@ struct PanelLaunch {
   int32_t store_masks;  // every problem writes its relu sign mask (3 stores per epilogue piece instead of 2)
   int32_t pad_;
   PanelProblem p[MML_MAX_GROUP];
-  uint16_t half_prob[PN_MAXH];
-  uint16_t half_col0[PN_MAXH];
+  int32_t half[PN_MAXH];  // problem << 16 | first column of the half tile (32-bit words: scalar loads, not VMEM)
 };
 static_assert(sizeof(PanelLaunch) <= 4096, "PanelLaunch must fit the kernel-argument block");
 
@@ -84,52 +86,93 @@ __device__ __forceinline__ int pn_scale_exp(uint32_t bits) {
 }
 __device__ __forceinline__ float pn_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
+// s_waitcnt vmcnt(n) for a run-time n (the immediate is six bits wide)
 __device__ __forceinline__ void pn_wait_vm(const int n) {
+#define PN_W1(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    PN_W1(0) PN_W1(1) PN_W1(2) PN_W1(3) PN_W1(4) PN_W1(5) PN_W1(6) PN_W1(7) PN_W1(8) PN_W1(9)
+    PN_W1(10) PN_W1(11) PN_W1(12) PN_W1(13) PN_W1(14) PN_W1(15) PN_W1(16) PN_W1(17) PN_W1(18) PN_W1(19)
+    PN_W1(20) PN_W1(21) PN_W1(22) PN_W1(23) PN_W1(24) PN_W1(25) PN_W1(26) PN_W1(27) PN_W1(28) PN_W1(29)
+    PN_W1(30) PN_W1(31) PN_W1(32) PN_W1(33) PN_W1(34) PN_W1(35) PN_W1(36) PN_W1(37) PN_W1(38) PN_W1(39)
+    PN_W1(40) PN_W1(41) PN_W1(42) PN_W1(43) PN_W1(44) PN_W1(45) PN_W1(46) PN_W1(47) PN_W1(48) PN_W1(49)
+    PN_W1(50) PN_W1(51) PN_W1(52) PN_W1(53) PN_W1(54) PN_W1(55) PN_W1(56) PN_W1(57) PN_W1(58) PN_W1(59)
+    PN_W1(60) PN_W1(61) PN_W1(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+#undef PN_W1
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void pn_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pn_static_for<I + 1, N>(f);
   }
 }
 
-enum { PN_FIRST = 0, PN_MID = 1, PN_LAST = 2 };
-
-// the raw LDS fragments of one k-step: a lane's 8 halves of the h and the l plane for two 32-row / 32-column sub-tiles
-struct PnFrag {
-  f32x4_t ah[2], al[2], bh[2], bl[2];
-  __device__ __forceinline__ void landed() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      lds_landed(ah[i]);
-      lds_landed(al[i]);
-      lds_landed(bh[i]);
-      lds_landed(bl[i]);
+// ---- the hand-placed schedule of a tile ----
+// One wave per SIMD means nothing overlaps by itself: a wave issues in program order, so whatever is to run beside the
+// MFMAs has to stand BETWEEN them in the instruction stream (~5 single-issue instructions hide in the 32-cycle shadow
+// of a v_mfma_f32_32x32x16; measured before this: MFMAs 56 us + loop skeleton 71 us + epilogue 100 us + DMA 47 us added
+// up to 273 us).  A k-step is twelve MFMAs = twelve gaps:
+//   gap 0, 1   the eight fragment reads of the next step
+//   gap 2, 4   the wave's two LDS-DMA instructions of the step PN_D - 1 ahead (+ cursor bookkeeping)
+//   the other eight gaps: PN_SPG slices each of the PREVIOUS tile's epilogue
+// The epilogue of a 32 x 32 sub-tile (lane = row, registers = four runs of four columns) is PN_NSL slices of about five
+// instructions: bias reads, then per run of four columns unscale + bias / ReLU + magnitude / sign bits / row-major turn
+// through LDS, then the mask word, the row-major reads and four whole-line stores.
+constexpr int PN_NSL = 26;                    // slices per sub-tile
+constexpr int PN_EGAPS = 8;                   // epilogue gaps per k-step
+// slices per gap: the epilogue ends before the tile's last k-step (whose first epilogue gap carries the bias DMA)
+constexpr int pn_spg(int KB) { return (4 * PN_NSL + (KB - 1) * PN_EGAPS - 1) / ((KB - 1) * PN_EGAPS); }
+// epilogue gap index (0..7) of MFMA gap m, or -1
+constexpr int pn_egap(int m) { return m == 3 ? 0 : (m >= 5 ? m - 4 : -1); }
+// VMEM operations slice S of a sub-tile issues
+constexpr int pn_slice_ops(int S, bool masks) { return S == 19 ? (masks ? 1 : 0) : ((S == 22 || S == 23) ? 2 : 0); }
+// VMEM operations the epilogue slices of half tile `half` issue in k-step kb of a tile (compile-time schedule)
+constexpr int pn_step_ops(int KB, int kb, int half, bool masks) {
+  int n = 0;
+  const int spg = pn_spg(KB);
+  for (int eg = 0; eg < PN_EGAPS; ++eg)
+    for (int q = 0; q < spg; ++q) {
+      const int e = (kb * PN_EGAPS + eg) * spg + q;
+      if (e < 4 * PN_NSL && (e / PN_NSL) / 2 == half) n += pn_slice_ops(e % PN_NSL, masks);
     }
-  }
+  return n;
+}
+// What a wave has issued after the weight DMA it waits for at the top of k-step kb: the PN_W steps before it.  nd = the
+// weight-DMA pairs after the awaited one; bias = bias-DMA steps (last step of a tile, waves 0 / 1); ops_*[h] = epilogue
+// stores of half tile h in the window, inside this tile / the tile before.
+struct PnWindow {
+  int nd, bias, ops_cur[2], ops_prev[2];
 };
+constexpr PnWindow pn_window(int KB, int kb, bool masks) {
+  PnWindow w{PN_W - 1, 0, {0, 0}, {0, 0}};
+  for (int d = 1; d <= PN_W; ++d) {  // step kb - d
+    int k = kb - d;
+    const bool prev = k < 0;
+    if (prev) k += KB;  // (PN_W <= KB: at most one tile back)
+    if (k == KB - 1) w.bias += 1;
+    for (int hh = 0; hh < 2; ++hh) (prev ? w.ops_prev : w.ops_cur)[hh] += pn_step_ops(KB, k, hh, masks);
+  }
+  return w;
+}
 
-template <bool MASKS>
+template <int KB, bool MASKS>
 __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch Larg) {
+  static_assert(KB >= PN_W && KB >= 10 && KB <= 15, "the panel kernel holds 10..15 k-blocks per row in registers");
+  constexpr int SPG = pn_spg(KB);
+  static_assert((KB - 1) * PN_EGAPS * SPG >= 4 * PN_NSL, "the epilogue must end before the tile's last k-step");
   typedef const __attribute__((address_space(4))) PanelLaunch KLaunch;
   KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float lds[PN_LDS_BYTES / 4];
-  constexpr int NSTORE = MASKS ? 3 : 2;  // VMEM operations of one epilogue piece (two 16-byte row stores + mask words)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane_ = lane;
-  const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
   const uint32_t lds0 = lds_byte_addr(lds);
-  const int KB = L.K >> 4;
   const int M = L.M;
+  const int dbg = L.pad_;  // lab switches (MMLREC_PANEL_DBG; results are garbage with any of them set): see the host side
   const int npairs = (L.n_half + 1) >> 1;
   const int npanels = (M + PN_BM - 1) / PN_BM;
 
@@ -148,45 +191,42 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   const int kA = __builtin_amdgcn_readfirstlane(pn_scale_exp(pn_amax_load(L.amaxA)));
   const float sA = pn_pow2(kA), invA = pn_pow2(-kA);
 
-  // ---- fragment read addresses (the image of gemm.hip: 64-byte rows, 16-byte chunk c of row r at c ^ ((r >> 2) & 3)) ----
+  // ---- weight fragment reads (the image of gemm.hip: 64-byte rows, 16-byte chunk c of row r at c ^ ((r >> 2) & 3)) ----
   const int swz = (l31 >> 2) & 3;
-  const uint32_t aAh = lds0 + PN_PANEL_OFF + (wm * 64 + l31) * 64 + ((h ^ swz) * 16);
-  const uint32_t aAl = lds0 + PN_PANEL_OFF + (wm * 64 + l31) * 64 + (((2 + h) ^ swz) * 16);
-  const uint32_t aBh = lds0 + PN_RING_OFF + (wn * 64 + l31) * 64 + ((h ^ swz) * 16);
-  const uint32_t aBl = lds0 + PN_RING_OFF + (wn * 64 + l31) * 64 + (((2 + h) ^ swz) * 16);
-  auto read_frags = [&](PnFrag& f, const int kb, const int stage) __attribute__((always_inline)) {
-    const uint32_t ka = (uint32_t)kb * PN_STAGE, sb = (uint32_t)stage * PN_STAGE;
-    f.bh[0] = ds_read128<0>(aBh + sb);
-    f.bl[0] = ds_read128<0>(aBl + sb);
-    f.ah[0] = ds_read128<0>(aAh + ka);
-    f.al[0] = ds_read128<0>(aAl + ka);
-    f.bh[1] = ds_read128<2048>(aBh + sb);
-    f.bl[1] = ds_read128<2048>(aBl + sb);
-    f.ah[1] = ds_read128<2048>(aAh + ka);
-    f.al[1] = ds_read128<2048>(aAl + ka);
+  const uint32_t aBh = lds0 + PN_RING_OFF + l31 * 64 + ((h ^ swz) * 16);
+  const uint32_t aBl = lds0 + PN_RING_OFF + l31 * 64 + (((2 + h) ^ swz) * 16);
+  struct FragB {
+    f32x4_t bh[4], bl[4];
+  };
+  auto landed_b = [&](FragB& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lds_landed(f.bh[i]);
+      lds_landed(f.bl[i]);
+    }
   };
 
   // ---- DMA lane geometry: wave-instruction t of a 128-row image covers rows 16 t .. 16 t + 15, lane -> (row, phys chunk) ----
   const int drow = lane >> 2;                          // row inside the 16-row group
   const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);   // logical chunk that lands at physical chunk lane & 3
 
-  // ---- per-tile context of this wave's half tile ----
+  // ---- context of a half tile whose epilogue is in progress ----
   struct Ctx {
     float* C;           // &C[0][col0]
     uint32_t* mask;     // &mask[0][col0 / 32] or null
-    int64_t ldc, ldmask;
+    int ldc, ldmask;
     float inv;          // 2^-(kA + kB)
     int pi;
-    bool valid, amax;
+    bool valid, amax, bias, relu;
   };
-  auto load_ctx = [&](Ctx& c, const int pair) __attribute__((always_inline)) {
-    int hi = 2 * pair + wn;
+  auto load_ctx = [&](Ctx& c, const int pair, const int j) __attribute__((always_inline)) {
+    int hi = 2 * pair + j;
     c.valid = hi < L.n_half;
     hi = c.valid ? hi : 2 * pair;
-    const int pi = L.half_prob[hi], col0 = L.half_col0[hi];
+    const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
     c.pi = pi;
-    c.ldc = L.p[pi].ldc;
-    c.ldmask = L.p[pi].ldmask;
+    c.ldc = (int)L.p[pi].ldc;
+    c.ldmask = (int)L.p[pi].ldmask;
     c.C = L.p[pi].C + col0;
     uint32_t* const mk = L.p[pi].mask;
     c.mask = mk ? mk + (col0 >> 5) : nullptr;
@@ -197,6 +237,8 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
     }
     c.inv = invA * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ib)));
     c.amax = L.p[pi].amax_out != nullptr;
+    c.bias = L.p[pi].bias != nullptr;
+    c.relu = L.p[pi].relu != 0;
   };
 
   // weight ring: source pointers of this wave's two DMA instructions per stage (j = half tile j of the pair)
@@ -206,322 +248,335 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
     for (int j = 0; j < 2; ++j) {
       int hi = 2 * pair + j;
       hi = hi < L.n_half ? hi : 2 * pair;
-      const int pi = L.half_prob[hi], col0 = L.half_col0[hi];
+      const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
       const float* base = reinterpret_cast<const float*>(L.p[pi].planes);
       pb[j] = base + (int64_t)(col0 + 16 * wave + drow) * L.p[pi].ldp + 4 * dchunk;
     }
   };
-  auto issue_b = [&](const int stage) __attribute__((always_inline)) {
-    float* sb = lds + (PN_RING_OFF + stage * PN_STAGE) / 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(pb[j], sb + (wave + 4 * j) * 256);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) pb[j] += 16;
-  };
+  // the 128 bias values of a tile pair travel to LDS by one 4-byte LDS-DMA per lane of waves 0 / 1 (half tile 0 / 1);
+  // always exactly one VMEM operation on those waves (a dummy address when there is no bias): the waits count it
+  const int bias_ops = wave < 2 ? 1 : 0;
   auto bias_dma = [&](const int pair) __attribute__((always_inline)) {
-    int hi = 2 * pair + wn;
+    if (wave >= 2) return;
+    int hi = 2 * pair + wave;
     hi = hi < L.n_half ? hi : 2 * pair;
-    const int pi = L.half_prob[hi], col0 = L.half_col0[hi];
+    const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
     const float* bias = L.p[pi].bias;
-    const float* src = bias ? bias + col0 + lane : L.A;  // (always exactly one VMEM operation: the waits count it)
-    __builtin_amdgcn_sched_barrier(0);
-    dma4(src, lds + (PN_BIAS_OFF + (pair & 1) * 1024 + wave * 256) / 4);
-    __builtin_amdgcn_sched_barrier(0);
+    const float* src = bias ? bias + col0 + lane : L.A;
+    dma4(src, lds + (PN_BIAS_OFF + (pair & 1) * 512 + wave * 256) / 4);
   };
 
-  pf32x16 acc[2][2], epi[2][2];
-  PnFrag F[2];
-  Ctx cctx, ectx;
-  float am_f = 0.f;
-  int row0 = 0;
-  bool full = true;
-  bool ectx_bias = false;
+  // ---- the wave's 32 panel rows as MFMA fragments: KB x (h plane, l plane) ----
+  f16x8 Ah[KB], Al[KB];
+  auto load_panel = [&](const int row0) __attribute__((always_inline)) {
+    int row = row0 + 32 * wave + l31;
+    row = row < M ? row : M - 1;
+    const float* ar = L.A + (int64_t)row * L.lda + 4 * h;
+    float4 q0[KB], q1[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      q0[kb] = *reinterpret_cast<const float4*>(ar + 16 * kb);
+      q1[kb] = *reinterpret_cast<const float4*>(ar + 16 * kb + 8);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const float x[8] = {q0[kb].x, q0[kb].y, q0[kb].z, q0[kb].w, q1[kb].x, q1[kb].y, q1[kb].z, q1[kb].w};
+      f16x8 hh, ll;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = x[e] * sA;          // exact: sA is a power of two
+        const _Float16 hv = (_Float16)y;    // round to nearest even
+        const float r = y - (float)hv;      // exact
+        hh[e] = hv;
+        ll[e] = (_Float16)r;
+      }
+      Ah[kb] = hh;
+      Al[kb] = ll;
+    }
+    // (all of it HERE: hipcc would otherwise sink the cut of block kb -- and the wait for its loads -- into k-step kb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      asm volatile("" : "+v"(Ah[kb]));
+      asm volatile("" : "+v"(Al[kb]));
+    }
+  };
+
+  pf32x16 acc[4], epi[4];
+  Ctx ectx[2];
+  float am_f[2] = {0.f, 0.f};
+  int row0 = 0;       // of the panel being computed
+  int erow0 = 0;      // of the panel the tile in `epi` belongs to
+  bool efull = true;
   int epair = 0;
 
-  // ---- one eighth of a tile's epilogue: sub-tile (mi, ni) = U >> 1, rows 16 (U & 1) .. + 15 of it ----
-  auto unit = [&](auto uc) __attribute__((always_inline)) {
-    constexpr int U = decltype(uc)::value;
-    constexpr int MI = U >> 2, NI = (U >> 1) & 1, RH = U & 1;
-    const pf32x16& a = epi[MI][NI];
-    // every address of a piece is derived from an OPAQUE copy of the lane number: hipcc otherwise hoists the address
-    // arithmetic of all 8 x 2 x 2 instantiations out of the panel loop and spills (256 VGPRs + scratch)
-    int lane = lane_;
-    asm volatile("" : "+v"(lane));
-    const int l31 = lane & 31, h = lane >> 5;
+  // ---- epilogue state that lives across slices ----
+  f32x4_t eb[4];      // bias of the four column runs of the sub-tile
+  f32x4_t ev[4];      // a run of four outputs (pre-turn), then the four row-major pieces
+  uint32_t emw = 0u;  // sign bits of this lane's 16 outputs
+  // One slice (S of PN_NSL) of the epilogue of sub-tile NI of the tile in `epi`.
+  auto eslice = [&](auto nic, auto sc) __attribute__((always_inline)) {
+    constexpr int NI = decltype(nic)::value, S = decltype(sc)::value, HT = NI >> 1;
+    const Ctx& ec = ectx[HT];
+    pf32x16& a = epi[NI];
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // (addresses from an opaque lane number: nothing for hipcc to hoist out of the loops)
     const uint32_t scr = lds0 + PN_SCR_OFF + wave * PN_SCR;
-    const int rr = l31 & 15;
-    if ((l31 >> 4) == RH) {
+    if constexpr (S == 0) {  // bias of the lane's columns 8 g + 4 h + j
+      if (ec.bias) {
+        const uint32_t ab = lds0 + PN_BIAS_OFF + (epair & 1) * 512 + (NI * 32 + 4 * (ln >> 5)) * 4;
+        eb[0] = ds_read128<0>(ab);
+        eb[1] = ds_read128<32>(ab);
+        eb[2] = ds_read128<64>(ab);
+        eb[3] = ds_read128<96>(ab);
+      }
+      emw = 0u;
+    } else if constexpr (S == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ec.bias) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4_t v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-        ds_write128(scr + rr * 128 + (((2 * g + h) ^ (rr & 7)) * 16), v);
+        for (int g = 0; g < 4; ++g) lds_landed(eb[g]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) eb[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    } else if constexpr (S >= 3 && S <= 18) {
+      constexpr int g = (S - 3) >> 2, part = (S - 3) & 3;
+      f32x4_t& x = ev[g];
+      if constexpr (part == 0) {  // unscale + bias (one exact multiplication by a power of two inside the FMA)
+        const float inv = ec.inv;
+        x.x = a[4 * g] * inv + eb[g].x;
+        x.y = a[4 * g + 1] * inv + eb[g].y;
+        x.z = a[4 * g + 2] * inv + eb[g].z;
+        x.w = a[4 * g + 3] * inv + eb[g].w;
+      } else if constexpr (part == 1) {  // ReLU, magnitude
+        if (ec.relu) {
+          x.x = x.x > 0.f ? x.x : 0.f;
+          x.y = x.y > 0.f ? x.y : 0.f;
+          x.z = x.z > 0.f ? x.z : 0.f;
+          x.w = x.w > 0.f ? x.w : 0.f;
+        }
+        am_f[HT] = fmaxf(fmaxf(am_f[HT], fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
+      } else if constexpr (part == 2) {  // sign bits of columns 8 g + j (shifted by 4 h at the end)
+        if (MASKS) {
+          emw |= (x.x > 0.f ? 1u : 0u) << (8 * g);
+          emw |= (x.y > 0.f ? 1u : 0u) << (8 * g + 1);
+          emw |= (x.z > 0.f ? 1u : 0u) << (8 * g + 2);
+          emw |= (x.w > 0.f ? 1u : 0u) << (8 * g + 3);
+        }
+      } else {  // the run goes to the wave's turn area: 16-byte chunk c of row r at c ^ (r & 7)
+        const int r = ln & 31, hh = ln >> 5;
+        ds_write128(scr + r * 128 + (((2 * g + hh) ^ (r & 7)) * 16), x);
+      }
+    } else if constexpr (S == 19) {  // the row's 32-column word: lanes r and r + 32 hold its two interleaved halves
+      if (MASKS) {
+        const uint32_t mine = emw << (4 * (ln >> 5));
+        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        const uint32_t word = sw[0] | sw[1];
+        const int row = erow0 + 32 * wave + (ln & 31);
+        if (ln < 32 && row < M) ec.mask[(int64_t)row * ec.ldmask + (NI & 1)] = word;
+      }
+    } else if constexpr (S == 20) {  // row-major pieces: lane (R, cc) takes columns 4 cc .. 4 cc + 3 of rows R + 8 p
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int R = ln >> 3, cc = ln & 7;
+      const uint32_t ar = scr + R * 128 + ((cc ^ R) * 16);
+      ev[0] = ds_read128<0>(ar);
+      ev[1] = ds_read128<1024>(ar);
+      ev[2] = ds_read128<2048>(ar);
+      ev[3] = ds_read128<3072>(ar);
+    } else if constexpr (S == 22 || S == 23) {
+      if constexpr (S == 22) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) lds_landed(ev[p]);
+      }
+      const int R = ln >> 3, cc = ln & 7;
+      const int rowb = erow0 + 32 * wave + R;
+      float* const cp = ec.C + (NI & 1) * 32 + 4 * cc;
+#pragma unroll
+      for (int p = 2 * (S - 22); p < 2 * (S - 22) + 2; ++p) {
+        const int row = rowb + 8 * p;
+        if (row < M)
+          *reinterpret_cast<float4*>(cp + (int64_t)row * ec.ldc) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+      }
+      if (!efull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (guarded stores may issue fewer than counted)
+    } else if constexpr (S == 24) {
+      if ((NI & 1) == 1 && ec.amax) {  // the half tile's largest |output| -> the workgroup's word of its problem
+        const uint32_t aw = lds0 + PN_AMAX_OFF + (uint32_t)ec.pi * 4u;
+        const uint32_t am_bits = __float_as_uint(am_f[HT]);
+        asm volatile("ds_max_u32 %0, %1" ::"v"(aw), "v"(am_bits) : "memory");
+        am_f[HT] = 0.f;
       }
     }
-    const int R = lane >> 3, cc = lane & 7;
-    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ectx_bias) b4 = ds_read128<0>(lds0 + PN_BIAS_OFF + (epair & 1) * 1024 + wave * 256 + (NI * 32 + 4 * cc) * 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (ectx_bias) lds_landed(b4);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4_t v[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) v[p] = ds_read128<0>(scr + (R + 8 * p) * 128 + ((cc ^ ((R + 8 * p) & 7)) * 16));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int p = 0; p < 2; ++p) lds_landed(v[p]);
-    __builtin_amdgcn_sched_barrier(0);
-    const float inv = ectx.inv;
-    const bool relu = L.p[ectx.pi].relu != 0;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      f32x4_t& x = v[p];
-      x.x = x.x * inv + b4.x;
-      x.y = x.y * inv + b4.y;
-      x.z = x.z * inv + b4.z;
-      x.w = x.w * inv + b4.w;
-      if (relu) {
-        x.x = x.x > 0.f ? x.x : 0.f;
-        x.y = x.y > 0.f ? x.y : 0.f;
-        x.z = x.z > 0.f ? x.z : 0.f;
-        x.w = x.w > 0.f ? x.w : 0.f;
-      }
-    }
-    const int rowb = row0 + wm * 64 + MI * 32 + RH * 16 + R;  // rows rowb, rowb + 8
-    const int colq = NI * 32 + 4 * cc;
-    if (MASKS) {  // the eight lanes cc = 0..7 of a row hold the eight nibbles of its 32-column word
-      uint32_t wsel = 0u;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const f32x4_t& x = v[p];
-        uint32_t w = ((x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u))
-                     << (4 * cc);
-        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xf, 0xf, true);
-        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x102, 0xf, 0xf, true);
-        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x101, 0xf, 0xf, true);
-        uint32_t moved = w;
-        if (p == 1) moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x111, 0xf, 0xf, true);
-        if (cc == p) wsel = moved;
-      }
-      const int mrow = rowb + 8 * cc;  // lane cc < 2 owns row R + 8 cc
-      if (cc < 2 && mrow < M) ectx.mask[(int64_t)mrow * ectx.ldmask + NI] = wsel;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = rowb + 8 * p;
-      if (row < M) {
-        const float4 x = make_float4(v[p].x, v[p].y, v[p].z, v[p].w);
-        *reinterpret_cast<float4*>(ectx.C + (int64_t)row * ectx.ldc + colq) = x;
-        am_f = fmaxf(fmaxf(am_f, fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
-      }
-    }
-    if (U == 7 && ectx.amax) {  // the tile's largest |output| -> the workgroup's word of its problem
-      const uint32_t aw = lds0 + PN_AMAX_OFF + (uint32_t)ectx.pi * 4u;
-      const uint32_t am_bits = __float_as_uint(am_f);
-      asm volatile("ds_max_u32 %0, %1" ::"v"(aw), "v"(am_bits) : "memory");
-      am_f = 0.f;
+  };
+  // epilogue slice number e of the tile (0 .. 4 PN_NSL - 1)
+  auto eslice_at = [&](auto ec_) __attribute__((always_inline)) {
+    constexpr int e = decltype(ec_)::value;
+    if constexpr (e < 4 * PN_NSL) {
+      constexpr int NI = e / PN_NSL, S = e % PN_NSL;
+      if (ectx[NI >> 1].valid) eslice(std::integral_constant<int, NI>{}, std::integral_constant<int, S>{});
     }
   };
 
-  int e2 = 0, e1 = 0;   // VMEM operations issued after the weight DMA of the step before last / of the last step
+  // ---- the weight stream: one cursor over (pair, k-block), cyclic over the pairs: it does not know about panels ----
+  const int my_panels = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_panels * npairs * KB;  // k-steps of this workgroup
+  int issued = 0, dpair = 0, dkb = 0, dstage = 0;
+  auto dma_one = [&](const int j) __attribute__((always_inline)) {
+    dma16(pb[j], lds + (PN_RING_OFF + dstage * PN_STAGE) / 4 + (wave + 4 * j) * 256);
+    pb[j] += 16;
+  };
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    dstage = dstage + 1 == PN_D ? 0 : dstage + 1;
+    ++issued;
+    if (++dkb == KB) {
+      dkb = 0;
+      dpair = dpair + 1 == npairs ? 0 : dpair + 1;
+      setup_b(dpair);
+    }
+  };
+  if (my_panels > 0) {
+    setup_b(0);
+    for (int st = 0; st < PN_D - 1; ++st)
+      if (issued < total) {
+        dma_one(0);
+        dma_one(1);
+        dma_advance();
+      }
+  }
+
+  FragB fb;            // the weight fragments of the step about to run
+  int gs = 0;          // k-steps done
+  int rstage = 0;      // ring stage of step gs
+  int ep_cur[2] = {0, 0}, ep_prev[2] = {0, 0};  // does half tile h of the tile in `epi` / of the tile before it store?
   bool have_epi = false;
 
-  // one k-step.  Q: fragment register set of this step; KIND: first / middle / last step of the tile; U: epilogue piece
-  // of the PREVIOUS tile dealt into this step (8 = none)
-  auto step = [&](auto qc, auto kindc, auto uc, const int kb, const int gs, const bool more_dma) __attribute__((always_inline)) {
-    constexpr int Q = decltype(qc)::value, KIND = decltype(kindc)::value, U = decltype(uc)::value;
-    // the weights of step gs + 1 were issued two steps ago; younger: what followed them in that step, the DMA of the
-    // step before this one and what followed it
-    pn_wait_vm(more_dma ? 2 + e2 + e1 : 0);
-    __builtin_amdgcn_s_barrier();
-    int ecur = 0;
-    if (more_dma) issue_b((gs + 3) % PN_NST);
-    // next step's fragments -> the other register set
-    const int kbn = (kb + 1 == KB) ? 0 : kb + 1;
-    read_frags(F[Q ^ 1], kbn, (gs + 1) % PN_NST);
-    __builtin_amdgcn_sched_barrier(0);
-    const PnFrag& f = F[Q];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, f.ah[mi]), al = __builtin_bit_cast(f16x8, f.al[mi]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, f.bh[ni]), bl = __builtin_bit_cast(f16x8, f.bl[ni]);
-        pf32x16 c0;
-        if (KIND == PN_FIRST) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-        } else {
-          c0 = acc[mi][ni];
-        }
-        pf32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, c0, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, t, 0, 0, 0);
-        if (KIND == PN_LAST) epi[mi][ni] = t;
-        else acc[mi][ni] = t;
-      }
-    if constexpr (U < 8) {
-      if (have_epi && ectx.valid) {
-        unit(uc);
-        ecur = NSTORE;
-        if (!full) {  // an edge panel's guarded stores may issue fewer operations than counted: drain
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    F[Q ^ 1].landed();
-    __builtin_amdgcn_sched_barrier(0);
-    e2 = e1;
-    e1 = ecur;
+  // a whole tile's epilogue with nothing beside it (the last tile of the workgroup; lab)
+  auto flush_epi = [&]() __attribute__((always_inline)) {
+    pn_static_for<0, 4 * PN_NSL>([&](auto ec_) __attribute__((always_inline)) {
+      eslice_at(ec_);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
-
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using KF = std::integral_constant<int, PN_FIRST>;
-  using KM = std::integral_constant<int, PN_MID>;
-  using KL = std::integral_constant<int, PN_LAST>;
-  using UN = std::integral_constant<int, 8>;
 
   for (int panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
     row0 = panel * PN_BM;
-    full = row0 + PN_BM <= M;
-    // ---- the activation panel: fp32 image by LDS-DMA, then cut in place into the planes of the scaled values ----
-    {
-      const float* pa[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int row = row0 + 16 * (wave + 4 * j) + drow;
-        row = row < M ? row : M - 1;
-        pa[j] = L.A + (int64_t)row * L.lda + 4 * dchunk;
-      }
-      for (int kb = 0; kb < KB; ++kb) {
-        float* sa = lds + (PN_PANEL_OFF + kb * PN_STAGE) / 4;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(pa[j] + 16 * kb, sa + (wave + 4 * j) * 256);
-      }
-    }
-    // the weight ring of the first tile starts while the panel lands
-    setup_b(0);
-    int dpair = 0, dkb = 0;  // cursor of the weight DMA
-    const int total = npairs * KB;
-    int issued = 0;
-#pragma unroll
-    for (int st = 0; st < PN_NST; ++st)
-      if (issued < total) {
-        issue_b(st);
-        ++issued;
-        if (++dkb == KB) {
-          dkb = 0;
-          ++dpair;
-          if (dpair < npairs) setup_b(dpair);
-        }
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kb = 0; kb < KB; ++kb) {
-      // thread = (row 32 wave' + l31, half h) for wave' = wave: rows 32 wave .. 32 wave + 31, all k-blocks
-      const int r = 32 * wave + l31;
-      const uint32_t a0 = lds0 + PN_PANEL_OFF + kb * PN_STAGE + r * 64 + ((h ^ swz) * 16);
-      const uint32_t a1 = lds0 + PN_PANEL_OFF + kb * PN_STAGE + r * 64 + (((2 + h) ^ swz) * 16);
-      f32x4_t q0 = ds_read128<0>(a0), q1 = ds_read128<0>(a1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      lds_landed(q0);
-      lds_landed(q1);
-      __builtin_amdgcn_sched_barrier(0);
-      const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-      uint32_t hw[4], lw[4];
+    if (!(dbg & 16) || gs == 0) load_panel(row0);
+    if (gs == 0) {  // the first fragments of the workgroup (later ones are read one step ahead, across panels too)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const uint32_t sb = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float y0 = x[2 * i] * sA, y1 = x[2 * i + 1] * sA;  // exact: sA is a power of two
-        const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;     // round to nearest even
-        const float r0 = y0 - (float)h0, r1 = y1 - (float)h1;    // exact
-        const _Float16 l0 = (_Float16)r0, l1 = (_Float16)r1;
-        hw[i] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-        lw[i] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+        fb.bh[i] = i == 0 ? ds_read128<0>(aBh + sb) : (i == 1 ? ds_read128<2048>(aBh + sb) : (i == 2 ? ds_read128<4096>(aBh + sb) : ds_read128<6144>(aBh + sb)));
+        fb.bl[i] = i == 0 ? ds_read128<0>(aBl + sb) : (i == 1 ? ds_read128<2048>(aBl + sb) : (i == 2 ? ds_read128<4096>(aBl + sb) : ds_read128<6144>(aBl + sb)));
       }
-      const f32x4_t ph = {__uint_as_float(hw[0]), __uint_as_float(hw[1]), __uint_as_float(hw[2]), __uint_as_float(hw[3])};
-      const f32x4_t pl = {__uint_as_float(lw[0]), __uint_as_float(lw[1]), __uint_as_float(lw[2]), __uint_as_float(lw[3])};
-      ds_write128(a0, ph);
-      ds_write128(a1, pl);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed_b(fb);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // (the loads of the panel were waited for with vmcnt(0) by the compiler: every count restarts from an empty queue;
+      // the stores of the epilogue slices still to come are counted from here)
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // stage 0 -> registers
-    read_frags(F[0], 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    F[0].landed();
-    __builtin_amdgcn_sched_barrier(0);
-    e2 = e1 = 0;
-    have_epi = false;
-    int gs = 0;  // step counter of this panel (its parity picks the fragment register set)
-    auto dma_advance = [&]() __attribute__((always_inline)) {
-      ++issued;
-      if (++dkb == KB) {
-        dkb = 0;
-        ++dpair;
-        if (dpair < npairs) setup_b(dpair);
-      }
-    };
     for (int pair = 0; pair < npairs; ++pair) {
-      load_ctx(cctx, pair);
-      for (int kb = 0; kb < KB; ++kb) {
-        const bool more = issued < total;
-        const int u = (kb >= 1 && kb <= 8) ? kb - 1 : 8;
-        const int q = gs & 1;
-        if (kb == 0) {
-          if (q == 0) step(I0{}, KF{}, UN{}, kb, gs, more);
-          else step(I1{}, KF{}, UN{}, kb, gs, more);
-          bias_dma(pair);
-          e1 += 1;
-        } else if (kb == KB - 1) {
-          if (q == 0) step(I0{}, KL{}, UN{}, kb, gs, more);
-          else step(I1{}, KL{}, UN{}, kb, gs, more);
-        } else {
-#define PN_CASE(U_)                                                                  \
-  case U_:                                                                           \
-    if (q == 0) step(I0{}, KM{}, std::integral_constant<int, U_>{}, kb, gs, more);   \
-    else step(I1{}, KM{}, std::integral_constant<int, U_>{}, kb, gs, more);          \
-    break;
-          switch (u) {
-            PN_CASE(0)
-            PN_CASE(1)
-            PN_CASE(2)
-            PN_CASE(3)
-            PN_CASE(4)
-            PN_CASE(5)
-            PN_CASE(6)
-            PN_CASE(7)
-            default:
-              if (q == 0) step(I0{}, KM{}, UN{}, kb, gs, more);
-              else step(I1{}, KM{}, UN{}, kb, gs, more);
-              break;
+      ep_prev[0] = ep_cur[0];
+      ep_prev[1] = ep_cur[1];
+      ep_cur[0] = (have_epi && ectx[0].valid && !(dbg & 1)) ? 1 : 0;
+      ep_cur[1] = (have_epi && ectx[1].valid && !(dbg & 1)) ? 1 : 0;
+      const bool run_epi = (ep_cur[0] | ep_cur[1]) != 0;
+      const bool common = ep_cur[0] && ep_cur[1] && ep_prev[0] && ep_prev[1];
+      pn_static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value;
+        // ---- wait for the weights of step gs + 1 (issued PN_W steps ago), then the workgroup's barrier ----
+        if (!(dbg & 2)) {
+          constexpr PnWindow w = pn_window(KB, kb, MASKS);
+          constexpr int NCOMMON = 2 * w.nd + w.ops_cur[0] + w.ops_cur[1] + w.ops_prev[0] + w.ops_prev[1];
+          static_assert(NCOMMON + PN_W <= 63, "vmcnt is six bits wide");
+          if (__builtin_expect(common && gs < total - PN_D + 1, 1)) {
+            // (the bias DMA of waves 0 / 1 is not counted: they wait for one operation more than they must)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCOMMON) : "memory");
+          } else {
+            // weight-DMA pairs of the window that were never issued (the stream ended): the steps from total - PN_D + 1
+            int nodma = gs - (total - PN_D + 1);
+            nodma = nodma < 0 ? 0 : (nodma > w.nd ? w.nd : nodma);
+            const int n = 2 * (w.nd - nodma) + w.bias * bias_ops + w.ops_cur[0] * ep_cur[0] + w.ops_cur[1] * ep_cur[1] +
+                          w.ops_prev[0] * ep_prev[0] + w.ops_prev[1] * ep_prev[1];
+            pn_wait_vm(n);
           }
-#undef PN_CASE
         }
-        if (more) dma_advance();
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+        const bool more = issued < total && !(dbg & 2);
+        FragB nf;
+        const int nstage = rstage + 1 == PN_D ? 0 : rstage + 1;
+        const uint32_t sb = (uint32_t)nstage * PN_STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        pn_static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value, ni = m / 3, j = m % 3;
+          if (!(dbg & 8)) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, fb.bh[ni]), bl = __builtin_bit_cast(f16x8, fb.bl[ni]);
+            if constexpr (j == 0) {
+              pf32x16 c0;
+              if constexpr (kb == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+              } else {
+                c0 = acc[ni];
+              }
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, Ah[kb], c0, 0, 0, 0);
+            } else if constexpr (j == 1) {
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Al[kb], acc[ni], 0, 0, 0);
+            } else {
+              if constexpr (kb == KB - 1) epi[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
+              else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
+            }
+          }
+          // ---- what stands in this MFMA's shadow ----
+          if constexpr (m == 0) {
+            nf.bh[0] = ds_read128<0>(aBh + sb);
+            nf.bl[0] = ds_read128<0>(aBl + sb);
+            nf.bh[1] = ds_read128<2048>(aBh + sb);
+            nf.bl[1] = ds_read128<2048>(aBl + sb);
+          } else if constexpr (m == 1) {
+            nf.bh[2] = ds_read128<4096>(aBh + sb);
+            nf.bl[2] = ds_read128<4096>(aBl + sb);
+            nf.bh[3] = ds_read128<6144>(aBh + sb);
+            nf.bl[3] = ds_read128<6144>(aBl + sb);
+          } else if constexpr (m == 2) {
+            if (more) dma_one(0);
+          } else if constexpr (m == 4) {
+            if (more) {
+              dma_one(1);
+              dma_advance();
+            }
+          } else {
+            constexpr int eg = pn_egap(m);
+            if constexpr (kb == KB - 1 && eg == 0) {
+              bias_dma(pair);  // (this tile's bias: its epilogue runs during the next tile)
+            } else if (run_epi) {
+              pn_static_for<0, SPG>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int e = (kb * PN_EGAPS + eg) * SPG + decltype(qc)::value;
+                eslice_at(std::integral_constant<int, e>{});
+              });
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        landed_b(nf);
+        __builtin_amdgcn_sched_barrier(0);
+        fb = nf;
+        rstage = nstage;
         ++gs;
-      }
-      // the finished tile sits in `epi`: its pieces go into the next tile's steps (or the flush below)
-      ectx = cctx;
-      ectx_bias = L.p[cctx.pi].bias != nullptr;
+      });
+      // the finished tile sits in `epi`: its slices go into the next tile's steps (or the flush at the end)
+      load_ctx(ectx[0], pair, 0);
+      load_ctx(ectx[1], pair, 1);
       epair = pair;
+      erow0 = row0;
+      efull = row0 + PN_BM <= M;
       have_epi = true;
     }
-    // ---- the last tile of the panel: its epilogue, un-overlapped ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its bias DMA included)
-    if (ectx.valid) {
-      unit(std::integral_constant<int, 0>{});
-      unit(std::integral_constant<int, 1>{});
-      unit(std::integral_constant<int, 2>{});
-      unit(std::integral_constant<int, 3>{});
-      unit(std::integral_constant<int, 4>{});
-      unit(std::integral_constant<int, 5>{});
-      unit(std::integral_constant<int, 6>{});
-      unit(std::integral_constant<int, 7>{});
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the panel and the ring may be overwritten
   }
+  if (my_panels > 0 && !(dbg & 1)) flush_epi();
 
   // the workgroup's magnitudes -> the slots
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -560,7 +615,7 @@ extern "C" int mml_gemm_set_panel(int32_t on) {
 int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   if (!pn_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_fwd_desc& d0 = d[0];
-  if (d0.K % 16 != 0 || d0.K < 16 * PN_KB_MIN || d0.K > 16 * PN_KB_MAX) return MML_ERR_UNSUPPORTED;
+  if (d0.K != 240 && d0.K != 208 && d0.K != 160) return MML_ERR_UNSUPPORTED;  // (the instantiated panel widths)
   if (d0.M < PN_BM * 64) return MML_ERR_UNSUPPORTED;  // (small batches: the tile kernel fills the chip better)
   if (!d0.amax_a || !aligned16(d0.A) || d0.lda % 4 != 0) return MML_ERR_UNSUPPORTED;
   int halves = 0, masks = 0, relus = 0;
@@ -587,6 +642,14 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
   L.K = d0.K;
   L.n_prob = n;
   L.store_masks = masks != 0;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("MMLREC_PANEL_DBG");  // lab: 1 no epilogue pieces, 2 no weight DMA / waits, 4 no barrier,
+      dbg = e ? atoi(e) : 0;                       //      8 no MFMAs, 16 panel loaded once (all give garbage results)
+    }
+    L.pad_ = dbg;
+  }
   int hidx = 0;
   for (int i = 0; i < n; ++i) {
     const mml_gemm_fwd_desc& q = d[i];
@@ -603,8 +666,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     P.N = q.N;
     P.relu = q.act == MML_ACT_RELU;
     for (int c = 0; c < q.N; c += 64) {
-      L.half_prob[hidx] = (uint16_t)i;
-      L.half_col0[hidx] = (uint16_t)c;
+      L.half[hidx] = (i << 16) | c;
       ++hidx;
     }
   }
@@ -618,8 +680,15 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     cus = nn;
   }
   const int npanels = (int)cdiv(L.M, PN_BM);
-  const int grid = npanels < cus ? npanels : cus;
-  if (L.store_masks) MML_LAUNCH((gemm_panel_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, L);
-  else MML_LAUNCH((gemm_panel_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, L);
+  const dim3 g((unsigned)(npanels < cus ? npanels : cus)), b(256);
+#define PN_GO(KB_)                                                                    \
+  do {                                                                                \
+    if (L.store_masks) MML_LAUNCH((gemm_panel_kernel<KB_, true>), g, b, 0, st, L);    \
+    else MML_LAUNCH((gemm_panel_kernel<KB_, false>), g, b, 0, st, L);                 \
+  } while (0)
+  if (L.K == 240) PN_GO(15);
+  else if (L.K == 208) PN_GO(13);
+  else PN_GO(10);
+#undef PN_GO
   return check_launch("mml_gemm_grouped_fwd(panel)");
 }
