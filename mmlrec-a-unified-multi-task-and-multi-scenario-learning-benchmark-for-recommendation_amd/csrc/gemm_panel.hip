@@ -42,9 +42,10 @@ constexpr int PN_MAXH = 64;              // half tiles per launch
 constexpr int PN_RING_OFF = 0;
 constexpr int PN_SCR_OFF = PN_RING_OFF + PN_D * PN_STAGE;
 constexpr int PN_BIAS_OFF = PN_SCR_OFF + 4 * PN_SCR;            // two buffers x 128 floats
-constexpr int PN_AMAX_OFF = PN_BIAS_OFF + 2 * 512;              // one word per problem
-constexpr int PN_INVB_OFF = PN_AMAX_OFF + MML_MAX_GROUP * 4;    // 2^-kB per problem (read once from the exponent words)
-constexpr int PN_LDS_BYTES = PN_INVB_OFF + MML_MAX_GROUP * 4;
+constexpr int PN_AMAX_OFF = PN_BIAS_OFF + 2 * 512;              // one word per problem, then dummy words
+constexpr int PN_INVB_OFF = PN_AMAX_OFF + 2 * MML_MAX_GROUP * 4;  // 2^-kB per problem (read once from the exponent words)
+constexpr int PN_ZERO_OFF = PN_INVB_OFF + MML_MAX_GROUP * 4;    // 128 zeros: the "bias" of a problem without one
+constexpr int PN_LDS_BYTES = PN_ZERO_OFF + 512;
 static_assert(PN_LDS_BYTES <= 160 * 1024, "panel kernel LDS budget");
 
 struct PanelProblem {
@@ -113,14 +114,21 @@ __device__ __forceinline__ void pn_static_for(F&& f) {
 // ---- the hand-placed schedule of a tile ----
 // One wave per SIMD means nothing overlaps by itself: a wave issues in program order, so whatever is to run beside the
 // MFMAs has to stand BETWEEN them in the instruction stream (~5 single-issue instructions hide in the 32-cycle shadow
-// of a v_mfma_f32_32x32x16; measured before this: MFMAs 56 us + loop skeleton 71 us + epilogue 100 us + DMA 47 us added
-// up to 273 us).  A k-step is twelve MFMAs = twelve gaps:
+// of a v_mfma_f32_32x32x16), and every scalar branch is a bubble nothing covers (the first hand-placed form tested its
+// run-time switches per gap: 124 us for the empty loop skeleton alone).  Hence: no branch inside a k-step -- what varies
+// (epilogue running or not, the tile before stored or not) is a template argument of the tile body, what is optional
+// per problem (bias, magnitude slot) is an address that points at a zero / dummy area -- and launches with anything
+// irregular (ragged last panel, odd number of half tiles, an activation other than ReLU) go to the tile kernel.
+// A k-step is twelve MFMAs = twelve gaps:
 //   gap 0, 1   the eight fragment reads of the next step
 //   gap 2, 4   the wave's two LDS-DMA instructions of the step PN_D - 1 ahead (+ cursor bookkeeping)
 //   the other eight gaps: PN_SPG slices each of the PREVIOUS tile's epilogue
 // The epilogue of a 32 x 32 sub-tile (lane = row, registers = four runs of four columns) is PN_NSL slices of about five
 // instructions: bias reads, then per run of four columns unscale + bias / ReLU + magnitude / sign bits / row-major turn
 // through LDS, then the mask word, the row-major reads and four whole-line stores.
+#ifndef PN_LAB
+#define PN_LAB 0  // lab builds (tools/lab/panel_lab.sh): 1 no epilogue slices, 2 no weight DMA / waits, 8 no MFMAs,
+#endif            // 16 the panel is loaded once, 32 no epilogue stores, 128 no vmcnt waits (all give garbage results)
 constexpr int PN_NSL = 26;                    // slices per sub-tile
 constexpr int PN_EGAPS = 8;                   // epilogue gaps per k-step
 // slices per gap: the epilogue ends before the tile's last k-step (whose first epilogue gap carries the bias DMA)
@@ -129,33 +137,27 @@ constexpr int pn_spg(int KB) { return (4 * PN_NSL + (KB - 1) * PN_EGAPS - 1) / (
 constexpr int pn_egap(int m) { return m == 3 ? 0 : (m >= 5 ? m - 4 : -1); }
 // VMEM operations slice S of a sub-tile issues
 constexpr int pn_slice_ops(int S, bool masks) { return S == 19 ? (masks ? 1 : 0) : ((S == 22 || S == 23) ? 2 : 0); }
-// VMEM operations the epilogue slices of half tile `half` issue in k-step kb of a tile (compile-time schedule)
-constexpr int pn_step_ops(int KB, int kb, int half, bool masks) {
+// VMEM operations the epilogue slices issue in k-step kb of a tile (compile-time schedule)
+constexpr int pn_step_ops(int KB, int kb, bool masks) {
   int n = 0;
   const int spg = pn_spg(KB);
   for (int eg = 0; eg < PN_EGAPS; ++eg)
     for (int q = 0; q < spg; ++q) {
       const int e = (kb * PN_EGAPS + eg) * spg + q;
-      if (e < 4 * PN_NSL && (e / PN_NSL) / 2 == half) n += pn_slice_ops(e % PN_NSL, masks);
+      if (e < 4 * PN_NSL && !(kb == KB - 1 && eg == 0)) n += pn_slice_ops(e % PN_NSL, masks);
     }
   return n;
 }
-// What a wave has issued after the weight DMA it waits for at the top of k-step kb: the PN_W steps before it.  nd = the
-// weight-DMA pairs after the awaited one; bias = bias-DMA steps (last step of a tile, waves 0 / 1); ops_*[h] = epilogue
-// stores of half tile h in the window, inside this tile / the tile before.
-struct PnWindow {
-  int nd, bias, ops_cur[2], ops_prev[2];
-};
-constexpr PnWindow pn_window(int KB, int kb, bool masks) {
-  PnWindow w{PN_W - 1, 0, {0, 0}, {0, 0}};
+// What a wave has issued after the weight DMA it waits for at the top of k-step kb: the PN_W steps before it hold
+// PN_W - 1 later weight-DMA pairs and the epilogue stores of this tile's slices (cur) / of the tile before (prev).
+// (The bias DMA of waves 0 / 1 is not counted: they wait for one operation more than they must.)
+constexpr int pn_younger(int KB, int kb, bool masks, bool cur, bool prev) {
+  int n = 2 * (PN_W - 1);
   for (int d = 1; d <= PN_W; ++d) {  // step kb - d
-    int k = kb - d;
-    const bool prev = k < 0;
-    if (prev) k += KB;  // (PN_W <= KB: at most one tile back)
-    if (k == KB - 1) w.bias += 1;
-    for (int hh = 0; hh < 2; ++hh) (prev ? w.ops_prev : w.ops_cur)[hh] += pn_step_ops(KB, k, hh, masks);
+    const int k = kb - d;
+    if (k >= 0 ? cur : prev) n += pn_step_ops(KB, k >= 0 ? k : k + KB, masks);  // (PN_W <= KB: at most one tile back)
   }
-  return w;
+  return n;
 }
 
 template <int KB, bool MASKS>
@@ -172,17 +174,22 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   const int l31 = lane & 31, h = lane >> 5;
   const uint32_t lds0 = lds_byte_addr(lds);
   const int M = L.M;
-  const int dbg = L.pad_;  // lab switches (MMLREC_PANEL_DBG; results are garbage with any of them set): see the host side
-  const int npairs = (L.n_half + 1) >> 1;
-  const int npanels = (M + PN_BM - 1) / PN_BM;
+  const int npairs = L.n_half >> 1;
+  const int npanels = M / PN_BM;
 
-  if (tid < MML_MAX_GROUP) {
+  if (tid < 2 * MML_MAX_GROUP) {  // magnitude words (+ the dummy word behind them) and 1 / scale of the weights
     const uint32_t a = lds0 + PN_AMAX_OFF + tid * 4, z = 0u;
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(z) : "memory");
+  }
+  if (tid < MML_MAX_GROUP) {
     // the weights' exponents, once: a global load inside the tile loop would make hipcc drain the LDS-DMA ring there
     const float ib = tid < L.n_prob ? pn_pow2(-*L.p[tid].kexp) : 1.f;
     const uint32_t b = lds0 + PN_INVB_OFF + tid * 4;
     asm volatile("ds_write_b32 %0, %1" ::"v"(b), "v"(ib) : "memory");
+  }
+  if (tid < 128) {  // the zero area a problem without bias reads its bias from
+    const uint32_t a = lds0 + PN_ZERO_OFF + tid * 4, z = 0u;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(z) : "memory");
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -210,35 +217,29 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   const int drow = lane >> 2;                          // row inside the 16-row group
   const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);   // logical chunk that lands at physical chunk lane & 3
 
-  // ---- context of a half tile whose epilogue is in progress ----
+  // ---- context of a half tile whose epilogue is in progress (all wave-uniform) ----
   struct Ctx {
     float* C;           // &C[0][col0]
-    uint32_t* mask;     // &mask[0][col0 / 32] or null
+    uint32_t* mask;     // &mask[0][col0 / 32]
     int ldc, ldmask;
     float inv;          // 2^-(kA + kB)
-    int pi;
-    bool valid, amax, bias, relu;
+    uint32_t bias_at;   // LDS byte address of the tile pair's 128 bias values -- or of the zero area
+    uint32_t amax_at;   // LDS byte address of the problem's magnitude word -- or of the dummy word
   };
   auto load_ctx = [&](Ctx& c, const int pair, const int j) __attribute__((always_inline)) {
-    int hi = 2 * pair + j;
-    c.valid = hi < L.n_half;
-    hi = c.valid ? hi : 2 * pair;
-    const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
-    c.pi = pi;
+    const int hw_ = L.half[2 * pair + j], pi = hw_ >> 16, col0 = hw_ & 0xffff;
     c.ldc = (int)L.p[pi].ldc;
     c.ldmask = (int)L.p[pi].ldmask;
     c.C = L.p[pi].C + col0;
-    uint32_t* const mk = L.p[pi].mask;
-    c.mask = mk ? mk + (col0 >> 5) : nullptr;
+    c.mask = L.p[pi].mask + (col0 >> 5);
     float ib;
     {
       const uint32_t b = lds0 + PN_INVB_OFF + (uint32_t)pi * 4u;
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ib) : "v"(b) : "memory");
     }
     c.inv = invA * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ib)));
-    c.amax = L.p[pi].amax_out != nullptr;
-    c.bias = L.p[pi].bias != nullptr;
-    c.relu = L.p[pi].relu != 0;
+    c.bias_at = lds0 + (L.p[pi].bias ? PN_BIAS_OFF + (pair & 1) * 512 : PN_ZERO_OFF);
+    c.amax_at = lds0 + PN_AMAX_OFF + (L.p[pi].amax_out ? pi : MML_MAX_GROUP) * 4;
   };
 
   // weight ring: source pointers of this wave's two DMA instructions per stage (j = half tile j of the pair)
@@ -246,31 +247,25 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   auto setup_b = [&](const int pair) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int hi = 2 * pair + j;
-      hi = hi < L.n_half ? hi : 2 * pair;
-      const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
+      const int hw_ = L.half[2 * pair + j], pi = hw_ >> 16, col0 = hw_ & 0xffff;
       const float* base = reinterpret_cast<const float*>(L.p[pi].planes);
       pb[j] = base + (int64_t)(col0 + 16 * wave + drow) * L.p[pi].ldp + 4 * dchunk;
     }
   };
-  // the 128 bias values of a tile pair travel to LDS by one 4-byte LDS-DMA per lane of waves 0 / 1 (half tile 0 / 1);
-  // always exactly one VMEM operation on those waves (a dummy address when there is no bias): the waits count it
-  const int bias_ops = wave < 2 ? 1 : 0;
+  // the 128 bias values of a tile pair travel to LDS by one 4-byte LDS-DMA per lane of waves 0 / 1 (half tile 0 / 1)
   auto bias_dma = [&](const int pair) __attribute__((always_inline)) {
-    if (wave >= 2) return;
-    int hi = 2 * pair + wave;
-    hi = hi < L.n_half ? hi : 2 * pair;
-    const int hw_ = L.half[hi], pi = hw_ >> 16, col0 = hw_ & 0xffff;
-    const float* bias = L.p[pi].bias;
-    const float* src = bias ? bias + col0 + lane : L.A;
-    dma4(src, lds + (PN_BIAS_OFF + (pair & 1) * 512 + wave * 256) / 4);
+    if (wave < 2) {
+      const int hw_ = L.half[2 * pair + wave], pi = hw_ >> 16, col0 = hw_ & 0xffff;
+      const float* bias = L.p[pi].bias;
+      const float* src = bias ? bias + col0 + lane : L.A;
+      dma4(src, lds + (PN_BIAS_OFF + (pair & 1) * 512 + wave * 256) / 4);
+    }
   };
 
   // ---- the wave's 32 panel rows as MFMA fragments: KB x (h plane, l plane) ----
   f16x8 Ah[KB], Al[KB];
   auto load_panel = [&](const int row0) __attribute__((always_inline)) {
-    int row = row0 + 32 * wave + l31;
-    row = row < M ? row : M - 1;
+    const int row = row0 + 32 * wave + l31;
     const float* ar = L.A + (int64_t)row * L.lda + 4 * h;
     float4 q0[KB], q1[KB];
 #pragma unroll
@@ -306,14 +301,12 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   float am_f[2] = {0.f, 0.f};
   int row0 = 0;       // of the panel being computed
   int erow0 = 0;      // of the panel the tile in `epi` belongs to
-  bool efull = true;
-  int epair = 0;
 
   // ---- epilogue state that lives across slices ----
   f32x4_t eb[4];      // bias of the four column runs of the sub-tile
   f32x4_t ev[4];      // a run of four outputs (pre-turn), then the four row-major pieces
   uint32_t emw = 0u;  // sign bits of this lane's 16 outputs
-  // One slice (S of PN_NSL) of the epilogue of sub-tile NI of the tile in `epi`.
+  // One slice (S of PN_NSL) of the epilogue of sub-tile NI of the tile in `epi`.  No branch in any of them.
   auto eslice = [&](auto nic, auto sc) __attribute__((always_inline)) {
     constexpr int NI = decltype(nic)::value, S = decltype(sc)::value, HT = NI >> 1;
     const Ctx& ec = ectx[HT];
@@ -322,23 +315,16 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
     asm volatile("" : "+v"(ln));  // (addresses from an opaque lane number: nothing for hipcc to hoist out of the loops)
     const uint32_t scr = lds0 + PN_SCR_OFF + wave * PN_SCR;
     if constexpr (S == 0) {  // bias of the lane's columns 8 g + 4 h + j
-      if (ec.bias) {
-        const uint32_t ab = lds0 + PN_BIAS_OFF + (epair & 1) * 512 + (NI * 32 + 4 * (ln >> 5)) * 4;
-        eb[0] = ds_read128<0>(ab);
-        eb[1] = ds_read128<32>(ab);
-        eb[2] = ds_read128<64>(ab);
-        eb[3] = ds_read128<96>(ab);
-      }
+      const uint32_t ab = ec.bias_at + (NI * 32 + 4 * (ln >> 5)) * 4;
+      eb[0] = ds_read128<0>(ab);
+      eb[1] = ds_read128<32>(ab);
+      eb[2] = ds_read128<64>(ab);
+      eb[3] = ds_read128<96>(ab);
       emw = 0u;
     } else if constexpr (S == 2) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (ec.bias) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) lds_landed(eb[g]);
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) eb[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int g = 0; g < 4; ++g) lds_landed(eb[g]);
     } else if constexpr (S >= 3 && S <= 18) {
       constexpr int g = (S - 3) >> 2, part = (S - 3) & 3;
       f32x4_t& x = ev[g];
@@ -348,14 +334,12 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
         x.y = a[4 * g + 1] * inv + eb[g].y;
         x.z = a[4 * g + 2] * inv + eb[g].z;
         x.w = a[4 * g + 3] * inv + eb[g].w;
-      } else if constexpr (part == 1) {  // ReLU, magnitude
-        if (ec.relu) {
-          x.x = x.x > 0.f ? x.x : 0.f;
-          x.y = x.y > 0.f ? x.y : 0.f;
-          x.z = x.z > 0.f ? x.z : 0.f;
-          x.w = x.w > 0.f ? x.w : 0.f;
-        }
-        am_f[HT] = fmaxf(fmaxf(am_f[HT], fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
+      } else if constexpr (part == 1) {  // ReLU (v > 0 ? v : 0 -- one v_max_f32: a NaN gives 0 like the comparison), magnitude
+        asm("v_max_f32 %0, 0, %0" : "+v"(x.x));
+        asm("v_max_f32 %0, 0, %0" : "+v"(x.y));
+        asm("v_max_f32 %0, 0, %0" : "+v"(x.z));
+        asm("v_max_f32 %0, 0, %0" : "+v"(x.w));
+        am_f[HT] = fmaxf(fmaxf(am_f[HT], x.x), fmaxf(x.y, fmaxf(x.z, x.w)));
       } else if constexpr (part == 2) {  // sign bits of columns 8 g + j (shifted by 4 h at the end)
         if (MASKS) {
           emw |= (x.x > 0.f ? 1u : 0u) << (8 * g);
@@ -373,7 +357,8 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
         const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
         const uint32_t word = sw[0] | sw[1];
         const int row = erow0 + 32 * wave + (ln & 31);
-        if (ln < 32 && row < M) ec.mask[(int64_t)row * ec.ldmask + (NI & 1)] = word;
+        if constexpr (!(PN_LAB & 32)) ec.mask[(int64_t)row * ec.ldmask + (NI & 1)] = word;  // (both lanes of a row store the same word)
+        else asm volatile("" ::"v"(word));
       }
     } else if constexpr (S == 20) {  // row-major pieces: lane (R, cc) takes columns 4 cc .. 4 cc + 3 of rows R + 8 p
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -394,16 +379,14 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
       float* const cp = ec.C + (NI & 1) * 32 + 4 * cc;
 #pragma unroll
       for (int p = 2 * (S - 22); p < 2 * (S - 22) + 2; ++p) {
-        const int row = rowb + 8 * p;
-        if (row < M)
-          *reinterpret_cast<float4*>(cp + (int64_t)row * ec.ldc) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+        if constexpr (!(PN_LAB & 32))
+          *reinterpret_cast<float4*>(cp + (int64_t)(rowb + 8 * p) * ec.ldc) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+        else asm volatile("" ::"v"(ev[p]), "v"(cp + (int64_t)(rowb + 8 * p) * ec.ldc));
       }
-      if (!efull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (guarded stores may issue fewer than counted)
     } else if constexpr (S == 24) {
-      if ((NI & 1) == 1 && ec.amax) {  // the half tile's largest |output| -> the workgroup's word of its problem
-        const uint32_t aw = lds0 + PN_AMAX_OFF + (uint32_t)ec.pi * 4u;
+      if constexpr ((NI & 1) == 1) {  // the half tile's largest |output| -> the workgroup's word of its problem (or the dummy)
         const uint32_t am_bits = __float_as_uint(am_f[HT]);
-        asm volatile("ds_max_u32 %0, %1" ::"v"(aw), "v"(am_bits) : "memory");
+        asm volatile("ds_max_u32 %0, %1" ::"v"(ec.amax_at), "v"(am_bits) : "memory");
         am_f[HT] = 0.f;
       }
     }
@@ -411,172 +394,155 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   // epilogue slice number e of the tile (0 .. 4 PN_NSL - 1)
   auto eslice_at = [&](auto ec_) __attribute__((always_inline)) {
     constexpr int e = decltype(ec_)::value;
-    if constexpr (e < 4 * PN_NSL) {
-      constexpr int NI = e / PN_NSL, S = e % PN_NSL;
-      if (ectx[NI >> 1].valid) eslice(std::integral_constant<int, NI>{}, std::integral_constant<int, S>{});
-    }
+    if constexpr (e < 4 * PN_NSL) eslice(std::integral_constant<int, e / PN_NSL>{}, std::integral_constant<int, e % PN_NSL>{});
   };
 
-  // ---- the weight stream: one cursor over (pair, k-block), cyclic over the pairs: it does not know about panels ----
+  // ---- the weight stream: one cursor over (pair, k-block), cyclic over the pairs; it does not know about panels and
+  // runs PN_D - 1 steps past the end (a few KB of weights nobody reads: no branch in the loop for it) ----
   const int my_panels = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = my_panels * npairs * KB;  // k-steps of this workgroup
-  int issued = 0, dpair = 0, dkb = 0, dstage = 0;
+  if (my_panels <= 0) return;
+  int dpair = 0, dstage = 0;
   auto dma_one = [&](const int j) __attribute__((always_inline)) {
     dma16(pb[j], lds + (PN_RING_OFF + dstage * PN_STAGE) / 4 + (wave + 4 * j) * 256);
     pb[j] += 16;
   };
-  auto dma_advance = [&]() __attribute__((always_inline)) {
-    dstage = dstage + 1 == PN_D ? 0 : dstage + 1;
-    ++issued;
-    if (++dkb == KB) {
-      dkb = 0;
-      dpair = dpair + 1 == npairs ? 0 : dpair + 1;
-      setup_b(dpair);
-    }
+  auto next_pair = [&]() __attribute__((always_inline)) {
+    dpair = dpair + 1 == npairs ? 0 : dpair + 1;
+    setup_b(dpair);
   };
-  if (my_panels > 0) {
-    setup_b(0);
-    for (int st = 0; st < PN_D - 1; ++st)
-      if (issued < total) {
-        dma_one(0);
-        dma_one(1);
-        dma_advance();
+  setup_b(0);
+  {
+    int dkb = 0;
+    for (int st = 0; st < PN_D - 1; ++st) {
+      dma_one(0);
+      dma_one(1);
+      dstage = dstage + 1;
+      if (++dkb == KB) {
+        dkb = 0;
+        next_pair();
       }
+    }
   }
 
   FragB fb;            // the weight fragments of the step about to run
-  int gs = 0;          // k-steps done
-  int rstage = 0;      // ring stage of step gs
-  int ep_cur[2] = {0, 0}, ep_prev[2] = {0, 0};  // does half tile h of the tile in `epi` / of the tile before it store?
-  bool have_epi = false;
+  int rstage = 0;      // ring stage of the step about to run
 
-  // a whole tile's epilogue with nothing beside it (the last tile of the workgroup; lab)
-  auto flush_epi = [&]() __attribute__((always_inline)) {
+  // ---- one tile: KB k-steps.  EPI: the slices of the tile in `epi` run in its gaps; PREV: the tile before ran slices too ----
+  auto tile = [&](auto epic, auto prevc, const int pair) __attribute__((always_inline)) {
+    constexpr bool EPI = decltype(epic)::value, PREV = decltype(prevc)::value;
+    pn_static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kbc)::value;
+      // ---- the weights of the next step (issued PN_W steps ago) have landed; then the workgroup's barrier ----
+      if constexpr (!(PN_LAB & 2) && !(PN_LAB & 128)) {
+        constexpr int N = pn_younger(KB, kb, MASKS, EPI && !(PN_LAB & 1), PREV && !(PN_LAB & 1));
+        static_assert(N <= 63, "vmcnt is six bits wide");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      FragB nf;
+      const int nstage = rstage + 1 == PN_D ? 0 : rstage + 1;
+      const uint32_t sb = (uint32_t)nstage * PN_STAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      pn_static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value, ni = m / 3, j = m % 3;
+        if constexpr (!(PN_LAB & 8)) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, fb.bh[ni]), bl = __builtin_bit_cast(f16x8, fb.bl[ni]);
+          if constexpr (j == 0) {
+            pf32x16 c0;
+            if constexpr (kb == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+            } else {
+              c0 = acc[ni];
+            }
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, Ah[kb], c0, 0, 0, 0);
+          } else if constexpr (j == 1) {
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Al[kb], acc[ni], 0, 0, 0);
+          } else {
+            if constexpr (kb == KB - 1) epi[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
+            else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
+          }
+        }
+        // ---- what stands in this MFMA's shadow ----
+        if constexpr (m == 0) {
+          nf.bh[0] = ds_read128<0>(aBh + sb);
+          nf.bl[0] = ds_read128<0>(aBl + sb);
+          nf.bh[1] = ds_read128<2048>(aBh + sb);
+          nf.bl[1] = ds_read128<2048>(aBl + sb);
+        } else if constexpr (m == 1) {
+          nf.bh[2] = ds_read128<4096>(aBh + sb);
+          nf.bl[2] = ds_read128<4096>(aBl + sb);
+          nf.bh[3] = ds_read128<6144>(aBh + sb);
+          nf.bl[3] = ds_read128<6144>(aBl + sb);
+        } else if constexpr (m == 2) {
+          if constexpr (!(PN_LAB & 2)) dma_one(0);
+        } else if constexpr (m == 4) {
+          if constexpr (!(PN_LAB & 2)) {
+            dma_one(1);
+            dstage = dstage + 1 == PN_D ? 0 : dstage + 1;
+            // (the cursor is PN_D - 1 steps ahead: it leaves its tile at a step known at compile time)
+            if constexpr ((kb + PN_D - 1) % KB == KB - 1) next_pair();
+          }
+        } else {
+          constexpr int eg = pn_egap(m);
+          if constexpr (kb == KB - 1 && eg == 0) {
+            bias_dma(pair);  // (this tile's bias: its epilogue runs during the next tile)
+          } else if constexpr (EPI && !(PN_LAB & 1)) {
+            pn_static_for<0, SPG>([&](auto qc) __attribute__((always_inline)) {
+              eslice_at(std::integral_constant<int, (kb * PN_EGAPS + eg) * SPG + decltype(qc)::value>{});
+            });
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed_b(nf);
+      __builtin_amdgcn_sched_barrier(0);
+      fb = nf;
+      rstage = nstage;
+    });
+    // the finished tile sits in `epi`: its slices go into the next tile's gaps (or the flush at the end)
+    load_ctx(ectx[0], pair, 0);
+    load_ctx(ectx[1], pair, 1);
+    erow0 = row0;
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+
+  int tiles_done = 0;
+  for (int panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
+    row0 = panel * PN_BM;
+    if (!(PN_LAB & 16) || tiles_done == 0) load_panel(row0);
+    if (tiles_done == 0) {  // the first fragments of the workgroup (later ones are read one step ahead, across panels too)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      fb.bh[0] = ds_read128<0>(aBh);
+      fb.bl[0] = ds_read128<0>(aBl);
+      fb.bh[1] = ds_read128<2048>(aBh);
+      fb.bl[1] = ds_read128<2048>(aBl);
+      fb.bh[2] = ds_read128<4096>(aBh);
+      fb.bl[2] = ds_read128<4096>(aBl);
+      fb.bh[3] = ds_read128<6144>(aBh);
+      fb.bl[3] = ds_read128<6144>(aBl);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed_b(fb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (at a panel switch hipcc has waited with vmcnt(0) for the panel's loads: counts that still include operations of
+    // the panel before only over-estimate what is in flight by operations that are done)
+    for (int pair = 0; pair < npairs; ++pair) {
+      if (tiles_done == 0) tile(FF{}, FF{}, pair);
+      else if (tiles_done == 1) tile(TT{}, FF{}, pair);
+      else tile(TT{}, TT{}, pair);
+      ++tiles_done;
+    }
+  }
+  // the last tile's epilogue, with nothing beside it
+  if constexpr (!(PN_LAB & 1))
     pn_static_for<0, 4 * PN_NSL>([&](auto ec_) __attribute__((always_inline)) {
       eslice_at(ec_);
       __builtin_amdgcn_sched_barrier(0);
     });
-  };
-
-  for (int panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
-    row0 = panel * PN_BM;
-    if (!(dbg & 16) || gs == 0) load_panel(row0);
-    if (gs == 0) {  // the first fragments of the workgroup (later ones are read one step ahead, across panels too)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const uint32_t sb = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fb.bh[i] = i == 0 ? ds_read128<0>(aBh + sb) : (i == 1 ? ds_read128<2048>(aBh + sb) : (i == 2 ? ds_read128<4096>(aBh + sb) : ds_read128<6144>(aBh + sb)));
-        fb.bl[i] = i == 0 ? ds_read128<0>(aBl + sb) : (i == 1 ? ds_read128<2048>(aBl + sb) : (i == 2 ? ds_read128<4096>(aBl + sb) : ds_read128<6144>(aBl + sb)));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      landed_b(fb);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      // (the loads of the panel were waited for with vmcnt(0) by the compiler: every count restarts from an empty queue;
-      // the stores of the epilogue slices still to come are counted from here)
-    }
-    for (int pair = 0; pair < npairs; ++pair) {
-      ep_prev[0] = ep_cur[0];
-      ep_prev[1] = ep_cur[1];
-      ep_cur[0] = (have_epi && ectx[0].valid && !(dbg & 1)) ? 1 : 0;
-      ep_cur[1] = (have_epi && ectx[1].valid && !(dbg & 1)) ? 1 : 0;
-      const bool run_epi = (ep_cur[0] | ep_cur[1]) != 0;
-      const bool common = ep_cur[0] && ep_cur[1] && ep_prev[0] && ep_prev[1];
-      pn_static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kbc)::value;
-        // ---- wait for the weights of step gs + 1 (issued PN_W steps ago), then the workgroup's barrier ----
-        if (!(dbg & 2)) {
-          constexpr PnWindow w = pn_window(KB, kb, MASKS);
-          constexpr int NCOMMON = 2 * w.nd + w.ops_cur[0] + w.ops_cur[1] + w.ops_prev[0] + w.ops_prev[1];
-          static_assert(NCOMMON + PN_W <= 63, "vmcnt is six bits wide");
-          if (__builtin_expect(common && gs < total - PN_D + 1, 1)) {
-            // (the bias DMA of waves 0 / 1 is not counted: they wait for one operation more than they must)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCOMMON) : "memory");
-          } else {
-            // weight-DMA pairs of the window that were never issued (the stream ended): the steps from total - PN_D + 1
-            int nodma = gs - (total - PN_D + 1);
-            nodma = nodma < 0 ? 0 : (nodma > w.nd ? w.nd : nodma);
-            const int n = 2 * (w.nd - nodma) + w.bias * bias_ops + w.ops_cur[0] * ep_cur[0] + w.ops_cur[1] * ep_cur[1] +
-                          w.ops_prev[0] * ep_prev[0] + w.ops_prev[1] * ep_prev[1];
-            pn_wait_vm(n);
-          }
-        }
-        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
-        const bool more = issued < total && !(dbg & 2);
-        FragB nf;
-        const int nstage = rstage + 1 == PN_D ? 0 : rstage + 1;
-        const uint32_t sb = (uint32_t)nstage * PN_STAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        pn_static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
-          constexpr int m = decltype(mc)::value, ni = m / 3, j = m % 3;
-          if (!(dbg & 8)) {
-            const f16x8 bh = __builtin_bit_cast(f16x8, fb.bh[ni]), bl = __builtin_bit_cast(f16x8, fb.bl[ni]);
-            if constexpr (j == 0) {
-              pf32x16 c0;
-              if constexpr (kb == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-              } else {
-                c0 = acc[ni];
-              }
-              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, Ah[kb], c0, 0, 0, 0);
-            } else if constexpr (j == 1) {
-              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Al[kb], acc[ni], 0, 0, 0);
-            } else {
-              if constexpr (kb == KB - 1) epi[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
-              else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Ah[kb], acc[ni], 0, 0, 0);
-            }
-          }
-          // ---- what stands in this MFMA's shadow ----
-          if constexpr (m == 0) {
-            nf.bh[0] = ds_read128<0>(aBh + sb);
-            nf.bl[0] = ds_read128<0>(aBl + sb);
-            nf.bh[1] = ds_read128<2048>(aBh + sb);
-            nf.bl[1] = ds_read128<2048>(aBl + sb);
-          } else if constexpr (m == 1) {
-            nf.bh[2] = ds_read128<4096>(aBh + sb);
-            nf.bl[2] = ds_read128<4096>(aBl + sb);
-            nf.bh[3] = ds_read128<6144>(aBh + sb);
-            nf.bl[3] = ds_read128<6144>(aBl + sb);
-          } else if constexpr (m == 2) {
-            if (more) dma_one(0);
-          } else if constexpr (m == 4) {
-            if (more) {
-              dma_one(1);
-              dma_advance();
-            }
-          } else {
-            constexpr int eg = pn_egap(m);
-            if constexpr (kb == KB - 1 && eg == 0) {
-              bias_dma(pair);  // (this tile's bias: its epilogue runs during the next tile)
-            } else if (run_epi) {
-              pn_static_for<0, SPG>([&](auto qc) __attribute__((always_inline)) {
-                constexpr int e = (kb * PN_EGAPS + eg) * SPG + decltype(qc)::value;
-                eslice_at(std::integral_constant<int, e>{});
-              });
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        landed_b(nf);
-        __builtin_amdgcn_sched_barrier(0);
-        fb = nf;
-        rstage = nstage;
-        ++gs;
-      });
-      // the finished tile sits in `epi`: its slices go into the next tile's steps (or the flush at the end)
-      load_ctx(ectx[0], pair, 0);
-      load_ctx(ectx[1], pair, 1);
-      epair = pair;
-      erow0 = row0;
-      efull = row0 + PN_BM <= M;
-      have_epi = true;
-    }
-  }
-  if (my_panels > 0 && !(dbg & 1)) flush_epi();
 
   // the workgroup's magnitudes -> the slots
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -616,7 +582,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
   if (!pn_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_fwd_desc& d0 = d[0];
   if (d0.K != 240 && d0.K != 208 && d0.K != 160) return MML_ERR_UNSUPPORTED;  // (the instantiated panel widths)
-  if (d0.M < PN_BM * 64) return MML_ERR_UNSUPPORTED;  // (small batches: the tile kernel fills the chip better)
+  if (d0.M < PN_BM * 64 || d0.M % PN_BM != 0) return MML_ERR_UNSUPPORTED;  // (small / ragged batches: the tile kernel)
   if (!d0.amax_a || !aligned16(d0.A) || d0.lda % 4 != 0) return MML_ERR_UNSUPPORTED;
   int halves = 0, masks = 0, relus = 0;
   for (int i = 0; i < n; ++i) {
@@ -624,7 +590,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     if (q.A != d0.A || q.lda != d0.lda || q.M != d0.M || q.K != d0.K || q.amax_a != d0.amax_a) return MML_ERR_UNSUPPORTED;
     if (q.w_kn != 0 || !q.w_planes || !q.w_kexp || !aligned16(q.w_planes) || q.ldw % 4 != 0) return MML_ERR_UNSUPPORTED;
     if (q.N % 64 != 0 || q.N < 64) return MML_ERR_UNSUPPORTED;
-    if (q.act != MML_ACT_RELU && q.act != MML_ACT_NONE) return MML_ERR_UNSUPPORTED;
+    if (q.act != MML_ACT_RELU) return MML_ERR_UNSUPPORTED;
     if (!aligned16(q.C) || q.ldc % 4 != 0 || (q.bias && !aligned16(q.bias))) return MML_ERR_UNSUPPORTED;
     const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
     if (m && q.ldmask * 32 < q.N) return MML_ERR_UNSUPPORTED;
@@ -632,7 +598,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     relus += 1;
     halves += q.N / 64;
   }
-  if (halves > PN_MAXH) return MML_ERR_UNSUPPORTED;
+  if (halves > PN_MAXH || halves % 2 != 0) return MML_ERR_UNSUPPORTED;
   if (masks != 0 && masks != relus) return MML_ERR_UNSUPPORTED;  // (the waits count the stores of a piece: all or none)
   PanelLaunch L{};
   L.A = d0.A;
@@ -642,14 +608,6 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
   L.K = d0.K;
   L.n_prob = n;
   L.store_masks = masks != 0;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("MMLREC_PANEL_DBG");  // lab: 1 no epilogue pieces, 2 no weight DMA / waits, 4 no barrier,
-      dbg = e ? atoi(e) : 0;                       //      8 no MFMAs, 16 panel loaded once (all give garbage results)
-    }
-    L.pad_ = dbg;
-  }
   int hidx = 0;
   for (int i = 0; i < n; ++i) {
     const mml_gemm_fwd_desc& q = d[i];

@@ -63,9 +63,9 @@ def run(torch, ops, lib, probs, M, panel, masks):
 
 @pytest.mark.parametrize("M,K,Ns,masks", [
     (8192, 240, [256, 256, 256, 256, 64, 64], True),     # AE-30's first layer: 4 experts + 2 gates, two gates in one tile
-    (8192, 240, [256, 64, 64, 64], False),               # odd number of half tiles (inference: no masks)
-    (8192 + 77, 160, [128, 64], True),                   # ragged last panel, the shortest reduction the kernel takes
-    (40000, 208, [64], True),                            # one half tile only; more panels than workgroups
+    (8192, 240, [256, 64, 64], False),                   # inference: no masks; a problem without bias
+    (8192 + 128, 160, [128, 64, 64], True),              # the shortest reduction the kernel takes, 65 panels
+    (40064, 208, [64, 64], True),                        # one tile only; more panels than workgroups (uneven shares)
 ])
 def test_panel_fwd_matches_float64_and_the_tile_kernel(env, M, K, Ns, masks):
     torch, L, ops, lib = env
@@ -100,8 +100,7 @@ def test_panel_fwd_is_scale_invariant(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
     for scale in (3e-9, 1.0, 2e20):
-        A, probs, _ = make_launch(torch, L, ops, 8192, 240, [128, 64], masks=False, bias=False, seed=3, scale=scale,
-                                  acts=[L.ACT_NONE, L.ACT_RELU])
+        A, probs, _ = make_launch(torch, L, ops, 8192, 240, [128, 64, 64], masks=False, bias=False, seed=3, scale=scale)
         name, out = run(torch, ops, lib, probs, 8192, True, False)
         assert name == "gemm_panel_kernel"
         for p, (C, _, _) in zip(probs, out):
@@ -114,11 +113,13 @@ def test_panel_fwd_is_scale_invariant(env):
 def test_launches_the_panel_kernel_does_not_serve_fall_back(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
-    # K beyond the LDS panel, a batch below the threshold, a sigmoid, a problem with another input
-    for M, K, Ns, acts in ((8192, 256, [128], None), (4096, 240, [128], None), (8192, 240, [128], [L.ACT_SIGMOID])):
+    # K beyond the registers, a batch below the threshold, a sigmoid, a linear layer, a ragged last panel, an odd number of
+    # half tiles
+    for M, K, Ns, acts in ((8192, 256, [128], None), (4096, 240, [128], None), (8192, 240, [128], [L.ACT_SIGMOID]),
+                           (8192, 240, [128], [L.ACT_NONE]), (8192 + 77, 240, [128], None), (8192, 240, [192], None)):
         A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=False, acts=acts)
         name, out = run(torch, ops, lib, probs, M, True, False)
         assert "gemm_pipe_kernel" in name, (M, K, name)
         z = A.double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
-        ref = torch.sigmoid(z) if acts else torch.relu(z)
+        ref = torch.relu(z) if not acts else (torch.sigmoid(z) if acts[0] == L.ACT_SIGMOID else z)
         assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL
