@@ -129,14 +129,14 @@ __device__ __forceinline__ void pn_static_for(F&& f) {
 #ifndef PN_LAB
 #define PN_LAB 0  // lab builds (tools/lab/panel_lab.sh): 1 no epilogue slices, 2 no weight DMA / waits, 8 no MFMAs,
 #endif            // 16 the panel is loaded once, 32 no epilogue stores, 128 no vmcnt waits (all give garbage results)
-constexpr int PN_NSL = 26;                    // slices per sub-tile
+constexpr int PN_NSL = 28;                    // slices per sub-tile
 constexpr int PN_EGAPS = 8;                   // epilogue gaps per k-step
 // slices per gap: the epilogue ends before the tile's last k-step (whose first epilogue gap carries the bias DMA)
 constexpr int pn_spg(int KB) { return (4 * PN_NSL + (KB - 1) * PN_EGAPS - 1) / ((KB - 1) * PN_EGAPS); }
 // epilogue gap index (0..7) of MFMA gap m, or -1
 constexpr int pn_egap(int m) { return m == 3 ? 0 : (m >= 5 ? m - 4 : -1); }
 // VMEM operations slice S of a sub-tile issues
-constexpr int pn_slice_ops(int S, bool masks) { return S == 19 ? (masks ? 1 : 0) : ((S == 22 || S == 23) ? 2 : 0); }
+constexpr int pn_slice_ops(int S, bool masks) { return S == 22 ? (masks ? 1 : 0) : ((S == 24 || S == 25) ? 2 : 0); }
 // VMEM operations the epilogue slices issue in k-step kb of a tile (compile-time schedule)
 constexpr int pn_step_ops(int KB, int kb, bool masks) {
   int n = 0;
@@ -300,90 +300,108 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   Ctx ectx[2];
   float am_f[2] = {0.f, 0.f};
   int row0 = 0;       // of the panel being computed
-  int erow0 = 0;      // of the panel the tile in `epi` belongs to
+  uint32_t erow0 = 0; // of the panel the tile in `epi` belongs to
 
   // ---- epilogue state that lives across slices ----
   f32x4_t eb[4];      // bias of the four column runs of the sub-tile
   f32x4_t ev[4];      // a run of four outputs (pre-turn), then the four row-major pieces
   uint32_t emw = 0u;  // sign bits of this lane's 16 outputs
-  // One slice (S of PN_NSL) of the epilogue of sub-tile NI of the tile in `epi`.  No branch in any of them.
+  // per-lane addresses of the epilogue, computed once (a handful of registers; the first form recomputed them from an
+  // opaque lane number in every slice, ~8 instructions each time)
+  const uint32_t scr = lds0 + PN_SCR_OFF + wave * PN_SCR;
+  uint32_t e_wr[4];   // turn area, write side: 16-byte chunk c = 2 g + h of row r at c ^ (r & 7)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) e_wr[g] = scr + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) * 16);
+  const int eR = lane >> 3, ecc = lane & 7;
+  const uint32_t e_rd = scr + eR * 128 + ((ecc ^ eR) * 16);  // read side: lane (R, cc) takes chunk cc of rows R + 8 p
+  const uint32_t e_bias = (uint32_t)(4 * h) * 4u;             // + bias_at + NI * 128: the lane's columns 8 g + 4 h + j
+  const uint32_t e_row = (uint32_t)(32 * wave + eR);          // row of the panel this lane stores (+ 8 p)
+  const uint32_t e_mrow = (uint32_t)(32 * wave + l31);        // row of the panel whose mask word this lane holds
+  const uint32_t e_sh = (uint32_t)(4 * h);
+  // One slice (S of PN_NSL) of the epilogue of sub-tile NI of the tile in `epi`: at most ~5 instructions, no branch.
+  //   0 bias reads | 1 wait | 2 + 5 g + {0, 1: unscale + bias, 2: ReLU, 3: magnitude + sign tests, 4: sign bits + turn}
+  //   22 mask word | 23 row-major reads | 24, 25 stores | 26 magnitude word
   auto eslice = [&](auto nic, auto sc) __attribute__((always_inline)) {
     constexpr int NI = decltype(nic)::value, S = decltype(sc)::value, HT = NI >> 1;
     const Ctx& ec = ectx[HT];
     pf32x16& a = epi[NI];
-    int ln = lane;
-    asm volatile("" : "+v"(ln));  // (addresses from an opaque lane number: nothing for hipcc to hoist out of the loops)
-    const uint32_t scr = lds0 + PN_SCR_OFF + wave * PN_SCR;
-    if constexpr (S == 0) {  // bias of the lane's columns 8 g + 4 h + j
-      const uint32_t ab = ec.bias_at + (NI * 32 + 4 * (ln >> 5)) * 4;
-      eb[0] = ds_read128<0>(ab);
-      eb[1] = ds_read128<32>(ab);
-      eb[2] = ds_read128<64>(ab);
-      eb[3] = ds_read128<96>(ab);
+    if constexpr (S == 0) {
+      const uint32_t ab = ec.bias_at + e_bias;
+      eb[0] = ds_read128<NI * 128>(ab);
+      eb[1] = ds_read128<NI * 128 + 32>(ab);
+      eb[2] = ds_read128<NI * 128 + 64>(ab);
+      eb[3] = ds_read128<NI * 128 + 96>(ab);
       emw = 0u;
-    } else if constexpr (S == 2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (S == 1) {
+      if constexpr (!(PN_LAB & 256)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int g = 0; g < 4; ++g) lds_landed(eb[g]);
-    } else if constexpr (S >= 3 && S <= 18) {
-      constexpr int g = (S - 3) >> 2, part = (S - 3) & 3;
+    } else if constexpr (S >= 2 && S <= 21) {
+      constexpr int g = (S - 2) / 5, part = (S - 2) % 5;
       f32x4_t& x = ev[g];
-      if constexpr (part == 0) {  // unscale + bias (one exact multiplication by a power of two inside the FMA)
-        const float inv = ec.inv;
-        x.x = a[4 * g] * inv + eb[g].x;
-        x.y = a[4 * g + 1] * inv + eb[g].y;
-        x.z = a[4 * g + 2] * inv + eb[g].z;
-        x.w = a[4 * g + 3] * inv + eb[g].w;
-      } else if constexpr (part == 1) {  // ReLU (v > 0 ? v : 0 -- one v_max_f32: a NaN gives 0 like the comparison), magnitude
+      if constexpr (((PN_LAB & 64) && part != 4) || ((PN_LAB & 512) && part <= 1) || ((PN_LAB & 1024) && part == 2) ||
+                    ((PN_LAB & 2048) && part == 3)) {
+      } else if constexpr (part == 0) {  // unscale + bias (one exact multiplication by a power of two inside the FMA)
+        x.x = a[4 * g] * ec.inv + eb[g].x;
+        x.y = a[4 * g + 1] * ec.inv + eb[g].y;
+      } else if constexpr (part == 1) {
+        x.z = a[4 * g + 2] * ec.inv + eb[g].z;
+        x.w = a[4 * g + 3] * ec.inv + eb[g].w;
+      } else if constexpr (part == 2) {  // ReLU (v > 0 ? v : 0 -- one v_max_f32: a NaN gives 0 like the comparison)
         asm("v_max_f32 %0, 0, %0" : "+v"(x.x));
         asm("v_max_f32 %0, 0, %0" : "+v"(x.y));
         asm("v_max_f32 %0, 0, %0" : "+v"(x.z));
         asm("v_max_f32 %0, 0, %0" : "+v"(x.w));
-        am_f[HT] = fmaxf(fmaxf(am_f[HT], x.x), fmaxf(x.y, fmaxf(x.z, x.w)));
-      } else if constexpr (part == 2) {  // sign bits of columns 8 g + j (shifted by 4 h at the end)
-        if (MASKS) {
-          emw |= (x.x > 0.f ? 1u : 0u) << (8 * g);
-          emw |= (x.y > 0.f ? 1u : 0u) << (8 * g + 1);
-          emw |= (x.z > 0.f ? 1u : 0u) << (8 * g + 2);
-          emw |= (x.w > 0.f ? 1u : 0u) << (8 * g + 3);
+      } else if constexpr (part == 3) {  // magnitude (the values are >= 0 now)
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(am_f[HT]) : "v"(x.x), "v"(x.y));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(am_f[HT]) : "v"(x.z), "v"(x.w));
+      } else {  // sign bits of columns 8 g + j (v > 0 <=> its bit pattern != 0; shifted by 4 h at the end); the turn
+        if (MASKS && !(PN_LAB & 64) && !(PN_LAB & 4096)) {
+          const uint32_t u0 = __float_as_uint(x.x), u1 = __float_as_uint(x.y), u2 = __float_as_uint(x.z), u3 = __float_as_uint(x.w);
+          uint32_t t0, t1, t2, t3;
+          asm("v_min_u32 %0, 1, %1" : "=v"(t0) : "v"(u0));
+          asm("v_min_u32 %0, 1, %1" : "=v"(t1) : "v"(u1));
+          asm("v_min_u32 %0, 1, %1" : "=v"(t2) : "v"(u2));
+          asm("v_min_u32 %0, 1, %1" : "=v"(t3) : "v"(u3));
+          asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(emw) : "v"(t0), "n"(8 * g));
+          asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(emw) : "v"(t1), "n"(8 * g + 1));
+          asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(emw) : "v"(t2), "n"(8 * g + 2));
+          asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(emw) : "v"(t3), "n"(8 * g + 3));
         }
-      } else {  // the run goes to the wave's turn area: 16-byte chunk c of row r at c ^ (r & 7)
-        const int r = ln & 31, hh = ln >> 5;
-        ds_write128(scr + r * 128 + (((2 * g + hh) ^ (r & 7)) * 16), x);
+        if constexpr (!(PN_LAB & 256)) ds_write128(e_wr[g], x);
+        else asm volatile("" ::"v"(x));
       }
-    } else if constexpr (S == 19) {  // the row's 32-column word: lanes r and r + 32 hold its two interleaved halves
+    } else if constexpr (S == 22) {  // the row's 32-column word: lanes r and r + 32 hold its two interleaved halves
       if (MASKS) {
-        const uint32_t mine = emw << (4 * (ln >> 5));
+        const uint32_t mine = emw << e_sh;
         const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
         const uint32_t word = sw[0] | sw[1];
-        const int row = erow0 + 32 * wave + (ln & 31);
-        if constexpr (!(PN_LAB & 32)) ec.mask[(int64_t)row * ec.ldmask + (NI & 1)] = word;  // (both lanes of a row store the same word)
-        else asm volatile("" ::"v"(word));
+        const uint32_t at = (erow0 + e_mrow) * (uint32_t)ec.ldmask + (NI & 1);
+        if constexpr (!(PN_LAB & 32)) ec.mask[at] = word;  // (both lanes of a row store the same word)
+        else asm volatile("" ::"v"(word), "v"(at));
       }
-    } else if constexpr (S == 20) {  // row-major pieces: lane (R, cc) takes columns 4 cc .. 4 cc + 3 of rows R + 8 p
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int R = ln >> 3, cc = ln & 7;
-      const uint32_t ar = scr + R * 128 + ((cc ^ R) * 16);
-      ev[0] = ds_read128<0>(ar);
-      ev[1] = ds_read128<1024>(ar);
-      ev[2] = ds_read128<2048>(ar);
-      ev[3] = ds_read128<3072>(ar);
-    } else if constexpr (S == 22 || S == 23) {
-      if constexpr (S == 22) {
+    } else if constexpr (S == 23) {
+      if constexpr (!(PN_LAB & 256)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ev[0] = ds_read128<0>(e_rd);
+        ev[1] = ds_read128<1024>(e_rd);
+        ev[2] = ds_read128<2048>(e_rd);
+        ev[3] = ds_read128<3072>(e_rd);
+      }
+    } else if constexpr (S == 24 || S == 25) {
+      if constexpr (S == 24 && !(PN_LAB & 256)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int p = 0; p < 4; ++p) lds_landed(ev[p]);
       }
-      const int R = ln >> 3, cc = ln & 7;
-      const int rowb = erow0 + 32 * wave + R;
-      float* const cp = ec.C + (NI & 1) * 32 + 4 * cc;
+      float* const cp = ec.C + (NI & 1) * 32;
 #pragma unroll
-      for (int p = 2 * (S - 22); p < 2 * (S - 22) + 2; ++p) {
-        if constexpr (!(PN_LAB & 32))
-          *reinterpret_cast<float4*>(cp + (int64_t)(rowb + 8 * p) * ec.ldc) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
-        else asm volatile("" ::"v"(ev[p]), "v"(cp + (int64_t)(rowb + 8 * p) * ec.ldc));
+      for (int p = 2 * (S - 24); p < 2 * (S - 24) + 2; ++p) {
+        const uint32_t at = (erow0 + e_row + 8 * p) * (uint32_t)ec.ldc + 4 * ecc;  // (< 2^32 bytes: checked on the host)
+        if constexpr (!(PN_LAB & 32)) *reinterpret_cast<float4*>(cp + at) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+        else asm volatile("" ::"v"(ev[p]), "v"(at));
       }
-    } else if constexpr (S == 24) {
+    } else if constexpr (S == 26) {
       if constexpr ((NI & 1) == 1) {  // the half tile's largest |output| -> the workgroup's word of its problem (or the dummy)
         const uint32_t am_bits = __float_as_uint(am_f[HT]);
         asm volatile("ds_max_u32 %0, %1" ::"v"(ec.amax_at), "v"(am_bits) : "memory");
@@ -438,13 +456,15 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
         static_assert(N <= 63, "vmcnt is six bits wide");
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(PN_LAB & 4)) __builtin_amdgcn_s_barrier();
       FragB nf;
       const int nstage = rstage + 1 == PN_D ? 0 : rstage + 1;
       const uint32_t sb = (uint32_t)nstage * PN_STAGE;
       __builtin_amdgcn_sched_barrier(0);
       pn_static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value, ni = m / 3, j = m % 3;
+        // (the three dependent MFMAs of a product block stand four apart: with one wave per SIMD a dependent MFMA issued
+        // right behind its producer waits for the producer's whole latency -- measured: the loop ran at half speed)
+        constexpr int m = decltype(mc)::value, ni = m % 4, j = m / 4;
         if constexpr (!(PN_LAB & 8)) {
           const f16x8 bh = __builtin_bit_cast(f16x8, fb.bh[ni]), bl = __builtin_bit_cast(f16x8, fb.bl[ni]);
           if constexpr (j == 0) {
@@ -464,7 +484,9 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
           }
         }
         // ---- what stands in this MFMA's shadow ----
-        if constexpr (m == 0) {
+        if constexpr ((PN_LAB & 16384) && (m == 0 || m == 1)) {
+          if constexpr (m == 0) nf = fb;
+        } else if constexpr (m == 0) {
           nf.bh[0] = ds_read128<0>(aBh + sb);
           nf.bl[0] = ds_read128<0>(aBl + sb);
           nf.bh[1] = ds_read128<2048>(aBh + sb);
@@ -501,10 +523,14 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
       fb = nf;
       rstage = nstage;
     });
+    if constexpr (PN_LAB != 0) {  // (lab builds: whatever is switched off, the products stay live)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(epi[ni]));
+    }
     // the finished tile sits in `epi`: its slices go into the next tile's gaps (or the flush at the end)
     load_ctx(ectx[0], pair, 0);
     load_ctx(ectx[1], pair, 1);
-    erow0 = row0;
+    erow0 = (uint32_t)row0;
   };
   using TT = std::true_type;
   using FF = std::false_type;
@@ -592,6 +618,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     if (q.N % 64 != 0 || q.N < 64) return MML_ERR_UNSUPPORTED;
     if (q.act != MML_ACT_RELU) return MML_ERR_UNSUPPORTED;
     if (!aligned16(q.C) || q.ldc % 4 != 0 || (q.bias && !aligned16(q.bias))) return MML_ERR_UNSUPPORTED;
+    if ((int64_t)q.M * q.ldc >= (1ll << 30) || (int64_t)q.M * q.ldmask >= (1ll << 30)) return MML_ERR_UNSUPPORTED;  // (32-bit offsets)
     const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
     if (m && q.ldmask * 32 < q.N) return MML_ERR_UNSUPPORTED;
     masks += m ? 1 : 0;
