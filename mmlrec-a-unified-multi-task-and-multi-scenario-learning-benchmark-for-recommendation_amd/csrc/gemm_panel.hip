@@ -35,7 +35,10 @@ using pf32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int PN_BM = 128;               // panel rows (four waves x 32)
 constexpr int PN_STAGE = 8192;           // bytes of one 128-column x 16-k weight image
-constexpr int PN_D = 12;                 // weight ring stages
+#ifndef PN_D_LAB
+#define PN_D_LAB 12
+#endif
+constexpr int PN_D = PN_D_LAB;           // weight ring stages
 constexpr int PN_W = PN_D - 2;           // k-steps between the issue of a stage and the wait for it
 constexpr int PN_SCR = 4096;             // bytes of a wave's row-major turn area (32 rows x 128 B)
 constexpr int PN_MAXH = 64;              // half tiles per launch
@@ -128,34 +131,36 @@ __device__ __forceinline__ void pn_static_for(F&& f) {
 // through LDS, then the mask word, the row-major reads and four whole-line stores.
 #ifndef PN_LAB
 #define PN_LAB 0  // lab builds (tools/lab/panel_lab.sh): 1 no epilogue slices, 2 no weight DMA / waits, 8 no MFMAs,
-#endif            // 16 the panel is loaded once, 32 no epilogue stores, 128 no vmcnt waits (all give garbage results)
+#endif            // 16 the panel is loaded once, 32 no epilogue stores, 64 / 512.. no epilogue arithmetic, 128 no vmcnt waits,
+                  // 256 no row-major turn, 16384 no fragment reads (all give garbage results), 65536 plain instead of nontemporal stores
 constexpr int PN_NSL = 28;                    // slices per sub-tile
 constexpr int PN_EGAPS = 8;                   // epilogue gaps per k-step
-// slices per gap: the epilogue ends before the tile's last k-step (whose first epilogue gap carries the bias DMA)
-constexpr int pn_spg(int KB) { return (4 * PN_NSL + (KB - 1) * PN_EGAPS - 1) / ((KB - 1) * PN_EGAPS); }
+constexpr int pn_spg(int KB) { return (4 * PN_NSL + KB * PN_EGAPS - 1) / (KB * PN_EGAPS); }  // slices per gap
 // epilogue gap index (0..7) of MFMA gap m, or -1
 constexpr int pn_egap(int m) { return m == 3 ? 0 : (m >= 5 ? m - 4 : -1); }
 // VMEM operations slice S of a sub-tile issues
 constexpr int pn_slice_ops(int S, bool masks) { return S == 22 ? (masks ? 1 : 0) : ((S == 24 || S == 25) ? 2 : 0); }
-// VMEM operations the epilogue slices issue in k-step kb of a tile (compile-time schedule)
-constexpr int pn_step_ops(int KB, int kb, bool masks) {
+// VMEM operations the epilogue slices issue in k-step kb of a tile, from epilogue gap eg0 on (compile-time schedule)
+constexpr int pn_step_ops(int KB, int kb, bool masks, int eg0) {
   int n = 0;
   const int spg = pn_spg(KB);
-  for (int eg = 0; eg < PN_EGAPS; ++eg)
+  for (int eg = eg0; eg < PN_EGAPS; ++eg)
     for (int q = 0; q < spg; ++q) {
       const int e = (kb * PN_EGAPS + eg) * spg + q;
-      if (e < 4 * PN_NSL && !(kb == KB - 1 && eg == 0)) n += pn_slice_ops(e % PN_NSL, masks);
+      if (e < 4 * PN_NSL) n += pn_slice_ops(e % PN_NSL, masks);
     }
   return n;
 }
-// What a wave has issued after the weight DMA it waits for at the top of k-step kb: the PN_W steps before it hold
-// PN_W - 1 later weight-DMA pairs and the epilogue stores of this tile's slices (cur) / of the tile before (prev).
-// (The bias DMA of waves 0 / 1 is not counted: they wait for one operation more than they must.)
+// What a wave has issued after the SECOND weight DMA (gap 4) of the pair it waits for at the top of k-step kb: the
+// PN_W - 1 later pairs and the epilogue stores of this tile's slices (cur) / of the tile before (prev) -- of the awaited
+// pair's own step only those behind gap 4 (epilogue gap 0 = MFMA gap 3 stands BEFORE it: counting its stores would let
+// the wait pass with that DMA still in flight).  Not counted: the bias DMA of waves 0 / 1 (they wait for one
+// operation more than they must).
 constexpr int pn_younger(int KB, int kb, bool masks, bool cur, bool prev) {
   int n = 2 * (PN_W - 1);
   for (int d = 1; d <= PN_W; ++d) {  // step kb - d
     const int k = kb - d;
-    if (k >= 0 ? cur : prev) n += pn_step_ops(KB, k >= 0 ? k : k + KB, masks);  // (PN_W <= KB: at most one tile back)
+    if (k >= 0 ? cur : prev) n += pn_step_ops(KB, k >= 0 ? k : k + KB, masks, d == PN_W ? 1 : 0);  // (PN_W <= KB)
   }
   return n;
 }
@@ -164,7 +169,7 @@ template <int KB, bool MASKS>
 __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch Larg) {
   static_assert(KB >= PN_W && KB >= 10 && KB <= 15, "the panel kernel holds 10..15 k-blocks per row in registers");
   constexpr int SPG = pn_spg(KB);
-  static_assert((KB - 1) * PN_EGAPS * SPG >= 4 * PN_NSL, "the epilogue must end before the tile's last k-step");
+  static_assert(KB * PN_EGAPS * SPG >= 4 * PN_NSL, "the epilogue must end inside the tile");
   typedef const __attribute__((address_space(4))) PanelLaunch KLaunch;
   KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float lds[PN_LDS_BYTES / 4];
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
     uint32_t bias_at;   // LDS byte address of the tile pair's 128 bias values -- or of the zero area
     uint32_t amax_at;   // LDS byte address of the problem's magnitude word -- or of the dummy word
   };
-  auto load_ctx = [&](Ctx& c, const int pair, const int j) __attribute__((always_inline)) {
+  auto load_ctx = [&](Ctx& c, const int pair, const int j, const int par) __attribute__((always_inline)) {
     const int hw_ = L.half[2 * pair + j], pi = hw_ >> 16, col0 = hw_ & 0xffff;
     c.ldc = (int)L.p[pi].ldc;
     c.ldmask = (int)L.p[pi].ldmask;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ib) : "v"(b) : "memory");
     }
     c.inv = invA * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ib)));
-    c.bias_at = lds0 + (L.p[pi].bias ? PN_BIAS_OFF + (pair & 1) * 512 : PN_ZERO_OFF);
+    c.bias_at = lds0 + (L.p[pi].bias ? PN_BIAS_OFF + par * 512 : PN_ZERO_OFF);
     c.amax_at = lds0 + PN_AMAX_OFF + (L.p[pi].amax_out ? pi : MML_MAX_GROUP) * 4;
   };
 
@@ -252,13 +257,17 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
       pb[j] = base + (int64_t)(col0 + 16 * wave + drow) * L.p[pi].ldp + 4 * dchunk;
     }
   };
-  // the 128 bias values of a tile pair travel to LDS by one 4-byte LDS-DMA per lane of waves 0 / 1 (half tile 0 / 1)
-  auto bias_dma = [&](const int pair) __attribute__((always_inline)) {
+  // The 128 bias values of a tile pair travel to LDS by one 4-byte LDS-DMA per lane of waves 0 / 1 (half tile 0 / 1), in
+  // k-step 1 of the tile: its epilogue reads them from step 0 of the NEXT tile on, behind PN_W later weight-DMA waits of
+  // the issuing wave and as many barriers (issued in the tile's last step -- the first hand-placed form -- they were
+  // read one step later: wrong bias in a few panels under load).  Two buffers, alternating by TILE (not by pair: the
+  // last pair of a panel and the first of the next may have the same parity).
+  auto bias_dma = [&](const int pair, const int par) __attribute__((always_inline)) {
     if (wave < 2) {
       const int hw_ = L.half[2 * pair + wave], pi = hw_ >> 16, col0 = hw_ & 0xffff;
       const float* bias = L.p[pi].bias;
       const float* src = bias ? bias + col0 + lane : L.A;
-      dma4(src, lds + (PN_BIAS_OFF + (pair & 1) * 512 + wave * 256) / 4);
+      dma4(src, lds + (PN_BIAS_OFF + par * 512 + wave * 256) / 4);
     }
   };
 
@@ -398,7 +407,9 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
 #pragma unroll
       for (int p = 2 * (S - 24); p < 2 * (S - 24) + 2; ++p) {
         const uint32_t at = (erow0 + e_row + 8 * p) * (uint32_t)ec.ldc + 4 * ecc;  // (< 2^32 bytes: checked on the host)
-        if constexpr (!(PN_LAB & 32)) *reinterpret_cast<float4*>(cp + at) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+        // (nontemporal: the outputs are read next by another kernel, long after this line has left the L2 -- 180 -> 172 us)
+        if constexpr (PN_LAB & 65536) *reinterpret_cast<float4*>(cp + at) = make_float4(ev[p].x, ev[p].y, ev[p].z, ev[p].w);
+        else if constexpr (!(PN_LAB & 32)) __builtin_nontemporal_store(ev[p], reinterpret_cast<f32x4_t*>(cp + at));
         else asm volatile("" ::"v"(ev[p]), "v"(at));
       }
     } else if constexpr (S == 26) {
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
   int rstage = 0;      // ring stage of the step about to run
 
   // ---- one tile: KB k-steps.  EPI: the slices of the tile in `epi` run in its gaps; PREV: the tile before ran slices too ----
-  auto tile = [&](auto epic, auto prevc, const int pair) __attribute__((always_inline)) {
+  auto tile = [&](auto epic, auto prevc, const int pair, const int par) __attribute__((always_inline)) {
     constexpr bool EPI = decltype(epic)::value, PREV = decltype(prevc)::value;
     pn_static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value;
@@ -498,6 +509,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
           nf.bl[3] = ds_read128<6144>(aBl + sb);
         } else if constexpr (m == 2) {
           if constexpr (!(PN_LAB & 2)) dma_one(0);
+          if constexpr (kb == 1) bias_dma(pair, par);
         } else if constexpr (m == 4) {
           if constexpr (!(PN_LAB & 2)) {
             dma_one(1);
@@ -507,9 +519,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
           }
         } else {
           constexpr int eg = pn_egap(m);
-          if constexpr (kb == KB - 1 && eg == 0) {
-            bias_dma(pair);  // (this tile's bias: its epilogue runs during the next tile)
-          } else if constexpr (EPI && !(PN_LAB & 1)) {
+          if constexpr (EPI && !(PN_LAB & 1)) {
             pn_static_for<0, SPG>([&](auto qc) __attribute__((always_inline)) {
               eslice_at(std::integral_constant<int, (kb * PN_EGAPS + eg) * SPG + decltype(qc)::value>{});
             });
@@ -528,8 +538,8 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
       for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(epi[ni]));
     }
     // the finished tile sits in `epi`: its slices go into the next tile's gaps (or the flush at the end)
-    load_ctx(ectx[0], pair, 0);
-    load_ctx(ectx[1], pair, 1);
+    load_ctx(ectx[0], pair, 0, par);
+    load_ctx(ectx[1], pair, 1, par);
     erow0 = (uint32_t)row0;
   };
   using TT = std::true_type;
@@ -557,9 +567,9 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch La
     // (at a panel switch hipcc has waited with vmcnt(0) for the panel's loads: counts that still include operations of
     // the panel before only over-estimate what is in flight by operations that are done)
     for (int pair = 0; pair < npairs; ++pair) {
-      if (tiles_done == 0) tile(FF{}, FF{}, pair);
-      else if (tiles_done == 1) tile(TT{}, FF{}, pair);
-      else tile(TT{}, TT{}, pair);
+      if (tiles_done == 0) tile(FF{}, FF{}, pair, 0);
+      else if (tiles_done == 1) tile(TT{}, FF{}, pair, 1);
+      else tile(TT{}, TT{}, pair, tiles_done & 1);
       ++tiles_done;
     }
   }

@@ -240,8 +240,13 @@ class BaseModel(nn.Module):
         # data-parallel ranks hold consecutive blocks of the global batch (rank r: rows [r B, (r + 1) B)) and must have
         # been built under the same torch seed: together they then draw the dropout mask of a one-rank step
         plan.row0 = par0.rank * int(B) if (par0 is not None and training) else 0
-        plan.step_dev = (self.optimizer().step_dev if getattr(self, "optim_name", None) is not None else
-                         torch.zeros(1, dtype=torch.int32, device=store.device))
+        if getattr(self, "optim_name", None) is not None:
+            plan.step_dev = self.optimizer().step_dev
+        else:  # an uncompiled model: ONE counter for all its plans (every training-mode forward bumps it, see below)
+            own = self.__dict__.get("_own_step_dev")
+            if own is None or own.device != store.device:
+                own = self.__dict__["_own_step_dev"] = torch.zeros(1, dtype=torch.int32, device=store.device)
+            plan.step_dev = own
         plan.generation = 0
         sp, de = self._sparse_cols(), self._dense_cols()
         ftot = max(e for _, e in self.feature_index.values())

@@ -66,6 +66,8 @@ def run(torch, ops, lib, probs, M, panel, masks):
     (8192, 240, [256, 64, 64], False),                   # inference: no masks; a problem without bias
     (8192 + 128, 160, [128, 64, 64], True),              # the shortest reduction the kernel takes, 65 panels
     (40064, 208, [64, 64], True),                        # one tile only; more panels than workgroups (uneven shares)
+    (65536, 240, [256, 256, 256, 256, 64, 64], True),    # the benchmark's launch: two panels of nine tiles per workgroup
+    (3 * 32768 + 128, 240, [128, 64, 64], False),        # three or four panels per workgroup
 ])
 def test_panel_fwd_matches_float64_and_the_tile_kernel(env, M, K, Ns, masks):
     torch, L, ops, lib = env
@@ -123,3 +125,22 @@ def test_launches_the_panel_kernel_does_not_serve_fall_back(env):
         z = A.double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
         ref = torch.relu(z) if not acts else (torch.sigmoid(z) if acts[0] == L.ACT_SIGMOID else z)
         assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL
+
+
+def test_panel_fwd_is_repeatable_on_a_full_chip(env):
+    """Race screen: the benchmark's launch (every CU busy, two panels per workgroup) forty times against the tile kernel's
+    result -- outputs, sign masks and magnitudes bit for bit every time.  (The first hand-placed form read a tile's bias
+    one k-step after its LDS-DMA was issued: wrong bias in ~3 % of the panels, only with every CU loaded.)"""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    M, K, Ns = 65536, 240, [256, 256, 256, 256, 64, 64]
+    A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=True, seed=11)
+    name_t, ref = run(torch, ops, lib, probs, M, False, True)
+    assert "gemm_pipe_kernel" in name_t
+    for rep in range(40):
+        name_p, out = run(torch, ops, lib, probs, M, True, True)
+        assert name_p == "gemm_panel_kernel"
+        for i, ((C, mk, am), (Ct, mkt, amt)) in enumerate(zip(out, ref)):
+            assert torch.equal(C, Ct), (rep, i, int((C != Ct).sum()))
+            assert torch.equal(mk, mkt), (rep, i)
+            assert float(torch.max(am.view(torch.float32))) == float(torch.max(amt.view(torch.float32))), (rep, i)

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../.."
 P=mmlrec-a-unified-multi-task-and-multi-scenario-learning-benchmark-for-recommendation_amd
 mkdir -p $P/lib/lab
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DPN_LAB=$n -c $P/csrc/gemm_panel.hip -o $P/lib/lab/gemm_panel_lab$n.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DPN_LAB=$n $PN_EXTRA -c $P/csrc/gemm_panel.hip -o $P/lib/lab/gemm_panel_lab$n.o
   objs=$(ls $P/lib/obj/*.o | grep -v gemm_panel.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/lib/lab/libmmlrec_panel_lab$n.so $objs $P/lib/lab/gemm_panel_lab$n.o
   echo built $P/lib/lab/libmmlrec_panel_lab$n.so
