@@ -1210,7 +1210,13 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
               const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
               x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
             }
+            // (nontemporal, MMLREC_GEMM_NT=1 at build time: the output is read next by another kernel, long after the
+            // line has left the L2 -- the panel kernel gained 4 % from it)
+#ifdef MML_GEMM_NT
+            __builtin_nontemporal_store(f32x4_t{x.x, x.y, x.z, x.w}, reinterpret_cast<f32x4_t*>(C + (int64_t)row * ldc + colg));
+#else
             *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;
+#endif
             am_f = fmaxf(fmaxf(am_f, fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
           }
         }

@@ -261,6 +261,69 @@ def test_bench_configuration_steps_match_oracle(W, table_update):
     check_tables(vocab, names, np.concatenate(Xs), before, sd, params)
 
 
+@pytest.mark.parametrize("table_update", ["dense_exact", "lazy_exact"])
+def test_row_sharded_bench_configuration_steps_match_oracle(W, table_update):
+    """The row-sharded step at the benchmark's configuration (only a builder-side MMLREC_BENCH_FORCE_SHARD run
+    covered it): B = 65 536, 1-rank RCCL group, de-duplicated exchange, HIP-graph segments, and the routing of batch
+    k + 1 prefetched on the side stream while step k is in flight (bench.py's loop: run(); prefetch(next)).  Three steps
+    on bench.py's batches against oracle.train_step -- losses, every MLP tensor, every table row the batches touched
+    element-wise and every other row bit for bit after the shards are gathered back (state_dict())."""
+    import os
+    import torch.distributed as dist
+    from oracle import mmlrec_oracle as orc
+    from mmlrec_amd import parallel
+    orc.use_fast(True)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        model, cfg, vocab, dense = _bench_model(W, table_update)
+        names = [f.name for f in model._sparse_cols()]
+        spec = orc.Spec(cfg, names, vocab, dense)
+        params = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+        before = {k: v.copy() for k, v in params.items()}
+        B, T, lr = 65536, W.num_tasks(cfg), cfg["optim_config"]["lr"]
+        par = parallel.shard_model(model, dist, B, mode="row_sharded")
+        runner = model.train_step_runner(B, use_graph=True, overlap=True, split_dense=False)
+        opt = orc.DenseOptimizer("adam", lr)
+        nsteps = 3
+        batches = [W.synth_batch(vocab, 0, B, T, seed=1 + i) for i in range(nsteps)]
+        dbatches = [(x.to(dev()), y.to(dev())) for x, y in batches]
+        Xs = []
+        for i in range(nsteps):
+            if not runner._has_next:          # (step 0 routes its batch itself; the others were prefetched)
+                runner.load(*dbatches[i])
+            else:
+                assert i > 0
+            runner.run()
+            if i + 1 < nsteps:
+                runner.prefetch(*dbatches[i + 1])
+            X, y = batches[i]
+            Xs.append(X.numpy())
+            loss_gpu = float(runner.plan.loss.item())
+            loss_ref = orc.train_step(spec, params, opt, X.numpy(), y.numpy())
+            assert abs(loss_gpu - loss_ref) / loss_ref < 1e-4, (i, loss_gpu, loss_ref)
+        runner.drop_prefetch()
+        assert runner.front.n_graphs + runner.sideq.n_graphs + runner.tail.n_graphs >= 2  # segments were captured
+        assert par.dirty
+        sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}  # gathers the shards (and flushes lazy rows)
+        assert not par.dirty
+        for k, ref in params.items():
+            if k.startswith("embedding_dict."):
+                continue
+            dv = np.abs(sd[k].astype(np.float64) - ref)
+            assert dv.max() <= 2.5 * lr * nsteps, k
+            check_update(k, before[k], sd[k], ref)
+        check_tables(vocab, names, np.concatenate(Xs), before, sd, params)
+    finally:
+        if created:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+
+
 def test_bench_sequence_losses_match_fixture(W):
     """The loss trajectory bench.py reports: its exact step sequence (4 resident batches, seeds 1-4, rotated) for 25
     steps (the driver's --warmup 5 --steps 20) against tests/golden/bench_losses_mmoe_ae30.json, which the ORACLE

@@ -342,7 +342,7 @@ def test_sharded_path_world1_matches_golden(mode):
         combos = [("adam", "dense_exact", 3), ("adagrad", "sparse_rows", 3)]
         if mode != "table_wise":
             combos.append(("adam", "lazy_exact", 3))
-        for case_name in ("mmoe_ae30d", "pepnet_amazon"):
+        for case_name in ("mmoe_ae30d", "pepnet_amazon", "star_amazon"):
             g = load_golden(case_name)
             for kind, tu, ck in combos:
                 model, cfg = build(g, table_update=tu)

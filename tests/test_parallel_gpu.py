@@ -176,7 +176,8 @@ def test_world2_dropout_step_is_the_one_rank_step():
 @pytest.mark.timeout(900)
 def test_world2_steps_match_reference_trajectories():
     jobs = []
-    for case_name in ("mmoe_ae30d", "pepnet_amazon"):
+    # (star_amazon: BASELINE configs[4] names STAR "over sharded tables" -- VERDICT r3)
+    for case_name in ("mmoe_ae30d", "pepnet_amazon", "star_amazon"):
         for mode in ("row_sharded", "replicated", "table_wise"):
             jobs.append((case_name, mode, "adam", "dense_exact", True))
             jobs.append((case_name, mode, "adagrad", "sparse_rows", False))
