@@ -45,6 +45,8 @@ def parse():
                     help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
                          "--kernel-trace of this command reports stand-alone kernel durations")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary lazy_exact measurement")
+    ap.add_argument("--lazy-epoch-steps", type=int, default=500,
+                    help="lazy_exact: also time an epoch of this many steps + its flush (0 = skip)")
     ap.add_argument("--split-dense", action="store_true",
                     help="dense table update as untouched rows beside the forward + touched rows after the scatter, "
                          "instead of ONE launch after the scatter that skips the gradient read of unmarked rows")
@@ -491,6 +493,16 @@ def main():
                        "value_incl_final_flush": round(B * steps / dt, 1),
                        "value_steps_only": round(B * steps / (dt - tf), 1),
                        "ms_per_step_steps_only": round((dt - tf) / steps * 1e3, 4), "final_flush_ms": round(tf * 1e3, 3)}
+            if B == args.batch and args.lazy_epoch_steps > 0:
+                # steady state: an "epoch" of lazy_epoch_steps steps, then the flush a fit() epoch ends with:
+                # rows no batch touched replay that many zero-gradient steps there
+                n_ep = args.lazy_epoch_steps
+                dt2, tf2 = timed_steps(r2, batches, n_ep, 0, dist, flush=model2.flush_tables)
+                lazy[B]["epoch"] = {"steps": n_ep, "ms_per_step_steps_only": round((dt2 - tf2) / n_ep * 1e3, 4),
+                                    "flush_ms": round(tf2 * 1e3, 3),
+                                    "value_incl_flush": round(B * n_ep / dt2, 1),
+                                    "note": "flush amortised over an epoch of this many steps (4 resident batches rotated: "
+                                            "the untouched rows skip every step of the epoch)"}
         del model2
 
     if dist is not None:
@@ -586,6 +598,16 @@ def main():
             pass
     if infer:
         line["inference"] = infer
+    if lazy and args.batch in lazy and "epoch" in lazy[args.batch]:
+        ep = lazy[args.batch]["epoch"]
+        line["table_update_modes"] = {
+            "dense_exact": {"value": line["value"], "ms_per_step": line["ms_per_step"],
+                            "note": "the primary `value`: the reference's literal schedule (every row of every table "
+                                    "every step)"},
+            "lazy_exact": {"value": ep["value_incl_flush"], "ms_per_step": ep["ms_per_step_steps_only"],
+                           "flush_ms": ep["flush_ms"], "epoch_steps": ep["steps"],
+                           "note": "what table_update='auto' (the default of fit() / main.run()) picks for Adam / RMSprop "
+                                   "since round 4: the same trajectory (tests: 2e-6), flush of the epoch included"}}
     if lazy:
         line["lazy_exact"] = {"note": "same dense-Adam trajectory (tests: <=2e-6 rel on parameters), table update "
                                       "restricted to the batch's rows + replay of skipped zero-gradient steps; the "

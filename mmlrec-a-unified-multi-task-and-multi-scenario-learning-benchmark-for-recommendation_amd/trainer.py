@@ -89,6 +89,9 @@ class TrainStep:
         if allreduce is None and par is not None:
             from .parallel import make_allreduce
             allreduce = make_allreduce(par)
+        if (self.opt.table_update == "lazy_exact" and getattr(self.opt, "auto", False) and par is not None and
+                par.mode == "table_wise" and self.opt.steps_done == 0 and self.opt.last is None):
+            self.opt.table_update = "dense_exact"  # ('auto' picked lazy_exact before the tables were sharded table-wise)
         lazy = self.opt.table_update == "lazy_exact"
         if lazy and par is not None and par.mode == "table_wise":
             raise NotImplementedError("lazy_exact table updates on the table-wise sharded path (use row_sharded)")
