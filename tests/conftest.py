@@ -18,7 +18,9 @@ GOLDEN_CASES = ["sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mm
                 "pepnet_amazon", "mlp_ml", "mlp_ae", "esmm_ml",
                 "cross_stitch_ae", "hmoe_ml", "aitm_ml", "snr_trans_ae",
                 "mssm_ml", "sharedbottom_bn", "mmoe_bn",
-                "mssm_bn", "cross_stitch_bn", "ple_l2", "escm_ml", "apg_ae", "star_dbn"]
+                "mssm_bn", "cross_stitch_bn", "ple_l2", "escm_ml", "apg_ae", "star_dbn",
+                # round 4: logits of +-4 (p = 0.0003 .. 0.994) and a partly SATURATED head (p exactly 0 / 1, clamped BCE)
+                "mmoe_ae30_s4", "mmoe_ae30_sat"]
 
 
 def pytest_configure(config):

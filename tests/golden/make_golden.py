@@ -56,7 +56,7 @@ B = 64
 # cases that also carry 3-step RMSprop and SGD trajectories (the two optimizers of basemodel.py:569-584 that
 # no fixture pinned)
 EXTRA_OPTIMIZER_CASES = ("sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "star_amazon",
-                         "pepnet_amazon")
+                         "pepnet_amazon", "mmoe_ae30_s4", "mmoe_ae30_sat")
 
 
 def base_config(task_name, model_name, label_columns, emb, optimizer, lr, **model_kw):
@@ -109,6 +109,12 @@ def make_cases():
     # cfg4 with dense columns (real-AE layout: sparse first then dense, data_utils.py:73-77)
     c = copy.deepcopy(c)
     cases.append(dict(name="mmoe_ae30d", cls=MMOE, cfg=c, vocab=v, nd=7, scene_last=True))
+    # every fixture's probabilities sat in 0.45-0.55.  The same model with the last tower layer scaled up:
+    # logits of +-4 (probabilities 0.02 .. 0.98), and a SATURATED variant (|logit| beyond 17 for many samples:
+    # sigmoid gives exactly 0 / 1 in fp32, the BCE's log is clamped at -100, the gradient through the head is 0 there)
+    for nm, sd in (("mmoe_ae30_s4", 2.5), ("mmoe_ae30_sat", 30.0)):
+        c2 = copy.deepcopy(c)
+        cases.append(dict(name=nm, cls=MMOE, cfg=c2, vocab=v, nd=0, scene_last=True, logit_std=sd))
     # cfg5: STAR + PepNet mtmsl / Amazon shape (configs_mtmsl/config_amazon.json)
     for nm, cls in (("star", STAR), ("pepnet", PepNet)):
         c = base_config("mtmsl", nm, ["label", "label", "label2", "label2"], 8, "adagrad", 0.01,
@@ -324,6 +330,18 @@ def run_case(case):
                 p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
             elif k.startswith("out."):
                 p.copy_(torch.randn(p.shape, generator=g2) * 0.1)
+        if case.get("logit_std"):
+            # centre and spread the logits of batch 0: logit_t' = (logit_t - mean_t) * logit_std / std_t, through the last
+            # tower layer's weight and the head's bias
+            model.eval()
+            z = torch.logit(model(X0, None).double())
+            model.train()
+            named = dict(model.named_parameters())
+            for t in range(T):
+                f = case["logit_std"] / float(z[:, t].std())
+                named[f"tower_dnn_final_layer.{t}.weight"].mul_(f)
+                b = named[f"out.{t}.bias"]
+                b.copy_((b - float(z[:, t].mean())) * f)
         if cls is STAR:
             for mods in (model.linears, model.final_layers):
                 for m in mods:

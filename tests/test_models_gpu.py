@@ -226,6 +226,14 @@ def test_fused_train_steps(case, graph, arith):
             m, c = build(g, table_update="sparse_rows")
             m.compile("adagrad", c["optim_config"]["loss"], ["auc"])
             m.train_step_runner(64, use_graph=False)
+    if name == "mmoe_ae30_sat":
+        # Half of this fixture's samples sit on a saturated head (gradient exactly 0) and the table gradients of the rest are
+        # sums of +-1e3-sized terms that cancel to rounding noise in many elements.  Adam / RMSprop / Adagrad normalise
+        # every element to an lr-sized step -- they turn the SIGN of that noise into a full step (measured: one table row
+        # of 30 off by > 5 % of its update in step 1, with every gradient inside 1e-4) -- so only SGD, whose step is
+        # proportional to the gradient, says anything here.  Forward, loss (clamped BCE) and gradients are tested above.
+        combos = tuple(c for c in combos if c[0] == "sgd")
+        assert combos
     for kind, checkpoints, tu in combos:
         model, cfg = build(g, table_update=tu)
         load_state(model, g)
@@ -236,7 +244,8 @@ def test_fused_train_steps(case, graph, arith):
         losses = []
         # models the oracle can step (no BatchNorm / unregistered tensors): every step after the first is ALSO taken by
         # the oracle from the MI355X's own state, the arbiter when the free-running comparison below trips
-        can_force = name in ("sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "pepnet_amazon")
+        can_force = name in ("sharedbottom_ml", "mmoe_kuairec", "ple_ijcai", "mmoe_ae30", "mmoe_ae30d", "pepnet_amazon",
+                             "mmoe_ae30_s4", "mmoe_ae30_sat")
         forced_ok = {}
         for i in range(3):
             X = torch.from_numpy(g[f"X{i}"]).cuda()
