@@ -278,8 +278,19 @@ typedef struct {
    * the two-plane arithmetic carries them, the kernel reads the planes instead of cutting W's fragments (same bits). */
   const uint32_t* w_planes;
   const int32_t* w_kexp;
+  /* K7, optional (PepNet: x = h (.) GateNN(.), reference model/pepnet.py:31-32, :72-78, :139-140): with mul != NULL the
+   * launch ALSO stores prod[r][c] = C[r][c] * mul[r][c] -- the gated layer input leaves the gate network's last Linear
+   * (act = MML_ACT_SIGMOID2) without a pass of its own over memory.  mul, prod: [M, N] at pitches ldmul / ldprod,
+   * 16-byte aligned, N % 4 == 0, C 16-byte aligned too; amax_prod receives the magnitude of prod.  Only on the LDS-DMA
+   * kernel (K % 16 == 0, aligned operands): other shapes return MML_ERR_UNSUPPORTED. */
+  const float* mul;
+  float* prod;
+  int64_t ldmul, ldprod;
+  uint32_t* amax_prod;
 } mml_gemm_fwd_desc;
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
+/* SURVEY 8(b) name of the K7 forward: mml_gemm_grouped_fwd restricted to descriptors that carry mul / prod. */
+int mml_pep_gate_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
 
 
 typedef struct {
@@ -308,8 +319,25 @@ typedef struct {
    * a problem cut as ONE group (one common exponent): honoured when every source of every problem of the launch has them. */
   const uint32_t* w_planes[MML_MAX_SRC];
   const int32_t* w_kexp[MML_MAX_SRC];
+  /* K7 backward, optional ("gate mode", gate_h != NULL): the problem's input is a product x = h (.) g; the input gradient
+   * v = sum_s dC_s W_s is NOT stored, the epilogue forms the gradients of the two factors from it:
+   *     d_h (+)= v * g * act_h'(h)          d_g (+)= v * h * act_g'(g)
+   * act_h / act_g: the activations that PRODUCED h / g (derivative from the outputs h, g; MML_ACT_NONE: factor 1), acc_h /
+   * acc_g: 1 = add to what d_h / d_g hold.  dA, Y, act, accumulate, relu_mask and amax_out are ignored.  gate_h, gate_g,
+   * d_h, d_g: [M, K] at pitches ld_h, ld_g, ld_dh, ld_dg, 16-byte aligned, K % 4 == 0; amax_dh / amax_dg receive the
+   * magnitudes of what was stored.  Only on the LDS-DMA kernel, like mul / prod of the forward. */
+  const float* gate_h;
+  const float* gate_g;
+  float* d_h;
+  float* d_g;
+  int64_t ld_h, ld_g, ld_dh, ld_dg;
+  int32_t act_h, act_g, acc_h, acc_g;
+  uint32_t* amax_dh;
+  uint32_t* amax_dg;
 } mml_gemm_dgrad_desc;
 int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
+/* SURVEY 8(b) name of the K7 backward: mml_gemm_grouped_dgrad restricted to gate-mode descriptors. */
+int mml_pep_gate_bwd(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
 
 /* Pre-cut weights for the two-plane fp16 arithmetic.  The GEMM kernels cut every fp32 operand fragment into its planes
  * h = rne16(x 2^k), l = rne16(x 2^k - h) in registers, once per wave that reads it; a weight matrix is read by every row

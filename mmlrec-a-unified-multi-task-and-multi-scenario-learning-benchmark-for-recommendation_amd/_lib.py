@@ -23,7 +23,8 @@ class GemmFwdDesc(C.Structure):
     _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("lda", i64), ("ldw", i64), ("ldc", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("w_kn", i32), ("pad_", i32),
                 ("relu_mask", fp), ("ldmask", i64), ("amax_a", fp), ("amax_w", fp), ("amax_out", fp),
-                ("w_planes", fp), ("w_kexp", fp)]
+                ("w_planes", fp), ("w_kexp", fp),
+                ("mul", fp), ("prod", fp), ("ldmul", i64), ("ldprod", i64), ("amax_prod", fp)]
 
 
 class AmaxDesc(C.Structure):
@@ -36,7 +37,10 @@ class GemmDgradDesc(C.Structure):
                 ("dC", fp * MAX_SRC), ("W", fp * MAX_SRC), ("lddc", i64 * MAX_SRC), ("ldw", i64 * MAX_SRC),
                 ("N", i32 * MAX_SRC), ("w_kn", i32 * MAX_SRC), ("relu_mask", fp), ("ldmask", i64),
                 ("amax_dc", fp * MAX_SRC), ("amax_w", fp * MAX_SRC), ("amax_out", fp),
-                ("w_planes", fp * MAX_SRC), ("w_kexp", fp * MAX_SRC)]
+                ("w_planes", fp * MAX_SRC), ("w_kexp", fp * MAX_SRC),
+                ("gate_h", fp), ("gate_g", fp), ("d_h", fp), ("d_g", fp),
+                ("ld_h", i64), ("ld_g", i64), ("ld_dh", i64), ("ld_dg", i64),
+                ("act_h", i32), ("act_g", i32), ("acc_h", i32), ("acc_g", i32), ("amax_dh", fp), ("amax_dg", fp)]
 
 
 class PlanesDesc(C.Structure):
@@ -137,6 +141,8 @@ _SIGS = {
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),
     "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
+    "mml_pep_gate_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
+    "mml_pep_gate_bwd": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_gemm_grouped_wgrad_workspace_bytes": (i64, [_PP(GemmWgradDesc), i32]),
     "mml_gemm_grouped_wgrad": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, fp]),
     "mml_gemm_grouped_wgrad_phase": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, i32, fp]),

@@ -67,6 +67,14 @@ struct Problem {
   float* bias_slab;    // [S][n] partial sums over the batch of dC, or null
   int64_t slab_off;    // float offset of this problem's slab in the workspace
   uint32_t* amax_out;  // fwd / dgrad: MML_AMAX_WORDS words that receive max |C| (atomic max of bit patterns), or null
+  // K7 (PepNet gate products fused into the epilogues; the kernel-argument block has no room for nine more fields per
+  // problem, so the operands travel in fields the launch kind does not use):
+  //   fwd, bias_slab != null: prod = C * mul is stored as well -- mul = Y / ldy, prod = bias_slab / slab_off (pitch),
+  //        amax_out2 = magnitude of prod;
+  //   dgrad, bias_slab != null ("gate mode"): the input gradient v of h (.) g is not stored, its two factors' gradients
+  //        are: dH (+)= v g act_h'(h) -> C / ldc (accumulate, amax_out), dG (+)= v h act_g'(g) -> bias_slab / slab_off
+  //        (accumulate = bias_cols, amax_out2); h = Y / ldy with act_h = act, g = bias / ldmask with act_g = tiles_m.
+  uint32_t* amax_out2;
 };
 
 // ---- operand magnitudes (mml_amax_*, the amax fields of the GEMM descriptors) ----
@@ -714,10 +722,12 @@ __device__ __forceinline__ float act_bwd_t(float y) {
 // BPL (EMU 2, forward / input-gradient launches): the column operand (the weights) arrives PRE-CUT -- Source::B points at
 // the plane image mml_gemm_planes_cut wrote (same shape, pitch and LDS image as the floats), Source::amaxB at the
 // exponent it was scaled with -- so its fragments are used as they land, without the in-register cut.
-template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false, bool BPL = false>
+// K7 (forward / input-gradient launches): the epilogue also handles the PepNet gate products (Problem: second output).
+// Its own instantiations: the extra operands cost registers (the plain kernels spilled with the code merely present).
+template <bool ARC, bool BRC, int BN, int EPI, int EMU, bool BCOLS = false, bool BPL = false, bool K7 = false>
 // (128 x 64 input-gradient kernels: two workgroups per CU like the wide tiles -- their epilogue (mask words, Y, the
 // accumulate target) does not fit the 168 registers three would leave)
-__global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
+__global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD && !K7) ? 3 : 2)) void gemm_pipe_kernel(const Launch Larg) {
   typedef const __attribute__((address_space(4))) Launch KLaunch;
   KLaunch& L = *(KLaunch*)__builtin_amdgcn_kernarg_segment_ptr();  // see gemm_glds_kernel
   constexpr int NI = BN / 64;
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
   constexpr int NMFMA = EMU == 0 ? 8 : (EMU == 1 ? 1 : (EMU == 2 ? 3 : 6));  // MFMAs per block
   constexpr int NVALU = EMU == 0 ? 0 : 8;  // VALU slots per MFMA of a block with one prepare (EMU 1: 4 cvt_pk)
   // + one 64-float bias slot per wave + one word per problem: the largest |output| this workgroup stored for it
-  __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256 + MML_MAX_GROUP];
+  __shared__ __attribute__((aligned(16))) float lds[PSTAGES * STG + 256 + 2 * MML_MAX_GROUP];
   const int tid = threadIdx.x;
   // wave as a SCALAR: the LDS destinations of the DMA (wave-dependent) then live in SGPRs; as a VGPR expression every
   // DMA needed v_readfirstlane -> s_mov m0 inside the loop, a VALU -> SALU hand-over that waits for the wave's MFMAs
@@ -823,6 +833,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
     c.want_bias = (EPI == EPI_SLAB) && L.p[pi].bias_slab != nullptr && (c.bias_cols ? c.row0 == 0 : c.col0 == 0);
     c.short_tile = (EPI != EPI_SLAB) && (c.nsrc == 1) && (c.kend - c.k0 < 3 * GK);
     c.counted = c.row0 + BM <= c.M && c.col0 + BN <= c.N && (EPI == EPI_SLAB || L.p[pi].vec_out != 0);
+    if (K7 && EPI != EPI_SLAB && L.p[pi].bias_slab != nullptr) c.counted = false;  // (K7 tiles store a second output: drain)
     if constexpr (EMU == 2) problem_scales(pi, c.sA, c.sB, c.inv);
     else c.sA = c.sB = c.inv = 1.f;
   };
@@ -1038,11 +1049,21 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
           for (int g = 0; g < 4; ++g) lds_landed(b4[ni][g]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // K7: a second output (see Problem)
+      float* const C2 = K7 ? L.p[pi].bias_slab : nullptr;
+      const int64_t ldc2 = L.p[pi].slab_off;
+      const bool mulf = K7 && (EPI == EPI_FWD) && C2 != nullptr;   // prod = C * mul
+      const bool gate = K7 && (EPI == EPI_DGRAD) && C2 != nullptr; // dH, dG instead of dA
+      const float* const Gm = gate ? L.p[pi].bias : nullptr;
+      const int act_g = L.p[pi].tiles_m;
+      const bool acc2 = L.p[pi].bias_cols != 0;
+      float am2 = 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int row = row0 + wm * 64 + mi * 32 + l31;
         const bool row_ok = row < PM;
         float4 y4[NI][4];
+        float4 g4[K7 ? NI : 1][4];
         uint32_t mw[NI];  // this row's mask word per 32-column group: read (dgrad) or built (fwd)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mw[ni] = 0u;
@@ -1052,7 +1073,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
             const int cg = col0 + wn * (BN / 2) + ni * 32;
             if (row_ok && cg < PN) mw[ni] = mask[(int64_t)row * ldmask + (cg >> 5)];
           }
-        } else if (EPI == EPI_DGRAD && ACT != MML_ACT_NONE) {
+        } else if ((EPI == EPI_DGRAD && ACT != MML_ACT_NONE) || mulf || gate) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -1060,6 +1081,16 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
               const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
               y4[ni][g] = (row_ok && col < PN) ? *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + col)
                                                : make_float4(0, 0, 0, 0);
+            }
+        }
+        if (gate) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int col = col0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * h;
+              g4[K7 ? ni : 0][g] = (row_ok && col < PN) ? *reinterpret_cast<const float4*>(Gm + (int64_t)row * ldmask + col)
+                                                        : make_float4(0, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1081,6 +1112,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
                 mw[ni] |= nib << (8 * g + 4 * h);
               }
             } else {
+              const float4 raw = v;  // (gate mode: the input gradient of h (.) g before h's derivative)
               if (use_mask) {
                 const uint32_t nib = mw[ni] >> (8 * g + 4 * h);
                 if (!(nib & 1u)) v.x = 0.f;
@@ -1091,6 +1123,22 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
                 v.x *= act_bwd_t<ACT>(y4[ni][g].x); v.y *= act_bwd_t<ACT>(y4[ni][g].y);
                 v.z *= act_bwd_t<ACT>(y4[ni][g].z); v.w *= act_bwd_t<ACT>(y4[ni][g].w);
               }
+              if (gate) {  // v = raw act_h'(h) so far: dH = v g; dG = raw h act_g'(g)
+                const float4 gq = g4[K7 ? ni : 0][g], hq = y4[ni][g];
+                float4 dg = make_float4(raw.x * hq.x, raw.y * hq.y, raw.z * hq.z, raw.w * hq.w);
+                if (act_g != MML_ACT_NONE) {
+                  dg.x *= act_bwd(gq.x, act_g); dg.y *= act_bwd(gq.y, act_g);
+                  dg.z *= act_bwd(gq.z, act_g); dg.w *= act_bwd(gq.w, act_g);
+                }
+                v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
+                float* const d2 = C2 + (int64_t)row * ldc2 + col;
+                if (acc2) {
+                  const float4 o = *reinterpret_cast<const float4*>(d2);
+                  dg.x += o.x; dg.y += o.y; dg.z += o.z; dg.w += o.w;
+                }
+                *reinterpret_cast<float4*>(d2) = dg;
+                am2 = fmaxf(fmaxf(am2, fabsf(dg.x)), fmaxf(fabsf(dg.y), fmaxf(fabsf(dg.z), fabsf(dg.w))));
+              }
               if (accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(dst);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -1098,6 +1146,12 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
             }
             *reinterpret_cast<float4*>(dst) = v;
             am_f = fmaxf(fmaxf(am_f, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+            if (mulf) {  // prod = C * mul
+              const float4 mq = y4[ni][g];
+              const float4 pr = make_float4(v.x * mq.x, v.y * mq.y, v.z * mq.z, v.w * mq.w);
+              *reinterpret_cast<float4*>(C2 + (int64_t)row * ldc2 + col) = pr;
+              am2 = fmaxf(fmaxf(am2, fabsf(pr.x)), fmaxf(fabsf(pr.y), fmaxf(fabsf(pr.z), fabsf(pr.w))));
+            }
           }
         if (EPI == EPI_FWD && mask) {  // the two half-waves hold the odd / even 4-column groups of the same rows
 #pragma unroll
@@ -1107,6 +1161,11 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
             if (h == 0 && row_ok && cg < PN) mask[(int64_t)row * ldmask + (cg >> 5)] = w;
           }
         }
+      }
+      if ((mulf || gate) && L.p[pi].amax_out2) {  // (like am_f: the workgroup's word of the problem, second set)
+        const uint32_t a2 = lds0 + (uint32_t)(PSTAGES * STG + 256 + MML_MAX_GROUP + pi) * 4u;
+        const uint32_t am2_bits = __float_as_uint(am2);
+        asm volatile("ds_max_u32 %0, %1" ::"v"(a2), "v"(am2_bits) : "memory");
       }
     } else if (vec) {
       // Each 32 x 32 sub-tile is turned row-major through this wave's 4 KiB of the stage buffer the step just consumed
@@ -1128,12 +1187,31 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
           y[p] = ok ? *reinterpret_cast<const float4*>(Y + (int64_t)(rowb + 8 * p) * ldy + colg) : make_float4(0, 0, 0, 0);
         }
       };
-      const bool USE_Y = (EPI == EPI_DGRAD) && (ACT != MML_ACT_NONE) && !use_mask;
+      // K7: a second output (see Problem)
+      float* const C2 = (K7 && EPI != EPI_SLAB) ? L.p[pi].bias_slab : nullptr;
+      const int64_t ldc2 = L.p[pi].slab_off;
+      const bool mulf = K7 && (EPI == EPI_FWD) && C2 != nullptr;   // prod = C * mul
+      const bool gate = K7 && (EPI == EPI_DGRAD) && C2 != nullptr; // dH, dG instead of dA
+      const float* const Gm = gate ? L.p[pi].bias : nullptr;
+      const int64_t ldg = ldmask;
+      const int act_g = L.p[pi].tiles_m;
+      const bool acc2 = L.p[pi].bias_cols != 0;
+      float am2 = 0.f;
+      const bool USE_Y = ((EPI == EPI_DGRAD) && (ACT != MML_ACT_NONE) && !use_mask) || gate;
+      float4 g4[4];
 #pragma unroll
       for (int sidx = 0; sidx < 2 * NI; ++sidx) {
         const int mi = sidx / NI, ni = sidx % NI;
         {
           if (USE_Y) load_y(sidx, y4);  // in flight during the LDS round trip
+          if (gate) {
+            const int colg_ = col0 + wn * (BN / 2) + ni * 32 + 4 * cc, rowb_ = row0 + wm * 64 + mi * 32 + R;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              g4[p] = (rowb_ + 8 * p < PM && colg_ < PN)
+                          ? *reinterpret_cast<const float4*>(Gm + (int64_t)(rowb_ + 8 * p) * ldg + colg_)
+                          : make_float4(0, 0, 0, 0);
+          }
           const int colg = col0 + wn * (BN / 2) + ni * 32 + 4 * cc;  // this lane's 4 columns
           const int rowb = row0 + wm * 64 + mi * 32 + R;             // ... of rows rowb + 8p
           uint32_t mw[4];  // mask word of row rowb + 8p (all eight lanes of a row read / build the same word)
@@ -1163,7 +1241,9 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             f32x4_t& x = v[p];
-            if (EPI == EPI_FWD) {
+            if (gate) {
+              // (gate mode: both gradients are formed from the raw input gradient in the store loop below)
+            } else if (EPI == EPI_FWD) {
               x.x = act_fwd_t<ACT>(x.x + b4.x); x.y = act_fwd_t<ACT>(x.y + b4.y);
               x.z = act_fwd_t<ACT>(x.z + b4.z); x.w = act_fwd_t<ACT>(x.w + b4.w);
             } else if (use_mask) {
@@ -1206,9 +1286,30 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
             const int row = rowb + 8 * p;
             if (row >= PM || colg >= PN) continue;
             float4 x = make_float4(v[p].x, v[p].y, v[p].z, v[p].w);
-            if (EPI == EPI_DGRAD && accumulate) {  // (rare: outputs summed over more than MML_MAX_SRC sources)
+            if (EPI == EPI_DGRAD && accumulate && !gate) {  // (rare: outputs summed over more than MML_MAX_SRC sources)
               const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
               x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+            }
+            if (gate) {  // x = the raw input gradient v of h (.) g: dG = v h act_g'(g), dH = v g act_h'(h)
+              const float4 gq = g4[p], hq = y4[p];
+              float4 dg = make_float4(x.x * hq.x, x.y * hq.y, x.z * hq.z, x.w * hq.w);
+              if (act_g != MML_ACT_NONE) {
+                dg.x *= act_bwd(gq.x, act_g); dg.y *= act_bwd(gq.y, act_g);
+                dg.z *= act_bwd(gq.z, act_g); dg.w *= act_bwd(gq.w, act_g);
+              }
+              x.x *= gq.x * act_bwd_t<ACT>(hq.x); x.y *= gq.y * act_bwd_t<ACT>(hq.y);
+              x.z *= gq.z * act_bwd_t<ACT>(hq.z); x.w *= gq.w * act_bwd_t<ACT>(hq.w);
+              if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(C + (int64_t)row * ldc + colg);
+                x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+              }
+              float* const d2 = C2 + (int64_t)row * ldc2 + colg;
+              if (acc2) {
+                const float4 o = *reinterpret_cast<const float4*>(d2);
+                dg.x += o.x; dg.y += o.y; dg.z += o.z; dg.w += o.w;
+              }
+              *reinterpret_cast<float4*>(d2) = dg;
+              am2 = fmaxf(fmaxf(am2, fabsf(dg.x)), fmaxf(fabsf(dg.y), fmaxf(fabsf(dg.z), fabsf(dg.w))));
             }
             // (nontemporal, MMLREC_GEMM_NT=1 at build time: the output is read next by another kernel, long after the
             // line has left the L2 -- the panel kernel gained 4 % from it)
@@ -1218,8 +1319,19 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
             *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;
 #endif
             am_f = fmaxf(fmaxf(am_f, fabsf(x.x)), fmaxf(fabsf(x.y), fmaxf(fabsf(x.z), fabsf(x.w))));
+            if (mulf) {  // prod = C * mul (mul is read here, piece by piece: its registers are not held across the turn)
+              const float4 mq = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + colg);
+              const float4 pr = make_float4(x.x * mq.x, x.y * mq.y, x.z * mq.z, x.w * mq.w);
+              *reinterpret_cast<float4*>(C2 + (int64_t)row * ldc2 + colg) = pr;
+              am2 = fmaxf(fmaxf(am2, fabsf(pr.x)), fmaxf(fabsf(pr.y), fmaxf(fabsf(pr.z), fabsf(pr.w))));
+            }
           }
         }
+      }
+      if ((mulf || gate) && L.p[pi].amax_out2) {  // (like am_f below: the workgroup's word of the problem, second set)
+        const uint32_t a2 = lds0 + (uint32_t)(PSTAGES * STG + 256 + MML_MAX_GROUP + pi) * 4u;
+        const uint32_t am2_bits = __float_as_uint(am2);
+        asm volatile("ds_max_u32 %0, %1" ::"v"(a2), "v"(am2_bits) : "memory");
       }
     } else {  // unaligned / odd-width outputs: element-wise
 #pragma unroll  // (full unroll: run-time indices would put the accumulators in scratch)
@@ -1305,7 +1417,7 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
   RawFrag<ARC> RA1[2];
   RawFrag<BRC> RB1[2];
 
-  if (EPI != EPI_SLAB && tid < MML_MAX_GROUP) {  // (ordered before the first epilogue by the barriers of the k-steps)
+  if (EPI != EPI_SLAB && tid < 2 * MML_MAX_GROUP) {  // (ordered before the first epilogue by the barriers of the k-steps)
     const uint32_t a = lds0 + (uint32_t)(PSTAGES * STG + 256 + tid) * 4u;
     const uint32_t z = 0u;
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(z) : "memory");
@@ -1512,6 +1624,13 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD) ? 3 : 2)) void
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
         if (v) atomicMax(amo + (blockIdx.x & (MML_AMAX_WORDS - 1)), v);
       }
+      uint32_t* const amo2 = K7 ? L.p[tid].amax_out2 : nullptr;  // (K7: the second output's magnitude)
+      if (amo2) {
+        const uint32_t a = lds0 + (uint32_t)(PSTAGES * STG + 256 + MML_MAX_GROUP + tid) * 4u;
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        if (v) atomicMax(amo2 + (blockIdx.x & (MML_AMAX_WORDS - 1)), v);
+      }
     }
   }
 }
@@ -1575,7 +1694,8 @@ static void note_kernel(const char* fam, bool arc, bool brc, int bn, int epi, in
 // (mml_gemm_planes_cut); used when EVERY source has them and the launch runs the two-plane arithmetic on the LDS-DMA path
 template <int EPI>
 static int launch_tiles(const Launch& Lin, bool arc, bool brc, TileChoice tc, int64_t nblocks, hipStream_t st,
-                        const char* who, const uint32_t* const* planes = nullptr, const int32_t* const* kexps = nullptr) {
+                        const char* who, const uint32_t* const* planes = nullptr, const int32_t* const* kexps = nullptr,
+                        bool k7 = false) {
   Launch Lcopy;
   const Launch* Lp = &Lin;
   const int bn = tc.bn;
@@ -1639,7 +1759,7 @@ static int launch_tiles(const Launch& Lin, bool arc, bool brc, TileChoice tc, in
         n = 256;
       cus = n;
     }
-    const int64_t slots = (int64_t)cus * ((bn == 64 && EPI != EPI_DGRAD) ? 3 : 2);
+    const int64_t slots = (int64_t)cus * ((bn == 64 && EPI != EPI_DGRAD && !k7) ? 3 : 2);
     if (nblocks > slots) g = dim3((unsigned)slots);
 #ifdef MML_LAB  // ablation builds (tools/lab): one tile width / arithmetic only, to keep compile times short
 #define MML_GL(A_, B_)                                                                                            \
@@ -1651,6 +1771,18 @@ static int launch_tiles(const Launch& Lin, bool arc, bool brc, TileChoice tc, in
 #else
 #define MML_GL3(A_, B_, N_, C_)                                                              \
   do {                                                                                       \
+    /* (nn.Linear weights [N, K] only; gate mode on 128 x 64 tiles only: h, g and both gradients of a 128-wide */ \
+    /* tile do not fit the registers next to the accumulators -- the host picks the narrow tiles for it)       */ \
+    if constexpr (EPI != EPI_SLAB && ((EPI == EPI_FWD) == (B_)) && (EPI == EPI_FWD || N_ == 64)) {                 \
+      if (k7) { /* (the two-plane and three-plane forms only: what the engine runs) */            \
+        if (emu == 2 && bpl) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2, false, true, true>), g, b, dyn, st, L);  \
+        else if (emu == 2) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 2, false, false, true>), g, b, dyn, st, L);   \
+        else if (emu == 3) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 3, false, false, true>), g, b, dyn, st, L);   \
+        else { set_error("%s: the K7 products run on the plane-emulated GEMM forms only", who); return MML_ERR_UNSUPPORTED; } \
+        break;                                                                                    \
+      }                                                                                           \
+    }                                                                                             \
+    if (k7) { set_error("%s: the K7 products need nn.Linear weights ([N, K])", who); return MML_ERR_UNSUPPORTED; }  \
     if (emu == 0) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 0, C_>), g, b, dyn, st, L);       \
     else if (emu == 1) MML_LAUNCH((gemm_pipe_kernel<A_, B_, N_, EPI, 1, C_>), g, b, dyn, st, L);  \
     else if (emu == 2 && bpl)                                                                     \
@@ -1818,6 +1950,7 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     int j = i;
     int32_t Ns[MML_MAX_GROUP];
     Launch L{};
+    bool any_k7 = false;
     const uint32_t* planes[MAX_SOURCES] = {};
     const int32_t* kexps[MAX_SOURCES] = {};
     while (j < n && j - i < MML_MAX_GROUP && d[j].w_kn == d[i].w_kn && d[j].M == d[i].M) {
@@ -1840,6 +1973,14 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       MML_REQUIRE(!q.relu_mask || q.ldmask * 32 >= q.N, "mml_gemm_grouped_fwd: ldmask too small in problem %d", j);
       P.mask = (q.act == MML_ACT_RELU) ? q.relu_mask : nullptr; P.ldmask = q.ldmask;
       P.vec_out = (vec_ok(q.C, q.ldc) && q.N % 4 == 0 && (!q.bias || aligned16(q.bias))) ? 1 : 0;
+      if (q.mul || q.prod) {  // K7: prod = C * mul from the same epilogue (see Problem)
+        MML_REQUIRE(q.mul && q.prod && q.ldmul >= q.N && q.ldprod >= q.N,
+                    "mml_gemm_grouped_fwd: problem %d needs both mul and prod, with pitches >= N", j);
+        MML_REQUIRE(P.vec_out && vec_ok(q.mul, q.ldmul) && vec_ok(q.prod, q.ldprod),
+                    "mml_gemm_grouped_fwd: mul / prod of problem %d need 16-byte aligned operands and N %% 4 == 0", j);
+        P.Y = q.mul; P.ldy = q.ldmul; P.bias_slab = q.prod; P.slab_off = q.ldprod; P.amax_out2 = q.amax_prod;
+        any_k7 = true;
+      }
       Ns[j - i] = q.N;
       ++j;
     }
@@ -1856,8 +1997,12 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     }
     L.total_ntiles = t;
     L.tiles_m = (int)cdiv(d[i].M, BM);
+    if (any_k7 && !pipe_ok(L, true, d[i].w_kn == 0, bn, EPI_FWD)) {
+      set_error("mml_gemm_grouped_fwd: mul / prod need the LDS-DMA kernel (K %% 16 == 0, 16-byte aligned operands)");
+      return MML_ERR_UNSUPPORTED;
+    }
     int rc = launch_tiles<EPI_FWD>(L, true, d[i].w_kn == 0, tc, (int64_t)L.tiles_m * t, to_stream(stream),
-                                   "mml_gemm_grouped_fwd", planes, kexps);
+                                   "mml_gemm_grouped_fwd", planes, kexps, any_k7);
     if (rc) return rc;
     i = j;
   }
@@ -1873,11 +2018,12 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     Launch L{};
     const int32_t lay = d[i].n_src > 0 ? d[i].w_kn[0] : 0;
     int nsources = 0;
+    bool any_k7 = false;
     const uint32_t* planes[MAX_SOURCES] = {};
     const int32_t* kexps[MAX_SOURCES] = {};
     while (j < n && j - i < MML_MAX_GROUP && d[j].M == d[i].M) {
       const mml_gemm_dgrad_desc& q = d[j];
-      MML_REQUIRE(q.dA && q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", j);
+      MML_REQUIRE((q.dA || q.gate_h) && q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", j);
       MML_REQUIRE(q.M >= 0 && q.K > 0 && q.ldda >= q.K, "mml_gemm_grouped_dgrad: bad sizes in problem %d", j);
       MML_REQUIRE(q.act == MML_ACT_NONE || q.Y || q.relu_mask, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", j);
       bool same = true;
@@ -1904,6 +2050,21 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
       P.mask = const_cast<uint32_t*>(q.relu_mask); P.ldmask = q.ldmask;
       P.vec_out = (vec_ok(q.dA, q.ldda) && q.K % 4 == 0 && (!q.Y || vec_ok(q.Y, q.ldy))) ? 1 : 0;
       P.accumulate = q.accumulate;
+      if (q.gate_h) {  // K7 backward: the gradients of the two factors of the gated input (see Problem)
+        MML_REQUIRE(q.gate_g && q.d_h && q.d_g && q.ld_h >= q.K && q.ld_g >= q.K && q.ld_dh >= q.K && q.ld_dg >= q.K,
+                    "mml_gemm_grouped_dgrad: gate mode of problem %d needs gate_g, d_h, d_g and pitches >= K", j);
+        MML_REQUIRE(q.K % 4 == 0 && vec_ok(q.gate_h, q.ld_h) && vec_ok(q.gate_g, q.ld_g) && vec_ok(q.d_h, q.ld_dh) &&
+                        vec_ok(q.d_g, q.ld_dg),
+                    "mml_gemm_grouped_dgrad: gate mode of problem %d needs 16-byte aligned operands and K %% 4 == 0", j);
+        P.C = q.d_h; P.ldc = q.ld_dh; P.Y = q.gate_h; P.ldy = q.ld_h; P.act = q.act_h; P.accumulate = q.acc_h;
+        P.mask = nullptr; P.ldmask = q.ld_g;  // (ldmask carries the pitch of g in gate mode)
+        P.bias = q.gate_g; P.bias_slab = q.d_g; P.slab_off = q.ld_dg; P.tiles_m = q.act_g; P.bias_cols = q.acc_g;
+        P.amax_out = q.amax_dh; P.amax_out2 = q.amax_dg;
+        P.vec_out = 1;
+        any_k7 = true;
+      } else {
+        MML_REQUIRE(q.dA, "mml_gemm_grouped_dgrad: problem %d has no dA", j);
+      }
       Ns[j - i] = q.K;
       ++j;
     }
@@ -1914,7 +2075,8 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
       for (int s2 = 0; s2 < L.p[k].nsrc; ++s2) sum += L.src[L.p[k].src0 + s2].Kred;
       kred = sum > kred ? sum : kred;
     }
-    const TileChoice tc = pick_tiles(Ns, L.n, 1, kred, cdiv(d[i].M, BM));
+    TileChoice tc = pick_tiles(Ns, L.n, 1, kred, cdiv(d[i].M, BM));
+    if (any_k7) tc.bn = 64;  // (gate mode: see launch_tiles)
     const int bn = tc.bn;
     int t = 0;
     for (int k = 0; k < L.n; ++k) {
@@ -1924,13 +2086,29 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     }
     L.total_ntiles = t;
     L.tiles_m = (int)cdiv(d[i].M, BM);
+    if (any_k7 && !pipe_ok(L, true, lay == 1, bn, EPI_DGRAD)) {
+      set_error("mml_gemm_grouped_dgrad: gate mode needs the LDS-DMA kernel (N_s %% 16 == 0, 16-byte aligned operands)");
+      return MML_ERR_UNSUPPORTED;
+    }
     // col operand = W: reduction index is W's row for [N,K] (not contiguous) and contiguous for [K,N]
     int rc = launch_tiles<EPI_DGRAD>(L, true, lay == 1, tc, (int64_t)L.tiles_m * t, to_stream(stream),
-                                     "mml_gemm_grouped_dgrad", planes, kexps);
+                                     "mml_gemm_grouped_dgrad", planes, kexps, any_k7);
     if (rc) return rc;
     i = j;
   }
   return MML_OK;
+}
+
+extern "C" int mml_pep_gate_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_pep_gate_fwd: bad descriptor array");
+  for (int i = 0; i < n; ++i) MML_REQUIRE(d[i].mul && d[i].prod, "mml_pep_gate_fwd: problem %d carries no mul / prod", i);
+  return mml_gemm_grouped_fwd(d, n, stream);
+}
+
+extern "C" int mml_pep_gate_bwd(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_pep_gate_bwd: bad descriptor array");
+  for (int i = 0; i < n; ++i) MML_REQUIRE(d[i].gate_h, "mml_pep_gate_bwd: problem %d is not in gate mode", i);
+  return mml_gemm_grouped_dgrad(d, n, stream);
 }
 
 // wgrad planning shared by the workspace query and the launch

@@ -623,6 +623,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
   int halves = 0, masks = 0, relus = 0;
   for (int i = 0; i < n; ++i) {
     const mml_gemm_fwd_desc& q = d[i];
+    if (q.mul || q.prod) return MML_ERR_UNSUPPORTED;  // (K7 products: the tile kernel's epilogue)
     if (q.A != d0.A || q.lda != d0.lda || q.M != d0.M || q.K != d0.K || q.amax_a != d0.amax_a) return MML_ERR_UNSUPPORTED;
     if (q.w_kn != 0 || !q.w_planes || !q.w_kexp || !aligned16(q.w_planes) || q.ldw % 4 != 0) return MML_ERR_UNSUPPORTED;
     if (q.N % 64 != 0 || q.N < 64) return MML_ERR_UNSUPPORTED;

@@ -585,16 +585,23 @@ def _kpad_of(q):
 
 class LinearGroupOp(Op):
     """K3: a set of independent Linear(+activation) problems launched together.
-    problems: dicts with x (Val), W (PVal), b (PVal or None), out (Val; out.act is the activation), w_kn."""
+    problems: dicts with x (Val), W (PVal), b (PVal or None), out (Val; out.act is the activation), w_kn.
+    K7 (PepNet, reference model/pepnet.py:72-78, :139-140): a problem may also carry mul (Val) and prod (Val) -- the launch
+    then stores prod = out * mul from the same epilogue (mml_gemm_fwd_desc.mul / prod), and the product's backward is
+    folded into the input-gradient launch of the layer that READS prod (gate mode of mml_gemm_grouped_dgrad): neither
+    direction makes a pass of its own over memory.  prod must feed exactly one LinearGroupOp."""
 
     def __init__(self, problems):
         self.p = problems
+        for q in self.p:
+            if q.get("mul") is not None:
+                q["prod"].gate = (q["mul"], q["out"])  # (h, g): factors of the product, for the consumer's dgrad
 
     def inputs(self):
-        return [q["x"] for q in self.p]
+        return [q["x"] for q in self.p] + [q["mul"] for q in self.p if q.get("mul") is not None]
 
     def outputs(self):
-        return [q["out"] for q in self.p]
+        return [q["out"] for q in self.p] + [q["prod"] for q in self.p if q.get("mul") is not None]
 
     def fwd_calls(self, plan):
         # training plans: a ReLU output also leaves its sign bits (1 bit per element) for the dgrad that will apply
@@ -621,6 +628,8 @@ class LinearGroupOp(Op):
             q["amax_w"] = plan.weight_amax(q["W"], q.get("Wp", q["W"].data), need)
             if q["out"].amax is None:
                 q["out"].amax = plan.new_amax()
+            if q.get("mul") is not None and q["prod"].amax is None:
+                q["prod"].amax = plan.new_amax()
         if need:
             pre.append(plan.amax_call(need))
         # pre-cut weights: all problems of the launch or none (the kernel takes the planes form per launch)
@@ -631,7 +640,10 @@ class LinearGroupOp(Op):
                                          bias=q["b"].data if q.get("b") else None,
                                          C=q["out"].buf, act=q["out"].act, w_kn=q.get("w_kn", 0),
                                          mask=q["out"].mask, amax_a=q["amax_a"], amax_w=q["amax_w"],
-                                         amax_out=q["out"].amax, w_planes=pl, w_kexp=kx)
+                                         amax_out=q["out"].amax, w_planes=pl, w_kexp=kx,
+                                         mul=q["mul"].buf if q.get("mul") is not None else None,
+                                         prod=q["prod"].buf if q.get("mul") is not None else None,
+                                         amax_prod=q["prod"].amax if q.get("mul") is not None else None)
                                     for q, (pl, kx) in zip(self.p, wp)])
         plan.keep.append(descs)
         kn = self.p[0].get("w_kn", 0)
@@ -699,9 +711,47 @@ class LinearGroupOp(Op):
                 by_x.setdefault(id(q["x"]), (q["x"], []))[1].append(q)
         waves = []  # chunk k of every input goes into launch k: chunks of ONE input must not run concurrently
         post = []   # sums of split input gradients, after the launches
+        gate_wave = {}  # K7: id(factor value) -> last launch that writes its gradient
         for x, qs in by_x.values():
-            plan.grad_of(x)
             chunks = [qs[i:i + L.MAX_SRC] for i in range(0, len(qs), L.MAX_SRC)]
+            gate = getattr(x, "gate", None)
+            if gate is not None:
+                # K7: x = h (.) g was written by the epilogue of the GEMM that produced g; its gradient is not stored,
+                # this launch writes the gradients of the two factors (gate mode)
+                if len(chunks) != 1 or len(x.consumers) != 1 or x.kpad:
+                    raise L.MMLError("a fused gate product must feed exactly one Linear group (<= MAX_SRC layers)")
+                h, g = gate
+                gd = dict(h=h.buf, g=g.buf)
+                for key, v, nc in (("h", h, 1), ("g", g, 0)):
+                    gv = plan.grad_of(v)
+                    acc = _claim(v)
+                    fold = (not acc and v.act != L.ACT_NONE and not v.deriv_applied and len(v.consumers) == nc)
+                    if fold:
+                        v.deriv_applied = True
+                    slot = None
+                    if plan.amax_pool is not None:
+                        if v.gamax is None:
+                            v.gamax = plan.new_amax()
+                        if v.gamax_writers == v.written - 1:
+                            v.gamax_writers += 1
+                            slot = v.gamax
+                    gd.update({"d" + key: gv, "act_" + key: v.act if fold else L.ACT_NONE, "acc_" + key: acc,
+                               "amax_d" + key: slot})
+                ch = chunks[0]
+                gp = [plan.weight_planes(q, ops.PLANES_COLS, ch) for q in ch]
+                if any(pl is None for pl, _ in gp):
+                    gp = [(None, None)] * len(ch)
+                # products that share a factor (the gated input feeds every task's first product) write the SAME
+                # gradient buffer, the first overwriting, the others adding: they must not run in one launch
+                wi = max(gate_wave.get(id(h), -1), gate_wave.get(id(g), -1)) + 1
+                gate_wave[id(h)] = gate_wave[id(g)] = wi
+                while len(waves) <= wi:
+                    waves.append([])
+                waves[wi].append(dict(dA=gd["dh"], gate=gd, Y=None, act=L.ACT_NONE, mask=None, accumulate=0,
+                                     srcs=[(q["out"].grad, q["W"].data, q.get("w_kn", 0), q["amax_dc"], q["amax_w"]) +
+                                           ((pl, kx) if pl is not None else ()) for q, (pl, kx) in zip(ch, gp)]))
+                continue
+            plan.grad_of(x)
             fuse = len(chunks) == 1 and len(x.consumers) == 1 and x.act != L.ACT_NONE
             # Small batches: an input fed by many layers (dnn_input: every expert and gate) is ONE problem with a long
             # reduction -- 128 tiles of 72 k-steps at B = 4 096 on AE-30, 41 us on a chip with 256 CUs.  Its sources are

@@ -71,26 +71,52 @@ class PepNet(BaseModel):
         self.out = nn.ModuleList([PredictionLayer(task) for task in self.task_types])
         self.to(device)
 
-    def _gate_nn(self, plan, store, prefix, gin_vals):
-        """Two grouped launches for a list of (prefix, input value) gate networks: Linear+ReLU then Linear+2*sigmoid."""
-        l1, l2 = [], []
+    def _gate_hidden(self, plan, store, gin_vals):
+        """First layer (Linear + ReLU) of a list of (prefix, input value) gate networks as ONE grouped launch."""
+        l1 = []
         for pfx, gin in gin_vals:
             w0 = store.pvals[f"{pfx}.gate.0.weight"]
             h = plan.val(w0.data.shape[0], act=L.ACT_RELU, name=pfx + ".h", pad_k=True)
             l1.append(dict(x=gin, W=w0, b=store.pvals[f"{pfx}.gate.0.bias"], out=h))
+        plan.add(E.LinearGroupOp(l1))
+        return [q["out"] for q in l1]
+
+    def _gate_out(self, plan, store, items, fuse):
+        """Second layer (Linear + 2 * sigmoid) of gate networks and the products x (.) gate (reference pepnet.py:31-32,
+        :72-78): items = (prefix, gate hidden value, x value, product value).  fuse: K7 -- the product leaves the GEMM's
+        epilogue (mml_pep_gate_fwd) and its backward rides on the input-gradient launch of the layer that reads it
+        (mml_pep_gate_bwd); else one batched element-wise launch each way (the product feeds the heads)."""
+        l2 = []
+        for pfx, hg, x, prod in items:
             w2 = store.pvals[f"{pfx}.gate.2.weight"]
             g = plan.val(w2.data.shape[0], act=L.ACT_SIGMOID2, name=pfx + ".g", pad_k=True)
-            l2.append(dict(x=h, W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g))
-        plan.add(E.LinearGroupOp(l1))
+            q = dict(x=hg, W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g)
+            if fuse:
+                q.update(mul=x, prod=prod)
+            l2.append(q)
         plan.add(E.LinearGroupOp(l2))
-        return [q["out"] for q in l2]
+        if not fuse:
+            plan.add(E.MulBatchOp([(x, q["out"], prod) for (pfx, hg, x, prod), q in zip(items, l2)]))
 
     def _build_graph(self, plan, store, x0):
+        import os
         Edim = self.embedding_size
         K0 = x0.n
         T, nl = self.num_tasks, len(self.dnn_hidden_units)
         p = self.scene_index[0]  # column offset used as list position (reference pepnet.py:97, :126)
         scene = x0.buf[:, p * Edim:(p + 1) * Edim]
+        # K7 fusion needs operands the LDS-DMA GEMM can take as 16-byte vectors (MMLREC_PEP_FUSE=0: the batched
+        # element-wise products of round 2)
+        # MMLREC_PEP_FUSE=1: K7 -- the products of the hidden PPNet layers leave the gate GEMM's epilogue and their backward
+        # rides on the input-gradient launch of the layer that reads them.  OFF by default: measured on Amazon-8 at
+        # B = 65 536 (DESIGN 10.13) it is level with the batched element-wise products (2.33 against 2.34 ms): what the
+        # products lose (0.58 -> 0.28 ms) the GEMMs give back -- their epilogues load the extra operands (the LDS-DMA
+        # pipeline drains at every tile) and the gate mode only fits 128 x 64 tiles.  Fusing the forward alone is a loss
+        # (2.58 ms: the activation derivatives no longer fold into a single consumer).
+        fuse_on = os.environ.get("MMLREC_PEP_FUSE", "0") == "1" and plan.device.type == "cuda"
+
+        def can_fuse(n):
+            return fuse_on and n % 16 == 0
 
         def gate_input(src_val, name):
             # (zero-padded rows: K0 + E is rarely a multiple of the GEMM's 16-wide k-step, e.g. 64 + 8)
@@ -99,19 +125,24 @@ class PepNet(BaseModel):
             plan.add(E.CopyColsOp(scene, v.buf[:, K0:]))
             return v
 
-        fg = self._gate_nn(plan, store, "feature_gate", [("feature_gate", gate_input(x0, "epnet_in"))])[0]
+        # EPNet: the feature gate on the input
+        fh = self._gate_hidden(plan, store, [("feature_gate", gate_input(x0, "epnet_in"))])[0]
         x2 = plan.val(K0, name="gated_input", pad_k=True)
-        plan.add(E.MulBatchOp([(fg, x0, x2)]))
+        # (not fused: the gated input feeds the tasks' first PRODUCTS, not a Linear layer whose input-gradient launch
+        # could carry its backward)
+        self._gate_out(plan, store, [("feature_gate", fh, x0, x2)], fuse=False)
         gin = gate_input(x2, "ppnet_in")
-        gws = self._gate_nn(plan, store, "ppn", [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T)
-                                                 for l in range(nl + 1)])
+        # PPNet: the hidden layers of ALL gate networks read the same input: one grouped launch
+        ghs = self._gate_hidden(plan, store, [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T) for l in range(nl + 1)])
         hidden = [x2] * T
         heads = []
         for l in range(nl + 1):
-            # the gate products of all tasks of this layer: one launch each way (K7 batched, not fused into the GEMMs:
-            # DESIGN 10)
             hins = [plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True) for t in range(T)]
-            plan.add(E.MulBatchOp([(hidden[t], gws[t * (nl + 1) + l], hins[t]) for t in range(T)]))
+            # the gate products of all tasks of this layer: fused into the gates' output GEMM where the product feeds a
+            # Linear layer (l < nl), one batched launch each way in front of the heads
+            fuse = l < nl and all(can_fuse(hidden[t].n) for t in range(T))  # (the last product feeds the heads)
+            self._gate_out(plan, store, [(f"ppn.{t}.gate_layers.{l}", ghs[t * (nl + 1) + l], hidden[t], hins[t])
+                                         for t in range(T)], fuse=fuse)
             if l < nl:
                 probs = [dict(x=hins[t], W=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.weight"],
                               b=store.pvals[f"ppn.{t}.mlp_layers.{l}.0.bias"],

@@ -280,6 +280,10 @@ def make_fwd_descs(problems):
         d.ldmask = _ld(m) if m is not None else 0
         d.amax_a, d.amax_w, d.amax_out = L.ptr(p.get("amax_a")), L.ptr(p.get("amax_w")), L.ptr(p.get("amax_out"))
         d.w_planes, d.w_kexp = L.ptr(p.get("w_planes")), L.ptr(p.get("w_kexp"))  # pre-cut weight (planes_cut)
+        mul, prod = p.get("mul"), p.get("prod")  # K7: prod = C * mul from the same epilogue
+        if mul is not None:
+            d.mul, d.prod, d.ldmul, d.ldprod = mul.data_ptr(), prod.data_ptr(), _ld(mul), _ld(prod)
+            d.amax_prod = L.ptr(p.get("amax_prod"))
     return arr
 
 
@@ -369,8 +373,14 @@ def make_dgrad_descs(problems):
     """problems: dicts with dA [M,K], Y (or None), act, accumulate, srcs = [(dC [M,N], W, w_kn), ...]."""
     arr = (L.GemmDgradDesc * len(problems))()
     for d, p in zip(arr, problems):
-        dA = p["dA"]
-        d.dA = dA.data_ptr()
+        gate = p.get("gate")  # K7 backward: dict(h, g, dh, dg, act_h, act_g, acc_h, acc_g[, amax_dh, amax_dg]); no dA
+        if gate is not None:
+            d.gate_h, d.gate_g, d.d_h, d.d_g = (gate[k].data_ptr() for k in ("h", "g", "dh", "dg"))
+            d.ld_h, d.ld_g, d.ld_dh, d.ld_dg = (_ld(gate[k]) for k in ("h", "g", "dh", "dg"))
+            d.act_h, d.act_g, d.acc_h, d.acc_g = (int(gate[k]) for k in ("act_h", "act_g", "acc_h", "acc_g"))
+            d.amax_dh, d.amax_dg = L.ptr(gate.get("amax_dh")), L.ptr(gate.get("amax_dg"))
+        dA = p["dA"] if gate is None else gate["dh"]
+        d.dA = dA.data_ptr() if gate is None else None
         Y = p.get("Y")
         d.Y = L.ptr(Y)
         d.ldda = _ld(dA)
