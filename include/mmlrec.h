@@ -344,8 +344,10 @@ int mml_pep_gate_bwd(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t s
  * tile of the batch, so it can be cut ONCE per step instead: `planes` has W's shape and pitch and holds, per aligned
  * block of 16 values along the reduction, the 32 bytes of h and the 32 bytes of l in the order the kernel's fragment
  * reads deliver them (so the planes travel through the same LDS image as the floats would).
- *   MML_PLANES_ROWS: the reduction runs along a ROW of W ([N, K] read by the forward: K % 16 == 0, or any K with ldp);
- *   MML_PLANES_COLS: the reduction runs down the ROWS of W ([N, K] read by the input gradient: N % 16 == 0).
+ *   MML_PLANES_ROWS: the reduction runs along a ROW of W ([N, K] read by the forward: K % 16 == 0, or any K with ldp;
+ *                    a [K, N] matrix (w_kn = 1) read by the input gradient);
+ *   MML_PLANES_COLS: the reduction runs down the ROWS of W ([N, K] read by the input gradient: N % 16 == 0; a [K, N]
+ *                    matrix read by the forward).
  * k = the largest exponent that keeps every |w| 2^k below 2^15 for the LARGEST of the n_amax magnitude slots given
  * (the weights that feed one input-gradient problem share their exponent); it is written to *kexp.  Bit-identical to
  * the in-kernel cut with the same magnitudes. */
@@ -366,8 +368,20 @@ typedef struct {
    * missing columns are written as zero planes); with MML_PLANES_COLS the columns beyond `cols` are not touched (the
    * caller zeroes the buffer once). */
   int64_t ldp;
+  /* K6, optional (STAR, reference model/utils.py:214-218: the layer's weight is W_specific (.) W_shared): with W2 != NULL
+   * the planes are cut from the element-wise PRODUCT W[r][c] * W2[r][c] (W2: same shape, pitch ld2) -- the derived weight
+   * reaches the GEMMs pre-cut without ever being read back.  The magnitude bound of the product is the product of the
+   * factors' bounds: amax[0 .. n_amax) belong to the W factors of the group, amax[n_amax .. 2 n_amax) to their W2
+   * factors (2 n_amax <= MML_MAX_SRC). */
+  const float* W2;
+  int64_t ld2;
 } mml_planes_desc;
 int mml_gemm_planes_cut(const mml_planes_desc* descs, int32_t n, mml_stream_t stream);
+/* SURVEY 8(b) names of K6: the grouped forward / input-gradient GEMMs restricted to layers in STAR's [K, N] weight layout
+ * (w_kn = 1) that carry pre-cut planes of the derived weight (mml_gemm_planes_cut with W2; layout MML_PLANES_COLS for the
+ * forward -- the reduction runs down the rows of a [K, N] matrix --, MML_PLANES_ROWS for the input gradient). */
+int mml_star_linear_fwd(const mml_gemm_fwd_desc* descs, int32_t n, mml_stream_t stream);
+int mml_star_linear_bwd(const mml_gemm_dgrad_desc* descs, int32_t n, mml_stream_t stream);
 
 typedef struct {
   const float* dC;  /* [M, N] gradient w.r.t. pre-activation output */

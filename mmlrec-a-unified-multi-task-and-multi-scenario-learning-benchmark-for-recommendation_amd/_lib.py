@@ -45,7 +45,8 @@ class GemmDgradDesc(C.Structure):
 
 class PlanesDesc(C.Structure):
     _fields_ = [("W", fp), ("planes", fp), ("rows", i64), ("ld", i64), ("cols", i32), ("layout", i32),
-                ("n_amax", i32), ("pad_", i32), ("amax", fp * MAX_SRC), ("kexp", fp), ("ldp", i64)]
+                ("n_amax", i32), ("pad_", i32), ("amax", fp * MAX_SRC), ("kexp", fp), ("ldp", i64),
+                ("W2", fp), ("ld2", i64)]
 
 
 class GemmWgradDesc(C.Structure):
@@ -143,6 +144,8 @@ _SIGS = {
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_pep_gate_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_pep_gate_bwd": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
+    "mml_star_linear_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
+    "mml_star_linear_bwd": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_gemm_grouped_wgrad_workspace_bytes": (i64, [_PP(GemmWgradDesc), i32]),
     "mml_gemm_grouped_wgrad": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, fp]),
     "mml_gemm_grouped_wgrad_phase": (C.c_int, [_PP(GemmWgradDesc), i32, fp, i64, i32, fp]),

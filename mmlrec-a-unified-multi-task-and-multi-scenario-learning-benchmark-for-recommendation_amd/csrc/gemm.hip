@@ -108,7 +108,7 @@ __device__ __forceinline__ void amax_publish(uint32_t am, uint32_t* slot, int sa
 
 // ---- pre-cut weights (mml_gemm_planes_cut): the two fp16 planes of a weight matrix, laid out so that they travel through
 // the SAME global -> LDS image and fragment reads as the floats (see planes_of) ----
-constexpr int PLANES_PER_LAUNCH = 30;  // (kernel-argument block: 30 x 128 B + 128 B < 4 KiB)
+constexpr int PLANES_PER_LAUNCH = 27;  // (kernel-argument block: 27 x 144 B + 116 B < 4 KiB)
 struct PlanesLaunch {
   mml_planes_desc d[PLANES_PER_LAUNCH];
   int32_t item0[PLANES_PER_LAUNCH + 1];  // first work item of matrix i (one item = one block of 16 along the reduction)
@@ -123,9 +123,16 @@ __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
   __shared__ uint32_t mx;
   if (threadIdx.x == 0) mx = 0u;
   __syncthreads();
-  if ((int)threadIdx.x < D.n_amax * MML_AMAX_WORDS) {
-    const uint32_t* sl = D.amax[threadIdx.x / MML_AMAX_WORDS];
-    atomicMax(&mx, sl[threadIdx.x % MML_AMAX_WORDS]);
+  if (D.W2 == nullptr) {
+    if ((int)threadIdx.x < D.n_amax * MML_AMAX_WORDS) {
+      const uint32_t* sl = D.amax[threadIdx.x / MML_AMAX_WORDS];
+      atomicMax(&mx, sl[threadIdx.x % MML_AMAX_WORDS]);
+    }
+  } else if ((int)threadIdx.x < D.n_amax) {
+    // K6: the matrix is a product of two factors: its magnitude bound is the product of theirs (a non-finite factor
+    // bound stays non-finite: exponent 0 below)
+    const float a = __uint_as_float(amax_load(D.amax[threadIdx.x])), b = __uint_as_float(amax_load(D.amax[D.n_amax + threadIdx.x]));
+    atomicMax(&mx, __float_as_uint(a * b));
   }
   __syncthreads();
   // (amax_scale_exp is monotone: the exponent of the largest magnitude is the smallest exponent of the group; an
@@ -134,7 +141,9 @@ __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
   if (D.n_amax > 1 && (mx >> 23) >= 255u) {  // a non-finite slot must not hide the finite ones' exponents: redo per slot
     k = 110;
     for (int a = 0; a < D.n_amax; ++a) {
-      const int ka = amax_scale_exp(amax_load(D.amax[a]));
+      uint32_t bits = amax_load(D.amax[a]);
+      if (D.W2) bits = __float_as_uint(__uint_as_float(bits) * __uint_as_float(amax_load(D.amax[D.n_amax + a])));
+      const int ka = amax_scale_exp(bits);
       k = ka < k ? ka : k;
     }
   }
@@ -163,6 +172,21 @@ __global__ __launch_bounds__(256) void planes_cut_kernel(const PlanesLaunch L) {
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = e < live ? D.W[base + e * stride] : 0.f;
+    if (D.W2) {  // K6: the derived weight W (.) W2 (the fp32 product the element-wise kernel would have stored)
+      int64_t base2, stride2;
+      if (D.layout == MML_PLANES_ROWS) {
+        const int nb = (D.cols + 15) / 16;
+        const int64_t r = loc / nb;
+        base2 = r * D.ld2 + 16 * (int)(loc - r * nb);
+        stride2 = 1;
+      } else {
+        const int64_t rb = loc / D.cols;
+        base2 = 16 * rb * D.ld2 + (loc - rb * D.cols);
+        stride2 = D.ld2;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] *= e < live ? D.W2[base2 + e * stride2] : 0.f;
+    }
     uint32_t hp[16], lp[16];  // half bit patterns
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1899,9 +1923,11 @@ extern "C" int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stre
       MML_REQUIRE(q.layout == MML_PLANES_ROWS ? ldp >= (q.cols + 15) / 16 * 16 : (q.rows % 16 == 0 && ldp >= q.cols),
                   "mml_gemm_planes_cut: matrix %d: the planes pitch cannot hold the reduction extent rounded up to 16 "
                   "(ROWS), or the row count is not a multiple of 16 (COLS)", i);
-      MML_REQUIRE(q.n_amax >= 1 && q.n_amax <= MML_MAX_SRC, "mml_gemm_planes_cut: matrix %d needs 1..%d magnitude slots", i,
-                  MML_MAX_SRC);
-      for (int a = 0; a < q.n_amax; ++a) MML_REQUIRE(q.amax[a], "mml_gemm_planes_cut: null magnitude slot (matrix %d)", i);
+      MML_REQUIRE(q.n_amax >= 1 && q.n_amax * (q.W2 ? 2 : 1) <= MML_MAX_SRC,
+                  "mml_gemm_planes_cut: matrix %d needs 1..%d magnitude slots (half as many pairs with W2)", i, MML_MAX_SRC);
+      MML_REQUIRE(!q.W2 || q.ld2 >= q.cols, "mml_gemm_planes_cut: matrix %d: ld2 < cols", i);
+      for (int a = 0; a < q.n_amax * (q.W2 ? 2 : 1); ++a)
+        MML_REQUIRE(q.amax[a], "mml_gemm_planes_cut: null magnitude slot (matrix %d)", i);
       const int64_t it = q.layout == MML_PLANES_ROWS ? q.rows * ((q.cols + 15) / 16) : (q.rows / 16) * q.cols;
       MML_REQUIRE(items + it < 0x7fffffff, "mml_gemm_planes_cut: too many blocks");
       L.item0[L.n] = (int32_t)items;
@@ -1966,8 +1992,8 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
       S0.A = q.A; S0.lda = q.lda; S0.B = q.W; S0.ldb = q.ldw; S0.Kred = q.K;
       S0.vecA = vec_ok(q.A, q.lda); S0.vecB = vec_ok(q.W, q.ldw);
       S0.amaxA = q.amax_a; S0.amaxB = q.amax_w;
-      planes[j - i] = q.w_kn == 0 ? q.w_planes : nullptr;
-      kexps[j - i] = q.w_kn == 0 ? q.w_kexp : nullptr;
+      planes[j - i] = q.w_planes;  // ([K, N] weights: the MML_PLANES_COLS image, K6)
+      kexps[j - i] = q.w_kexp;
       P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.N; P.C = q.C; P.ldc = q.ldc; P.bias = q.bias; P.act = q.act;
       MML_REQUIRE(!q.relu_mask || q.ldmask * 32 >= q.N, "mml_gemm_grouped_fwd: ldmask too small in problem %d", j);
@@ -2040,8 +2066,8 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
         S.Kred = q.N[s];
         S.vecA = vec_ok(q.dC[s], q.lddc[s]); S.vecB = vec_ok(q.W[s], q.ldw[s]);
         S.amaxA = q.amax_dc[s]; S.amaxB = q.amax_w[s];
-        planes[nsources - 1] = lay == 0 ? q.w_planes[s] : nullptr;
-        kexps[nsources - 1] = lay == 0 ? q.w_kexp[s] : nullptr;
+        planes[nsources - 1] = q.w_planes[s];  // ([K, N] weights: the MML_PLANES_ROWS image, K6)
+        kexps[nsources - 1] = q.w_kexp[s];
       }
       P.amax_out = q.amax_out;
       P.M = q.M; P.N = q.K; P.C = q.dA; P.ldc = q.ldda; P.Y = q.Y; P.ldy = q.ldy; P.act = q.act;
@@ -2103,6 +2129,23 @@ extern "C" int mml_pep_gate_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_strea
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_pep_gate_fwd: bad descriptor array");
   for (int i = 0; i < n; ++i) MML_REQUIRE(d[i].mul && d[i].prod, "mml_pep_gate_fwd: problem %d carries no mul / prod", i);
   return mml_gemm_grouped_fwd(d, n, stream);
+}
+
+extern "C" int mml_star_linear_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_star_linear_fwd: bad descriptor array");
+  for (int i = 0; i < n; ++i)
+    MML_REQUIRE(d[i].w_kn == 1 && d[i].w_planes && d[i].w_kexp,
+                "mml_star_linear_fwd: problem %d is not a [K, N]-layout layer with pre-cut planes", i);
+  return mml_gemm_grouped_fwd(d, n, stream);
+}
+
+extern "C" int mml_star_linear_bwd(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_star_linear_bwd: bad descriptor array");
+  for (int i = 0; i < n; ++i)
+    for (int s2 = 0; s2 < d[i].n_src && s2 < MML_MAX_SRC; ++s2)
+      MML_REQUIRE(d[i].w_kn[s2] == 1 && d[i].w_planes[s2] && d[i].w_kexp[s2],
+                  "mml_star_linear_bwd: source %d of problem %d is not a [K, N]-layout layer with pre-cut planes", s2, i);
+  return mml_gemm_grouped_dgrad(d, n, stream);
 }
 
 extern "C" int mml_pep_gate_bwd(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {

@@ -191,28 +191,52 @@ class Plan:
             return None, None
         qs = [q] if group is None else group
         slots = []
+        # K6: a derived weight W = A (.) B whose factors are stable parameters (STAR: W_specific (.) W_shared, reference
+        # model/utils.py:214-218) is cut straight from its factors; all members of a group must be of one kind
+        prod = [getattr(g["W"], "factors", None) is not None for g in qs]
+        if any(prod) and not all(prod):
+            return None, None
         for g in qs:
             W = g["W"]
-            key = (W.data.data_ptr(), tuple(W.data.shape))
-            red = W.data.shape[1] if layout == ops.PLANES_ROWS else W.data.shape[0]
-            if (g.get("w_kn", 0) or ("Wp" in g) != bool(padded) or not getattr(W, "stable", False) or
-                    key not in self.amax_weights or W.data.dim() != 2 or W.data.stride(1) != 1 or
-                    (red % 16 and not (padded and layout == ops.PLANES_ROWS)) or
+            kn = int(g.get("w_kn", 0))
+            # a [K, N] matrix (w_kn = 1) swaps the roles: the forward's reduction runs down its rows
+            lay = layout if not kn else (ops.PLANES_COLS if layout == ops.PLANES_ROWS else ops.PLANES_ROWS)
+            red = W.data.shape[1] if lay == ops.PLANES_ROWS else W.data.shape[0]
+            if (("Wp" in g) != bool(padded) or W.data.dim() != 2 or W.data.stride(1) != 1 or
+                    (red % 16 and not (padded and lay == ops.PLANES_ROWS)) or
                     W.data.data_ptr() % 16 or (W.data.stride(0) % 4 and not padded)):
                 return None, None
+            fac = getattr(W, "factors", None)
+            if fac is not None:
+                if padded or not all(getattr(f, "stable", False) and f.data.shape == W.data.shape and
+                                     f.data.stride(1) == 1 for f in fac):
+                    return None, None
+                sl = tuple(self.weight_amax(f, f.data, None) for f in fac)  # (stable: the start-of-step launch)
+                slots.append(sl)
+                continue
+            key = (W.data.data_ptr(), tuple(W.data.shape))
+            if kn or not getattr(W, "stable", False) or key not in self.amax_weights:
+                return None, None
             slots.append(self.amax_weights[key])
-        W = q["W"].data
+        if any(prod) and 2 * len(slots) > L.MAX_SRC:
+            return None, None
+        Wq = q["W"]
+        W = Wq.data
+        kn = int(q.get("w_kn", 0))
+        lay = layout if not kn else (ops.PLANES_COLS if layout == ops.PLANES_ROWS else ops.PLANES_ROWS)
         shape = tuple(q["Wp"].shape) if padded else (W.shape[0], W.stride(0))
-        ck = (W.data_ptr(), tuple(W.shape), layout, bool(padded), tuple(sl.data_ptr() for sl in slots))
+        flat = tuple(s_.data_ptr() for sl in slots for s_ in (sl if isinstance(sl, tuple) else (sl,)))
+        ck = (W.data_ptr(), tuple(W.shape), lay, bool(padded), flat)
         if ck not in self.planes_cache:
-            gk = ("kexp", layout, bool(padded), tuple(sl.data_ptr() for sl in slots))  # one exponent word per group
+            gk = ("kexp", lay, bool(padded), flat)  # one exponent word per group
             if gk not in self.planes_cache:
                 self.planes_cache[gk] = torch.zeros(1, dtype=torch.int32, device=self.device)
             planes = torch.zeros(shape, dtype=torch.int32, device=self.device)
             if not padded:
                 planes = planes[:, :W.shape[1]]
             self.planes_cache[ck] = (planes, self.planes_cache[gk])
-            self.planes_items.append((W, planes, layout, slots, self.planes_cache[gk]))
+            src = W if not any(prod) else tuple(f.data for f in Wq.factors)
+            self.planes_items.append((src, planes, lay, slots, self.planes_cache[gk]))
         return self.planes_cache[ck]
 
     def value_amax(self, v, view, need):
@@ -379,7 +403,8 @@ class Plan:
             arr = ops.make_planes_descs(self.planes_items)
             self.keep.append(arr)
             pre.append((L.load().mml_gemm_planes_cut, (arr, len(self.planes_items)),
-                        dict(kernel="planes_cut_kernel", bytes=8.0 * sum(it[0].numel() for it in self.planes_items))))
+                        dict(kernel="planes_cut_kernel", bytes=8.0 * sum((it[0][0] if isinstance(it[0], tuple) else it[0]).numel()
+                                                                        for it in self.planes_items))))
         self.fwd = pre + self.fwd
         self.n_pre = len(pre)
 

@@ -4,6 +4,8 @@ the weights is a tiny elementwise kernel per step; the GEMMs then run on the pla
 
 Reference quirk kept: only the LAST domain's specific tensors are registered parameters, so heads
 i < T-1 run on frozen specific weights times the trained shared ones."""
+import os
+
 import torch.nn as nn
 
 from .. import engine as E
@@ -47,8 +49,16 @@ class STAR(BaseModel):
         else:
             ws = E.PVal(module.specific_weights[d].data, None, f"{prefix}.frozen_w.{d}", needs_grad=False)
             bs = E.PVal(module.specific_biases[d].data, None, f"{prefix}.frozen_b.{d}", needs_grad=False)
+            ws.stable = bs.stable = True  # (constants: their magnitude is taken once, at the start of a step)
         wsh, bsh = store.pvals[f"{prefix}.shared_weight"], store.pvals[f"{prefix}.shared_bias"]
         weff = E.PVal(plan.empty(*wsh.data.shape), plan.zeros(*wsh.data.shape), f"{prefix}.weff.{d}")
+        # K6 (MMLREC_STAR_PLANES=1): the GEMMs take the derived weight as planes cut straight from its two factors
+        # (mml_gemm_planes_cut with W2, mml_star_linear_fwd / _bwd); the fp32 product below is still formed for the heads
+        # and as the shape the weight gradient is chained through.  Measured on Amazon-8 at 65 536 (round 4, same box):
+        # serial 692.5 vs 693.1 us (GEMMs -5 us, magnitudes -9 us, the start-of-step cut +16 us), two-stream 0.687 vs
+        # 0.676 ms -- level to a 1.5 % loss, so it is opt-in.
+        if os.environ.get("MMLREC_STAR_PLANES", "0") == "1":
+            weff.factors = (ws, wsh)
         beff = E.PVal(plan.empty(*bsh.data.shape), plan.zeros(*bsh.data.shape), f"{prefix}.beff.{d}")
         # (collected: ALL derived parameters of the model are produced by one batched launch, see _build_graph)
         self._derived.append((weff, [(ws, wsh)]))

@@ -297,6 +297,15 @@ def make_planes_descs(items):
     [1] tensor) -> the descriptor block of mml_gemm_planes_cut."""
     arr = (L.PlanesDesc * len(items))()
     for d, (W, planes, layout, slots, kexp) in zip(arr, items):
+        # K6: W = (A, B) -> the planes of the element-wise product A * B; slots = [(slot of A_i, slot of B_i)] for the
+        # matrices of the group that shares the exponent
+        W2 = None
+        if isinstance(W, tuple):
+            W, W2 = W
+            if W2.shape != W.shape:
+                raise L.MMLError("factors of a derived weight must have one shape")
+            if 2 * len(slots) > L.MAX_SRC:
+                raise L.MMLError("too many product weights share one exponent")
         # planes: the weight's shape (pitch may differ), or -- for the zero-padded operand of a reduction that is not a
         # multiple of 16 -- the same rows with the columns rounded up (a zero-initialised buffer)
         if planes.shape[0] != W.shape[0] or planes.shape[1] < W.shape[1]:
@@ -307,8 +316,14 @@ def make_planes_descs(items):
         d.ldp = _ld(planes)
         d.layout = int(layout)
         d.n_amax = len(slots)
-        for a, sl in enumerate(slots):
-            d.amax[a] = sl.data_ptr()
+        if W2 is not None:
+            d.W2, d.ld2 = W2.data_ptr(), _ld(W2)
+            for a, (sa, sb) in enumerate(slots):
+                d.amax[a] = sa.data_ptr()
+                d.amax[len(slots) + a] = sb.data_ptr()
+        else:
+            for a, sl in enumerate(slots):
+                d.amax[a] = sl.data_ptr()
         d.kexp = kexp.data_ptr()
     return arr
 

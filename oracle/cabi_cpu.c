@@ -206,9 +206,25 @@ int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stream_t stream
     REQUIRE(q->W && q->planes && q->kexp && q->n_amax >= 1 && q->n_amax <= MML_MAX_SRC, "mml_gemm_planes_cut: matrix %d malformed", i);
     REQUIRE(q->layout == MML_PLANES_ROWS ? ldp >= (q->cols + 15) / 16 * 16 : (q->rows % 16 == 0 && ldp >= q->cols),
             "mml_gemm_planes_cut: matrix %d: pitch / reduction extent", i);
+    REQUIRE(!q->W2 || (2 * q->n_amax <= MML_MAX_SRC && q->ld2 >= q->cols), "mml_gemm_planes_cut: matrix %d: product factors", i);
     int k = 110;
     for (int a = 0; a < q->n_amax; ++a) {
-      const int ka = amax_exp(q->amax[a]);
+      int ka;
+      if (q->W2) { /* K6: the bound of a product is the product of the factors' bounds (fp32 product, as on the device) */
+        uint32_t ma = 0, mb = 0, pb[MML_AMAX_WORDS] = {0};
+        for (int w = 0; w < MML_AMAX_WORDS; ++w) {
+          ma = q->amax[a][w] > ma ? q->amax[a][w] : ma;
+          mb = q->amax[q->n_amax + a][w] > mb ? q->amax[q->n_amax + a][w] : mb;
+        }
+        float fa, fb;
+        memcpy(&fa, &ma, 4);
+        memcpy(&fb, &mb, 4);
+        const float pr = fa * fb;
+        memcpy(&pb[0], &pr, 4);
+        ka = amax_exp(pb);
+      } else {
+        ka = amax_exp(q->amax[a]);
+      }
       k = ka < k ? ka : k;
     }
     *q->kexp = k;
@@ -221,7 +237,8 @@ int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stream_t stream
         for (int e = 0; e < 16; ++e) {
           const int64_t kk = 16 * b + e;
           const int live = rows_k ? kk < q->cols : 1;
-          const float x = live ? (rows_k ? q->W[o * q->ld + kk] : q->W[kk * q->ld + o]) : 0.f;
+          float x = live ? (rows_k ? q->W[o * q->ld + kk] : q->W[kk * q->ld + o]) : 0.f;
+          if (q->W2 && live) x = x * (rows_k ? q->W2[o * q->ld2 + kk] : q->W2[kk * q->ld2 + o]);
           const float y = x * s;
           hp[e] = half_bits(y);
           lp[e] = half_bits(y - half_value(hp[e]));
@@ -261,6 +278,11 @@ int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t str
         const float v = act_fwd((float)s, q->act);
         q->C[m * q->ldc + nn] = v;
         amax_raise(q->amax_out, v);
+        if (q->mul && q->prod) { /* K7: the gated layer input leaves with the gate */
+          const float pv = v * q->mul[m * q->ldmul + nn];
+          q->prod[m * q->ldprod + nn] = pv;
+          amax_raise(q->amax_prod, pv);
+        }
         if (q->relu_mask && q->act == MML_ACT_RELU) {
           uint32_t* w = q->relu_mask + m * q->ldmask + (nn >> 5);
           if (v > 0.f) *w |= 1u << (nn & 31); else *w &= ~(1u << (nn & 31));
@@ -275,8 +297,10 @@ int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t
   REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_dgrad: bad descriptor array");
   for (int p = 0; p < n; ++p) {
     const mml_gemm_dgrad_desc* q = d + p;
-    REQUIRE(q->dA && q->n_src >= 1 && q->n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", p);
-    REQUIRE(q->act == MML_ACT_NONE || q->Y || q->relu_mask, "mml_gemm_grouped_dgrad: act set but Y null in problem %d", p);
+    REQUIRE((q->dA || q->gate_h) && q->n_src >= 1 && q->n_src <= MML_MAX_SRC, "mml_gemm_grouped_dgrad: problem %d malformed", p);
+    REQUIRE(q->gate_h || q->act == MML_ACT_NONE || q->Y || q->relu_mask,
+            "mml_gemm_grouped_dgrad: act set but Y null in problem %d", p);
+    REQUIRE(!q->gate_h || (q->gate_g && q->d_h && q->d_g), "mml_gemm_grouped_dgrad: gate-mode problem %d lacks a factor", p);
     for (int64_t m = 0; m < q->M; ++m)
       for (int k = 0; k < q->K; ++k) {
         double s = 0.0;
@@ -285,6 +309,18 @@ int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t
             s += (double)q->dC[sidx][m * q->lddc[sidx] + nn] *
                  (q->w_kn[sidx] ? q->W[sidx][(int64_t)k * q->ldw[sidx] + nn] : q->W[sidx][(int64_t)nn * q->ldw[sidx] + k]);
         float v = (float)s;
+        if (q->gate_h) { /* K7 backward: the gradients of the two factors of x = h (.) g */
+          const float hv = q->gate_h[m * q->ld_h + k], gv = q->gate_g[m * q->ld_g + k];
+          float* ph = q->d_h + m * q->ld_dh + k;
+          float* pg = q->d_g + m * q->ld_dg + k;
+          const float vh = v * gv * (q->act_h != MML_ACT_NONE ? act_bwd_from_output(hv, q->act_h) : 1.f) + (q->acc_h ? *ph : 0.f);
+          const float vg = v * hv * (q->act_g != MML_ACT_NONE ? act_bwd_from_output(gv, q->act_g) : 1.f) + (q->acc_g ? *pg : 0.f);
+          *ph = vh;
+          *pg = vg;
+          amax_raise(q->amax_dh, vh);
+          amax_raise(q->amax_dg, vg);
+          continue;
+        }
         if (q->relu_mask) {
           if (!((q->relu_mask[m * q->ldmask + (k >> 5)] >> (k & 31)) & 1u)) v = 0.f;
         } else if (q->act != MML_ACT_NONE) {
@@ -296,6 +332,33 @@ int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t
       }
   }
   return MML_OK;
+}
+
+/* SURVEY 8(b) names of K7 / K6 (include/mmlrec.h): the grouped GEMMs restricted to the descriptors they are named for */
+int mml_pep_gate_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_pep_gate_fwd: bad descriptor array");
+  for (int i = 0; i < n; ++i) REQUIRE(d[i].mul && d[i].prod, "mml_pep_gate_fwd: problem %d carries no mul / prod", i);
+  return mml_gemm_grouped_fwd(d, n, stream);
+}
+int mml_pep_gate_bwd(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_pep_gate_bwd: bad descriptor array");
+  for (int i = 0; i < n; ++i) REQUIRE(d[i].gate_h, "mml_pep_gate_bwd: problem %d is not in gate mode", i);
+  return mml_gemm_grouped_dgrad(d, n, stream);
+}
+int mml_star_linear_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_star_linear_fwd: bad descriptor array");
+  for (int i = 0; i < n; ++i)
+    REQUIRE(d[i].w_kn == 1 && d[i].w_planes && d[i].w_kexp,
+            "mml_star_linear_fwd: problem %d is not a [K, N]-layout layer with pre-cut planes", i);
+  return mml_gemm_grouped_fwd(d, n, stream);
+}
+int mml_star_linear_bwd(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
+  REQUIRE(n >= 0 && (n == 0 || d), "mml_star_linear_bwd: bad descriptor array");
+  for (int i = 0; i < n; ++i)
+    for (int s2 = 0; s2 < d[i].n_src && s2 < MML_MAX_SRC; ++s2)
+      REQUIRE(d[i].w_kn[s2] == 1 && d[i].w_planes[s2] && d[i].w_kexp[s2],
+              "mml_star_linear_bwd: source %d of problem %d is not a [K, N]-layout layer with pre-cut planes", s2, i);
+  return mml_gemm_grouped_dgrad(d, n, stream);
 }
 
 int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_desc* d, int32_t n) { (void)d; (void)n; return 256; }

@@ -123,6 +123,67 @@ def test_cpu_library_planes_cut_layout(cpu):
     assert np.array_equal(outs[2], image(Wpad, k_grp, 1))
     arr[0].ldp = K  # no room for the rounded-up block of the ragged reduction
     assert lib.mml_gemm_planes_cut(arr, 1, None) == -1
+    # K6: planes of the element-wise product of two factors (STAR's W_specific (.) W_shared, [K, N] layout), exponent from
+    # the product of the factors' bounds
+    Kk, Nn = 64, 48
+    A = (rng.standard_normal((Kk, Nn)) * 2.0).astype(np.float32)
+    B = (rng.standard_normal((Kk, Nn)) * 0.05).astype(np.float32)
+    sa, sb = slot(np.abs(A).max()), slot(np.abs(B).max())
+    arr = (L.PlanesDesc * 2)()
+    outs = [np.zeros((Kk, Nn), dtype=np.uint32) for _ in range(2)]
+    kx = np.zeros(2, dtype=np.int32)
+    for i, layout in enumerate((1, 0)):  # forward of a [K, N] weight: down the rows; its input gradient: along a row
+        d = arr[i]
+        d.W, d.W2, d.planes, d.rows, d.ld, d.ld2, d.cols, d.layout = A.ctypes.data, B.ctypes.data, outs[i].ctypes.data, Kk, Nn, Nn, Nn, layout
+        d.n_amax = 1
+        d.amax[0], d.amax[1] = sa.ctypes.data, sb.ctypes.data
+        d.kexp = kx[i:i + 1].ctypes.data
+    assert lib.mml_gemm_planes_cut(arr, 2, None) == 0
+    kp = kexp(np.float32(np.abs(A).max()) * np.float32(np.abs(B).max()))
+    assert kx.tolist() == [kp, kp]
+    assert np.array_equal(outs[0], image(A * B, kp, 1))
+    assert np.array_equal(outs[1], image(A * B, kp, 0))
+
+
+def test_cpu_library_named_k7_k6_entry_points(cpu):
+    """mml_pep_gate_fwd / _bwd and mml_star_linear_fwd / _bwd (include/mmlrec.h): the grouped GEMMs restricted to the
+    descriptors they are named for -- results against numpy, and the refusals."""
+    lib, L = cpu
+    rng = np.random.default_rng(9)
+    M, K, N = 37, 24, 16
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 5).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    mul = rng.standard_normal((M, N)).astype(np.float32)
+    C, prod = np.zeros((M, N), np.float32), np.zeros((M, N), np.float32)
+    d = (L.GemmFwdDesc * 1)()
+    q = d[0]
+    q.A, q.W, q.bias, q.C, q.lda, q.ldw, q.ldc, q.M, q.N, q.K, q.act = ptr(A), ptr(W), ptr(b), ptr(C), K, K, N, M, N, K, L.ACT_SIGMOID2
+    assert lib.mml_pep_gate_fwd(d, 1, None) == -1          # no mul / prod
+    q.mul, q.prod, q.ldmul, q.ldprod = ptr(mul), ptr(prod), N, N
+    assert lib.mml_pep_gate_fwd(d, 1, None) == 0
+    gate = 2.0 / (1.0 + np.exp(-(A.astype(np.float64) @ W.T.astype(np.float64) + b)))
+    assert np.allclose(C, gate, rtol=1e-6) and np.allclose(prod, gate * mul, rtol=1e-6, atol=1e-7)
+    assert lib.mml_star_linear_fwd(d, 1, None) == -1       # nn.Linear layout, no planes
+    # gate-mode input gradient
+    dC = rng.standard_normal((M, N)).astype(np.float32)
+    h = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    g = (2.0 / (1.0 + np.exp(-rng.standard_normal((M, K))))).astype(np.float32)
+    dh, dg = np.ones((M, K), np.float32), np.zeros((M, K), np.float32)
+    e = (L.GemmDgradDesc * 1)()
+    r = e[0]
+    r.M, r.K, r.n_src = M, K, 1
+    r.dC[0], r.W[0], r.lddc[0], r.ldw[0], r.N[0], r.w_kn[0] = ptr(dC), ptr(W), N, K, N, 0
+    dA = np.zeros((M, K), np.float32)
+    r.dA, r.ldda = ptr(dA), K
+    assert lib.mml_pep_gate_bwd(e, 1, None) == -1          # not in gate mode
+    assert lib.mml_star_linear_bwd(e, 1, None) == -1
+    r.gate_h, r.gate_g, r.d_h, r.d_g, r.ld_h, r.ld_g, r.ld_dh, r.ld_dg = ptr(h), ptr(g), ptr(dh), ptr(dg), K, K, K, K
+    r.act_h, r.act_g, r.acc_h, r.acc_g = L.ACT_RELU, L.ACT_SIGMOID2, 1, 0
+    assert lib.mml_pep_gate_bwd(e, 1, None) == 0
+    v = dC.astype(np.float64) @ W.astype(np.float64)
+    assert np.allclose(dh, 1.0 + v * g * (h > 0), rtol=1e-5, atol=1e-6)
+    assert np.allclose(dg, v * h * (g.astype(np.float64) * (1 - g.astype(np.float64) / 2)), rtol=1e-5, atol=1e-6)
 
 
 def ptr(a):
