@@ -222,14 +222,22 @@ int mml_rows_clear(const int32_t* list, const int32_t* count, int32_t cap, const
  * Environment MMLREC_GEMM_MODE overrides the default. */
 int mml_gemm_set_mode(int32_t mode);
 int mml_gemm_get_mode(void);
-/* The activation-stationary forward kernel (csrc/gemm_panel.hip; round 4).  A grouped forward launch whose problems ALL
- * read one input A [M, K] (the first DNN layer of every expert / gate tower: reference model/mmoe.py:69-79) with
- * 160 <= K <= 240, K % 16 == 0, M >= 8 192, N % 64 == 0, nn.Linear weights with pre-cut planes, the magnitude of A,
- * activation relu or none, 16-byte aligned operands, and relu sign masks on all problems or on none, is served by a
- * persistent workgroup per 128-row block that keeps the block's fp16 planes in LDS and sweeps every N-tile from it
- * (bitwise the results of the tile kernel).  on = 0 switches it off (process-wide; default on; environment
- * MMLREC_GEMM_PANEL=0 does the same). */
+/* Activation-stationary forward (csrc/gemm_panel.hip).  A forward launch whose problems all read ONE input A [M, K] (the
+ * first DNN layer of every expert / gate tower: reference model/mmoe.py:69-79) with K in {160, 208, 240}, M >= 8 192 and
+ * M % 128 == 0, N % 64 == 0 (an even number of 64-column half tiles over the launch), nn.Linear weights with pre-cut
+ * planes, the magnitude of A, activation relu, 16-byte aligned operands, and relu sign masks on all problems or on
+ * none, is served by a persistent workgroup per 128-row block that keeps the block's fp16 planes as MFMA fragments in
+ * registers and sweeps every N-tile past them (bitwise the results of the tile kernel).  on = 0 switches it off
+ * (process-wide; default on; environment MMLREC_GEMM_PANEL=0 does the same). */
 int mml_gemm_set_panel(int32_t on);
+/* Weight-stationary streaming GEMM (csrc/gemm_ws.hip).  A forward launch whose problems have one shape with K % 64 == 0,
+ * N in {64, 128}, N K <= 32 768 (the two fp16 planes of the weight fit 128 KiB of LDS), M >= 8 192, pre-cut planes
+ * (either weight layout), the magnitude of A, activation relu or none -- and an input-gradient launch of single-source
+ * problems of one shape with K in {128, 256} output columns, N % 64 == 0, N K <= 32 768, activation none or relu by
+ * sign mask -- is served by persistent workgroups that keep one problem's weight planes in LDS while their waves
+ * stream 32-row blocks of the batch past them (second expert layers, towers: reference model/mmoe.py:69-119).  Bitwise
+ * the results of the tile kernel.  on = 0 switches it off (default on; environment MMLREC_GEMM_WS=0 does the same). */
+int mml_gemm_set_ws(int32_t on);
 /* Kernel symbol (as rocprofv3 prints it, without the mml:: prefix) of the calling thread's most recent GEMM launch;
  * "" before the first one.  For profilers / benchmark labels. */
 const char* mml_gemm_last_kernel(void);

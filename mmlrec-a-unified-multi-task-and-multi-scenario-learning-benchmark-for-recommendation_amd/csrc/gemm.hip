@@ -1961,12 +1961,22 @@ extern "C" int mml_gemm_set_wgrad_lds_pad(int32_t bytes) {
 // gemm_panel.hip: the activation-stationary kernel for launches whose problems all read ONE input (first DNN layers)
 int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st);
 
+// gemm_ws.hip: the weight-stationary kernel for launches whose problems each stream their own input past a weight that
+// fits the LDS (second expert layers, towers, and their input gradients)
+int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st);
+int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t st);
+
 extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");
   if (n > 0 && gemm_mode() >= 2 && gemm_mode() != 3) {  // (auto / two-plane arithmetic only)
-    const int rc = mml_gemm_panel_try_fwd(d, n, to_stream(stream));
+    int rc = mml_gemm_panel_try_fwd(d, n, to_stream(stream));
     if (rc != MML_ERR_UNSUPPORTED) {
       if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_panel_kernel");
+      return rc;
+    }
+    rc = mml_gemm_ws_try_fwd(d, n, to_stream(stream));
+    if (rc != MML_ERR_UNSUPPORTED) {
+      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_ws_kernel");
       return rc;
     }
   }
@@ -2037,6 +2047,13 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
 
 extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_dgrad: bad descriptor array");
+  if (n > 0 && gemm_mode() >= 2 && gemm_mode() != 3) {
+    const int rc = mml_gemm_ws_try_dgrad(d, n, to_stream(stream));
+    if (rc != MML_ERR_UNSUPPORTED) {
+      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_ws_kernel");
+      return rc;
+    }
+  }
   int i = 0;
   while (i < n) {
     int j = i;

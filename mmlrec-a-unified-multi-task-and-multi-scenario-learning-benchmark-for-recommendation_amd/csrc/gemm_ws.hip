@@ -1,0 +1,412 @@
+// K3 (round 4): weight-stationary streaming GEMM for the layers whose WHOLE weight fits the LDS.
+//
+// The second expert layer, the towers and their input gradients (reference model/mmoe.py:69-119: expert_dnn / tower_dnn
+// called per expert / task on its OWN input; model/utils.py:146-161 is the Linear -> ReLU layer) are streaming problems:
+// every problem reads its own [M, K] activations once and writes [M, N] once, K and N <= 256 -- at M = 65 536 about
+// 400 MB of traffic against 50 GFLOP of plane products.  gemm_pipe_kernel (gemm.hip) runs them as 128 x 128 tiles of 8
+// or 16 k-steps: a tile is mostly its own prologue (pipeline fill, barriers) and epilogue, two of them fit a CU, and
+// the launch ends up bound by neither HBM (2.9 TB/s) nor the MFMA pipe (15 %).  Here:
+//   * a persistent workgroup (eight waves, two per SIMD) serves ONE problem and keeps that problem's pre-cut weight
+//     planes (mml_gemm_planes_cut; <= 128 KiB) in LDS for its whole life, in fragment order: a wave's ds_read_b128 of a
+//     32-column x 16-k fragment is 1 KiB of consecutive bytes;
+//   * a wave owns 32-row blocks of the batch and never meets another wave again: no barrier, no tile prologue.  Its
+//     activations come straight from global memory as MFMA fragments (two 16-byte loads per lane and k-step, four
+//     k-steps ahead in a register ring, across block boundaries), are cut into their two fp16 planes in registers and
+//     meet the weight fragments from LDS in 3 x NS v_mfma_f32_32x32x16_f16 per k-step; the epilogue (unscale, bias /
+//     ReLU + sign mask, or the mask / accumulation of an input gradient) stores 16 bytes per lane (lane = batch row);
+//     the other wave of the SIMD computes meanwhile;
+//   * an output wider than 128 columns (the input gradient of a 256-wide layer) is swept in passes of 128 columns over
+//     the same rows (the second pass re-reads the block from the L1 / L2).
+// Products, their order (W_l A_h, W_h A_l, W_h A_h per 16-k block) and the k order are those of gemm_pipe_kernel<..,
+// EMU = 2, BPL>: same bits (tests/test_gemm_ws_gpu.py).
+#include "common.hpp"
+#include "lds_async.hpp"
+
+#include <stdlib.h>
+
+namespace mml {
+
+using wf32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int WS_W_BYTES = 128 * 1024;              // the weight image
+constexpr int WS_BIAS_OFF = WS_W_BYTES;             // <= 256 bias values
+constexpr int WS_AMAX_OFF = WS_BIAS_OFF + 1024;     // the workgroup's magnitude word
+constexpr int WS_LDS_BYTES = WS_AMAX_OFF + 64;
+static_assert(WS_LDS_BYTES <= 160 * 1024, "weight-stationary kernel LDS budget");
+constexpr int WS_MIN_ROWS = 8192;                   // below: the tile kernel (a persistent grid would idle)
+struct WsProblem {
+  const float* A;          // [M, Kred] activations (forward) / output gradients (input gradient)
+  const uint32_t* amaxA;   // magnitude slot of A
+  const uint32_t* planes;  // pre-cut weight, pitch ldp words
+  const int32_t* kexp;     // exponent the planes were cut with
+  float* C;                // [M, Nout]
+  const float* bias;       // forward: [Nout] or null
+  uint32_t* mask;          // forward: sign mask written; input gradient: sign mask read
+  uint32_t* amax_out;
+  int64_t lda, ldp, ldc, ldmask;
+  int32_t layout;          // MML_PLANES_ROWS: planes[out col][k]; MML_PLANES_COLS: planes[k][out col]
+  int32_t relu;            // forward: ReLU
+  int32_t accumulate;      // input gradient: C +=
+  int32_t pad_;
+};
+
+struct WsLaunch {
+  int32_t M, n_prob, wg_per_prob, G;  // G: groups of four k-steps (Kred = 64 G)
+  WsProblem p[MML_MAX_GROUP];
+};
+static_assert(sizeof(WsLaunch) <= 4096, "WsLaunch must fit the kernel-argument block");
+
+__device__ __forceinline__ uint32_t ws_amax_load(const uint32_t* p) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < MML_AMAX_WORDS; ++i) m = p[i] > m ? p[i] : m;
+  return m;
+}
+// (the rule of gemm.hip: |x| 2^k < 2^15 for every |x| <= the slot's value; Inf / NaN: scale 1)
+__device__ __forceinline__ int ws_scale_exp(uint32_t bits) {
+  const int e = (int)((bits >> 23) & 0xffu);
+  if (e == 255) return 0;
+  const int k = 141 - e;
+  return k > 110 ? 110 : (k < -110 ? -110 : k);
+}
+__device__ __forceinline__ float ws_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// MODE 0: forward (bias, ReLU, sign mask out when MASKS); MODE 1: input gradient (sign mask in when MASKS, accumulation)
+template <int NS, int NPASS, int MODE, bool MASKS>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
+  constexpr int NSTOT = NS * NPASS;
+  __shared__ __attribute__((aligned(16))) float lds[WS_LDS_BYTES / 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int pi = (int)blockIdx.x / L.wg_per_prob;
+  const int wl = (int)blockIdx.x - pi * L.wg_per_prob;
+  const WsProblem& P = L.p[pi];
+  const int G = L.G, KB = 4 * G, M = L.M;
+
+  // ---- the problem's weight planes -> LDS, fragment order: [k-step][plane][32-column sub-tile][lane] x 16 bytes ----
+  {
+    uint32_t* const lw = reinterpret_cast<uint32_t*>(lds);
+    if (P.layout == MML_PLANES_ROWS) {  // row = output column, 16 words per k-step: chunk c = 2 plane + lane half
+      const int total = NSTOT * 32 * KB * 4;
+      for (int idx = tid; idx < total; idx += 512) {
+        const int c = idx & 3, b = (idx >> 2) % KB, n = idx / (4 * KB);
+        const uint4 v = *reinterpret_cast<const uint4*>(P.planes + (int64_t)n * P.ldp + 16 * b + 4 * c);
+        *reinterpret_cast<uint4*>(lw + ((((b * 2 + (c >> 1)) * NSTOT + (n >> 5)) * 64 + (c & 1) * 32 + (n & 31)) * 4)) = v;
+      }
+    } else {                            // row = k, word e = 8 plane + 4 lane half + i of its block of 16
+      constexpr int NO = NSTOT * 32;
+      const int total = KB * 16 * NO;
+      for (int idx = tid; idx < total; idx += 512) {
+        const int c = idx % NO, r = idx / NO;
+        const int b = r >> 4, e = r & 15;
+        lw[(((b * 2 + (e >> 3)) * NSTOT + (c >> 5)) * 64 + ((e >> 2) & 1) * 32 + (c & 31)) * 4 + (e & 3)] =
+            P.planes[(int64_t)r * P.ldp + c];
+      }
+    }
+    if (MODE == 0 && tid < NSTOT * 32) lds[WS_BIAS_OFF / 4 + tid] = P.bias ? P.bias[tid] : 0.f;
+    if (tid == 0) reinterpret_cast<uint32_t*>(lds)[WS_AMAX_OFF / 4] = 0u;
+  }
+  __syncthreads();
+
+  const int kA = __builtin_amdgcn_readfirstlane(ws_scale_exp(ws_amax_load(P.amaxA)));
+  const int kB = __builtin_amdgcn_readfirstlane(*P.kexp);
+  const float sA = ws_pow2(kA);
+  const float inv = ws_pow2(-kA) * ws_pow2(-kB);
+
+  const int nrb = (M + 31) >> 5;
+  const int stride = L.wg_per_prob * 8;
+  int rb = wl * 8 + wave;
+  float am = 0.f;
+
+  auto arow = [&](const int rb_) __attribute__((always_inline)) {
+    int row = rb_ * 32 + l31;
+    row = row < M ? row : M - 1;
+    return P.A + (int64_t)row * P.lda + 4 * h;
+  };
+  const f32x4_t* const wfrag = reinterpret_cast<const f32x4_t*>(lds) + lane;  // + 64 x (fragment number)
+
+  if (rb < nrb) {
+    // The raw fragments of the next four k-steps (plain loads: hipcc places the waits.  It gathers a group's refills behind
+    // the group's last MFMA and waits for them at the top of the next group, so a wave overlaps nothing by itself -- the
+    // seven other waves of the CU do.  Hand-counted waits with a look-ahead of eight k-steps, refills in bursts of 512
+    // bytes per row and twelve waves per CU were all built and measured level with this form: DESIGN 9.)
+    float4 r0[4], r1[4];
+    const float* ap = arow(rb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r0[j] = *reinterpret_cast<const float4*>(ap + 16 * j);
+      r1[j] = *reinterpret_cast<const float4*>(ap + 16 * j + 8);
+    }
+    for (; rb < nrb; rb += stride) {
+      const float* const ap_next = arow(rb + stride < nrb ? rb + stride : rb);
+#pragma unroll 1
+      for (int pass = 0; pass < NPASS; ++pass) {
+        wf32x16 acc[NS];
+#pragma unroll
+        for (int ni = 0; ni < NS; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+        const float* const unit_next = (pass + 1 < NPASS) ? ap : ap_next;
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+          const float* const pf = (g + 1 < G) ? ap + 64 * (g + 1) : unit_next;
+          const f32x4_t* const wg_ = wfrag + (g * 8 * NSTOT + pass * NS) * 64;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x[8] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+            F16Cut c;
+            f16_cut_a2(x, sA, c, 0);
+            f16_cut_a2(x, sA, c, 2);
+            f16_cut_b2(x, sA, c, 0);
+            f16_cut_b2(x, sA, c, 2);
+            f16_cut_l(c, 0);
+            f16_cut_l(c, 1);
+            f16_cut_l(c, 2);
+            f16_cut_l(c, 3);
+            f16x8 Ah, Al;
+            f16_cut_done(c, Ah, Al);
+            r0[j] = *reinterpret_cast<const float4*>(pf + 16 * j);
+            r1[j] = *reinterpret_cast<const float4*>(pf + 16 * j + 8);
+            f16x8 bh[NS], bl[NS];
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) {
+              bh[ni] = __builtin_bit_cast(f16x8, wg_[((j * 2 + 0) * NSTOT + ni) * 64]);
+              bl[ni] = __builtin_bit_cast(f16x8, wg_[((j * 2 + 1) * NSTOT + ni) * 64]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ni], Ah, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], Al, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], Ah, acc[ni], 0, 0, 0);
+          }
+        }
+        // ---- the block's outputs: lane = batch row, registers = four runs of four columns (8 g + 4 h + j) ----
+        const int row = rb * 32 + l31;
+        const bool ok = row < M;
+        const int col0 = pass * NS * 32 + 4 * h;
+        float* const crow = P.C + (int64_t)row * P.ldc + col0;
+        if constexpr (MODE == 0) {
+          const bool relu = P.relu != 0;
+#pragma unroll
+          for (int ni = 0; ni < NS; ++ni) {
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 b4 = *reinterpret_cast<const float4*>(lds + WS_BIAS_OFF / 4 + col0 + ni * 32 + 8 * g);
+              float4 v;
+              v.x = acc[ni][4 * g] * inv + b4.x;
+              v.y = acc[ni][4 * g + 1] * inv + b4.y;
+              v.z = acc[ni][4 * g + 2] * inv + b4.z;
+              v.w = acc[ni][4 * g + 3] * inv + b4.w;
+              if (relu) {
+                v.x = __builtin_fmaxf(v.x, 0.f);
+                v.y = __builtin_fmaxf(v.y, 0.f);
+                v.z = __builtin_fmaxf(v.z, 0.f);
+                v.w = __builtin_fmaxf(v.w, 0.f);
+              }
+              amax_acc(am, v);
+              if (MASKS)
+                bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (8 * g);
+              if (ok) *reinterpret_cast<float4*>(crow + ni * 32 + 8 * g) = v;
+            }
+            if (MASKS) {  // the two lanes of a row hold the interleaved halves of its 32-column word
+              const uint32_t mine = bits << (4 * h);
+              const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+              const uint32_t word = sw[0] | sw[1];
+              if (ok && h == 0) P.mask[(int64_t)row * P.ldmask + pass * NS + ni] = word;
+            }
+          }
+        } else {
+          const bool accumulate = P.accumulate != 0;
+          uint32_t mw[NS];
+          if (MASKS) {
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) mw[ni] = ok ? P.mask[(int64_t)row * P.ldmask + pass * NS + ni] : 0u;
+          }
+#pragma unroll
+          for (int ni = 0; ni < NS; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float4 v;
+              v.x = acc[ni][4 * g] * inv;
+              v.y = acc[ni][4 * g + 1] * inv;
+              v.z = acc[ni][4 * g + 2] * inv;
+              v.w = acc[ni][4 * g + 3] * inv;
+              if (MASKS) {
+                const uint32_t nib = mw[ni] >> (8 * g + 4 * h);
+                if (!(nib & 1u)) v.x = 0.f;
+                if (!(nib & 2u)) v.y = 0.f;
+                if (!(nib & 4u)) v.z = 0.f;
+                if (!(nib & 8u)) v.w = 0.f;
+              }
+              float* const dst = crow + ni * 32 + 8 * g;
+              if (accumulate && ok) {
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                v.x += o.x;
+                v.y += o.y;
+                v.z += o.z;
+                v.w += o.w;
+              }
+              amax_acc(am, v);
+              if (ok) *reinterpret_cast<float4*>(dst) = v;
+            }
+          }
+        }
+      }
+      ap = ap_next;
+    }
+  }
+
+  // the workgroup's largest |output| -> the problem's slot (one atomic per workgroup)
+  if (P.amax_out) {  // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    uint32_t* const word = reinterpret_cast<uint32_t*>(lds) + WS_AMAX_OFF / 4;
+    if (lane == 0) atomicMax(word, __float_as_uint(am));
+    __syncthreads();
+    if (tid == 0 && *word) atomicMax(P.amax_out + (blockIdx.x & (MML_AMAX_WORDS - 1)), *word);
+  }
+}
+
+static int g_ws_on = -1;
+static int ws_enabled() {
+  if (g_ws_on < 0) {
+    const char* e = getenv("MMLREC_GEMM_WS");
+    g_ws_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_ws_on;
+}
+static int ws_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, nn = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&nn, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nn <= 0)
+      nn = 256;
+    cus = nn;
+  }
+  return cus;
+}
+
+template <int MODE>
+static int ws_launch(const WsLaunch& L, const int nout, const bool masks, hipStream_t st) {
+  const dim3 g((unsigned)(L.wg_per_prob * L.n_prob)), b(512);
+#define WS_GO(NS_, NP_)                                                                  \
+  do {                                                                                   \
+    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, NP_, MODE, true>), g, b, 0, st, L);       \
+    else MML_LAUNCH((gemm_ws_kernel<NS_, NP_, MODE, false>), g, b, 0, st, L);            \
+  } while (0)
+  if constexpr (MODE == 0) {
+    if (nout == 128) WS_GO(4, 1);
+    else WS_GO(2, 1);
+  } else {
+    if (nout == 128) WS_GO(4, 1);
+    else WS_GO(4, 2);
+  }
+#undef WS_GO
+  return check_launch(MODE == 0 ? "mml_gemm_grouped_fwd(ws)" : "mml_gemm_grouped_dgrad(ws)");
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+extern "C" int mml_gemm_set_ws(int32_t on) {
+  g_ws_on = on ? 1 : 0;
+  return MML_OK;
+}
+
+// Both return MML_OK when the weight-stationary kernel took the launch and MML_ERR_UNSUPPORTED (no error text) when the
+// launch is not one it serves: the caller then runs the tile kernel.
+int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
+  if (!ws_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
+  const mml_gemm_fwd_desc& d0 = d[0];
+  if (d0.M < WS_MIN_ROWS || d0.K <= 0 || d0.K % 64 != 0) return MML_ERR_UNSUPPORTED;
+  if (d0.N != 128 && d0.N != 64) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
+  if ((int64_t)d0.N * d0.K * 4 > WS_W_BYTES) return MML_ERR_UNSUPPORTED;
+  const int wgp = ws_cus() / n;
+  if (wgp < 1) return MML_ERR_UNSUPPORTED;
+  int masks = 0;
+  WsLaunch L{};
+  for (int i = 0; i < n; ++i) {
+    const mml_gemm_fwd_desc& q = d[i];
+    if (q.M != d0.M || q.K != d0.K || q.N != d0.N) return MML_ERR_UNSUPPORTED;
+    if (!q.A || !q.C || !q.w_planes || !q.w_kexp || !q.amax_a) return MML_ERR_UNSUPPORTED;
+    if (q.mul || q.prod) return MML_ERR_UNSUPPORTED;  // (K7 products: the tile kernel's epilogue)
+    if (q.act != MML_ACT_RELU && q.act != MML_ACT_NONE) return MML_ERR_UNSUPPORTED;
+    if (!aligned16(q.A) || q.lda % 4 != 0 || !aligned16(q.C) || q.ldc % 4 != 0) return MML_ERR_UNSUPPORTED;
+    if (!q.w_kn && (!aligned16(q.w_planes) || q.ldw % 4 != 0)) return MML_ERR_UNSUPPORTED;
+    const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+    if (m && q.ldmask * 32 < q.N) return MML_ERR_UNSUPPORTED;
+    masks += m ? 1 : 0;
+    WsProblem& P = L.p[i];
+    P.A = q.A;
+    P.amaxA = q.amax_a;
+    P.planes = q.w_planes;
+    P.kexp = q.w_kexp;
+    P.C = q.C;
+    P.bias = q.bias;
+    P.mask = m ? q.relu_mask : nullptr;
+    P.amax_out = q.amax_out;
+    P.lda = q.lda;
+    P.ldp = q.ldw;
+    P.ldc = q.ldc;
+    P.ldmask = q.ldmask;
+    P.layout = q.w_kn ? MML_PLANES_COLS : MML_PLANES_ROWS;  // ([K, N]: the reduction runs down the rows)
+    P.relu = q.act == MML_ACT_RELU;
+  }
+  if (masks != 0 && masks != n) return MML_ERR_UNSUPPORTED;
+  L.M = d0.M;
+  L.n_prob = n;
+  L.wg_per_prob = wgp;
+  L.G = d0.K / 64;
+  return ws_launch<0>(L, d0.N, masks != 0, st);
+}
+
+int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t st) {
+  if (!ws_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
+  const mml_gemm_dgrad_desc& d0 = d[0];
+  if (d0.n_src != 1 || d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
+  const int32_t kred = d0.N[0];
+  if (kred <= 0 || kred % 64 != 0) return MML_ERR_UNSUPPORTED;
+  if (d0.K != 128 && d0.K != 256) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
+  if ((int64_t)d0.K * kred * 4 > WS_W_BYTES) return MML_ERR_UNSUPPORTED;
+  const int wgp = ws_cus() / n;
+  if (wgp < 1) return MML_ERR_UNSUPPORTED;
+  int masks = 0;
+  WsLaunch L{};
+  for (int i = 0; i < n; ++i) {
+    const mml_gemm_dgrad_desc& q = d[i];
+    if (q.n_src != 1 || q.gate_h || !q.dA) return MML_ERR_UNSUPPORTED;
+    if (q.M != d0.M || q.K != d0.K || q.N[0] != kred) return MML_ERR_UNSUPPORTED;
+    if (!q.dC[0] || !q.w_planes[0] || !q.w_kexp[0] || !q.amax_dc[0]) return MML_ERR_UNSUPPORTED;
+    const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+    if (q.act != MML_ACT_NONE && !m) return MML_ERR_UNSUPPORTED;  // (derivatives from the stored outputs: the tile kernel)
+    if (m && q.ldmask * 32 < q.K) return MML_ERR_UNSUPPORTED;
+    if (!aligned16(q.dC[0]) || q.lddc[0] % 4 != 0 || !aligned16(q.dA) || q.ldda % 4 != 0) return MML_ERR_UNSUPPORTED;
+    if (q.w_kn[0] && (!aligned16(q.w_planes[0]) || q.ldw[0] % 4 != 0)) return MML_ERR_UNSUPPORTED;
+    masks += m ? 1 : 0;
+    WsProblem& P = L.p[i];
+    P.A = q.dC[0];
+    P.amaxA = q.amax_dc[0];
+    P.planes = q.w_planes[0];
+    P.kexp = q.w_kexp[0];
+    P.C = q.dA;
+    P.mask = m ? const_cast<uint32_t*>(q.relu_mask) : nullptr;
+    P.amax_out = q.amax_out;
+    P.lda = q.lddc[0];
+    P.ldp = q.ldw[0];
+    P.ldc = q.ldda;
+    P.ldmask = q.ldmask;
+    P.layout = q.w_kn[0] ? MML_PLANES_ROWS : MML_PLANES_COLS;  // ([N, K]: the reduction runs down the rows)
+    P.accumulate = q.accumulate;
+  }
+  if (masks != 0 && masks != n) return MML_ERR_UNSUPPORTED;
+  L.M = d0.M;
+  L.n_prob = n;
+  L.wg_per_prob = wgp;
+  L.G = kred / 64;
+  return ws_launch<1>(L, d0.K, masks != 0, st);
+}

@@ -1,0 +1,242 @@
+"""The weight-stationary streaming kernel (csrc/gemm_ws.hip) against float64 and, bit for bit, against the tile kernel it
+replaces for the second expert layers, the towers and their input gradients (reference model/mmoe.py:69-119,
+model/utils.py:146-161; STAR's [K, N] layout: model/utils.py:171-218)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-6  # max-norm, against float64 (the two-plane fp16 arithmetic measures 3.3e-7)
+
+
+@pytest.fixture()
+def env():
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import _lib as L, ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    lib = L.load()
+    mode0 = lib.mml_gemm_get_mode()
+    yield torch, L, ops, lib
+    lib.mml_gemm_set_mode(mode0)
+    lib.mml_gemm_set_ws(1)
+
+
+def unpack(words, n):
+    w = words.cpu().numpy().view(np.uint32)
+    return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
+
+
+def fwd_launch(torch, L, ops, M, K, N, nprob, kn=False, acts=None, bias=True, seed=0, scale=1.0):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    slots = ops.amax_slots(3 * nprob, dev)
+    probs, items = [], []
+    for i in range(nprob):
+        A = (torch.randn(M, K, generator=g) * scale * (1 + i)).to(dev)
+        W = (torch.randn(*((K, N) if kn else (N, K)), generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev) if (bias and i % 3 != 2) else None
+        sa, sw, so = slots[3 * i], slots[3 * i + 1], slots[3 * i + 2]
+        ops.amax_batch([(A, sa), (W, sw)])
+        planes = torch.zeros(W.shape, dtype=torch.int32, device=dev)
+        kexp = torch.zeros(1, dtype=torch.int32, device=dev)
+        items.append((W, planes, ops.PLANES_COLS if kn else ops.PLANES_ROWS, [sw], kexp))
+        probs.append(dict(A=A, W=W, bias=b, act=(acts[i] if acts else L.ACT_RELU), w_kn=int(kn), amax_a=sa, amax_w=sw,
+                          w_planes=planes, w_kexp=kexp, amax_out=so))
+    ops.planes_cut(items)
+    return probs
+
+
+def run_fwd(torch, ops, lib, probs, ws, masks):
+    dev = torch.device("cuda:0")
+    lib.mml_gemm_set_ws(1 if ws else 0)
+    for p in probs:
+        M = p["A"].shape[0]
+        N = p["W"].shape[1] if p["w_kn"] else p["W"].shape[0]
+        p["C"] = torch.full((M, N), float("nan"), device=dev)
+        if masks:
+            p["mask"] = torch.full((M, (N + 31) // 32), 0x55555555, dtype=torch.int32, device=dev)
+        else:
+            p.pop("mask", None)
+        p["amax_out"].zero_()
+    ops.gemm_fwd(probs)
+    torch.cuda.synchronize()
+    name = lib.mml_gemm_last_kernel().decode()
+    return name, [(p["C"].clone(), p["mask"].clone() if masks else None, p["amax_out"].clone()) for p in probs]
+
+
+@pytest.mark.parametrize("M,K,N,nprob,kn,masks", [
+    (65536, 256, 128, 4, False, True),     # AE-30's second expert layer at the benchmark batch
+    (65536, 128, 64, 2, False, True),      # its towers
+    (8192 + 77, 256, 128, 3, False, False),  # ragged batch, three problems (85 workgroups each, one idle), inference
+    (8192, 64, 128, 1, False, True),       # one group of four k-steps
+    (16384 + 5, 192, 64, 5, True, True),   # STAR's [K, N] layout (planes cut down the rows), five domains
+    (40000, 128, 128, 16, False, False),   # sixteen problems
+])
+def test_ws_fwd_matches_float64_and_the_tile_kernel(env, M, K, N, nprob, kn, masks):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    probs = fwd_launch(torch, L, ops, M, K, N, nprob, kn=kn, seed=M + K)
+    name_w, out_w = run_fwd(torch, ops, lib, probs, True, masks)
+    assert name_w == "gemm_ws_kernel", name_w
+    name_t, out_t = run_fwd(torch, ops, lib, probs, False, masks)
+    assert "gemm_pipe_kernel" in name_t, name_t
+    for p, (C, mk, am), (Ct, mkt, amt) in zip(probs, out_w, out_t):
+        Wd = p["W"].double() if kn else p["W"].double().t()
+        z = p["A"].double() @ Wd
+        if p["bias"] is not None:
+            z = z + p["bias"].double()
+        ref = torch.relu(z)
+        err = float((C.double() - ref).abs().max() / ref.abs().max())
+        assert err < RTOL, err
+        assert torch.equal(C, Ct)                       # same planes, same product and k order: same bits
+        if masks:
+            assert np.array_equal(unpack(mk, N), (C > 0).cpu().numpy())
+            assert torch.equal(mk, mkt)
+        amax = float(torch.max(am.view(torch.float32)))
+        assert amax >= float(C.abs().max()) and amax <= float(C.abs().max()) * (1 + 1e-6)
+
+
+def test_ws_fwd_linear_layers_and_scales(env):
+    """No activation (negative outputs, magnitude of |v|), operands far outside fp16's own range."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    for scale in (3e-9, 1.0, 2e20):
+        probs = fwd_launch(torch, L, ops, 8192 + 33, 128, 128, 2, acts=[L.ACT_NONE, L.ACT_RELU], seed=3, scale=scale)
+        name, out = run_fwd(torch, ops, lib, probs, True, False)
+        assert name == "gemm_ws_kernel"
+        for p, (C, _, am) in zip(probs, out):
+            z = p["A"].double() @ p["W"].double().t()
+            if p["bias"] is not None:
+                z = z + p["bias"].double()
+            ref = torch.relu(z) if p["act"] == L.ACT_RELU else z
+            err = float((C.double() - ref).abs().max() / ref.abs().max())
+            assert err < RTOL, (scale, err)
+            amax = float(torch.max(am.view(torch.float32)))
+            assert amax >= float(C.abs().max()) and amax <= float(C.abs().max()) * (1 + 1e-6)
+
+
+def test_launches_the_ws_kernel_does_not_serve_fall_back(env):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    # a weight beyond the LDS, a reduction that is not a multiple of 64, a batch below the threshold, a sigmoid, an output
+    # width that is not instantiated
+    for M, K, N, acts in ((8192, 512, 128, None), (8192, 240, 128, None), (4096, 256, 128, None),
+                          (8192, 256, 128, [L.ACT_SIGMOID]), (8192, 256, 256, None)):
+        probs = fwd_launch(torch, L, ops, M, K, N, 1, acts=acts)
+        name, out = run_fwd(torch, ops, lib, probs, True, False)
+        assert name != "gemm_ws_kernel", (M, K, N, name)
+        z = probs[0]["A"].double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
+        ref = torch.sigmoid(z) if acts else torch.relu(z)
+        assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL
+
+
+def dgrad_launch(torch, L, ops, M, Nred, K, nprob, kn=False, relu=True, seed=0):
+    """dA [M, K] = dC [M, Nred] W, W = [Nred, K] (nn.Linear) or [K, Nred] (kn)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    slots = ops.amax_slots(3 * nprob, dev)
+    probs, items = [], []
+    for i in range(nprob):
+        dC = (torch.randn(M, Nred, generator=g) * (1 + i)).to(dev)
+        W = (torch.randn(*((K, Nred) if kn else (Nred, K)), generator=g) / Nred ** 0.5).to(dev)
+        Y = torch.relu(torch.randn(M, K, generator=g)).to(dev)
+        sd, sw, so = slots[3 * i], slots[3 * i + 1], slots[3 * i + 2]
+        ops.amax_batch([(dC, sd), (W, sw)])
+        planes = torch.zeros(W.shape, dtype=torch.int32, device=dev)
+        kexp = torch.zeros(1, dtype=torch.int32, device=dev)
+        items.append((W, planes, ops.PLANES_ROWS if kn else ops.PLANES_COLS, [sw], kexp))
+        bits = (Y > 0).cpu().numpy()
+        words = np.packbits(bits.reshape(M, K // 32, 32), axis=2, bitorder="little").view(np.uint32).reshape(M, K // 32)
+        mask = torch.from_numpy(words.view(np.int32).copy()).to(dev)
+        probs.append(dict(Y=Y, act=L.ACT_RELU if relu else L.ACT_NONE, mask=mask if relu else None, amax_out=so,
+                          srcs=[(dC, W, int(kn), sd, sw, planes, kexp)]))
+    ops.planes_cut(items)
+    return probs
+
+
+def run_dgrad(torch, ops, lib, probs, ws, accumulate):
+    dev = torch.device("cuda:0")
+    lib.mml_gemm_set_ws(1 if ws else 0)
+    g = torch.Generator(device="cpu").manual_seed(77)
+    olds = []
+    for p in probs:
+        M, K = p["Y"].shape
+        old = torch.randn(M, K, generator=g).to(dev)
+        olds.append(old)
+        p["dA"] = old.clone() if accumulate else torch.full((M, K), float("nan"), device=dev)
+        p["accumulate"] = int(accumulate)
+        p["amax_out"].zero_()
+    ops.gemm_dgrad(probs)
+    torch.cuda.synchronize()
+    name = lib.mml_gemm_last_kernel().decode()
+    return name, olds, [(p["dA"].clone(), p["amax_out"].clone()) for p in probs]
+
+
+@pytest.mark.parametrize("M,Nred,K,nprob,kn,relu,acc", [
+    (65536, 128, 256, 4, False, True, False),    # AE-30: input gradient of the second expert layer (two passes of 128)
+    (65536, 64, 128, 2, False, False, False),    # of the towers (no derivative: the mixed expert outputs)
+    (8192 + 77, 128, 256, 3, False, True, True),   # ragged, accumulating
+    (16384 + 5, 192, 128, 5, True, True, False),   # STAR's [K, N] layout
+    (8192, 64, 256, 1, False, False, True),
+])
+def test_ws_dgrad_matches_float64_and_the_tile_kernel(env, M, Nred, K, nprob, kn, relu, acc):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    probs = dgrad_launch(torch, L, ops, M, Nred, K, nprob, kn=kn, relu=relu, seed=M + K)
+    name_w, olds, out_w = run_dgrad(torch, ops, lib, probs, True, acc)
+    assert name_w == "gemm_ws_kernel", name_w
+    name_t, _, out_t = run_dgrad(torch, ops, lib, probs, False, acc)
+    assert "gemm_pipe_kernel" in name_t, name_t
+    for p, old, (dA, am), (dAt, amt) in zip(probs, olds, out_w, out_t):
+        dC, W = p["srcs"][0][:2]
+        v = dC.double() @ (W.double().t() if kn else W.double())
+        if relu:
+            v = v * (p["Y"] > 0).double()
+        if acc:
+            v = v + old.double()
+        err = float((dA.double() - v).abs().max() / v.abs().max())
+        assert err < RTOL, err
+        assert torch.equal(dA, dAt)
+        amax = float(torch.max(am.view(torch.float32)))
+        assert amax >= float(dA.abs().max()) and amax <= float(dA.abs().max()) * (1 + 1e-6)
+
+
+def test_dgrad_launches_the_ws_kernel_does_not_serve_fall_back(env):
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    # two sources; a derivative taken from the stored outputs (no sign mask); an output width that is not instantiated
+    probs = dgrad_launch(torch, L, ops, 8192, 128, 256, 2, seed=5)
+    two = [dict(probs[0], srcs=probs[0]["srcs"] + probs[1]["srcs"])]
+    name, _, out = run_dgrad(torch, ops, lib, two, True, False)
+    assert name != "gemm_ws_kernel"
+    v = sum(s[0].double() @ s[1].double() for s in two[0]["srcs"]) * (two[0]["Y"] > 0).double()
+    assert float((out[0][0].double() - v).abs().max() / v.abs().max()) < RTOL
+    noy = [dict(probs[0], mask=None)]
+    name, _, out = run_dgrad(torch, ops, lib, noy, True, False)
+    assert name != "gemm_ws_kernel"
+    probs = dgrad_launch(torch, L, ops, 8192, 128, 64, 1, seed=6)
+    name, _, _ = run_dgrad(torch, ops, lib, probs, True, False)
+    assert name != "gemm_ws_kernel"
+
+
+def test_ws_kernels_are_repeatable_on_a_full_chip(env):
+    """Race screen: the benchmark's launches twenty times each against the tile kernel's results, bit for bit."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    probs = fwd_launch(torch, L, ops, 65536, 256, 128, 4, seed=11)
+    _, ref = run_fwd(torch, ops, lib, probs, False, True)
+    for rep in range(20):
+        name, out = run_fwd(torch, ops, lib, probs, True, True)
+        assert name == "gemm_ws_kernel"
+        for i, ((C, mk, am), (Ct, mkt, amt)) in enumerate(zip(out, ref)):
+            assert torch.equal(C, Ct), (rep, i, int((C != Ct).sum()))
+            assert torch.equal(mk, mkt), (rep, i)
+            assert float(torch.max(am.view(torch.float32))) == float(torch.max(amt.view(torch.float32))), (rep, i)
+    dprobs = dgrad_launch(torch, L, ops, 65536, 128, 256, 4, seed=12)
+    _, _, dref = run_dgrad(torch, ops, lib, dprobs, False, False)
+    for rep in range(20):
+        name, _, out = run_dgrad(torch, ops, lib, dprobs, True, False)
+        assert name == "gemm_ws_kernel"
+        for i, ((dA, am), (dAt, amt)) in enumerate(zip(out, dref)):
+            assert torch.equal(dA, dAt), (rep, i, int((dA != dAt).sum()))
