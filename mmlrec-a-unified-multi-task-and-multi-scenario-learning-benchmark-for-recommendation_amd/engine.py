@@ -263,7 +263,7 @@ class Plan:
     def amax_call(self, need, **meta):
         arr = ops.make_amax_descs(need)
         self.keep.append(arr)
-        m = dict(kernel="amax_kernel", bytes=4.0 * sum(t.numel() for t, _ in need))
+        m = dict(kernel="amax_kernel", bytes=4.0 * sum(t.numel() for t, _ in need), need=list(need))
         m.update(meta)
         return (L.load().mml_amax_batch, (arr, len(need)), m)
 
@@ -395,16 +395,32 @@ class Plan:
         measure the stable weights, as the first entries of `fwd`.  Called when the whole plan has been recorded."""
         if self.amax_pool is None or not self.amax_next or self.n_pre:
             return
-        pre = [(L.load().mml_amax_reset, (self.amax_pool.data_ptr(), self.amax_next),
+        lib = L.load()
+        pre = [(lib.mml_amax_reset, (self.amax_pool.data_ptr(), self.amax_next),
                 dict(kernel="amax_reset", bytes=32.0 * self.amax_next))]
-        if self.amax_wlist:
-            pre.append(self.amax_call(self.amax_wlist))
+        cut = []
         if self.planes_items:  # (after the magnitudes of the weights: the cut reads them)
             arr = ops.make_planes_descs(self.planes_items)
             self.keep.append(arr)
-            pre.append((L.load().mml_gemm_planes_cut, (arr, len(self.planes_items)),
+            cut.append((lib.mml_gemm_planes_cut, (arr, len(self.planes_items)),
                         dict(kernel="planes_cut_kernel", bytes=8.0 * sum((it[0][0] if isinstance(it[0], tuple) else it[0]).numel()
                                                                         for it in self.planes_items))))
+        # The weights' magnitudes ride in the magnitude launch that stands in front of the first GEMM anyway (the pass over
+        # the gathered input): one launch fewer at the head of the step (~6 us of a 1.7 ms step).  Nothing in front of the
+        # first GEMM reads a weight's slot or planes.  MMLREC_AMAX_MERGE=0: the separate launch of round 3.
+        first_gemm = next((i for i, c in enumerate(self.fwd) if c[0] in (lib.mml_gemm_grouped_fwd, lib.mml_pep_gate_fwd)),
+                          len(self.fwd))
+        host = next((i for i, c in enumerate(self.fwd[:first_gemm]) if c[0] is lib.mml_amax_batch and
+                     isinstance(c[-1], dict) and "need" in c[-1]), None)
+        if self.amax_wlist and host is not None and os.environ.get("MMLREC_AMAX_MERGE", "1") != "0":
+            c = self.fwd[host]
+            merged = self.amax_call(c[-1]["need"] + self.amax_wlist,
+                                    **{k: v for k, v in c[-1].items() if k not in ("kernel", "bytes", "need")})
+            self.fwd = self.fwd[:host] + [merged] + cut + self.fwd[host + 1:]
+        else:
+            if self.amax_wlist:
+                pre.append(self.amax_call(self.amax_wlist))
+            pre += cut
         self.fwd = pre + self.fwd
         self.n_pre = len(pre)
 

@@ -121,7 +121,7 @@ def test_launches_the_panel_kernel_does_not_serve_fall_back(env):
                            (8192, 240, [128], [L.ACT_NONE]), (8192 + 77, 240, [128], None), (8192, 240, [192], None)):
         A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=False, acts=acts)
         name, out = run(torch, ops, lib, probs, M, True, False)
-        assert "gemm_pipe_kernel" in name, (M, K, name)
+        assert name != "gemm_panel_kernel", (M, K, name)   # (the tile kernel, or the weight-stationary one: K = 256)
         z = A.double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
         ref = torch.relu(z) if not acts else (torch.sigmoid(z) if acts[0] == L.ACT_SIGMOID else z)
         assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL

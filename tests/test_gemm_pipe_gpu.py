@@ -24,8 +24,10 @@ def env():
         pytest.skip("needs an MI355X")
     lib = L.load()
     mode0 = lib.mml_gemm_get_mode()
+    lib.mml_gemm_set_ws(0)     # this file pins the TILE kernel (the weight-stationary one: tests/test_gemm_ws_gpu.py)
     yield torch, L, ops, lib
     lib.mml_gemm_set_mode(mode0)
+    lib.mml_gemm_set_ws(1)
 
 
 def rel(a, b):
