@@ -31,7 +31,8 @@ using wf32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int WS_W_BYTES = 128 * 1024;              // the weight image
 constexpr int WS_BIAS_OFF = WS_W_BYTES;             // <= 256 bias values
 constexpr int WS_AMAX_OFF = WS_BIAS_OFF + 1024;     // the workgroup's magnitude word
-constexpr int WS_LDS_BYTES = WS_AMAX_OFF + 64;
+constexpr int WS_TURN_OFF = WS_AMAX_OFF + 64;       // eight waves x 2 KiB: 32 rows x 64 bytes turned row-major for the stores
+constexpr int WS_LDS_BYTES = WS_TURN_OFF + 8 * 2048;
 static_assert(WS_LDS_BYTES <= 160 * 1024, "weight-stationary kernel LDS budget");
 constexpr int WS_MIN_ROWS = 8192;                   // below: the tile kernel (a persistent grid would idle)
 struct WsProblem {
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
     return P.A + (int64_t)row * P.lda + 4 * h;
   };
   const f32x4_t* const wfrag = reinterpret_cast<const f32x4_t*>(lds) + lane;  // + 64 x (fragment number)
+  float* const turn = lds + WS_TURN_OFF / 4 + wave * 512;                       // this wave's row-major turn area
 
   if (rb < nrb) {
     // The raw fragments of the next four k-steps (plain loads: hipcc places the waits.  It gathers a group's refills behind
@@ -182,19 +184,55 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
             for (int ni = 0; ni < NS; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], Ah, acc[ni], 0, 0, 0);
           }
         }
-        // ---- the block's outputs: lane = batch row, registers = four runs of four columns (8 g + 4 h + j) ----
+        // ---- the block's outputs.  Accumulators: lane = batch row, registers = four runs of four columns (8 g + 4 h + j).
+        // Stored like that a wave-instruction writes 32 bytes of each of 32 rows -- partial lines the L2 has to merge: the
+        // second expert layer ran 89 us that way.  So every 16-column half of a sub-tile is turned row-major through the
+        // wave's 2 KiB of LDS: a lane then moves 16 bytes of a row and an instruction covers 16 rows x 64 contiguous bytes:
+        // 81 us (16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3): conflict-free both ways; a wave's LDS
+        // operations execute in order, so no barrier stands between the two directions).  Measured beside it: whole
+        // 128-byte lines through 4 KiB per wave, with the bias read from global memory to make room: 105 us; nontemporal
+        // stores 161 (32-byte pieces) / 95 (64) / 96 (128).
         const int row = rb * 32 + l31;
         const bool ok = row < M;
-        const int col0 = pass * NS * 32 + 4 * h;
-        float* const crow = P.C + (int64_t)row * P.ldc + col0;
+        const int colp = pass * NS * 32;                       // first column of the pass
+        float* const tw = turn + l31 * 16;                     // write side: row l31 (floats)
+        const int tR = lane >> 2, tc = lane & 3;               // read side: rows tR, tR + 16, logical chunk tc
+        const int orow = rb * 32 + tR;
+        float* const cst = P.C + (int64_t)orow * P.ldc + colp + 4 * tc;
+        const int64_t c16 = 16 * P.ldc;
+        const bool ok0 = orow < M, ok1 = orow + 16 < M;
+        auto turn_store = [&](const float4 va, const float4 vb, const int ni, const int half) __attribute__((always_inline)) {
+          // va / vb: this lane's runs g = 2 half, 2 half + 1 (columns 16 half + 4 h + {0..3}, + 8)
+          *reinterpret_cast<float4*>(tw + 4 * ((0 + h) ^ ((l31 >> 2) & 3))) = va;
+          *reinterpret_cast<float4*>(tw + 4 * ((2 + h) ^ ((l31 >> 2) & 3))) = vb;
+          asm volatile("" ::: "memory");
+          float4 q0 = *reinterpret_cast<const float4*>(turn + tR * 16 + 4 * (tc ^ ((tR >> 2) & 3)));
+          float4 q1 = *reinterpret_cast<const float4*>(turn + (tR + 16) * 16 + 4 * (tc ^ (((tR + 16) >> 2) & 3)));
+          float* const d0 = cst + ni * 32 + 16 * half;
+          if (MODE == 1 && P.accumulate) {
+            if (ok0) {
+              const float4 o = *reinterpret_cast<const float4*>(d0);
+              q0.x += o.x; q0.y += o.y; q0.z += o.z; q0.w += o.w;
+            }
+            if (ok1) {
+              const float4 o = *reinterpret_cast<const float4*>(d0 + c16);
+              q1.x += o.x; q1.y += o.y; q1.z += o.z; q1.w += o.w;
+            }
+            amax_acc(am, q0);
+            amax_acc(am, q1);
+          }
+          if (ok0) *reinterpret_cast<float4*>(d0) = q0;
+          if (ok1) *reinterpret_cast<float4*>(d0 + c16) = q1;
+        };
         if constexpr (MODE == 0) {
           const bool relu = P.relu != 0;
 #pragma unroll
           for (int ni = 0; ni < NS; ++ni) {
             uint32_t bits = 0u;
+            float4 vv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const float4 b4 = *reinterpret_cast<const float4*>(lds + WS_BIAS_OFF / 4 + col0 + ni * 32 + 8 * g);
+              const float4 b4 = *reinterpret_cast<const float4*>(lds + WS_BIAS_OFF / 4 + colp + 4 * h + ni * 32 + 8 * g);
               float4 v;
               v.x = acc[ni][4 * g] * inv + b4.x;
               v.y = acc[ni][4 * g + 1] * inv + b4.y;
@@ -209,8 +247,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
               amax_acc(am, v);
               if (MASKS)
                 bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (8 * g);
-              if (ok) *reinterpret_cast<float4*>(crow + ni * 32 + 8 * g) = v;
+              vv[g] = v;
             }
+            turn_store(vv[0], vv[1], ni, 0);
+            turn_store(vv[2], vv[3], ni, 1);
             if (MASKS) {  // the two lanes of a row hold the interleaved halves of its 32-column word
               const uint32_t mine = bits << (4 * h);
               const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
@@ -227,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
           }
 #pragma unroll
           for (int ni = 0; ni < NS; ++ni) {
+            float4 vv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float4 v;
@@ -241,17 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
                 if (!(nib & 4u)) v.z = 0.f;
                 if (!(nib & 8u)) v.w = 0.f;
               }
-              float* const dst = crow + ni * 32 + 8 * g;
-              if (accumulate && ok) {
-                const float4 o = *reinterpret_cast<const float4*>(dst);
-                v.x += o.x;
-                v.y += o.y;
-                v.z += o.z;
-                v.w += o.w;
-              }
-              amax_acc(am, v);
-              if (ok) *reinterpret_cast<float4*>(dst) = v;
+              if (!accumulate) amax_acc(am, v);  // (accumulating: the magnitude of the sums, taken behind the turn)
+              vv[g] = v;
             }
+            turn_store(vv[0], vv[1], ni, 0);
+            turn_store(vv[2], vv[3], ni, 1);
           }
         }
       }
