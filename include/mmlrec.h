@@ -231,7 +231,7 @@ int mml_gemm_get_mode(void);
  * (process-wide; default on; environment MMLREC_GEMM_PANEL=0 does the same). */
 int mml_gemm_set_panel(int32_t on);
 /* Weight-stationary streaming GEMM (csrc/gemm_ws.hip).  A forward launch whose problems have one shape with K % 64 == 0,
- * N in {64, 128}, N K <= 32 768 (the two fp16 planes of the weight fit 128 KiB of LDS), M >= 8 192, pre-cut planes
+ * N in {64, 128, 256}, N K <= 32 768 (the two fp16 planes of the weight fit 128 KiB of LDS), M >= 8 192, pre-cut planes
  * (either weight layout), the magnitude of A, activation relu or none -- and an input-gradient launch of single-source
  * problems of one shape with K in {128, 256} output columns, N % 64 == 0, N K <= 32 768, activation none or relu by
  * sign mask -- is served by persistent workgroups that keep one problem's weight planes in LDS while their waves

@@ -15,8 +15,8 @@
 //     meet the weight fragments from LDS in 3 x NS v_mfma_f32_32x32x16_f16 per k-step; the epilogue (unscale, bias /
 //     ReLU + sign mask, or the mask / accumulation of an input gradient) stores 16 bytes per lane (lane = batch row);
 //     the other wave of the SIMD computes meanwhile;
-//   * an output wider than 128 columns (the input gradient of a 256-wide layer) is swept in passes of 128 columns over
-//     the same rows (the second pass re-reads the block from the L1 / L2).
+//   * up to 256 output columns (eight 32-column sub-tiles of accumulators) per wave: the input gradient of a 256-wide
+//     layer reads its rows once.
 // Products, their order (W_l A_h, W_h A_l, W_h A_h per 16-k block) and the k order are those of gemm_pipe_kernel<..,
 // EMU = 2, BPL>: same bits (tests/test_gemm_ws_gpu.py).
 #include "common.hpp"
@@ -73,9 +73,9 @@ __device__ __forceinline__ int ws_scale_exp(uint32_t bits) {
 __device__ __forceinline__ float ws_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 // MODE 0: forward (bias, ReLU, sign mask out when MASKS); MODE 1: input gradient (sign mask in when MASKS, accumulation)
-template <int NS, int NPASS, int MODE, bool MASKS>
+template <int NS, int MODE, bool MASKS>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
-  constexpr int NSTOT = NS * NPASS;
+  constexpr int NSTOT = NS;
   __shared__ __attribute__((aligned(16))) float lds[WS_LDS_BYTES / 4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,18 +142,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
     }
     for (; rb < nrb; rb += stride) {
       const float* const ap_next = arow(rb + stride < nrb ? rb + stride : rb);
-#pragma unroll 1
-      for (int pass = 0; pass < NPASS; ++pass) {
+      {
         wf32x16 acc[NS];
 #pragma unroll
         for (int ni = 0; ni < NS; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-        const float* const unit_next = (pass + 1 < NPASS) ? ap : ap_next;
+        const float* const unit_next = ap_next;
 #pragma unroll 1
         for (int g = 0; g < G; ++g) {
           const float* const pf = (g + 1 < G) ? ap + 64 * (g + 1) : unit_next;
-          const f32x4_t* const wg_ = wfrag + (g * 8 * NSTOT + pass * NS) * 64;
+          const f32x4_t* const wg_ = wfrag + g * 8 * NSTOT * 64;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float x[8] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
@@ -194,11 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
         // stores 161 (32-byte pieces) / 95 (64) / 96 (128).
         const int row = rb * 32 + l31;
         const bool ok = row < M;
-        const int colp = pass * NS * 32;                       // first column of the pass
         float* const tw = turn + l31 * 16;                     // write side: row l31 (floats)
         const int tR = lane >> 2, tc = lane & 3;               // read side: rows tR, tR + 16, logical chunk tc
         const int orow = rb * 32 + tR;
-        float* const cst = P.C + (int64_t)orow * P.ldc + colp + 4 * tc;
+        float* const cst = P.C + (int64_t)orow * P.ldc + 4 * tc;
         const int64_t c16 = 16 * P.ldc;
         const bool ok0 = orow < M, ok1 = orow + 16 < M;
         auto turn_store = [&](const float4 va, const float4 vb, const int ni, const int half) __attribute__((always_inline)) {
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
             float4 vv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const float4 b4 = *reinterpret_cast<const float4*>(lds + WS_BIAS_OFF / 4 + colp + 4 * h + ni * 32 + 8 * g);
+              const float4 b4 = *reinterpret_cast<const float4*>(lds + WS_BIAS_OFF / 4 + 4 * h + ni * 32 + 8 * g);
               float4 v;
               v.x = acc[ni][4 * g] * inv + b4.x;
               v.y = acc[ni][4 * g + 1] * inv + b4.y;
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
               const uint32_t mine = bits << (4 * h);
               const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
               const uint32_t word = sw[0] | sw[1];
-              if (ok && h == 0) P.mask[(int64_t)row * P.ldmask + pass * NS + ni] = word;
+              if (ok && h == 0) P.mask[(int64_t)row * P.ldmask + ni] = word;
             }
           }
         } else {
@@ -263,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
           uint32_t mw[NS];
           if (MASKS) {
 #pragma unroll
-            for (int ni = 0; ni < NS; ++ni) mw[ni] = ok ? P.mask[(int64_t)row * P.ldmask + pass * NS + ni] : 0u;
+            for (int ni = 0; ni < NS; ++ni) mw[ni] = ok ? P.mask[(int64_t)row * P.ldmask + ni] : 0u;
           }
 #pragma unroll
           for (int ni = 0; ni < NS; ++ni) {
@@ -328,17 +326,19 @@ static int ws_cus() {
 template <int MODE>
 static int ws_launch(const WsLaunch& L, const int nout, const bool masks, hipStream_t st) {
   const dim3 g((unsigned)(L.wg_per_prob * L.n_prob)), b(512);
-#define WS_GO(NS_, NP_)                                                                  \
-  do {                                                                                   \
-    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, NP_, MODE, true>), g, b, 0, st, L);       \
-    else MML_LAUNCH((gemm_ws_kernel<NS_, NP_, MODE, false>), g, b, 0, st, L);            \
+#define WS_GO(NS_)                                                                  \
+  do {                                                                              \
+    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, true>), g, b, 0, st, L);       \
+    else MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false>), g, b, 0, st, L);            \
   } while (0)
   if constexpr (MODE == 0) {
-    if (nout == 128) WS_GO(4, 1);
-    else WS_GO(2, 1);
+    if (nout == 256) WS_GO(8);
+    else if (nout == 128) WS_GO(4);
+    else WS_GO(2);
   } else {
-    if (nout == 128) WS_GO(4, 1);
-    else WS_GO(4, 2);
+    if (nout == 128) WS_GO(4);
+    else WS_GO(8);  // (256 output columns: eight sub-tiles at once -- swept in two passes of four the rows were read twice
+                    //  from HBM, PMC 300 MB against 138 algorithmic: 106 -> 93 us)
   }
 #undef WS_GO
   return check_launch(MODE == 0 ? "mml_gemm_grouped_fwd(ws)" : "mml_gemm_grouped_dgrad(ws)");
@@ -359,7 +359,7 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   if (!ws_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_fwd_desc& d0 = d[0];
   if (d0.M < WS_MIN_ROWS || d0.K <= 0 || d0.K % 64 != 0) return MML_ERR_UNSUPPORTED;
-  if (d0.N != 128 && d0.N != 64) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
+  if (d0.N != 256 && d0.N != 128 && d0.N != 64) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
   if ((int64_t)d0.N * d0.K * 4 > WS_W_BYTES) return MML_ERR_UNSUPPORTED;
   const int wgp = ws_cus() / n;
   if (wgp < 1) return MML_ERR_UNSUPPORTED;

@@ -72,6 +72,7 @@ def run_fwd(torch, ops, lib, probs, ws, masks):
     (8192, 64, 128, 1, False, True),       # one group of four k-steps
     (16384 + 5, 192, 64, 5, True, True),   # STAR's [K, N] layout (planes cut down the rows), five domains
     (40000, 128, 128, 16, False, False),   # sixteen problems
+    (8192 + 64, 128, 256, 2, False, True),  # 256 output columns: eight sub-tiles of accumulators per wave
 ])
 def test_ws_fwd_matches_float64_and_the_tile_kernel(env, M, K, N, nprob, kn, masks):
     torch, L, ops, lib = env
@@ -119,10 +120,10 @@ def test_ws_fwd_linear_layers_and_scales(env):
 def test_launches_the_ws_kernel_does_not_serve_fall_back(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
-    # a weight beyond the LDS, a reduction that is not a multiple of 64, a batch below the threshold, a sigmoid, an output
-    # width that is not instantiated
+    # a weight beyond the LDS (twice), a reduction that is not a multiple of 64, a batch below the threshold, a sigmoid, an
+    # output width that is not instantiated
     for M, K, N, acts in ((8192, 512, 128, None), (8192, 240, 128, None), (4096, 256, 128, None),
-                          (8192, 256, 128, [L.ACT_SIGMOID]), (8192, 256, 256, None)):
+                          (8192, 256, 128, [L.ACT_SIGMOID]), (8192, 256, 256, None), (8192, 128, 192, None)):
         probs = fwd_launch(torch, L, ops, M, K, N, 1, acts=acts)
         name, out = run_fwd(torch, ops, lib, probs, True, False)
         assert name != "gemm_ws_kernel", (M, K, N, name)
@@ -174,7 +175,7 @@ def run_dgrad(torch, ops, lib, probs, ws, accumulate):
 
 
 @pytest.mark.parametrize("M,Nred,K,nprob,kn,relu,acc", [
-    (65536, 128, 256, 4, False, True, False),    # AE-30: input gradient of the second expert layer (two passes of 128)
+    (65536, 128, 256, 4, False, True, False),    # AE-30: input gradient of the second expert layer (eight sub-tiles per wave)
     (65536, 64, 128, 2, False, False, False),    # of the towers (no derivative: the mixed expert outputs)
     (8192 + 77, 128, 256, 3, False, True, True),   # ragged, accumulating
     (16384 + 5, 192, 128, 5, True, True, False),   # STAR's [K, N] layout

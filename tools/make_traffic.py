@@ -16,7 +16,7 @@ import sys
 
 def label(kernel_name, avg_bytes_hint=0):
     k = kernel_name.replace("void ", "").replace("mml::", "")
-    m = re.match(r"(gemm_pipe_kernel|gemm_glds_kernel|gemm_kernel|opt_dense_kernel)<([^>]+)>", k)
+    m = re.match(r"(gemm_pipe_kernel|gemm_panel_kernel|gemm_ws_kernel|gemm_glds_kernel|gemm_kernel|opt_dense_kernel)<([^>]+)>", k)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     for a, b in (("gather_vec4_kernel", "gather_vec4_kernel"), ("scatter_hash_kernel", "scatter_hash_kernel"),
