@@ -226,7 +226,7 @@ def kernel_breakdown(runner, batches, steps):
     # objects of a large plan) lands in it -- with one list per phase that was the table scatter, first of `bwd_tail`
     # (snr_trans_ae30 once reported 4 ms for an 87 us kernel)
     calls = (list(runner.plan.fwd) + list(runner.plan.head_train) + list(runner.plan.bwd) + list(runner.plan.bwd_tail) +
-             list(runner.plan.bwd_side) + list(runner.opt_calls))
+             list(getattr(runner.plan, "head_side", [])) + list(runner.plan.bwd_side) + list(runner.opt_calls))
     was = gc.isenabled()
     gc.disable()
     try:

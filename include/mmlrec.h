@@ -82,6 +82,15 @@ int mml_stream_destroy(mml_stream_t stream);
 int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
                    const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
                    float* out, int64_t ldo, int32_t* status, mml_stream_t stream);
+/* mml_gather_fwd that also leaves the magnitude of what it wrote: workgroup w stores the largest |value| of its part
+ * of `out` to wg_max[w] (plain stores, no atomics; wg_max_len = mml_gather_wgmax_len(F, E, Nd, B) values, all of them
+ * written by every call).  Feeding wg_max -- viewed as one row of floats -- to mml_amax_batch gives the magnitude slot of
+ * `out` from a few KB instead of a pass over the whole output.  Needs E % 4 == 0, ldo % 4 == 0 and 16-byte aligned
+ * tables and output (MML_ERR_ARG otherwise). */
+int64_t mml_gather_wgmax_len(int32_t F, int32_t E, int32_t Nd, int64_t B);
+int mml_gather_fwd_wgmax(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                         const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, float* out,
+                         int64_t ldo, float* wg_max, int64_t wg_max_len, int32_t* status, mml_stream_t stream);
 /* mml_gather_fwd that also marks every row it reads in row_marks (a byte per table row, layout and contract of
  * mml_scatter_bwd's row_marks): the split dense table update (mml_opt_tensor.skip_rows) gets the batch's row set from
  * the gather itself; mml_rows_compact then turns the marks into the `seen` bitmaps and the touched-row list
@@ -457,6 +466,12 @@ typedef struct {
 int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream);
 int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp);
 int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
+/* The same in two launches, like mml_gemm_grouped_wgrad_phase: phase 1 runs the row kernel (input gradients stored, the
+ * per-workgroup partial sums of dWg left in the workspace), phase 2 reduces them into dWg (phase 0 = both).  Only the
+ * optimizer reads dWg, so a trainer issues phase 2 off its backward chain (beside the weight-gradient GEMMs); the
+ * workspace must stay untouched between the two. */
+int mml_gate_mix_bwd_phase(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
+                           mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5  prediction heads + loss.
@@ -500,6 +515,10 @@ int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream);
 /* forward + loss + backward of the heads in one pass (training).  With y != NULL the loss is the summed BCE;
  * with y == NULL and dprob != NULL the heads are differentiated against the given upstream gradient. */
 int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
+/* The same in two launches: phase 1 = the row kernel (probabilities, dH), phase 2 = the reduction of the per-workgroup
+ * partial sums into dw / dbias / loss (phase 0 = both); see mml_gate_mix_bwd_phase. */
+int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
+                               mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6/K7  elementwise helpers for STAR / PepNet.

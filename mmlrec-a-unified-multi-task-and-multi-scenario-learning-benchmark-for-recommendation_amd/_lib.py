@@ -114,6 +114,8 @@ _SIGS = {
     "mml_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _PP(C.c_void_p)]),
     "mml_stream_destroy": (C.c_int, [C.c_void_p]),
     "mml_gather_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
+    "mml_gather_wgmax_len": (i64, [i32, i32, i32, i64]),
+    "mml_gather_fwd_wgmax": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, i64, fp, fp]),
     "mml_gather_fwd_mark": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp, fp]),
     "mml_rows_compact": (C.c_int, [_PP(fp), _PP(i64), _PP(i64), i32, fp, fp, i32, fp, fp]),
     "mml_gather_fwd_idx32": (C.c_int, [_PP(fp), _PP(i64), i32, i32, fp, i64, fp, i64, i32, i64, fp, i64, fp, fp]),
@@ -153,9 +155,11 @@ _SIGS = {
     "mml_gate_mix_fwd": (C.c_int, [_PP(GateGroup), fp]),
     "mml_gate_mix_bwd_workspace_bytes": (i64, [_PP(GateGroup)]),
     "mml_gate_mix_bwd": (C.c_int, [_PP(GateGroup), fp, i64, fp]),
+    "mml_gate_mix_bwd_phase": (C.c_int, [_PP(GateGroup), fp, i64, i32, fp]),
     "mml_head_workspace_bytes": (i64, [_PP(HeadGroup)]),
     "mml_head_fwd": (C.c_int, [_PP(HeadGroup), fp]),
     "mml_head_bce_fwd_bwd": (C.c_int, [_PP(HeadGroup), fp, i64, fp]),
+    "mml_head_bce_fwd_bwd_phase": (C.c_int, [_PP(HeadGroup), fp, i64, i32, fp]),
     "mml_ew_mul": (C.c_int, [fp, fp, fp, i64, fp]),
     "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
     "mml_ew_mul_bwd_act": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, i32, i32, fp]),

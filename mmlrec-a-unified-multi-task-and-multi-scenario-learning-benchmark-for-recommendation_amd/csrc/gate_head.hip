@@ -348,8 +348,17 @@ extern "C" int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp) {
 
 extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes,
                                 mml_stream_t stream) {
+  return mml_gate_mix_bwd_phase(grp, workspace, workspace_bytes, 0, stream);
+}
+
+// phase 1: the row kernel (input gradients stored, per-workgroup partial sums of dWg left in the workspace); phase 2: the
+// reduction of those partial sums into dWg; 0: both.  (Which kernel phase 1 ran is a function of the group alone, so
+// phase 2 finds the same layout.)
+extern "C" int mml_gate_mix_bwd_phase(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
+                                      mml_stream_t stream) {
   int rc = check_gate_group(grp, true, "mml_gate_mix_bwd");
   if (rc) return rc;
+  MML_REQUIRE(phase >= 0 && phase <= 2, "mml_gate_mix_bwd_phase: bad phase");
   if (grp->B == 0) return MML_OK;
   {
     GateFastAux fa{};
@@ -357,9 +366,12 @@ extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int6
       MML_REQUIRE(workspace && (int64_t)fa.grid * fa.wg_total * 4 <= workspace_bytes,
                   "mml_gate_mix_bwd: workspace too small");
       fa.slab = static_cast<float*>(workspace);
-      rc = gate_bwd_fast(grp, fa, to_stream(stream));
+      rc = 0;
+      if (phase != 2) rc = gate_bwd_fast(grp, fa, to_stream(stream));
+      else if (!gate_bwd_fast_serves(grp, fa)) rc = 1;
       if (rc < 0) return rc;
       if (rc == 0) {
+        if (phase == 1) return MML_OK;
         ReduceLaunch R{};
         int64_t start = 0;
         for (int i = 0; i < grp->n_gates; ++i) {
@@ -382,9 +394,12 @@ extern "C" int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int6
   const size_t lds = (size_t)(tot + ROW_WAVES * MML_MAX_GATES * MML_MAX_EXPERTS) * 4;
   MML_REQUIRE(lds <= 64 * 1024, "mml_gate_mix_bwd: gate weights too large for the LDS accumulators (%zu B)", lds);
   aux.slab = static_cast<float*>(workspace);
-  MML_LAUNCH(gate_mix_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), lds, to_stream(stream), *grp, aux);
-  rc = check_launch("mml_gate_mix_bwd");
-  if (rc) return rc;
+  if (phase != 2) {
+    MML_LAUNCH(gate_mix_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), lds, to_stream(stream), *grp, aux);
+    rc = check_launch("mml_gate_mix_bwd");
+    if (rc) return rc;
+  }
+  if (phase == 1) return MML_OK;
   ReduceLaunch R{};
   int64_t start = 0;
   for (int i = 0; i < grp->n_gates; ++i) {
@@ -443,6 +458,14 @@ extern "C" int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream) {
 
 extern "C" int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t workspace_bytes,
                                     mml_stream_t stream) {
+  return mml_head_bce_fwd_bwd_phase(grp, workspace, workspace_bytes, 0, stream);
+}
+
+// phase 1: the row kernel (probabilities, input gradients; per-workgroup partial sums of dw / dbias / loss left in the
+// workspace); phase 2: their reduction; 0: both
+extern "C" int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
+                                          mml_stream_t stream) {
+  MML_REQUIRE(phase >= 0 && phase <= 2, "mml_head_bce_fwd_bwd_phase: bad phase");
   int hmax;
   int rc = check_head_group(grp, true, "mml_head_bce_fwd_bwd", hmax);
   if (rc) return rc;
@@ -457,14 +480,17 @@ extern "C" int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, 
   if (fast) grid = fa.grid;
   MML_REQUIRE(workspace && (int64_t)grid * aux.stride * 4 <= workspace_bytes, "mml_head_bce_fwd_bwd: workspace too small");
   aux.slab = static_cast<float*>(workspace);
-  if (fast) {
-    fa.slab = aux.slab; fa.stride = aux.stride; fa.train = 1;
-    rc = head_fast(grp, fa, to_stream(stream));
-  } else {
-    MML_LAUNCH(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
-    rc = check_launch("mml_head_bce_fwd_bwd");
+  if (phase != 2) {
+    if (fast) {
+      fa.slab = aux.slab; fa.stride = aux.stride; fa.train = 1;
+      rc = head_fast(grp, fa, to_stream(stream));
+    } else {
+      MML_LAUNCH(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
+      rc = check_launch("mml_head_bce_fwd_bwd");
+    }
+    if (rc) return rc;
   }
-  if (rc) return rc;
+  if (phase == 1) return MML_OK;
   ReduceLaunch R{};
   int64_t start = 0;
   for (int t = 0; t < grp->n_heads; ++t) {

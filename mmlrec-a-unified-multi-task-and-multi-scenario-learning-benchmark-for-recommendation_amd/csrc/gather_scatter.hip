@@ -33,6 +33,7 @@ struct GatherArgs {
   int32_t* status;
   uint8_t* marks;  // optional: a byte per table row (layout of mml_scatter_bwd's row_marks), set for every row read
   int64_t markbase[MML_MAX_FIELDS];
+  float* wgmax;    // optional (mml_gather_fwd_wgmax): workgroup w stores the largest |value| it wrote to wgmax[w]
 };
 
 // Reference semantics of X[:, c].long(): truncation toward zero (model/basemodel.py:476).
@@ -58,8 +59,9 @@ __device__ __forceinline__ int64_t load_index(const GatherArgs& a, int64_t b, in
 
 // One thread = one 16-byte piece of the output row (E % 4 == 0) or one dense scalar.
 // ITEMS (index -> row -> store) chains per thread; launched with ITEMS = 1 (see launch_gather).
-template <int ITEMS>
+template <int ITEMS, bool WGMAX = false>
 __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, const GatherArgs a) {
+  float am = 0.f;  // (WGMAX) the largest |value| this thread stored
   const int e4 = a.E >> 2;
   const int nvec = a.F * e4;             // 16-byte pieces per sample
   const int per_sample = nvec + a.Nd;    // + dense scalars
@@ -98,18 +100,34 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, c
         }
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
-        if (b0 + i < a.B) *reinterpret_cast<float4*>(a.out + (b0 + i) * a.ldo + (int64_t)c * 4) = v[i];
+        if (b0 + i < a.B) {
+          *reinterpret_cast<float4*>(a.out + (b0 + i) * a.ldo + (int64_t)c * 4) = v[i];
+          if (WGMAX) amax_acc(am, v[i]);
+        }
     } else {
       const int j = c - nvec;
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
         if (b0 + i < a.B) {
           const int64_t b = b0 + i;
-          a.out[b * a.ldo + (int64_t)a.F * a.E + j] = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+          const float d = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
+          a.out[b * a.ldo + (int64_t)a.F * a.E + j] = d;
+          if (WGMAX) amax_acc(am, d);
         }
     }
   }
   if (bad && a.status) atomicOr(a.status, bad);
+  if (WGMAX) {
+    // The magnitude of the gathered input without a pass over it and without atomics (15 000 workgroups raising one slot
+    // cost +0.1 ms, common.hpp): ONE plain store per workgroup; the consumer's magnitude launch reads these 60 KB instead
+    // of the 63 MB of the output.
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) a.wgmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  }
 }
 
 // north_star's "LDS-staged index dedup", measured rather than argued: the tables with at most kLdsRows rows
@@ -203,7 +221,7 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
       const char* e = getenv("MMLREC_GATHER_LDS");
       use_lds = e ? atoi(e) : 0;  // n > 0: the persistent LDS-staged variant with n workgroups per CU (measurement knob)
     }
-    if (use_lds > 0 && !a.marks) {
+    if (use_lds > 0 && !a.marks && !a.wgmax) {
       SmallTabs st{};
       int off = 0;
       for (int f = 0; f < a.F; ++f) {
@@ -222,9 +240,11 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
     const int64_t total = cdiv(a.B, (int64_t)items) * per_sample;
     int64_t blocks = cdiv(total, (int64_t)threads);
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;  // (grid-stride beyond that)
-    if (items == 4) MML_LAUNCH(gather_vec4_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    if (a.wgmax) MML_LAUNCH((gather_vec4_kernel<1, true>), dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    else if (items == 4) MML_LAUNCH(gather_vec4_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
     else MML_LAUNCH(gather_vec4_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
   } else {
+    MML_REQUIRE(!a.wgmax, "mml_gather_fwd_wgmax: needs E %% 4 == 0, ldo %% 4 == 0 and 16-byte aligned tables and output");
     const int64_t total = a.B * ((int64_t)a.F * a.E + a.Nd);
     int64_t blocks = cdiv(total, threads);
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -839,6 +859,32 @@ extern "C" int mml_gather_fwd(const float* const* tables, const int64_t* vocab, 
   GatherArgs a{};
   a.X = X; a.ldX = ldX; a.F = F; a.E = E; a.dense_col0 = dense_col0; a.Nd = Nd; a.B = B;
   a.out = out; a.ldo = ldo; a.status = status;
+  return launch_gather(ft, a, to_stream(stream));
+}
+
+// number of workgroups (= partial maxima) mml_gather_fwd_wgmax writes for these sizes
+extern "C" int64_t mml_gather_wgmax_len(int32_t F, int32_t E, int32_t Nd, int64_t B) {
+  if (F <= 0 || E <= 0 || E % 4 != 0 || Nd < 0 || B <= 0) return 0;
+  const int64_t per_sample = (int64_t)F * (E / 4) + Nd;
+  const int64_t blocks = cdiv(B * per_sample, (int64_t)256);
+  return blocks > 0x7fffffff ? 0 : blocks;
+}
+
+extern "C" int mml_gather_fwd_wgmax(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F,
+                                    int32_t E, const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B,
+                                    float* out, int64_t ldo, float* wg_max, int64_t wg_max_len, int32_t* status,
+                                    mml_stream_t stream) {
+  FieldTable ft;
+  int rc = fill_fields(ft, tables, vocab, col, F, "mml_gather_fwd_wgmax");
+  if (rc) return rc;
+  MML_REQUIRE(B > 0 && E > 0 && Nd >= 0 && X && out && wg_max, "mml_gather_fwd_wgmax: bad arguments");
+  MML_REQUIRE(ldo >= (int64_t)F * E + Nd, "mml_gather_fwd_wgmax: ldo=%lld < F*E+Nd", (long long)ldo);
+  const int64_t need = mml_gather_wgmax_len(F, E, Nd, B);
+  MML_REQUIRE(need > 0 && wg_max_len == need, "mml_gather_fwd_wgmax: wg_max_len must be mml_gather_wgmax_len() = %lld",
+              (long long)need);
+  GatherArgs a{};
+  a.X = X; a.ldX = ldX; a.F = F; a.E = E; a.dense_col0 = dense_col0; a.Nd = Nd; a.B = B;
+  a.out = out; a.ldo = ldo; a.status = status; a.wgmax = wg_max;
   return launch_gather(ft, a, to_stream(stream));
 }
 

@@ -807,8 +807,13 @@ static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipS
   return check_launch("mml_gate_mix_bwd(fast)");
 }
 
+bool gate_bwd_fast_serves(const mml_gate_group* g, const GateFastAux& aux) {
+  (void)g;
+  return gate_bwd_fast_lds(aux) <= 60 * 1024;
+}
+
 int gate_bwd_fast(const mml_gate_group* g, GateFastAux& aux, hipStream_t st) {
-  if (gate_bwd_fast_lds(aux) > 60 * 1024) return 1;
+  if (!gate_bwd_fast_serves(g, aux)) return 1;
   if (aux.lps == 16) return launch_gate_bwd<16>(*g, aux, st);
   if (aux.lps == 32) return launch_gate_bwd<32>(*g, aux, st);
   return launch_gate_bwd<64>(*g, aux, st);

@@ -24,6 +24,8 @@ int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux&
 // return 1 = not handled (caller falls back), MML_OK, or a negative error
 int gate_fwd_fast(const mml_gate_group* g, hipStream_t st);
 int gate_bwd_fast(const mml_gate_group* g, GateFastAux& aux, hipStream_t st);
+// whether gate_bwd_fast takes the group (the reduction phase of mml_gate_mix_bwd_phase must find the layout phase 1 used)
+bool gate_bwd_fast_serves(const mml_gate_group* g, const GateFastAux& aux);
 int head_fast(const mml_head_group* g, const HeadFastAux& aux, hipStream_t st);
 
 }  // namespace mml

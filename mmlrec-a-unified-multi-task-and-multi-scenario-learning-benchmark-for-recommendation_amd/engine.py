@@ -79,6 +79,7 @@ class Plan:
         # HBM-bound table optimizer), `bwd_side` = every weight-gradient GEMM (MFMA-bound, needs only values the
         # chain has already produced).  Sequential order bwd -> bwd_tail -> bwd_side is always valid.
         self.bwd_tail, self.bwd_side = [], []
+        self.head_side = []  # the deferred reduction of the fused head call (dw / dbias / loss): beside `bwd_side`
         self.keep = []  # ctypes descriptor blocks + buffers referenced by raw pointer
         # dropout (DropoutOp): on iff the MODULE is in training mode; the step word of its mask stream is read from
         # `step_dev` (the optimizer's device step counter when the model has one, else a counter of the plan's own)
@@ -245,7 +246,9 @@ class Plan:
             return None
         if v.amax is None:
             v.amax = self.new_amax()
-            need.append((view, v.amax))
+            # (a producer may have left partial maxima of the whole value: a bound of any view of it)
+            src = getattr(v, "amax_src", None)
+            need.append((src if src is not None else view, v.amax))
         return v.amax
 
     def grad_amax(self, v, need):
@@ -333,6 +336,7 @@ class Plan:
         self._run(self.head_train)
         self._run(self.bwd)
         self._run(self.bwd_tail)
+        self._run(self.head_side)
         self._run(self.bwd_side)
 
     def run_backward_from_dprob(self):
@@ -362,7 +366,11 @@ class Plan:
         if not self.training:
             self._amax_prologue()
             return
-        self.head_train = head_op.train_calls(self, use_dprob=False)
+        calls = head_op.train_calls(self, use_dprob=False)
+        is_side = lambda c: isinstance(c[-1], dict) and c[-1].get("side")  # noqa: E731
+        self.head_train = [c for c in calls if not is_side(c)]
+        # (belongs to head_train, not to the backward every path shares: run_backward_from_dprob has its own head call)
+        self.head_side = [c for c in calls if is_side(c)]
         self.head_bwd = head_op.train_calls(self, use_dprob=True, claim=False)
         for op in reversed(self.ops):
             for v in op.outputs():
@@ -550,9 +558,19 @@ class GatherOp(Op):
                     (lib.mml_rows_compact, (ps, vocab, rb, F, mr.touched.data_ptr(), mr.count.data_ptr(),
                                             mr.touched.numel(), mr.marks.data_ptr()),
                      dict(kernel="rows_compact_kernel", bytes=float(mr.marks.numel())))]
+        out = self.out.buf
+        nwg = int(lib.mml_gather_wgmax_len(F, E, self.nd, plan.B)) if plan.amax_pool is not None else 0
+        if (nwg > 0 and os.environ.get("MMLREC_GATHER_WGMAX", "1") != "0" and ops._ld(out) % 4 == 0 and
+                out.data_ptr() % 16 == 0 and all(t.data.data_ptr() % 16 == 0 for t in self.tables)):
+            # the magnitude of the gathered input comes out of the gather itself: one value per workgroup, read by the
+            # magnitude launch in front of the first GEMM instead of a pass over the whole output (25 -> 6 us at 65 536)
+            wg = plan.zeros(1, nwg)
+            self.out.amax_src = wg
+            return [(lib.mml_gather_fwd_wgmax, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X),
+                                                self.dense_col0, self.nd, plan.B, out.data_ptr(), ops._ld(out),
+                                                wg.data_ptr(), nwg, plan.status.data_ptr()), meta)]
         return [(lib.mml_gather_fwd, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), self.dense_col0,
-                                      self.nd, plan.B, self.out.buf.data_ptr(), ops._ld(self.out.buf),
-                                      plan.status.data_ptr()), meta)]
+                                      self.nd, plan.B, out.data_ptr(), ops._ld(out), plan.status.data_ptr()), meta)]
 
     def bwd_calls(self, plan):
         if self.out.grad is None or not any(t.needs_grad for t in self.tables):
@@ -934,12 +952,32 @@ class GateGroupOp(Op):
             for g in self.gates:
                 if g["mix"].grad is not None:
                     g["G"].gamax, g["G"].gamax_writers = s_dg, g["G"].written
-        ws = ops.workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)), plan.device)
+        nws = int(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(grp)))
+        # (deferred reduction: the partial sums must survive until the side list runs -- a buffer of this op's own, not the
+        # shared scratch every other call overwrites)
+        ws = (torch.empty(max(nws, 256), dtype=torch.uint8, device=plan.device) if _defer_reduce()
+              else ops.workspace(nws, plan.device))
         plan.keep += [grp, ws]
         act = [g for g in self.gates if g["mix"].grad is not None]
         byts = 4.0 * plan.B * (2 * len(self.experts) * self.H + sum(2 * g["G"].n + len(g["expert"]) + self.H for g in act))
+        if _defer_reduce():
+            # only the optimizer reads dWg: the reduction of the per-workgroup partial sums leaves the backward chain and
+            # runs beside the weight-gradient GEMMs (the workspace is this op's own)
+            return [(lib.mml_gate_mix_bwd_phase, (C.byref(grp), ws.data_ptr(), ws.numel(), 1),
+                     dict(kernel="gate_bwd_kernel", bytes=byts)),
+                    (lib.mml_gate_mix_bwd_phase, (C.byref(grp), ws.data_ptr(), ws.numel(), 2),
+                     dict(kernel="slab_reduce", bytes=float(ws.numel()), side=True, rank=1))]
         return [(lib.mml_gate_mix_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
                  dict(kernel="gate_bwd_kernel", bytes=byts))]
+
+
+def _defer_reduce():
+    """MMLREC_DEFER_REDUCE=1: the reductions of the gate / head kernels' partial sums (only the optimizer reads their
+    results) leave the backward chain and run beside the weight-gradient GEMMs (mml_gate_mix_bwd_phase,
+    mml_head_bce_fwd_bwd_phase).  Off by default: two launches fewer on the chain (-18 us in a serial trace of the AE-30
+    step), but the two-stream step measured 1.702 against 1.666 ms with it (three interleaved pairs, round 4) -- the step
+    is bound by what its kernels take from HBM and the CUs together, not by the length of the chain."""
+    return os.environ.get("MMLREC_DEFER_REDUCE", "0") == "1"
 
 
 class HeadOp(Op):
@@ -1033,9 +1071,19 @@ class HeadOp(Op):
         if use_dprob and plan.dprob is None:
             plan.dprob = plan.empty(plan.B, len(self.heads))
         grp, post = self._group(plan, True, use_dprob, claim)
-        ws = ops.workspace(lib.mml_head_workspace_bytes(C.byref(grp)), plan.device)
+        defer = not use_dprob and not post and _defer_reduce()
+        nws = int(lib.mml_head_workspace_bytes(C.byref(grp)))
+        ws = (torch.empty(max(nws, 256), dtype=torch.uint8, device=plan.device) if defer  # (its own: see GateGroupOp)
+              else ops.workspace(nws, plan.device))
         plan.keep.append(ws)
         byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
+        if defer:
+            # (dw / dbias / loss are read by the optimizer and the host only: their reduction runs beside the
+            # weight-gradient GEMMs; Plan.finish moves the call tagged `side` out of the head's list)
+            return [(lib.mml_head_bce_fwd_bwd_phase, (C.byref(grp), ws.data_ptr(), ws.numel(), 1),
+                     dict(kernel="head_kernel", bytes=byts)),
+                    (lib.mml_head_bce_fwd_bwd_phase, (C.byref(grp), ws.data_ptr(), ws.numel(), 2),
+                     dict(kernel="slab_reduce", bytes=float(ws.numel()), side=True, rank=1, ready=0))]
         return [(lib.mml_head_bce_fwd_bwd, (C.byref(grp), ws.data_ptr(), ws.numel()),
                  dict(kernel="head_kernel", bytes=byts))] + post
 

@@ -163,6 +163,24 @@ def gather_fwd(tables, X, cols, dense_col0=0, nd=0, out=None, status=None):
     return out
 
 
+def gather_fwd_wgmax(tables, X, cols, dense_col0=0, nd=0, out=None, status=None):
+    """gather_fwd that also returns the per-workgroup maxima of |out| (include/mmlrec.h: mml_gather_fwd_wgmax)."""
+    lib = L.load()
+    _need_gpu(X, *tables)
+    X = _f32_2d(X, "X")
+    F, E, B = len(tables), tables[0].shape[1], X.shape[0]
+    if out is None:
+        out = torch.empty((B, F * E + nd), dtype=torch.float32, device=X.device)
+    n = int(lib.mml_gather_wgmax_len(F, E, nd, B))
+    wg = torch.full((1, max(n, 1)), float("nan"), dtype=torch.float32, device=X.device)
+    vocab = (L.i64 * F)(*[t.shape[0] for t in tables])
+    col = (L.i32 * F)(*cols)
+    rc = lib.mml_gather_fwd_wgmax(_ptr_array(tables), vocab, col, F, E, X.data_ptr(), _ld(X), dense_col0, nd, B,
+                                  out.data_ptr(), _ld(out), wg.data_ptr(), n, L.ptr(status), _stream())
+    L.check(rc, "mml_gather_fwd_wgmax")
+    return out, wg
+
+
 def gather_fwd_idx32(tables, idx, dense=None, out=None, status=None):
     lib = L.load()
     _need_gpu(idx, *tables)
@@ -502,9 +520,15 @@ def gate_mix_fwd(group):
     L.check(lib.mml_gate_mix_fwd(C.byref(group), _stream()), "mml_gate_mix_fwd")
 
 
-def gate_mix_bwd(group, device):
+def gate_mix_bwd(group, device, phases=False):
+    """phases: the two-launch form (row kernel, then the reduction of its partial sums)."""
     lib = L.load()
     ws = workspace(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(group)), device)
+    if phases:
+        for ph in (1, 2):
+            L.check(lib.mml_gate_mix_bwd_phase(C.byref(group), ws.data_ptr(), ws.numel(), ph, _stream()),
+                    "mml_gate_mix_bwd_phase")
+        return
     L.check(lib.mml_gate_mix_bwd(C.byref(group), ws.data_ptr(), ws.numel(), _stream()), "mml_gate_mix_bwd")
 
 
@@ -545,9 +569,14 @@ def head_fwd(group):
     L.check(lib.mml_head_fwd(C.byref(group), _stream()), "mml_head_fwd")
 
 
-def head_bce_fwd_bwd(group, device):
+def head_bce_fwd_bwd(group, device, phases=False):
     lib = L.load()
     ws = workspace(lib.mml_head_workspace_bytes(C.byref(group)), device)
+    if phases:
+        for ph in (1, 2):
+            L.check(lib.mml_head_bce_fwd_bwd_phase(C.byref(group), ws.data_ptr(), ws.numel(), ph, _stream()),
+                    "mml_head_bce_fwd_bwd_phase")
+        return
     L.check(lib.mml_head_bce_fwd_bwd(C.byref(group), ws.data_ptr(), ws.numel(), _stream()), "mml_head_bce_fwd_bwd")
 
 

@@ -195,14 +195,16 @@ class TrainStep:
         self.side_a = Segments(side_a, self.use_graph, min_calls=1) if k else None
         self.ev_fork_a = torch.cuda.Event() if k else None
         self.early_fork = k
-        self.sideq = Segments(p.bwd_side[len(side_a):] + ar + self.opt_split["mlp"], self.use_graph)
+        head_side = list(getattr(p, "head_side", []))
+        self.sideq = Segments(head_side + p.bwd_side[len(side_a):] + ar + self.opt_split["mlp"], self.use_graph)
         self.tail = Segments(p.bwd_tail + wait + self.opt_split["tables"], self.use_graph)
         # one stream: the whole step is ONE call list (one HIP graph when it holds no Python-issued entry) -- every graph
         # seam is ~16 us of idle stream, a tenth of a small-batch step
         self.whole = None
         if not self.overlap and not self.split_dense:
             self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
-                                  self.opt_split["tables"] + p.bwd_side + ar + self.opt_split["mlp"], self.use_graph)
+                                  self.opt_split["tables"] + head_side + p.bwd_side + ar + self.opt_split["mlp"],
+                                  self.use_graph)
         self.calls = 0
         self._nX = self._ny = None  # staging buffers of a prefetched batch
         self._has_next = False

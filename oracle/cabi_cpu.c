@@ -517,6 +517,17 @@ int mml_head_bce_fwd_bwd(const mml_head_group* g, void* workspace, int64_t works
   (void)workspace; (void)workspace_bytes; (void)stream;
   return heads(g, 1);
 }
+/* the two-launch forms of include/mmlrec.h: here phase 1 (and 0) does everything, phase 2 has nothing left to reduce */
+int mml_head_bce_fwd_bwd_phase(const mml_head_group* g, void* workspace, int64_t workspace_bytes, int32_t phase,
+                               mml_stream_t stream) {
+  REQUIRE(phase >= 0 && phase <= 2, "mml_head_bce_fwd_bwd_phase: bad phase");
+  return phase == 2 ? MML_OK : mml_head_bce_fwd_bwd(g, workspace, workspace_bytes, stream);
+}
+int mml_gate_mix_bwd_phase(const mml_gate_group* g, void* workspace, int64_t workspace_bytes, int32_t phase,
+                           mml_stream_t stream) {
+  REQUIRE(phase >= 0 && phase <= 2, "mml_gate_mix_bwd_phase: bad phase");
+  return phase == 2 ? MML_OK : mml_gate_mix_bwd(g, workspace, workspace_bytes, stream);
+}
 
 /* ------------------------------------------------------------------------------------------------ K8 */
 int mml_opt_step_dense(const mml_opt_tensor* t, int32_t n, const mml_opt_hyper* h, mml_stream_t stream) {

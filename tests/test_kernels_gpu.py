@@ -53,6 +53,30 @@ def test_gather_bit_exact(ops, E, nd, B):
     assert np.array_equal(out2.cpu().numpy().view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("E,nd,B", [(8, 0, 65536), (16, 4, 333), (8, 64, 4096)])
+def test_gather_workgroup_maxima(ops, E, nd, B):
+    """mml_gather_fwd_wgmax: the same output bits, and per-workgroup maxima whose maximum IS the magnitude of the output
+    (fed to mml_amax_batch as one row of floats: the slot the stand-alone pass over the output would give)."""
+    rng = np.random.default_rng(1)
+    vocab = [3, 100, 5000, 70000]
+    F = len(vocab)
+    tabs = [T((rng.standard_normal((v, E)) * (10.0 ** (f - 2))).astype(np.float32)) for f, v in enumerate(vocab)]
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    X = T(np.concatenate([idx.astype(np.float32), -50.0 * rng.random((B, nd), dtype=np.float32)], 1))
+    ref = ops.gather_fwd(tabs, X, list(range(F)), F, nd)
+    out, wg = ops.gather_fwd_wgmax(tabs, X, list(range(F)), F, nd)
+    assert torch.equal(out, ref)
+    assert not torch.isnan(wg).any() and float(wg.min()) >= 0.0     # every workgroup wrote its value
+    assert float(wg.max()) == float(ref.abs().max())
+    slots = ops.amax_slots(2, dev())
+    ops.amax_batch([(wg, slots[0]), (ref, slots[1])])
+    torch.cuda.synchronize()
+    assert int(slots[0].max()) == int(slots[1].max())
+    # E not a multiple of 4: no partial maxima (the caller keeps the stand-alone pass)
+    import mmlrec_amd._lib as L_
+    assert L_.load().mml_gather_wgmax_len(F, 6, 0, B) == 0
+
+
 def test_gather_out_of_range_sets_status(ops):
     tabs = [torch.zeros(10, 8, device=dev())]
     X = torch.tensor([[3.0], [10.0], [-1.0]], device=dev())
@@ -253,6 +277,18 @@ def test_gate_mix_fwd_bwd(ops, B, H, nexp, gate_sets, Gd):
         if "ref_dG" in q:
             assert rel(q["dG"].cpu().numpy(), q["ref_dG"]) < 2e-5
             assert rel(q["dWg"].cpu().numpy(), q["ref_dWg"]) < 2e-5
+    # the two-launch form (mml_gate_mix_bwd_phase: row kernel, then the reduction of its partial sums): the same bits
+    act = [q for q in gd if "ref_dG" in q]
+    one_w, one_g = [q["dWg"].clone() for q in act], [q["dG"].clone() for q in act]
+    for q in act:
+        q["dWg"].fill_(float("nan"))
+    dE2 = [torch.full((B, H), 7.0, device=dev()) for _ in range(nexp)]
+    ops.gate_mix_bwd(ops.make_gate_group(Et, gd, B, H, d_experts=dE2), dev(), phases=True)
+    for q, w_, g_ in zip(act, one_w, one_g):
+        # (the generic kernel -- H = 300 here -- sums dWg with LDS float atomics: its order, hence the last bit, varies run to run)
+        assert rel(q["dWg"].cpu().numpy(), w_.cpu().numpy()) < 1e-6 and torch.equal(q["dG"], g_)
+    for a_, b_ in zip(dEt, dE2):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize("B,H,T_,masked", [(1000, 64, 2, False), (333, 16, 4, True), (64, 200, 1, False)])
@@ -290,6 +326,17 @@ def test_head_bce(ops, B, H, T_, masked):
     prob2 = torch.empty(B, T_, device=dev())
     ops.head_fwd(ops.make_head_group(heads, prob2, mask=T(mask) if masked else None))
     assert torch.equal(prob, prob2)
+    # the two-launch form (mml_head_bce_fwd_bwd_phase): the same bits
+    keep = [(h["dw"].clone(), h["dbias"].clone(), h["dH"].clone()) for h in heads]
+    for h in heads:
+        h["dw"].fill_(float("nan"))
+        h["dbias"].fill_(float("nan"))
+    loss2 = torch.full((1,), float("nan"), device=dev())
+    ops.head_bce_fwd_bwd(ops.make_head_group(heads, prob, y=T(y), mask=T(mask) if masked else None, loss=loss2), dev(),
+                         phases=True)
+    assert float(loss2.item()) == float(loss.item())
+    for h, (w_, b_, d_) in zip(heads, keep):
+        assert torch.equal(h["dw"], w_) and torch.equal(h["dbias"], b_) and torch.equal(h["dH"], d_)
 
 
 @pytest.mark.parametrize("H", [64, 200])
