@@ -49,7 +49,9 @@ def _worker(rank, world, port, jobs, ret):
         from conftest import load_golden
         from test_models_gpu import build, load_state
         out = []
-        for case_name, mode, kind, tu, graph in jobs:
+        for job in jobs:
+            case_name, mode, kind, tu, graph = job[:5]
+            prefetch = len(job) > 5 and job[5]
             g = load_golden(case_name)
             model, cfg = build(g, table_update=tu)
             load_state(model, g)
@@ -59,16 +61,30 @@ def _worker(rank, world, port, jobs, ret):
             mode = mode.replace("_nodedup", "")
             par = parallel.shard_model(model, dist, 64 // world, mode=mode, dedup=dedup)
             losses = []
+            # prefetch: the index-only half of the next batch's exchange (counts all-to-all included) runs on the routing
+            # stream while the step is in flight (TrainStep.prefetch; bench.py's loop) -- on TWO ranks here
+            pre = prefetch and mode == "row_sharded" and graph
+            batches = [(torch.from_numpy(g[f"X{i}"])[rank::world].contiguous().cuda(),
+                        torch.from_numpy(g[f"y{i}"])[rank::world].contiguous().cuda()) for i in range(3)]
             for i in range(3):
-                X = torch.from_numpy(g[f"X{i}"])[rank::world].contiguous().cuda()
-                y = torch.from_numpy(g[f"y{i}"])[rank::world].contiguous().cuda()
+                X, y = batches[i]
                 step = model.train_step_runner(X.shape[0], use_graph=graph)
-                step.plan.X.copy_(X)
-                step.plan.y.copy_(y)
+                if pre:
+                    if not step._has_next:
+                        step.load(X, y)
+                    else:
+                        assert i > 0
+                else:
+                    step.plan.X.copy_(X)
+                    step.plan.y.copy_(y)
                 step.run()
+                if pre and i + 1 < 3:
+                    step.prefetch(*batches[i + 1])
                 lt = step.plan.loss.detach().clone().double()
                 par.comm.all_reduce(lt)
                 losses.append(float(lt.item()))
+            if pre:
+                step.drop_prefetch()
             sd = model.state_dict()  # flushes lazy rows and synchronises the tables (collective)
             bad = _check_state(sd, g, f"{kind}3", cfg["optim_config"]["lr"], 3)
             ok_loss = bool(np.allclose(losses, g[f"{kind}_losses"], rtol=RTOL))
@@ -182,6 +198,7 @@ def test_world2_steps_match_reference_trajectories():
             jobs.append((case_name, mode, "adam", "dense_exact", True))
             jobs.append((case_name, mode, "adagrad", "sparse_rows", False))
         jobs.append((case_name, "row_sharded", "adam", "lazy_exact", True))
+        jobs.append((case_name, "row_sharded", "adam", "dense_exact", True, True))   # + prefetched routing
         jobs.append((case_name, "row_sharded_nodedup", "adam", "dense_exact", True))
         jobs.append((case_name, "row_sharded_nodedup", "adagrad", "sparse_rows", False))
         jobs.append((case_name, "replicated", "adam", "lazy_exact", False))
