@@ -52,12 +52,13 @@ class STAR(BaseModel):
             ws.stable = bs.stable = True  # (constants: their magnitude is taken once, at the start of a step)
         wsh, bsh = store.pvals[f"{prefix}.shared_weight"], store.pvals[f"{prefix}.shared_bias"]
         weff = E.PVal(plan.empty(*wsh.data.shape), plan.zeros(*wsh.data.shape), f"{prefix}.weff.{d}")
-        # K6 (MMLREC_STAR_PLANES=1): the GEMMs take the derived weight as planes cut straight from its two factors
-        # (mml_gemm_planes_cut with W2, mml_star_linear_fwd / _bwd); the fp32 product below is still formed for the heads
-        # and as the shape the weight gradient is chained through.  Measured on Amazon-8 at 65 536 (round 4, same box):
-        # serial 692.5 vs 693.1 us (GEMMs -5 us, magnitudes -9 us, the start-of-step cut +16 us), two-stream 0.687 vs
-        # 0.676 ms -- level to a 1.5 % loss, so it is opt-in.
-        if os.environ.get("MMLREC_STAR_PLANES", "0") == "1":
+        # K6: the GEMMs take the derived weight as planes cut straight from its two factors (mml_gemm_planes_cut with W2,
+        # mml_star_linear_fwd / _bwd); the fp32 product below is still formed for the heads and as the shape the weight
+        # gradient is chained through.  Amazon-8 at 65 536 (round 4, same box, three interleaved pairs): with the tile kernel
+        # alone this was level (0.687 vs 0.676 ms: GEMMs -5 us, magnitudes -9 us, the start-of-step cut +16 us); with the
+        # weight-stationary kernel, which needs pre-cut planes and now serves these [K, N] layers, 0.6435 vs 0.6604 ms
+        # (101.8 vs 99.2 M samples/s).  MMLREC_STAR_PLANES=0: the in-kernel cut of the stored product.
+        if os.environ.get("MMLREC_STAR_PLANES", "1") != "0":
             weff.factors = (ws, wsh)
         beff = E.PVal(plan.empty(*bsh.data.shape), plan.zeros(*bsh.data.shape), f"{prefix}.beff.{d}")
         # (collected: ALL derived parameters of the model are produced by one batched launch, see _build_graph)

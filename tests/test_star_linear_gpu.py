@@ -180,10 +180,10 @@ def test_star_model_steps_from_product_planes(env, monkeypatch):
     dev = torch.device("cuda:0")
     B = 8192
     monkeypatch.setenv("MMLREC_AMAX", "1")
-    monkeypatch.setenv("MMLREC_STAR_PLANES", "1")
 
     def one(planes):
         monkeypatch.setenv("MMLREC_GEMM_PLANES", "1" if planes else "0")
+        monkeypatch.setenv("MMLREC_STAR_PLANES", "1" if planes else "0")
         torch.manual_seed(3)
         model, cfg, vocab, dense = W.build_model("star_amazon", dev)
         T = W.num_tasks(cfg)
