@@ -46,13 +46,13 @@ struct WsProblem {
   uint32_t* amax_out;
   int64_t lda, ldp, ldc, ldmask;
   int32_t layout;          // MML_PLANES_ROWS: planes[out col][k]; MML_PLANES_COLS: planes[k][out col]
-  int32_t relu;            // forward: ReLU
+  int32_t act;             // forward: MML_ACT_NONE / RELU / SIGMOID / SIGMOID2
   int32_t accumulate;      // input gradient: C +=
-  int32_t pad_;
+  int32_t G;               // groups of four k-steps (Kred = 64 G)
 };
 
 struct WsLaunch {
-  int32_t M, n_prob, wg_per_prob, G;  // G: groups of four k-steps (Kred = 64 G)
+  int32_t M, n_prob, wg_per_prob, pad_;
   WsProblem p[MML_MAX_GROUP];
 };
 static_assert(sizeof(WsLaunch) <= 4096, "WsLaunch must fit the kernel-argument block");
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
   const int pi = (int)blockIdx.x / L.wg_per_prob;
   const int wl = (int)blockIdx.x - pi * L.wg_per_prob;
   const WsProblem& P = L.p[pi];
-  const int G = L.G, KB = 4 * G, M = L.M;
+  const int G = P.G, KB = 4 * G, M = L.M;
 
   // ---- the problem's weight planes -> LDS, fragment order: [k-step][plane][32-column sub-tile][lane] x 16 bytes ----
   {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
           if (ok1) *reinterpret_cast<float4*>(d0 + c16) = q1;
         };
         if constexpr (MODE == 0) {
-          const bool relu = P.relu != 0;
+          const int act = P.act;  // (uniform)
 #pragma unroll
           for (int ni = 0; ni < NS; ++ni) {
             uint32_t bits = 0u;
@@ -236,11 +236,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
               v.y = acc[ni][4 * g + 1] * inv + b4.y;
               v.z = acc[ni][4 * g + 2] * inv + b4.z;
               v.w = acc[ni][4 * g + 3] * inv + b4.w;
-              if (relu) {
+              if (act == MML_ACT_RELU) {
                 v.x = __builtin_fmaxf(v.x, 0.f);
                 v.y = __builtin_fmaxf(v.y, 0.f);
                 v.z = __builtin_fmaxf(v.z, 0.f);
                 v.w = __builtin_fmaxf(v.w, 0.f);
+              } else if (act != MML_ACT_NONE) {  // sigmoid, or PepNet's 2 sigmoid: the tile kernel's expressions
+                const float two = act == MML_ACT_SIGMOID2 ? 2.f : 1.f;
+                v.x = two / (1.f + __expf(-v.x));
+                v.y = two / (1.f + __expf(-v.y));
+                v.z = two / (1.f + __expf(-v.z));
+                v.w = two / (1.f + __expf(-v.w));
               }
               amax_acc(am, v);
               if (MASKS)
@@ -336,7 +342,8 @@ static int ws_launch(const WsLaunch& L, const int nout, const bool masks, hipStr
     else if (nout == 128) WS_GO(4);
     else WS_GO(2);
   } else {
-    if (nout == 128) WS_GO(4);
+    if (nout == 64) WS_GO(2);
+    else if (nout == 128) WS_GO(4);
     else WS_GO(8);  // (256 output columns: eight sub-tiles at once -- swept in two passes of four the rows were read twice
                     //  from HBM, PMC 300 MB against 138 algorithmic: 106 -> 93 us)
   }
@@ -354,94 +361,122 @@ extern "C" int mml_gemm_set_ws(int32_t on) {
 }
 
 // Both return MML_OK when the weight-stationary kernel took the launch and MML_ERR_UNSUPPORTED (no error text) when the
-// launch is not one it serves: the caller then runs the tile kernel.
+// launch is not one it serves: the caller then runs the tile kernel.  A launch whose problems differ in shape (PepNet's
+// and PLE's layers: 128- and 64-wide siblings in one call) is served as one kernel launch per (output width, sign masks)
+// class -- all of its problems must qualify.
+static bool ws_fwd_ok(const mml_gemm_fwd_desc& q, const mml_gemm_fwd_desc& d0) {
+  if (q.M != d0.M || q.K <= 0 || q.K % 64 != 0) return false;
+  if (q.N != 256 && q.N != 128 && q.N != 64) return false;  // (the instantiated output widths)
+  if ((int64_t)q.N * q.K * 4 > WS_W_BYTES) return false;
+  if (!q.A || !q.C || !q.w_planes || !q.w_kexp || !q.amax_a) return false;
+  if (q.mul || q.prod) return false;  // (K7 products: the tile kernel's epilogue)
+  if (q.act != MML_ACT_RELU && q.act != MML_ACT_NONE && q.act != MML_ACT_SIGMOID && q.act != MML_ACT_SIGMOID2) return false;
+  if (!aligned16(q.A) || q.lda % 4 != 0 || !aligned16(q.C) || q.ldc % 4 != 0) return false;
+  if (!q.w_kn && (!aligned16(q.w_planes) || q.ldw % 4 != 0)) return false;
+  if (q.act == MML_ACT_RELU && q.relu_mask && q.ldmask * 32 < q.N) return false;
+  return true;
+}
+
 int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   if (!ws_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_fwd_desc& d0 = d[0];
-  if (d0.M < WS_MIN_ROWS || d0.K <= 0 || d0.K % 64 != 0) return MML_ERR_UNSUPPORTED;
-  if (d0.N != 256 && d0.N != 128 && d0.N != 64) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
-  if ((int64_t)d0.N * d0.K * 4 > WS_W_BYTES) return MML_ERR_UNSUPPORTED;
-  const int wgp = ws_cus() / n;
-  if (wgp < 1) return MML_ERR_UNSUPPORTED;
-  int masks = 0;
-  WsLaunch L{};
+  if (d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i)
+    if (!ws_fwd_ok(d[i], d0)) return MML_ERR_UNSUPPORTED;
+  bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
-    const mml_gemm_fwd_desc& q = d[i];
-    if (q.M != d0.M || q.K != d0.K || q.N != d0.N) return MML_ERR_UNSUPPORTED;
-    if (!q.A || !q.C || !q.w_planes || !q.w_kexp || !q.amax_a) return MML_ERR_UNSUPPORTED;
-    if (q.mul || q.prod) return MML_ERR_UNSUPPORTED;  // (K7 products: the tile kernel's epilogue)
-    if (q.act != MML_ACT_RELU && q.act != MML_ACT_NONE) return MML_ERR_UNSUPPORTED;
-    if (!aligned16(q.A) || q.lda % 4 != 0 || !aligned16(q.C) || q.ldc % 4 != 0) return MML_ERR_UNSUPPORTED;
-    if (!q.w_kn && (!aligned16(q.w_planes) || q.ldw % 4 != 0)) return MML_ERR_UNSUPPORTED;
-    const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-    if (m && q.ldmask * 32 < q.N) return MML_ERR_UNSUPPORTED;
-    masks += m ? 1 : 0;
-    WsProblem& P = L.p[i];
-    P.A = q.A;
-    P.amaxA = q.amax_a;
-    P.planes = q.w_planes;
-    P.kexp = q.w_kexp;
-    P.C = q.C;
-    P.bias = q.bias;
-    P.mask = m ? q.relu_mask : nullptr;
-    P.amax_out = q.amax_out;
-    P.lda = q.lda;
-    P.ldp = q.ldw;
-    P.ldc = q.ldc;
-    P.ldmask = q.ldmask;
-    P.layout = q.w_kn ? MML_PLANES_COLS : MML_PLANES_ROWS;  // ([K, N]: the reduction runs down the rows)
-    P.relu = q.act == MML_ACT_RELU;
+    if (done[i]) continue;
+    const bool mi = d[i].act == MML_ACT_RELU && d[i].relu_mask != nullptr;
+    WsLaunch L{};
+    for (int j = i; j < n; ++j) {
+      const mml_gemm_fwd_desc& q = d[j];
+      const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+      if (done[j] || q.N != d[i].N || m != mi) continue;
+      done[j] = true;
+      WsProblem& P = L.p[L.n_prob++];
+      P.A = q.A;
+      P.amaxA = q.amax_a;
+      P.planes = q.w_planes;
+      P.kexp = q.w_kexp;
+      P.C = q.C;
+      P.bias = q.bias;
+      P.mask = m ? q.relu_mask : nullptr;
+      P.amax_out = q.amax_out;
+      P.lda = q.lda;
+      P.ldp = q.ldw;
+      P.ldc = q.ldc;
+      P.ldmask = q.ldmask;
+      P.layout = q.w_kn ? MML_PLANES_COLS : MML_PLANES_ROWS;  // ([K, N]: the reduction runs down the rows)
+      P.act = q.act;
+      P.G = q.K / 64;
+    }
+    L.M = d0.M;
+    L.wg_per_prob = ws_cus() / L.n_prob;
+    if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;  // (more problems than CUs: not before the first launch only in theory)
+    const int rc = ws_launch<0>(L, d[i].N, mi, st);
+    if (rc != MML_OK) return rc;
   }
-  if (masks != 0 && masks != n) return MML_ERR_UNSUPPORTED;
-  L.M = d0.M;
-  L.n_prob = n;
-  L.wg_per_prob = wgp;
-  L.G = d0.K / 64;
-  return ws_launch<0>(L, d0.N, masks != 0, st);
+  return MML_OK;
+}
+
+static bool ws_dgrad_ok(const mml_gemm_dgrad_desc& q, const mml_gemm_dgrad_desc& d0) {
+  if (q.n_src != 1 || q.gate_h || !q.dA || q.M != d0.M) return false;
+  const int32_t kred = q.N[0];
+  if (kred <= 0 || kred % 64 != 0) return false;
+  if (q.K != 64 && q.K != 128 && q.K != 256) return false;  // (the instantiated output widths)
+  if ((int64_t)q.K * kred * 4 > WS_W_BYTES) return false;
+  if (!q.dC[0] || !q.w_planes[0] || !q.w_kexp[0] || !q.amax_dc[0]) return false;
+  const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+  if (q.act != MML_ACT_NONE && !m) return false;  // (derivatives from the stored outputs: the tile kernel)
+  if (m && q.ldmask * 32 < q.K) return false;
+  if (!aligned16(q.dC[0]) || q.lddc[0] % 4 != 0 || !aligned16(q.dA) || q.ldda % 4 != 0) return false;
+  if (q.w_kn[0] && (!aligned16(q.w_planes[0]) || q.ldw[0] % 4 != 0)) return false;
+  return true;
 }
 
 int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t st) {
   if (!ws_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_dgrad_desc& d0 = d[0];
-  if (d0.n_src != 1 || d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
-  const int32_t kred = d0.N[0];
-  if (kred <= 0 || kred % 64 != 0) return MML_ERR_UNSUPPORTED;
-  if (d0.K != 128 && d0.K != 256) return MML_ERR_UNSUPPORTED;  // (the instantiated output widths)
-  if ((int64_t)d0.K * kred * 4 > WS_W_BYTES) return MML_ERR_UNSUPPORTED;
-  const int wgp = ws_cus() / n;
-  if (wgp < 1) return MML_ERR_UNSUPPORTED;
-  int masks = 0;
-  WsLaunch L{};
+  if (d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i)
+    if (!ws_dgrad_ok(d[i], d0)) return MML_ERR_UNSUPPORTED;
+  // (problems of one launch may write the same dA -- accumulate -- in order: classes are launched in the order of their
+  // first member and keep their members' order; two problems with one target in DIFFERENT classes would be reordered)
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (d[i].dA == d[j].dA && (d[i].K != d[j].K || (d[i].relu_mask != nullptr) != (d[j].relu_mask != nullptr)))
+        return MML_ERR_UNSUPPORTED;
+  bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
-    const mml_gemm_dgrad_desc& q = d[i];
-    if (q.n_src != 1 || q.gate_h || !q.dA) return MML_ERR_UNSUPPORTED;
-    if (q.M != d0.M || q.K != d0.K || q.N[0] != kred) return MML_ERR_UNSUPPORTED;
-    if (!q.dC[0] || !q.w_planes[0] || !q.w_kexp[0] || !q.amax_dc[0]) return MML_ERR_UNSUPPORTED;
-    const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-    if (q.act != MML_ACT_NONE && !m) return MML_ERR_UNSUPPORTED;  // (derivatives from the stored outputs: the tile kernel)
-    if (m && q.ldmask * 32 < q.K) return MML_ERR_UNSUPPORTED;
-    if (!aligned16(q.dC[0]) || q.lddc[0] % 4 != 0 || !aligned16(q.dA) || q.ldda % 4 != 0) return MML_ERR_UNSUPPORTED;
-    if (q.w_kn[0] && (!aligned16(q.w_planes[0]) || q.ldw[0] % 4 != 0)) return MML_ERR_UNSUPPORTED;
-    masks += m ? 1 : 0;
-    WsProblem& P = L.p[i];
-    P.A = q.dC[0];
-    P.amaxA = q.amax_dc[0];
-    P.planes = q.w_planes[0];
-    P.kexp = q.w_kexp[0];
-    P.C = q.dA;
-    P.mask = m ? const_cast<uint32_t*>(q.relu_mask) : nullptr;
-    P.amax_out = q.amax_out;
-    P.lda = q.lddc[0];
-    P.ldp = q.ldw[0];
-    P.ldc = q.ldda;
-    P.ldmask = q.ldmask;
-    P.layout = q.w_kn[0] ? MML_PLANES_ROWS : MML_PLANES_COLS;  // ([N, K]: the reduction runs down the rows)
-    P.accumulate = q.accumulate;
+    if (done[i]) continue;
+    const bool mi = d[i].act == MML_ACT_RELU && d[i].relu_mask != nullptr;
+    WsLaunch L{};
+    for (int j = i; j < n; ++j) {
+      const mml_gemm_dgrad_desc& q = d[j];
+      const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+      if (done[j] || q.K != d[i].K || m != mi) continue;
+      done[j] = true;
+      WsProblem& P = L.p[L.n_prob++];
+      P.A = q.dC[0];
+      P.amaxA = q.amax_dc[0];
+      P.planes = q.w_planes[0];
+      P.kexp = q.w_kexp[0];
+      P.C = q.dA;
+      P.mask = m ? const_cast<uint32_t*>(q.relu_mask) : nullptr;
+      P.amax_out = q.amax_out;
+      P.lda = q.lddc[0];
+      P.ldp = q.ldw[0];
+      P.ldc = q.ldda;
+      P.ldmask = q.ldmask;
+      P.layout = q.w_kn[0] ? MML_PLANES_ROWS : MML_PLANES_COLS;  // ([N, K]: the reduction runs down the rows)
+      P.accumulate = q.accumulate;
+      P.G = q.N[0] / 64;
+    }
+    L.M = d0.M;
+    L.wg_per_prob = ws_cus() / L.n_prob;
+    if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;
+    const int rc = ws_launch<1>(L, d[i].K, mi, st);
+    if (rc != MML_OK) return rc;
   }
-  if (masks != 0 && masks != n) return MML_ERR_UNSUPPORTED;
-  L.M = d0.M;
-  L.n_prob = n;
-  L.wg_per_prob = wgp;
-  L.G = kred / 64;
-  return ws_launch<1>(L, d0.K, masks != 0, st);
+  return MML_OK;
 }

@@ -28,11 +28,15 @@ def unpack(words, n):
 
 
 def fwd_launch(torch, L, ops, M, K, N, nprob, kn=False, acts=None, bias=True, seed=0, scale=1.0):
+    """K, N: one value for all problems, or a list with one value per problem."""
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(seed)
     slots = ops.amax_slots(3 * nprob, dev)
     probs, items = [], []
+    Ks = K if isinstance(K, (list, tuple)) else [K] * nprob
+    Ns = N if isinstance(N, (list, tuple)) else [N] * nprob
     for i in range(nprob):
+        K, N = Ks[i], Ns[i]
         A = (torch.randn(M, K, generator=g) * scale * (1 + i)).to(dev)
         W = (torch.randn(*((K, N) if kn else (N, K)), generator=g) / K ** 0.5).to(dev)
         b = torch.randn(N, generator=g).to(dev) if (bias and i % 3 != 2) else None
@@ -117,18 +121,44 @@ def test_ws_fwd_linear_layers_and_scales(env):
             assert amax >= float(C.abs().max()) and amax <= float(C.abs().max()) * (1 + 1e-6)
 
 
+def test_ws_fwd_mixed_widths_and_gate_activations(env):
+    """PepNet's / PLE's sibling layers: 128- and 64-wide problems with different reductions in ONE call (served as one
+    launch per width), and the gate networks' sigmoid / 2 sigmoid outputs -- float64, and the tile kernel's bits."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    M = 8192 + 32
+    Ns = [64, 128, 128, 64, 256]
+    Ks = [64, 64, 128, 192, 128]
+    acts = [L.ACT_RELU, L.ACT_SIGMOID2, L.ACT_SIGMOID, L.ACT_NONE, L.ACT_SIGMOID2]
+    probs = fwd_launch(torch, L, ops, M, Ks, Ns, 5, acts=acts, seed=21)
+    name_w, out_w = run_fwd(torch, ops, lib, probs, True, False)
+    assert name_w == "gemm_ws_kernel", name_w
+    name_t, out_t = run_fwd(torch, ops, lib, probs, False, False)
+    assert "gemm_pipe_kernel" in name_t
+    for p, (C, _, am), (Ct, _, _) in zip(probs, out_w, out_t):
+        z = p["A"].double() @ p["W"].double().t()
+        if p["bias"] is not None:
+            z = z + p["bias"].double()
+        ref = {L.ACT_RELU: torch.relu(z), L.ACT_NONE: z, L.ACT_SIGMOID: torch.sigmoid(z),
+               L.ACT_SIGMOID2: 2 * torch.sigmoid(z)}[p["act"]]
+        assert float((C.double() - ref).abs().max() / ref.abs().max()) < RTOL
+        assert torch.equal(C, Ct)
+        amax = float(torch.max(am.view(torch.float32)))
+        assert amax >= float(C.abs().max()) and amax <= float(C.abs().max()) * (1 + 1e-6)
+
+
 def test_launches_the_ws_kernel_does_not_serve_fall_back(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
-    # a weight beyond the LDS (twice), a reduction that is not a multiple of 64, a batch below the threshold, a sigmoid, an
-    # output width that is not instantiated
+    # a weight beyond the LDS (twice), a reduction that is not a multiple of 64, a batch below the threshold, an output
+    # width that is not instantiated
     for M, K, N, acts in ((8192, 512, 128, None), (8192, 240, 128, None), (4096, 256, 128, None),
-                          (8192, 256, 128, [L.ACT_SIGMOID]), (8192, 256, 256, None), (8192, 128, 192, None)):
+                          (8192, 256, 256, None), (8192, 128, 192, None)):
         probs = fwd_launch(torch, L, ops, M, K, N, 1, acts=acts)
         name, out = run_fwd(torch, ops, lib, probs, True, False)
         assert name != "gemm_ws_kernel", (M, K, N, name)
         z = probs[0]["A"].double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
-        ref = torch.sigmoid(z) if acts else torch.relu(z)
+        ref = torch.relu(z)
         assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL
 
 
@@ -180,6 +210,7 @@ def run_dgrad(torch, ops, lib, probs, ws, accumulate):
     (8192 + 77, 128, 256, 3, False, True, True),   # ragged, accumulating
     (16384 + 5, 192, 128, 5, True, True, False),   # STAR's [K, N] layout
     (8192, 64, 256, 1, False, False, True),
+    (8192 + 96, 128, 64, 4, False, True, False),   # 64 output columns (PepNet's gate networks)
 ])
 def test_ws_dgrad_matches_float64_and_the_tile_kernel(env, M, Nred, K, nprob, kn, relu, acc):
     torch, L, ops, lib = env
@@ -216,7 +247,7 @@ def test_dgrad_launches_the_ws_kernel_does_not_serve_fall_back(env):
     noy = [dict(probs[0], mask=None)]
     name, _, out = run_dgrad(torch, ops, lib, noy, True, False)
     assert name != "gemm_ws_kernel"
-    probs = dgrad_launch(torch, L, ops, 8192, 128, 64, 1, seed=6)
+    probs = dgrad_launch(torch, L, ops, 8192, 64, 192, 1, seed=6)
     name, _, _ = run_dgrad(torch, ops, lib, probs, True, False)
     assert name != "gemm_ws_kernel"
 
