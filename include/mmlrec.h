@@ -239,10 +239,10 @@ int mml_gemm_get_mode(void);
  * registers and sweeps every N-tile past them (bitwise the results of the tile kernel).  on = 0 switches it off
  * (process-wide; default on; environment MMLREC_GEMM_PANEL=0 does the same). */
 int mml_gemm_set_panel(int32_t on);
-/* Weight-stationary streaming GEMM (csrc/gemm_ws.hip).  A forward launch whose problems ALL have K % 64 == 0, N in {64, 128,
- * 256}, N K <= 32 768 (the two fp16 planes of the weight fit 128 KiB of LDS), one M >= 8 192, pre-cut planes (either
+/* Weight-stationary streaming GEMM (csrc/gemm_ws.hip).  A forward launch whose problems ALL have K % 64 == 0 or K % 80 == 0, N in {64,
+ * 128, 256}, N K <= 32 768 (the two fp16 planes of the weight fit 128 KiB of LDS), one M >= 8 192, pre-cut planes (either
  * weight layout), the magnitude of A and activation relu, none, sigmoid or 2 sigmoid -- and an input-gradient launch of
- * single-source problems with K in {64, 128, 256} output columns, N % 64 == 0, N K <= 32 768, activation none or relu by sign
+ * single-source problems with K in {64, 128, 256} output columns, N % 64 == 0 or N % 80 == 0, N K <= 32 768, activation none or relu by sign
  * mask -- is served by persistent workgroups that keep one problem's weight planes in LDS while their waves stream 32-row
  * blocks of the batch past them (second expert layers, towers, PepNet's and STAR's layers: reference model/mmoe.py:69-119,
  * model/pepnet.py:64-78, model/utils.py:171-218); problems of different widths in one call become one kernel launch per

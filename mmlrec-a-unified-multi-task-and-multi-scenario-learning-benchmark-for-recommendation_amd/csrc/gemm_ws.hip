@@ -48,7 +48,7 @@ struct WsProblem {
   int32_t layout;          // MML_PLANES_ROWS: planes[out col][k]; MML_PLANES_COLS: planes[k][out col]
   int32_t act;             // forward: MML_ACT_NONE / RELU / SIGMOID / SIGMOID2
   int32_t accumulate;      // input gradient: C +=
-  int32_t G;               // groups of four k-steps (Kred = 64 G)
+  int32_t G;               // groups of D k-steps (Kred = 16 D G)
 };
 
 struct WsLaunch {
@@ -73,7 +73,7 @@ __device__ __forceinline__ int ws_scale_exp(uint32_t bits) {
 __device__ __forceinline__ float ws_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 // MODE 0: forward (bias, ReLU, sign mask out when MASKS); MODE 1: input gradient (sign mask in when MASKS, accumulation)
-template <int NS, int MODE, bool MASKS>
+template <int NS, int MODE, bool MASKS, int D>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
   constexpr int NSTOT = NS;
   __shared__ __attribute__((aligned(16))) float lds[WS_LDS_BYTES / 4];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
   const int pi = (int)blockIdx.x / L.wg_per_prob;
   const int wl = (int)blockIdx.x - pi * L.wg_per_prob;
   const WsProblem& P = L.p[pi];
-  const int G = P.G, KB = 4 * G, M = L.M;
+  const int G = P.G, KB = D * G, M = L.M;  // D: k-steps per group (4, or 5 for reductions of 80, 160, 240)
 
   // ---- the problem's weight planes -> LDS, fragment order: [k-step][plane][32-column sub-tile][lane] x 16 bytes ----
   {
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
     // the group's last MFMA and waits for them at the top of the next group, so a wave overlaps nothing by itself -- the
     // seven other waves of the CU do.  Hand-counted waits with a look-ahead of eight k-steps, refills in bursts of 512
     // bytes per row and twelve waves per CU were all built and measured level with this form: DESIGN 9.)
-    float4 r0[4], r1[4];
+    float4 r0[D], r1[D];
     const float* ap = arow(rb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < D; ++j) {
       r0[j] = *reinterpret_cast<const float4*>(ap + 16 * j);
       r1[j] = *reinterpret_cast<const float4*>(ap + 16 * j + 8);
     }
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
         const float* const unit_next = ap_next;
 #pragma unroll 1
         for (int g = 0; g < G; ++g) {
-          const float* const pf = (g + 1 < G) ? ap + 64 * (g + 1) : unit_next;
-          const f32x4_t* const wg_ = wfrag + g * 8 * NSTOT * 64;
+          const float* const pf = (g + 1 < G) ? ap + 16 * D * (g + 1) : unit_next;
+          const f32x4_t* const wg_ = wfrag + g * 2 * D * NSTOT * 64;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < D; ++j) {
             const float x[8] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
             F16Cut c;
             f16_cut_a2(x, sA, c, 0);
@@ -330,26 +330,29 @@ static int ws_cus() {
 }
 
 template <int MODE>
-static int ws_launch(const WsLaunch& L, const int nout, const bool masks, hipStream_t st) {
+static int ws_launch(const WsLaunch& L, const int nout, const bool masks, const int dgroup, hipStream_t st) {
   const dim3 g((unsigned)(L.wg_per_prob * L.n_prob)), b(512);
-#define WS_GO(NS_)                                                                  \
-  do {                                                                              \
-    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, true>), g, b, 0, st, L);       \
-    else MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false>), g, b, 0, st, L);            \
+#define WS_GO2(NS_, D_)                                                                 \
+  do {                                                                                  \
+    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, true, D_>), g, b, 0, st, L);       \
+    else MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false, D_>), g, b, 0, st, L);            \
   } while (0)
-  if constexpr (MODE == 0) {
-    if (nout == 256) WS_GO(8);
-    else if (nout == 128) WS_GO(4);
-    else WS_GO(2);
-  } else {
-    if (nout == 64) WS_GO(2);
-    else if (nout == 128) WS_GO(4);
-    else WS_GO(8);  // (256 output columns: eight sub-tiles at once -- swept in two passes of four the rows were read twice
-                    //  from HBM, PMC 300 MB against 138 algorithmic: 106 -> 93 us)
-  }
+#define WS_GO(NS_)                 \
+  do {                             \
+    if (dgroup == 5) WS_GO2(NS_, 5); \
+    else WS_GO2(NS_, 4);           \
+  } while (0)
+  if (nout == 64) WS_GO(2);
+  else if (nout == 128) WS_GO(4);
+  else WS_GO(8);  // (256 output columns of an input gradient: eight sub-tiles at once -- swept in two passes of four the rows
+                  //  were read twice from HBM, PMC 300 MB against 138 algorithmic: 106 -> 93 us)
 #undef WS_GO
+#undef WS_GO2
   return check_launch(MODE == 0 ? "mml_gemm_grouped_fwd(ws)" : "mml_gemm_grouped_dgrad(ws)");
 }
+
+// k-steps per group for a reduction of `kred` values: 4 (multiples of 64), 5 (other multiples of 80), 0 = not served
+static int ws_dgroup(const int kred) { return kred <= 0 ? 0 : (kred % 64 == 0 ? 4 : (kred % 80 == 0 ? 5 : 0)); }
 
 }  // namespace mml
 
@@ -365,7 +368,7 @@ extern "C" int mml_gemm_set_ws(int32_t on) {
 // and PLE's layers: 128- and 64-wide siblings in one call) is served as one kernel launch per (output width, sign masks)
 // class -- all of its problems must qualify.
 static bool ws_fwd_ok(const mml_gemm_fwd_desc& q, const mml_gemm_fwd_desc& d0) {
-  if (q.M != d0.M || q.K <= 0 || q.K % 64 != 0) return false;
+  if (q.M != d0.M || ws_dgroup(q.K) == 0) return false;
   if (q.N != 256 && q.N != 128 && q.N != 64) return false;  // (the instantiated output widths)
   if ((int64_t)q.N * q.K * 4 > WS_W_BYTES) return false;
   if (!q.A || !q.C || !q.w_planes || !q.w_kexp || !q.amax_a) return false;
@@ -391,7 +394,7 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
     for (int j = i; j < n; ++j) {
       const mml_gemm_fwd_desc& q = d[j];
       const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-      if (done[j] || q.N != d[i].N || m != mi) continue;
+      if (done[j] || q.N != d[i].N || m != mi || ws_dgroup(q.K) != ws_dgroup(d[i].K)) continue;
       done[j] = true;
       WsProblem& P = L.p[L.n_prob++];
       P.A = q.A;
@@ -408,12 +411,12 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
       P.ldmask = q.ldmask;
       P.layout = q.w_kn ? MML_PLANES_COLS : MML_PLANES_ROWS;  // ([K, N]: the reduction runs down the rows)
       P.act = q.act;
-      P.G = q.K / 64;
+      P.G = q.K / (16 * ws_dgroup(q.K));
     }
     L.M = d0.M;
     L.wg_per_prob = ws_cus() / L.n_prob;
     if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;  // (more problems than CUs: not before the first launch only in theory)
-    const int rc = ws_launch<0>(L, d[i].N, mi, st);
+    const int rc = ws_launch<0>(L, d[i].N, mi, ws_dgroup(d[i].K), st);
     if (rc != MML_OK) return rc;
   }
   return MML_OK;
@@ -422,7 +425,7 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
 static bool ws_dgrad_ok(const mml_gemm_dgrad_desc& q, const mml_gemm_dgrad_desc& d0) {
   if (q.n_src != 1 || q.gate_h || !q.dA || q.M != d0.M) return false;
   const int32_t kred = q.N[0];
-  if (kred <= 0 || kred % 64 != 0) return false;
+  if (ws_dgroup(kred) == 0) return false;
   if (q.K != 64 && q.K != 128 && q.K != 256) return false;  // (the instantiated output widths)
   if ((int64_t)q.K * kred * 4 > WS_W_BYTES) return false;
   if (!q.dC[0] || !q.w_planes[0] || !q.w_kexp[0] || !q.amax_dc[0]) return false;
@@ -444,7 +447,8 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
   // first member and keep their members' order; two problems with one target in DIFFERENT classes would be reordered)
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j)
-      if (d[i].dA == d[j].dA && (d[i].K != d[j].K || (d[i].relu_mask != nullptr) != (d[j].relu_mask != nullptr)))
+      if (d[i].dA == d[j].dA && (d[i].K != d[j].K || (d[i].relu_mask != nullptr) != (d[j].relu_mask != nullptr) ||
+                                 ws_dgroup(d[i].N[0]) != ws_dgroup(d[j].N[0])))
         return MML_ERR_UNSUPPORTED;
   bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
@@ -454,7 +458,7 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
     for (int j = i; j < n; ++j) {
       const mml_gemm_dgrad_desc& q = d[j];
       const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-      if (done[j] || q.K != d[i].K || m != mi) continue;
+      if (done[j] || q.K != d[i].K || m != mi || ws_dgroup(q.N[0]) != ws_dgroup(d[i].N[0])) continue;
       done[j] = true;
       WsProblem& P = L.p[L.n_prob++];
       P.A = q.dC[0];
@@ -470,12 +474,12 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
       P.ldmask = q.ldmask;
       P.layout = q.w_kn[0] ? MML_PLANES_ROWS : MML_PLANES_COLS;  // ([N, K]: the reduction runs down the rows)
       P.accumulate = q.accumulate;
-      P.G = q.N[0] / 64;
+      P.G = q.N[0] / (16 * ws_dgroup(q.N[0]));
     }
     L.M = d0.M;
     L.wg_per_prob = ws_cus() / L.n_prob;
     if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;
-    const int rc = ws_launch<1>(L, d[i].K, mi, st);
+    const int rc = ws_launch<1>(L, d[i].K, mi, ws_dgroup(d[i].N[0]), st);
     if (rc != MML_OK) return rc;
   }
   return MML_OK;

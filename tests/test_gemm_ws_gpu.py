@@ -127,10 +127,10 @@ def test_ws_fwd_mixed_widths_and_gate_activations(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
     M = 8192 + 32
-    Ns = [64, 128, 128, 64, 256]
-    Ks = [64, 64, 128, 192, 128]
-    acts = [L.ACT_RELU, L.ACT_SIGMOID2, L.ACT_SIGMOID, L.ACT_NONE, L.ACT_SIGMOID2]
-    probs = fwd_launch(torch, L, ops, M, Ks, Ns, 5, acts=acts, seed=21)
+    Ns = [64, 128, 128, 64, 256, 128, 64]
+    Ks = [64, 64, 128, 192, 128, 80, 160]          # (80, 160: groups of five k-steps -- PepNet's 72 -> 80 padded inputs)
+    acts = [L.ACT_RELU, L.ACT_SIGMOID2, L.ACT_SIGMOID, L.ACT_NONE, L.ACT_SIGMOID2, L.ACT_RELU, L.ACT_RELU]
+    probs = fwd_launch(torch, L, ops, M, Ks, Ns, 7, acts=acts, seed=21)
     name_w, out_w = run_fwd(torch, ops, lib, probs, True, False)
     assert name_w == "gemm_ws_kernel", name_w
     name_t, out_t = run_fwd(torch, ops, lib, probs, False, False)
@@ -150,9 +150,9 @@ def test_ws_fwd_mixed_widths_and_gate_activations(env):
 def test_launches_the_ws_kernel_does_not_serve_fall_back(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
-    # a weight beyond the LDS (twice), a reduction that is not a multiple of 64, a batch below the threshold, an output
+    # a weight beyond the LDS (twice), a reduction that is neither a multiple of 64 nor of 80, a batch below the threshold, an output
     # width that is not instantiated
-    for M, K, N, acts in ((8192, 512, 128, None), (8192, 240, 128, None), (4096, 256, 128, None),
+    for M, K, N, acts in ((8192, 512, 128, None), (8192, 208, 128, None), (4096, 256, 128, None),
                           (8192, 256, 256, None), (8192, 128, 192, None)):
         probs = fwd_launch(torch, L, ops, M, K, N, 1, acts=acts)
         name, out = run_fwd(torch, ops, lib, probs, True, False)
@@ -211,6 +211,7 @@ def run_dgrad(torch, ops, lib, probs, ws, accumulate):
     (16384 + 5, 192, 128, 5, True, True, False),   # STAR's [K, N] layout
     (8192, 64, 256, 1, False, False, True),
     (8192 + 96, 128, 64, 4, False, True, False),   # 64 output columns (PepNet's gate networks)
+    (8192, 80, 128, 2, False, True, False),        # a reduction of 80: one group of five k-steps
 ])
 def test_ws_dgrad_matches_float64_and_the_tile_kernel(env, M, Nred, K, nprob, kn, relu, acc):
     torch, L, ops, lib = env
