@@ -12,7 +12,8 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for p in ("p1", "p2", "p3", "p4"):
-    for f in glob.glob(f"{src}/{p}/**/*counter_collection.csv", recursive=True):
+    # (gpurun merges a run's files next to those of earlier runs: the newest file of each pass only)
+    for f in sorted(glob.glob(f"{src}/{p}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if "gemm" not in r["Kernel_Name"]:
                 continue
