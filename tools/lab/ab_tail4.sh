@@ -1,0 +1,12 @@
+run() { env $1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-lazy --alt-batch 0 --no-configs 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', d['ms_per_step'], round(d['value']/1e6,2))"; }
+for rep in 1 2; do
+run "X=0"
+run "MMLREC_TAIL_BLOCKS=3072 MMLREC_OPT_U=4"
+run "MMLREC_TAIL_BLOCKS=2048 MMLREC_OPT_U=4"
+run "MMLREC_TAIL_BLOCKS=1024 MMLREC_OPT_U=4"
+run "MMLREC_TAIL_BLOCKS=2048 MMLREC_OPT_U=2"
+done
