@@ -194,9 +194,13 @@ def timed_steps(runner, batches, steps, warmup, dist, flush=None, warm_losses=No
     gc.collect()
     gc.disable()
     barrier(dist)
+    comm = getattr(getattr(runner, "par", None), "comm", None)
+    snap0 = comm.stats_snapshot() if comm is not None else None
     t0 = time.perf_counter()
     for i in range(steps):
         one(warmup + i)
+    if comm is not None:  # what this rank issued inside the timed region, per step (host-side counters of parallel.Comm)
+        runner.collectives_per_step = comm.stats_delta(snap0, comm.stats_snapshot(), per=steps)
     t_flush = 0.0
     if flush is not None:  # lazy_exact: the deferred zero-gradient updates of every untouched row are paid HERE
         torch.cuda.synchronize()
@@ -258,6 +262,10 @@ def roofline_of(acc):
         m = re.match(r"gemm_pipe_kernel<\w+, \w+, \d+, \d+, (\d+)", name)
         if m and int(m.group(1)) in (1, 2, 3):
             planes = int(m.group(1))
+        elif name.startswith(("gemm_ws_kernel", "gemm_panel_kernel")):
+            # the weight-stationary / activation-stationary kernels issue the same three f16 MFMAs per product block as
+            # gemm_pipe_kernel<..., 2, ...> (csrc/gemm_ws.hip, csrc/gemm_panel.hip), one per block in the bf16 forms
+            planes = 1 if name.endswith("<bf16>") else 2
         if planes:  # fp32 emulated on the 16-bit MFMA pipe: 3 (two fp16 planes) or 6 (three bf16 planes) MFMAs per block
             per = {1: 1, 2: 3, 3: 6}[planes]
             peak = 2500.0 / per
@@ -334,8 +342,13 @@ def cpu_baseline(args):
                "dense_optimizer_GB_per_s": round(28.0 * n_tab * nb / t_opt / 1e9, 1),
                "note": "dense_optimizer_GB_per_s = 28 B x table parameters / the optimizer's time (MLP tensors included "
                        "in the time, negligible): the host's DRAM streams a few hundred GB/s"}
-    return {"value": round(args.cpu_batch * args.cpu_steps / dt, 1), "unit": "samples/s", "cores": cores,
-            "kind": "port", "batch": args.cpu_batch, "at_headline_batch": big,
+    torch_leg = None
+    try:
+        torch_leg = torch_cpu_baseline(args, cfg, names, vocab, dense, params, T)
+    except Exception as e:  # (mmoe / sharedbottom only; never lose the line to the host side)
+        torch_leg = {"failed": repr(e)}
+    numpy_port = {"value": round(args.cpu_batch * args.cpu_steps / dt, 1), "unit": "samples/s", "cores": cores,
+                  "kind": "port", "batch": args.cpu_batch, "at_headline_batch": big,
             "note": "the oracle (numpy / BLAS + C/OpenMP restatement of the reference step, pinned to the reference by "
                     "tests/golden), NOT the reference's PyTorch path: that one measured 8.1 k samples/s on 8 cores in "
                     "the build container (BASELINE.md) and cannot travel to the GPU box",
@@ -343,6 +356,56 @@ def cpu_baseline(args):
                       f"{args.workload} at batch {args.cpu_batch}, {args.dist} indices; oracle/mmlrec_oracle.py with "
                       f"multi-threaded BLAS GEMMs and " + ("C/OpenMP" if fast else "numpy (single-thread)") +
                       " gather/scatter/dense-Adam loops"}
+    if torch_leg and "value" in torch_leg:
+        # the headline CPU figure is the PyTorch one: that is what the reference runs on a CPU host
+        # (model/basemodel.py:268-313); the numpy oracle stays beside it
+        out = dict(torch_leg)
+        out["numpy_port"] = numpy_port
+        return out
+    numpy_port["torch_cpu"] = torch_leg
+    return numpy_port
+
+
+def torch_cpu_baseline(args, cfg, names, vocab, dense, params_np, T):
+    """oracle/torch_cpu.py -- the reference's own ATen calls in functional form, golden-checked against reference-made
+    fixtures (tests/test_torch_cpu_baseline.py) -- on the host cores: full steps incl. autograd's dense [V, E] table
+    gradients and torch.optim over every table row, at the reference's batch (cpu_batch) and at the headline batch."""
+    from oracle import torch_cpu as tc
+    from mmlrec_amd import workloads as W
+    cores = os.cpu_count() or 1
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        spec = tc.Spec(cfg, names, vocab, dense)
+        p = tc.params_from_numpy(params_np)
+        opt = tc.make_optimizer(cfg["optim_config"]["optimizer"], p, cfg["optim_config"]["lr"])
+        runs = []
+        for B, steps, warm in ((args.cpu_batch, max(3, min(args.cpu_steps, 8)), 2), (args.batch, args.cpu_big_steps, 1)):
+            if steps <= 0 or (runs and B == runs[0]["batch"]):
+                continue
+            bs = [W.synth_batch(vocab, len(dense), B, T, seed=100 + i, dist=args.dist) for i in range(2)]
+            for i in range(warm):
+                tc.train_step(spec, p, opt, *bs[i % 2])
+            t0 = time.perf_counter()
+            for i in range(steps):
+                tc.train_step(spec, p, opt, *bs[i % 2])
+            dt = time.perf_counter() - t0
+            runs.append({"batch": B, "steps": steps, "value": round(B * steps / dt, 1), "unit": "samples/s",
+                         "ms_per_step": round(dt / steps * 1e3, 1)})
+    finally:
+        torch.set_num_threads(n0)
+    return {"value": runs[0]["value"], "unit": "samples/s", "cores": cores, "kind": "port",
+            "implementation": "torch-CPU restatement of the reference step (oracle/torch_cpu.py: F.embedding / F.linear / "
+                              "softmax / matmul / sigmoid / binary_cross_entropy(sum), autograd's dense table gradients, "
+                              f"torch.optim.{cfg['optim_config']['optimizer']} over every table row), torch {torch.__version__}, "
+                              f"torch.set_num_threads({cores})",
+            "batch": runs[0]["batch"], "at_headline_batch": runs[1] if len(runs) > 1 else None,
+            "sample": f"{runs[0]['steps']} full train steps of {args.workload} at batch {runs[0]['batch']}"
+                      + (f" and {runs[1]['steps']} at batch {runs[1]['batch']}" if len(runs) > 1 else "")
+                      + f", {args.dist} indices, after warm-up steps",
+            "note": "pinned to the unmodified reference by tests/test_torch_cpu_baseline.py (forward bit for bit, "
+                    "gradients and Adam / Adagrad steps to 1e-6); the reference itself measured 8.1 k samples/s on the 8 "
+                    "cores of the build container (BASELINE.md) and cannot travel to the GPU box"}
 
 
 def secondary_configs(args, dev):
@@ -396,6 +459,22 @@ def secondary_configs(args, dev):
         finally:
             lib.mml_gemm_set_mode(mode0)
     return out
+
+
+def expected_collectives(args, world, main_r):
+    """DESIGN section 5's model of one step's exchange for this run (per rank): distinct rows of the local batch that
+    live on other ranks x 4 B of keys, x 4 E B of rows each way; the MLP gradient arena through a ring."""
+    if args.parallel_mode != "row_sharded":
+        return None
+    d = main_r.get("distinct_rows")
+    if d is None:
+        return None
+    remote = d * (world - 1) / max(world, 1)
+    E = main_r["emb"]
+    arena = main_r["arena_bytes"]
+    return {"distinct_rows_of_a_batch": int(d), "all_to_all_calls": 4, "all_reduce_calls": 1,
+            "keys_MB": round(remote * 4 / 1e6, 4), "rows_MB_each_way": round(remote * 4 * E / 1e6, 4),
+            "all_reduce_ring_MB": round(2 * arena * (world - 1) / max(world, 1) / 1e6, 4)}
 
 
 def describe_workload(name, cfg, vocab, dense):
@@ -466,6 +545,11 @@ def main():
                           loss=float(runner.plan.loss.item()) / B, warm_losses=warm_losses)
         if B == args.batch:
             runner0 = runner
+            if getattr(model, "_parallel", None) is not None:
+                Xi = batches[0][0][:, :len(vocab)].long()
+                results[B]["distinct_rows"] = int(sum(torch.unique(Xi[:, f]).numel() for f in range(len(vocab))))
+                results[B]["emb"] = int(cfg["model_config"]["emb"])
+                results[B]["arena_bytes"] = int(runner.store.arena.numel() * 4)
         acc = kernel_breakdown(runner, batches, min(args.steps, 10))
         results[B]["acc"] = acc
         results[B]["bsteps"] = min(args.steps, 10)
@@ -577,6 +661,19 @@ def main():
         "mean_loss_per_sample": round(main_r["loss"], 5),
         "gradients_finite": main_r.get("finite", True),
     }
+    # the whole step against the HBM roofline: every launch's compulsory bytes -- each distinct
+    # operand read once, each output written once; GEMM launches included (engine: `hbm_bytes`) -- over the MEASURED step
+    kern = {k: v for k, v in main_r["acc"].items()
+            if not k.startswith(("all_to_all", "all_reduce", "all_gather", "row_sharded_"))}
+    step_bytes = sum(v.get("hbm_bytes", v["bytes"]) for v in kern.values()) / main_r["bsteps"]
+    step_flops = sum(v["flops"] for v in kern.values()) / main_r["bsteps"]
+    line["whole_step"] = {
+        "algorithmic_hbm_bytes": round(step_bytes), "algorithmic_flops": round(step_flops),
+        "achieved_GB_per_s": round(step_bytes / (main_r["ms"] * 1e-3) / 1e9, 1), "peak_GB_per_s": 8000.0,
+        "frac_of_hbm_peak": round(step_bytes / (main_r["ms"] * 1e-3) / 8e12, 4),
+        "hbm_floor_ms": round(step_bytes / 8e12 * 1e3, 4),
+        "note": "sum over the step's launches of their compulsory HBM bytes / ms_per_step / 8 TB/s; the phases of a step "
+                "depend on each other, so the floor is the sum of the launches' floors"}
     if not line["gradients_finite"]:
         sys.stderr.write("bench: the input gradients of the last step are not finite -- the model diverged on this "
                          "synthetic stream; the timing is that of a diverged run\n")
@@ -609,6 +706,15 @@ def main():
             if k.startswith(("all_to_all", "all_reduce", "all_gather", "row_sharded_"))}
     if comm:  # serial, event-bracketed time of the exchange steps of rank 0 (second, instrumented pass)
         line["collectives_ms_per_step"] = {k: round(v["ms"] / main_r["bsteps"], 4) for k, v in comm.items()}
+    cps = getattr(runner0, "collectives_per_step", None)
+    if cps is not None:
+        # rank 0's collectives INSIDE the timed region, per step: number of calls and the bytes that left / reached this
+        # rank (all_to_all: what goes to / comes from the other ranks; all_reduce: the ring's 2 (N - 1) / N of the
+        # buffer).  To be read against the per-N table of DESIGN section 5: row_sharded = 4 all-to-alls (per-owner
+        # counts, keys, rows, row gradients) + 1 all-reduce (the MLP gradient arena) per step.
+        line["collectives_per_step"] = {k: {"calls": round(v["calls"], 3), "MB_sent": round(v["bytes_sent"] / 1e6, 4),
+                                            "MB_received": round(v["bytes_received"] / 1e6, 4)} for k, v in cps.items()}
+        line["collectives_per_step"]["expected"] = expected_collectives(args, world, main_r)
     if args.alt_batch and args.alt_batch in results:
         r = results[args.alt_batch]
         line["alt"] = {"batch_per_gpu": args.alt_batch, "value": round(r["value"], 1), "unit": "samples/s",

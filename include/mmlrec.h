@@ -88,6 +88,11 @@ int mml_gather_fwd(const float* const* tables, const int64_t* vocab, const int32
  * `out` from a few KB instead of a pass over the whole output.  Needs E % 4 == 0, ldo % 4 == 0 and 16-byte aligned
  * tables and output (MML_ERR_ARG otherwise). */
 int64_t mml_gather_wgmax_len(int32_t F, int32_t E, int32_t Nd, int64_t B);
+/* Kernel symbol of the calling thread's most recent gather launch ("gather_vec4_kernel", "gather_lds_kernel" -- the
+ * LDS-staged variant for tables of at most 128 rows, north_star's "LDS-staged index dedup", which runs when the
+ * environment holds MMLREC_GATHER_LDS = n > 0 workgroups per CU at the time of the call and the launch neither marks rows
+ * nor leaves workgroup maxima -- or "gather_scalar_kernel"); "" before the first one.  For tests / benchmark labels. */
+const char* mml_gather_last_kernel(void);
 int mml_gather_fwd_wgmax(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
                          const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, float* out,
                          int64_t ldo, float* wg_max, int64_t wg_max_len, int32_t* status, mml_stream_t stream);

@@ -142,6 +142,7 @@ _SIGS = {
     "mml_gemm_set_panel": (C.c_int, [i32]),
     "mml_gemm_set_ws": (C.c_int, [i32]),
     "mml_gemm_last_kernel": (C.c_char_p, []),
+    "mml_gather_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),
     "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),

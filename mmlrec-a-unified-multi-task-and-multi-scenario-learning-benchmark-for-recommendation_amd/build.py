@@ -14,8 +14,14 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmmlrec_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 GEMM_SOURCES = ("gemm.hip",)  # kernels with hand-counted waits: resource / assembly checks below
+# also order their LDS-DMA rings with compile-time counted s_waitcnt vmcnt(N) (gemm_panel.hip: pn_younger counts the
+# epilogue stores of each piece): a spill would add scratch VMEM operations to the count -> resource report checked too
+COUNTED_WAIT_SOURCES = GEMM_SOURCES + ("gemm_panel.hip", "gemm_ws.hip")
+COUNTED_WAIT_KERNELS = ("gemm_pipe_kernel", "gemm_panel_kernel", "gemm_ws_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
+if os.environ.get("MMLREC_GEMM_NT") == "1":  # nontemporal output stores of the tile kernel's epilogue (csrc/gemm.hip)
+    FLAGS.append("-DMML_GEMM_NT")
 
 
 def _newest(paths):
@@ -93,11 +99,12 @@ def _build_locked(force, verbose, jobs):
             obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             stderr = None
-            if os.path.basename(src) in GEMM_SOURCES:
+            if os.path.basename(src) in COUNTED_WAIT_SOURCES:
                 # the pipelined GEMM counts its own VMEM operations (s_waitcnt vmcnt(N)): a register spill would add
                 # scratch traffic to that count and silently break the waits -> check the resource report
                 cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
-                cmd.insert(-4, "-save-temps=obj")  # keeps the device assembly next to the object (checked below)
+                if os.path.basename(src) in GEMM_SOURCES:
+                    cmd.insert(-4, "-save-temps=obj")  # keeps the device assembly next to the object (checked below)
                 stderr = open(obj + ".log", "w")
             if verbose:
                 print("[mmlrec build]", " ".join(cmd), flush=True)
@@ -110,7 +117,7 @@ def _build_locked(force, verbose, jobs):
             if os.path.exists(log):
                 sys.stderr.write("".join(l for l in open(log) if "remark:" not in l)[-4000:])
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    for g in GEMM_SOURCES:
+    for g in COUNTED_WAIT_SOURCES:
         check_no_scratch(os.path.join(objdir, g[:-4] + ".o.log"))
     check_async_lds(objdir)
     tmp = LIBPATH + ".tmp.%d" % os.getpid()
@@ -124,14 +131,15 @@ def _build_locked(force, verbose, jobs):
 
 
 def check_no_scratch(log):
-    """Every gemm_pipe_kernel instantiation must use no scratch memory (see build_library)."""
+    """Every instantiation of a kernel with counted vmcnt waits (COUNTED_WAIT_KERNELS) must use no scratch memory (see
+    build_library)."""
     if not os.path.exists(log):
         return
     name, bad = None, []
     for line in open(log):
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split()[0]
-        elif "ScratchSize" in line and name and ("gemm_pipe_kernel" in name):
+        elif "ScratchSize" in line and name and any(k in name for k in COUNTED_WAIT_KERNELS):
             if int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
                 bad.append(name)
     if bad:

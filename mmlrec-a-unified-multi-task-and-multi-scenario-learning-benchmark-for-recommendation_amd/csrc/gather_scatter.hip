@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256) void gather_scalar_kernel(const FieldTable ft,
   if (bad && a.status) atomicOr(a.status, bad);
 }
 
+static thread_local const char* g_last_gather = "";
+extern "C" const char* mml_gather_last_kernel(void) { return g_last_gather; }
+
 static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t stream) {
   if (a.B == 0) return MML_OK;
   bool vec = (a.E % 4 == 0) && (a.ldo % 4 == 0) && aligned16(a.out);
@@ -216,12 +219,11 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
       const char* e = getenv("MMLREC_GATHER_ITEMS");
       items = (e && atoi(e) == 4) ? 4 : 1;
     }
-    static int use_lds = -1;
-    if (use_lds < 0) {
-      const char* e = getenv("MMLREC_GATHER_LDS");
-      use_lds = e ? atoi(e) : 0;  // n > 0: the persistent LDS-staged variant with n workgroups per CU (measurement knob)
-    }
-    if (use_lds > 0 && !a.marks && !a.wgmax) {
+    // n > 0: the persistent LDS-staged variant with n workgroups per CU (measurement knob; read on every call so that a
+    // test can switch it inside one process -- a getenv is nanoseconds next to a launch)
+    const char* e_lds = getenv("MMLREC_GATHER_LDS");
+    const int use_lds = e_lds ? atoi(e_lds) : 0;
+    if (use_lds > 0 && use_lds <= 16 && !a.marks && !a.wgmax) {
       SmallTabs st{};
       int off = 0;
       for (int f = 0; f < a.F; ++f) {
@@ -234,6 +236,7 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
       }
       st.total = off;
       MML_LAUNCH(gather_lds_kernel, dim3(256u * (unsigned)use_lds), dim3(threads), 0, stream, ft, a, st);
+      g_last_gather = "gather_lds_kernel";
       return check_launch("mml_gather_fwd(lds)");
     }
     const int64_t per_sample = (int64_t)a.F * (a.E / 4) + a.Nd;
@@ -243,12 +246,14 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
     if (a.wgmax) MML_LAUNCH((gather_vec4_kernel<1, true>), dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
     else if (items == 4) MML_LAUNCH(gather_vec4_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
     else MML_LAUNCH(gather_vec4_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    g_last_gather = "gather_vec4_kernel";
   } else {
     MML_REQUIRE(!a.wgmax, "mml_gather_fwd_wgmax: needs E %% 4 == 0, ldo %% 4 == 0 and 16-byte aligned tables and output");
     const int64_t total = a.B * ((int64_t)a.F * a.E + a.Nd);
     int64_t blocks = cdiv(total, threads);
     if (blocks > 256 * 32) blocks = 256 * 32;
     MML_LAUNCH(gather_scalar_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, ft, a);
+    g_last_gather = "gather_scalar_kernel";
   }
   return check_launch("mml_gather_fwd");
 }

@@ -386,6 +386,7 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   if (d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
   for (int i = 0; i < n; ++i)
     if (!ws_fwd_ok(d[i], d0)) return MML_ERR_UNSUPPORTED;
+  if (n > ws_cus()) return MML_ERR_UNSUPPORTED;  // (decided before the first launch, never between two of them)
   bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
@@ -415,7 +416,6 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
     }
     L.M = d0.M;
     L.wg_per_prob = ws_cus() / L.n_prob;
-    if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;  // (more problems than CUs: not before the first launch only in theory)
     const int rc = ws_launch<0>(L, d[i].N, mi, ws_dgroup(d[i].K), st);
     if (rc != MML_OK) return rc;
   }
@@ -443,13 +443,14 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
   if (d0.M < WS_MIN_ROWS) return MML_ERR_UNSUPPORTED;
   for (int i = 0; i < n; ++i)
     if (!ws_dgrad_ok(d[i], d0)) return MML_ERR_UNSUPPORTED;
-  // (problems of one launch may write the same dA -- accumulate -- in order: classes are launched in the order of their
-  // first member and keep their members' order; two problems with one target in DIFFERENT classes would be reordered)
+  // Two problems of one call that write the same dA (an overwriting and an accumulating one) need an ORDER: the
+  // problems of a class run in one kernel launch on disjoint workgroup ranges, i.e. concurrently, and classes are
+  // launched in the order of their first members -- neither keeps the call's order.  Left to the tile kernel (the
+  // engine never builds such a call: chunks of one input go into different launches).
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j)
-      if (d[i].dA == d[j].dA && (d[i].K != d[j].K || (d[i].relu_mask != nullptr) != (d[j].relu_mask != nullptr) ||
-                                 ws_dgroup(d[i].N[0]) != ws_dgroup(d[j].N[0])))
-        return MML_ERR_UNSUPPORTED;
+      if (d[i].dA == d[j].dA) return MML_ERR_UNSUPPORTED;
+  if (n > ws_cus()) return MML_ERR_UNSUPPORTED;  // (every class gets >= 1 workgroup per problem: decided BEFORE the first launch)
   bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
@@ -477,8 +478,7 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
       P.G = q.N[0] / (16 * ws_dgroup(q.N[0]));
     }
     L.M = d0.M;
-    L.wg_per_prob = ws_cus() / L.n_prob;
-    if (L.wg_per_prob < 1) return MML_ERR_UNSUPPORTED;
+    L.wg_per_prob = ws_cus() / L.n_prob;  // (>= 1: n <= ws_cus() was checked before the first launch)
     const int rc = ws_launch<1>(L, d[i].K, mi, ws_dgroup(d[i].N[0]), st);
     if (rc != MML_OK) return rc;
   }

@@ -320,11 +320,15 @@ class Plan:
                 meta = c[3] if len(c) > 3 else {"kernel": getattr(c[1], "__name__", "python")}
             else:
                 meta = c[2] if len(c) > 2 else {"kernel": c[0].__name__}
-            e = acc.setdefault(label or meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            e = acc.setdefault(label or meta["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0,
+                                                         "hbm_bytes": 0.0})
             e["ms"] += a.elapsed_time(b)
             e["launches"] += 1
             e["flops"] += meta.get("flops", 0.0)
             e["bytes"] += meta.get("bytes", 0.0)
+            # compulsory HBM bytes of the call (every distinct operand read once, every output written once): the GEMM
+            # launches are priced in FLOPs (`flops`) but still move their operands -- bench.py's whole-step fraction
+            e["hbm_bytes"] = e.get("hbm_bytes", 0.0) + meta.get("hbm_bytes", meta.get("bytes", 0.0))
 
     def run_forward(self):
         self._run(self.fwd)
@@ -458,8 +462,9 @@ class Plan:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         self.keep += [arr, ws]
         flops = sum(self.bwd_side[i][2].get("flops", 0.0) for i in idx)
+        hbm = sum(self.bwd_side[i][2].get("hbm_bytes", 0.0) for i in idx)
         merged = [(fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 1),
-                   dict(kernel=_gemm_symbol(False, False, [], 2), flops=flops, side=True, rank=0)),
+                   dict(kernel=_gemm_symbol(False, False, [], 2), flops=flops, hbm_bytes=hbm, side=True, rank=0)),
                   (fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 2),
                    dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1))]
         rest = [c for i, c in enumerate(self.bwd_side) if i not in set(idx)]  # (un-padding copies: after the reduction)
@@ -478,6 +483,19 @@ class Plan:
 # ==================================================================================================
 # ops
 # ==================================================================================================
+def _distinct_bytes(tensors):
+    """Bytes of the distinct buffers among `tensors` (torch tensors / None; a view counts its own elements)."""
+    seen, n = set(), 0
+    for t in tensors:
+        if t is None:
+            continue
+        key = (t.data_ptr(), tuple(t.shape))
+        if key not in seen:
+            seen.add(key)
+            n += t.numel() * t.element_size()
+    return float(n)
+
+
 def _gemm_symbol(arc, brc, cols, epi, kreds=(), tensors=(), nrc_extents=()):
     """Provisional label of a grouped GEMM launch; Plan.run_timed replaces it with the symbol the C side actually
     launched (mml_gemm_last_kernel), which depends on the tile / arithmetic choice made in csrc/gemm.hip."""
@@ -711,7 +729,11 @@ class LinearGroupOp(Op):
                                         tensors=[q.get("Ap", q["x"].buf) for q in self.p] +
                                                 [q.get("Wp", q["W"].data) for q in self.p],
                                         nrc_extents=[q["out"].n for q in self.p] if kn else []),
-                    flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in self.p))
+                    flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in self.p),
+                    hbm_bytes=_distinct_bytes([q["x"].buf for q in self.p] + [q["W"].data for q in self.p] +
+                                              [q["out"].buf for q in self.p] + [q["out"].mask for q in self.p] +
+                                              [q["prod"].buf for q in self.p if q.get("mul") is not None] +
+                                              [q["mul"].buf for q in self.p if q.get("mul") is not None]))
         return pre + [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
 
     def bwd_calls(self, plan):
@@ -754,7 +776,8 @@ class LinearGroupOp(Op):
             meta = dict(kernel=_gemm_symbol(False, False, [q["dW"].shape[1] for q in wg], 2, kreds=[plan.B],
                                             tensors=[q["dC"] for q in wg] + [q["A"] for q in wg],
                                             nrc_extents=[d for q in wg for d in q["dW"].shape]),
-                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True, rank=0)
+                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in wg), side=True, rank=0,
+                        hbm_bytes=_distinct_bytes([q["dC"] for q in wg] + [q["A"] for q in wg] + [q["dW"] for q in wg]))
             calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 1), meta))
             calls.append((lib.mml_gemm_grouped_wgrad_phase, (descs, len(wg), ws.data_ptr(), ws.numel(), 2),
                           dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1)))
@@ -877,7 +900,9 @@ class LinearGroupOp(Op):
                                             tensors=[t_ for q in dg for sr in q["srcs"] for t_ in sr[:2]],
                                             nrc_extents=[] if kn else [q["dA"].shape[1] for q in dg]),
                         flops=sum(2.0 * plan.B * q["dA"].shape[1] * sum(sr[0].shape[1] for sr in q["srcs"])
-                                  for q in dg))
+                                  for q in dg),
+                        hbm_bytes=_distinct_bytes([q["dA"] for q in dg] + [q.get("mask") for q in dg] +
+                                                  [t_ for q in dg for sr in q["srcs"] for t_ in sr[:2]]))
             calls.append((lib.mml_gemm_grouped_dgrad, (descs, len(dg)), meta))
         return calls + post
 

@@ -98,6 +98,15 @@ def evaluate_predictions(model, config, test, target, test_mask, pred_ans):
 
 
 def run(args):
+    """One process of a run.  --is_parallel: a rank that loses a collective exits with code 70 at once
+    (parallel.exit_on_collective_error) so the launcher can reap the others instead of waiting for the RCCL timeout."""
+    if getattr(args, "is_parallel", False):
+        from .parallel import exit_on_collective_error
+        return exit_on_collective_error(_run, args)
+    return _run(args)
+
+
+def _run(args):
     dist = None
     if getattr(args, "profile", False):
         from . import profiling

@@ -202,6 +202,8 @@ class BaseModel(nn.Module):
         return new
 
     def _apply(self, fn, *a, **k):
+        if "_caches" in self.__dict__ and getattr(self, "_optimizer", None) is not None:
+            self.flush_tables()  # (model.to() / .float(): the store and its optimizer are rebuilt on the new storage)
         out = super()._apply(fn, *a, **k)
         if "_caches" in self.__dict__:
             self._caches = {"store": None, "plans": {}, "steps": {}}
@@ -214,6 +216,13 @@ class BaseModel(nn.Module):
     def _store(self):
         st = self._caches["store"]
         if st is None or st.stale():
+            old = getattr(self, "_optimizer", None)
+            if (st is not None and old is not None and old.store is st and old.table_update == "lazy_exact" and
+                    old.dirty and old.last is not None):
+                # the parameters were re-seated behind the optimizer's back (p.data = ...): the pending replays of the
+                # old storage cannot be applied to the new one
+                raise L.MMLError("parameter storage replaced while lazy_exact table updates were pending: call "
+                                 "model.flush_tables() before re-seating parameters")
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise L.MMLError("mmlrec_amd models run on an MI355X only: move the model to cuda (no CPU fallback)")
@@ -242,11 +251,16 @@ class BaseModel(nn.Module):
         plan.row0 = par0.rank * int(B) if (par0 is not None and training) else 0
         if getattr(self, "optim_name", None) is not None:
             plan.step_dev = self.optimizer().step_dev
-        else:  # an uncompiled model: ONE counter for all its plans (every training-mode forward bumps it, see below)
+        else:
+            # an uncompiled model: ONE counter for all its plans (every training-mode forward bumps it, see below) and a
+            # step word per PLAN that holds the value its latest forward drew -- the backward regenerates the mask from the
+            # plan's word, so a forward of another plan (another batch size, the masked variant, a no_grad forward) between
+            # a forward and its backward cannot change it
             own = self.__dict__.get("_own_step_dev")
             if own is None or own.device != store.device:
                 own = self.__dict__["_own_step_dev"] = torch.zeros(1, dtype=torch.int32, device=store.device)
-            plan.step_dev = own
+            plan.shared_step_dev = own
+            plan.step_dev = plan.zeros(1, dtype=torch.int32)
         plan.generation = 0
         sp, de = self._sparse_cols(), self._dense_cols()
         ftot = max(e for _, e in self.feature_index.values())
@@ -313,9 +327,13 @@ class BaseModel(nn.Module):
             # an uncompiled model in a custom training loop: the plan owns its step counter, and nothing else would ever
             # move it -- every forward would draw the SAME dropout mask.  The forward bumps it first; the
             # backward of that forward regenerates the mask from the same value.
-            plan.fwd.insert(0, (L.load().mml_counter_update, (plan.step_dev.data_ptr(), 1, 0),
+            own = plan.shared_step_dev
+            plan.fwd.insert(0, (L.load().mml_counter_update, (own.data_ptr(), 1, 0),
                                 dict(kernel="mml_counter_update", bytes=4.0)))
-            plan.n_pre += 1
+            # (a 4-byte copy: the kernel moves the word's bits unchanged)
+            plan.fwd.insert(1, (L.load().mml_copy2d, (own.data_ptr(), 1, plan.step_dev.data_ptr(), 1, 1, 1, 0),
+                                dict(kernel="copy2d_kernel", bytes=8.0)))
+            plan.n_pre += 2
         return plan
 
     def _maybe_deterministic(self, gop, store, tables, training, E_dim):
@@ -410,6 +428,10 @@ class BaseModel(nn.Module):
 
     # ---- compile (reference :557-647) ------------------------------------------------------------
     def compile(self, optimizer, loss=None, metrics=None):
+        # a second compile (new optimizer / lr for a second training phase) drops the fused optimizer: rows whose
+        # zero-gradient steps are still pending under lazy_exact must replay them first, or the tables silently leave
+        # the reference's dense trajectory
+        self.flush_tables()
         self.metrics_names = ["loss"]
         if isinstance(optimizer, str):
             if optimizer not in ("sgd", "adam", "adagrad", "rmsprop"):

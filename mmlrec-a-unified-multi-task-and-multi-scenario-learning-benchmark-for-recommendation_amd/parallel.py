@@ -36,6 +36,24 @@ class CollectiveError(RuntimeError):
     """A collective failed on this rank: the ranks are out of step and the job has to end."""
 
 
+def exit_on_collective_error(fn, *args, **kwargs):
+    """Run fn(*args, **kwargs); a CollectiveError ends the PROCESS at once with exit code 70 (traceback printed, streams
+    flushed) instead of unwinding through interpreter / ProcessGroup teardown with a broken communicator -- that can block
+    while the other ranks sit in the collective until the RCCL timeout.  The launcher (torch.distributed.run) then reaps
+    the other ranks.  Used by main.run (--is_parallel) and bench.py; a library caller of fit() under its own launcher
+    wraps its entry point the same way (or sets MMLREC_COMM_EXIT=1: exit inside the failing collective)."""
+    try:
+        return fn(*args, **kwargs)
+    except CollectiveError:
+        import os
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(70)
+
+
 class Comm:
     """The few collectives the step needs, on one process group.  RCCL ("nccl") moves device buffers directly; under
     "gloo" (the world-2 tests: two processes on one GPU or on CPU) device buffers are staged through the host."""
@@ -44,17 +62,41 @@ class Comm:
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.staged = dist.get_backend(group) == "gloo"
+        # what was issued, by kind: calls / bytes this rank sent to OTHER ranks / bytes it received from them (host-side
+        # bookkeeping only; bench.py prints the per-step figures so that a multi-GPU run can be checked line by line
+        # against the per-N table of DESIGN section 5)
+        self.stats = {}
 
     def __deepcopy__(self, memo):
         return self
+
+    def _count(self, kind, sent, received):
+        e = self.stats.setdefault(kind, {"calls": 0, "bytes_sent": 0, "bytes_received": 0})
+        e["calls"] += 1
+        e["bytes_sent"] += int(sent)
+        e["bytes_received"] += int(received)
+
+    def stats_snapshot(self):
+        return {k: dict(v) for k, v in self.stats.items()}
+
+    @staticmethod
+    def stats_delta(a, b, per=1):
+        """(b - a) / per for two stats_snapshot() results."""
+        out = {}
+        for k, v in b.items():
+            w = a.get(k, {})
+            d = {f: (v[f] - w.get(f, 0)) / per for f in v}
+            if d["calls"]:
+                out[k] = d
+        return out
 
     def _stage(self, t):
         return t.detach().cpu() if (self.staged and t.is_cuda) else t
 
     def _call(self, what, fn, *a, **k):
         """A failed collective leaves the ranks out of step: every later exchange would hang or mix batches.  Say which
-        rank failed in what and re-raise as CollectiveError; launcher scripts (bench.py, main.run) turn that into a
-        non-zero exit of the whole job (failure detection; the launcher reaps the others).  Errors that never
+        rank failed in what and re-raise as CollectiveError; launcher scripts (bench.py, main.run: exit_on_collective_error
+        above) turn that into exit code 70 of this rank at once (failure detection; the launcher reaps the others).  Errors that never
         left this rank (a bad split list, a dtype mismatch: TypeError / ValueError) pass through unchanged.  With
         MMLREC_COMM_EXIT=1 a backend failure ends the process at once (for jobs without such a launcher)."""
         try:
@@ -75,24 +117,42 @@ class Comm:
 
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         o, i = self._stage(out), self._stage(inp)
+        row_i = inp.element_size() * (inp.numel() // max(inp.shape[0], 1)) if inp.dim() else inp.element_size()
+        row_o = out.element_size() * (out.numel() // max(out.shape[0], 1)) if out.dim() else out.element_size()
+        if in_splits is not None:
+            sent = sum(int(n) for r, n in enumerate(in_splits) if r != self.rank) * row_i
+        else:
+            sent = inp.numel() * inp.element_size() * (self.world - 1) // self.world
+        if out_splits is not None:
+            recv = sum(int(n) for r, n in enumerate(out_splits) if r != self.rank) * row_o
+        else:
+            recv = out.numel() * out.element_size() * (self.world - 1) // self.world
+        self._count("all_to_all", sent, recv)
         self._call("all_to_all_single", self.dist.all_to_all_single, o, i, out_splits, in_splits, group=self.group)
         if o is not out:
             out.copy_(o)
 
     def all_reduce(self, t):
         s = self._stage(t)
+        # (a ring moves 2 (N - 1) / N of the buffer per rank and direction)
+        ring = 2 * t.numel() * t.element_size() * (self.world - 1) // self.world
+        self._count("all_reduce", ring, ring)
         self._call("all_reduce(sum)", self.dist.all_reduce, s, op=self.dist.ReduceOp.SUM, group=self.group)
         if s is not t:
             t.copy_(s)
 
     def all_reduce_max(self, t):
         s = self._stage(t)
+        ring = 2 * t.numel() * t.element_size() * (self.world - 1) // self.world
+        self._count("all_reduce", ring, ring)
         self._call("all_reduce(max)", self.dist.all_reduce, s, op=self.dist.ReduceOp.MAX, group=self.group)
         if s is not t:
             t.copy_(s)
 
     def all_gather_into_tensor(self, out, inp):
         o, i = self._stage(out), self._stage(inp)
+        nb = inp.numel() * inp.element_size() * (self.world - 1)
+        self._count("all_gather", nb, nb)
         if self.staged:
             parts = list(o.view(self.world, -1).unbind(0))
             self._call("all_gather", self.dist.all_gather, parts, i.reshape(-1).contiguous(), group=self.group)
@@ -103,6 +163,8 @@ class Comm:
 
     def broadcast(self, t, src):
         s = self._stage(t)
+        nb = t.numel() * t.element_size()
+        self._count("broadcast", nb * (self.world - 1) if self.rank == src else 0, 0 if self.rank == src else nb)
         self._call("broadcast", self.dist.broadcast, s, src=src, group=self.group)
         if s is not t:
             t.copy_(s)

@@ -263,6 +263,7 @@ int mml_gemm_planes_cut(const mml_planes_desc* d, int32_t n, mml_stream_t stream
 int mml_gemm_set_mode(int32_t mode) { (void)mode; return MML_OK; }
 int mml_gemm_get_mode(void) { return 0; }
 const char* mml_gemm_last_kernel(void) { return "cpu"; }
+const char* mml_gather_last_kernel(void) { return "cpu"; }
 
 int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
   (void)stream;

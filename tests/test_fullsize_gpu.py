@@ -201,6 +201,60 @@ def test_full_size_fused_step_other_configs(W, workload, B):
     check_tables(vocab, names, X.numpy(), before, sd, params)
 
 
+@pytest.mark.parametrize("workload,expect", [("mmoe_kuairec", "gemm_pipe_kernel"), ("ple_ijcai", "gemm"),
+                                             ("star_amazon", "gemm_ws_kernel"), ("pepnet_amazon", "gemm_ws_kernel")])
+def test_bench_secondary_configurations_steps_match_oracle(W, workload, expect):
+    """The configurations bench.py's `configs` block times, AS it times them: B = 65 536, HIP-graph
+    replay, the default stream schedule, table_update = "auto" -- where other code runs than at 8 192 (per-layer
+    weight-gradient launches, operand magnitudes + pre-cut planes, STAR's product planes under the weight-stationary
+    kernel, PepNet's 80-wide k-groups).  Two steps (the first eager, the second captured and replayed): losses, every MLP
+    tensor and every table against oracle.train_step, then the kernel symbols of one more (instrumented) step."""
+    from oracle import mmlrec_oracle as orc
+    from mmlrec_amd import engine as E
+    orc.use_fast(True)
+    B = 65536
+    model, cfg, vocab, dense = W.build_model(workload, dev(), table_update="auto", use_hip_graph=True)
+    frozen = _randomize(model, 11)
+    names = [f.name for f in model._sparse_cols()]
+    spec = orc.Spec(cfg, names, vocab, dense)
+    params = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    before = {k: v.copy() for k, v in params.items()}
+    T = W.num_tasks(cfg)
+    kind, lr = cfg["optim_config"]["optimizer"], cfg["optim_config"]["lr"]
+    model.compile(kind, cfg["optim_config"]["loss"], cfg["optim_config"]["metrics"])
+    model.train()
+    runner = model.train_step_runner(B, use_graph=True)   # bench.py secondary_configs' call
+    opt = orc.DenseOptimizer(kind, lr)
+    nsteps, Xs = 2, []
+    for i in range(nsteps):
+        X, y = W.synth_batch(vocab, len(dense), B, T, seed=1 + i)
+        Xs.append(X.numpy())
+        runner.load(X.to(dev()), y.to(dev()))
+        runner.run()
+        loss_gpu = float(runner.plan.loss.item())
+        loss_ref = orc.train_step(spec, params, opt, X.numpy(), y.numpy(), frozen or None)
+        assert abs(loss_gpu - loss_ref) / loss_ref < 1e-4, (i, loss_gpu, loss_ref)
+    segs = [runner.whole] if runner.whole is not None else [runner.front, runner.tail, runner.sideq]
+    assert sum(s_.n_graphs for s_ in segs if s_ is not None) >= 1   # the replayed path really ran
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}  # (lazy_exact: flushes every row first)
+    for k, ref in params.items():
+        if k.startswith("embedding_dict."):
+            continue
+        dv = np.abs(sd[k].astype(np.float64) - ref)
+        assert dv.max() <= 2.5 * lr * nsteps * (10.0 if kind == "rmsprop" else 1.0), k
+        check_update(k, before[k], sd[k], ref)
+    check_tables(vocab, names, np.concatenate(Xs), before, sd, params)
+    # which kernels this configuration's step launches at this size
+    p = runner.plan
+    acc = {}
+    E.Plan.run_timed(list(p.fwd) + list(p.head_train) + list(p.bwd) + list(p.bwd_tail) + list(p.head_side) +
+                     list(p.bwd_side), acc)
+    assert any(expect in k for k in acc), sorted(acc)
+    gemms = [k for k in acc if k.startswith("gemm")]
+    # two scaled fp16 planes (operand magnitudes on from 32 768 samples): no launch falls back to the bf16 x 3 form
+    assert gemms and not any(k.startswith("gemm_pipe_kernel") and ", 3, " in k for k in gemms), gemms
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The BENCHMARKED configuration itself (VERDICT r2: every full-size step above runs B = 8 192 eagerly; bench.py times
 # B = 65 536, HIP-graph replay, two streams, the > 8 192 code paths: per-layer weight-gradient launches, the single

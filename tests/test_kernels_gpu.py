@@ -77,6 +77,56 @@ def test_gather_workgroup_maxima(ops, E, nd, B):
     assert L_.load().mml_gather_wgmax_len(F, 6, 0, B) == 0
 
 
+@pytest.mark.parametrize("wg_per_cu", [1, 4])
+def test_gather_lds_variant_bit_exact(ops, wg_per_cu, monkeypatch):
+    """north_star's "LDS-staged index dedup" (gather_lds_kernel: tables of <= 128 rows served from a per-workgroup LDS
+    copy; opt-in, MMLREC_GATHER_LDS = workgroups per CU): the same bits as gather_vec4_kernel and as numpy, on a field
+    mix with LDS-resident tables, HBM tables, a table that would overflow the 48 KiB LDS budget, dense columns, a ragged
+    batch -- and on the reference-made golden dnn_input of the AE-30 fixture.  The symbol that ran is asserted."""
+    import mmlrec_amd._lib as L_
+    from conftest import load_golden
+    lib = L_.load()
+    rng = np.random.default_rng(7)
+    E, nd, B = 8, 3, 70001
+    vocab = [2, 100, 128, 129, 5000, 100, 1, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 120, 90000]
+    F = len(vocab)
+    tabs = [rng.standard_normal((v, E)).astype(np.float32) for v in vocab]
+    tabs[2] = (np.arange(vocab[2] * E, dtype=np.uint32) * np.uint32(2654435761)).view(np.float32).reshape(vocab[2], E)
+    tabs[2] = np.where(np.isfinite(tabs[2]), tabs[2], np.float32(-3.0)).astype(np.float32)
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    idx[0, :] = 0
+    idx[1, :] = np.array(vocab) - 1
+    X = np.concatenate([idx.astype(np.float32), rng.random((B, nd), dtype=np.float32)], 1)
+    ref = np.concatenate([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
+    dt, dX = [T(t) for t in tabs], T(X)
+    monkeypatch.delenv("MMLREC_GATHER_LDS", raising=False)
+    plain = ops.gather_fwd(dt, dX, list(range(F)), F, nd)
+    assert lib.mml_gather_last_kernel().decode() == "gather_vec4_kernel"
+    monkeypatch.setenv("MMLREC_GATHER_LDS", str(wg_per_cu))
+    status = ops.new_status(dev())
+    out = ops.gather_fwd(dt, dX, list(range(F)), F, nd, status=status)
+    assert lib.mml_gather_last_kernel().decode() == "gather_lds_kernel"
+    ops.check_status(status)
+    assert torch.equal(out, plain)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # out-of-range indices are flagged by this kernel too
+    bad = dX.clone()
+    bad[5, 1] = 100.0
+    ops.gather_fwd(dt, bad, list(range(F)), F, nd, status=status)
+    with pytest.raises(IndexError):
+        ops.check_status(status)
+    # the reference's own dnn_input (tests/golden/mmoe_ae30.npz: 30 fields of 2 .. 96 rows -- every table LDS-resident)
+    g = load_golden("mmoe_ae30")
+    names = [str(n) for n in g["sparse_names"]]
+    gt = [T(g[f"state/embedding_dict.{n}.weight"]) for n in names]
+    out = ops.gather_fwd(gt, T(g["X0"]), list(range(len(names))), len(names), 0)
+    assert lib.mml_gather_last_kernel().decode() == "gather_lds_kernel"
+    assert np.array_equal(out.cpu().numpy(), g["dnn_input"])
+    # the variants that mark rows / leave workgroup maxima keep the plain kernel (they have no LDS form)
+    ops.gather_fwd_wgmax(dt, dX, list(range(F)), F, nd)
+    assert lib.mml_gather_last_kernel().decode() == "gather_vec4_kernel"
+
+
 def test_gather_out_of_range_sets_status(ops):
     tabs = [torch.zeros(10, 8, device=dev())]
     X = torch.tensor([[3.0], [10.0], [-1.0]], device=dev())

@@ -645,3 +645,79 @@ def test_step_uses_precut_weight_planes(monkeypatch):
         if k.startswith("embedding_dict."):
             continue  # (the table scatter's float atomics are order-dependent run to run)
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_recompile_flushes_pending_lazy_updates():
+    """table_update='auto' picks lazy_exact for Adam; a second compile() (new training phase) drops the fused
+    optimizer -- the rows whose zero-gradient steps were still pending must replay them first.  Two Adam steps under
+    'auto', compile() again, read the parameters directly (no state_dict(): that would flush by itself): the tables equal
+    the reference's dense trajectory (the golden adam state after two steps is not stored, so dense_exact is the yardstick,
+    itself pinned by test_fused_train_steps)."""
+    g = load_golden("mmoe_ae30")
+    outs = {}
+    for tu in ("auto", "dense_exact"):
+        model, cfg = build(g, table_update=tu)
+        load_state(model, g)
+        model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+        model.train()
+        assert model.optimizer().table_update == ("lazy_exact" if tu == "auto" else "dense_exact")
+        for i in range(2):
+            step = model.train_step_runner(64, use_graph=False)
+            step.plan.X.copy_(torch.from_numpy(g[f"X{i}"]).cuda())
+            step.plan.y.copy_(torch.from_numpy(g[f"y{i}"]).cuda())
+            step.run()
+        model.compile("adam", cfg["optim_config"]["loss"], ["auc"])   # second phase: must not lose the pending replays
+        assert model._optimizer is None
+        outs[tu] = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    lr = json.loads(str(g["cfg"]))["optim_config"]["lr"]
+    moved = bad = total = 0
+    for n in outs["auto"]:
+        if not n.startswith("embedding_dict."):
+            continue
+        a, b = outs["auto"][n].astype(np.float64), outs["dense_exact"][n].astype(np.float64)
+        # a row only the FIRST batch touched moves in step 2 by ~lr under dense Adam -- the replay this test is about --
+        # so a missing flush shows as an lr-sized difference in all E elements of every such row.  (Elements whose
+        # gradient cancels to rounding noise may flip an lr-sized step between two runs of the float-atomic scatter:
+        # counted, not forbidden.)
+        bad += int((np.abs(a - b) > 1e-2 * lr).sum())
+        total += a.size
+        assert np.abs(a - b).max() <= 2.5 * lr * 2, n
+        moved += int(np.abs(a - g["state/" + n]).max() > 0)
+    assert moved >= 20
+    # rows of step 0's batch that step 1 did not touch (otherwise the test proves nothing)
+    only_first = 0
+    for f in range(len(g["vocab"])):
+        only_first += len(set(g["X0"][:, f].astype(int)) - set(g["X1"][:, f].astype(int)))
+    E_dim = outs["auto"]["embedding_dict.s0.weight"].shape[1]
+    assert only_first >= 10
+    assert bad <= max(2e-3 * total, 4) and bad < only_first * E_dim // 4, (bad, total, only_first)
+
+
+def test_dropout_backward_uses_its_own_forwards_mask_across_plans():
+    """the plans of an uncompiled model share one step counter that every training-mode forward bumps; the
+    backward regenerates the dropout mask, so it must read the value ITS forward drew even when a forward of another
+    plan (another batch size) ran in between."""
+    g = load_golden("mmoe_ae30")
+    P = 0.25
+    bce = torch.nn.functional.binary_cross_entropy
+    X, y = torch.from_numpy(g["X0"]).cuda(), torch.from_numpy(g["y0"]).cuda()
+
+    def grads(interleave):
+        model, cfg = build(g, dnn_dropout=P)
+        load_state(model, g)
+        model.train()
+        yp = model(X)
+        if interleave:
+            model(X[:32])              # another plan (B = 32): bumps the shared counter
+            with torch.no_grad():
+                model(X[:16])          # and a no_grad training-mode forward of a third one
+        loss = sum(bce(yp[:, i], y[:, i], reduction="sum") for i in range(yp.shape[1]))
+        loss.backward()
+        return yp.detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()
+                                           if p.grad is not None and not n.startswith("embedding_dict.")}
+    y0, g0 = grads(False)
+    y1, g1 = grads(True)
+    assert np.array_equal(y0, y1)
+    assert g0.keys() == g1.keys() and len(g0) >= 8
+    for n in g0:  # the MLP gradients are deterministic launches: identical masks give identical bits
+        assert np.array_equal(g0[n], g1[n]), n

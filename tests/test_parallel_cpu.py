@@ -283,3 +283,63 @@ def test_failed_collective_names_the_rank(monkeypatch, capsys):
         comm.all_to_all_single(torch.zeros(4), torch.zeros(4), [1, 2], [2, 2])
     assert not isinstance(ei.value, parallel.CollectiveError)
     assert capsys.readouterr().err == ""
+
+
+def test_exit_on_collective_error_ends_the_process_with_70():
+    """main.run(--is_parallel) / bench.py: a rank that loses a collective must not unwind through ProcessGroup teardown
+    (it can block there while the peers wait for the RCCL timeout): traceback, flush, os._exit(70).  ADVICE r4."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import mmlrec_amd; from mmlrec_amd import parallel\n"
+            "def boom():\n"
+            "    raise parallel.CollectiveError('rank 1/2: collective all_reduce(sum) failed')\n"
+            "print('before', flush=True)\n"
+            "parallel.exit_on_collective_error(boom)\n"
+            "print('unreachable')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 70, (r.returncode, r.stderr[-500:])
+    assert "before" in r.stdout and "unreachable" not in r.stdout
+    assert "CollectiveError" in r.stderr and "all_reduce(sum)" in r.stderr
+    # anything else passes through, results are returned
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import parallel
+    assert parallel.exit_on_collective_error(lambda a, b=0: a + b, 2, b=3) == 5
+    import pytest
+    with pytest.raises(KeyError):
+        parallel.exit_on_collective_error(lambda: {}["x"])
+
+
+def test_comm_counts_calls_and_bytes():
+    """parallel.Comm's host-side counters (bench.py prints them per step so that the first multi-GPU run can be checked
+    against the per-N table of DESIGN section 5): bytes that leave / reach THIS rank."""
+    import torch
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import parallel
+
+    class FakeDist:
+        class ReduceOp:
+            SUM, MAX = 0, 1
+        get_world_size = staticmethod(lambda group=None: 4)
+        get_rank = staticmethod(lambda group=None: 1)
+        get_backend = staticmethod(lambda group=None: "nccl")
+        all_reduce = staticmethod(lambda t, op=None, group=None: None)
+        all_to_all_single = staticmethod(lambda o, i, out_splits=None, in_splits=None, group=None: None)
+        all_gather_into_tensor = staticmethod(lambda o, i, group=None: None)
+        broadcast = staticmethod(lambda t, src=0, group=None: None)
+
+    comm = parallel.Comm(FakeDist)
+    s0 = comm.stats_snapshot()
+    comm.all_reduce(torch.zeros(1000))                        # ring: 2 * 3/4 * 4000 B
+    comm.all_to_all_single(torch.zeros(40, dtype=torch.int32), torch.zeros(60, dtype=torch.int32),
+                           [10, 10, 10, 10], [20, 5, 15, 20])  # rank 1 keeps its own 5 / 10
+    comm.all_to_all_single(torch.zeros(8, 4), torch.zeros(8, 4))  # even split of [8, 4] float rows
+    comm.all_gather_into_tensor(torch.zeros(4, 100), torch.zeros(100))
+    d = comm.stats_delta(s0, comm.stats_snapshot(), per=1)
+    assert d["all_reduce"] == {"calls": 1, "bytes_sent": 6000, "bytes_received": 6000}
+    assert d["all_to_all"]["calls"] == 2
+    assert d["all_to_all"]["bytes_sent"] == (20 + 15 + 20) * 4 + 8 * 4 * 4 * 3 // 4
+    assert d["all_to_all"]["bytes_received"] == 30 * 4 + 8 * 4 * 4 * 3 // 4
+    assert d["all_gather"] == {"calls": 1, "bytes_sent": 1200, "bytes_received": 1200}
+    half = comm.stats_delta(s0, comm.stats_snapshot(), per=2)
+    assert half["all_reduce"]["calls"] == 0.5
