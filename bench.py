@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--parallel-mode", default="row_sharded", choices=["row_sharded", "replicated", "table_wise"],
                     help="how the tables are spread over the ranks when --gpus > 1 (mmlrec_amd/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true",
-                    help="single HIP stream (no wgrad || table-update overlap): kernels do not co-run, so a rocprofv3 "
-                         "--kernel-trace of this command reports stand-alone kernel durations")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="1 (default since round 5: the whole step is ONE HIP graph on one stream; kernels do not co-run, "
+                         "so a rocprofv3 --kernel-trace reports stand-alone kernel durations) or 2 (forked tail: table "
+                         "scatter + table optimizer beside the weight-gradient GEMMs; tools/lab/ab_streams.sh holds the A/B)")
+    ap.add_argument("--serial", action="store_true", help="same as --streams 1 (kept for old command lines)")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary lazy_exact measurement")
     ap.add_argument("--lazy-epoch-steps", type=int, default=500,
                     help="lazy_exact: also time an epoch of this many steps + its flush (0 = skip)")
@@ -536,7 +538,7 @@ def main():
     results = {}
     for B in [args.batch] + ([args.alt_batch] if args.alt_batch and args.alt_batch != args.batch else []):
         batches = make_batches(B)
-        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=not args.serial,
+        runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=(args.streams == 2 and not args.serial),
                                          split_dense="force" if args.split_dense else False)
         steps = args.steps if B == args.batch else max(args.steps, 50)
         warm_losses = [] if (B == args.batch and world == 1 and getattr(model, "_parallel", None) is None) else None

@@ -64,7 +64,10 @@ class _PlanFunction(torch.autograd.Function):
         grads = []
         for name, p in model.named_parameters():
             pv = store.pvals[name]
-            if not pv.written or pv.grad is None:
+            # (the set THIS plan's backward writes, taken when it was recorded: the store's `written` counters belong
+            # to whichever plan was recorded last -- a no_grad forward of a new batch size between this forward and its
+            # backward resets them)
+            if name not in plan.written_names or pv.grad is None:
                 grads.append(None)
             elif pv.is_table:
                 grads.append(pv.grad.clone())
@@ -322,6 +325,7 @@ class BaseModel(nn.Module):
         head = self._build_graph(plan, store, x0)
         head.mask_cols = self._head_mask_cols()
         plan.finish(head)
+        plan.written_names = {n for n, pv in store.pvals.items() if pv.written}
         if (getattr(self, "optim_name", None) is None and plan.dropout_on and
                 any(isinstance(o, E.DropoutOp) for o in plan.ops)):
             # an uncompiled model in a custom training loop: the plan owns its step counter, and nothing else would ever
@@ -483,10 +487,11 @@ class BaseModel(nn.Module):
         return opt
 
     # ---- fused training step ---------------------------------------------------------------------
-    def train_step_runner(self, B, use_graph=None, allreduce=None, overlap=True, split_dense=True):
+    def train_step_runner(self, B, use_graph=None, allreduce=None, overlap=None, split_dense=True):
         """Returns a TrainStep for batch size B (cached).  split_dense: run the reference-exact dense table update as
         (untouched rows beside the forward) + (touched rows after the scatter) when possible (trainer.TrainStep)."""
-        from ..trainer import TrainStep
+        from ..trainer import TrainStep, resolve_overlap
+        overlap = resolve_overlap(overlap)  # (None: the default schedule -- one stream since round 5)
         key = (int(B), bool(self.training))  # BatchNorm follows the MODULE's mode: a step is recorded for one of them
         st = self._caches["steps"].get(key)
         if (st is None or st.store is not self._store() or st.overlap != bool(overlap) or

@@ -2,10 +2,11 @@
 once per batch size and replayed (as HIP graphs when enabled).  Counterpart of the loop body of BaseModel.fit in the
 reference (model/basemodel.py:261-313) minus logging.
 
-Two HIP streams: after the backward chain has produced every dL/d(pre-activation), the step forks --
+Default (round 5): ONE HIP stream, the whole step one HIP graph (resolve_overlap below holds the A/B).  With two streams
+(overlap=True / MMLREC_STREAMS=2), after the backward chain has produced every dL/d(pre-activation), the step forks --
   main stream : table scatter -> table optimizer            (HBM / atomics bound)
   side stream : all weight-gradient GEMMs -> [all-reduce] -> MLP optimizer   (MFMA bound)
--- and joins at the end, so the 3.2 GB table stream of the reference-exact dense Adam hides behind the wgrad GEMMs.
+-- and joins at the end: the table stream of the reference-exact dense Adam beside the wgrad GEMMs.
 
 Multi-GPU steps (parallel.py) contain Python-issued entries (collectives, the row-sharded exchange with its run-time
 sizes).  Those run eagerly; the runs of C-ABI calls between them -- static shapes, static pointers -- are still captured
@@ -77,8 +78,21 @@ class Segments:
         return sum(1 for p in self.parts if p[2] is not None)
 
 
+def resolve_overlap(overlap):
+    """Stream schedule of a fused step: None = the default.  Round 5: ONE stream -- the whole step as one HIP graph.
+    Same-box interleaved A/B of bench.py (three pairs each, tools/lab/ab_streams.sh, profiles/r05_ab_streams.txt): the
+    forked tail (table scatter + table optimizer | weight-gradient GEMMs + MLP optimizer on a second stream) returned
+    +0.5 % on AE-30 at B = 65 536 (1.7158 against 1.7265 ms) and LOST 3.4 % at B = 4 096 (0.693 against 0.670), 1.8 % on
+    PepNet / Amazon-8 (2.238 against 2.200), level on KuaiRec-32: everything it co-schedules is HBM-bound together, and
+    every graph seam costs ~16 us of idle stream.  Two streams stay available: overlap=True, or MMLREC_STREAMS=2."""
+    if overlap is None:
+        return os.environ.get("MMLREC_STREAMS", "1") == "2"
+    return bool(overlap)
+
+
 class TrainStep:
-    def __init__(self, model, B, use_graph=True, allreduce=None, overlap=True, split_dense=True):
+    def __init__(self, model, B, use_graph=True, allreduce=None, overlap=None, split_dense=True):
+        overlap = resolve_overlap(overlap)
         self.model = model
         self.store = model._store()
         self.opt = model.optimizer()
