@@ -264,10 +264,12 @@ def roofline_of(acc):
         m = re.match(r"gemm_pipe_kernel<\w+, \w+, \d+, \d+, (\d+)", name)
         if m and int(m.group(1)) in (1, 2, 3):
             planes = int(m.group(1))
+        elif name.startswith("g16_"):  # bf16-storage kernels (csrc/gemm16.hip): one bf16 MFMA per product block
+            planes = 1
         elif name.startswith(("gemm_ws_kernel", "gemm_panel_kernel")):
             # the weight-stationary / activation-stationary kernels issue the same three f16 MFMAs per product block as
             # gemm_pipe_kernel<..., 2, ...> (csrc/gemm_ws.hip, csrc/gemm_panel.hip), one per block in the bf16 forms
-            planes = 1 if name.endswith("<bf16>") else 2
+            planes = 2
         if planes:  # fp32 emulated on the 16-bit MFMA pipe: 3 (two fp16 planes) or 6 (three bf16 planes) MFMAs per block
             per = {1: 1, 2: 3, 3: 6}[planes]
             peak = 2500.0 / per
@@ -471,7 +473,8 @@ def secondary_configs(args, dev):
     mode0 = lib.mml_gemm_get_mode()
     out = []
     plan = [("configs[1] MMoE / KuaiRec-32, E=16", "mmoe_kuairec", None),
-            ("configs[1] MMoE / KuaiRec-32, E=16, bf16 GEMM operands (opt-in, outside the 1e-4 contract)", "mmoe_kuairec", 1),
+            ("configs[1] MMoE / KuaiRec-32, E=16, bf16 (GEMM mode 1, opt-in, outside the 1e-4 contract: bf16 operands, activations "
+             "and gradients between GEMMs stored as bf16, fp32 accumulation / master weights / optimizer)", "mmoe_kuairec", 1),
             ("configs[2] PLE / Ijcai-7, 2 levels x (3 specific + 2 shared) experts", "ple_ijcai", None),
             ("configs[4] STAR / Amazon-8", "star_amazon", None),
             ("configs[4] PepNet / Amazon-8", "pepnet_amazon", None)]
@@ -486,7 +489,7 @@ def secondary_configs(args, dev):
             T = W.num_tasks(cfg)
             entry = {"config": label, "workload": describe_workload(wl, cfg, vocab, dense),
                      "table_update": model.optimizer().table_update,
-                     "dtype": "bf16 GEMM operands, f32 accumulate" if mode == 1 else "f32", "runs": []}
+                     "dtype": "bf16 storage + operands, f32 accumulate" if mode == 1 else "f32", "runs": []}
             for B, steps in ((65536, 10), (4096, 40)):
                 batches = []
                 for i in range(2):

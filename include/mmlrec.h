@@ -469,7 +469,16 @@ typedef struct {
   uint32_t* amax_mix;
   uint32_t* amax_dE;
   uint32_t* amax_dG;
+  /* bf16-storage path (K3'): bit 0 = every gate's `mix` is a bf16 [B, H] buffer (ldmix in bf16 elements), bit 1 = every
+   * dE, bit 2 = every dG -- the tensors that only GEMMs read are written as their operands (round to nearest even);
+   * everything the kernels READ stays fp32.  Only the fast row kernels honour it: other shapes return
+   * MML_ERR_UNSUPPORTED when a bit is set. */
+  int32_t out_bf16;
+  int32_t pad_;
 } mml_gate_group;
+#define MML_GATE_MIX_BF16 1
+#define MML_GATE_DE_BF16 2
+#define MML_GATE_DG_BF16 4
 int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream);
 int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp);
 int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);
@@ -503,7 +512,8 @@ typedef struct {
   int32_t mask_col;  /* column of `mask` multiplied into the probability, or -1                        */
 } mml_head_desc;
 typedef struct {
-  int32_t n_heads; int32_t pad_;
+  int32_t n_heads;
+  int32_t dh_bf16;    /* bf16-storage path (K3'): 1 = every head's dH is a bf16 [B, H] buffer (lddh in bf16 elements); fast kernel only */
   int64_t B;
   float* prob;        /* [B, ldprob] probabilities, head t in column t                                 */
   int64_t ldprob;
@@ -526,6 +536,70 @@ int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t wor
  * partial sums into dw / dbias / loss (phase 0 = both); see mml_gate_mix_bwd_phase. */
 int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
                                mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3'  bf16-STORAGE GEMM family (round 5; csrc/gemm16.hip) -- BASELINE.json configs[1] ("MMoE ... KuaiRec-shaped ...
+ * bf16"): the DNN layers of model/utils.py:146-161 with activations and their gradients STORED as bf16 wherever
+ * producer and consumers are GEMMs.  Arithmetic: one v_mfma_f32_32x32x16_bf16 per 16-k block, fp32 accumulation --
+ * exactly the products of mml_gemm_set_mode(1) (operands rounded to bf16, there in registers, here when they are
+ * stored), with half the activation traffic and no conversion work in the kernels: bf16 tiles go HBM -> LDS by DMA and
+ * LDS -> MFMA fragments as they are (ds_read_b128; the batch-reduction of the weight gradient through the transposing
+ * LDS read ds_read_b64_tr_b16).  Opt-in like mode 1, outside the 1e-4 fp32 parity contract; bf16 values are
+ * uint16_t bit patterns (round to nearest even).
+ *   mml_cast16_batch      bf16 copies of fp32 matrices, optionally transposed: the weights of a step, once per step
+ *                         ([N, K] for the forward, [K, N] for the input gradient -- both read reduction-contiguous)
+ *   mml_gather16_fwd      mml_gather_fwd writing dnn_input as bf16 (the table rows rounded on the way)
+ *   mml_g16_tn            C[M, N] = epilogue(sum_s A_s[M, K_s] B_s[N, K_s]^T): forward (one source, + bias, ReLU, ReLU
+ *                         sign masks like mml_gemm_fwd_desc.relu_mask) and input gradient (the sources of
+ *                         mml_gemm_dgrad_desc with the TRANSPOSED bf16 weights, ReLU derivative from the sign masks);
+ *                         C bf16 or fp32.  M % 128 == 0, N % 64 == 0, every K_s % 64 == 0, 16-byte aligned rows.
+ *   mml_g16_wgrad         dW[N, K] (+)= dC[M, N]^T A[M, K], dbias[N] (+)= column sums of dC; dC, A bf16, dW / dbias
+ *                         fp32; the batch is cut into slabs, partial tiles go to the workspace and are summed in a fixed
+ *                         order (bitwise reproducible).  N % 128 == 0, K % 128 == 0, M % 64 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src;   /* fp32 [rows, cols], row pitch lds (elements) */
+  uint16_t* dst;      /* bf16 [rows, cols] (transpose = 0) or [cols, rows] (transpose = 1), row pitch ldd */
+  int64_t rows, lds, ldd;
+  int32_t cols, transpose;
+} mml_cast16_desc;
+int mml_cast16_batch(const mml_cast16_desc* descs, int32_t n, mml_stream_t stream);
+int mml_gather16_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                     const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, uint16_t* out, int64_t ldo,
+                     int32_t* status, mml_stream_t stream);
+typedef struct {
+  int32_t M, N;
+  int32_t n_src;      /* 1 .. MML_MAX_SRC: the reduction runs over the sources one after the other */
+  int32_t act;        /* MML_ACT_NONE / MML_ACT_RELU applied to (sum + bias) -- forward */
+  const uint16_t* A[MML_MAX_SRC];   /* bf16 [M, K_s] */
+  const uint16_t* B[MML_MAX_SRC];   /* bf16 [N, K_s]: the weight with the reduction along its rows */
+  int64_t lda[MML_MAX_SRC], ldb[MML_MAX_SRC];
+  int32_t K[MML_MAX_SRC];
+  const float* bias;  /* [N] or NULL */
+  void* C;            /* [M, N]: bf16 (c_bf16 = 1) or fp32 */
+  int64_t ldc;
+  int32_t c_bf16;
+  int32_t accumulate; /* fp32 C only: C += result */
+  uint32_t* mask_out;       /* forward, act = RELU: bit (c & 31) of mask_out[r * ldmask + (c >> 5)] = (C[r][c] > 0), or NULL */
+  const uint32_t* mask_in;  /* input gradient: the result is multiplied by that bit (ReLU derivative), or NULL */
+  int64_t ldmask;
+} mml_g16_tn_desc;
+int mml_g16_tn(const mml_g16_tn_desc* descs, int32_t n, mml_stream_t stream);
+typedef struct {
+  const uint16_t* dC; /* bf16 [M, N] */
+  const uint16_t* A;  /* bf16 [M, K] */
+  float* dW;          /* fp32 [N, K] */
+  float* dbias;       /* fp32 [N] or NULL */
+  int64_t lddc, lda, lddw;
+  int32_t M, N, K;
+  int32_t accumulate;
+} mml_g16_wgrad_desc;
+int64_t mml_g16_wgrad_workspace_bytes(const mml_g16_wgrad_desc* descs, int32_t n);
+/* phase 0 = both launches, 1 = the partial products, 2 = their reduction (like mml_gemm_grouped_wgrad_phase) */
+int mml_g16_wgrad(const mml_g16_wgrad_desc* descs, int32_t n, void* workspace, int64_t workspace_bytes, int32_t phase,
+                  mml_stream_t stream);
+/* Kernel symbol of the calling thread's most recent launch of this family ("" before the first). */
+const char* mml_g16_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * K6/K7  elementwise helpers for STAR / PepNet.

@@ -55,6 +55,25 @@ class GemmWgradDesc(C.Structure):
                 ("amax_dc", fp), ("amax_a", fp)]
 
 
+class Cast16Desc(C.Structure):
+    _fields_ = [("src", fp), ("dst", fp), ("rows", i64), ("lds", i64), ("ldd", i64), ("cols", i32), ("transpose", i32)]
+
+
+class G16TnDesc(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("n_src", i32), ("act", i32), ("A", fp * MAX_SRC), ("B", fp * MAX_SRC),
+                ("lda", i64 * MAX_SRC), ("ldb", i64 * MAX_SRC), ("K", i32 * MAX_SRC), ("bias", fp), ("C", fp),
+                ("ldc", i64), ("c_bf16", i32), ("accumulate", i32), ("mask_out", fp), ("mask_in", fp), ("ldmask", i64)]
+
+
+class G16WgradDesc(C.Structure):
+    _fields_ = [("dC", fp), ("A", fp), ("dW", fp), ("dbias", fp), ("lddc", i64), ("lda", i64), ("lddw", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("accumulate", i32)]
+
+
+G16_MAX_GROUP = 8
+GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16 = 1, 2, 4
+
+
 class GateDesc(C.Structure):
     _fields_ = [("G", fp), ("Wg", fp), ("P", fp), ("mix", fp), ("dmix", fp), ("dG", fp), ("dWg", fp),
                 ("ldg", i64), ("ldp", i64), ("ldmix", i64), ("lddmix", i64), ("lddg", i64),
@@ -64,7 +83,8 @@ class GateDesc(C.Structure):
 class GateGroup(C.Structure):
     _fields_ = [("E", fp * MAX_EXPERTS), ("dE", fp * MAX_EXPERTS), ("lde", i64 * MAX_EXPERTS),
                 ("ldde", i64 * MAX_EXPERTS), ("n_experts", i32), ("n_gates", i32), ("H", i32), ("e_relu", i32),
-                ("B", i64), ("gate", GateDesc * MAX_GATES), ("amax_mix", fp), ("amax_dE", fp), ("amax_dG", fp)]
+                ("B", i64), ("gate", GateDesc * MAX_GATES), ("amax_mix", fp), ("amax_dE", fp), ("amax_dG", fp),
+                ("out_bf16", i32), ("pad_", i32)]
 
 
 class HeadDesc(C.Structure):
@@ -74,7 +94,7 @@ class HeadDesc(C.Structure):
 
 
 class HeadGroup(C.Structure):
-    _fields_ = [("n_heads", i32), ("pad_", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
+    _fields_ = [("n_heads", i32), ("dh_bf16", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
                 ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("dprob", fp), ("lddprob", i64),
                 ("head", HeadDesc * MAX_HEADS), ("amax_dH", fp)]
 
@@ -144,6 +164,12 @@ _SIGS = {
     "mml_gemm_last_kernel": (C.c_char_p, []),
     "mml_gather_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),
+    "mml_cast16_batch": (C.c_int, [_PP(Cast16Desc), i32, fp]),
+    "mml_gather16_fwd": (C.c_int, [_PP(fp), _PP(i64), _PP(i32), i32, i32, fp, i64, i32, i32, i64, fp, i64, fp, fp]),
+    "mml_g16_tn": (C.c_int, [_PP(G16TnDesc), i32, fp]),
+    "mml_g16_wgrad_workspace_bytes": (i64, [_PP(G16WgradDesc), i32]),
+    "mml_g16_wgrad": (C.c_int, [_PP(G16WgradDesc), i32, fp, i64, i32, fp]),
+    "mml_g16_last_kernel": (C.c_char_p, []),
     "mml_gemm_grouped_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),
     "mml_gemm_grouped_dgrad": (C.c_int, [_PP(GemmDgradDesc), i32, fp]),
     "mml_pep_gate_fwd": (C.c_int, [_PP(GemmFwdDesc), i32, fp]),

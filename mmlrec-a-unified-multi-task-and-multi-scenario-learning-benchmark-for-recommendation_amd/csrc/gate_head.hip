@@ -325,6 +325,10 @@ extern "C" int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream) 
   if (grp->B == 0) return MML_OK;
   rc = gate_fwd_fast(grp, to_stream(stream));
   if (rc <= 0) return rc;  // handled by the aligned fast path (or failed there)
+  if (grp->out_bf16) {     // (bf16 outputs exist in the fast row kernels only: include/mmlrec.h)
+    set_error("mml_gate_mix_fwd: out_bf16 on a shape the fast row kernel does not serve");
+    return MML_ERR_UNSUPPORTED;
+  }
   MML_LAUNCH(gate_mix_fwd_kernel, dim3(row_grid(grp->B)), dim3(ROW_BLOCK), 0, to_stream(stream), *grp);
   return check_launch("mml_gate_mix_fwd");
 }
@@ -386,6 +390,10 @@ extern "C" int mml_gate_mix_bwd_phase(const mml_gate_group* grp, void* workspace
         return launch_slab_reduce(R, to_stream(stream), "mml_gate_mix_bwd(reduce)");
       }
     }
+  }
+  if (grp->out_bf16) {  // (bf16 outputs exist in the fast row kernels only: include/mmlrec.h)
+    set_error("mml_gate_mix_bwd: out_bf16 on a shape the fast row kernel does not serve");
+    return MML_ERR_UNSUPPORTED;
   }
   GateBwdAux aux{};
   const int tot = gate_bwd_layout(grp, aux);
@@ -485,6 +493,10 @@ extern "C" int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* works
       fa.slab = aux.slab; fa.stride = aux.stride; fa.train = 1;
       rc = head_fast(grp, fa, to_stream(stream));
     } else {
+      if (grp->dh_bf16) {
+        set_error("mml_head_bce_fwd_bwd: dh_bf16 on a shape the fast row kernel does not serve");
+        return MML_ERR_UNSUPPORTED;
+      }
       MML_LAUNCH(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);
       rc = check_launch("mml_head_bce_fwd_bwd");
     }

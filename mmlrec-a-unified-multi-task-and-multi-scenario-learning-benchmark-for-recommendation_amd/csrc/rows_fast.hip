@@ -56,6 +56,20 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// bf16-storage path (include/mmlrec.h, K3'): a tensor only GEMMs read is written as four bf16 values (8 bytes, round to
+// nearest even) at ELEMENT offset `off` of the same base pointer seen as a bf16 buffer; `as16` is launch-uniform
+__device__ __forceinline__ void st4o(float* base, int64_t off, const float4& v, bool as16) {
+  if (as16) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) =
+        make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, b2)),
+                   __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, b2)));
+  } else {
+    *reinterpret_cast<float4*>(base + off) = v;
+  }
+}
 
 constexpr int FB = 256;          // threads per workgroup
 constexpr int FW = FB / 64;      // waves per workgroup
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 #pragma unroll
         for (int e = 0; e < NE; ++e) fma4(acc, p[e], Ev[e]);  // p[e] == 0 beyond the gate's expert count
         if (valid) {
-          st4(d.mix + b * d.ldmix + 4 * sub, acc);
+          st4o(d.mix, b * d.ldmix + 4 * sub, acc, (g.out_bf16 & MML_GATE_MIX_BF16) != 0);
           amax_acc(am_mix, acc);
         }
       }
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
 #pragma unroll
         for (int x = 0; x < NE; ++x) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], Ev[x]);
         if (valid) {
-          st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 4 * sub, acc);
+          st4o(g.gate[gi].mix, b * g.gate[gi].ldmix + 4 * sub, acc, (g.out_bf16 & MML_GATE_MIX_BF16) != 0);
           amax_acc(am_mix, acc);
         }
       }
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
         }
         if (valid) {
-          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          st4o(d.dG, b * d.lddg + 4 * sub, dg, (g.out_bf16 & MML_GATE_DG_BF16) != 0);
           amax_acc(am_dg, dg);
         }
       }
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev[x].w > 0.f)) acc.w = 0.f;
         }
         if (valid) {
-          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          st4o(g.dE[x], b * g.ldde[x] + 4 * sub, acc, (g.out_bf16 & MML_GATE_DE_BF16) != 0);
           amax_acc(am_de, acc);
         }
       }
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv[gi].w > 0.f)) dg.w = 0.f;
         }
         if (valid) {
-          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          st4o(d.dG, b * d.lddg + 4 * sub, dg, (g.out_bf16 & MML_GATE_DG_BF16) != 0);
           amax_acc(am_dg, dg);
         }
       }
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev[x].w > 0.f)) acc.w = 0.f;
         }
         if (valid) {
-          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          st4o(g.dE[x], b * g.ldde[x] + 4 * sub, acc, (g.out_bf16 & MML_GATE_DE_BF16) != 0);
           amax_acc(am_de, acc);
         }
       }
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Gv.w > 0.f)) dg.w = 0.f;
         }
         if (valid) {
-          st4(d.dG + b * d.lddg + 4 * sub, dg);
+          st4o(d.dG, b * d.lddg + 4 * sub, dg, (g.out_bf16 & MML_GATE_DG_BF16) != 0);
           amax_acc(am_dg, dg);
         }
       }
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
           if (!(Ev.w > 0.f)) acc.w = 0.f;
         }
         if (valid) {
-          st4(g.dE[x] + b * g.ldde[x] + 4 * sub, acc);
+          st4o(g.dE[x], b * g.ldde[x] + 4 * sub, acc, (g.out_bf16 & MML_GATE_DE_BF16) != 0);
           amax_acc(am_de, acc);
         }
       }
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
             if (!(hv.w > 0.f)) dh.w = 0.f;
           }
           if (valid) {
-            st4(d.dH + b * d.lddh + 4 * sub, dh);
+            st4o(d.dH, b * d.lddh + 4 * sub, dh, g.dh_bf16 != 0);
             amax_acc(am_dh, dh);
           }
         }

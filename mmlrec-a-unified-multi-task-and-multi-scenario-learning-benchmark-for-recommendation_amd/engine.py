@@ -54,6 +54,13 @@ class Val:
         self.amax = None
         self.gamax = None
         self.gamax_writers = 0
+        # bf16-storage path (include/mmlrec.h K3'): the value lives in a bf16 buffer -- only GEMMs read it; producer16:
+        # a bf16-storage layer group produced it and will read its GRADIENT as a GEMM operand (Plan.grad_of)
+        self.producer16 = False
+
+    @property
+    def is16(self):
+        return self.buf.dtype == torch.bfloat16
 
     @property
     def n(self):
@@ -107,6 +114,16 @@ class Plan:
         # below.  MMLREC_AMAX=0 / 1 forces.
         env = os.environ.get("MMLREC_AMAX", "")
         self.use_amax = (env != "0") and (env == "1" or self.B >= 32768)
+        # bf16-STORAGE path (round 5, include/mmlrec.h K3'; BASELINE.json configs[1]): under the opt-in reduced-precision
+        # GEMM mode 1 (operands rounded to bf16) the values and gradients that only GEMMs read are STORED as bf16 and the
+        # layer groups that read them run csrc/gemm16.hip -- same products, half the activation traffic, no conversion in
+        # the kernels.  Models mark such values (Plan.val(store16=True)); MMLREC_BF16_STORAGE=0 keeps fp32 buffers.
+        self.bf16 = (device.type == "cuda" and os.environ.get("MMLREC_BF16_STORAGE", "1") != "0" and
+                     L.load().mml_gemm_get_mode() == 1)
+        if self.bf16:
+            self.use_amax = False  # (mode 1 reads no operand magnitudes)
+        self.cast16_items = []   # (fp32 weight, bf16 copy, transposed): refreshed by ONE launch at the start of a step
+        self.cast16_cache = {}
         self.amax_pool = ops.amax_slots(1024, device) if (device.type == "cuda" and self.use_amax) else None
         self.amax_next = 0
         self.amax_weights = {}   # (data_ptr, shape) -> slot
@@ -137,19 +154,48 @@ class Plan:
         ld = (n + 3) // 4 * 4
         return (self.empty(self.B, ld)[:, :n] if ld != n else self.empty(self.B, n)), 0
 
-    def val(self, n, act=L.ACT_NONE, needs_grad=True, name="", buf=None, pad_k=False):
-        """pad_k: for values that feed a GEMM as the reduction operand (see Val.kpad)."""
+    def val(self, n, act=L.ACT_NONE, needs_grad=True, name="", buf=None, pad_k=False, store16=False):
+        """pad_k: for values that feed a GEMM as the reduction operand (see Val.kpad).  store16: the value is read by
+        bf16-storage layer groups ONLY (the caller vouches for it; finish() checks) -- a bf16 buffer when the plan runs
+        the bf16-storage path."""
         kp = 0
         if buf is None:
-            buf, kp = self._rows(n, pad_k)
+            if store16 and self.bf16 and n % 8 == 0:
+                buf = self.empty(self.B, n, dtype=torch.bfloat16)
+            else:
+                buf, kp = self._rows(n, pad_k)
         v = Val(buf, act, needs_grad, name)
         v.kpad = kp
         return v
 
+    def _grad16(self, v):
+        """dL/dv as a bf16 buffer: a bf16-storage layer group produced v (it reads the gradient as a GEMM operand), and v's
+        one consumer writes the gradient exactly once, in bf16."""
+        return (self.bf16 and v.producer16 and v.n % 8 == 0 and len(v.consumers) == 1 and
+                v.consumers[0].writes_grad16(self, v))
+
+    def weight16(self, pv, transposed):
+        """bf16 copy of a weight ([N, K], or transposed [K, N]: the input gradient reads W^T rows), refreshed by the
+        cast launch that opens the step."""
+        key = (pv.data.data_ptr(), tuple(pv.data.shape), bool(transposed))
+        if key not in self.cast16_cache:
+            W = pv.data
+            if W.dim() != 2 or W.stride(1) != 1:
+                raise L.MMLError("bf16-storage path: 2-D weights with unit inner stride")
+            shape = (W.shape[1], W.shape[0]) if transposed else tuple(W.shape)
+            dst = torch.zeros(shape, dtype=torch.bfloat16, device=self.device)
+            self.cast16_cache[key] = dst
+            self.cast16_items.append((W, dst, bool(transposed)))
+        return self.cast16_cache[key]
+
     def grad_of(self, v):
         """Allocate v.grad on first use (same row pitch as the value)."""
         if v.grad is None:
-            if v.kpad:
+            if self._grad16(v):
+                v.grad = self.empty(self.B, v.n, dtype=torch.bfloat16)
+            elif v.is16:  # (a bf16 value whose gradient is fp32: the gather's output -- the table scatter reads it)
+                v.grad = self.empty(self.B, v.n)
+            elif v.kpad:
                 v.grad = self.zeros(self.B, v.kpad)[:, :v.n]
             else:
                 ld = (v.n + 3) // 4 * 4
@@ -369,6 +415,7 @@ class Plan:
         self.head_infer = head_op.infer_calls(self)
         if not self.training:
             self._amax_prologue()
+            self._cast16_prologue()
             return
         calls = head_op.train_calls(self, use_dprob=False)
         is_side = lambda c: isinstance(c[-1], dict) and c[-1].get("side")  # noqa: E731
@@ -379,6 +426,8 @@ class Plan:
         for op in reversed(self.ops):
             for v in op.outputs():
                 if isinstance(v, Val) and v.grad is not None and v.act != L.ACT_NONE and not v.deriv_applied:
+                    if v.is16 or v.grad.dtype != torch.float32:
+                        raise L.MMLError(f"bf16 value {v.name!r}: its activation derivative must fold into its one consumer")
                     self.bwd.append((L.load().mml_act_bwd, (v.buf.data_ptr(), v.grad.data_ptr(), v.grad.data_ptr(),
                                                             self._flat_numel(v), v.act)))
                     v.deriv_applied = True
@@ -397,10 +446,29 @@ class Plan:
             for c in mine:
                 c[-1]["ready"] = len(self.bwd)
         self._amax_prologue()
+        self._cast16_prologue()
         # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
         # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
+
+    def _cast16_prologue(self):
+        """bf16-storage path: the bf16 copies of the weights, ONE launch in front of everything else; and the promise
+        behind every bf16 value -- only bf16-storage layer groups read it -- is checked."""
+        for op in list(self.ops) + [getattr(self, "head_op", None)]:
+            for v in (op.inputs() if op is not None else []):
+                if isinstance(v, Val) and v.is16 and not (isinstance(op, LinearGroupOp) and op.use16):
+                    raise L.MMLError(f"bf16 value {v.name!r} is read by {type(op).__name__}: only bf16-storage layer "
+                                     "groups may read a store16 value")
+        if not self.cast16_items or getattr(self, "_cast16_done", False):
+            return
+        arr = ops.make_cast16_descs(self.cast16_items)
+        self.keep.append(arr)
+        n = sum(w.numel() for w, _, _ in self.cast16_items)
+        self.fwd.insert(0, (L.load().mml_cast16_batch, (arr, len(self.cast16_items)),
+                            dict(kernel="cast16_kernel", bytes=6.0 * n)))
+        self.n_pre += 1
+        self._cast16_done = True
 
     def _amax_prologue(self):
         """Zero EVERY magnitude slot of the plan (forward and backward ones: the producers only ever raise them) and
@@ -518,6 +586,10 @@ def _opt_dense_symbol(numel, ntensors, form=0):
 
 
 class Op:
+    def writes_grad16(self, plan, v):
+        """bf16-storage path: this op, as the ONLY consumer of v, writes dL/dv once and can write it as bf16."""
+        return False
+
     def inputs(self):
         return []
 
@@ -566,6 +638,13 @@ class GatherOp(Op):
         meta = dict(kernel="gather_vec4_kernel" if E % 4 == 0 else "gather_scalar_kernel",
                     bytes=float(plan.B) * (F * (4 + 8 * E) + 8 * self.nd))  # index + row read + row write
         mr = self.mark_rows
+        if self.out.is16:  # bf16-storage path: dnn_input leaves the gather as the first layers' GEMM operand
+            if mr is not None:
+                raise L.MMLError("the row-marking gather has no bf16 form (split dense update)")
+            meta16 = dict(kernel="gather16_kernel", bytes=float(plan.B) * (F * (4 + 6 * E) + 6 * self.nd))
+            return [(lib.mml_gather16_fwd, (tabs, vocab, col, F, E, self.X.data_ptr(), ops._ld(self.X), self.dense_col0,
+                                            self.nd, plan.B, self.out.buf.data_ptr(), ops._ld(self.out.buf),
+                                            plan.status.data_ptr()), meta16)]
         if mr is not None:
             ps = ops._ptr_array(mr.seen)
             rb = (L.i64 * (F + 1))(*mr.rowbase)
@@ -635,6 +714,19 @@ class GatherOp(Op):
                  (plan.status.data_ptr(),), meta)]
 
 
+def g16_layer_ok(B, K, N, training):
+    """A Linear(K -> N) at batch B can run on the bf16-storage kernels (include/mmlrec.h K3': tile-aligned extents; the
+    weight gradient's tiles are 128 x 128)."""
+    ok = B % 128 == 0 and K % 64 == 0 and N % 64 == 0 and K > 0 and N > 0
+    if training:
+        ok = ok and K % 128 == 0 and N % 128 == 0
+    return ok
+
+
+def _fast_row_width_ok(n):
+    return n % 4 == 0 and 0 < n <= 256  # (csrc/rows_fast.hip: gate_fast_config / head_fast_config)
+
+
 def _padded_view(buf, kp):
     """[B, kp] view over a value / gradient allocated by Plan._rows (columns [n, kp) are zero)."""
     if buf.stride(0) < kp or buf.stride(1) != 1:
@@ -670,9 +762,120 @@ class LinearGroupOp(Op):
 
     def __init__(self, problems):
         self.p = problems
+        self.use16 = False  # bf16-storage path (csrc/gemm16.hip): decided when the forward is recorded
         for q in self.p:
             if q.get("mul") is not None:
                 q["prod"].gate = (q["mul"], q["out"])  # (h, g): factors of the product, for the consumer's dgrad
+
+    def writes_grad16(self, plan, v):
+        return self.use16 and v.is16
+
+    # ---- bf16-storage path (include/mmlrec.h K3') --------------------------------------------------------------
+    def _fwd16(self, plan):
+        lib = L.load()
+        probs = []
+        for q in self.p:
+            out = q["out"]
+            if (not q["x"].is16 or q.get("w_kn") or q.get("mul") is not None or q["x"].kpad or
+                    not g16_layer_ok(plan.B, q["x"].n, out.n, plan.training)):
+                raise L.MMLError("bf16-storage layer group: every problem needs a bf16 input, a plain nn.Linear weight and "
+                                 f"tile-aligned extents (got {q['x'].n} -> {out.n} at batch {plan.B})")
+            if out.act not in (L.ACT_NONE, L.ACT_RELU):
+                raise NotImplementedError("bf16-storage layer group: relu / linear activations")
+            if plan.training and out.act == L.ACT_RELU and out.mask is None:
+                out.mask = torch.zeros(plan.B, (out.n + 31) // 32, dtype=torch.int32, device=plan.device)
+            out.producer16 = True
+            probs.append(dict(srcs=[(q["x"].buf, plan.weight16(q["W"], False))], C=out.buf,
+                              bias=q["b"].data if q.get("b") else None, act=out.act,
+                              mask_out=out.mask if out.act == L.ACT_RELU else None))
+        calls = []
+        for i in range(0, len(probs), L.G16_MAX_GROUP):
+            ch, qs = probs[i:i + L.G16_MAX_GROUP], self.p[i:i + L.G16_MAX_GROUP]
+            descs = ops.make_g16_tn_descs(ch)
+            plan.keep.append(descs)
+            meta = dict(kernel="g16_tn_kernel(fwd)", flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in qs),
+                        hbm_bytes=_distinct_bytes([q["x"].buf for q in qs] + [q["out"].buf for q in qs] +
+                                                  [q["out"].mask for q in qs]) +
+                        2.0 * sum(q["W"].data.numel() for q in qs))
+            calls.append((lib.mml_g16_tn, (descs, len(ch)), meta))
+        return calls
+
+    def _bwd16(self, plan):
+        lib = L.load()
+        calls = []
+        live = [q for q in self.p if q["out"].grad is not None]
+        # the incoming gradients as bf16 operands: written that way by their producer (Plan.grad_of), else cast here
+        casts = []
+        for q in live:
+            g = q["out"].grad
+            if g.dtype == torch.bfloat16:
+                q["dC16"] = g
+            else:
+                if q["out"].act != L.ACT_NONE and not q["out"].deriv_applied:
+                    raise L.MMLError("bf16-storage layer group: the activation derivative must be applied upstream")
+                q["dC16"] = plan.empty(plan.B, q["out"].n, dtype=torch.bfloat16)
+                casts.append((g, q["dC16"], False))
+        if casts:
+            arr = ops.make_cast16_descs(casts)
+            plan.keep.append(arr)
+            calls.append((lib.mml_cast16_batch, (arr, len(casts)),
+                          dict(kernel="cast16_kernel", bytes=6.0 * sum(g.numel() for g, _, _ in casts))))
+        # weight / bias gradients (side list: only the optimizer reads them)
+        wg = []
+        for q in live:
+            W, b = q["W"], q.get("b")
+            if not W.needs_grad:
+                continue
+            acc = _claim(W)
+            if b is not None and b.needs_grad and _claim(b) != acc:
+                raise L.MMLError("weight and bias of one layer must be written in the same order")
+            wg.append(dict(dC=q["dC16"], A=q["x"].buf, dW=W.grad, dbias=b.grad if (b and b.needs_grad) else None,
+                           accumulate=acc))
+        for i in range(0, len(wg), L.G16_MAX_GROUP):
+            ch = wg[i:i + L.G16_MAX_GROUP]
+            descs = ops.make_g16_wgrad_descs(ch)
+            nbytes = int(lib.mml_g16_wgrad_workspace_bytes(descs, len(ch)))
+            if nbytes < 0:
+                L.check(-1, "mml_g16_wgrad_workspace_bytes")
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=plan.device)
+            plan.keep += [descs, ws]
+            meta = dict(kernel="g16_nt_kernel(wgrad)", flops=sum(2.0 * plan.B * q["dW"].numel() for q in ch), side=True,
+                        rank=0, hbm_bytes=_distinct_bytes([q["dC"] for q in ch] + [q["A"] for q in ch] +
+                                                          [q["dW"] for q in ch]))
+            calls.append((lib.mml_g16_wgrad, (descs, len(ch), ws.data_ptr(), ws.numel(), 1), meta))
+            calls.append((lib.mml_g16_wgrad, (descs, len(ch), ws.data_ptr(), ws.numel(), 2),
+                          dict(kernel="g16_reduce_kernel", bytes=float(nbytes), side=True, rank=1)))
+        # input gradients: one problem per distinct input value, its layers as the sources
+        by_x = {}
+        for q in live:
+            if q["x"].needs_grad:
+                by_x.setdefault(id(q["x"]), (q["x"], []))[1].append(q)
+        dg = []
+        for x, qs in by_x.values():
+            if len(qs) > L.MAX_SRC:
+                raise NotImplementedError("bf16-storage layer group: more than MAX_SRC layers on one input")
+            plan.grad_of(x)
+            fuse = len(x.consumers) == 1 and x.act == L.ACT_RELU and x.mask is not None
+            if x.act != L.ACT_NONE and not fuse:
+                raise L.MMLError(f"bf16 value {x.name!r}: its activation derivative must fold into its one consumer")
+            acc = _claim(x)
+            if acc and x.grad.dtype != torch.float32:
+                raise L.MMLError("bf16 gradients cannot accumulate")
+            dg.append((dict(srcs=[(q["dC16"], plan.weight16(q["W"], True)) for q in qs], C=x.grad, accumulate=acc,
+                            mask_in=x.mask if fuse else None), x, qs))
+            if fuse:
+                x.deriv_applied = True
+        for i in range(0, len(dg), L.G16_MAX_GROUP):
+            ch = dg[i:i + L.G16_MAX_GROUP]
+            descs = ops.make_g16_tn_descs([c[0] for c in ch])
+            plan.keep.append(descs)
+            meta = dict(kernel="g16_tn_kernel(dgrad)",
+                        flops=sum(2.0 * plan.B * x.n * sum(q["out"].n for q in qs) for _, x, qs in ch),
+                        hbm_bytes=_distinct_bytes([x.grad for _, x, _ in ch] + [x.mask for _, x, _ in ch] +
+                                                  [q["dC16"] for _, _, qs in ch for q in qs]) +
+                        2.0 * sum(q["W"].data.numel() for _, _, qs in ch for q in qs))
+            calls.append((lib.mml_g16_tn, (descs, len(ch)), meta))
+        return calls
 
     def inputs(self):
         return [q["x"] for q in self.p] + [q["mul"] for q in self.p if q.get("mul") is not None]
@@ -681,6 +884,9 @@ class LinearGroupOp(Op):
         return [q["out"] for q in self.p] + [q["prod"] for q in self.p if q.get("mul") is not None]
 
     def fwd_calls(self, plan):
+        if plan.bf16 and any(q["x"].is16 for q in self.p):
+            self.use16 = True
+            return self._fwd16(plan)
         # training plans: a ReLU output also leaves its sign bits (1 bit per element) for the dgrad that will apply
         # relu' to its gradient -- 32x less to re-read than the activations themselves
         for q in self.p:
@@ -737,6 +943,8 @@ class LinearGroupOp(Op):
         return pre + [(L.load().mml_gemm_grouped_fwd, (descs, len(self.p)), meta)]
 
     def bwd_calls(self, plan):
+        if self.use16:
+            return self._bwd16(plan)
         lib = L.load()
         calls = []
         live = [q for q in self.p if q["out"].grad is not None]
@@ -914,6 +1122,11 @@ class GateGroupOp(Op):
     def __init__(self, experts, gates, H):
         self.experts, self.gates, self.H = experts, gates, H
 
+    def writes_grad16(self, plan, v):
+        # (the fast row kernels write dE / dG as bf16: mml_gate_group.out_bf16; their shape conditions)
+        return (_fast_row_width_ok(self.H) and all(_fast_row_width_ok(g["G"].n) for g in self.gates) and
+                len(self.experts) * max(len(self.gates), 2) <= 32)
+
     def inputs(self):
         return list(self.experts) + [g["G"] for g in self.gates]
 
@@ -1012,6 +1225,11 @@ class HeadOp(Op):
     def __init__(self, heads, mask_cols=None):
         self.heads = heads
         self.mask_cols = mask_cols
+
+    def writes_grad16(self, plan, v):
+        # (the fast head kernel writes dH as bf16: mml_head_group.dh_bf16 -- all heads or none)
+        return (type(self) is HeadOp and all(_fast_row_width_ok(h["Hin"].n) for h in self.heads) and
+                all(h["Hin"].producer16 and h["Hin"].n % 8 == 0 and len(h["Hin"].consumers) == 1 for h in self.heads))
 
     def inputs(self):
         return [h["Hin"] for h in self.heads]

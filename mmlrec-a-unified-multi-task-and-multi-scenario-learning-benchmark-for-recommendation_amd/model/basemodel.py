@@ -284,7 +284,10 @@ class BaseModel(nn.Module):
                 if self.feature_index[f.name][0] != pos:
                     raise NotImplementedError("dense feature columns must be contiguous in X")
                 pos += f.dimension
-        x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input", pad_k=True)
+        par_ = getattr(self, "_parallel", None)
+        x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input", pad_k=True,
+                      store16=(plan.bf16 and par_ is None and mark_rows is None and E_dim % 4 == 0 and
+                               self._dnn_input_store16(plan)))
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
         cols = [self.feature_index[f.name][0] for f in sp]
         par = getattr(self, "_parallel", None)
@@ -371,6 +374,11 @@ class BaseModel(nn.Module):
     def _build_graph(self, plan, store, x0):
         raise NotImplementedError
 
+    def _dnn_input_store16(self, plan):
+        """bf16-storage path (engine.Plan.bf16): True when ONLY bf16-storage layer groups read dnn_input in this model's
+        graph, so that the gather may write it as bf16 (models override; Plan.finish checks the promise)."""
+        return False
+
     def flush_tables(self):
         """lazy_exact table optimizer: replay the zero-gradient steps of rows the recent batches did not touch, so that
         every table equals what the reference's dense optimizer holds.  Called automatically by forward / predict /
@@ -425,9 +433,9 @@ class BaseModel(nn.Module):
         out = {}
         for k, v in plan.layer_outputs.items():
             if isinstance(v, (list, tuple)):
-                out[k] = torch.stack([getattr(x, "buf", x) for x in v], 1).clone()
+                out[k] = torch.stack([getattr(x, "buf", x).float() for x in v], 1).clone()
             else:
-                out[k] = getattr(v, "buf", v).clone()
+                out[k] = getattr(v, "buf", v).float().clone()  # (bf16-storage plans keep some values as bf16)
         return out
 
     # ---- compile (reference :557-647) ------------------------------------------------------------

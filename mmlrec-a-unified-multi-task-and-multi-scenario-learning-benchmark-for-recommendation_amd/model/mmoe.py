@@ -38,6 +38,15 @@ class MMOE(BaseModel):
                 filter(lambda x: "weight" in x[0] and "bn" not in x[0], module.named_parameters()), l2=l2)
         self.to(device)
 
+    def _dnn_input_store16(self, plan):
+        """bf16-storage path: dnn_input is read by the first layers of the expert and gate networks only (no gate DNN:
+        the gate kernel reads it too) -- a bf16 buffer when every one of those layers runs on the bf16-storage kernels."""
+        if not hasattr(self, "gate_dnn"):
+            return False
+        plain = not self.model_config.get("dnn_use_bn", False)
+        firsts = [d.linears[0] for d in list(self.expert_dnn) + list(self.gate_dnn)]
+        return plain and all(E.g16_layer_ok(plan.B, l.in_features, l.out_features, plan.training) for l in firsts)
+
     def _build_graph(self, plan, store, x0):
         Ne, T = self.num_experts, self.num_tasks
         stacks = [self.expert_dnn[e].layer_problems(plan, store, f"expert_dnn.{e}", x0) for e in range(Ne)]
@@ -47,8 +56,14 @@ class MMOE(BaseModel):
         experts = tops[:Ne]
         gate_in = tops[Ne:] if hasattr(self, "gate_dnn") else [x0] * T
         H = self.expert_dnn_hidden_units[-1]
+        # bf16-storage path: a task's mixture is read by its tower's first layer only -- the gate kernel writes it as bf16
+        # when that layer runs on the bf16-storage kernels (mml_gate_group.out_bf16)
+        mc = self.model_config
+        mix16 = (plan.bf16 and hasattr(self, "tower_dnn") and not mc.get("dnn_use_bn", False) and
+                 E._fast_row_width_ok(H) and all(E._fast_row_width_ok(g.n) for g in gate_in) and
+                 E.g16_layer_ok(plan.B, H, self.tower_dnn_hidden_units[0], plan.training))
         gates = [dict(G=gate_in[t], Wg=store.pvals[f"gate_dnn_final_layer.{t}.weight"],
-                      mix=plan.val(H, name=f"mmoe_out.{t}"), expert=list(range(Ne))) for t in range(T)]
+                      mix=plan.val(H, name=f"mmoe_out.{t}", store16=mix16), expert=list(range(Ne))) for t in range(T)]
         plan.add(E.GateGroupOp(experts, gates, H))
         plan.layer_outputs["expert_outputs"] = experts
         plan.layer_outputs["mmoe_outputs"] = [g["mix"] for g in gates]

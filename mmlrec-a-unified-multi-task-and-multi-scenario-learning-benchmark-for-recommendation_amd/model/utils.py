@@ -158,8 +158,15 @@ class DNN(nn.Module):
         launches layer l of sibling stacks together (emit_dnn_stacks)."""
         h = x
         out = []
+        plain = not self.use_bn and not (self.dropout_rate and plan.dropout_on)
         for l, lin in enumerate(self.linears):
             q = dict(x=h, W=store.pvals[f"{prefix}.linears.{l}.weight"], b=store.pvals[f"{prefix}.linears.{l}.bias"])
+            # bf16-storage path (engine.Plan.bf16): the value between two layers of the stack is read by the next layer's
+            # GEMM only -- stored as bf16 when this layer and the next both run on the bf16-storage kernels
+            nxt = self.linears[l + 1] if l + 1 < len(self.linears) else None
+            store16 = (plan.bf16 and plain and h.is16 and nxt is not None and
+                       E.g16_layer_ok(plan.B, lin.in_features, lin.out_features, plan.training) and
+                       E.g16_layer_ok(plan.B, nxt.in_features, nxt.out_features, plan.training))
             if self.use_bn:  # the GEMM writes the pre-normalisation value; emit_dnn_stacks adds the BatchNorm op
                 q["out"] = plan.val(lin.out_features, name=f"{prefix}.{l}.z")
                 q["bn"] = dict(y=plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}"),
@@ -167,7 +174,7 @@ class DNN(nn.Module):
                                module=self.bn[l])
                 h = q["bn"]["y"]
             else:
-                q["out"] = h = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}")
+                q["out"] = h = plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}", store16=store16)
             if self.dropout_rate and plan.dropout_on:  # act -> dropout (reference :156-159); emit_dnn_stacks adds the op
                 q["drop"] = dict(x=h, y=plan.val(lin.out_features, name=f"{prefix}.{l}.drop"), p=self.dropout_rate,
                                  site=E.dropout_site(f"{prefix}.{l}"))

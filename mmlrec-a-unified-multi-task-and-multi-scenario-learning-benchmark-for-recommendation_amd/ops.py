@@ -512,6 +512,21 @@ def make_gate_group(experts, gates, B, H, d_experts=None, e_relu=True):
             d.dWg = q["dWg"].data_ptr()
         for s, x in enumerate(q["expert"]):
             d.expert[s] = x
+    # bf16-storage path: tensors only GEMMs read may be bf16 buffers (include/mmlrec.h: mml_gate_group.out_bf16)
+    def _all16(ts, what):
+        ts = [t for t in ts if t is not None]
+        n16 = sum(t.dtype == torch.bfloat16 for t in ts)
+        if n16 not in (0, len(ts)):
+            raise L.MMLError(f"gate group: {what} must be all bf16 or all fp32")
+        return bool(ts) and n16 == len(ts)
+    bits = 0
+    if _all16([q.get("mix") for q in gates], "mix"):
+        bits |= L.GATE_MIX_BF16
+    if d_experts is not None and _all16(list(d_experts), "dE"):
+        bits |= L.GATE_DE_BF16
+    if _all16([q.get("dG") for q in gates], "dG"):
+        bits |= L.GATE_DG_BF16
+    g.out_bf16 = bits
     return g
 
 
@@ -561,6 +576,11 @@ def make_head_group(heads, prob, y=None, mask=None, loss=None, dprob=None):
         d.dw, d.dbias = L.ptr(q.get("dw")), L.ptr(q.get("dbias"))
         d.h_relu = int(q.get("h_relu", 1))
         d.mask_col = int(q.get("mask_col", -1))
+    dhs = [q["dH"] for q in heads if q.get("dH") is not None]
+    n16 = sum(t.dtype == torch.bfloat16 for t in dhs)
+    if n16 not in (0, len(dhs)):
+        raise L.MMLError("head group: dH must be all bf16 or all fp32")
+    g.dh_bf16 = int(bool(dhs) and n16 == len(dhs))  # (include/mmlrec.h: mml_head_group.dh_bf16)
     return g
 
 
@@ -698,3 +718,112 @@ def auc_segments(pred, y, seg):
     L.check(lib.mml_auc_segments(pred.data_ptr(), pred.stride(0), y.data_ptr(), y.stride(0), n, c, int(seg),
                                  out.data_ptr(), _stream()), "mml_auc_segments")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- K3' (bf16 storage)
+def _is16(t):
+    return t.dtype == torch.bfloat16
+
+
+def _need16(t, name):
+    if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
+        raise L.MMLError(f"{name}: expected a bf16 2-D tensor with unit inner stride, got {t.dtype} {tuple(t.shape)}")
+    return t
+
+
+def make_cast16_descs(items):
+    """items: (src fp32 [r, c], dst bf16 [r, c] or, transposed, [c, r], transpose flag)."""
+    arr = (L.Cast16Desc * len(items))()
+    for d, (src, dst, tr) in zip(arr, items):
+        _f32_2d(src, "cast16 source")
+        _need16(dst, "cast16 destination")
+        want = (src.shape[1], src.shape[0]) if tr else tuple(src.shape)
+        if tuple(dst.shape) != want:
+            raise L.MMLError(f"cast16: destination shape {tuple(dst.shape)}, expected {want}")
+        d.src, d.dst, d.rows, d.cols = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
+        d.lds, d.ldd, d.transpose = _ld(src), _ld(dst), int(bool(tr))
+    return arr
+
+
+def cast16(src, transpose=False, out=None):
+    _need_gpu(src)
+    if out is None:
+        shape = (src.shape[1], src.shape[0]) if transpose else tuple(src.shape)
+        out = torch.empty(shape, dtype=torch.bfloat16, device=src.device)
+    arr = make_cast16_descs([(src, out, transpose)])
+    L.check(L.load().mml_cast16_batch(arr, 1, _stream()), "mml_cast16_batch")
+    return out
+
+
+def gather16_fwd(tables, X, cols, dense_col0=0, nd=0, out=None, status=None):
+    """gather_fwd writing dnn_input as bf16 (mml_gather16_fwd)."""
+    lib = L.load()
+    _need_gpu(X, *tables)
+    X = _f32_2d(X, "X")
+    F, E, B = len(tables), tables[0].shape[1], X.shape[0]
+    if out is None:
+        out = torch.empty((B, F * E + nd), dtype=torch.bfloat16, device=X.device)
+    vocab = (L.i64 * F)(*[t.shape[0] for t in tables])
+    col = (L.i32 * F)(*cols)
+    L.check(lib.mml_gather16_fwd(_ptr_array(tables), vocab, col, F, E, X.data_ptr(), _ld(X), dense_col0, nd, B,
+                                 out.data_ptr(), _ld(out), L.ptr(status), _stream()), "mml_gather16_fwd")
+    return out
+
+
+def make_g16_tn_descs(problems):
+    """problems: dicts with srcs [(A bf16 [M, K_s], B bf16 [N, K_s]), ...], C ([M, N] bf16 or fp32), optional bias [N]
+    fp32, act, accumulate, mask_out / mask_in (int32 [M, ceil(N / 32)])."""
+    arr = (L.G16TnDesc * len(problems))()
+    for d, q in zip(arr, problems):
+        Cm = q["C"]
+        d.M, d.N = Cm.shape
+        d.n_src = len(q["srcs"])
+        if not 1 <= d.n_src <= L.MAX_SRC:
+            raise L.MMLError("g16_tn: 1 .. MAX_SRC sources")
+        for s, (A, Bm) in enumerate(q["srcs"]):
+            _need16(A, "g16_tn A")
+            _need16(Bm, "g16_tn B")
+            if A.shape[0] != d.M or Bm.shape[0] != d.N or A.shape[1] != Bm.shape[1]:
+                raise L.MMLError(f"g16_tn: source {s} shapes {tuple(A.shape)} x {tuple(Bm.shape)} for C {tuple(Cm.shape)}")
+            d.A[s], d.B[s], d.lda[s], d.ldb[s], d.K[s] = A.data_ptr(), Bm.data_ptr(), _ld(A), _ld(Bm), A.shape[1]
+        d.act = int(q.get("act", L.ACT_NONE))
+        d.bias = L.ptr(q.get("bias"))
+        d.C, d.ldc, d.c_bf16 = Cm.data_ptr(), _ld(Cm), int(_is16(Cm))
+        if not d.c_bf16 and Cm.dtype != torch.float32:
+            raise L.MMLError("g16_tn: C must be bf16 or fp32")
+        d.accumulate = int(q.get("accumulate", 0))
+        mo, mi = q.get("mask_out"), q.get("mask_in")
+        d.mask_out, d.mask_in = L.ptr(mo), L.ptr(mi)
+        m = mo if mo is not None else mi
+        d.ldmask = _ld(m) if m is not None else 0
+    return arr
+
+
+def g16_tn(problems):
+    arr = make_g16_tn_descs(problems)
+    L.check(L.load().mml_g16_tn(arr, len(problems), _stream()), "mml_g16_tn")
+
+
+def make_g16_wgrad_descs(problems):
+    """problems: dicts with dC bf16 [M, N], A bf16 [M, K], dW fp32 [N, K], optional dbias fp32 [N], accumulate."""
+    arr = (L.G16WgradDesc * len(problems))()
+    for d, q in zip(arr, problems):
+        dC, A, dW = _need16(q["dC"], "g16_wgrad dC"), _need16(q["A"], "g16_wgrad A"), _f32_2d(q["dW"], "g16_wgrad dW")
+        d.M, d.N, d.K = dC.shape[0], dC.shape[1], A.shape[1]
+        if A.shape[0] != d.M or tuple(dW.shape) != (d.N, d.K):
+            raise L.MMLError("g16_wgrad: shape mismatch")
+        d.dC, d.A, d.dW, d.dbias = dC.data_ptr(), A.data_ptr(), dW.data_ptr(), L.ptr(q.get("dbias"))
+        d.lddc, d.lda, d.lddw = _ld(dC), _ld(A), _ld(dW)
+        d.accumulate = int(q.get("accumulate", 0))
+    return arr
+
+
+def g16_wgrad(problems, phases=False):
+    lib = L.load()
+    arr = make_g16_wgrad_descs(problems)
+    n = int(lib.mml_g16_wgrad_workspace_bytes(arr, len(problems)))
+    if n < 0:
+        L.check(-1, "mml_g16_wgrad_workspace_bytes")
+    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=problems[0]["dW"].device)
+    for ph in ((1, 2) if phases else (0,)):
+        L.check(lib.mml_g16_wgrad(arr, len(problems), ws.data_ptr(), ws.numel(), ph, _stream()), "mml_g16_wgrad")

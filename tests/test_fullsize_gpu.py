@@ -444,9 +444,12 @@ def test_bench_sequence_losses_match_fixture(W):
     print("bench-sequence loss rel. errors:", ["%.1e" % r for r in worst])
 
 
-def test_bf16_operand_mode_full_size_kuairec(W):
-    """BASELINE configs[1] names bf16: the opt-in GEMM mode 1 (operands rounded to bf16 in registers, fp32 accumulate,
-    everything else fp32) on the FULL KuaiRec-32 shapes (E = 16, experts 512 -> 512 -> 256) at B = 8 192 against the
+@pytest.mark.parametrize("storage", ["bf16", "fp32"])
+def test_bf16_operand_mode_full_size_kuairec(W, storage, monkeypatch):
+    """BASELINE configs[1] names bf16: the opt-in GEMM mode 1 (operands rounded to bf16, fp32 accumulate) -- with the
+    activations and gradients between GEMMs STORED as bf16 and every layer group on csrc/gemm16.hip (round 5, the default
+    of mode 1), or with fp32 buffers and the operands rounded in registers (MMLREC_BF16_STORAGE=0): the same products,
+    so the same tolerances -- on the FULL KuaiRec-32 shapes (E = 16, experts 512 -> 512 -> 256) at B = 8 192 against the
     fp32 oracle: loss within 2e-3 (measured 3e-6), every MLP weight gradient within 6 % relative rms (the shrunken golden
     with 64 samples only supported 15 %), table gradients within 10 % relative rms over the touched rows.  The reference
     has no bf16 path; SURVEY 8 (A5) probed rms(dlogit)/rms(logit) ~ 8e-3 for it under CPU autocast(bfloat16)."""
@@ -454,6 +457,7 @@ def test_bf16_operand_mode_full_size_kuairec(W):
     from mmlrec_amd import _lib
     lib = _lib.load()
     mode0 = lib.mml_gemm_get_mode()
+    monkeypatch.setenv("MMLREC_BF16_STORAGE", "1" if storage == "bf16" else "0")
     try:
         lib.mml_gemm_set_mode(1)
         model, cfg, vocab, dense = W.build_model("mmoe_kuairec", dev())
@@ -470,7 +474,20 @@ def test_bf16_operand_mode_full_size_kuairec(W):
         step.plan.y.copy_(y.to(dev()))
         step.plan.run_train_fwd_bwd()  # forward + BCE + backward, no optimizer: the gradients stay in their buffers
         torch.cuda.synchronize()
-        assert ", 1, " in lib.mml_gemm_last_kernel().decode()  # the one-plane bf16 kernel really ran
+        calls = list(step.plan.fwd) + list(step.plan.bwd) + list(step.plan.bwd_side)
+        n16 = sum(c[0] in (lib.mml_g16_tn, lib.mml_g16_wgrad) for c in calls)
+        n32 = sum(c[0] in (lib.mml_gemm_grouped_fwd, lib.mml_gemm_grouped_dgrad, lib.mml_gemm_grouped_wgrad_phase)
+                  for c in calls)
+        if storage == "bf16":
+            # every layer group of the model (first / second expert layers, gate networks, towers; forward, input and
+            # weight gradients) runs the bf16-storage kernels, the gather writes bf16, the row kernels bf16 gradients
+            assert n16 >= 9 and n32 == 0, (n16, n32)
+            assert any(c[0] is lib.mml_gather16_fwd for c in calls)
+            assert step.plan.layer_outputs["dnn_input"].buf.dtype == torch.bfloat16
+            assert lib.mml_g16_last_kernel().decode().startswith("g16_")
+        else:
+            assert n16 == 0 and n32 >= 9
+            assert ", 1, " in lib.mml_gemm_last_kernel().decode()  # the one-plane bf16 kernel really ran
         loss_ref, grads, _ = orc.loss_and_grads(spec, params, X.numpy(), y.numpy())
         loss_gpu = float(step.plan.loss.item())
         assert abs(loss_gpu - loss_ref) / loss_ref < 2e-3, (loss_gpu, loss_ref)

@@ -721,3 +721,77 @@ def test_dropout_backward_uses_its_own_forwards_mask_across_plans():
     assert g0.keys() == g1.keys() and len(g0) >= 8
     for n in g0:  # the MLP gradients are deterministic launches: identical masks give identical bits
         assert np.array_equal(g0[n], g1[n]), n
+
+
+def test_bf16_storage_path_equals_operand_rounding_kuairec():
+    """GEMM mode 1 with the activations / gradients between GEMMs STORED as bf16 (csrc/gemm16.hip, the default of mode 1
+    since round 5) against mode 1 on fp32 buffers (operands rounded in registers, MMLREC_BF16_STORAGE=0): the same
+    operand values enter the same products, so loss, probabilities and every gradient agree to fp32 summation order plus
+    the rare value that lands on the other side of a bf16 rounding boundary -- on the KuaiRec-32 MMoE (experts
+    512 -> 512 -> 256, gates 512 -> 128, towers 256 -> 128: reference configs_mtl/config_kuairec.json) at B = 256, for the
+    fused step and for the drop-in forward / autograd path."""
+    import os
+    from mmlrec_amd import _lib, workloads as W
+    lib = _lib.load()
+    mode0 = lib.mml_gemm_get_mode()
+    dev = torch.device("cuda:0")
+    res = {}
+    old = os.environ.get("MMLREC_BF16_STORAGE")
+    try:
+        lib.mml_gemm_set_mode(1)
+        for storage in ("1", "0"):
+            os.environ["MMLREC_BF16_STORAGE"] = storage
+            model, cfg, vocab, dense = W.build_model("mmoe_kuairec", dev, vocab_scale=0.05, seed=0, table_update="dense_exact")
+            g = torch.Generator().manual_seed(3)
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    if p.dim() == 2:
+                        sc = 0.1 if n.startswith("embedding") else (2.0 / p.shape[1]) ** 0.5
+                        p.copy_((torch.randn(p.shape, generator=g) * sc).to(dev))
+            B, T = 256, W.num_tasks(cfg)
+            X, y = W.synth_batch(vocab, len(dense), B, T, seed=5)
+            model.compile("adam", cfg["optim_config"]["loss"], ["auc"])
+            model.train()
+            step = model.train_step_runner(B, use_graph=False)
+            step.plan.X.copy_(X.to(dev))
+            step.plan.y.copy_(y.to(dev))
+            step.plan.run_train_fwd_bwd()
+            torch.cuda.synchronize()
+            calls = list(step.plan.fwd) + list(step.plan.bwd) + list(step.plan.bwd_side)
+            n16 = sum(c[0] in (lib.mml_g16_tn, lib.mml_g16_wgrad) for c in calls)
+            assert (n16 >= 9) == (storage == "1"), (storage, n16)
+            st = model._store()
+            grads = {k: pv.grad.detach().float().cpu().numpy().copy() for k, pv in st.pvals.items() if pv.grad is not None}
+            out = dict(loss=float(step.plan.loss.item()), prob=step.plan.prob.cpu().numpy().copy(), grads=grads)
+            # the drop-in path: forward under autograd, torch's BCE, backward
+            for pv in st.pvals.values():
+                if pv.is_table and pv.grad is not None:
+                    pv.grad.zero_()
+            yp = model(X.to(dev))
+            bce = torch.nn.functional.binary_cross_entropy
+            ls = sum(bce(yp[:, i], y.to(dev)[:, i], reduction="sum") for i in range(T))
+            ls.backward()
+            out["auto_loss"] = float(ls.detach())
+            out["auto_grads"] = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+            res[storage] = out
+            del model, step
+    finally:
+        lib.mml_gemm_set_mode(mode0)
+        if old is None:
+            os.environ.pop("MMLREC_BF16_STORAGE", None)
+        else:
+            os.environ["MMLREC_BF16_STORAGE"] = old
+    a, b = res["1"], res["0"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(b["loss"]), (a["loss"], b["loss"])
+    assert np.abs(a["prob"] - b["prob"]).max() < 1e-4
+    assert abs(a["auto_loss"] - a["loss"]) <= 1e-5 * abs(a["loss"])
+
+    def rms_rel(x, r):
+        x, r = x.astype(np.float64), r.astype(np.float64)
+        return np.sqrt(np.mean((x - r) ** 2)) / max(np.sqrt(np.mean(r ** 2)), 1e-30)
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) >= 20
+    for k in a["grads"]:
+        assert rms_rel(a["grads"][k], b["grads"][k]) < 2e-3, (k, rms_rel(a["grads"][k], b["grads"][k]))
+    for k in a["auto_grads"]:
+        if k in a["grads"]:
+            assert rms_rel(a["auto_grads"][k], a["grads"][k]) < 2e-3, k
