@@ -525,9 +525,10 @@ static int g16_wgrad_plan(const mml_g16_wgrad_desc* d, int32_t n, int* slabs_out
     MML_REQUIRE(q.M == d[0].M && q.M > 0 && q.M % 64 == 0, "mml_g16_wgrad: the problems share M, a positive multiple of 64");
     MML_REQUIRE(q.N > 0 && q.N % 128 == 0 && q.K > 0 && q.K % 128 == 0, "mml_g16_wgrad: N and K must be multiples of 128 (problem %d)", i);
     MML_REQUIRE(q.dC && q.A && q.dW, "mml_g16_wgrad: null operand (problem %d)", i);
-    MML_REQUIRE(aligned16(q.dC) && aligned16(q.A) && aligned16(q.dW) && q.lddc % 8 == 0 && q.lda % 8 == 0 && q.lddw % 4 == 0 &&
-                    q.lddc >= q.N && q.lda >= q.K && q.lddw >= q.K,
-                "mml_g16_wgrad: operands must be 16-byte aligned, bf16 pitches multiples of 8 (problem %d)", i);
+    // (dW / dbias may sit anywhere in a flat gradient arena: the reduction stores them element by element)
+    MML_REQUIRE(aligned16(q.dC) && aligned16(q.A) && q.lddc % 8 == 0 && q.lda % 8 == 0 && q.lddc >= q.N && q.lda >= q.K &&
+                    q.lddw >= q.K,
+                "mml_g16_wgrad: dC and A must be 16-byte aligned with pitches that are multiples of 8 (problem %d)", i);
     tiles += (int64_t)(q.N / 128) * (q.K / 128);
     elems += (int64_t)q.N * q.K + q.N;
   }

@@ -486,7 +486,7 @@ def test_bf16_operand_mode_full_size_kuairec(W, storage, monkeypatch):
             assert step.plan.layer_outputs["dnn_input"].buf.dtype == torch.bfloat16
             assert lib.mml_g16_last_kernel().decode().startswith("g16_")
         else:
-            assert n16 == 0 and n32 >= 9
+            assert n16 == 0 and n32 >= 6, (n16, n32)
             assert ", 1, " in lib.mml_gemm_last_kernel().decode()  # the one-plane bf16 kernel really ran
         loss_ref, grads, _ = orc.loss_and_grads(spec, params, X.numpy(), y.numpy())
         loss_gpu = float(step.plan.loss.item())
