@@ -471,14 +471,16 @@ typedef struct {
   uint32_t* amax_dG;
   /* bf16-storage path (K3'): bit 0 = every gate's `mix` is a bf16 [B, H] buffer (ldmix in bf16 elements), bit 1 = every
    * dE, bit 2 = every dG -- the tensors that only GEMMs read are written as their operands (round to nearest even);
-   * everything the kernels READ stays fp32.  Only the fast row kernels honour it: other shapes return
-   * MML_ERR_UNSUPPORTED when a bit is set. */
+   * bit 3 = every expert output E ARRIVES as bf16 (lde in bf16 elements; written that way by the layer that produced it:
+   * mml_g16_tn_desc.c_bf16) and is widened exactly; everything else the kernels read stays fp32.  Only the fast row
+   * kernels honour it: other shapes return MML_ERR_UNSUPPORTED when a bit is set. */
   int32_t out_bf16;
   int32_t pad_;
 } mml_gate_group;
 #define MML_GATE_MIX_BF16 1
 #define MML_GATE_DE_BF16 2
 #define MML_GATE_DG_BF16 4
+#define MML_GATE_E_BF16 8
 int mml_gate_mix_fwd(const mml_gate_group* grp, mml_stream_t stream);
 int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* grp);
 int mml_gate_mix_bwd(const mml_gate_group* grp, void* workspace, int64_t workspace_bytes, mml_stream_t stream);

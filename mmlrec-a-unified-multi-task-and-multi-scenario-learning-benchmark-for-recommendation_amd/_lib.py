@@ -71,7 +71,7 @@ class G16WgradDesc(C.Structure):
 
 
 G16_MAX_GROUP = 8
-GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16 = 1, 2, 4
+GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16, GATE_E_BF16 = 1, 2, 4, 8
 
 
 class GateDesc(C.Structure):

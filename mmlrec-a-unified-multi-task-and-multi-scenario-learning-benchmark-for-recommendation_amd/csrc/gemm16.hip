@@ -25,6 +25,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
+#ifndef G16_TN_WAVES
+#define G16_TN_WAVES 4   // waves per SIMD the forward / input-gradient kernel is compiled for: 128 VGPRs, 20 bytes of
+                         // scratch in the epilogue; same-box A/B on KuaiRec-32 at 65 536: 1.68 against 1.70 ms with 3 (140 VGPRs)
+#endif
 constexpr int G16_MAX_GROUP = 8;  // problems per launch (the launch struct travels in the 4 KiB kernel-argument block)
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // {bf16(a), bf16(b)}, round to nearest even
@@ -42,6 +46,31 @@ struct Cast16Launch {
 // blockIdx.y = matrix; grid-stride over 4-element pieces of the OUTPUT rows
 __global__ __launch_bounds__(256) void cast16_kernel(const Cast16Launch L) {
   const mml_cast16_desc& d = L.d[blockIdx.y];
+  if (d.transpose) {
+    // 32 x 32 tiles through LDS: 128-byte row pieces are read, 64-byte row pieces of the transposed copy written (the
+    // element-wise form below reads a COLUMN of the source per output row: 36 us for the 3.5 M weights of KuaiRec MMoE)
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tr = (int)((d.rows + 31) >> 5), tc = (d.cols + 31) >> 5;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+      const int64_t r0 = (int64_t)(t / tc) * 32;
+      const int c0 = (t % tc) * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k;
+        tile[ty + 8 * k][tx] = (r < d.rows && c0 + tx < d.cols) ? d.src[r * d.lds + c0 + tx] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k;          // row of the transposed copy
+        const int64_t r = r0 + tx;              // its column
+        if (c < d.cols && r < d.rows) d.dst[(int64_t)c * d.ldd + r] = to_bf16(tile[tx][ty + 8 * k]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int64_t orows = d.transpose ? d.cols : d.rows;
   const int ocols = d.transpose ? (int)d.rows : d.cols;
   const int pieces = (ocols + 3) >> 2;
@@ -132,7 +161,7 @@ struct G16TnLaunch {
 __device__ __forceinline__ int tn_swz(int row) { return (row >> 1) & 7; }
 
 template <int BN>
-__global__ __launch_bounds__(256, 3) void g16_tn_kernel(const G16TnLaunch L) {
+__global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLaunch L) {
   constexpr int NJ = BN / 64;  // 32-column subtiles per wave along N (waves 2 x 2: wave tile 64 x BN/2)
   __shared__ __attribute__((aligned(16))) uint16_t lds[(128 + BN) * 64];
   uint16_t* const sA = lds;
@@ -201,36 +230,131 @@ __global__ __launch_bounds__(256, 3) void g16_tn_kernel(const G16TnLaunch L) {
     }
   }
 
-  // epilogue: element (reg r of subtile i, j) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+  // Epilogue.  Element (reg r of subtile i, j) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of its 32 x 32
+  // subtile: stored from the registers a wave would write 64-byte (bf16) row pieces with 2-byte stores and fetch one mask
+  // word per element.  Instead every wave turns its 64 x BN/2 tile row-major through its quarter of the (now idle)
+  // operand LDS and stores 16 bytes per lane -- whole 128-byte lines; the ReLU sign masks are formed from / applied to the
+  // eight (bf16) or four (fp32) consecutive values a lane then holds (a quad of lanes = one 32-column mask word).
+  constexpr int WTN = BN / 2;                     // columns of a wave's tile
+  constexpr int REGION = (128 + BN) * 64 / 4;     // bf16 elements of LDS per wave (8 KiB at BN = 128, 6 KiB at 64)
+  uint16_t* const stage = lds + w * REGION;
   const int h = lane >> 5, c31 = lane & 31;
+  const int64_t mrow0 = m0 + wm * 64;
+  const int ncol0 = n0 + wn * WTN;
+  float bias[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j) bias[j] = P.bias ? P.bias[ncol0 + j * 32 + c31] : 0.f;
+  const bool relu = P.act == MML_ACT_RELU;
+
+  if (P.c_bf16) {
+    // write: pairs of columns packed; even lanes store the pair of reg r, odd lanes the pair of reg r + 1
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + c31;
-      const float bias = P.bias ? P.bias[n] : 0.f;
-      const int word = (n0 + wn * (BN / 2) + j * 32) >> 5;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[i][j][r] + bias;
-        if (P.act == MML_ACT_RELU) v = fmaxf(v, 0.f);
-        if (P.mask_out) {  // (uniform) sign bits of this row's 32 columns: one ballot, two lanes store their half's word
-          const unsigned long long bal = __ballot(v > 0.f);
-          if (c31 == 0) P.mask_out[m * P.ldmask + word] = (uint32_t)(h ? (bal >> 32) : bal);
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float va = acc[i][j][r] + bias[j], vb = acc[i][j][r + 1] + bias[j];
+          if (relu) {
+            va = fmaxf(va, 0.f);
+            vb = fmaxf(vb, 0.f);
+          }
+          const float na = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(va), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+          const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(vb), 0xB1, 0xF, 0xF, true));
+          const bool odd = lane & 1;
+          const uint32_t word = odd ? pack_bf16(nb, vb) : pack_bf16(va, na);
+          const int rr = odd ? r + 1 : r;
+          const int row = i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          const int col = j * 32 + (c31 & ~1);
+          *reinterpret_cast<uint32_t*>(stage + row * WTN + col) = word;
         }
-        if (P.mask_in) {   // (uniform) ReLU derivative: the forward's sign bit of this element
-          const uint32_t bits = P.mask_in[m * P.ldmask + word];
-          v = ((bits >> c31) & 1u) ? v : 0.f;
-        }
-        if (P.c_bf16) {
-          reinterpret_cast<uint16_t*>(P.C)[m * P.ldc + n] = to_bf16(v);
-        } else {
-          float* const o = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
-          *o = P.accumulate ? *o + v : v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = WTN / 8;         // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;        // rows per iteration
+    const int ch = lane % CPR, rsub = lane / CPR;
+    uint16_t* const C = reinterpret_cast<uint16_t*>(P.C);
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row = it * RPI + rsub;
+      const int64_t m = mrow0 + row;
+      uint4 q = *reinterpret_cast<const uint4*>(stage + row * WTN + ch * 8);
+      uint32_t* qq = reinterpret_cast<uint32_t*>(&q);
+      const int widx = (ncol0 >> 5) + (ch >> 2);
+      if (P.mask_in) {   // (uniform) ReLU derivative: the forward's sign bits of these eight columns
+        const uint32_t bits = P.mask_in[m * P.ldmask + widx] >> (8 * (ch & 3));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!((bits >> (2 * e)) & 1u)) qq[e] &= 0xffff0000u;
+          if (!((bits >> (2 * e + 1)) & 1u)) qq[e] &= 0x0000ffffu;
         }
       }
+      if (P.mask_out) {  // (uniform) sign bits of the stored values (ReLU outputs: positive = any magnitude bit)
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bits |= ((qq[e] & 0x00007fffu) ? 1u : 0u) << (2 * e);
+          bits |= ((qq[e] & 0x7fff0000u) ? 1u : 0u) << (2 * e + 1);
+        }
+        uint32_t wd = bits << (8 * (ch & 3));
+        wd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+        wd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 0x4E, 0xF, 0xF, true);  // lane ^ 2
+        if ((ch & 3) == 0) P.mask_out[m * P.ldmask + widx] = wd;
+      }
+      *reinterpret_cast<uint4*>(C + m * P.ldc + ncol0 + ch * 8) = q;
     }
+  } else {
+    float* const st32 = reinterpret_cast<float*>(stage);
+    float* const C = reinterpret_cast<float*>(P.C);
+    constexpr int CPR = WTN / 4;         // 16-byte chunks (four floats) per row
+    constexpr int RPI = 64 / CPR;        // rows per iteration
+    const int ch = lane % CPR, rsub = lane / CPR;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {        // two passes of 32 rows: a pass fills the wave's LDS region
+      if (i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bias[j];
+          if (relu) v = fmaxf(v, 0.f);
+          st32[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + c31] = v;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + rsub;
+        const int64_t m = mrow0 + i * 32 + row;
+        float4 q = *reinterpret_cast<const float4*>(st32 + row * WTN + ch * 4);
+        const int widx = (ncol0 >> 5) + (ch >> 3);
+        if (P.mask_in) {
+          const uint32_t bits = P.mask_in[m * P.ldmask + widx] >> (4 * (ch & 7));
+          if (!(bits & 1u)) q.x = 0.f;
+          if (!(bits & 2u)) q.y = 0.f;
+          if (!(bits & 4u)) q.z = 0.f;
+          if (!(bits & 8u)) q.w = 0.f;
+        }
+        if (P.mask_out) {
+          uint32_t wd = ((q.x > 0.f ? 1u : 0u) | (q.y > 0.f ? 2u : 0u) | (q.z > 0.f ? 4u : 0u) | (q.w > 0.f ? 8u : 0u))
+                        << (4 * (ch & 7));
+          wd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+          wd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 0x4E, 0xF, 0xF, true);  // lane ^ 2
+          wd |= (uint32_t)__shfl_xor((int)wd, 4, 64);
+          if ((ch & 7) == 0) P.mask_out[m * P.ldmask + widx] = wd;
+        }
+        float* const o = C + m * P.ldc + ncol0 + ch * 4;
+        if (P.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(o);
+          q.x += old.x; q.y += old.y; q.z += old.z; q.w += old.w;
+        }
+        *reinterpret_cast<float4*>(o) = q;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -489,6 +613,7 @@ extern "C" int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stre
     MML_REQUIRE(q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_g16_tn: n_src out of range (problem %d)", i);
     MML_REQUIRE(q.act == MML_ACT_NONE || q.act == MML_ACT_RELU, "mml_g16_tn: activation must be none or relu");
     MML_REQUIRE(q.C != nullptr && q.ldc >= q.N, "mml_g16_tn: null output or pitch below N (problem %d)", i);
+    MML_REQUIRE(aligned16(q.C) && q.ldc % (q.c_bf16 ? 8 : 4) == 0, "mml_g16_tn: output rows must be 16-byte aligned (problem %d)", i);
     MML_REQUIRE(!(q.c_bf16 && q.accumulate), "mml_g16_tn: accumulation needs an fp32 output");
     MML_REQUIRE(!((q.mask_out || q.mask_in) && q.ldmask * 32 < q.N), "mml_g16_tn: mask pitch below ceil(N / 32) words");
     MML_REQUIRE(!(q.mask_out && q.act != MML_ACT_RELU), "mml_g16_tn: sign masks belong to a ReLU output");

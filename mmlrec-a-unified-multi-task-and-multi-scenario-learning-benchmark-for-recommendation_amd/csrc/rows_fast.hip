@@ -56,6 +56,16 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// bf16-storage path: the expert outputs may ARRIVE as bf16 (mml_gate_group.out_bf16 & MML_GATE_E_BF16): four values = 8
+// bytes at element offset `off`, widened exactly (a bf16 is the upper half of an fp32)
+__device__ __forceinline__ float4 ld4i(const float* base, int64_t off, bool as16) {
+  if (as16) {
+    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+    return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                       __uint_as_float(q.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(base + off);
+}
 // bf16-storage path (include/mmlrec.h, K3'): a tensor only GEMMs read is written as four bf16 values (8 bytes, round to
 // nearest even) at ELEMENT offset `off` of the same base pointer seen as a bf16 buffer; `as16` is launch-uniform
 __device__ __forceinline__ void st4o(float* base, int64_t off, const float4& v, bool as16) {
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const int x = d.expert[e < d.ne ? e : d.ne - 1];
-        Ev[e] = hcol ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+        Ev[e] = hcol ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
     float4 Ev[NE], Gv[NG];
 #pragma unroll
     for (int x = 0; x < NE; ++x)
-      Ev[x] = (hcol && x < g.n_experts) ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+      Ev[x] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi)
       Gv[gi] = (gi < g.n_gates && 4 * sub < g.gate[gi].Gd) ? ld4(g.gate[gi].G + b * g.gate[gi].ldg + 4 * sub)
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
     float4 dmv[NG], Gv[NG], Ev[NE];
     float pv[NG][NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) Ev[e] = (hcol && e < g.n_experts) ? ld4(g.E[e] + b * g.lde[e] + 4 * sub) : make_float4(0, 0, 0, 0);
+    for (int e = 0; e < NE; ++e) Ev[e] = (hcol && e < g.n_experts) ? ld4i(g.E[e], b * g.lde[e] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       dmv[gi] = make_float4(0, 0, 0, 0);
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
     float4 Ev[NE], dmv[NG], Gv[NG];
 #pragma unroll
     for (int x = 0; x < NE; ++x)
-      Ev[x] = (hcol && x < g.n_experts) ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+      Ev[x] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       dmv[gi] = make_float4(0, 0, 0, 0);
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
         for (int e = 0; e < NE; ++e) {
           const int ec = e < d.ne ? e : d.ne - 1;
           const int x = d.expert[ec];
-          Ev[e] = hcol ? ld4(g.E[x] + b * g.lde[x] + 4 * sub) : make_float4(0, 0, 0, 0);
+          Ev[e] = hcol ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
           p[e] = d.P[b * d.ldp + ec];
         }
 #pragma unroll
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], dmv[gi]);
         if (g.e_relu) {
-          const float4 Ev = ld4(g.E[x] + b * g.lde[x] + 4 * sub);
+          const float4 Ev = ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0);
           if (!(Ev.x > 0.f)) acc.x = 0.f;
           if (!(Ev.y > 0.f)) acc.y = 0.f;
           if (!(Ev.z > 0.f)) acc.z = 0.f;

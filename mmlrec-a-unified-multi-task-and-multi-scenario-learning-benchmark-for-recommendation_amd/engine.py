@@ -457,6 +457,8 @@ class Plan:
         behind every bf16 value -- only bf16-storage layer groups read it -- is checked."""
         for op in list(self.ops) + [getattr(self, "head_op", None)]:
             for v in (op.inputs() if op is not None else []):
+                if isinstance(v, Val) and v.is16 and isinstance(op, GateGroupOp) and any(v is e for e in op.experts):
+                    continue  # (the fast gate kernels read bf16 expert outputs: mml_gate_group.out_bf16 bit 3)
                 if isinstance(v, Val) and v.is16 and not (isinstance(op, LinearGroupOp) and op.use16):
                     raise L.MMLError(f"bf16 value {v.name!r} is read by {type(op).__name__}: only bf16-storage layer "
                                      "groups may read a store16 value")
@@ -793,7 +795,8 @@ class LinearGroupOp(Op):
             ch, qs = probs[i:i + L.G16_MAX_GROUP], self.p[i:i + L.G16_MAX_GROUP]
             descs = ops.make_g16_tn_descs(ch)
             plan.keep.append(descs)
-            meta = dict(kernel="g16_tn_kernel(fwd)", flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in qs),
+            meta = dict(kernel="g16_tn_kernel(fwd %dx%d->%d)" % (len(qs), qs[0]["x"].n, max(q["out"].n for q in qs)),
+                        flops=sum(2.0 * plan.B * q["out"].n * q["x"].n for q in qs),
                         hbm_bytes=_distinct_bytes([q["x"].buf for q in qs] + [q["out"].buf for q in qs] +
                                                   [q["out"].mask for q in qs]) +
                         2.0 * sum(q["W"].data.numel() for q in qs))
@@ -839,7 +842,8 @@ class LinearGroupOp(Op):
                 L.check(-1, "mml_g16_wgrad_workspace_bytes")
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=plan.device)
             plan.keep += [descs, ws]
-            meta = dict(kernel="g16_nt_kernel(wgrad)", flops=sum(2.0 * plan.B * q["dW"].numel() for q in ch), side=True,
+            meta = dict(kernel="g16_nt_kernel(wgrad %dx%dx%d)" % (len(ch), ch[0]["dW"].shape[0], ch[0]["dW"].shape[1]),
+                        flops=sum(2.0 * plan.B * q["dW"].numel() for q in ch), side=True,
                         rank=0, hbm_bytes=_distinct_bytes([q["dC"] for q in ch] + [q["A"] for q in ch] +
                                                           [q["dW"] for q in ch]))
             calls.append((lib.mml_g16_wgrad, (descs, len(ch), ws.data_ptr(), ws.numel(), 1), meta))
@@ -869,7 +873,7 @@ class LinearGroupOp(Op):
             ch = dg[i:i + L.G16_MAX_GROUP]
             descs = ops.make_g16_tn_descs([c[0] for c in ch])
             plan.keep.append(descs)
-            meta = dict(kernel="g16_tn_kernel(dgrad)",
+            meta = dict(kernel="g16_tn_kernel(dgrad %dx%d<-%d)" % (len(ch), ch[0][1].n, sum(q["out"].n for q in ch[0][2])),
                         flops=sum(2.0 * plan.B * x.n * sum(q["out"].n for q in qs) for _, x, qs in ch),
                         hbm_bytes=_distinct_bytes([x.grad for _, x, _ in ch] + [x.mask for _, x, _ in ch] +
                                                   [q["dC16"] for _, _, qs in ch for q in qs]) +
@@ -2152,7 +2156,11 @@ class Optimizer:
                 widths = {int(p.shape[1]) for p in tabs}
                 cols = store.model._sparse_cols() if hasattr(store.model, "_sparse_cols") else []
                 one_per_field = len({f.embedding_name for f in cols}) == len(cols)
-                ok = (bool(tabs) and widths <= {4, 8, 16} and len(widths) == 1 and one_per_field and
+                # (small tables: the literal dense update of a few hundred thousand parameters is one short launch, the
+                # row bookkeeping of lazy_exact -- mark + compact, catch-up, row update: four launches -- costs more than it
+                # saves; KuaiRec-32's 24 k rows x 16: 90 us of bookkeeping against ~5 us, round 5)
+                big = sum(p.numel() for p in tabs) > int(os.environ.get("MMLREC_LAZY_MIN_PARAMS", str(1 << 22)))
+                ok = (bool(tabs) and widths <= {4, 8, 16} and len(widths) == 1 and one_per_field and big and
                       os.environ.get("MMLREC_AUTO_TABLE_UPDATE", "lazy_exact") == "lazy_exact")
                 table_update = "lazy_exact" if ok else "dense_exact"
             if self._table_reg(self._reg_map()):  # a regulariser on the tables moves every row every step

@@ -153,7 +153,7 @@ class DNN(nn.Module):
     def out_dim(self):
         return self.linears[-1].out_features
 
-    def layer_problems(self, plan, store, prefix, x):
+    def layer_problems(self, plan, store, prefix, x, last16=False):
         """One LinearGroup problem per layer (the output value of layer l is the input of layer l+1); the caller
         launches layer l of sibling stacks together (emit_dnn_stacks)."""
         h = x
@@ -164,9 +164,11 @@ class DNN(nn.Module):
             # bf16-storage path (engine.Plan.bf16): the value between two layers of the stack is read by the next layer's
             # GEMM only -- stored as bf16 when this layer and the next both run on the bf16-storage kernels
             nxt = self.linears[l + 1] if l + 1 < len(self.linears) else None
-            store16 = (plan.bf16 and plain and h.is16 and nxt is not None and
+            # (last16: the caller vouches that whatever reads the stack's OUTPUT takes bf16 -- the fast gate kernels)
+            store16 = (plan.bf16 and plain and h.is16 and
                        E.g16_layer_ok(plan.B, lin.in_features, lin.out_features, plan.training) and
-                       E.g16_layer_ok(plan.B, nxt.in_features, nxt.out_features, plan.training))
+                       (E.g16_layer_ok(plan.B, nxt.in_features, nxt.out_features, plan.training) if nxt is not None
+                        else bool(last16)))
             if self.use_bn:  # the GEMM writes the pre-normalisation value; emit_dnn_stacks adds the BatchNorm op
                 q["out"] = plan.val(lin.out_features, name=f"{prefix}.{l}.z")
                 q["bn"] = dict(y=plan.val(lin.out_features, act=self.act_code, name=f"{prefix}.{l}"),

@@ -526,6 +526,8 @@ def make_gate_group(experts, gates, B, H, d_experts=None, e_relu=True):
         bits |= L.GATE_DE_BF16
     if _all16([q.get("dG") for q in gates], "dG"):
         bits |= L.GATE_DG_BF16
+    if _all16(list(experts), "E"):
+        bits |= L.GATE_E_BF16
     g.out_bf16 = bits
     return g
 

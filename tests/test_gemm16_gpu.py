@@ -200,7 +200,7 @@ def test_row_kernels_write_bf16_operands(ops):
     from mmlrec_amd import _lib as L
     g = torch.Generator().manual_seed(6)
     B, H, Gd, Ne, T = 1024, 256, 128, 4, 2
-    E = [torch.randn(B, H, generator=g).relu().to(dev()) for _ in range(Ne)]
+    E = [torch.randn(B, H, generator=g).relu().to(dev()) for _ in range(Ne)]   # (run() reads the current binding)
     Gs = [torch.randn(B, Gd, generator=g).relu().to(dev()) for _ in range(T)]
     Wg = [(torch.randn(Ne, Gd, generator=g) * 0.1).to(dev()) for _ in range(T)]
 
@@ -217,6 +217,17 @@ def test_row_kernels_write_bf16_operands(ops):
         return [q["mix"] for q in gates], dE, [q["dG"] for q in gates], [q["dWg"] for q in gates]
     m32, e32, g32, w32 = run(torch.float32)
     m16, e16, g16, w16 = run(torch.bfloat16)
+    # expert outputs ARRIVING as bf16 (out_bf16 bit 3) are widened exactly: the fp32 run on the same (rounded) values
+    E_keep = E
+    E = [e.to(torch.bfloat16) for e in E_keep]
+    m16b, e16b, g16b, w16b = run(torch.bfloat16)
+    E = [e.float() for e in E]
+    m32b, e32b, g32b, w32b = run(torch.float32)
+    for a, b in zip(m32b + e32b + g32b, m16b + e16b + g16b):
+        assert torch.equal(a.to(torch.bfloat16), b)
+    for a, b in zip(w32b, w16b):
+        assert torch.equal(a, b)
+    E = E_keep
     for a, b in zip(m32 + e32 + g32, m16 + e16 + g16):
         assert b.dtype == torch.bfloat16 and torch.equal(a.to(torch.bfloat16), b)
     for a, b in zip(w32, w16):

@@ -647,7 +647,7 @@ def test_step_uses_precut_weight_planes(monkeypatch):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-def test_recompile_flushes_pending_lazy_updates():
+def test_recompile_flushes_pending_lazy_updates(monkeypatch):
     """table_update='auto' picks lazy_exact for Adam; a second compile() (new training phase) drops the fused
     optimizer -- the rows whose zero-gradient steps were still pending must replay them first.  Two Adam steps under
     'auto', compile() again, read the parameters directly (no state_dict(): that would flush by itself): the tables equal
@@ -655,6 +655,7 @@ def test_recompile_flushes_pending_lazy_updates():
     itself pinned by test_fused_train_steps)."""
     g = load_golden("mmoe_ae30")
     outs = {}
+    monkeypatch.setenv("MMLREC_LAZY_MIN_PARAMS", "0")  # ('auto' keeps the dense update for tables as small as the fixture's)
     for tu in ("auto", "dense_exact"):
         model, cfg = build(g, table_update=tu)
         load_state(model, g)
