@@ -52,8 +52,12 @@ class MMOE(BaseModel):
         # bf16-storage path: the expert outputs are read by the gate kernels only, which widen bf16 exactly
         # (mml_gate_group.out_bf16 bit 3) -- half the bytes of the largest tensor three kernels move
         H_, G_ = self.expert_dnn_hidden_units[-1], (self.gate_dnn_hidden_units[-1] if hasattr(self, "gate_dnn") else 0)
-        e16 = (plan.bf16 and hasattr(self, "gate_dnn") and E._fast_row_width_ok(H_) and E._fast_row_width_ok(G_) and
-               H_ % 8 == 0 and Ne * max(T, 2) <= 32)
+        # Measured (KuaiRec-32, B = 65 536, same box): the second layers' forward 136 -> 121 us, but the gate kernels -- one
+        # 16-byte load per lane and expert -- fall to 8-byte loads: backward 161 -> 191, forward 90 -> 98; a net loss, so
+        # the experts stay fp32 unless MMLREC_BF16_EXPERTS=1.
+        import os
+        e16 = (plan.bf16 and os.environ.get("MMLREC_BF16_EXPERTS", "0") == "1" and hasattr(self, "gate_dnn") and
+               E._fast_row_width_ok(H_) and E._fast_row_width_ok(G_) and H_ % 8 == 0 and Ne * max(T, 2) <= 32)
         stacks = [self.expert_dnn[e].layer_problems(plan, store, f"expert_dnn.{e}", x0, last16=e16) for e in range(Ne)]
         if hasattr(self, "gate_dnn"):
             stacks += [self.gate_dnn[t].layer_problems(plan, store, f"gate_dnn.{t}", x0) for t in range(T)]

@@ -399,7 +399,8 @@ def test_row_sharded_bench_configuration_steps_match_oracle(W, table_update):
             loss_ref = orc.train_step(spec, params, opt, X.numpy(), y.numpy())
             assert abs(loss_gpu - loss_ref) / loss_ref < 1e-4, (i, loss_gpu, loss_ref)
         runner.drop_prefetch()
-        assert runner.front.n_graphs + runner.sideq.n_graphs + runner.tail.n_graphs >= 2  # segments were captured
+        segs = [runner.whole] if runner.whole is not None else [runner.front, runner.sideq, runner.tail]
+        assert sum(s_.n_graphs for s_ in segs) >= 2  # the runs of launches between the collectives were captured
         assert par.dirty
         sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}  # gathers the shards (and flushes lazy rows)
         assert not par.dirty
