@@ -254,6 +254,16 @@ int mml_gemm_set_panel(int32_t on);
  * width.  Bitwise the results of the tile kernel.  on = 0 switches it off (default on; environment MMLREC_GEMM_WS=0 does
  * the same). */
 int mml_gemm_set_ws(int32_t on);
+/* Weight gradients cut once per workgroup (csrc/gemm_nt.hip).  A weight-gradient launch of <= 8 problems in nn.Linear
+ * layout that all carry both operand magnitudes, with M % 32 == 0, M >= 16 384, N % 32 == 0, K % 4 == 0 and 16-byte
+ * aligned operand rows (the DNN layers of a large batch: reference model/utils.py:146-161, autograd's mm backward) is
+ * served by workgroups that own a 128 x 128 tile of dW for a slab of the batch: the rows of both operands are cut into
+ * their fp16 planes ONCE, stored to LDS as they lie in memory, and the MFMA fragments -- consecutive batch rows of a column
+ * -- are read with the transposing LDS read ds_read_b64_tr_b16; partial tiles go to the same workspace, summed in slab order.
+ * Same products and fp32 accumulation as the tile kernel, another summation order (not bitwise equal to it; bitwise
+ * repeatable).  OFF by default -- level with the tile kernel on the first layers, behind it on the small ones
+ * (csrc/gemm_nt.hip holds the numbers); on = 1 or environment MMLREC_GEMM_NT=1 switches it on. */
+int mml_gemm_set_nt(int32_t on);
 /* Kernel symbol (as rocprofv3 prints it, without the mml:: prefix) of the calling thread's most recent GEMM launch;
  * "" before the first one.  For profilers / benchmark labels. */
 const char* mml_gemm_last_kernel(void);

@@ -161,6 +161,7 @@ _SIGS = {
     "mml_gemm_get_mode": (C.c_int, []),
     "mml_gemm_set_panel": (C.c_int, [i32]),
     "mml_gemm_set_ws": (C.c_int, [i32]),
+    "mml_gemm_set_nt": (C.c_int, [i32]),
     "mml_gemm_last_kernel": (C.c_char_p, []),
     "mml_gather_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),

@@ -2225,12 +2225,24 @@ extern "C" int64_t mml_gemm_grouped_wgrad_workspace_bytes(const mml_gemm_wgrad_d
   return best + 256;
 }
 
+// gemm_nt.hip: weight gradients cut once per workgroup, fragments through the transposing LDS read (large batches, both
+// operand magnitudes known)
+int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes, int32_t phase,
+                          hipStream_t st);
+
 extern "C" int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace,
                                             int64_t workspace_bytes, int32_t phase, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_wgrad: bad descriptor array");
   MML_REQUIRE(phase >= 0 && phase <= 2, "mml_gemm_grouped_wgrad_phase: phase must be 0 (both), 1 (partials) or 2 (reduce)");
   if (n == 0) return MML_OK;
   MML_REQUIRE(workspace && aligned16(workspace), "mml_gemm_grouped_wgrad: workspace null or misaligned");
+  if (gemm_mode() >= 2 && gemm_mode() != 3) {  // (auto / two-plane arithmetic only)
+    const int rc = mml_gemm_nt_try_wgrad(d, n, workspace, workspace_bytes, phase, to_stream(stream));
+    if (rc != MML_ERR_UNSUPPORTED) {
+      if (rc == MML_OK && phase != 2) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_nt_kernel");
+      return rc;
+    }
+  }
   int i = 0;
   int64_t ws_off = 0;  // bytes: every group of problems owns its own piece of the workspace
   while (i < n) {

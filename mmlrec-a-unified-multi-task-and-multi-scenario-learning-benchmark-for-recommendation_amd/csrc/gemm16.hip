@@ -506,9 +506,19 @@ __global__ __launch_bounds__(256) void g16_reduce_kernel(const G16RedLaunch L) {
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = it / k4;
     const int k = (int)(it - n * k4) * 4;
-    float4 s = *reinterpret_cast<const float4*>(P.ws + n * P.K + k);
-    for (int sl = 1; sl < L.slabs; ++sl) {
-      const float4 v = *reinterpret_cast<const float4*>(P.ws + sl * plane + n * P.K + k);
+    // (eight slabs' loads in flight per thread -- one load per iteration is latency-bound; additions in slab order)
+    const float* const src = P.ws + n * P.K + k;
+    float4 s = *reinterpret_cast<const float4*>(src);
+    int sl = 1;
+    for (; sl + 8 <= L.slabs; sl += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (sl + u) * plane);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; sl < L.slabs; ++sl) {
+      const float4 v = *reinterpret_cast<const float4*>(src + sl * plane);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     float* const o = P.dW + n * P.lddw + k;

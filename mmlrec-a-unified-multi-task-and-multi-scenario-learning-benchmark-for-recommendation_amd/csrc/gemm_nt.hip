@@ -1,0 +1,428 @@
+// Weight gradients of the fp32-equivalent GEMM family, cut ONCE per workgroup and transposed by the LDS
+// (round 5; reference: autograd's mm backward of nn.Linear, model/utils.py:146-161 -- dW = dC^T A, db = column sums of dC).
+//
+// Both operands of a weight gradient are activations [batch, columns]: the reduction runs down the SLOW dimension of
+// both, and both need their two fp16 planes cut (include/mmlrec.h, mml_gemm_set_mode: h = rne16(x s), l = rne16(x s - h),
+// three v_mfma_f32_32x32x16_f16 per product block).  The tile kernel (gemm.hip, gemm_pipe_kernel<false, false, ...>) lets
+// every wave cut the fragments it reads -- a dnn_input fragment is cut by 9 x 2 waves, a gradient fragment by 2 x 2 --
+// and assembles k-contiguous fragments from a batch-major image with 4-byte LDS reads: 12 VALU instructions per MFMA,
+// matrix pipe 36 % busy (profiles/r04_mfma.csv).  Here
+//   * a workgroup (4 waves, 2 x 2) owns a 128 x 128 tile of dW for a slab of the batch and walks it in steps of 32 rows;
+//   * the step's rows travel HBM -> registers as they lie in memory (16 bytes per lane, whole 512-byte row pieces),
+//     every element is cut ONCE (2.5 VALU instructions) and its planes are written to LDS row-major as 8-byte pieces;
+//   * the MFMA fragments -- eight consecutive BATCH rows of one column per lane -- come out of the transposing LDS read
+//     of CDNA4, ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major): no strided reads, no
+//     register transposition;
+//   * the loads of step s + 1 are issued before the MFMAs of step s and cut + stored behind them (two LDS stages, one
+//     barrier per step);
+//   * the bias gradient is a fourth and fifth MFMA per block row against an all-ones column (k-tile 0 only);
+//   * partial tiles go to the caller's workspace, scaled back exactly, and are summed in slab order (bitwise
+//     reproducible) by nt_reduce_kernel.
+// Serves launches whose problems carry both magnitudes, nn.Linear weight layout, M % 32 == 0, M >= 16 384, N % 32 == 0,
+// K % 4 == 0 and 16-byte aligned rows; everything else stays on the tile kernel (mml_gemm_nt_try_wgrad returns
+// MML_ERR_UNSUPPORTED).
+#include "common.hpp"
+#include "lds_async.hpp"
+
+namespace mml {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+constexpr int NT_MAX_GROUP = 8;
+constexpr int NT_STEP = 32;          // batch rows per step
+constexpr int NT_PLANE = NT_STEP * 128;   // fp16 elements of one plane image ([32 rows][128 columns])
+constexpr int NT_STAGE = 4 * NT_PLANE;    // dC h, dC l, A h, A l
+
+struct NtProblem {
+  const float* dC;
+  const float* A;
+  float* ws;       // [slabs][N][K]
+  float* ws_bias;  // [slabs][N] or null
+  const uint32_t* amax_dc;
+  const uint32_t* amax_a;
+  int64_t lddc, lda;
+  int32_t N, K, ntiles, ktiles;
+};
+struct NtLaunch {
+  NtProblem p[NT_MAX_GROUP];
+  int32_t n_prob, steps, slabs, tiles;
+};
+
+__device__ __forceinline__ uint32_t nt_amax_load(const uint32_t* p) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < MML_AMAX_WORDS; ++i) m = p[i] > m ? p[i] : m;
+  return m;
+}
+// power-of-two exponent k with |x| 2^k < 2^15 for every |x| <= the slot's value (the rule of gemm.hip)
+__device__ __forceinline__ int nt_scale_exp(uint32_t bits) {
+  const int e = (int)((bits >> 23) & 0xffu);
+  if (e == 255) return 0;
+  const int k = 141 - e;
+  return k > 110 ? 110 : (k < -110 ? -110 : k);
+}
+__device__ __forceinline__ float nt_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// image (b) of the CDNA programming guide, T10: 256-byte rows, chunk c of row r at position c ^ (((r & 3) << 2) | ((r >> 2) & 3))
+__device__ __forceinline__ int nt_swz32(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ f16x8 nt_frag32(const uint16_t* plane, int ms, int chunk0, int lane) {
+  const int g = lane >> 4, hh = g >> 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int ch = chunk0 + 2 * (g & 1) + (p >> 1);
+  s16x4 lo, hi;
+  {
+    const int row = ms + 8 * hh + q;
+    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(plane + row * 128 + ((ch ^ nt_swz32(row)) << 3) + 4 * (p & 1)));
+  }
+  {
+    const int row = ms + 8 * hh + 4 + q;
+    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(plane + row * 128 + ((ch ^ nt_swz32(row)) << 3) + 4 * (p & 1)));
+  }
+  const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// four values -> their two planes (8 bytes each): h = rne16(x s), l = rne16(x s - h); x s is exact (s a power of two).
+// Twelve full-rate VALU instructions (the sequence of lds_async.hpp: f16_cut_hr2 + f16_cut_l -- hipcc forms packed fp32
+// operations from the C expression, which issue at half rate): 4 v_mul, 2 + 2 v_cvt_pk_f16_f32, 4 v_fma_mix_f32 that read
+// the fp16 halves of h directly.
+__device__ __forceinline__ void nt_cut4(const float4& x, const float s, uint2& h, uint2& l) {
+  float y0, y1, y2, y3, r0, r1, r2, r3;
+  uint32_t h0, h1, l0, l1;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x.x), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x.y), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y2) : "v"(x.z), "s"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(y3) : "v"(x.w), "s"(s));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h0) : "v"(y0), "v"(y1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(y2), "v"(y3));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x.x), "s"(s), "v"(h0));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x.y), "s"(s), "v"(h0));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(x.z), "s"(s), "v"(h1));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(x.w), "s"(s), "v"(h1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l0) : "v"(r0), "v"(r1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l1) : "v"(r2), "v"(r3));
+  h = make_uint2(h0, h1);
+  l = make_uint2(l0, l1);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * NT_STAGE];  // 64 KiB: two stages of four plane images
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: scalar branches)
+  const int wn = w >> 1, wk = w & 1;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = id / L.tiles;
+  int t = id - slab * L.tiles;
+  int pi = 0;
+  while (t >= L.p[pi].ntiles * L.p[pi].ktiles) t -= L.p[pi].ntiles * L.p[pi].ktiles, ++pi;  // (uniform)
+  const NtProblem& P = L.p[pi];
+  const int nt = t / P.ktiles, kt = t - nt * P.ktiles;
+  const int n0 = nt * 128, k0 = kt * 128;
+  const int per = (L.steps + L.slabs - 1) / L.slabs;
+  const int s_begin = slab * per, s_end = min(L.steps, s_begin + per);
+  const bool want_bias = P.ws_bias != nullptr && kt == 0;  // (uniform)
+
+  // scales (one pair per problem); 1 / (sC sA) must be one fp32 number: where the exponents add up beyond its range both
+  // give way equally (gemm.hip: problem_scales)
+  int kC = nt_scale_exp(nt_amax_load(P.amax_dc)), kA = nt_scale_exp(nt_amax_load(P.amax_a));
+  {
+    const int over = kC + kA - 126, under = -126 - (kC + kA);
+    if (over > 0) { kC -= (over + 1) >> 1; kA -= over >> 1; }
+    if (under > 0) { kC += (under + 1) >> 1; kA += under >> 1; }
+  }
+  kC = __builtin_amdgcn_readfirstlane(kC);
+  kA = __builtin_amdgcn_readfirstlane(kA);
+  const float sC = nt_pow2(kC), sA = nt_pow2(kA), inv = nt_pow2(-(kC + kA)), invC = nt_pow2(-kC);
+
+  f32x16 acc[2][2], accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (lane & 31) == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+
+  // staging map: 32 lanes cover one 128-column row (16 bytes each), 8 rows per pass, 4 passes per operand
+  const int c4 = tid & 31, r8 = tid >> 5;
+  const bool colC = n0 + 4 * c4 < P.N, colA = k0 + 4 * c4 < P.K;  // (columns beyond the problem: zeros)
+  const float* const gC = P.dC + n0 + 4 * c4;
+  const float* const gA = P.A + k0 + 4 * c4;
+  // two steps of rows in flight: the loads of step s + 2 are issued before the MFMAs of step s (one step's MFMAs are
+  // ~0.7 us, a load's round trip 1-2: with one step ahead the kernel waited for memory every step)
+  float4 rc0[4], ra0[4], rc1[4], ra1[4];
+  auto load_step = [&](const int st, float4 (&rc)[4], float4 (&ra)[4]) __attribute__((always_inline)) {
+    const int64_t m0 = (int64_t)st * NT_STEP;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t m = m0 + r8 + 8 * p;
+      rc[p] = colC ? *reinterpret_cast<const float4*>(gC + m * P.lddc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[p] = colA ? *reinterpret_cast<const float4*>(gA + m * P.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_step = [&](uint16_t* stage, const float4 (&rc)[4], const float4 (&ra)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = r8 + 8 * p;
+      const int off = row * 128 + (((c4 >> 1) ^ nt_swz32(row)) << 3) + 4 * (c4 & 1);
+      uint2 h, l;
+      nt_cut4(rc[p], sC, h, l);
+      *reinterpret_cast<uint2*>(stage + off) = h;
+      *reinterpret_cast<uint2*>(stage + NT_PLANE + off) = l;
+      nt_cut4(ra[p], sA, h, l);
+      *reinterpret_cast<uint2*>(stage + 2 * NT_PLANE + off) = h;
+      *reinterpret_cast<uint2*>(stage + 3 * NT_PLANE + off) = l;
+    }
+  };
+  // sub-tiles of this wave that lie inside the problem (uniform per wave: whole 32-column blocks)
+  bool vi[2], vj[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    vi[i] = n0 + wn * 64 + i * 32 < P.N;
+    vj[i] = k0 + wk * 64 + i * 32 < P.K;
+  }
+  auto compute = [&](const uint16_t* cur) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = nt_frag32(cur, sub * 16, wn * 8 + i * 4, lane);
+        al[i] = nt_frag32(cur + NT_PLANE, sub * 16, wn * 8 + i * 4, lane);
+        bh[i] = nt_frag32(cur + 2 * NT_PLANE, sub * 16, wk * 8 + i * 4, lane);
+        bl[i] = nt_frag32(cur + 3 * NT_PLANE, sub * 16, wk * 8 + i * 4, lane);
+      }
+      // product by product over the (up to) four accumulators: consecutive MFMAs are independent (back to back on ONE
+      // accumulator each would wait out the previous one's passes)
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (!vi[i]) continue;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (!vj[j]) continue;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      if (want_bias && wk == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (!vi[i]) continue;
+          accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ones, accb[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (!vi[i]) continue;
+          accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], ones, accb[i], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  uint16_t* const stage0 = lds;
+  uint16_t* const stage1 = lds + NT_STAGE;
+  if (s_begin < s_end) {
+    load_step(s_begin, rc0, ra0);
+    if (s_begin + 1 < s_end) load_step(s_begin + 1, rc1, ra1);
+    store_step(stage0, rc0, ra0);
+  }
+  __syncthreads();
+  // two steps per trip: step st reads stage0 (register set 1 holds step st + 1), step st + 1 reads stage1
+  for (int st = s_begin; st < s_end; st += 2) {
+    if (st + 2 < s_end) load_step(st + 2, rc0, ra0);
+    compute(stage0);
+    if (st + 1 < s_end) store_step(stage1, rc1, ra1);
+    __syncthreads();
+    if (st + 1 >= s_end) break;
+    if (st + 3 < s_end) load_step(st + 3, rc1, ra1);
+    compute(stage1);
+    if (st + 2 < s_end) store_step(stage0, rc0, ra0);
+    __syncthreads();
+  }
+
+  const int h = lane >> 5, c31 = lane & 31;
+  float* const ws = P.ws + (int64_t)slab * P.N * P.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!vi[i] || !vj[j]) continue;
+      const int k = k0 + wk * 64 + j * 32 + c31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < P.K) ws[(int64_t)n * P.K + k] = acc[i][j][r] * inv;
+      }
+    }
+  if (want_bias && wk == 0 && c31 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!vi[i]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        P.ws_bias[(int64_t)slab * P.N + n] = accb[i][r] * invC;
+      }
+    }
+  }
+}
+
+struct NtRedProblem {
+  const float* ws;
+  const float* ws_bias;
+  float* dW;
+  float* dbias;
+  int64_t lddw;
+  int32_t N, K, accumulate;
+};
+struct NtRedLaunch {
+  NtRedProblem p[NT_MAX_GROUP];
+  int32_t n_prob, slabs;
+};
+// blockIdx.y = problem; the slabs are added in their fixed order
+__global__ __launch_bounds__(256) void nt_reduce_kernel(const NtRedLaunch L) {
+  const NtRedProblem& P = L.p[blockIdx.y];
+  const int k4 = P.K >> 2;
+  const int64_t total = (int64_t)P.N * k4;
+  const int64_t plane = (int64_t)P.N * P.K;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = it / k4;
+    const int k = (int)(it - n * k4) * 4;
+    // (eight slabs' loads in flight per thread: one load per iteration made the pass latency-bound, 85 us for 45 MB; the
+    // additions stay in slab order)
+    const float* const src = P.ws + n * P.K + k;
+    float4 s = *reinterpret_cast<const float4*>(src);
+    int sl = 1;
+    for (; sl + 8 <= L.slabs; sl += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (sl + u) * plane);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; sl < L.slabs; ++sl) {
+      const float4 v = *reinterpret_cast<const float4*>(src + sl * plane);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* const o = P.dW + n * P.lddw + k;
+    if (P.accumulate) {
+      s.x += o[0]; s.y += o[1]; s.z += o[2]; s.w += o[3];
+    }
+    o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+  }
+  if (P.dbias && blockIdx.x == 0) {
+    for (int n = threadIdx.x; n < P.N; n += blockDim.x) {
+      float s = P.ws_bias[n];
+      for (int sl = 1; sl < L.slabs; ++sl) s += P.ws_bias[(int64_t)sl * P.N + n];
+      P.dbias[n] = P.accumulate ? P.dbias[n] + s : s;
+    }
+  }
+}
+
+// OFF by default (mml_gemm_set_nt(1) / MMLREC_GEMM_NT=1 switch it on).  Measured, cold caches, B = 65 536, same box,
+// partial-product launch + reduction (tools/lab/nt_time.py, profiles/r05_nt_time.txt): AE-30 first layers 198 + 23 us
+// against the tile kernel's 200 + 15; second layers 134 + 42 against 134 + 17; towers 61 + 36 against 48 + 11; KuaiRec-32
+// first layers 706 + 21 against 648 + 24.  The cut is no longer what bounds these launches (4 VALU instructions per MFMA
+// here, 12 there, the same time): with one step of rows in flight the kernel took 258 us on the first layers, with two
+// 198 -- it waits for memory at two workgroups of 224 VGPRs per CU, where the tile kernel's persistent workgroups keep a
+// four-stage LDS-DMA ring full.  Kept as a tested alternative (tests/test_gemm_nt_gpu.py), not as the default.
+static int g_nt_on = -1;
+static bool nt_enabled() {
+  if (g_nt_on < 0) {
+    const char* e = getenv("MMLREC_GEMM_NT");
+    g_nt_on = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  return g_nt_on != 0;
+}
+static int nt_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+}  // namespace mml
+
+using namespace mml;
+
+extern "C" int mml_gemm_set_nt(int32_t on) {
+  g_nt_on = on ? 1 : 0;
+  return MML_OK;
+}
+
+// MML_OK: the launch (phase 1 = partial tiles, 2 = their reduction, 0 = both) was served; MML_ERR_UNSUPPORTED (no error
+// text): not a launch this kernel serves -- the caller runs the tile kernel.  The decision depends on the descriptors and
+// the workspace size only, so phase 2 of a call pair decides like its phase 1.
+int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes, int32_t phase,
+                          hipStream_t st) {
+  if (!nt_enabled() || n < 1 || n > NT_MAX_GROUP || !workspace) return MML_ERR_UNSUPPORTED;
+  const int32_t M = d[0].M;
+  if (M < 16384 || M % NT_STEP != 0) return MML_ERR_UNSUPPORTED;
+  int64_t tiles = 0, elems = 0;
+  for (int i = 0; i < n; ++i) {
+    const mml_gemm_wgrad_desc& q = d[i];
+    if (q.M != M || q.w_kn || !q.dC || !q.A || !q.dW || !q.amax_dc || !q.amax_a) return MML_ERR_UNSUPPORTED;
+    if (q.N <= 0 || q.N % 32 != 0 || q.K <= 0 || q.K % 4 != 0) return MML_ERR_UNSUPPORTED;
+    if (!aligned16(q.dC) || !aligned16(q.A) || q.lddc % 4 != 0 || q.lda % 4 != 0 || q.lddc < q.N || q.lda < q.K ||
+        q.lddw < q.K)
+      return MML_ERR_UNSUPPORTED;
+    tiles += cdiv(q.N, 128) * cdiv(q.K, 128);
+    elems += (int64_t)q.N * q.K + q.N;
+  }
+  const int steps = M / NT_STEP;
+  int64_t slabs = (2 * (int64_t)nt_cus()) / tiles;   // two workgroups per CU (64 KiB of LDS each)
+  if (slabs > steps / 8) slabs = steps / 8;           // at least 256 batch rows per slab
+  if (slabs > 64) slabs = 64;
+  const int64_t fit = workspace_bytes / (elems * 4);  // (the caller sized the workspace for the tile kernel's split)
+  if (slabs > fit) slabs = fit;
+  if (slabs < 1) return MML_ERR_UNSUPPORTED;
+
+  NtLaunch L{};
+  NtRedLaunch R{};
+  L.n_prob = R.n_prob = n;
+  L.steps = steps;
+  L.slabs = R.slabs = (int)slabs;
+  float* ws = reinterpret_cast<float*>(workspace);
+  int maxred = 1;
+  for (int i = 0; i < n; ++i) {
+    const mml_gemm_wgrad_desc& q = d[i];
+    NtProblem& P = L.p[i];
+    P.dC = q.dC; P.A = q.A; P.lddc = q.lddc; P.lda = q.lda; P.N = q.N; P.K = q.K;
+    P.amax_dc = q.amax_dc; P.amax_a = q.amax_a;
+    P.ntiles = (int)cdiv(q.N, 128); P.ktiles = (int)cdiv(q.K, 128);
+    P.ws = ws;
+    ws += slabs * q.N * q.K;
+    P.ws_bias = q.dbias ? ws : nullptr;
+    ws += slabs * q.N;
+    L.tiles += P.ntiles * P.ktiles;
+    NtRedProblem& Q = R.p[i];
+    Q.ws = P.ws; Q.ws_bias = P.ws_bias; Q.dW = q.dW; Q.dbias = q.dbias; Q.lddw = q.lddw; Q.N = q.N; Q.K = q.K;
+    Q.accumulate = q.accumulate;
+    const int blocks = (int)cdiv((int64_t)q.N * q.K / 4, 256);
+    maxred = blocks > maxred ? blocks : maxred;
+  }
+  if (phase != 2) {
+    MML_LAUNCH(gemm_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, st, L);
+    const int rc = check_launch("mml_gemm_grouped_wgrad(nt)");
+    if (rc != MML_OK) return rc;
+  }
+  if (phase != 1) {
+    if (maxred > 512) maxred = 512;
+    MML_LAUNCH(nt_reduce_kernel, dim3((unsigned)maxred, (unsigned)n), dim3(256), 0, st, R);
+    return check_launch("mml_gemm_grouped_wgrad(nt reduce)");
+  }
+  return MML_OK;
+}

@@ -292,6 +292,17 @@ def test_bench_two_ranks_control_flow():
     assert "row-wise sharded" in d["config"]["tables"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
     assert any(k.startswith("row_sharded_") for k in d.get("collectives_ms_per_step", {}))
+    # what rank 0 issued inside the timed region, per step, against DESIGN section 5's model of the exchange (VERDICT r4
+    # item 10: the first multi-GPU run is checked against this line by line): four all-to-alls -- per-owner counts of the
+    # NEXT batch (prefetched routing), keys, rows, row gradients -- and one all-reduce of the MLP gradient arena
+    cps = d["collectives_per_step"]
+    exp = cps["expected"]
+    assert cps["all_to_all"]["calls"] == exp["all_to_all_calls"] == 4
+    assert cps["all_reduce"]["calls"] == exp["all_reduce_calls"] == 1
+    assert abs(cps["all_reduce"]["MB_sent"] - exp["all_reduce_ring_MB"]) < 1e-3
+    want = exp["keys_MB"] + 2 * exp["rows_MB_each_way"]   # (+ 2 x 4 bytes of counts; the four batches differ by a few %)
+    assert abs(cps["all_to_all"]["MB_sent"] - want) < 0.1 * want, (cps, exp)
+    assert abs(cps["all_to_all"]["MB_received"] - want) < 0.1 * want, (cps, exp)
 
 
 @pytest.mark.timeout(900)
