@@ -529,8 +529,18 @@ __global__ __launch_bounds__(256) void g16_reduce_kernel(const G16RedLaunch L) {
   }
   if (P.dbias && blockIdx.x == 0) {
     for (int n = threadIdx.x; n < P.N; n += blockDim.x) {
+      // (eight slabs' loads in flight: a dependent load per slab made this loop -- 64 slabs, a few KB -- the longest part
+      //  of the launch, ~30 us)
       float s = P.ws_bias[n];
-      for (int sl = 1; sl < L.slabs; ++sl) s += P.ws_bias[(int64_t)sl * P.N + n];
+      int sl = 1;
+      for (; sl + 8 <= L.slabs; sl += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = P.ws_bias[(int64_t)(sl + u) * P.N + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; sl < L.slabs; ++sl) s += P.ws_bias[(int64_t)sl * P.N + n];
       P.dbias[n] = P.accumulate ? P.dbias[n] + s : s;
     }
   }

@@ -69,20 +69,21 @@ __device__ __forceinline__ float nt_pow2(int k) { return __uint_as_float((uint32
 // image (b) of the CDNA programming guide, T10: 256-byte rows, chunk c of row r at position c ^ (((r & 3) << 2) | ((r >> 2) & 3))
 __device__ __forceinline__ int nt_swz32(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__device__ __forceinline__ f16x8 nt_frag32(const uint16_t* plane, int ms, int chunk0, int lane) {
-  const int g = lane >> 4, hh = g >> 1, q = (lane & 15) >> 2, p = lane & 3;
-  const int ch = chunk0 + 2 * (g & 1) + (p >> 1);
-  s16x4 lo, hi;
-  {
-    const int row = ms + 8 * hh + q;
-    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(plane + row * 128 + ((ch ^ nt_swz32(row)) << 3) + 4 * (p & 1)));
-  }
-  {
-    const int row = ms + 8 * hh + 4 + q;
-    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(plane + row * 128 + ((ch ^ nt_swz32(row)) << 3) + 4 * (p & 1)));
-  }
+// One fragment = two transposing reads (batch rows 8 h + q and 8 h + 4 + q of the 16-row sub-step).  `lo_off` / `hi_off` are
+// the lane's element offsets of the two reads inside a plane image for sub-step 0 (computed once per kernel); the stage, the
+// plane and the sub-step (16 rows = 2 048 elements, swizzle-neutral: the row's low four bits do not change) are compile-time
+// offsets that fold into the instruction's immediate.
+__device__ __forceinline__ f16x8 nt_frag32(const uint16_t* img, int lo_off, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + lo_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + hi_off));
   const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ int nt_frag_off(int chunk0, int lane, int t) {
+  const int g = lane >> 4, hh = g >> 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int ch = chunk0 + 2 * (g & 1) + (p >> 1);
+  const int row = 8 * hh + 4 * t + q;
+  return row * 128 + ((ch ^ nt_swz32(row)) << 3) + 4 * (p & 1);
 }
 
 // four values -> their two planes (8 bytes each): h = rne16(x s), l = rne16(x s - h); x s is exact (s a power of two).
@@ -134,41 +135,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
   }
   kC = __builtin_amdgcn_readfirstlane(kC);
   kA = __builtin_amdgcn_readfirstlane(kA);
-  const float sC = nt_pow2(kC), sA = nt_pow2(kA), inv = nt_pow2(-(kC + kA)), invC = nt_pow2(-kC);
+  const float sC = nt_pow2(kC), sA = nt_pow2(kA), inv = nt_pow2(-(kC + kA));
 
-  f32x16 acc[2][2], accb[2];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
-  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  h8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (lane & 31) == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+  // bias gradient (k-tile 0): every thread sums the four dC columns it stages, in fp32; the eight row groups of a column
+  // meet in LDS at the end (no accumulator registers, no extra MFMAs)
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // staging map: 32 lanes cover one 128-column row (16 bytes each), 8 rows per pass, 4 passes per operand
   const int c4 = tid & 31, r8 = tid >> 5;
-  const bool colC = n0 + 4 * c4 < P.N, colA = k0 + 4 * c4 < P.K;  // (columns beyond the problem: zeros)
-  const float* const gC = P.dC + n0 + 4 * c4;
-  const float* const gA = P.A + k0 + 4 * c4;
-  // two steps of rows in flight: the loads of step s + 2 are issued before the MFMAs of step s (one step's MFMAs are
-  // ~0.7 us, a load's round trip 1-2: with one step ahead the kernel waited for memory every step)
+  // (columns beyond the problem: the lane re-reads the problem's first columns -- finite values whose products land in
+  //  accumulator columns / rows the epilogue never stores)
+  const bool colC = n0 + 4 * c4 < P.N, colA = k0 + 4 * c4 < P.K;
+  const float* const gC = P.dC + (colC ? n0 + 4 * c4 : 0);
+  const float* const gA = P.A + (colA ? k0 + 4 * c4 : 0);
+  // TWO steps of rows in flight (two register sets, the trip below unrolled by two): one step's MFMAs are ~0.7 us, a load's
+  // round trip 1-2 us -- with one step ahead the first-layer launch took 258 us, with two 198, with three 201 (and a
+  // branch-free body with three sets spills: 508 bytes of scratch).  The body of a step
+  // is ONE basic block (no branch: loads past the slab re-read its last step, sub-tiles outside the problem multiply zeros),
+  // so that the compiler interleaves the next rows' cut and LDS stores with this step's MFMAs.
   float4 rc0[4], ra0[4], rc1[4], ra1[4];
-  auto load_step = [&](const int st, float4 (&rc)[4], float4 (&ra)[4]) __attribute__((always_inline)) {
+  const int last = s_end - 1;
+  auto load_step = [&](int st, float4 (&rc)[4], float4 (&ra)[4]) __attribute__((always_inline)) {
+    st = st > last ? last : st;
     const int64_t m0 = (int64_t)st * NT_STEP;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int64_t m = m0 + r8 + 8 * p;
-      rc[p] = colC ? *reinterpret_cast<const float4*>(gC + m * P.lddc) : make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[p] = colA ? *reinterpret_cast<const float4*>(gA + m * P.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rc[p] = *reinterpret_cast<const float4*>(gC + m * P.lddc);
+      ra[p] = *reinterpret_cast<const float4*>(gA + m * P.lda);
     }
   };
-  auto store_step = [&](uint16_t* stage, const float4 (&rc)[4], const float4 (&ra)[4]) __attribute__((always_inline)) {
+  auto store_step = [&](uint16_t* stage, const float4 (&rc)[4], const float4 (&ra)[4], const bool count) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = r8 + 8 * p;
@@ -180,73 +184,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
       nt_cut4(ra[p], sA, h, l);
       *reinterpret_cast<uint2*>(stage + 2 * NT_PLANE + off) = h;
       *reinterpret_cast<uint2*>(stage + 3 * NT_PLANE + off) = l;
+      if (count) { bsum.x += rc[p].x; bsum.y += rc[p].y; bsum.z += rc[p].z; bsum.w += rc[p].w; }
     }
   };
-  // sub-tiles of this wave that lie inside the problem (uniform per wave: whole 32-column blocks)
+  // per-lane offsets of the fragment reads (sub-step 0): [n / k sub-tile][low / high half of the fragment]
+  int offC[2][2], offA[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      offC[i][t2] = nt_frag_off(wn * 8 + i * 4, lane, t2);
+      offA[i][t2] = nt_frag_off(wk * 8 + i * 4, lane, t2);
+    }
+  auto compute = [&](const uint16_t* cur) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const uint16_t* const b0 = cur + sub * 16 * 128;
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = nt_frag32(b0, offC[i][0], offC[i][1]);
+        al[i] = nt_frag32(b0 + NT_PLANE, offC[i][0], offC[i][1]);
+        bh[i] = nt_frag32(b0 + 2 * NT_PLANE, offA[i][0], offA[i][1]);
+        bl[i] = nt_frag32(b0 + 3 * NT_PLANE, offA[i][0], offA[i][1]);
+      }
+      // product by product over the four accumulators: consecutive MFMAs are independent
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // step q computes from LDS stage q & 1; its rows were cut into that stage one step earlier and loaded two steps earlier
+  const int ns = s_end - s_begin;
+  if (ns > 0) {
+    load_step(s_begin, rc0, ra0);
+    load_step(s_begin + 1, rc1, ra1);
+    store_step(lds, rc0, ra0, want_bias);
+  }
+  __syncthreads();
+  // trip of two steps: set 0 was stored for step q already and takes the rows of step q + 2; set 1 (step q + 1) is cut into
+  // the other stage behind the MFMAs of step q (past the end of the slab: a harmless re-cut of the last step into the stage
+  // nobody reads again; the bias sums count real steps only)
+#define NT_TRIP(Q, RCL, RAL, RCS, RAS)                                                        \
+  {                                                                                           \
+    const int q_ = (Q);                                                                       \
+    if (q_ >= ns) break;                                                                      \
+    load_step(s_begin + q_ + 2, RCL, RAL);                                                    \
+    compute(lds + (q_ & 1) * NT_STAGE);                                                       \
+    store_step(lds + ((q_ + 1) & 1) * NT_STAGE, RCS, RAS, want_bias && q_ + 1 < ns);          \
+    __syncthreads();                                                                          \
+  }
+  for (int q = 0; q < ns; q += 2) {
+    NT_TRIP(q, rc0, ra0, rc1, ra1)
+    NT_TRIP(q + 1, rc1, ra1, rc0, ra0)
+  }
+#undef NT_TRIP
+  // sub-tiles of this wave that lie inside the problem (whole 32-column blocks)
   bool vi[2], vj[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     vi[i] = n0 + wn * 64 + i * 32 < P.N;
     vj[i] = k0 + wk * 64 + i * 32 < P.K;
-  }
-  auto compute = [&](const uint16_t* cur) __attribute__((always_inline)) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = nt_frag32(cur, sub * 16, wn * 8 + i * 4, lane);
-        al[i] = nt_frag32(cur + NT_PLANE, sub * 16, wn * 8 + i * 4, lane);
-        bh[i] = nt_frag32(cur + 2 * NT_PLANE, sub * 16, wk * 8 + i * 4, lane);
-        bl[i] = nt_frag32(cur + 3 * NT_PLANE, sub * 16, wk * 8 + i * 4, lane);
-      }
-      // product by product over the (up to) four accumulators: consecutive MFMAs are independent (back to back on ONE
-      // accumulator each would wait out the previous one's passes)
-#pragma unroll
-      for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (!vi[i]) continue;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (!vj[j]) continue;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
-          }
-        }
-      if (want_bias && wk == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (!vi[i]) continue;
-          accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ones, accb[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (!vi[i]) continue;
-          accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], ones, accb[i], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  uint16_t* const stage0 = lds;
-  uint16_t* const stage1 = lds + NT_STAGE;
-  if (s_begin < s_end) {
-    load_step(s_begin, rc0, ra0);
-    if (s_begin + 1 < s_end) load_step(s_begin + 1, rc1, ra1);
-    store_step(stage0, rc0, ra0);
-  }
-  __syncthreads();
-  // two steps per trip: step st reads stage0 (register set 1 holds step st + 1), step st + 1 reads stage1
-  for (int st = s_begin; st < s_end; st += 2) {
-    if (st + 2 < s_end) load_step(st + 2, rc0, ra0);
-    compute(stage0);
-    if (st + 1 < s_end) store_step(stage1, rc1, ra1);
-    __syncthreads();
-    if (st + 1 >= s_end) break;
-    if (st + 3 < s_end) load_step(st + 3, rc1, ra1);
-    compute(stage1);
-    if (st + 2 < s_end) store_step(stage0, rc0, ra0);
-    __syncthreads();
   }
 
   const int h = lane >> 5, c31 = lane & 31;
@@ -263,15 +266,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
         if (k < P.K) ws[(int64_t)n * P.K + k] = acc[i][j][r] * inv;
       }
     }
-  if (want_bias && wk == 0 && c31 == 0) {
+  if (want_bias) {  // (uniform) the eight row groups of every column meet in LDS; the operand images are idle by now
+    float* const red = reinterpret_cast<float*>(lds);
+    *reinterpret_cast<float4*>(red + (r8 * 32 + c4) * 4) = bsum;
+    __syncthreads();
+    if (tid < 128 && n0 + tid < P.N) {
+      float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (!vi[i]) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        P.ws_bias[(int64_t)slab * P.N + n] = accb[i][r] * invC;
-      }
+      for (int g = 0; g < 8; ++g) sum += red[(g * 32 + (tid >> 2)) * 4 + (tid & 3)];
+      P.ws_bias[(int64_t)slab * P.N + n0 + tid] = sum;
     }
   }
 }
@@ -288,60 +291,98 @@ struct NtRedLaunch {
   NtRedProblem p[NT_MAX_GROUP];
   int32_t n_prob, slabs;
 };
-// blockIdx.y = problem; the slabs are added in their fixed order
+// blockIdx.y = problem.  A workgroup sums 64 four-element pieces: its four waves take a quarter of the slabs each (eight
+// loads in flight per lane), the quarters meet in LDS and are added in their fixed order -- bitwise reproducible, and four
+// times the loads in flight of a thread-per-piece loop (second layers, 64 slabs: 42 -> see profiles/r05_nt_time.txt).
 __global__ __launch_bounds__(256) void nt_reduce_kernel(const NtRedLaunch L) {
+  __shared__ float4 part[4][64];
   const NtRedProblem& P = L.p[blockIdx.y];
   const int k4 = P.K >> 2;
   const int64_t total = (int64_t)P.N * k4;
   const int64_t plane = (int64_t)P.N * P.K;
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = it / k4;
-    const int k = (int)(it - n * k4) * 4;
-    // (eight slabs' loads in flight per thread: one load per iteration made the pass latency-bound, 85 us for 45 MB; the
-    // additions stay in slab order)
-    const float* const src = P.ws + n * P.K + k;
-    float4 s = *reinterpret_cast<const float4*>(src);
-    int sl = 1;
-    for (; sl + 8 <= L.slabs; sl += 8) {
-      float4 v[8];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int per = (L.slabs + 3) >> 2;
+  const int s0 = g * per, s1 = min(L.slabs, s0 + per);
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t it = base + e;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t n = 0;
+    int k = 0;
+    if (it < total) {
+      n = it / k4;
+      k = (int)(it - n * k4) * 4;
+      const float* const src = P.ws + n * P.K + k;
+      int sl = s0;
+      for (; sl + 8 <= s1; sl += 8) {
+        float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (sl + u) * plane);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (sl + u) * plane);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; sl < s1; ++sl) {
+        const float4 v = *reinterpret_cast<const float4*>(src + sl * plane);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
     }
-    for (; sl < L.slabs; ++sl) {
-      const float4 v = *reinterpret_cast<const float4*>(src + sl * plane);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    part[g][e] = s;
+    __syncthreads();
+    if (g == 0 && it < total) {
+      float4 t = part[0][e];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) { t.x += part[q][e].x; t.y += part[q][e].y; t.z += part[q][e].z; t.w += part[q][e].w; }
+      float* const o = P.dW + n * P.lddw + k;
+      if (P.accumulate) {
+        t.x += o[0]; t.y += o[1]; t.z += o[2]; t.w += o[3];
+      }
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
     }
-    float* const o = P.dW + n * P.lddw + k;
-    if (P.accumulate) {
-      s.x += o[0]; s.y += o[1]; s.z += o[2]; s.w += o[3];
-    }
-    o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+    __syncthreads();
   }
   if (P.dbias && blockIdx.x == 0) {
     for (int n = threadIdx.x; n < P.N; n += blockDim.x) {
+      // (eight slabs' loads in flight: a dependent load per slab made this loop -- 64 slabs, a few KB -- the longest part
+      //  of the launch, ~30 us)
       float s = P.ws_bias[n];
-      for (int sl = 1; sl < L.slabs; ++sl) s += P.ws_bias[(int64_t)sl * P.N + n];
+      int sl = 1;
+      for (; sl + 8 <= L.slabs; sl += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = P.ws_bias[(int64_t)(sl + u) * P.N + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; sl < L.slabs; ++sl) s += P.ws_bias[(int64_t)sl * P.N + n];
       P.dbias[n] = P.accumulate ? P.dbias[n] + s : s;
     }
   }
 }
 
-// OFF by default (mml_gemm_set_nt(1) / MMLREC_GEMM_NT=1 switch it on).  Measured, cold caches, B = 65 536, same box,
-// partial-product launch + reduction (tools/lab/nt_time.py, profiles/r05_nt_time.txt): AE-30 first layers 198 + 23 us
-// against the tile kernel's 200 + 15; second layers 134 + 42 against 134 + 17; towers 61 + 36 against 48 + 11; KuaiRec-32
-// first layers 706 + 21 against 648 + 24.  The cut is no longer what bounds these launches (4 VALU instructions per MFMA
-// here, 12 there, the same time): with one step of rows in flight the kernel took 258 us on the first layers, with two
-// 198 -- it waits for memory at two workgroups of 224 VGPRs per CU, where the tile kernel's persistent workgroups keep a
-// four-stage LDS-DMA ring full.  Kept as a tested alternative (tests/test_gemm_nt_gpu.py), not as the default.
+// Which launches: mml_gemm_set_nt / MMLREC_GEMM_NT = 0 none, 1 (DEFAULT) every launch that qualifies, 2 only those of at
+// least NT_MIN_TILES output tiles.  Measured on one box, B = 65 536:
+//   * stand-alone, cold caches, partial-product launch + reduction (tools/lab/nt_time.py, profiles/r05_nt_time.txt): AE-30
+//     first layers (20 tiles) 196 + 15 us against the tile kernel's 212 + 16; KuaiRec-32 first layers (72 tiles) 665 + 20
+//     against 681 + 24; second layers (8 tiles) 135 + 22 against 137 + 17; towers (2 half-empty tiles) 50 + 13 against 49 + 11;
+//   * in the replayed AE-30 step, interleaved (tools/lab/ab_nt.sh, profiles/r05_ab_nt.txt): mode 0 1.673 / 1.695 ms, mode 2
+//     1.644 / 1.602, mode 1 **1.598 / 1.609** (weight-gradient launches 0.287 -> 0.265 ms in the instrumented pass; the
+//     step gains more than that); KuaiRec-32 fp32 3.12 -> 3.03 ms.
+// How it got there: one step of rows in flight 258 us (first layers), two 198, three 201 (and spills in a branch-free body);
+// then the step body as ONE basic block -- no branch around the MFMAs of sub-tiles outside the problem, no conditional loads
+// -- so that the compiler interleaves the next rows' cut and LDS stores with the MFMAs: 184-196; the bias gradient from the
+// staging threads' own sums instead of two more MFMAs and 32 accumulator registers; a reduction whose bias loop kept one
+// dependent load in flight cost 30 us by itself.  Counters (tools/lab/nt_pmc.sh, profiles/r05_nt_pmc.txt, before the last two
+// steps): 8.8 VALU instructions per MFMA against 11.9, MFMA pipe busy 0.32 against 0.34, no LDS bank conflicts either way,
+// the same L2 requests and hit rate (70 %): neither kernel is bound by its cuts or by HBM; both wait on the short
+// dependent chain read -> MFMA -> next read at two to three waves per SIMD.
+constexpr int NT_MIN_TILES = 16;
 static int g_nt_on = -1;
-static bool nt_enabled() {
+static int nt_mode() {
   if (g_nt_on < 0) {
     const char* e = getenv("MMLREC_GEMM_NT");
-    g_nt_on = (e && atoi(e) == 1) ? 1 : 0;
+    g_nt_on = e ? atoi(e) : 1;
+    if (g_nt_on < 0 || g_nt_on > 2) g_nt_on = 1;
   }
-  return g_nt_on != 0;
+  return g_nt_on;
 }
 static int nt_cus() {
   static int n = 0;
@@ -359,7 +400,8 @@ static int nt_cus() {
 using namespace mml;
 
 extern "C" int mml_gemm_set_nt(int32_t on) {
-  g_nt_on = on ? 1 : 0;
+  MML_REQUIRE(on >= 0 && on <= 2, "mml_gemm_set_nt: 0 (off), 1 (every qualifying launch: default) or 2 (launches of >= 16 tiles)");
+  g_nt_on = on;
   return MML_OK;
 }
 
@@ -368,7 +410,7 @@ extern "C" int mml_gemm_set_nt(int32_t on) {
 // the workspace size only, so phase 2 of a call pair decides like its phase 1.
 int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes, int32_t phase,
                           hipStream_t st) {
-  if (!nt_enabled() || n < 1 || n > NT_MAX_GROUP || !workspace) return MML_ERR_UNSUPPORTED;
+  if (nt_mode() == 0 || n < 1 || n > NT_MAX_GROUP || !workspace) return MML_ERR_UNSUPPORTED;
   const int32_t M = d[0].M;
   if (M < 16384 || M % NT_STEP != 0) return MML_ERR_UNSUPPORTED;
   int64_t tiles = 0, elems = 0;
@@ -382,6 +424,7 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
     tiles += cdiv(q.N, 128) * cdiv(q.K, 128);
     elems += (int64_t)q.N * q.K + q.N;
   }
+  if (nt_mode() == 2 && tiles < NT_MIN_TILES) return MML_ERR_UNSUPPORTED;
   const int steps = M / NT_STEP;
   int64_t slabs = (2 * (int64_t)nt_cus()) / tiles;   // two workgroups per CU (64 KiB of LDS each)
   if (slabs > steps / 8) slabs = steps / 8;           // at least 256 batch rows per slab
@@ -411,7 +454,7 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
     NtRedProblem& Q = R.p[i];
     Q.ws = P.ws; Q.ws_bias = P.ws_bias; Q.dW = q.dW; Q.dbias = q.dbias; Q.lddw = q.lddw; Q.N = q.N; Q.K = q.K;
     Q.accumulate = q.accumulate;
-    const int blocks = (int)cdiv((int64_t)q.N * q.K / 4, 256);
+    const int blocks = (int)cdiv((int64_t)q.N * q.K / 4, 64);
     maxred = blocks > maxred ? blocks : maxred;
   }
   if (phase != 2) {
@@ -420,7 +463,7 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
     if (rc != MML_OK) return rc;
   }
   if (phase != 1) {
-    if (maxred > 512) maxred = 512;
+    if (maxred > 2048) maxred = 2048;
     MML_LAUNCH(nt_reduce_kernel, dim3((unsigned)maxred, (unsigned)n), dim3(256), 0, st, R);
     return check_launch("mml_gemm_grouped_wgrad(nt reduce)");
   }

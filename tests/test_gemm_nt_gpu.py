@@ -21,7 +21,7 @@ def env():
     lib.mml_gemm_set_mode(4)
     yield L, ops, lib
     lib.mml_gemm_set_mode(mode0)
-    lib.mml_gemm_set_nt(0)   # (the library's default)
+    lib.mml_gemm_set_nt(1)   # (the library's default)
 
 
 def rel(a, b):
