@@ -490,7 +490,7 @@ def secondary_configs(args, dev):
             entry = {"config": label, "workload": describe_workload(wl, cfg, vocab, dense),
                      "table_update": model.optimizer().table_update,
                      "dtype": "bf16 storage + operands, f32 accumulate" if mode == 1 else "f32", "runs": []}
-            for B, steps in ((65536, 10), (4096, 40)):
+            for B, steps in ((65536, 20), (4096, 40)):
                 batches = []
                 for i in range(2):
                     X, y = W.synth_batch(vocab, len(dense), B, T, seed=1 + i, dist=args.dist)
