@@ -25,6 +25,7 @@ def label(kernel_name, avg_bytes_hint=0):
                  ("gate_bwd_fast_kernel", "gate_bwd_kernel"), ("gate_fwd_fast_kernel", "gate_fwd_kernel"), ("gate_fwd_once_kernel", "gate_fwd_kernel"),
                  ("head_fast_kernel", "head_kernel"),
                  ("opt_flat_kernel", "opt_flat_kernel"),
+                 ("gemm_nt_kernel", "gemm_nt_kernel"), ("nt_reduce_kernel", "slab_reduce"),
                  ("slab_reduce", "slab_reduce")):
         if k.startswith(a):
             return b
