@@ -15,6 +15,9 @@
  *   mml_dropout               nn.Dropout after a DNN layer (model/utils.py:121, :159) under this build's Philox mask stream
  *   mml_gemm_planes_cut       the pre-cut weight planes of the two-plane GEMM arithmetic (a contract of ours; the CPU GEMMs
  *                             here ignore w_planes / w_kexp and read the float weights)
+ *   mml_cast16_batch / mml_gather16_fwd / mml_g16_tn / mml_g16_wgrad   the bf16-STORAGE layer family (K3' of the header: the
+ *                             same DNN layers, model/utils.py:146-161, on operands stored as bf16 -- round to nearest even --
+ *                             with float64 accumulation here)
  * tests/test_cabi_cpu.py drives one full MMoE training step of a reference-made golden fixture through these entry
  * points (the call sequence of mmlrec_amd/engine.py) in the CPU container.
  * Build: oracle/build_fast.py (gcc -O2 -shared -fPIC), output oracle/_build/libmmlrec_cpu.so. */
@@ -397,6 +400,7 @@ int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* worksp
 int mml_gate_mix_fwd(const mml_gate_group* g, mml_stream_t stream) {
   (void)stream;
   REQUIRE(g && g->n_experts >= 1 && g->n_gates >= 1 && g->H > 0, "mml_gate_mix_fwd: bad group");
+  if (g->out_bf16) return MML_ERR_UNSUPPORTED;  /* (bf16 outputs exist in the HIP library's fast row kernels only) */
   for (int64_t b = 0; b < g->B; ++b)
     for (int gi = 0; gi < g->n_gates; ++gi) {
       const mml_gate_desc* d = &g->gate[gi];
@@ -423,6 +427,7 @@ int64_t mml_gate_mix_bwd_workspace_bytes(const mml_gate_group* g) { (void)g; ret
 int mml_gate_mix_bwd(const mml_gate_group* g, void* workspace, int64_t workspace_bytes, mml_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   REQUIRE(g && g->n_experts >= 1 && g->n_gates >= 1 && g->H > 0, "mml_gate_mix_bwd: bad group");
+  if (g->out_bf16) return MML_ERR_UNSUPPORTED;
   for (int gi = 0; gi < g->n_gates; ++gi)
     if (g->gate[gi].active)
       memset(g->gate[gi].dWg, 0, sizeof(float) * (size_t)g->gate[gi].ne * g->gate[gi].Gd);
@@ -470,6 +475,7 @@ int mml_gate_mix_bwd(const mml_gate_group* g, void* workspace, int64_t workspace
 /* ------------------------------------------------------------------------------------------------ K5 */
 static int heads(const mml_head_group* g, int train) {
   REQUIRE(g && g->n_heads >= 1 && g->n_heads <= MML_MAX_HEADS && g->prob, "mml_head_*: bad group");
+  if (g->dh_bf16) return MML_ERR_UNSUPPORTED;   /* (bf16 outputs exist in the HIP library's fast row kernels only) */
   double loss = 0.0;
   if (train)
     for (int t = 0; t < g->n_heads; ++t) {
@@ -564,6 +570,114 @@ int mml_opt_step_dense(const mml_opt_tensor* t, int32_t n, const mml_opt_hyper* 
       if (h->zero_grad || t[i].zero_grads) ((float*)t[i].grad)[j] = 0.f;
     }
     if (t[i].grad_marks && t[i].row_elems > 0) memset(t[i].grad_marks, 0, (size_t)(t[i].n / t[i].row_elems));
+  }
+  return MML_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ K3' (bf16 storage) */
+static uint16_t to_bf16(float f) {  /* round to nearest even; NaN stays NaN */
+  union { float f; uint32_t u; } c;
+  c.f = f;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((c.u >> 16) | 0x40u);
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);
+  return (uint16_t)(c.u >> 16);
+}
+static float from_bf16(uint16_t h) {
+  union { float f; uint32_t u; } c;
+  c.u = (uint32_t)h << 16;
+  return c.f;
+}
+const char* mml_g16_last_kernel(void) { return "cpu"; }
+int mml_gemm_set_nt(int32_t on) { (void)on; return MML_OK; }
+
+int mml_cast16_batch(const mml_cast16_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(d || n == 0, "mml_cast16_batch: descriptor array is null");
+  for (int i = 0; i < n; ++i) {
+    const mml_cast16_desc* q = d + i;
+    REQUIRE(q->src && q->dst, "mml_cast16_batch: null matrix (item %d)", i);
+    for (int64_t r = 0; r < q->rows; ++r)
+      for (int c = 0; c < q->cols; ++c) {
+        const uint16_t v = to_bf16(q->src[r * q->lds + c]);
+        if (q->transpose) q->dst[(int64_t)c * q->ldd + r] = v;
+        else q->dst[r * q->ldd + c] = v;
+      }
+  }
+  return MML_OK;
+}
+
+int mml_gather16_fwd(const float* const* tables, const int64_t* vocab, const int32_t* col, int32_t F, int32_t E,
+                     const float* X, int64_t ldX, int32_t dense_col0, int32_t Nd, int64_t B, uint16_t* out, int64_t ldo,
+                     int32_t* status, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(tables && vocab && col && X && out, "mml_gather16_fwd: null argument");
+  for (int64_t b = 0; b < B; ++b) {
+    for (int f = 0; f < F; ++f) {
+      int64_t i = (int64_t)X[b * ldX + col[f]];
+      if (i < 0) { if (status) *status |= 1; i = 0; }
+      else if (i >= vocab[f]) { if (status) *status |= 2; i = vocab[f] - 1; }
+      for (int e = 0; e < E; ++e) out[b * ldo + (int64_t)f * E + e] = to_bf16(tables[f][i * E + e]);
+    }
+    for (int j = 0; j < Nd; ++j) out[b * ldo + (int64_t)F * E + j] = to_bf16(X[b * ldX + dense_col0 + j]);
+  }
+  return MML_OK;
+}
+
+int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(d, "mml_g16_tn: descriptor array is null");
+  for (int i = 0; i < n; ++i) {
+    const mml_g16_tn_desc* q = d + i;
+    REQUIRE(q->M % 128 == 0 && q->N % 64 == 0 && q->n_src >= 1 && q->n_src <= MML_MAX_SRC, "mml_g16_tn: extents (problem %d)", i);
+    REQUIRE(!(q->c_bf16 && q->accumulate), "mml_g16_tn: accumulation needs an fp32 output");
+    for (int64_t m = 0; m < q->M; ++m)
+      for (int c = 0; c < q->N; ++c) {
+        double acc = 0.0;
+        for (int s = 0; s < q->n_src; ++s) {
+          REQUIRE(q->K[s] % 64 == 0, "mml_g16_tn: K %% 64 (problem %d)", i);
+          const uint16_t* a = q->A[s] + m * q->lda[s];
+          const uint16_t* b = q->B[s] + (int64_t)c * q->ldb[s];
+          for (int k = 0; k < q->K[s]; ++k) acc += (double)from_bf16(a[k]) * (double)from_bf16(b[k]);
+        }
+        float v = (float)acc + (q->bias ? q->bias[c] : 0.f);
+        if (q->act == MML_ACT_RELU) v = v > 0.f ? v : 0.f;
+        if (q->mask_out) {
+          uint32_t* w = q->mask_out + m * q->ldmask + (c >> 5);
+          if (v > 0.f) *w |= 1u << (c & 31); else *w &= ~(1u << (c & 31));
+        }
+        if (q->mask_in && !((q->mask_in[m * q->ldmask + (c >> 5)] >> (c & 31)) & 1u)) v = 0.f;
+        if (q->c_bf16) ((uint16_t*)q->C)[m * q->ldc + c] = to_bf16(v);
+        else {
+          float* o = (float*)q->C + m * q->ldc + c;
+          *o = q->accumulate ? *o + v : v;
+        }
+      }
+  }
+  return MML_OK;
+}
+
+int64_t mml_g16_wgrad_workspace_bytes(const mml_g16_wgrad_desc* d, int32_t n) { (void)d; (void)n; return 256; }
+int mml_g16_wgrad(const mml_g16_wgrad_desc* d, int32_t n, void* workspace, int64_t workspace_bytes, int32_t phase,
+                  mml_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  REQUIRE(d, "mml_g16_wgrad: descriptor array is null");
+  REQUIRE(phase >= 0 && phase <= 2, "mml_g16_wgrad: phase must be 0, 1 or 2");
+  if (phase == 1) return MML_OK;  /* (everything happens in the reduction phase here) */
+  for (int i = 0; i < n; ++i) {
+    const mml_g16_wgrad_desc* q = d + i;
+    REQUIRE(q->M % 64 == 0 && q->N % 128 == 0 && q->K % 128 == 0, "mml_g16_wgrad: extents (problem %d)", i);
+    for (int r = 0; r < q->N; ++r) {
+      double bsum = 0.0;
+      for (int64_t m = 0; m < q->M; ++m) bsum += (double)from_bf16(q->dC[m * q->lddc + r]);
+      if (q->dbias) q->dbias[r] = (q->accumulate ? q->dbias[r] : 0.f) + (float)bsum;
+      for (int k = 0; k < q->K; ++k) {
+        double acc = 0.0;
+        for (int64_t m = 0; m < q->M; ++m)
+          acc += (double)from_bf16(q->dC[m * q->lddc + r]) * (double)from_bf16(q->A[m * q->lda + k]);
+        float* o = q->dW + (int64_t)r * q->lddw + k;
+        *o = (q->accumulate ? *o : 0.f) + (float)acc;
+      }
+    }
   }
   return MML_OK;
 }

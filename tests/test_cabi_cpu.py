@@ -347,3 +347,68 @@ def test_mmoe_training_step_through_the_cpu_cabi_matches_the_reference_golden(cp
         # first-step Adam turns a noise-level gradient's sign into an lr-sized move: outlier share + absolute bound
         assert (dv > RTOL * max(np.abs(ref).max(), 1e-30)).mean() < 2e-3, k
         assert dv.max() <= 2.5 * cfg_lr, k
+
+
+def test_bf16_storage_family_on_the_cpu_library(cpu):
+    """The bf16-storage entry points (include/mmlrec.h K3': mml_gather16_fwd, mml_cast16_batch, mml_g16_tn forward and input
+    gradient, mml_g16_wgrad) through the SAME ctypes descriptors ops.py builds for the HIP library, on host tensors: pins
+    the descriptor layouts and argument meaning of the new section of the header without a GPU -- a two-layer chain
+    (gather -> Linear + ReLU with sign masks -> Linear) and its backward against float64 torch on the bf16-rounded
+    operands."""
+    import torch
+    lib, L = cpu
+    from mmlrec_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B, F, E, H1, H2 = 128, 8, 16, 128, 128
+    vocab = [5, 9, 100, 3, 40, 7, 2, 11]
+    tabs = [torch.randn(v, E, generator=g) for v in vocab]
+    idx = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocab], 1)
+    X = idx.float().contiguous()
+    x0 = torch.empty(B, F * E, dtype=torch.bfloat16)
+    vs = (L.i64 * F)(*vocab)
+    col = (L.i32 * F)(*range(F))
+    status = torch.zeros(1, dtype=torch.int32)
+    assert lib.mml_gather16_fwd(ops._ptr_array(tabs), vs, col, F, E, X.data_ptr(), F, 0, 0, B, x0.data_ptr(), F * E,
+                                status.data_ptr(), None) == 0 and int(status) == 0
+    ref0 = torch.cat([tabs[f][idx[:, f]] for f in range(F)], 1).to(torch.bfloat16)
+    assert torch.equal(x0, ref0)
+    W1, b1 = torch.randn(H1, F * E, generator=g) / (F * E) ** 0.5, torch.randn(H1, generator=g) * 0.1
+    W2 = torch.randn(H2, H1, generator=g) / H1 ** 0.5
+    W1b, W2b = torch.empty(H1, F * E, dtype=torch.bfloat16), torch.empty(H2, H1, dtype=torch.bfloat16)
+    W2t = torch.empty(H1, H2, dtype=torch.bfloat16)
+    arr = ops.make_cast16_descs([(W1, W1b, False), (W2, W2b, False), (W2, W2t, True)])
+    assert lib.mml_cast16_batch(arr, 3, None) == 0
+    assert torch.equal(W1b, W1.to(torch.bfloat16)) and torch.equal(W2t, W2.t().contiguous().to(torch.bfloat16))
+    h1 = torch.empty(B, H1, dtype=torch.bfloat16)
+    mask = torch.zeros(B, H1 // 32, dtype=torch.int32)
+    y = torch.empty(B, H2)
+    d1 = ops.make_g16_tn_descs([dict(srcs=[(x0, W1b)], C=h1, bias=b1, act=L.ACT_RELU, mask_out=mask)])
+    assert lib.mml_g16_tn(d1, 1, None) == 0
+    d2 = ops.make_g16_tn_descs([dict(srcs=[(h1, W2b)], C=y)])
+    assert lib.mml_g16_tn(d2, 1, None) == 0
+    r1 = torch.relu(x0.double() @ W1b.double().t() + b1.double())
+    assert (h1.double() - r1).abs().max() <= 2.0 ** -8 * r1.abs().max()
+    r2 = h1.double() @ W2b.double().t()
+    assert (y.double() - r2).abs().max() <= 1e-5 * r2.abs().max()
+    bits = ((mask.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(B, -1).bool()
+    assert torch.equal(bits, h1.float() > 0)
+    # backward: dy -> (dW2, db2), dh1 (ReLU derivative from the sign bits, bf16), then dW1
+    dy = torch.randn(B, H2, generator=g).to(torch.bfloat16)
+    dW2, db2 = torch.full((H2, H1), 7.0), torch.full((H2,), 7.0)
+    wd = ops.make_g16_wgrad_descs([dict(dC=dy, A=h1, dW=dW2, dbias=db2)])
+    ws = torch.empty(256, dtype=torch.uint8)
+    assert lib.mml_g16_wgrad_workspace_bytes(wd, 1) >= 0
+    assert lib.mml_g16_wgrad(wd, 1, ws.data_ptr(), ws.numel(), 0, None) == 0
+    rw = dy.double().t() @ h1.double()
+    assert (dW2.double() - rw).abs().max() <= 1e-5 * rw.abs().max()
+    assert (db2.double() - dy.double().sum(0)).abs().max() <= 1e-5 * dy.double().sum(0).abs().max()
+    dh1 = torch.empty(B, H1, dtype=torch.bfloat16)
+    dd = ops.make_g16_tn_descs([dict(srcs=[(dy, W2t)], C=dh1, mask_in=mask)])
+    assert lib.mml_g16_tn(dd, 1, None) == 0
+    rd = (dy.double() @ W2t.double().t()) * bits
+    assert (dh1.double() - rd).abs().max() <= 2.0 ** -8 * rd.abs().max()
+    assert bool((dh1.float()[~bits] == 0).all())
+    # the row kernels' bf16 outputs exist in the HIP library only: the CPU library says so instead of writing fp32
+    grp = L.GateGroup()
+    grp.n_experts, grp.n_gates, grp.H, grp.B, grp.out_bf16 = 1, 1, 4, 0, 1
+    assert lib.mml_gate_mix_fwd(C.byref(grp), None) == -3
