@@ -20,8 +20,8 @@ COUNTED_WAIT_SOURCES = GEMM_SOURCES + ("gemm_panel.hip", "gemm_ws.hip")
 COUNTED_WAIT_KERNELS = ("gemm_pipe_kernel", "gemm_panel_kernel", "gemm_ws_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
-if os.environ.get("MMLREC_GEMM_NT") == "1":  # nontemporal output stores of the tile kernel's epilogue (csrc/gemm.hip)
-    FLAGS.append("-DMML_GEMM_NT")
+if os.environ.get("MMLREC_BUILD_NTSTORE") == "1":  # nontemporal output stores of the tile kernel's epilogue (csrc/gemm.hip)
+    FLAGS.append("-DMML_GEMM_NTSTORE")
 
 
 def _newest(paths):

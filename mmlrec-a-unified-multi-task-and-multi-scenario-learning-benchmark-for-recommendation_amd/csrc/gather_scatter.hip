@@ -57,14 +57,17 @@ __device__ __forceinline__ int64_t load_index(const GatherArgs& a, int64_t b, in
   return i;
 }
 
-// One thread = one 16-byte piece of the output row (E % 4 == 0) or one dense scalar.
+// One thread = one 16-byte piece of the output row (E % 4 == 0): four values of an embedding row, or four dense
+// features (the last piece of a row: Nd % 4 of them, stored as scalars -- the columns behind them are not this kernel's).
+// (Until round 5 a dense feature was a thread of its own: AE's 63 dense columns, reference configs_msl/config_AE.json,
+// doubled the threads of the launch and stored 4 bytes each -- 36 -> 66 us at B = 65 536.)
 // ITEMS (index -> row -> store) chains per thread; launched with ITEMS = 1 (see launch_gather).
 template <int ITEMS, bool WGMAX = false>
 __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, const GatherArgs a) {
   float am = 0.f;  // (WGMAX) the largest |value| this thread stored
   const int e4 = a.E >> 2;
   const int nvec = a.F * e4;             // 16-byte pieces per sample
-  const int per_sample = nvec + a.Nd;    // + dense scalars
+  const int per_sample = nvec + ((a.Nd + 3) >> 2);  // + pieces of four dense features
   // A thread keeps ONE output column slot c and walks ITEMS consecutive samples: the (sample, slot) split costs one
   // 32-bit division per ITEMS items instead of a 64-bit one per item, the field / piece decode happens once per
   // thread, and neighbouring lanes still write neighbouring 16-byte pieces of the same row.
@@ -105,13 +108,25 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const FieldTable ft, c
           if (WGMAX) amax_acc(am, v[i]);
         }
     } else {
-      const int j = c - nvec;
+      const int j = 4 * (c - nvec);
+      const int nj = a.Nd - j;  // >= 1
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
         if (b0 + i < a.B) {
           const int64_t b = b0 + i;
-          const float d = a.X ? a.X[b * a.ldX + a.dense_col0 + j] : a.dense[b * a.ldd + j];
-          a.out[b * a.ldo + (int64_t)a.F * a.E + j] = d;
+          const float* src = a.X ? a.X + b * a.ldX + a.dense_col0 + j : a.dense + b * a.ldd + j;  // (4-byte aligned only)
+          float* dst = a.out + b * a.ldo + (int64_t)a.F * a.E + j;                                // (16-byte aligned)
+          float4 d = make_float4(src[0], 0.f, 0.f, 0.f);
+          if (nj > 1) d.y = src[1];
+          if (nj > 2) d.z = src[2];
+          if (nj > 3) d.w = src[3];
+          if (nj > 3) {
+            *reinterpret_cast<float4*>(dst) = d;
+          } else {
+            dst[0] = d.x;
+            if (nj > 1) dst[1] = d.y;
+            if (nj > 2) dst[2] = d.z;
+          }
           if (WGMAX) amax_acc(am, d);
         }
     }
@@ -239,7 +254,7 @@ static int launch_gather(const FieldTable& ft, const GatherArgs& a, hipStream_t 
       g_last_gather = "gather_lds_kernel";
       return check_launch("mml_gather_fwd(lds)");
     }
-    const int64_t per_sample = (int64_t)a.F * (a.E / 4) + a.Nd;
+    const int64_t per_sample = (int64_t)a.F * (a.E / 4) + (a.Nd + 3) / 4;
     const int64_t total = cdiv(a.B, (int64_t)items) * per_sample;
     int64_t blocks = cdiv(total, (int64_t)threads);
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;  // (grid-stride beyond that)
@@ -870,7 +885,7 @@ extern "C" int mml_gather_fwd(const float* const* tables, const int64_t* vocab, 
 // number of workgroups (= partial maxima) mml_gather_fwd_wgmax writes for these sizes
 extern "C" int64_t mml_gather_wgmax_len(int32_t F, int32_t E, int32_t Nd, int64_t B) {
   if (F <= 0 || E <= 0 || E % 4 != 0 || Nd < 0 || B <= 0) return 0;
-  const int64_t per_sample = (int64_t)F * (E / 4) + Nd;
+  const int64_t per_sample = (int64_t)F * (E / 4) + (Nd + 3) / 4;  // (threads per sample of gather_vec4_kernel)
   const int64_t blocks = cdiv(B * per_sample, (int64_t)256);
   return blocks > 0x7fffffff ? 0 : blocks;
 }

@@ -1335,9 +1335,9 @@ __global__ __launch_bounds__(256, ((BN == 64 && EPI != EPI_DGRAD && !K7) ? 3 : 2
               *reinterpret_cast<float4*>(d2) = dg;
               am2 = fmaxf(fmaxf(am2, fabsf(dg.x)), fmaxf(fabsf(dg.y), fmaxf(fabsf(dg.z), fabsf(dg.w))));
             }
-            // (nontemporal, MMLREC_GEMM_NT=1 at build time: the output is read next by another kernel, long after the
+            // (nontemporal, MMLREC_BUILD_NTSTORE=1 at build time: the output is read next by another kernel, long after the
             // line has left the L2 -- the panel kernel gained 4 % from it)
-#ifdef MML_GEMM_NT
+#ifdef MML_GEMM_NTSTORE
             __builtin_nontemporal_store(f32x4_t{x.x, x.y, x.z, x.w}, reinterpret_cast<f32x4_t*>(C + (int64_t)row * ldc + colg));
 #else
             *reinterpret_cast<float4*>(C + (int64_t)row * ldc + colg) = x;

@@ -6,8 +6,8 @@
 // fetched, staged and cut into its two fp16 planes once per N-TILE -- nine times for AE-30's 4 x 256 + 2 x 64 output
 // columns -- and every tile pays its own prologue.  Here a persistent workgroup owns a 128-row panel:
 //   * one wave per SIMD (256 threads, 512 VGPRs each): a wave keeps the MFMA fragments of ITS 32 rows of the panel -- all
-//     K <= 240 of them, already cut into the two fp16 planes of the scaled values (same bits as the in-register cut of
-//     gemm.hip: h = rne16(x s), l = rne16(x s - h)) -- in 8 K / 16 registers while the workgroup sweeps every N-tile of
+//     K <= 320 of them, already cut into the two fp16 planes of the scaled values (same bits as the in-register cut of
+//     gemm.hip: h = rne16(x s), l = rne16(x s - h)) -- in 8 K / 16 registers (160 of the 512 at K = 320) while the workgroup sweeps every N-tile of
 //     the row block: the activations are read and cut ONCE per panel and never touch LDS;
 //   * the whole LDS is a twelve-stage ring for the pre-cut weights (mml_gemm_planes_cut, MML_PLANES_ROWS): ten k-steps
 //     of LDS-DMA in flight.  The depth is not a luxury: vector-memory operations of a wave retire IN ORDER, so a weight
@@ -167,7 +167,7 @@ constexpr int pn_younger(int KB, int kb, bool masks, bool cur, bool prev) {
 
 template <int KB, bool MASKS>
 __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(const PanelLaunch Larg) {
-  static_assert(KB >= PN_W && KB >= 10 && KB <= 15, "the panel kernel holds 10..15 k-blocks per row in registers");
+  static_assert(KB >= PN_W && KB >= 10 && KB <= 20, "the panel kernel holds 10..20 k-blocks per row in registers");
   constexpr int SPG = pn_spg(KB);
   static_assert(KB * PN_EGAPS * SPG >= 4 * PN_NSL, "the epilogue must end inside the tile");
   typedef const __attribute__((address_space(4))) PanelLaunch KLaunch;
@@ -617,8 +617,28 @@ extern "C" int mml_gemm_set_panel(int32_t on) {
 int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   if (!pn_enabled() || n < 1 || n > MML_MAX_GROUP) return MML_ERR_UNSUPPORTED;
   const mml_gemm_fwd_desc& d0 = d[0];
-  if (d0.K != 240 && d0.K != 208 && d0.K != 160) return MML_ERR_UNSUPPORTED;  // (the instantiated panel widths)
-  if (d0.M < PN_BM * 64 || d0.M % PN_BM != 0) return MML_ERR_UNSUPPORTED;  // (small / ragged batches: the tile kernel)
+  // the instantiated panel widths: every K = 16 k from 160 to 320 (the caller pads other reduction lengths with zero
+  // columns on both operands -- engine.py, Val.kpad: AE with its 63 dense columns, K0 = 303, arrives here as 304)
+  if (d0.K % 16 != 0 || d0.K < 160 || d0.K > 320) return MML_ERR_UNSUPPORTED;
+  if (d0.M < PN_BM * 64) return MML_ERR_UNSUPPORTED;  // (small batches: the tile kernel)
+  if (d0.M % PN_BM != 0) {
+    // ragged batch: the whole panels here, the last M % 128 rows through the tile kernel (a row's result does not depend
+    // on the tile it is computed in: same planes, same product and k order -- tests/test_gemm_panel_gpu.py)
+    mml_gemm_fwd_desc head[MML_MAX_GROUP], tail[MML_MAX_GROUP];
+    const int64_t mh = d0.M - d0.M % PN_BM;
+    for (int i = 0; i < n; ++i) {
+      head[i] = tail[i] = d[i];
+      head[i].M = (int32_t)mh;
+      tail[i].M = d[i].M - (int32_t)mh;
+      tail[i].A = d[i].A + mh * d[i].lda;
+      tail[i].C = d[i].C + mh * d[i].ldc;
+      if (d[i].relu_mask) tail[i].relu_mask = d[i].relu_mask + mh * d[i].ldmask;
+      if (d[i].M != d0.M) return MML_ERR_UNSUPPORTED;
+    }
+    const int rc = mml_gemm_panel_try_fwd(head, n, st);
+    if (rc != MML_OK) return rc;
+    return mml_gemm_grouped_fwd(tail, n, (void*)st);  // (M < 128: never comes back here)
+  }
   if (!d0.amax_a || !aligned16(d0.A) || d0.lda % 4 != 0) return MML_ERR_UNSUPPORTED;
   int halves = 0, masks = 0, relus = 0;
   for (int i = 0; i < n; ++i) {
@@ -682,9 +702,19 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
     if (L.store_masks) MML_LAUNCH((gemm_panel_kernel<KB_, true>), g, b, 0, st, L);    \
     else MML_LAUNCH((gemm_panel_kernel<KB_, false>), g, b, 0, st, L);                 \
   } while (0)
-  if (L.K == 240) PN_GO(15);
-  else if (L.K == 208) PN_GO(13);
-  else PN_GO(10);
+  switch (L.K / 16) {
+    case 10: PN_GO(10); break;
+    case 11: PN_GO(11); break;
+    case 12: PN_GO(12); break;
+    case 13: PN_GO(13); break;
+    case 14: PN_GO(14); break;
+    case 15: PN_GO(15); break;
+    case 16: PN_GO(16); break;
+    case 17: PN_GO(17); break;
+    case 18: PN_GO(18); break;
+    case 19: PN_GO(19); break;
+    default: PN_GO(20); break;
+  }
 #undef PN_GO
   return check_launch("mml_gemm_grouped_fwd(panel)");
 }

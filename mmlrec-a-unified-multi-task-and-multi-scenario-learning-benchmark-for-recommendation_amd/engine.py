@@ -49,6 +49,10 @@ class Val:
         # never written -- a GEMM may then read it as a [B, kpad] operand (LinearGroupOp: reduction lengths that
         # are not a multiple of the 16-wide k-step, e.g. 30 x 8 embedding columns + 63 dense columns = 303)
         self.kpad = 0
+        # > 0: only the first grad_cols columns of the gradient have a reader (dnn_input: the table scatter reads the
+        # embedding columns, nobody the dense features' -- model/basemodel.py:461-487 concatenates them behind the
+        # embeddings); LinearGroupOp then forms the input gradient for those columns only
+        self.grad_cols = 0
         # operand magnitudes for the two-plane fp16 GEMMs (include/mmlrec.h): slot of the value, slot of its gradient,
         # and how many of the gradient's writers raised that slot (valid iff it equals `written`)
         self.amax = None
@@ -1047,6 +1051,12 @@ class LinearGroupOp(Op):
                 continue
             plan.grad_of(x)
             fuse = len(chunks) == 1 and len(x.consumers) == 1 and x.act != L.ACT_NONE
+            # columns of the input gradient somebody reads (Val.grad_cols): a narrower launch over the same buffers
+            gc = x.grad_cols if (0 < x.grad_cols < x.n and x.grad_cols % 16 == 0 and x.act == L.ACT_NONE and
+                                 all(isinstance(c, LinearGroupOp) for c in x.consumers) and
+                                 not any(q.get("w_kn", 0) for q in qs) and
+                                 os.environ.get("MMLREC_GRAD_COLS", "1") != "0") else 0
+            cut = (lambda t: t[:, :gc]) if gc else (lambda t: t)
             # Small batches: an input fed by many layers (dnn_input: every expert and gate) is ONE problem with a long
             # reduction -- 128 tiles of 72 k-steps at B = 4 096 on AE-30, 41 us on a chip with 256 CUs.  Its sources are
             # dealt to up to four problems of the same launch (partial sums into scratch, one add afterwards): 4x the
@@ -1060,7 +1070,7 @@ class LinearGroupOp(Op):
                     min(parts, key=lambda p_: sum(r["out"].n for r in p_)).append(q)
                 acc = _claim(x)
                 padded = x.kpad and all("Wp" in q for q in qs)
-                g0 = _padded_view(x.grad, x.kpad) if padded else x.grad
+                g0 = cut(_padded_view(x.grad, x.kpad) if padded else x.grad)
                 pitch = x.grad.stride(0)
                 targets = [g0]
                 for _ in parts[1:]:
@@ -1070,7 +1080,7 @@ class LinearGroupOp(Op):
                     waves.append([])
                 for part, dst in zip(parts, targets):
                     waves[0].append(dict(dA=dst, Y=None, act=L.ACT_NONE, mask=None, accumulate=acc if dst is g0 else 0,
-                                         srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0),
+                                         srcs=[(q["out"].grad, cut(q["Wp"] if padded else q["W"].data), q.get("w_kn", 0),
                                                 q["amax_dc"], q["amax_w"]) for q in part]))
                 arr = ops._ptr_array([x.grad] + [t_ for t_ in targets[1:]])
                 plan.keep.append(arr)
@@ -1094,11 +1104,11 @@ class LinearGroupOp(Op):
                 gp = [plan.weight_planes(q, ops.PLANES_COLS, ch, padded=bool(padded)) for q in ch]
                 if any(pl is None for pl, _ in gp):
                     gp = [(None, None)] * len(ch)
-                waves[ci].append(dict(dA=_padded_view(x.grad, x.kpad) if padded else x.grad,
+                waves[ci].append(dict(dA=cut(_padded_view(x.grad, x.kpad) if padded else x.grad),
                                       Y=x.buf if fuse else None, act=x.act if fuse else L.ACT_NONE,
                                       mask=x.mask if (fuse and x.act == L.ACT_RELU) else None,
                                       accumulate=acc, amax_out=out_slot,
-                                      srcs=[(q["out"].grad, q["Wp"] if padded else q["W"].data, q.get("w_kn", 0),
+                                      srcs=[(q["out"].grad, cut(q["Wp"] if padded else q["W"].data), q.get("w_kn", 0),
                                              q["amax_dc"], q["amax_w"]) + ((pl, kx) if pl is not None else ())
                                             for q, (pl, kx) in zip(ch, gp)]))
             if fuse:

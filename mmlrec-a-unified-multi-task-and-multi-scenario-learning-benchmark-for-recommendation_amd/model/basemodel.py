@@ -288,6 +288,8 @@ class BaseModel(nn.Module):
         x0 = plan.val(len(sp) * E_dim + nd, needs_grad=training, name="dnn_input", pad_k=True,
                       store16=(plan.bf16 and par_ is None and mark_rows is None and E_dim % 4 == 0 and
                                self._dnn_input_store16(plan)))
+        if nd:
+            x0.grad_cols = len(sp) * E_dim  # the dense features' gradient has no reader (they are input data)
         tables = [store.pvals[f"embedding_dict.{f.embedding_name}.weight"] for f in sp]
         cols = [self.feature_index[f.name][0] for f in sp]
         par = getattr(self, "_parallel", None)

@@ -70,6 +70,16 @@ def run(torch, ops, lib, probs, M, panel, masks):
     (40064, 208, [64, 64], True),                        # one tile only; more panels than workgroups (uneven shares)
     (65536, 240, [256, 256, 256, 256, 64, 64], True),    # the benchmark's launch: two panels of nine tiles per workgroup
     (3 * 32768 + 128, 240, [128, 64, 64], False),        # three or four panels per workgroup
+    (65536, 304, [256, 256, 256, 256, 64, 64], True),    # AE-30 with the 63 dense columns (K0 = 303 zero-padded to 304)
+    (8192, 320, [128, 64, 64], True),                    # the longest reduction the registers hold
+    (8192, 176, [128, 128], True),                       # every k-block count between 10 and 20 is instantiated
+    (8192, 192, [64, 64], False),
+    (8192, 224, [128, 64, 64], True),
+    (8192, 256, [256, 128], True),
+    (8192, 272, [128, 128], False),
+    (8192, 288, [128, 64, 64], True),
+    (16384 + 77, 240, [256, 64, 64], True),              # ragged batch: whole panels here, the last 77 rows through the tile kernel
+    (8192 + 3, 304, [128, 128], False),
 ])
 def test_panel_fwd_matches_float64_and_the_tile_kernel(env, M, K, Ns, masks):
     torch, L, ops, lib = env
@@ -117,10 +127,11 @@ def test_panel_fwd_is_scale_invariant(env):
 def test_launches_the_panel_kernel_does_not_serve_fall_back(env):
     torch, L, ops, lib = env
     lib.mml_gemm_set_mode(4)
-    # K beyond the registers, a batch below the threshold, a sigmoid, a linear layer, a ragged last panel, an odd number of
-    # half tiles
-    for M, K, Ns, acts in ((8192, 256, [128], None), (4096, 240, [128], None), (8192, 240, [128], [L.ACT_SIGMOID]),
-                           (8192, 240, [128], [L.ACT_NONE]), (8192 + 77, 240, [128], None), (8192, 240, [192], None)):
+    # K beyond the registers, K below the ring's depth, a batch below the threshold (also after the ragged rows are taken
+    # off), a sigmoid, a linear layer, an odd number of half tiles
+    for M, K, Ns, acts in ((8192, 336, [128], None), (8192, 144, [128], None), (4096, 240, [128], None),
+                           (8192 + 77 - 128, 240, [128], None), (8192, 240, [128], [L.ACT_SIGMOID]),
+                           (8192, 240, [128], [L.ACT_NONE]), (8192, 240, [192], None)):
         A, probs, _ = make_launch(torch, L, ops, M, K, Ns, masks=False, acts=acts)
         name, out = run(torch, ops, lib, probs, M, True, False)
         assert "gemm_pipe_kernel" in name, (M, K, name)

@@ -53,6 +53,35 @@ def test_gather_bit_exact(ops, E, nd, B):
     assert np.array_equal(out2.cpu().numpy().view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("nd", [63, 62, 61, 5, 1])
+def test_gather_dense_pieces_into_padded_rows(ops, nd):
+    """The vectorised kernel moves the dense features four at a time; a row whose dense part is not a multiple of four
+    (AE: 63 columns, reference configs_msl/config_AE.json -> K0 = 303 in rows of 304) ends in scalar stores, and the
+    columns behind the row are not touched (engine.Val.kpad keeps them zero for the GEMM that reads the padded row)."""
+    import mmlrec_amd._lib as L_
+    rng = np.random.default_rng(nd)
+    E, B = 8, 3001
+    vocab = [3, 100, 5000, 70000, 2, 17]
+    F = len(vocab)
+    K0 = F * E + nd
+    ld = (K0 + 15) // 16 * 16
+    tabs = [rng.standard_normal((v, E)).astype(np.float32) for v in vocab]
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    X = np.concatenate([idx.astype(np.float32), (rng.random((B, nd), dtype=np.float32) - 0.5) * 100], 1)
+    ref = np.concatenate([tabs[f][idx[:, f]] for f in range(F)] + [X[:, F:]], 1)
+    dt, dX = [T(t) for t in tabs], T(X)
+    buf = torch.full((B + 1, ld), 12345.0, device=dev())
+    ops.gather_fwd(dt, dX, list(range(F)), F, nd, out=buf[:B, :K0])
+    assert L_.load().mml_gather_last_kernel().decode() == "gather_vec4_kernel"
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:B, :K0].view(np.uint32), ref.view(np.uint32))
+    assert (got[:B, K0:] == 12345.0).all() and (got[B] == 12345.0).all()
+    buf2 = torch.full((B + 1, ld), 12345.0, device=dev())
+    out2, wg = ops.gather_fwd_wgmax(dt, dX, list(range(F)), F, nd, out=buf2[:B, :K0])
+    assert torch.equal(buf2, buf)
+    assert not torch.isnan(wg).any() and float(wg.max()) == float(np.abs(ref).max())
+
+
 @pytest.mark.parametrize("E,nd,B", [(8, 0, 65536), (16, 4, 333), (8, 64, 4096)])
 def test_gather_workgroup_maxima(ops, E, nd, B):
     """mml_gather_fwd_wgmax: the same output bits, and per-workgroup maxima whose maximum IS the magnitude of the output
