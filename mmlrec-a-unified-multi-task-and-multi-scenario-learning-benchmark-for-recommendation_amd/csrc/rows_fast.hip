@@ -621,46 +621,105 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
       for (int i = 0; i < d.n_bias2; ++i) bias[t] += d.bias2[i];
     }
   }
-  for (int64_t it = 0; it < iters; ++it) {
-    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
-    const bool valid = b < g.B;
-    if (!valid) b = g.B - 1;
+  // U samples per lane group and trip: every load of the trip (U x n_heads rows, labels, masks) is issued before the
+  // first logit is formed.  One sample per trip (until round 5) left a wave with two 16-byte loads in flight in front of
+  // a chain of DPP sums, exp, log and log1p: 28 us for 67 MB at B = 65 536 (2.3 TB/s).  The samples of a lane group
+  // are visited in the same order as before: the partial sums of dw / dbias / loss are the same bits.
+  constexpr int U = NT <= 2 ? 4 : 2;
+  for (int64_t it0 = 0; it0 < iters; it0 += U) {
+    int64_t bb[U];
+    bool vld[U];
+    float4 hvu[U][NT];
+    float yu[U][NT], mu[U][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t >= g.n_heads) continue;
-      const mml_head_desc& d = g.head[t];
-      const bool col = 4 * sub < d.H;
-      const float4 hv = col ? ld4(d.Hin + b * d.ldh + 4 * sub) : make_float4(0, 0, 0, 0);
-      const float logit = group_sum<LPS>(dot4(hv, wv[t])) + bias[t];
-      const float p = 1.f / (1.f + expf(-logit));
-      const float m = (d.mask_col >= 0 && g.mask) ? g.mask[b * g.ldmask + d.mask_col] : 1.f;
-      const float pm = p * m;
-      if (valid && sub == 0) g.prob[b * g.ldprob + t] = pm;
-      if (aux.train) {
-        float dpm;
-        if (g.y) {
-          const float y = g.y[b * g.ldy + t];
-          const float lp = bce_log_clamp(logf(pm));
-          const float l1p = bce_log_clamp(log1pf(-pm));
-          if (valid && sub == 0) lossacc += -(y * lp + (1.f - y) * l1p);
-          dpm = (pm - y) / fmaxf((1.f - pm) * pm, 1e-12f);
-        } else {
-          dpm = g.dprob[b * g.lddprob + t];
+    for (int u = 0; u < U; ++u) {
+      bb[u] = (it0 + u) * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+      vld[u] = bb[u] < g.B;
+      if (!vld[u]) bb[u] = g.B - 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        hvu[u][t] = make_float4(0, 0, 0, 0);
+        yu[u][t] = 0.f;
+        mu[u][t] = 1.f;
+        if (t >= g.n_heads || it0 + u >= iters) continue;  // (a trip past the last one: uniform, nothing loaded)
+        const mml_head_desc& d = g.head[t];
+        if (4 * sub < d.H) hvu[u][t] = ld4(d.Hin + bb[u] * d.ldh + 4 * sub);
+        if (d.mask_col >= 0 && g.mask) mu[u][t] = g.mask[bb[u] * g.ldmask + d.mask_col];
+        if (aux.train) yu[u][t] = g.y ? g.y[bb[u] * g.ldy + t] : g.dprob[bb[u] * g.lddprob + t];
+      }
+    }
+    // the logits of the trip: after the lane-group sums every lane of a group holds all U x NT of them
+    constexpr int NI = U * NT;  // (<= 16 <= LPS)
+    float lg[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        lg[u][t] = (t < g.n_heads && it0 + u < iters) ? group_sum<LPS>(dot4(hvu[u][t], wv[t])) + bias[t] : 0.f;
+    // The per-sample scalar chain (sigmoid, the two clamped logarithms of the BCE, its derivative) ONCE per trip: lane
+    // j of a group takes item j = (u, t) of the trip instead of every lane repeating all NI chains -- the chain is ~150
+    // instructions with three transcendentals and two divisions, and it, not the 67 MB, was the kernel's time
+    // (28 us at B = 65 536 for AE-30's two heads, 92 us for PepNet's four).  Same instructions on the same values:
+    // probabilities, gradients and the dw / dbias sums are the bits of the former form; the loss is now summed per lane
+    // first (fixed order, deterministic).
+    const int j = sub & (NI - 1);
+    const int tj = j % NT;
+    float lgj = 0.f, mj = 1.f, yj = 0.f;
+    bool vj = false;
+    int64_t bj = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (j == u * NT + t) {
+          lgj = lg[u][t];
+          mj = mu[u][t];
+          yj = yu[u][t];
+          vj = vld[u] && t < g.n_heads && it0 + u < iters;
+          bj = bb[u];
         }
-        const float dlogit = valid ? dpm * m * p * (1.f - p) : 0.f;
-        if (sub == 0) dbacc[t] += dlogit;
-        if (col) {
-          fma4(dwacc[t], dlogit, hv);
-          float4 dh = make_float4(dlogit * wv[t].x, dlogit * wv[t].y, dlogit * wv[t].z, dlogit * wv[t].w);
-          if (d.h_relu) {
-            if (!(hv.x > 0.f)) dh.x = 0.f;
-            if (!(hv.y > 0.f)) dh.y = 0.f;
-            if (!(hv.z > 0.f)) dh.z = 0.f;
-            if (!(hv.w > 0.f)) dh.w = 0.f;
-          }
-          if (valid) {
-            st4o(d.dH, b * d.lddh + 4 * sub, dh, g.dh_bf16 != 0);
-            amax_acc(am_dh, dh);
+    const bool own = vj && sub < NI;
+    const float pj = 1.f / (1.f + expf(-lgj));
+    const float pmj = pj * mj;
+    if (own) g.prob[bj * g.ldprob + tj] = pmj;
+    float dlj = 0.f;
+    if (aux.train) {
+      float dpm;
+      if (g.y) {
+        const float lp = bce_log_clamp(logf(pmj));
+        const float l1p = bce_log_clamp(log1pf(-pmj));
+        if (own) lossacc += -(yj * lp + (1.f - yj) * l1p);
+        dpm = (pmj - yj) / fmaxf((1.f - pmj) * pmj, 1e-12f);
+      } else {
+        dpm = yj;
+      }
+      dlj = vj ? dpm * mj * pj * (1.f - pj) : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (it0 + u >= iters) break;
+        const int64_t b = bb[u];
+        const bool valid = vld[u];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t >= g.n_heads) continue;
+          const mml_head_desc& d = g.head[t];
+          const bool col = 4 * sub < d.H;
+          const float4 hv = hvu[u][t];
+          const float dlogit = __shfl(dlj, (lane & ~(LPS - 1)) + u * NT + t, 64);
+          if (sub == 0) dbacc[t] += dlogit;
+          if (col) {
+            fma4(dwacc[t], dlogit, hv);
+            float4 dh = make_float4(dlogit * wv[t].x, dlogit * wv[t].y, dlogit * wv[t].z, dlogit * wv[t].w);
+            if (d.h_relu) {
+              if (!(hv.x > 0.f)) dh.x = 0.f;
+              if (!(hv.y > 0.f)) dh.y = 0.f;
+              if (!(hv.z > 0.f)) dh.z = 0.f;
+              if (!(hv.w > 0.f)) dh.w = 0.f;
+            }
+            if (valid) {
+              st4o(d.dH, b * d.lddh + 4 * sub, dh, g.dh_bf16 != 0);
+              amax_acc(am_dh, dh);
+            }
           }
         }
       }
@@ -686,7 +745,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
       if (sub == 0) red[wave][t * PH + 4 * LPS] = db;
     }
   }
-  const float ls = cross_group_sum<LPS>(lossacc);
+  const float ls = cross_group_sum<LPS>(group_sum<LPS>(lossacc));
   if (lane == 0) red[wave][NT * PH] = ls;
   __syncthreads();
   float* out = aux.slab + (int64_t)blockIdx.x * aux.stride;

@@ -148,7 +148,10 @@ class TrainStep:
         # every weight-gradient GEMM of the step in one launch: at small batches (a layer's launch does not fill the chip)
         # and whenever no table stream runs beside them (same-box A/B at B = 65 536: lazy_exact 1.677 -> 1.628 ms, but
         # dense_exact 1.94 -> 1.98: next to the dense table update the per-layer order shares the chip better)
-        self.wgrad_merged = (int(B) <= 8192 or self.opt.table_update != "dense_exact") and \
+        # Round 5, ONE stream (no table update beside the weight gradients): merged at every batch -- the per-layer
+        # launches of a large batch do not all fill the chip either (AE-30's tower layers: 2 tiles x 64 slabs = 128
+        # workgroups for 512 slots), and one reduction over 17 slabs replaces three over 25 / 64 / 64.
+        self.wgrad_merged = (int(B) <= 8192 or self.opt.table_update != "dense_exact" or not overlap) and \
             os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0" and self.plan.merge_wgrad()
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
