@@ -266,7 +266,7 @@ def roofline_of(acc):
             planes = int(m.group(1))
         elif name.startswith("g16_"):  # bf16-storage kernels (csrc/gemm16.hip): one bf16 MFMA per product block
             planes = 1
-        elif name.startswith(("gemm_ws_kernel", "gemm_panel_kernel", "gemm_nt_kernel")):
+        elif name.startswith(("gemm_ws_kernel", "gemm_panel_kernel", "gemm_nt_kernel", "gemm_os_kernel")):
             # the weight-stationary / activation-stationary kernels issue the same three f16 MFMAs per product block as
             # gemm_pipe_kernel<..., 2, ...> (csrc/gemm_ws.hip, csrc/gemm_panel.hip), one per block in the bf16 forms
             planes = 2

@@ -16,8 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 GEMM_SOURCES = ("gemm.hip",)  # kernels with hand-counted waits: resource / assembly checks below
 # also order their LDS-DMA rings with compile-time counted s_waitcnt vmcnt(N) (gemm_panel.hip: pn_younger counts the
 # epilogue stores of each piece): a spill would add scratch VMEM operations to the count -> resource report checked too
-COUNTED_WAIT_SOURCES = GEMM_SOURCES + ("gemm_panel.hip", "gemm_ws.hip")
-COUNTED_WAIT_KERNELS = ("gemm_pipe_kernel", "gemm_panel_kernel", "gemm_ws_kernel")
+COUNTED_WAIT_SOURCES = GEMM_SOURCES + ("gemm_panel.hip", "gemm_ws.hip", "gemm_os.hip")
+COUNTED_WAIT_KERNELS = ("gemm_pipe_kernel", "gemm_panel_kernel", "gemm_ws_kernel", "gemm_os_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 if os.environ.get("MMLREC_BUILD_NTSTORE") == "1":  # nontemporal output stores of the tile kernel's epilogue (csrc/gemm.hip)

@@ -2045,10 +2045,19 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
   return MML_OK;
 }
 
+// gemm_os.hip: the output-stationary kernel for ONE wide input gradient summed over many sources (d(dnn_input): every
+// expert's and gate's first layer feeds it)
+int mml_gemm_os_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t st);
+
 extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_dgrad: bad descriptor array");
   if (n > 0 && gemm_mode() >= 2 && gemm_mode() != 3) {
-    const int rc = mml_gemm_ws_try_dgrad(d, n, to_stream(stream));
+    int rc = mml_gemm_os_try_dgrad(d, n, to_stream(stream));
+    if (rc != MML_ERR_UNSUPPORTED) {
+      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_os_kernel");
+      return rc;
+    }
+    rc = mml_gemm_ws_try_dgrad(d, n, to_stream(stream));
     if (rc != MML_ERR_UNSUPPORTED) {
       if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_ws_kernel");
       return rc;

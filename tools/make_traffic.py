@@ -26,6 +26,7 @@ def label(kernel_name, avg_bytes_hint=0):
                  ("head_fast_kernel", "head_kernel"),
                  ("opt_flat_kernel", "opt_flat_kernel"),
                  ("gemm_nt_kernel", "gemm_nt_kernel"), ("nt_reduce_kernel", "slab_reduce"),
+                 ("gemm_os_kernel", "gemm_os_kernel"),
                  ("slab_reduce", "slab_reduce")):
         if k.startswith(a):
             return b
