@@ -186,6 +186,22 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
   const int64_t iters = (g.B + stride - 1) / stride;
   const bool hcol = 4 * sub < g.H;
   float am_mix = 0.f;
+  // The rows of trip it + 1 are requested before trip it is worked on (round 5): a trip is a chain of a global load, two
+  // LDS round trips, the softmax and the stores -- 11 us per trip at B = 65 536 with six workgroups per CU, and a wave had
+  // nothing in flight while it worked through it.
+  float4 Evn[NE], Gvn[NG];
+  auto request = [&](const int64_t it) __attribute__((always_inline)) {
+    int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
+    if (b >= g.B) b = g.B - 1;
+#pragma unroll
+    for (int x = 0; x < NE; ++x)
+      Evn[x] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+      Gvn[gi] = (gi < g.n_gates && 4 * sub < g.gate[gi].Gd) ? ld4(g.gate[gi].G + b * g.gate[gi].ldg + 4 * sub)
+                                                             : make_float4(0, 0, 0, 0);
+  };
+  if (iters > 0) request(0);
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -193,12 +209,10 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
     for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
     float4 Ev[NE], Gv[NG];
 #pragma unroll
-    for (int x = 0; x < NE; ++x)
-      Ev[x] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+    for (int x = 0; x < NE; ++x) Ev[x] = Evn[x];
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi)
-      Gv[gi] = (gi < g.n_gates && 4 * sub < g.gate[gi].Gd) ? ld4(g.gate[gi].G + b * g.gate[gi].ldg + 4 * sub)
-                                                            : make_float4(0, 0, 0, 0);
+    for (int gi = 0; gi < NG; ++gi) Gv[gi] = Gvn[gi];
+    if (it + 1 < iters) request(it + 1);
     __builtin_amdgcn_wave_barrier();  // coef zeroed before the scattered writes below
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -303,6 +317,8 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 
   if constexpr (MODE == 1) {
   // every gate mixes experts 0..ne-1 in order (MMoE): one set of expert rows serves all gates and the final dE loop
+  // (requesting the next trip's rows ahead, as the forward kernel does, costs 47 more VGPRs here -- 165, three waves per
+  // SIMD: 92.7 us with two workgroups per CU, 96.6 with three, 110.6 with four, against 95.6 without it: not taken)
   for (int64_t it = 0; it < iters; ++it) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     const bool valid = b < g.B;
@@ -809,12 +825,18 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
   static int fwd_per_cu = -1;
   if (fwd_per_cu < 0) {
     const char* e = getenv("MMLREC_GATE_FWD_WGS");
-    fwd_per_cu = e ? atoi(e) : 6;
+    fwd_per_cu = e ? atoi(e) : 4;
   }
-  // the forward kernel writes no per-workgroup partials; since it tracks the magnitude of its output it holds 73-94
-  // VGPRs (five or six waves per SIMD), so six workgroups per CU are ONE round of resident workgroups (eight were a round
-  // and a third: 67-68 us against 64 at B = 65 536 on AE-30; twelve 72)
-  aux.grid = fast_row_grid(g->B, aux.lps, bwd ? 4 : fwd_per_cu);
+  // the forward kernel writes no per-workgroup partials.  Round 5: with the next trip's rows requested ahead (91 VGPRs for
+  // MMoE's 4 experts x 2 gates) FOUR workgroups per CU are the best grid -- AE-30 at B = 65 536, device time of the call:
+  // 45.7 us (5.2 TB/s of its own bytes) against 48.4 with five, 54.5 with six, 52.8 with eight; before the prefetch six
+  // were one round of resident workgroups (64 us; eight 67-68, twelve 72).
+  static int bwd_per_cu = -1;
+  if (bwd_per_cu < 0) {
+    const char* e = getenv("MMLREC_GATE_BWD_WGS");
+    bwd_per_cu = e ? atoi(e) : 4;
+  }
+  aux.grid = fast_row_grid(g->B, aux.lps, bwd ? bwd_per_cu : fwd_per_cu);
   return aux.lps;
 }
 
@@ -912,7 +934,15 @@ int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux&
   aux.lps = pick_lps(hmax);
   aux.nt = g->n_heads <= 2 ? 2 : (g->n_heads <= 4 ? 4 : 8);
   aux.hmax = hmax;
-  aux.grid = fast_row_grid(g->B, aux.lps);
+  static int head_per_cu = -1;
+  if (head_per_cu < 0) {
+    const char* e = getenv("MMLREC_HEAD_WGS");
+    head_per_cu = e ? atoi(e) : 2;
+  }
+  // (two workgroups per CU since the trips hold U samples per lane group: the call -- kernel + the reduction of one
+  // partial row per workgroup -- takes 29.4 us on AE-30 / 77.9 on PepNet at B = 65 536 against 34.3 / 83.0 with four,
+  // 47.8 / 84.0 with eight, 31.5 / 104.8 with one)
+  aux.grid = fast_row_grid(g->B, aux.lps, head_per_cu);
   return aux.lps;
 }
 

@@ -527,41 +527,58 @@ class Plan:
             if c[1][4] == 1:  # the partial-product phase carries the problems (phase 2 repeats them)
                 groups.append([c[1][0][k] for k in range(c[1][1])])
                 descs += groups[-1]
+        chunks = [descs]  # (small batches: ONE call, the library splits it into groups of MML_MAX_GROUP for the tile kernel)
         if self.B >= 16384:
-            if len(descs) > L.MAX_GROUP:  # (one grouped launch: beyond it the library would split the call again)
-                return False
             # Large batches (gemm_nt_kernel: 128 x 128 output tiles, the batch cut into `slabs` pieces so that tiles x
-            # slabs fill the chip's 512 workgroup slots once): merge when one launch over every tile takes fewer batch
-            # steps than the per-layer launches together, a launch + reduction pair priced at ~8 steps.  AE-30: 20 / 8 /
-            # 2 tiles -> 82 + 32 + 32 steps per layer against 121 merged (measured 1.65 -> 1.565 ms); KuaiRec-32: 72 /
-            # 32 / 4 tiles -> 293 + 128 + 32 against 512 merged (108 tiles x 4 slabs leave 80 slots idle: 3.33 -> 3.38 ms
-            # merged, so it stays per layer).
+            # slabs fill the chip's 512 workgroup slots once; at most MML_MAX_GROUP problems per launch): merge when the
+            # merged launches take fewer batch steps than the per-layer launches together, a launch + reduction pair
+            # priced at ~8 steps.  AE-30: 20 / 8 / 2 tiles -> 82 + 32 + 32 steps per layer against 121 merged (measured
+            # 1.65 -> 1.565 ms); KuaiRec-32: 72 / 32 / 4 tiles -> 293 + 128 + 32 against 512 merged (108 tiles x 4 slabs
+            # leave 80 slots idle: 3.33 -> 3.38 ms merged, so it stays per layer); PepNet's 40-odd small problems go
+            # into launches of 16 (2.21 -> 2.13 ms already as ONE call that fell to the tile kernel).
             steps = self.B // 32
+            # (what gemm_nt_kernel takes -- csrc/gemm_nt.hip, mml_gemm_nt_try_wgrad -- goes together: ONE problem it does
+            # not take, e.g. a final layer with a single output row, would send its whole launch to the tile kernel)
+            fits = [d for d in descs if d.N % 32 == 0 and d.K % 4 == 0 and not d.w_kn and d.amax_dc and d.amax_a]
+            other = [d for d in descs if not (d.N % 32 == 0 and d.K % 4 == 0 and not d.w_kn and d.amax_dc and d.amax_a)]
+            chunks = []
+            for part in (fits, other):
+                if part:
+                    nch = -(-len(part) // L.MAX_GROUP)
+                    per = -(-len(part) // nch)
+                    chunks += [part[i:i + per] for i in range(0, len(part), per)]
 
             def cost(tiles):
                 sl = max(1, min(512 // max(tiles, 1), steps // 8, 64))
                 return -(-steps // sl) * -(-tiles * sl // 512) + 8
 
-            tl = [sum(-(-d.N // 128) * -(-d.K // 128) for d in g) for g in groups]
-            if cost(sum(tl)) >= sum(cost(t) for t in tl):
+            def tiles_of(g):
+                return sum(-(-d.N // 128) * -(-d.K // 128) for d in g)
+
+            if sum(cost(tiles_of(g)) for g in chunks) >= sum(cost(tiles_of(g)) for g in groups):
                 return False
         targets = [d.dW for d in descs] + [d.dbias for d in descs if d.dbias]
         if len(set(targets)) != len(targets) or any(d.accumulate for d in descs):
             return False
-        arr = (L.GemmWgradDesc * len(descs))()
-        for k, d in enumerate(descs):
-            C.memmove(C.byref(arr[k]), C.byref(d), C.sizeof(L.GemmWgradDesc))
-        nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(descs))
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        self.keep += [arr, ws]
         flops = sum(self.bwd_side[i][2].get("flops", 0.0) for i in idx)
         hbm = sum(self.bwd_side[i][2].get("hbm_bytes", 0.0) for i in idx)
-        merged = [(fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 1),
-                   dict(kernel=_gemm_symbol(False, False, [], 2), flops=flops, hbm_bytes=hbm, side=True, rank=0)),
-                  (fn, (arr, len(descs), ws.data_ptr(), ws.numel(), 2),
-                   dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1))]
+        merged, reduces = [], []
+        for ch in chunks:
+            arr = (L.GemmWgradDesc * len(ch))()
+            for k, d in enumerate(ch):
+                C.memmove(C.byref(arr[k]), C.byref(d), C.sizeof(L.GemmWgradDesc))
+            nbytes = lib.mml_gemm_grouped_wgrad_workspace_bytes(arr, len(ch))
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.keep += [arr, ws]
+            share = len(ch) / float(len(descs))
+            merged.append((fn, (arr, len(ch), ws.data_ptr(), ws.numel(), 1),
+                           dict(kernel=_gemm_symbol(False, False, [], 2), flops=flops * share, hbm_bytes=hbm * share,
+                                side=True, rank=0)))
+            reduces.append((fn, (arr, len(ch), ws.data_ptr(), ws.numel(), 2),
+                            dict(kernel="slab_reduce", bytes=float(nbytes), side=True, rank=1)))
         rest = [c for i, c in enumerate(self.bwd_side) if i not in set(idx)]  # (un-padding copies: after the reduction)
-        self.bwd_side = merged + rest
+        # (each reduction right behind its launch: the next launch's first tiles start beside it)
+        self.bwd_side = [c for pair in zip(merged, reduces) for c in pair] + rest
         return True
 
     def _flat_numel(self, v):
