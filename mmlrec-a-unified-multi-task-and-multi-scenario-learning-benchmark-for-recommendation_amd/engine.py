@@ -581,6 +581,59 @@ class Plan:
         self.bwd_side = [c for pair in zip(merged, reduces) for c in pair] + rest
         return True
 
+    def merge_wgrad16(self):
+        """bf16-storage path (csrc/gemm16.hip: mml_g16_wgrad, at most G16_MAX_GROUP problems per launch, 128 x 128 tiles
+        of 64-row steps, at most 32 slabs): neighbouring weight-gradient launches go together where the tile model says
+        the merged launch takes fewer steps -- KuaiRec-32: towers (4 tiles -> 128 workgroups for 512 slots) + second
+        expert layers (32 tiles) as one launch of 36 tiles."""
+        lib = L.load()
+        fn = lib.mml_g16_wgrad
+        idx = [i for i, c in enumerate(self.bwd_side) if c[0] is fn and c[1][4] == 1]
+        if len(idx) < 2 or any(self.bwd_side[i + 1][0] is not fn or self.bwd_side[i + 1][1][4] != 2 for i in idx):
+            return False
+        steps = max(self.B // 64, 1)
+
+        def cost(g):
+            tiles = sum((d.N // 128) * (d.K // 128) for d in g)
+            sl = max(1, min(512 // max(tiles, 1), steps // 4, 32))
+            return -(-steps // sl) * -(-tiles * sl // 512) + 8
+
+        groups = [[self.bwd_side[i][1][0][k] for k in range(self.bwd_side[i][1][1])] for i in idx]
+        metas = [self.bwd_side[i][2] for i in idx]
+        out, om = [groups[0]], [dict(metas[0])]
+        for g, m in zip(groups[1:], metas[1:]):
+            cur = out[-1]
+            tg = [d.dW for d in cur + g] + [d.dbias for d in cur + g if d.dbias]
+            if (len(cur) + len(g) <= L.G16_MAX_GROUP and cost(cur + g) < cost(cur) + cost(g) and
+                    len(set(tg)) == len(tg) and not any(d.accumulate for d in cur + g)):
+                out[-1] = cur + g
+                for k in ("flops", "hbm_bytes"):
+                    om[-1][k] = om[-1].get(k, 0.0) + m.get(k, 0.0)
+            else:
+                out.append(g)
+                om.append(dict(m))
+        if len(out) == len(groups):
+            return False
+        calls = []
+        for g, m in zip(out, om):
+            arr = (L.G16WgradDesc * len(g))()
+            for k, d in enumerate(g):
+                C.memmove(C.byref(arr[k]), C.byref(d), C.sizeof(L.G16WgradDesc))
+            nbytes = int(lib.mml_g16_wgrad_workspace_bytes(arr, len(g)))
+            if nbytes < 0:
+                L.check(-1, "mml_g16_wgrad_workspace_bytes")
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self.keep += [arr, ws]
+            m["kernel"] = "g16_nt_kernel(wgrad %d problems)" % len(g)
+            calls.append((fn, (arr, len(g), ws.data_ptr(), ws.numel(), 1), m))
+            calls.append((fn, (arr, len(g), ws.data_ptr(), ws.numel(), 2),
+                          dict(kernel="g16_reduce_kernel", bytes=float(nbytes), side=True, rank=1)))
+        drop = set(idx) | {i + 1 for i in idx}
+        first = idx[0]
+        self.bwd_side = ([c for i, c in enumerate(self.bwd_side) if i < first and i not in drop] + calls +
+                         [c for i, c in enumerate(self.bwd_side) if i > first and i not in drop])
+        return True
+
     def _flat_numel(self, v):
         # act_bwd is a flat kernel: value and gradient must share the padded pitch (they do by construction)
         if v.buf.stride(0) != v.grad.stride(0):

@@ -153,6 +153,8 @@ class TrainStep:
         # workgroups for 512 slots), and one reduction over 17 slabs replaces three over 25 / 64 / 64.
         self.wgrad_merged = (int(B) <= 8192 or self.opt.table_update != "dense_exact" or not overlap) and \
             os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0" and self.plan.merge_wgrad()
+        if not overlap and os.environ.get("MMLREC_MERGE_WGRAD", "1") != "0":
+            self.plan.merge_wgrad16()  # (the bf16-storage path's launches: csrc/gemm16.hip)
         self.opt_split = self.opt.calls_split(self.plan, split_dense=split)
         self.split_dense = bool(self.opt_split["early"])
         self.opt_calls = (self.opt_split["pre"] + self.opt_split["early"] + self.opt_split["mlp"] +
