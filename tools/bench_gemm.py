@@ -117,7 +117,7 @@ def main():
         if os.environ.get("FWD_ONLY") == "1":
             continue
         t = timeit(lambda: ops.gemm_wgrad(probs_w))
-        print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s")
+        print(f"{name:22s} wgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s   [{L.load().mml_gemm_last_kernel().decode()}]")
         K0 = shapes[0][1]
         if name.startswith("L2"):  # one dgrad problem per expert (single source each), as the step runs them
             pd = [dict(dA=torch.empty(M, K0, device=dev), Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx_p(p)],
@@ -126,11 +126,14 @@ def main():
             print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {flops / t / 1e9:7.1f} TFLOP/s  (one problem per expert)")
         elif all(k == K0 for _, k in shapes):
             dA = torch.empty(M, K0, device=dev)
-            pd = [dict(dA=dA, Y=A[K0], act=L.ACT_RELU, srcs=[(p["C"], p["W"], 0) + amx_p(p) for p in probs_f[:8]],
+            # (the first layers' input is dnn_input: no activation derivative in its gradient, as in the step)
+            first = name.startswith("L1")
+            pd = [dict(dA=dA, Y=None if first else A[K0], act=L.ACT_NONE if first else L.ACT_RELU,
+                       srcs=[(p["C"], p["W"], 0) + amx_p(p) for p in probs_f[:8]],
                        amax_out=ops.amax_slots(1, dev)[0] if AOUT else None)]
             fl = sum(2.0 * M * n * k for n, k in shapes[:8])
             t = timeit(lambda: ops.gemm_dgrad(pd))
-            print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s")
+            print(f"{name:22s} dgrad {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s   [{L.load().mml_gemm_last_kernel().decode()}]")
 
 
 if __name__ == "__main__":
