@@ -548,6 +548,20 @@ int mml_head_bce_fwd_bwd(const mml_head_group* grp, void* workspace, int64_t wor
  * partial sums into dw / dbias / loss (phase 0 = both); see mml_gate_mix_bwd_phase. */
 int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
                                mml_stream_t stream);
+/* The reductions (phase 2) of several head / gate groups in ONE launch (round 5): items[i] names a group whose phase 1 has
+ * run into `workspace`; the result is what the phase-2 calls give one by one (dw / dbias / loss of a head group, dWg of a
+ * gate group) -- in the last bits it may differ where the merged list is long enough for another reduction kernel (the
+ * order of the partial sums is fixed either way).  At most 40 result tensors per call. */
+#define MML_ROWS_REDUCE_HEAD 0
+#define MML_ROWS_REDUCE_GATE 1
+typedef struct {
+  int32_t kind; /* MML_ROWS_REDUCE_HEAD: group = const mml_head_group*; MML_ROWS_REDUCE_GATE: const mml_gate_group* */
+  int32_t pad_;
+  const void* group;
+  void* workspace;
+  int64_t workspace_bytes;
+} mml_rows_reduce_item;
+int mml_rows_reduce_batch(const mml_rows_reduce_item* items, int32_t n, mml_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3'  bf16-STORAGE GEMM family (round 5; csrc/gemm16.hip) -- BASELINE.json configs[1] ("MMoE ... KuaiRec-shaped ...

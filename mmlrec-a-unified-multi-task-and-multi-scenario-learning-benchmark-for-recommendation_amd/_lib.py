@@ -71,6 +71,13 @@ class G16WgradDesc(C.Structure):
 
 
 G16_MAX_GROUP = 8
+
+
+class RowsReduceItem(C.Structure):
+    _fields_ = [("kind", i32), ("pad_", i32), ("group", fp), ("workspace", fp), ("workspace_bytes", i64)]
+
+
+ROWS_REDUCE_HEAD, ROWS_REDUCE_GATE = 0, 1
 GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16, GATE_E_BF16 = 1, 2, 4, 8
 
 
@@ -188,6 +195,7 @@ _SIGS = {
     "mml_head_fwd": (C.c_int, [_PP(HeadGroup), fp]),
     "mml_head_bce_fwd_bwd": (C.c_int, [_PP(HeadGroup), fp, i64, fp]),
     "mml_head_bce_fwd_bwd_phase": (C.c_int, [_PP(HeadGroup), fp, i64, i32, fp]),
+    "mml_rows_reduce_batch": (C.c_int, [_PP(RowsReduceItem), i32, fp]),
     "mml_ew_mul": (C.c_int, [fp, fp, fp, i64, fp]),
     "mml_ew_mul_bwd": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, fp]),
     "mml_ew_mul_bwd_act": (C.c_int, [fp, fp, fp, fp, fp, i32, i32, i64, i32, i32, fp]),

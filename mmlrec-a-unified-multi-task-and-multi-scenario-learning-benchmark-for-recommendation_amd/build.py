@@ -20,6 +20,8 @@ COUNTED_WAIT_SOURCES = GEMM_SOURCES + ("gemm_panel.hip", "gemm_ws.hip", "gemm_os
 COUNTED_WAIT_KERNELS = ("gemm_pipe_kernel", "gemm_panel_kernel", "gemm_ws_kernel", "gemm_os_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
+if os.environ.get("MMLREC_BUILD_OS_LAB") == "1":  # the parts-switched-off variants of gemm_os_kernel (tools/lab/os_lab.sh)
+    FLAGS.append("-DMML_OS_LAB")
 if os.environ.get("MMLREC_BUILD_NTSTORE") == "1":  # nontemporal output stores of the tile kernel's epilogue (csrc/gemm.hip)
     FLAGS.append("-DMML_GEMM_NTSTORE")
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ void os_wait_vm(const int n) {  // n in {0, 2, 4, 6}
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// LAB (tools/lab/os_lab.sh, MMLREC_OS_LAB): 1 no MFMAs, 2 no cut, 4 no weight fragment reads, 8 no gradient fragment reads,
+// LAB (lab builds only, -DMML_OS_LAB: tools/lab/os_lab.sh, MMLREC_OS_LAB): 1 no MFMAs, 2 no cut, 4 no weight fragment reads, 8 no gradient fragment reads,
 // 16 no DMA / waits, 32 no barrier (all give garbage results)
 template <int LAB>
 __global__ __launch_bounds__(512, 1) void gemm_os_kernel(const OsLaunch Larg) {
@@ -423,6 +423,7 @@ int mml_gemm_os_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
   }
   const int npanels = (int)cdiv(L.M, OS_BM);
   const dim3 grid((unsigned)(npanels < cus ? npanels : cus)), block(512);
+#ifdef MML_OS_LAB  // lab build only (MMLREC_BUILD_OS_LAB=1 python -m ...build; tools/lab/os_lab.sh): garbage-result variants
   const char* lab = getenv("MMLREC_OS_LAB");
   switch (lab ? atoi(lab) : 0) {
     case 1: MML_LAUNCH(gemm_os_kernel<1>, grid, block, 0, st, L); break;
@@ -438,5 +439,8 @@ int mml_gemm_os_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
     case 15: MML_LAUNCH(gemm_os_kernel<15>, grid, block, 0, st, L); break;
     default: MML_LAUNCH(gemm_os_kernel<0>, grid, block, 0, st, L); break;
   }
+#else
+  MML_LAUNCH(gemm_os_kernel<0>, grid, block, 0, st, L);
+#endif
   return check_launch("mml_gemm_grouped_dgrad(os)");
 }

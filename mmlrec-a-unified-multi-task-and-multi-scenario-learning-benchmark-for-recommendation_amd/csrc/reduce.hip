@@ -98,8 +98,25 @@ __global__ __launch_bounds__(1024) void slab_reduce_block_kernel(const ReduceLau
   }
 }
 
+static thread_local ReduceLaunch* g_collect = nullptr;
+void reduce_collect(ReduceLaunch* into) { g_collect = into; }
+
 int launch_slab_reduce(const ReduceLaunch& R, hipStream_t st, const char* who) {
   if (R.total <= 0) return MML_OK;
+  if (g_collect) {
+    ReduceLaunch& C = *g_collect;
+    if (C.n + R.n > MAX_REDUCE_SEGS) {
+      set_error("%s: more than %d reduction segments in one batch", who, MAX_REDUCE_SEGS);
+      return MML_ERR_ARG;
+    }
+    for (int i = 0; i < R.n; ++i) {
+      C.seg[C.n] = R.seg[i];
+      C.seg[C.n].start += C.total;
+      ++C.n;
+    }
+    C.total += R.total;
+    return MML_OK;
+  }
   int maxS = 0;
   for (int i = 0; i < R.n; ++i)
     if (R.seg[i].S > maxS) maxS = R.seg[i].S;

@@ -26,5 +26,8 @@ struct ReduceLaunch {
 };
 
 int launch_slab_reduce(const ReduceLaunch& R, hipStream_t st, const char* who);
+// mml_rows_reduce_batch: while a collector is set (this thread), launch_slab_reduce appends the segments it is given to the
+// collector instead of launching them; the batch entry launches the collected list once.
+void reduce_collect(ReduceLaunch* into);
 
 }  // namespace mml

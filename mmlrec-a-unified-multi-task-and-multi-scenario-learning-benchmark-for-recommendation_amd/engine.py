@@ -581,6 +581,29 @@ class Plan:
         self.bwd_side = [c for pair in zip(merged, reduces) for c in pair] + rest
         return True
 
+    def merge_row_reduces(self):
+        """The deferred reductions of the head / gate kernels' partial sums (`head_side`, and the gate groups' entries of
+        `bwd_side`: only the optimizer and the host read their results) as ONE launch in front of the weight gradients."""
+        lib = L.load()
+        fh, fg = lib.mml_head_bce_fwd_bwd_phase, lib.mml_gate_mix_bwd_phase
+        is_red = lambda c: c[0] in (fh, fg) and c[1][3] == 2  # noqa: E731
+        picked = [c for c in list(self.head_side) + list(self.bwd_side) if is_red(c)]
+        if len(picked) < 2:
+            return False
+        items = (L.RowsReduceItem * len(picked))()
+        for it, c in zip(items, picked):
+            grp, ws, nbytes, _ = c[1]
+            it.kind = L.ROWS_REDUCE_HEAD if c[0] is fh else L.ROWS_REDUCE_GATE
+            it.group = C.addressof(grp._obj)  # (the ops pass C.byref(group); the group itself lives in plan.keep)
+            it.workspace, it.workspace_bytes = ws, nbytes
+        self.keep.append(items)
+        call = (lib.mml_rows_reduce_batch, (items, len(picked)),
+                dict(kernel="slab_reduce", bytes=sum(c[2].get("bytes", 0.0) for c in picked), side=True, rank=1,
+                     ready=max(c[2].get("ready", 0) for c in picked)))
+        self.head_side = [c for c in self.head_side if not is_red(c)]
+        self.bwd_side = [call] + [c for c in self.bwd_side if not is_red(c)]
+        return True
+
     def merge_wgrad16(self):
         """bf16-storage path (csrc/gemm16.hip: mml_g16_wgrad, at most G16_MAX_GROUP problems per launch, 128 x 128 tiles
         of 64-row steps, at most 32 slabs): neighbouring weight-gradient launches go together where the tile model says
@@ -1312,13 +1335,21 @@ class GateGroupOp(Op):
                  dict(kernel="gate_bwd_kernel", bytes=byts))]
 
 
+_DEFER = None  # set by trainer.TrainStep around the recording of its plan (one stream: True)
+
+
 def _defer_reduce():
     """MMLREC_DEFER_REDUCE=1: the reductions of the gate / head kernels' partial sums (only the optimizer reads their
     results) leave the backward chain and run beside the weight-gradient GEMMs (mml_gate_mix_bwd_phase,
     mml_head_bce_fwd_bwd_phase).  Off by default: two launches fewer on the chain (-18 us in a serial trace of the AE-30
     step), but the two-stream step measured 1.702 against 1.666 ms with it (three interleaved pairs, round 4) -- the step
     is bound by what its kernels take from HBM and the CUs together, not by the length of the chain."""
-    return os.environ.get("MMLREC_DEFER_REDUCE", "0") == "1"
+    e = os.environ.get("MMLREC_DEFER_REDUCE")
+    if e is not None:
+        return e == "1"
+    # Round 5, ONE stream: deferred, and Plan.merge_row_reduces turns the deferred reductions of a step into ONE launch
+    # (mml_rows_reduce_batch): MMoE one launch fewer per step, a PLE of two levels two.
+    return bool(_DEFER)
 
 
 class HeadOp(Op):

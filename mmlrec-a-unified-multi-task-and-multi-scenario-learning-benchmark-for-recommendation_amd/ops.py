@@ -602,6 +602,31 @@ def head_bce_fwd_bwd(group, device, phases=False):
     L.check(lib.mml_head_bce_fwd_bwd(C.byref(group), ws.data_ptr(), ws.numel(), _stream()), "mml_head_bce_fwd_bwd")
 
 
+def rows_phase1_then_batched_reduce(head_groups, gate_groups, device):
+    """The row kernels of the given head / gate groups (phase 1, each into a workspace of its own), then ALL their
+    reductions in one launch (include/mmlrec.h: mml_rows_reduce_batch)."""
+    lib = L.load()
+    items = (L.RowsReduceItem * (len(head_groups) + len(gate_groups)))()
+    keep, k = [], 0
+    for kind, groups in ((L.ROWS_REDUCE_HEAD, head_groups), (L.ROWS_REDUCE_GATE, gate_groups)):
+        for g in groups:
+            if kind == L.ROWS_REDUCE_HEAD:
+                ws = torch.empty(max(int(lib.mml_head_workspace_bytes(C.byref(g))), 256), dtype=torch.uint8, device=device)
+                L.check(lib.mml_head_bce_fwd_bwd_phase(C.byref(g), ws.data_ptr(), ws.numel(), 1, _stream()),
+                        "mml_head_bce_fwd_bwd_phase")
+            else:
+                ws = torch.empty(max(int(lib.mml_gate_mix_bwd_workspace_bytes(C.byref(g))), 256), dtype=torch.uint8,
+                                 device=device)
+                L.check(lib.mml_gate_mix_bwd_phase(C.byref(g), ws.data_ptr(), ws.numel(), 1, _stream()),
+                        "mml_gate_mix_bwd_phase")
+            keep.append(ws)
+            items[k].kind, items[k].group = kind, C.addressof(g)
+            items[k].workspace, items[k].workspace_bytes = ws.data_ptr(), ws.numel()
+            k += 1
+    L.check(lib.mml_rows_reduce_batch(items, k, _stream()), "mml_rows_reduce_batch")
+    return keep
+
+
 # ---------------------------------------------------------------------------------------------- K6/K7
 def ew_mul(a, b, out):
     L.check(L.load().mml_ew_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), _stream()), "mml_ew_mul")

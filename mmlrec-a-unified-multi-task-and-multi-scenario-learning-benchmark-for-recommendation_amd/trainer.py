@@ -141,9 +141,19 @@ class TrainStep:
         marked = (self.opt.table_update == "dense_exact" and not split and
                   (par is None or par.mode in ("row_sharded", "replicated")) and
                   os.environ.get("MMLREC_GRAD_MARKS", "1") != "0" and not os.environ.get("MMLREC_SCATTER_OLD"))
-        self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
-                                  lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
-                                  grad_marks=marked)
+        from . import engine as _E
+        # one stream (and no split table update, whose early pass forks anyway): the reductions of the head / gate kernels'
+        # partial sums are deferred behind the backward chain and merged into ONE launch (Plan.merge_row_reduces)
+        one_list = not overlap and not split and os.environ.get("MMLREC_MERGE_REDUCES", "1") != "0"
+        _E._DEFER = one_list
+        try:
+            self.plan = model._record(B, True, False, self.store, sparse_rows=None if (lazy or split) else rows,
+                                      lazy=lazy or split, mark_rows=rows if (split and par is None) else None,
+                                      grad_marks=marked)
+        finally:
+            _E._DEFER = None
+        if one_list:
+            self.plan.merge_row_reduces()
         self.grad_marks = getattr(self.plan.ops[0], "grad_marks", None) is not None
         # every weight-gradient GEMM of the step in one launch: at small batches (a layer's launch does not fill the chip)
         # and whenever no table stream runs beside them (same-box A/B at B = 65 536: lazy_exact 1.677 -> 1.628 ms, but

@@ -535,6 +535,15 @@ int mml_gate_mix_bwd_phase(const mml_gate_group* g, void* workspace, int64_t wor
   REQUIRE(phase >= 0 && phase <= 2, "mml_gate_mix_bwd_phase: bad phase");
   return phase == 2 ? MML_OK : mml_gate_mix_bwd(g, workspace, workspace_bytes, stream);
 }
+/* (phase 1 of the CPU restatement leaves finished results: nothing to reduce) */
+int mml_rows_reduce_batch(const mml_rows_reduce_item* items, int32_t n, mml_stream_t stream) {
+  (void)stream;
+  REQUIRE(n >= 0 && (n == 0 || items), "mml_rows_reduce_batch: bad item array");
+  for (int i = 0; i < n; ++i)
+    REQUIRE((items[i].kind == MML_ROWS_REDUCE_HEAD || items[i].kind == MML_ROWS_REDUCE_GATE) && items[i].group,
+            "mml_rows_reduce_batch: bad item");
+  return MML_OK;
+}
 
 /* ------------------------------------------------------------------------------------------------ K8 */
 int mml_opt_step_dense(const mml_opt_tensor* t, int32_t n, const mml_opt_hyper* h, mml_stream_t stream) {

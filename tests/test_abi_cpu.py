@@ -35,7 +35,7 @@ def test_struct_sizes_match_header():
              "mml_gate_group": _lib.GateGroup, "mml_head_desc": _lib.HeadDesc, "mml_head_group": _lib.HeadGroup,
              "mml_opt_tensor": _lib.OptTensor, "mml_opt_hyper": _lib.OptHyper,
              "mml_copy2d_desc": _lib.Copy2dDesc, "mml_sumprod_desc": _lib.SumProdDesc, "mml_attn2_desc": _lib.Attn2Desc,
-             "mml_amax_desc": _lib.AmaxDesc, "mml_cast16_desc": _lib.Cast16Desc, "mml_g16_tn_desc": _lib.G16TnDesc,
+             "mml_amax_desc": _lib.AmaxDesc, "mml_rows_reduce_item": _lib.RowsReduceItem, "mml_cast16_desc": _lib.Cast16Desc, "mml_g16_tn_desc": _lib.G16TnDesc,
              "mml_g16_wgrad_desc": _lib.G16WgradDesc, "mml_planes_desc": _lib.PlanesDesc}
     src = '#include <stdio.h>\n#include "mmlrec.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"

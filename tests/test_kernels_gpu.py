@@ -441,6 +441,65 @@ def test_head_bce_loss_propagates_nan(ops, H):
     assert np.isnan(orc.bce_sum(orc.sigmoid(logit), y[:, 0]))  # the oracle agrees
 
 
+@pytest.mark.parametrize("B,levels", [(65536, 1), (4096, 1), (3001, 2)])
+def test_rows_reduce_batch_equals_the_phase_two_calls(ops, B, levels):
+    """mml_rows_reduce_batch: the reductions of a head group and of `levels` gate groups (MMoE: one; a PLE: one per level)
+    in ONE launch give what the groups' own phase-2 calls give -- dw / dbias / loss / dWg bit for bit at these sizes
+    (the same reduction kernel either way), row outputs untouched."""
+    rng = np.random.default_rng(B + levels)
+    H, T_, Gd, nexp = 64, 2, 64, 4
+    y = T((rng.random((B, T_)) < 0.4).astype(np.float32))
+
+    def head_group(loss, prob):
+        heads = []
+        for t in range(T_):
+            r = np.random.default_rng(100 + t)
+            heads.append(dict(Hin=T(np.maximum(r.standard_normal((B, H)), 0).astype(np.float32)),
+                              w=T((r.standard_normal(H) / np.sqrt(H)).astype(np.float32)),
+                              bias=T(r.standard_normal(1).astype(np.float32)), dH=torch.empty(B, H, device=dev()),
+                              dw=torch.full((H,), float("nan"), device=dev()),
+                              dbias=torch.full((1,), float("nan"), device=dev()), h_relu=1, mask_col=-1))
+        return heads, ops.make_head_group(heads, prob, y=y, mask=None, loss=loss)
+
+    def gate_group(level):
+        r = np.random.default_rng(200 + level)
+        E, gates = _gate_setup(r, B, 128, nexp, [[0, 1, 2, 3], [0, 1, 2, 3]], Gd)
+        Et = [T(e) for e in E]
+        gd = []
+        for G, Wg, members in gates:
+            gd.append(dict(G=T(G), Wg=T(Wg), P=torch.empty(B, len(members), device=dev()),
+                           mix=torch.empty(B, 128, device=dev()), expert=members))
+        ops.gate_mix_fwd(ops.make_gate_group(Et, gd, B, 128))
+        for q in gd:
+            q.update(dmix=T(r.standard_normal((B, 128)).astype(np.float32)), dG=torch.empty(B, Gd, device=dev()),
+                     dWg=torch.full((len(q["expert"]), Gd), float("nan"), device=dev()), active=1, g_relu=1)
+        dE = [torch.empty(B, 128, device=dev()) for _ in range(nexp)]
+        return gd, dE, ops.make_gate_group(Et, gd, B, 128, d_experts=dE), Et  # (Et: the group holds raw pointers)
+
+    # one by one
+    loss1, prob1 = torch.zeros(1, device=dev()), torch.empty(B, T_, device=dev())
+    heads1, hg1 = head_group(loss1, prob1)
+    ops.head_bce_fwd_bwd(hg1, dev(), phases=True)
+    gates1 = [gate_group(lv) for lv in range(levels)]
+    for gd, dE, gg, _ in gates1:
+        ops.gate_mix_bwd(gg, dev(), phases=True)
+    # phase 1 each, then ONE reduction launch
+    loss2, prob2 = torch.zeros(1, device=dev()), torch.empty(B, T_, device=dev())
+    heads2, hg2 = head_group(loss2, prob2)
+    gates2 = [gate_group(lv) for lv in range(levels)]
+    ops.rows_phase1_then_batched_reduce([hg2], [g[2] for g in gates2], dev())
+    torch.cuda.synchronize()
+    assert torch.equal(loss1, loss2) and float(loss1) > 0 and torch.equal(prob1, prob2)
+    for a, b in zip(heads1, heads2):
+        assert torch.equal(a["dw"], b["dw"]) and torch.equal(a["dbias"], b["dbias"]) and torch.equal(a["dH"], b["dH"])
+        assert not torch.isnan(a["dw"]).any()
+    for (gd1, dE1, _, _), (gd2, dE2, _, _) in zip(gates1, gates2):
+        for a, b in zip(gd1, gd2):
+            assert torch.equal(a["dWg"], b["dWg"]) and torch.equal(a["dG"], b["dG"]) and not torch.isnan(a["dWg"]).any()
+        for a, b in zip(dE1, dE2):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "rmsprop"])
 def test_optimizer_dense_matches_oracle(ops, kind):
     rng = np.random.default_rng(9)
