@@ -451,10 +451,78 @@ class Plan:
                 c[-1]["ready"] = len(self.bwd)
         self._amax_prologue()
         self._cast16_prologue()
+        if os.environ.get("MMLREC_MERGE_COPIES", "1") != "0":
+            for name in ("fwd", "bwd", "bwd_tail", "bwd_side", "head_train", "head_bwd"):
+                setattr(self, name, self._merge_copies(getattr(self, name)))
         # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
         # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
+
+    def _merge_copies(self, calls):
+        """Runs of neighbouring strided copies (mml_copy2d / mml_copy2d_batch: concat / split of feature blocks, gradient
+        hand-overs of shared parameters) as ONE launch each -- inside a step's graph every launch takes >= 4.6 us from
+        start to end, and PepNet's step had four of them in a row three times.  A copy joins the run only if it touches
+        nothing an earlier copy of the run writes, and writes nothing an earlier one reads (one launch has no order)."""
+        lib = L.load()
+        f1, fb = lib.mml_copy2d, lib.mml_copy2d_batch
+
+        def descs_of(c):
+            if c[0] is f1:
+                src, lds, dst, ldd, rows, cols, acc = c[1]
+                return [(src, lds, dst, ldd, rows, cols, acc)]
+            arr, n = c[1]
+            return [(arr[k].src, arr[k].lds, arr[k].dst, arr[k].ldd, arr[k].rows, arr[k].cols, arr[k].accumulate)
+                    for k in range(n)]
+
+        def span(ptr, ld, rows, cols):
+            return (ptr, ptr + 4 * ((max(rows, 1) - 1) * ld + cols))
+
+        def hits(a, b):
+            return a[0] < b[1] and b[0] < a[1]
+
+        out, run, meta_run = [], [], []
+
+        def flush():
+            if not run:
+                return
+            if len(meta_run) == 1:
+                out.append(meta_run[0])
+            else:
+                arr = (L.Copy2dDesc * len(run))()
+                for d, (src, lds, dst, ldd, rows, cols, acc) in zip(arr, run):
+                    d.src, d.lds, d.dst, d.ldd, d.rows, d.cols, d.accumulate = src, lds, dst, ldd, rows, cols, acc
+                self.keep.append(arr)
+                meta = dict(kernel="copy2d_batch_kernel",
+                            bytes=sum(8.0 * r[4] * r[5] for r in run))
+                for c in meta_run:  # (the scheduling tags of the merged calls: they were neighbours of ONE list)
+                    m = c[-1] if isinstance(c[-1], dict) else {}
+                    for k in ("side", "tail", "rank", "ready"):
+                        if k in m:
+                            meta[k] = max(meta.get(k, m[k]), m[k]) if k == "ready" else m[k]
+                out.append((fb, (arr, len(run)), meta))
+            run.clear()
+            meta_run.clear()
+
+        for c in calls:
+            if c[0] is f1 or c[0] is fb:
+                ds = descs_of(c)
+                ok = len(run) + len(ds) <= 32
+                for (src, lds, dst, ldd, rows, cols, acc) in ds:
+                    rs, ws = span(src, lds, rows, cols), span(dst, ldd, rows, cols)
+                    for (s2, l2, d2, ld2, r2, c2, a2) in run:
+                        rs2, ws2 = span(s2, l2, r2, c2), span(d2, ld2, r2, c2)
+                        if hits(rs, ws2) or hits(ws, rs2) or hits(ws, ws2):
+                            ok = False
+                if not ok:
+                    flush()
+                run.extend(ds)
+                meta_run.append(c)
+            else:
+                flush()
+                out.append(c)
+        flush()
+        return out
 
     def _cast16_prologue(self):
         """bf16-storage path: the bf16 copies of the weights, ONE launch in front of everything else; and the promise
