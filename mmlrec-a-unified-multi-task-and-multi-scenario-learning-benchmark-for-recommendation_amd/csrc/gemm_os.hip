@@ -322,7 +322,9 @@ __global__ __launch_bounds__(512, 1) void gemm_os_kernel(const OsLaunch Larg) {
     // are requested behind the MFMAs (into the registers their fragments have just left: 256 VGPRs per wave do not hold
     // both), and the rows are cut while those arrive and the matrix pipe works through the 24 products.
     // (Two wave groups half a k-step apart -- one reading and cutting while the other issues its MFMAs -- were built and
-    // measured: 165.7 us against 163.8 in phase; the phases of a k-step do not simply add up, see profiles/r05_os_lab.txt.)
+    // measured: 165.7 us against 163.8 in phase; the phases of a k-step do not simply add up, see profiles/r05_os_lab.txt.
+    // Four waves of 128 x 128 (one per SIMD, 64 KB of fragment reads per k-step instead of 96) were built too: hipcc spills
+    // 208 bytes per lane at 256 VGPRs + 256 AGPRs in that form -- not run.)
     sync_top(0);
     reads_a(0);
     reads_b(0);
