@@ -42,7 +42,18 @@ __global__ __launch_bounds__(256) void slab_reduce_wave_kernel(const ReduceLaunc
     const ReduceSeg& g = R.seg[si];
     const int64_t j = i - g.start;
     float s = 0.f;
-    for (int k = lane; k < g.S; k += 64) s += g.slab[(int64_t)k * g.sstride + j];
+    const float* src = g.slab + j;
+    int k = lane;
+    // eight loads in flight per lane, the adds in the order k = lane, lane + 64, ... (round 5: a lane's partials were
+    // fetched one dependent load at a time -- 16 round trips for the 1 024 partials of a gate kernel's grid)
+    for (; k + 7 * 64 < g.S; k += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 64 * u) * g.sstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < g.S; k += 64) s += src[(int64_t)k * g.sstride];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) {
