@@ -191,20 +191,32 @@ __global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLa
     const uint16_t* const A = P.A[s] + m0 * P.lda[s];
     const uint16_t* const B = P.B[s] + (int64_t)n0 * P.ldb[s];
     const int64_t lda = P.lda[s], ldb = P.ldb[s];
+    // the lane's source pointers, once per source: a k-step moves them on by 64 elements (recomputed per k-step they were
+    // five VALU instructions per MFMA: 64-bit row x pitch products for twelve DMA instructions against sixteen MFMAs)
+    const uint16_t* ga[4];
+    const uint16_t* gb[BN / 32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = w * 32 + i * 8 + lrow;
+      ga[i] = A + (int64_t)row * lda + ((lpos ^ tn_swz(row)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int row = w * (BN / 4) + i * 8 + lrow;
+      gb[i] = B + (int64_t)row * ldb + ((lpos ^ tn_swz(row)) << 3);
+    }
     for (int k0 = 0; k0 < P.K[s]; k0 += 64) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {  // A tile: 128 rows, 4 DMA instructions of 8 rows per wave
-        const int row = w * 32 + i * 8 + lrow;
-        const uint16_t* g = A + (int64_t)row * lda + k0 + ((lpos ^ tn_swz(row)) << 3);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(g),
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(ga[i]),
                                          reinterpret_cast<float*>(sA + (w * 32 + i * 8) * 64), 16, 0, 0);
+        ga[i] += 64;
       }
 #pragma unroll
       for (int i = 0; i < BN / 32; ++i) {  // B tile: BN rows
-        const int row = w * (BN / 4) + i * 8 + lrow;
-        const uint16_t* g = B + (int64_t)row * ldb + k0 + ((lpos ^ tn_swz(row)) << 3);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(g),
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(gb[i]),
                                          reinterpret_cast<float*>(sB + (w * (BN / 4) + i * 8) * 64), 16, 0, 0);
+        gb[i] += 64;
       }
       __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
 #pragma unroll
