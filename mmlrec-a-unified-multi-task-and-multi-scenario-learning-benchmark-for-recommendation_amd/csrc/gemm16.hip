@@ -14,7 +14,9 @@
 //     transposition in registers, no strided 2-byte LDS reads;
 //   * 128 x 128 (x 64-k) tiles, 4 waves as 2 x 2, ~32 KiB of LDS and < 128 VGPRs per workgroup: three to four workgroups
 //     per CU overlap each other's load, MFMA and epilogue phases (the layers' reductions are 4-36 k-steps long, far too
-//     short for a deep software pipeline inside one workgroup to pay).
+//     short for a deep software pipeline inside one workgroup to pay).  Measured at the end of round 5: the same kernel with
+//     two LDS buffers (the DMA of k-step t + 1 issued before k-step t is worked on, fragments by asm ds_read_b128, 64 KiB
+//     of LDS -> two workgroups per CU) ran KuaiRec-32's step at 1.720 ms against 1.610 (three interleaved pairs); not kept.
 #include "common.hpp"
 #include "lds_async.hpp"
 
