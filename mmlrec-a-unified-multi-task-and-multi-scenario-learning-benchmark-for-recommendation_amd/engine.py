@@ -71,6 +71,8 @@ class Val:
         return self.buf.shape[1]
 
 
+INLINE = object()  # call-list marker: (INLINE, python_callable, args) run in place like a PY entry but do NOT cut a HIP graph
+# (stream fork / join of trainer.InnerFork: event record / wait, capturable)
 PY = object()  # call-list marker: (PY, python_callable, args[, meta]) entries (collectives) next to (c_fn, args[, meta])
 
 
@@ -326,6 +328,9 @@ class Plan:
         s = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         if profiling.enabled:  # --profile: one roctx range per call, named after its kernel
             for c in calls:
+                if c[0] is INLINE:  # (stream fork / join: the calls it issues open their own ranges)
+                    c[1](*c[2])
+                    continue
                 meta = c[3] if (c[0] is PY and len(c) > 3) else (c[2] if (c[0] is not PY and len(c) > 2) else {})
                 with profiling.range(meta.get("kernel") or getattr(c[1] if c[0] is PY else c[0], "__name__", "call")):
                     if c[0] is PY:
@@ -336,7 +341,7 @@ class Plan:
                             L.check(rc, c[0].__name__)
             return
         for c in calls:
-            if c[0] is PY:
+            if c[0] is PY or c[0] is INLINE:
                 c[1](*c[2])
                 continue
             rc = c[0](*c[1], s)

@@ -78,6 +78,27 @@ class Segments:
         return sum(1 for p in self.parts if p[2] is not None)
 
 
+class InnerFork:
+    """A fork / join INSIDE one call list (one HIP graph): `fork` sends `calls` to a second stream behind everything
+    issued so far, `join` makes the current stream wait for them.  Lab knob MMLREC_INNER_FORK (TrainStep): no graph seam,
+    unlike the two-stream schedule of overlap=True."""
+
+    def __init__(self, device, calls):
+        self.side = torch.cuda.Stream(device=device)
+        self.calls = calls
+        self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
+
+    def fork(self):
+        self.ev_fork.record(torch.cuda.current_stream())
+        self.side.wait_event(self.ev_fork)
+        with torch.cuda.stream(self.side):
+            E.Plan._run(self.calls)
+            self.ev_join.record(self.side)
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self.ev_join)
+
+
 def resolve_overlap(overlap):
     """Stream schedule of a fused step: None = the default.  Round 5: ONE stream -- the whole step as one HIP graph.
     Same-box interleaved A/B of bench.py (three pairs each, tools/lab/ab_streams.sh, profiles/r05_ab_streams.txt): the
@@ -231,9 +252,29 @@ class TrainStep:
         # seam is ~16 us of idle stream, a tenth of a small-batch step
         self.whole = None
         if not self.overlap and not self.split_dense:
-            self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
-                                  self.opt_split["tables"] + head_side + p.bwd_side + ar + self.opt_split["mlp"],
-                                  self.use_graph)
+            # The weight gradients on a second stream INSIDE the step's one graph (a fork / join of graph nodes: no seam):
+            # beside the table scatter and the table optimizer.  Same-box interleaved pairs (tools/lab/ab_env.sh
+            # MMLREC_INNER_FORK=0 / 2, B = 65 536): AE-30 1.4773 / 1.4818 / 1.4860 / 1.4952 / 1.4772 -> 1.4635 / 1.4683 /
+            # 1.4851 / 1.4623 / 1.4731 ms, AE-30d 1.613 -> 1.582, PLE 1.535 -> 1.509, PepNet 2.028 -> 2.006; at B = 4 096
+            # it loses (0.670 -> 0.679 ms), so large batches only.  MMLREC_INNER_FORK: 0 off, 1 joined in front of the table
+            # optimizer (beside the scatter only: level), 2 the default form.
+            env_fork = os.environ.get("MMLREC_INNER_FORK")
+            inner = int(env_fork) if env_fork is not None else (2 if int(B) >= 16384 else 0)
+            side_calls = head_side + p.bwd_side
+            mid = (p.bwd_tail + self.opt_split["tables"])
+            if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
+                    not any(c[0] is E.PY for c in mid)):  # (fork and join must land in ONE graph)
+                self.inner_fork = InnerFork(self.store.device, side_calls)
+                fk = [(E.INLINE, self.inner_fork.fork, ())]
+                jn = [(E.INLINE, self.inner_fork.join, ())]
+                mid = (p.bwd_tail + jn + self.opt_split["tables"]) if inner == 1 else \
+                    (p.bwd_tail + self.opt_split["tables"] + jn)
+                self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + fk + mid + ar +
+                                      self.opt_split["mlp"], self.use_graph)
+            else:
+                self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
+                                      self.opt_split["tables"] + head_side + p.bwd_side + ar + self.opt_split["mlp"],
+                                      self.use_graph)
         self.calls = 0
         self._nX = self._ny = None  # staging buffers of a prefetched batch
         self._has_next = False

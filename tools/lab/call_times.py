@@ -10,6 +10,7 @@ import torch  # noqa: E402
 
 
 def main():
+    os.environ.setdefault("MMLREC_INNER_FORK", "0")  # (every call of the step in ONE list: no fork / join entries)
     import mmlrec_amd  # noqa: F401
     from mmlrec_amd import workloads as W, engine as E
     wl = sys.argv[1] if len(sys.argv) > 1 else "mmoe_ae30"
