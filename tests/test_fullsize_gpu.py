@@ -202,7 +202,11 @@ def test_full_size_fused_step_other_configs(W, workload, B):
 
 
 @pytest.mark.parametrize("workload,expect", [("mmoe_kuairec", "gemm_pipe_kernel"), ("ple_ijcai", "gemm"),
-                                             ("star_amazon", "gemm_ws_kernel"), ("pepnet_amazon", "gemm_ws_kernel")])
+                                             ("star_amazon", "gemm_ws_kernel"), ("pepnet_amazon", "gemm_ws_kernel"),
+                                             # AE-30 with AliExpress' 63 dense columns (K0 = 303 in rows of 304): the panel
+                                             # kernel at K = 304, the narrowed input gradient under gemm_os_kernel, the
+                                             # gather's dense pieces, the merged weight-gradient launch
+                                             ("mmoe_ae30d", "gemm_panel_kernel")])
 def test_bench_secondary_configurations_steps_match_oracle(W, workload, expect):
     """The configurations bench.py's `configs` block times, AS it times them: B = 65 536, HIP-graph
     replay, the default stream schedule, table_update = "auto" -- where other code runs than at 8 192 (per-layer
@@ -287,6 +291,8 @@ def test_bench_secondary_configurations_steps_match_oracle(W, workload, expect):
     E.Plan.run_timed(list(p.fwd) + list(p.head_train) + list(p.bwd) + list(p.bwd_tail) + list(p.head_side) +
                      list(p.bwd_side), acc)
     assert any(expect in k for k in acc), sorted(acc)
+    if workload == "mmoe_ae30d":
+        assert any("gemm_os_kernel" in k for k in acc) and any("gemm_nt_kernel" in k for k in acc), sorted(acc)
     gemms = [k for k in acc if k.startswith("gemm")]
     # two scaled fp16 planes (operand magnitudes on from 32 768 samples): no launch falls back to the bf16 x 3 form
     assert gemms and not any(k.startswith("gemm_pipe_kernel") and ", 3, " in k for k in gemms), gemms
