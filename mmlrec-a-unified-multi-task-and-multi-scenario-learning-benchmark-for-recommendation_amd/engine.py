@@ -464,12 +464,12 @@ class Plan:
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
 
-    def _merge_copies(self, calls):
+    def _merge_copies(self, calls, lib=None):
         """Runs of neighbouring strided copies (mml_copy2d / mml_copy2d_batch: concat / split of feature blocks, gradient
         hand-overs of shared parameters) as ONE launch each -- inside a step's graph every launch takes >= 4.6 us from
         start to end, and PepNet's step had four of them in a row three times.  A copy joins the run only if it touches
         nothing an earlier copy of the run writes, and writes nothing an earlier one reads (one launch has no order)."""
-        lib = L.load()
+        lib = lib or L.load()  # (tests/test_plan_passes_cpu.py passes stand-ins: only the functions' identity is used)
         f1, fb = lib.mml_copy2d, lib.mml_copy2d_batch
 
         def descs_of(c):
@@ -481,10 +481,23 @@ class Plan:
                     for k in range(n)]
 
         def span(ptr, ld, rows, cols):
-            return (ptr, ptr + 4 * ((max(rows, 1) - 1) * ld + cols))
+            return (ptr, ld, rows, cols)
 
         def hits(a, b):
-            return a[0] < b[1] and b[0] < a[1]
+            """Do the [rows, cols] regions a, b (pointer, pitch, rows, cols; float32) share an element?  Exact for regions of
+            one pitch (column blocks of one buffer: the concat / split case), the byte-interval test otherwise."""
+            (pa, la, ra, ca), (pb, lb, rb, cb) = a, b
+            ea, eb = pa + 4 * ((max(ra, 1) - 1) * la + ca), pb + 4 * ((max(rb, 1) - 1) * lb + cb)
+            if not (pa < eb and pb < ea):
+                return False
+            if la == lb and la > 0 and (pb - pa) % 4 == 0:
+                delta = (pb - pa) // 4
+                q, r = divmod(delta, la)   # b's origin in a's grid: row q, column r (Python's floor semantics)
+                if ca <= la and r + cb <= la:
+                    rows_meet = q < ra and q + rb > 0
+                    cols_meet = r < ca and r + cb > 0
+                    return rows_meet and cols_meet
+            return True
 
         out, run, meta_run = [], [], []
 
