@@ -254,7 +254,7 @@ int mml_gemm_set_panel(int32_t on);
  * width.  Bitwise the results of the tile kernel.  on = 0 switches it off (default on; environment MMLREC_GEMM_WS=0 does
  * the same). */
 int mml_gemm_set_ws(int32_t on);
-/* Weight gradients cut once per workgroup (csrc/gemm_nt.hip).  A weight-gradient launch of <= 8 problems in nn.Linear
+/* Weight gradients cut once per workgroup (csrc/gemm_nt.hip).  A weight-gradient launch of <= 16 (MML_MAX_GROUP) problems in nn.Linear
  * layout that all carry both operand magnitudes, with M % 32 == 0, M >= 16 384, N % 32 == 0, K % 4 == 0 and 16-byte
  * aligned operand rows (the DNN layers of a large batch: reference model/utils.py:146-161, autograd's mm backward) is
  * served by workgroups that own a 128 x 128 tile of dW for a slab of the batch: the rows of both operands are cut into
@@ -442,6 +442,11 @@ int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* descs, int32_t n, void* wo
  * needs its own workspace. */
 int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* descs, int32_t n, void* workspace,
                                  int64_t workspace_bytes, int32_t phase, mml_stream_t stream);
+/* 1 when ONE weight-gradient problem satisfies every per-problem condition of the cut-once weight-gradient kernel (mml_gemm_set_nt, csrc/gemm_nt.hip) (layout, both
+ * magnitudes, M, N, K, alignment and row pitches), else 0.  A launch is served when all of its problems are and they share
+ * M: a caller that groups problems into launches (engine.Plan.merge_wgrad) asks here, so that its grouping and the
+ * library's decision cannot drift apart.  No GPU work, no error text. */
+int mml_gemm_nt_serves(const mml_gemm_wgrad_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  gate: skinny linear [Gd -> ne] (no bias) + softmax over experts + expert mix.

@@ -78,6 +78,7 @@ class RowsReduceItem(C.Structure):
 
 
 ROWS_REDUCE_HEAD, ROWS_REDUCE_GATE = 0, 1
+MAX_REDUCE_SEGS = 40  # csrc/reduce.hpp: segments of one reduction launch
 GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16, GATE_E_BF16 = 1, 2, 4, 8
 
 
@@ -169,6 +170,7 @@ _SIGS = {
     "mml_gemm_set_panel": (C.c_int, [i32]),
     "mml_gemm_set_ws": (C.c_int, [i32]),
     "mml_gemm_set_nt": (C.c_int, [i32]),
+    "mml_gemm_nt_serves": (C.c_int, [_PP(GemmWgradDesc)]),
     "mml_gemm_last_kernel": (C.c_char_p, []),
     "mml_gather_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),

@@ -399,6 +399,19 @@ static int nt_cus() {
 
 using namespace mml;
 
+// the per-problem conditions (mml_gemm_nt_serves: the grouping pass of the host side asks the same question)
+static bool nt_serves(const mml_gemm_wgrad_desc& q) {
+  if (q.M < 16384 || q.M % NT_STEP != 0) return false;
+  if (q.w_kn || !q.dC || !q.A || !q.dW || !q.amax_dc || !q.amax_a) return false;
+  if (q.N <= 0 || q.N % 32 != 0 || q.K <= 0 || q.K % 4 != 0) return false;
+  if (!aligned16(q.dC) || !aligned16(q.A) || q.lddc % 4 != 0 || q.lda % 4 != 0 || q.lddc < q.N || q.lda < q.K ||
+      q.lddw < q.K)
+    return false;
+  return true;
+}
+
+extern "C" int mml_gemm_nt_serves(const mml_gemm_wgrad_desc* desc) { return (desc && nt_serves(*desc)) ? 1 : 0; }
+
 extern "C" int mml_gemm_set_nt(int32_t on) {
   MML_REQUIRE(on >= 0 && on <= 2, "mml_gemm_set_nt: 0 (off), 1 (every qualifying launch: default) or 2 (launches of >= 16 tiles)");
   g_nt_on = on;
@@ -416,11 +429,7 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
   int64_t tiles = 0, elems = 0;
   for (int i = 0; i < n; ++i) {
     const mml_gemm_wgrad_desc& q = d[i];
-    if (q.M != M || q.w_kn || !q.dC || !q.A || !q.dW || !q.amax_dc || !q.amax_a) return MML_ERR_UNSUPPORTED;
-    if (q.N <= 0 || q.N % 32 != 0 || q.K <= 0 || q.K % 4 != 0) return MML_ERR_UNSUPPORTED;
-    if (!aligned16(q.dC) || !aligned16(q.A) || q.lddc % 4 != 0 || q.lda % 4 != 0 || q.lddc < q.N || q.lda < q.K ||
-        q.lddw < q.K)
-      return MML_ERR_UNSUPPORTED;
+    if (q.M != M || !nt_serves(q)) return MML_ERR_UNSUPPORTED;
     tiles += cdiv(q.N, 128) * cdiv(q.K, 128);
     elems += (int64_t)q.N * q.K + q.N;
   }

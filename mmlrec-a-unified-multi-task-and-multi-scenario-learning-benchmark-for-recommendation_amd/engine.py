@@ -355,6 +355,9 @@ class Plan:
         s = torch.cuda.current_stream()
         evs = []
         for c in calls:
+            if c[0] is INLINE:  # (stream fork / join: run in place, untimed -- what it issues is not this stream's time)
+                c[1](*c[2])
+                continue
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(s)
             if c[0] is PY:
@@ -458,17 +461,27 @@ class Plan:
         self._cast16_prologue()
         if os.environ.get("MMLREC_MERGE_COPIES", "1") != "0":
             for name in ("fwd", "bwd", "bwd_tail", "bwd_side", "head_train", "head_bwd"):
-                setattr(self, name, self._merge_copies(getattr(self, name)))
+                where = [] if name == "bwd" else None
+                setattr(self, name, self._merge_copies(getattr(self, name), where=where))
+                if name == "bwd" and where:
+                    # the side calls' `ready` tags count entries of the UNMERGED chain: into the merged list's index
+                    # space (ready = k: the first k entries have been issued -> everything up to the merged entry that
+                    # holds old entry k - 1)
+                    for c in list(self.bwd_side) + list(self.head_side):
+                        m = c[-1] if isinstance(c[-1], dict) else None
+                        if m is not None and m.get("ready"):
+                            m["ready"] = where[min(m["ready"], len(where)) - 1] + 1
         # (Measured on MI355X: issuing every weight-gradient partial-product GEMM before the first reduction -- the
         # phased wgrad entry point allows it -- makes the step SLOWER, 2.35 ms vs 2.19 ms: the GEMMs then run next to
         # the table scatter and the dense table optimizer for longer and all of them are HBM-bound together.  The
         # list stays in program order: partial products and reduction of one layer back to back.)
 
-    def _merge_copies(self, calls, lib=None):
+    def _merge_copies(self, calls, lib=None, where=None):
         """Runs of neighbouring strided copies (mml_copy2d / mml_copy2d_batch: concat / split of feature blocks, gradient
         hand-overs of shared parameters) as ONE launch each -- inside a step's graph every launch takes >= 4.6 us from
         start to end, and PepNet's step had four of them in a row three times.  A copy joins the run only if it touches
-        nothing an earlier copy of the run writes, and writes nothing an earlier one reads (one launch has no order)."""
+        nothing an earlier copy of the run writes, and writes nothing an earlier one reads (one launch has no order).
+        where: a list that receives, per input call, the index of the output entry it went into."""
         lib = lib or L.load()  # (tests/test_plan_passes_cpu.py passes stand-ins: only the functions' identity is used)
         f1, fb = lib.mml_copy2d, lib.mml_copy2d_batch
 
@@ -500,10 +513,15 @@ class Plan:
             return True
 
         out, run, meta_run = [], [], []
+        pos = [0] * len(calls)
+        run_src = []
 
         def flush():
             if not run:
                 return
+            for i_ in run_src:
+                pos[i_] = len(out)
+            run_src.clear()
             if len(meta_run) == 1:
                 out.append(meta_run[0])
             else:
@@ -522,7 +540,7 @@ class Plan:
             run.clear()
             meta_run.clear()
 
-        for c in calls:
+        for ci, c in enumerate(calls):
             if c[0] is f1 or c[0] is fb:
                 ds = descs_of(c)
                 ok = len(run) + len(ds) <= 32
@@ -536,10 +554,14 @@ class Plan:
                     flush()
                 run.extend(ds)
                 meta_run.append(c)
+                run_src.append(ci)
             else:
                 flush()
+                pos[ci] = len(out)
                 out.append(c)
         flush()
+        if where is not None:
+            where[:] = pos
         return out
 
     def _cast16_prologue(self):
@@ -625,8 +647,9 @@ class Plan:
             steps = self.B // 32
             # (what gemm_nt_kernel takes -- csrc/gemm_nt.hip, mml_gemm_nt_try_wgrad -- goes together: ONE problem it does
             # not take, e.g. a final layer with a single output row, would send its whole launch to the tile kernel)
-            fits = [d for d in descs if d.N % 32 == 0 and d.K % 4 == 0 and not d.w_kn and d.amax_dc and d.amax_a]
-            other = [d for d in descs if not (d.N % 32 == 0 and d.K % 4 == 0 and not d.w_kn and d.amax_dc and d.amax_a)]
+            serves = [bool(lib.mml_gemm_nt_serves(C.byref(d))) for d in descs]  # (the library's own predicate)
+            fits = [d for d, ok in zip(descs, serves) if ok]
+            other = [d for d, ok in zip(descs, serves) if not ok]
             chunks = []
             for part in (fits, other):
                 if part:
@@ -667,27 +690,55 @@ class Plan:
         self.bwd_side = [c for pair in zip(merged, reduces) for c in pair] + rest
         return True
 
-    def merge_row_reduces(self):
+    def merge_row_reduces(self, lib=None):
         """The deferred reductions of the head / gate kernels' partial sums (`head_side`, and the gate groups' entries of
-        `bwd_side`: only the optimizer and the host read their results) as ONE launch in front of the weight gradients."""
-        lib = L.load()
+        `bwd_side`: only the optimizer and the host read their results) as ONE launch in front of the weight gradients
+        (as few as the launch's segment capacity allows)."""
+        lib = lib or L.load()  # (tests/test_plan_passes_cpu.py passes stand-ins: only the functions' identity is used)
         fh, fg = lib.mml_head_bce_fwd_bwd_phase, lib.mml_gate_mix_bwd_phase
         is_red = lambda c: c[0] in (fh, fg) and c[1][3] == 2  # noqa: E731
         picked = [c for c in list(self.head_side) + list(self.bwd_side) if is_red(c)]
         if len(picked) < 2:
             return False
-        items = (L.RowsReduceItem * len(picked))()
-        for it, c in zip(items, picked):
-            grp, ws, nbytes, _ = c[1]
-            it.kind = L.ROWS_REDUCE_HEAD if c[0] is fh else L.ROWS_REDUCE_GATE
-            it.group = C.addressof(grp._obj)  # (the ops pass C.byref(group); the group itself lives in plan.keep)
-            it.workspace, it.workspace_bytes = ws, nbytes
-        self.keep.append(items)
-        call = (lib.mml_rows_reduce_batch, (items, len(picked)),
-                dict(kernel="slab_reduce", bytes=sum(c[2].get("bytes", 0.0) for c in picked), side=True, rank=1,
-                     ready=max(c[2].get("ready", 0) for c in picked)))
+
+        def segments(c):
+            """Reduction segments the C side makes of this item (csrc/gate_head.hip, phase 2): a head group one per dw and
+            dbias of every head plus the loss, a gate group one per active gate's dWg."""
+            g = c[1][0]._obj
+            if c[0] is fh:
+                return 2 * int(g.n_heads) + (1 if g.loss else 0)
+            return sum(1 for k in range(int(g.n_gates)) if g.gate[k].active)
+
+        # one launch takes at most MAX_REDUCE_SEGS segments (csrc/reduce.hpp): a deep PLE (7 tasks x 4 levels: 15 + 8 + 8 +
+        # 8 + 7 = 46) goes into as many launches as it needs, in list order
+        chunks, cur, nseg = [], [], 0
+        for c in picked:
+            s = segments(c)
+            if s > L.MAX_REDUCE_SEGS:
+                return False  # (a single group beyond the launch's capacity: leave every reduction where it was)
+            if cur and nseg + s > L.MAX_REDUCE_SEGS:
+                chunks.append(cur)
+                cur, nseg = [], 0
+            cur.append(c)
+            nseg += s
+        chunks.append(cur)
+        calls = []
+        for ch in chunks:
+            if len(ch) == 1:  # (nothing to merge it with: its own phase-2 call, on the side list)
+                calls.append(ch[0])
+                continue
+            items = (L.RowsReduceItem * len(ch))()
+            for it, c in zip(items, ch):
+                grp, ws, nbytes, _ = c[1]
+                it.kind = L.ROWS_REDUCE_HEAD if c[0] is fh else L.ROWS_REDUCE_GATE
+                it.group = C.addressof(grp._obj)  # (the ops pass C.byref(group); the group itself lives in plan.keep)
+                it.workspace, it.workspace_bytes = ws, nbytes
+            self.keep.append(items)
+            calls.append((lib.mml_rows_reduce_batch, (items, len(ch)),
+                          dict(kernel="slab_reduce", bytes=sum(c[2].get("bytes", 0.0) for c in ch), side=True, rank=1,
+                               ready=max(c[2].get("ready", 0) for c in ch))))
         self.head_side = [c for c in self.head_side if not is_red(c)]
-        self.bwd_side = [call] + [c for c in self.bwd_side if not is_red(c)]
+        self.bwd_side = calls + [c for c in self.bwd_side if not is_red(c)]
         return True
 
     def merge_wgrad16(self):

@@ -66,7 +66,7 @@ class Segments:
             elif graph is not None:
                 if profiling.enabled:
                     with profiling.range("hip_graph[%d calls: %s ...]" % (len(item), (item[0][2] if len(item[0]) > 2 and
-                                         isinstance(item[0][2], dict) else {}).get("kernel", item[0][0].__name__))):
+                                         isinstance(item[0][2], dict) else {}).get("kernel", getattr(item[0][0], "__name__", "inline")))):
                         graph.replay()
                 else:
                     graph.replay()
@@ -78,10 +78,32 @@ class Segments:
         return sum(1 for p in self.parts if p[2] is not None)
 
 
+def fork_conflicts(side_calls, mid_calls, shared_scratch=()):
+    """Raw device pointers that make a fork of `side_calls` beside `mid_calls` unsafe, as far as the call lists show it:
+    (a) a shared scratch buffer (ops.workspace: every non-deferred row kernel writes its partial sums there) named by
+    EITHER branch -- the other branch, or the chain that follows, may overwrite it -- and (b) a pointer argument both
+    branches carry (each branch must own what it names; descriptors hold further pointers the lists do not show: the
+    operands of the weight-gradient GEMMs are written by the chain BEFORE the fork and only read after it).  Returns the
+    offending pointers (empty = no conflict seen); TrainStep refuses to fork on any (tests/test_plan_passes_cpu.py)."""
+    def ptrs(calls):
+        out = set()
+        for c in calls:
+            if c[0] is E.PY or c[0] is E.INLINE:
+                continue
+            for a in c[1]:
+                if isinstance(a, int) and not isinstance(a, bool) and a >= (1 << 16):
+                    out.add(a)
+        return out
+    a, b = ptrs(side_calls), ptrs(mid_calls)
+    scratch = {int(x) for x in shared_scratch if x}
+    return sorted(((a | b) & scratch) | (a & b))
+
+
 class InnerFork:
     """A fork / join INSIDE one call list (one HIP graph): `fork` sends `calls` to a second stream behind everything
-    issued so far, `join` makes the current stream wait for them.  Lab knob MMLREC_INNER_FORK (TrainStep): no graph seam,
-    unlike the two-stream schedule of overlap=True."""
+    issued so far, `join` makes the current stream wait for them.  Opt-in knob MMLREC_INNER_FORK (TrainStep): no graph seam,
+    unlike the two-stream schedule of overlap=True -- but a multi-branch graph (see TrainStep.run's note on
+    hip::Graph::UpdateStreams)."""
 
     def __init__(self, device, calls):
         self.side = torch.cuda.Stream(device=device)
@@ -256,14 +278,23 @@ class TrainStep:
             # beside the table scatter and the table optimizer.  Same-box interleaved pairs (tools/lab/ab_env.sh
             # MMLREC_INNER_FORK=0 / 2, B = 65 536): AE-30 1.4773 / 1.4818 / 1.4860 / 1.4952 / 1.4772 -> 1.4635 / 1.4683 /
             # 1.4851 / 1.4623 / 1.4731 ms, AE-30d 1.613 -> 1.582, PLE 1.535 -> 1.509, PepNet 2.028 -> 2.006; at B = 4 096
-            # it loses (0.670 -> 0.679 ms), so large batches only.  MMLREC_INNER_FORK: 0 off, 1 joined in front of the table
-            # optimizer (beside the scatter only: level), 2 the default form.
+            # it loses (0.670 -> 0.679 ms).  MMLREC_INNER_FORK: 0 off (default), 1 joined in front of the table
+            # optimizer (beside the scatter only: level), 2 joined behind it (the measured form).
+            # Round 6: OPT-IN (default 0).  The fork makes the step's graph a multi-branch graph, the kind whose launch
+            # segfaulted sporadically in this runtime (hip::Graph::UpdateStreams, see run() below: dependent on how many
+            # streams the process created) -- 0.9 % is not worth that risk on a first 8-GPU run; the soak protocol and its
+            # result: profiles/r06_fork_soak.txt.
             env_fork = os.environ.get("MMLREC_INNER_FORK")
-            inner = int(env_fork) if env_fork is not None else (2 if int(B) >= 16384 else 0)
+            inner = int(env_fork) if env_fork is not None else 0
             side_calls = head_side + p.bwd_side
             mid = (p.bwd_tail + self.opt_split["tables"])
             if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
                     not any(c[0] is E.PY for c in mid)):  # (fork and join must land in ONE graph)
+                from . import ops as _ops
+                bad = fork_conflicts(side_calls, mid, [w.data_ptr() for w in _ops._workspaces.values()])
+                if bad:
+                    raise RuntimeError("inner fork: the two branches of the step share device buffers: " +
+                                       ", ".join(hex(x) for x in bad))
                 self.inner_fork = InnerFork(self.store.device, side_calls)
                 fk = [(E.INLINE, self.inner_fork.fork, ())]
                 jn = [(E.INLINE, self.inner_fork.join, ())]

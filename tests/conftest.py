@@ -1,8 +1,40 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _host_threads(cap=16):
+    """Threads the host-side checkers (numpy / OpenBLAS, the OpenMP loops of oracle/fast.c, torch-CPU) may use: the CPUs
+    this process may run on -- its affinity mask AND its cgroup CPU quota (a container limited to 16 CPUs of a 256-thread
+    host by quota still sees 256 in os.cpu_count(): 256 spinning OpenMP threads on 16 CPUs' worth of time is what turns a
+    3 s oracle step into 30 s) -- and never more than `cap` (measured on a 256-thread MI355X host: the GPU suite takes
+    145 s with 16 threads, 230 s with 256)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
+# (before numpy / torch load their thread pools; an explicit setting in the environment wins)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(_host_threads()))
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -96,3 +128,38 @@ def check_update(name, before, got, ref, allow=2e-3):
     share, rel = table_update_report(b, got.reshape(b.shape), ref.reshape(b.shape), rows)
     assert share < allow, (name, share, rel)
     return share
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The full-size step tests' initialisation (also used by tests/golden/make_bench_losses.py for the loss fixtures)
+# ---------------------------------------------------------------------------------------------------------------
+def randomize_he(model, seed):
+    """He-scaled weights / 0.05-scaled tables drawn on the host and copied into the model (and its unregistered STAR
+    tensors), so that logits are far from the 0.5 the reference's 1e-4 init gives."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("embedding_dict."):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(p.device))
+            elif p.dim() == 2:
+                fan_in = p.shape[0] if (".shared_weight" in n or ".specific_weight" in n) else p.shape[1]
+                scale = (2.0 / fan_in) ** 0.5
+                if ".specific_weight" in n:  # multiplies the shared weight elementwise: keep the product He-scaled
+                    p.copy_((1.0 + 0.25 * torch.randn(p.shape, generator=g)).to(p.device))
+                else:
+                    p.copy_((torch.randn(p.shape, generator=g) * scale).to(p.device))
+            elif not n.startswith("out."):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(p.device))
+        frozen = {}
+        for pfx in ("linears", "final_layers"):
+            for li, mod in enumerate(getattr(model, pfx, [])):
+                if not hasattr(mod, "specific_weights"):
+                    continue
+                for d in range(len(mod.specific_weights) - 1):  # the last one IS the registered parameter
+                    w, b = mod.specific_weights[d], mod.specific_biases[d]
+                    w.data.copy_((1.0 + 0.25 * torch.randn(w.shape, generator=g)).to(w.device))
+                    b.data.copy_((torch.randn(b.shape, generator=g) * 0.05).to(b.device))
+                    frozen[f"{pfx}.{li}.specific_weights.{d}"] = w.detach().cpu().numpy().copy()
+                    frozen[f"{pfx}.{li}.specific_biases.{d}"] = b.detach().cpu().numpy().copy()
+    return frozen

@@ -112,3 +112,118 @@ def test_existing_batches_join_and_strided_ranges_count(env):
     keep = [c[1][2] for c in many]  # (the destination buffers above are temporaries: only the split is checked)
     m = E.Plan._merge_copies(fake, many, lib=lib)
     assert sum(c[1][1] if c[0] is lib.mml_copy2d_batch else 1 for c in m) == 40 and len(m) >= 2 and keep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Plan.merge_row_reduces: the deferred head / gate reductions as few launches as the C side's segment capacity allows
+# (a PLE with 7 tasks and 4 levels needs 15 + 8 + 8 + 8 + 7 = 46 segments; csrc/reduce.hpp takes 40 per launch)
+# ---------------------------------------------------------------------------------------------------------------
+def _reduce_plan(env, n_heads, gate_groups):
+    """A stand-in plan whose side lists hold the phase-2 calls of one head group (n_heads heads + the loss) and of gate
+    groups with the given numbers of active gates (one inactive gate each on top)."""
+    L, E, _, _ = env
+    lib = types.SimpleNamespace(mml_head_bce_fwd_bwd_phase=lambda *a: 0, mml_gate_mix_bwd_phase=lambda *a: 0,
+                                mml_rows_reduce_batch=lambda *a: 0, other=lambda *a: 0)
+    hg = L.HeadGroup()
+    hg.n_heads, hg.loss = n_heads, 12345
+    plan = types.SimpleNamespace(keep=[hg])
+    plan.head_side = [(lib.mml_head_bce_fwd_bwd_phase, (C.byref(hg), 1000, 64, 2),
+                       dict(kernel="slab_reduce", bytes=64.0, side=True, rank=1, ready=0))]
+    plan.bwd_side = []
+    for i, n_active in enumerate(gate_groups):
+        gg = L.GateGroup()
+        gg.n_gates = min(n_active + 1, L.MAX_GATES)
+        for k in range(n_active):
+            gg.gate[k].active = 1
+        plan.keep.append(gg)
+        plan.bwd_side.append((lib.other, (i,), dict(kernel="gemm", side=True, ready=i + 1)))
+        plan.bwd_side.append((lib.mml_gate_mix_bwd_phase, (C.byref(gg), 2000 + i, 32, 2),
+                              dict(kernel="slab_reduce", bytes=32.0, side=True, rank=1, ready=i + 1)))
+    return lib, plan
+
+
+def _segments_of(L, lib, call):
+    """Segments a reduction launch of the merged list carries (what csrc/gate_head.hip makes of its items)."""
+    def of_group(fn, g):
+        if fn is lib.mml_head_bce_fwd_bwd_phase:
+            return 2 * g.n_heads + (1 if g.loss else 0)
+        return sum(1 for k in range(g.n_gates) if g.gate[k].active)
+    if call[0] is lib.mml_rows_reduce_batch:
+        items, n = call[1]
+        tot = 0
+        for k in range(n):
+            it = items[k]
+            if it.kind == L.ROWS_REDUCE_HEAD:
+                tot += of_group(lib.mml_head_bce_fwd_bwd_phase, C.cast(it.group, C.POINTER(L.HeadGroup)).contents)
+            else:
+                tot += of_group(lib.mml_gate_mix_bwd_phase, C.cast(it.group, C.POINTER(L.GateGroup)).contents)
+        return tot, n
+    return of_group(call[0], call[1][0]._obj), 1
+
+
+def test_merge_row_reduces_mmoe_is_one_launch(env):
+    L, E, _, _ = env
+    lib, plan = _reduce_plan(env, 2, [2])
+    assert E.Plan.merge_row_reduces(plan, lib=lib)
+    assert plan.head_side == []
+    assert [c[0] for c in plan.bwd_side] == [lib.mml_rows_reduce_batch, lib.other]
+    assert _segments_of(L, lib, plan.bwd_side[0]) == (2 * 2 + 1 + 2, 2)
+    assert plan.bwd_side[0][2]["ready"] == 1
+
+
+def test_merge_row_reduces_deep_ple_is_chunked(env):
+    L, E, _, _ = env
+    lib, plan = _reduce_plan(env, 7, [8, 8, 8, 7])           # 15 + 8 + 8 + 8 + 7 = 46 segments
+    assert E.Plan.merge_row_reduces(plan, lib=lib)
+    reds = [c for c in plan.bwd_side if c[0] is not lib.other]
+    assert plan.head_side == [] and len(reds) == 2 and plan.bwd_side[:2] == reds
+    segs = [_segments_of(L, lib, c) for c in reds]
+    assert all(s <= L.MAX_REDUCE_SEGS for s, _ in segs)
+    assert sum(s for s, _ in segs) == 46 and sum(n for _, n in segs) == 5   # every group exactly once
+    assert segs[0] == (39, 4) and segs[1] == (7, 1)
+    assert reds[1][0] is lib.mml_gate_mix_bwd_phase   # (a chunk of one keeps its own phase-2 call)
+    assert sum(1 for c in plan.bwd_side if c[0] is lib.other) == 4
+
+
+def test_merge_row_reduces_single_group_is_left_alone(env):
+    L, E, _, _ = env
+    lib, plan = _reduce_plan(env, 2, [])
+    before = list(plan.head_side)
+    assert not E.Plan.merge_row_reduces(plan, lib=lib)
+    assert plan.head_side == before and plan.bwd_side == []
+
+
+def test_merge_copies_reports_where_every_call_went(env):
+    """`where` maps old indices to merged ones: Plan.finish turns the side calls' `ready` tags (counted on the unmerged
+    backward chain) into the merged list's index space with it."""
+    L, E, lib, fake = env
+    bufs = [np.zeros((3, 4), np.float32) for _ in range(8)]
+    calls = [(lib.other, (0,)),
+             (lib.mml_copy2d, (addr(bufs[0]), 4, addr(bufs[1]), 4, 3, 4, 0)),
+             (lib.mml_copy2d, (addr(bufs[2]), 4, addr(bufs[3]), 4, 3, 4, 0)),
+             (lib.other, (1,)),
+             (lib.mml_copy2d, (addr(bufs[4]), 4, addr(bufs[5]), 4, 3, 4, 0)),
+             (lib.mml_copy2d, (addr(bufs[5]), 4, addr(bufs[6]), 4, 3, 4, 0)),   # reads what the previous wrote: its own launch
+             (lib.other, (2,))]
+    where = []
+    merged = E.Plan._merge_copies(fake, calls, lib=lib, where=where)
+    assert len(merged) == 6 and where == [0, 1, 1, 2, 3, 4, 5]
+    # ready = k (first k old entries issued) -> where[k - 1] + 1 merged entries
+    assert [where[k - 1] + 1 for k in (1, 2, 3, 4, 7)] == [1, 2, 2, 3, 6]
+
+
+def test_fork_conflicts_sees_shared_scratch_and_common_pointers():
+    """trainer.fork_conflicts: a fork inside the step's graph is refused when either branch names the shared
+    scratch buffer, or both name one pointer."""
+    import mmlrec_amd  # noqa: F401
+    from mmlrec_amd import engine as E, trainer
+    f = lambda *a: 0  # noqa: E731
+    side = [(f, (0x7f0000100000, 64, 1)), (E.INLINE, f, ()), (f, (0x7f0000200000, 3), dict(kernel="k"))]
+    mid = [(f, (0x7f0000300000, 0x7f0000400000, 128)), (E.PY, f, (0x7f0000100000,))]
+    assert trainer.fork_conflicts(side, mid) == []
+    assert trainer.fork_conflicts(side, mid, shared_scratch=[0x7f0000900000]) == []
+    assert trainer.fork_conflicts(side, mid, shared_scratch=[0x7f0000200000]) == [0x7f0000200000]     # side uses the scratch
+    assert trainer.fork_conflicts(side, mid, shared_scratch=[0x7f0000400000]) == [0x7f0000400000]     # mid uses it
+    mid2 = mid + [(f, (0x7f0000100000, 8))]
+    assert trainer.fork_conflicts(side, mid2) == [0x7f0000100000]                                     # a common pointer
+    assert trainer.fork_conflicts([(f, (64, 1, True))], [(f, (64, 1))]) == []                         # small integers are sizes
