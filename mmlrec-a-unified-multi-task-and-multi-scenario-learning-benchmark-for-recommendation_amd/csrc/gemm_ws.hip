@@ -19,6 +19,13 @@
 //     layer reads its rows once.
 // Products, their order (W_l A_h, W_h A_l, W_h A_h per 16-k block) and the k order are those of gemm_pipe_kernel<..,
 // EMU = 2, BPL>: same bits (tests/test_gemm_ws_gpu.py).
+//
+// K7 (round 6; PepNet, reference model/pepnet.py:64-78, :139-140: every PPNet layer's input is h (.) 2 sigmoid(gate(..))):
+//   * forward, template K7 of MODE 0: the gate network's output layer stores g = act(z) AND prod = g (.) mul from the same
+//     row-major turn -- the product makes no pass of its own (it cost a 12 B / element launch);
+//   * backward, K7 of MODE 1 ("gate mode" of mml_gemm_grouped_dgrad): the input gradient v of the layer that reads
+//     h (.) g is not stored; the turn reads h and g once and stores dH (+)= v g act_h'(h) and dG (+)= v h act_g'(g)
+//     (the expressions of gemm_pipe_kernel's gate mode) with one magnitude slot each.
 #include "common.hpp"
 #include "lds_async.hpp"
 
@@ -35,6 +42,15 @@ constexpr int WS_TURN_OFF = WS_AMAX_OFF + 64;       // eight waves x 2 KiB: 32 r
 constexpr int WS_LDS_BYTES = WS_TURN_OFF + 8 * 2048;
 static_assert(WS_LDS_BYTES <= 160 * 1024, "weight-stationary kernel LDS budget");
 constexpr int WS_MIN_ROWS = 8192;                   // below: the tile kernel (a persistent grid would idle)
+__device__ __forceinline__ float ws_act_bwd(const float y, const int act) {  // (gemm.hip: act_bwd)
+  if (act == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MML_ACT_SIGMOID2) {
+    const float s_ = 0.5f * y;
+    return 2.f * s_ * (1.f - s_);
+  }
+  return 1.f;
+}
 struct WsProblem {
   const float* A;          // [M, Kred] activations (forward) / output gradients (input gradient)
   const uint32_t* amaxA;   // magnitude slot of A
@@ -49,6 +65,13 @@ struct WsProblem {
   int32_t act;             // forward: MML_ACT_NONE / RELU / SIGMOID / SIGMOID2
   int32_t accumulate;      // input gradient: C +=
   int32_t G;               // groups of D k-steps (Kred = 16 D G)
+  // K7: forward: x1 = mul, c2 = prod; gate mode: x1 = h, x2 = g, C = dH (act1 = act_h, accumulate = acc_h), c2 = dG
+  const float* x1;
+  const float* x2;
+  float* c2;
+  uint32_t* amax_out2;     // magnitude of what c2 receives
+  int64_t ld1, ld2, ldc2;
+  int32_t act1, act2, acc2, pad_;
 };
 
 struct WsLaunch {
@@ -73,7 +96,8 @@ __device__ __forceinline__ int ws_scale_exp(uint32_t bits) {
 __device__ __forceinline__ float ws_pow2(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 // MODE 0: forward (bias, ReLU, sign mask out when MASKS); MODE 1: input gradient (sign mask in when MASKS, accumulation)
-template <int NS, int MODE, bool MASKS, int D>
+// K7: forward with the product epilogue / input gradient in gate mode (see the head of this file)
+template <int NS, int MODE, bool MASKS, int D, bool K7 = false>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
   constexpr int NSTOT = NS;
   __shared__ __attribute__((aligned(16))) float lds[WS_LDS_BYTES / 4];
@@ -106,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
       }
     }
     if (MODE == 0 && tid < NSTOT * 32) lds[WS_BIAS_OFF / 4 + tid] = P.bias ? P.bias[tid] : 0.f;
-    if (tid == 0) reinterpret_cast<uint32_t*>(lds)[WS_AMAX_OFF / 4] = 0u;
+    if (tid < 2) reinterpret_cast<uint32_t*>(lds)[WS_AMAX_OFF / 4 + tid] = 0u;
   }
   __syncthreads();
 
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
   const int nrb = (M + 31) >> 5;
   const int stride = L.wg_per_prob * 8;
   int rb = wl * 8 + wave;
-  float am = 0.f;
+  float am = 0.f, am2 = 0.f;
 
   auto arow = [&](const int rb_) __attribute__((always_inline)) {
     int row = rb_ * 32 + l31;
@@ -199,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
         float* const cst = P.C + (int64_t)orow * P.ldc + 4 * tc;
         const int64_t c16 = 16 * P.ldc;
         const bool ok0 = orow < M, ok1 = orow + 16 < M;
+        const int lrow0 = ok0 ? orow : M - 1, lrow1 = ok1 ? orow + 16 : M - 1;  // (K7: rows the extra operands are read from)
         auto turn_store = [&](const float4 va, const float4 vb, const int ni, const int half) __attribute__((always_inline)) {
           // va / vb: this lane's runs g = 2 half, 2 half + 1 (columns 16 half + 4 h + {0..3}, + 8)
           *reinterpret_cast<float4*>(tw + 4 * ((0 + h) ^ ((l31 >> 2) & 3))) = va;
@@ -207,6 +232,53 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
           float4 q0 = *reinterpret_cast<const float4*>(turn + tR * 16 + 4 * (tc ^ ((tR >> 2) & 3)));
           float4 q1 = *reinterpret_cast<const float4*>(turn + (tR + 16) * 16 + 4 * (tc ^ (((tR + 16) >> 2) & 3)));
           float* const d0 = cst + ni * 32 + 16 * half;
+          if constexpr (K7) {
+            // (rows past the batch read the last row: always a legal address, their results are never stored)
+            const int cofs = 4 * tc + ni * 32 + 16 * half;
+            const int64_t oc2 = (int64_t)orow * P.ldc2 + cofs;
+            const float4 m0 = *reinterpret_cast<const float4*>(P.x1 + (int64_t)lrow0 * P.ld1 + cofs);
+            const float4 m1 = *reinterpret_cast<const float4*>(P.x1 + (int64_t)lrow1 * P.ld1 + cofs);
+            if constexpr (MODE == 0) {  // prod = g (.) mul; g itself is stored below
+              const float4 p0 = make_float4(q0.x * m0.x, q0.y * m0.y, q0.z * m0.z, q0.w * m0.w);
+              const float4 p1 = make_float4(q1.x * m1.x, q1.y * m1.y, q1.z * m1.z, q1.w * m1.w);
+              if (ok0) *reinterpret_cast<float4*>(P.c2 + oc2) = p0;
+              if (ok1) *reinterpret_cast<float4*>(P.c2 + oc2 + 16 * P.ldc2) = p1;
+              amax_acc(am2, p0);
+              amax_acc(am2, p1);
+            } else {                    // q = the raw input gradient v of h (.) g: dG = v h act_g'(g), dH = v g act_h'(h)
+              const float4 g0 = *reinterpret_cast<const float4*>(P.x2 + (int64_t)lrow0 * P.ld2 + cofs);
+              const float4 g1 = *reinterpret_cast<const float4*>(P.x2 + (int64_t)lrow1 * P.ld2 + cofs);
+              const int a1 = P.act1, a2 = P.act2;
+              float4 e0 = make_float4(q0.x * m0.x, q0.y * m0.y, q0.z * m0.z, q0.w * m0.w);
+              float4 e1 = make_float4(q1.x * m1.x, q1.y * m1.y, q1.z * m1.z, q1.w * m1.w);
+              if (a2 != MML_ACT_NONE) {
+                e0.x *= ws_act_bwd(g0.x, a2); e0.y *= ws_act_bwd(g0.y, a2); e0.z *= ws_act_bwd(g0.z, a2); e0.w *= ws_act_bwd(g0.w, a2);
+                e1.x *= ws_act_bwd(g1.x, a2); e1.y *= ws_act_bwd(g1.y, a2); e1.z *= ws_act_bwd(g1.z, a2); e1.w *= ws_act_bwd(g1.w, a2);
+              }
+              q0.x *= g0.x * ws_act_bwd(m0.x, a1); q0.y *= g0.y * ws_act_bwd(m0.y, a1);
+              q0.z *= g0.z * ws_act_bwd(m0.z, a1); q0.w *= g0.w * ws_act_bwd(m0.w, a1);
+              q1.x *= g1.x * ws_act_bwd(m1.x, a1); q1.y *= g1.y * ws_act_bwd(m1.y, a1);
+              q1.z *= g1.z * ws_act_bwd(m1.z, a1); q1.w *= g1.w * ws_act_bwd(m1.w, a1);
+              if (P.acc2) {
+                if (ok0) {
+                  const float4 o = *reinterpret_cast<const float4*>(P.c2 + oc2);
+                  e0.x += o.x; e0.y += o.y; e0.z += o.z; e0.w += o.w;
+                }
+                if (ok1) {
+                  const float4 o = *reinterpret_cast<const float4*>(P.c2 + oc2 + 16 * P.ldc2);
+                  e1.x += o.x; e1.y += o.y; e1.z += o.z; e1.w += o.w;
+                }
+              }
+              if (ok0) *reinterpret_cast<float4*>(P.c2 + oc2) = e0;
+              if (ok1) *reinterpret_cast<float4*>(P.c2 + oc2 + 16 * P.ldc2) = e1;
+              amax_acc(am2, e0);
+              amax_acc(am2, e1);
+              if (!P.accumulate) {  // (accumulating: the magnitude of the sums, below)
+                amax_acc(am, q0);
+                amax_acc(am, q1);
+              }
+            }
+          }
           if (MODE == 1 && P.accumulate) {
             if (ok0) {
               const float4 o = *reinterpret_cast<const float4*>(d0);
@@ -286,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
                 if (!(nib & 4u)) v.z = 0.f;
                 if (!(nib & 8u)) v.w = 0.f;
               }
-              if (!accumulate) amax_acc(am, v);  // (accumulating: the magnitude of the sums, taken behind the turn)
+              if (!accumulate && !K7) amax_acc(am, v);  // (accumulating / gate mode: the magnitude of what is stored, taken behind the turn)
               vv[g] = v;
             }
             turn_store(vv[0], vv[1], ni, 0);
@@ -306,6 +378,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const WsLaunch L) {
     if (lane == 0) atomicMax(word, __float_as_uint(am));
     __syncthreads();
     if (tid == 0 && *word) atomicMax(P.amax_out + (blockIdx.x & (MML_AMAX_WORDS - 1)), *word);
+  }
+  if constexpr (K7) {
+    if (P.amax_out2) {  // (uniform) the second output's magnitude: prod, or dG
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) am2 = fmaxf(am2, __shfl_xor(am2, o, 64));
+      uint32_t* const word2 = reinterpret_cast<uint32_t*>(lds) + WS_AMAX_OFF / 4 + 1;
+      if (lane == 0) atomicMax(word2, __float_as_uint(am2));
+      __syncthreads();
+      if (tid == 0 && *word2) atomicMax(P.amax_out2 + (blockIdx.x & (MML_AMAX_WORDS - 1)), *word2);
+    }
   }
 }
 
@@ -330,12 +412,23 @@ static int ws_cus() {
 }
 
 template <int MODE>
-static int ws_launch(const WsLaunch& L, const int nout, const bool masks, const int dgroup, hipStream_t st) {
+static int ws_launch(const WsLaunch& L, const int nout, const bool masks, const int dgroup, const bool k7, hipStream_t st) {
   const dim3 g((unsigned)(L.wg_per_prob * L.n_prob)), b(512);
 #define WS_GO2(NS_, D_)                                                                 \
   do {                                                                                  \
-    if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, true, D_>), g, b, 0, st, L);       \
+    if (k7) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false, D_, true>), g, b, 0, st, L);   \
+    else if (masks) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, true, D_>), g, b, 0, st, L);  \
     else MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false, D_>), g, b, 0, st, L);            \
+  } while (0)
+#define WS_GO8()                                                                              \
+  do {                                                                                        \
+    if (dgroup == 5) {                                                                        \
+      if (masks) MML_LAUNCH((gemm_ws_kernel<8, MODE, true, 5>), g, b, 0, st, L);              \
+      else MML_LAUNCH((gemm_ws_kernel<8, MODE, false, 5>), g, b, 0, st, L);                   \
+    } else {                                                                                  \
+      if (masks) MML_LAUNCH((gemm_ws_kernel<8, MODE, true, 4>), g, b, 0, st, L);              \
+      else MML_LAUNCH((gemm_ws_kernel<8, MODE, false, 4>), g, b, 0, st, L);                   \
+    }                                                                                         \
   } while (0)
 #define WS_GO(NS_)                 \
   do {                             \
@@ -344,9 +437,12 @@ static int ws_launch(const WsLaunch& L, const int nout, const bool masks, const 
   } while (0)
   if (nout == 64) WS_GO(2);
   else if (nout == 128) WS_GO(4);
-  else WS_GO(8);  // (256 output columns of an input gradient: eight sub-tiles at once -- swept in two passes of four the rows
+  else if (k7) return MML_ERR_UNSUPPORTED;  // (never reached: ws_fwd_ok / ws_dgrad_ok refuse 256-wide K7 problems --
+                                            //  eight sub-tiles of accumulators plus the factors' registers would spill)
+  else WS_GO8();  // (256 output columns of an input gradient: eight sub-tiles at once -- swept in two passes of four the rows
                   //  were read twice from HBM, PMC 300 MB against 138 algorithmic: 106 -> 93 us)
 #undef WS_GO
+#undef WS_GO8
 #undef WS_GO2
   return check_launch(MODE == 0 ? "mml_gemm_grouped_fwd(ws)" : "mml_gemm_grouped_dgrad(ws)");
 }
@@ -372,7 +468,12 @@ static bool ws_fwd_ok(const mml_gemm_fwd_desc& q, const mml_gemm_fwd_desc& d0) {
   if (q.N != 256 && q.N != 128 && q.N != 64) return false;  // (the instantiated output widths)
   if ((int64_t)q.N * q.K * 4 > WS_W_BYTES) return false;
   if (!q.A || !q.C || !q.w_planes || !q.w_kexp || !q.amax_a) return false;
-  if (q.mul || q.prod) return false;  // (K7 products: the tile kernel's epilogue)
+  if (q.mul || q.prod) {  // K7: prod = act(..) (.) mul from the same turn
+    if (!q.mul || !q.prod || q.ldmul < q.N || q.ldprod < q.N) return false;
+    if (!aligned16(q.mul) || q.ldmul % 4 != 0 || !aligned16(q.prod) || q.ldprod % 4 != 0) return false;
+    if (q.act == MML_ACT_RELU && q.relu_mask) return false;  // (no instantiation with sign masks: gates end in a sigmoid)
+    if (q.N == 256) return false;                            // (nor with eight sub-tiles: registers)
+  }
   if (q.act != MML_ACT_RELU && q.act != MML_ACT_NONE && q.act != MML_ACT_SIGMOID && q.act != MML_ACT_SIGMOID2) return false;
   if (!aligned16(q.A) || q.lda % 4 != 0 || !aligned16(q.C) || q.ldc % 4 != 0) return false;
   if (!q.w_kn && (!aligned16(q.w_planes) || q.ldw % 4 != 0)) return false;
@@ -391,11 +492,12 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
     const bool mi = d[i].act == MML_ACT_RELU && d[i].relu_mask != nullptr;
+    const bool ki = d[i].mul != nullptr;
     WsLaunch L{};
     for (int j = i; j < n; ++j) {
       const mml_gemm_fwd_desc& q = d[j];
       const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-      if (done[j] || q.N != d[i].N || m != mi || ws_dgroup(q.K) != ws_dgroup(d[i].K)) continue;
+      if (done[j] || q.N != d[i].N || m != mi || (q.mul != nullptr) != ki || ws_dgroup(q.K) != ws_dgroup(d[i].K)) continue;
       done[j] = true;
       WsProblem& P = L.p[L.n_prob++];
       P.A = q.A;
@@ -413,23 +515,40 @@ int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st) {
       P.layout = q.w_kn ? MML_PLANES_COLS : MML_PLANES_ROWS;  // ([K, N]: the reduction runs down the rows)
       P.act = q.act;
       P.G = q.K / (16 * ws_dgroup(q.K));
+      if (ki) {
+        P.x1 = q.mul; P.ld1 = q.ldmul; P.c2 = q.prod; P.ldc2 = q.ldprod; P.amax_out2 = q.amax_prod;
+      }
     }
     L.M = d0.M;
     L.wg_per_prob = ws_cus() / L.n_prob;
-    const int rc = ws_launch<0>(L, d[i].N, mi, ws_dgroup(d[i].K), st);
+    const int rc = ws_launch<0>(L, d[i].N, mi, ws_dgroup(d[i].K), ki, st);
     if (rc != MML_OK) return rc;
   }
   return MML_OK;
 }
 
 static bool ws_dgrad_ok(const mml_gemm_dgrad_desc& q, const mml_gemm_dgrad_desc& d0) {
-  if (q.n_src != 1 || q.gate_h || !q.dA || q.M != d0.M) return false;
+  if (q.n_src != 1 || q.M != d0.M) return false;
+  if (q.gate_h) {  // K7 gate mode: dH / dG instead of dA
+    if (!q.gate_g || !q.d_h || !q.d_g || q.ld_h < q.K || q.ld_g < q.K || q.ld_dh < q.K || q.ld_dg < q.K) return false;
+    if (!aligned16(q.gate_h) || !aligned16(q.gate_g) || !aligned16(q.d_h) || !aligned16(q.d_g) || q.ld_h % 4 != 0 ||
+        q.ld_g % 4 != 0 || q.ld_dh % 4 != 0 || q.ld_dg % 4 != 0)
+      return false;
+  } else if (!q.dA) {
+    return false;
+  }
   const int32_t kred = q.N[0];
   if (ws_dgroup(kred) == 0) return false;
   if (q.K != 64 && q.K != 128 && q.K != 256) return false;  // (the instantiated output widths)
   if ((int64_t)q.K * kred * 4 > WS_W_BYTES) return false;
   if (!q.dC[0] || !q.w_planes[0] || !q.w_kexp[0] || !q.amax_dc[0]) return false;
   const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
+  if (q.gate_h) {
+    if (m || q.Y || q.K == 256) return false;  // (gate mode: no derivative of the product itself; no 256-wide instantiation)
+    if (!aligned16(q.dC[0]) || q.lddc[0] % 4 != 0) return false;
+    if (q.w_kn[0] && (!aligned16(q.w_planes[0]) || q.ldw[0] % 4 != 0)) return false;
+    return true;
+  }
   if (q.act != MML_ACT_NONE && !m) return false;  // (derivatives from the stored outputs: the tile kernel)
   if (m && q.ldmask * 32 < q.K) return false;
   if (!aligned16(q.dC[0]) || q.lddc[0] % 4 != 0 || !aligned16(q.dA) || q.ldda % 4 != 0) return false;
@@ -448,18 +567,25 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
   // launched in the order of their first members -- neither keeps the call's order.  Left to the tile kernel (the
   // engine never builds such a call: chunks of one input go into different launches).
   for (int i = 0; i < n; ++i)
-    for (int j = i + 1; j < n; ++j)
-      if (d[i].dA == d[j].dA) return MML_ERR_UNSUPPORTED;
+    for (int j = i + 1; j < n; ++j) {
+      const float* ti[2] = {d[i].gate_h ? d[i].d_h : d[i].dA, d[i].gate_h ? d[i].d_g : nullptr};
+      const float* tj[2] = {d[j].gate_h ? d[j].d_h : d[j].dA, d[j].gate_h ? d[j].d_g : nullptr};
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          if (ti[a] && ti[a] == tj[b]) return MML_ERR_UNSUPPORTED;
+    }
   if (n > ws_cus()) return MML_ERR_UNSUPPORTED;  // (every class gets >= 1 workgroup per problem: decided BEFORE the first launch)
   bool done[MML_MAX_GROUP] = {};
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
     const bool mi = d[i].act == MML_ACT_RELU && d[i].relu_mask != nullptr;
+    const bool ki = d[i].gate_h != nullptr;
     WsLaunch L{};
     for (int j = i; j < n; ++j) {
       const mml_gemm_dgrad_desc& q = d[j];
       const bool m = q.act == MML_ACT_RELU && q.relu_mask != nullptr;
-      if (done[j] || q.K != d[i].K || m != mi || ws_dgroup(q.N[0]) != ws_dgroup(d[i].N[0])) continue;
+      if (done[j] || q.K != d[i].K || m != mi || (q.gate_h != nullptr) != ki || ws_dgroup(q.N[0]) != ws_dgroup(d[i].N[0]))
+        continue;
       done[j] = true;
       WsProblem& P = L.p[L.n_prob++];
       P.A = q.dC[0];
@@ -476,10 +602,16 @@ int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t s
       P.layout = q.w_kn[0] ? MML_PLANES_ROWS : MML_PLANES_COLS;  // ([N, K]: the reduction runs down the rows)
       P.accumulate = q.accumulate;
       P.G = q.N[0] / (16 * ws_dgroup(q.N[0]));
+      if (ki) {
+        P.C = q.d_h; P.ldc = q.ld_dh; P.accumulate = q.acc_h; P.amax_out = q.amax_dh; P.mask = nullptr;
+        P.x1 = q.gate_h; P.ld1 = q.ld_h; P.act1 = q.act_h;
+        P.x2 = q.gate_g; P.ld2 = q.ld_g; P.act2 = q.act_g;
+        P.c2 = q.d_g; P.ldc2 = q.ld_dg; P.acc2 = q.acc_g; P.amax_out2 = q.amax_dg;
+      }
     }
     L.M = d0.M;
     L.wg_per_prob = ws_cus() / L.n_prob;  // (>= 1: n <= ws_cus() was checked before the first launch)
-    const int rc = ws_launch<1>(L, d[i].K, mi, ws_dgroup(d[i].N[0]), st);
+    const int rc = ws_launch<1>(L, d[i].K, mi, ws_dgroup(d[i].N[0]), ki, st);
     if (rc != MML_OK) return rc;
   }
   return MML_OK;

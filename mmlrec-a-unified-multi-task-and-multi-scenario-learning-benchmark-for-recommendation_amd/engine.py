@@ -1019,7 +1019,10 @@ class LinearGroupOp(Op):
         self.p = problems
         self.use16 = False  # bf16-storage path (csrc/gemm16.hip): decided when the forward is recorded
         for q in self.p:
-            if q.get("mul") is not None:
+            # prod_bwd = "ext": only the FORWARD of the product rides in this launch's epilogue; its backward belongs to
+            # another op (MulBatchOp(fwd_fused=True)) -- products no Linear layer reads (PepNet's gated input, the
+            # products in front of the heads)
+            if q.get("mul") is not None and q.get("prod_bwd") != "ext":
                 q["prod"].gate = (q["mul"], q["out"])  # (h, g): factors of the product, for the consumer's dgrad
 
     def writes_grad16(self, plan, v):
@@ -1135,7 +1138,8 @@ class LinearGroupOp(Op):
         return calls
 
     def inputs(self):
-        return [q["x"] for q in self.p] + [q["mul"] for q in self.p if q.get("mul") is not None]
+        return [q["x"] for q in self.p] + [q["mul"] for q in self.p
+                                           if q.get("mul") is not None and q.get("prod_bwd") != "ext"]
 
     def outputs(self):
         return [q["out"] for q in self.p] + [q["prod"] for q in self.p if q.get("mul") is not None]
@@ -2063,9 +2067,12 @@ class MulBatchOp(Op):
     with the derivative of the activation that produced the operand folded in when this op is its only consumer.
     items: (a Val, b Val, out Val)."""
 
-    def __init__(self, items):
+    def __init__(self, items, fwd_fused=False):
         self.items = items
         self.flat = [MulOp._flat_numel(it) for it in items]
+        # True: the products themselves leave the epilogue of the GEMM that produces b (LinearGroupOp problems with mul /
+        # prod and prod_bwd = "ext": K7 forward); this op only contributes the backward
+        self.fwd_fused = bool(fwd_fused)
 
     def inputs(self):
         return [v for a, b, _ in self.items for v in (a, b)]
@@ -2089,6 +2096,8 @@ class MulBatchOp(Op):
         return arr
 
     def fwd_calls(self, plan):
+        if self.fwd_fused:
+            return []
         rows = []
         for (a, b, o), n in zip(self.items, self.flat):
             # the product's magnitude for the GEMMs that read it (only when the flat launch covers no padding columns)

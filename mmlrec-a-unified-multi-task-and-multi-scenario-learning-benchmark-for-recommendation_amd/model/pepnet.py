@@ -83,9 +83,11 @@ class PepNet(BaseModel):
 
     def _gate_out(self, plan, store, items, fuse):
         """Second layer (Linear + 2 * sigmoid) of gate networks and the products x (.) gate (reference pepnet.py:31-32,
-        :72-78): items = (prefix, gate hidden value, x value, product value).  fuse: K7 -- the product leaves the GEMM's
-        epilogue (mml_pep_gate_fwd) and its backward rides on the input-gradient launch of the layer that reads it
-        (mml_pep_gate_bwd); else one batched element-wise launch each way (the product feeds the heads)."""
+        :72-78): items = (prefix, gate hidden value, x value, product value).  fuse: K7 -- "full": the product leaves the
+        GEMM's epilogue (mml_pep_gate_fwd) and its backward rides on the input-gradient launch of the layer that reads it
+        (mml_pep_gate_bwd); "fwd": the forward alone, the backward one batched element-wise launch (products no Linear
+        layer reads: the gated input, the products in front of the heads); False: one batched element-wise launch each
+        way."""
         l2 = []
         for pfx, hg, x, prod in items:
             w2 = store.pvals[f"{pfx}.gate.2.weight"]
@@ -93,10 +95,13 @@ class PepNet(BaseModel):
             q = dict(x=hg, W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g)
             if fuse:
                 q.update(mul=x, prod=prod)
+                if fuse == "fwd":
+                    q["prod_bwd"] = "ext"
             l2.append(q)
         plan.add(E.LinearGroupOp(l2))
-        if not fuse:
-            plan.add(E.MulBatchOp([(x, q["out"], prod) for (pfx, hg, x, prod), q in zip(items, l2)]))
+        if fuse != "full":
+            plan.add(E.MulBatchOp([(x, q["out"], prod) for (pfx, hg, x, prod), q in zip(items, l2)],
+                                  fwd_fused=(fuse == "fwd")))
 
     def _build_graph(self, plan, store, x0):
         import os
@@ -113,7 +118,14 @@ class PepNet(BaseModel):
         # products lose (0.58 -> 0.28 ms) the GEMMs give back -- their epilogues load the extra operands (the LDS-DMA
         # pipeline drains at every tile) and the gate mode only fits 128 x 64 tiles.  Fusing the forward alone is a loss
         # (2.58 ms: the activation derivatives no longer fold into a single consumer).
-        fuse_on = os.environ.get("MMLREC_PEP_FUSE", "0") == "1" and plan.device.type == "cuda"
+        # Round 6: ON from 8 192 samples, where the weight-stationary kernel (csrc/gemm_ws.hip) serves these layers: its
+        # turn stores 16 bytes per lane row-major, so the extra operands of the product (forward) and of the gate mode
+        # (backward) are read and written in the same whole-line pieces as the outputs, with no pipeline to drain; the
+        # forward of the two products no Linear layer reads (the gated input, the products in front of the heads) rides
+        # in its gate GEMM's epilogue as well ("fwd").  Below 8 192 the tile kernel would serve them: off (see above).
+        env = os.environ.get("MMLREC_PEP_FUSE")
+        fuse_on = plan.device.type == "cuda" and (env == "1" or (env is None and plan.B >= 8192))
+        fuse_fwd = fuse_on and os.environ.get("MMLREC_PEP_FUSE_FWD", "1") != "0"
 
         def can_fuse(n):
             return fuse_on and n % 16 == 0
@@ -130,7 +142,7 @@ class PepNet(BaseModel):
         x2 = plan.val(K0, name="gated_input", pad_k=True)
         # (not fused: the gated input feeds the tasks' first PRODUCTS, not a Linear layer whose input-gradient launch
         # could carry its backward)
-        self._gate_out(plan, store, [("feature_gate", fh, x0, x2)], fuse=False)
+        self._gate_out(plan, store, [("feature_gate", fh, x0, x2)], fuse="fwd" if (fuse_fwd and can_fuse(K0)) else False)
         gin = gate_input(x2, "ppnet_in")
         # PPNet: the hidden layers of ALL gate networks read the same input: one grouped launch
         ghs = self._gate_hidden(plan, store, [(f"ppn.{t}.gate_layers.{l}", gin) for t in range(T) for l in range(nl + 1)])
@@ -140,7 +152,8 @@ class PepNet(BaseModel):
             hins = [plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True) for t in range(T)]
             # the gate products of all tasks of this layer: fused into the gates' output GEMM where the product feeds a
             # Linear layer (l < nl), one batched launch each way in front of the heads
-            fuse = l < nl and all(can_fuse(hidden[t].n) for t in range(T))  # (the last product feeds the heads)
+            ok = all(can_fuse(hidden[t].n) for t in range(T))
+            fuse = ("full" if l < nl else ("fwd" if fuse_fwd else False)) if ok else False  # (the last product feeds the heads)
             self._gate_out(plan, store, [(f"ppn.{t}.gate_layers.{l}", ghs[t * (nl + 1) + l], hidden[t], hins[t])
                                          for t in range(T)], fuse=fuse)
             if l < nl:

@@ -273,3 +273,97 @@ def test_ws_kernels_are_repeatable_on_a_full_chip(env):
         assert name == "gemm_ws_kernel"
         for i, ((dA, am), (dAt, amt)) in enumerate(zip(out, dref)):
             assert torch.equal(dA, dAt), (rep, i, int((dA != dAt).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K7 (round 6): PepNet's gate products in the weight-stationary kernel's turn (reference model/pepnet.py:64-78, :139-140)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,nprob", [
+    (65536, 64, 64, 4),        # the four tasks' first-layer gates of Amazon-8 PepNet (gate hidden 64 -> K0 = 64)
+    (8192 + 77, 128, 128, 3),  # hidden-layer gates (128 -> 128), ragged batch
+    (16384, 80, 64, 2),        # a reduction of 80 (one group of five k-steps)
+])
+def test_ws_fwd_with_gate_product(env, M, K, N, nprob):
+    """C = 2 sigmoid(A W^T + b) and prod = C (.) mul from the same turn: against float64, and C / prod / both magnitude
+    slots bit for bit against the tile kernel's K7 epilogue."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    probs = fwd_launch(torch, L, ops, M, K, N, nprob, acts=[L.ACT_SIGMOID2] * nprob, seed=M + N)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for p in probs:
+        p["mul"] = torch.randn(M, N, generator=g).to(dev)
+        p["amax_prod"] = ops.amax_slots(1, dev)[0]
+    res = {}
+    for ws in (True, False):
+        for p in probs:
+            p["prod"] = torch.full((M, N), float("nan"), device=dev)
+            p["amax_prod"].zero_()
+        name, out = run_fwd(torch, ops, lib, probs, ws, False)
+        assert (name == "gemm_ws_kernel") == ws, name
+        res[ws] = [(C, p["prod"].clone(), am, p["amax_prod"].clone()) for p, (C, _, am) in zip(probs, out)]
+    for p, (C, prod, am, am2), (Ct, prodt, amt, am2t) in zip(probs, res[True], res[False]):
+        z = p["A"].double() @ p["W"].double().t() + (p["bias"].double() if p["bias"] is not None else 0.0)
+        c = 2 * torch.sigmoid(z)
+        assert float((C.double() - c).abs().max() / c.abs().max()) < RTOL
+        pr = c * p["mul"].double()
+        assert float((prod.double() - pr).abs().max() / pr.abs().max()) < RTOL
+        assert torch.equal(C, Ct) and torch.equal(prod, prodt)
+        a2 = float(torch.max(am2.view(torch.float32)))
+        assert a2 >= float(prod.abs().max()) and a2 <= float(prod.abs().max()) * (1 + 1e-6)
+        assert float(torch.max(am.view(torch.float32))) == float(torch.max(amt.view(torch.float32)))
+        assert a2 == float(torch.max(am2t.view(torch.float32)))
+
+
+@pytest.mark.parametrize("M,Nred,K,nprob,act_h,acc_h,acc_g", [
+    (65536, 128, 64, 4, "none", 0, 0),     # first PPNet layer of four tasks: h = the gated input, K0 = 64
+    (8192 + 77, 128, 128, 3, "relu", 0, 0),  # second layer: h = the ReLU output of the layer before
+    (8192, 128, 64, 1, "none", 1, 1),      # accumulating into both factors' gradients
+    (16384, 80, 128, 2, "relu", 1, 0),     # a reduction of 80
+])
+def test_ws_dgrad_gate_mode(env, M, Nred, K, nprob, act_h, acc_h, acc_g):
+    """v = dC W is not stored: dH (+)= v g act_h'(h), dG (+)= v h act_g'(g) -- against float64 and, bit for bit, against
+    the tile kernel's gate mode; both magnitude slots."""
+    torch, L, ops, lib = env
+    lib.mml_gemm_set_mode(4)
+    dev = torch.device("cuda:0")
+    probs = dgrad_launch(torch, L, ops, M, Nred, K, nprob, relu=False, seed=M + K)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gates = []
+    for p in probs:
+        h = torch.randn(M, K, generator=g)
+        if act_h == "relu":
+            h = torch.relu(h)
+        gt = 2 * torch.sigmoid(torch.randn(M, K, generator=g))
+        gates.append(dict(h=h.to(dev), g=gt.to(dev), old_h=torch.randn(M, K, generator=g).to(dev),
+                          old_g=torch.randn(M, K, generator=g).to(dev), slots=ops.amax_slots(2, dev)))
+    res = {}
+    for ws in (True, False):
+        lib.mml_gemm_set_ws(1 if ws else 0)
+        launch = []
+        for p, q in zip(probs, gates):
+            q["dh"] = q["old_h"].clone() if acc_h else torch.full((M, K), float("nan"), device=dev)
+            q["dg"] = q["old_g"].clone() if acc_g else torch.full((M, K), float("nan"), device=dev)
+            q["slots"].zero_()
+            launch.append(dict(dA=None, Y=None, act=L.ACT_NONE, srcs=p["srcs"],
+                               gate=dict(h=q["h"], g=q["g"], dh=q["dh"], dg=q["dg"],
+                                         act_h=L.ACT_RELU if act_h == "relu" else L.ACT_NONE, act_g=L.ACT_SIGMOID2,
+                                         acc_h=acc_h, acc_g=acc_g, amax_dh=q["slots"][0], amax_dg=q["slots"][1])))
+        arr = ops.make_dgrad_descs(launch)
+        L.check(lib.mml_pep_gate_bwd(arr, len(launch), ops._stream()), "mml_pep_gate_bwd")
+        torch.cuda.synchronize()
+        name = lib.mml_gemm_last_kernel().decode()
+        assert (name == "gemm_ws_kernel") == ws, name
+        res[ws] = [(q["dh"].clone(), q["dg"].clone(), q["slots"].clone()) for q in gates]
+    for p, q, (dh, dg, sl), (dht, dgt, slt) in zip(probs, gates, res[True], res[False]):
+        dC, W = p["srcs"][0][:2]
+        v = dC.double() @ W.double()
+        gd, hd = q["g"].double(), q["h"].double()
+        ref_h = v * gd * ((hd > 0).double() if act_h == "relu" else 1.0) + (q["old_h"].double() if acc_h else 0.0)
+        ref_g = v * hd * (gd * (1 - gd / 2)) + (q["old_g"].double() if acc_g else 0.0)
+        assert float((dh.double() - ref_h).abs().max() / ref_h.abs().max()) < RTOL
+        assert float((dg.double() - ref_g).abs().max() / ref_g.abs().max()) < RTOL
+        assert torch.equal(dh, dht) and torch.equal(dg, dgt)
+        for t, s in ((dh, sl[0]), (dg, sl[1])):
+            am = float(torch.max(s.view(torch.float32)))
+            assert am >= float(t.abs().max()) and am <= float(t.abs().max()) * (1 + 1e-6)
