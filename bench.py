@@ -532,6 +532,28 @@ def expected_collectives(args, world, main_r):
             "all_reduce_ring_MB": round(2 * arena * (world - 1) / max(world, 1) / 1e6, 4)}
 
 
+def check_collectives(cps, exp, world):
+    """Do the collectives counted inside the timed region (parallel.Comm's host-side counters, per step) agree with
+    DESIGN section 5's model?  Calls exactly; bytes within 15 % (the model prices the batch-0 row set, the four resident
+    batches differ by a few per cent; the count exchange's few bytes are not in the model).  None: no model for this mode."""
+    if exp is None or cps is None:
+        return None
+    a2a = {k: v for k, v in cps.items() if k.startswith("all_to_all")}
+    ar = {k: v for k, v in cps.items() if k.startswith("all_reduce")}
+    calls_a2a = sum(v["calls"] for v in a2a.values())
+    calls_ar = sum(v["calls"] for v in ar.values())
+    sent = sum(v["bytes_sent"] for v in a2a.values()) / 1e6
+    want = exp["keys_MB"] + 2 * exp["rows_MB_each_way"]
+    out = {"all_to_all_calls": [round(calls_a2a, 3), exp["all_to_all_calls"]],
+           "all_reduce_calls": [round(calls_ar, 3), exp["all_reduce_calls"]],
+           "all_to_all_MB_sent": [round(sent, 4), round(want, 4)]}
+    ok = abs(calls_a2a - exp["all_to_all_calls"]) < 1e-6 and abs(calls_ar - exp["all_reduce_calls"]) < 1e-6
+    if world > 1:
+        ok = ok and abs(sent - want) <= 0.15 * want + 0.01
+    out["ok"] = bool(ok)
+    return out
+
+
 def describe_workload(name, cfg, vocab, dense):
     mc = cfg["model_config"]
     keys = {"mmoe": ("expert", "gate", "tower"), "ple": ("expert", "gate", "tower"),
@@ -593,6 +615,17 @@ def main():
         batches = make_batches(B)
         runner = model.train_step_runner(B, use_graph=not args.no_graph, allreduce=allreduce, overlap=(args.streams == 2 and not args.serial),
                                          split_dense="force" if args.split_dense else False)
+        if B == args.batch and getattr(model, "_parallel", None) is not None:
+            # PREFLIGHT (before anything is timed; every rank computes it, rank 0 prints it): what DESIGN section 5's model
+            # says one step of THIS run exchanges per rank -- the JSON line repeats it next to what was counted inside the
+            # timed region and says whether the two agree (collectives_per_step.check)
+            Xi = batches[0][0][:, :len(vocab)].long()
+            pre = dict(distinct_rows=int(sum(torch.unique(Xi[:, f]).numel() for f in range(len(vocab)))),
+                       emb=int(cfg["model_config"]["emb"]), arena_bytes=int(runner.store.arena.numel() * 4))
+            exp = expected_collectives(args, world, pre)
+            if rank == 0:
+                print("bench.py preflight: world %d, mode %s, batch %d per rank -> expected per step and rank: %s"
+                      % (world, args.parallel_mode, B, json.dumps(exp)), file=sys.stderr, flush=True)
         steps = args.steps if B == args.batch else max(args.steps, 50)
         warm_losses = [] if (B == args.batch and world == 1 and getattr(model, "_parallel", None) is None) else None
         dt = timed_steps(runner, batches, steps, args.warmup, dist, warm_losses=warm_losses)
@@ -769,7 +802,9 @@ def main():
         # counts, keys, rows, row gradients) + 1 all-reduce (the MLP gradient arena) per step.
         line["collectives_per_step"] = {k: {"calls": round(v["calls"], 3), "MB_sent": round(v["bytes_sent"] / 1e6, 4),
                                             "MB_received": round(v["bytes_received"] / 1e6, 4)} for k, v in cps.items()}
-        line["collectives_per_step"]["expected"] = expected_collectives(args, world, main_r)
+        exp = expected_collectives(args, world, main_r)
+        line["collectives_per_step"]["expected"] = exp
+        line["collectives_per_step"]["check"] = check_collectives(cps, exp, world)
     if args.alt_batch and args.alt_batch in results:
         r = results[args.alt_batch]
         line["alt"] = {"batch_per_gpu": args.alt_batch, "value": round(r["value"], 1), "unit": "samples/s",
