@@ -527,6 +527,17 @@ typedef struct {
   int32_t h_relu;
   int32_t n_bias2;
   int32_t mask_col;  /* column of `mask` multiplied into the probability, or -1                        */
+  /* Gated head (round 6; PepNet, reference model/pepnet.py:72-78: the last PPNet layer reads h (.) 2 sigmoid(gate)):
+   * gate != NULL -> the head's input is Hin (.) gate, formed in registers (the product never goes to memory);
+   * backward: dH = dlogit w gate (* relu'(Hin) if h_relu), dgate = dlogit w Hin act'(gate) with act = gate_act
+   * (MML_ACT_NONE / SIGMOID / SIGMOID2, the derivative taken from the stored gate value), dw = sum_b dlogit Hin gate.
+   * Served by the fast row kernel only (H % 4 == 0, H <= 256, 16-byte aligned rows; fp32 dH): anything else is
+   * MML_ERR_UNSUPPORTED. */
+  const float* gate; /* [B, H] or NULL                                                                 */
+  float* dgate;      /* [B, H] backward (required when gate != NULL and the group trains)              */
+  int64_t ldgate, lddgate;
+  int32_t gate_act;
+  int32_t pad_;
 } mml_head_desc;
 typedef struct {
   int32_t n_heads;
@@ -543,6 +554,7 @@ typedef struct {
   int64_t lddprob;
   mml_head_desc head[MML_MAX_HEADS];
   uint32_t* amax_dH;  /* optional operand-magnitude slot raised with max |dH| over all heads (training), or NULL */
+  uint32_t* amax_dG;  /* the same for max |dgate| over all gated heads, or NULL                                   */
 } mml_head_group;
 int64_t mml_head_workspace_bytes(const mml_head_group* grp);
 int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream);

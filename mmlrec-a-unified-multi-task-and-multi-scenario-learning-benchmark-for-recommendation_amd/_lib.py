@@ -98,13 +98,14 @@ class GateGroup(C.Structure):
 class HeadDesc(C.Structure):
     _fields_ = [("Hin", fp), ("w", fp), ("w2", fp), ("bias", fp), ("bias2", fp), ("dH", fp), ("dw", fp),
                 ("dbias", fp), ("ldh", i64), ("lddh", i64), ("H", i32), ("h_relu", i32), ("n_bias2", i32),
-                ("mask_col", i32)]
+                ("mask_col", i32), ("gate", fp), ("dgate", fp), ("ldgate", i64), ("lddgate", i64),
+                ("gate_act", i32), ("pad_", i32)]
 
 
 class HeadGroup(C.Structure):
     _fields_ = [("n_heads", i32), ("dh_bf16", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
                 ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("dprob", fp), ("lddprob", i64),
-                ("head", HeadDesc * MAX_HEADS), ("amax_dH", fp)]
+                ("head", HeadDesc * MAX_HEADS), ("amax_dH", fp), ("amax_dG", fp)]
 
 
 class OptTensor(C.Structure):

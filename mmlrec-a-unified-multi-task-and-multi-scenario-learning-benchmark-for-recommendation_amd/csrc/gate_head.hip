@@ -422,6 +422,12 @@ extern "C" int mml_gate_mix_bwd_phase(const mml_gate_group* grp, void* workspace
   return launch_slab_reduce(R, to_stream(stream), "mml_gate_mix_bwd(reduce)");
 }
 
+static bool head_group_gated(const mml_head_group* g) {
+  for (int t = 0; t < g->n_heads; ++t)
+    if (g->head[t].gate) return true;
+  return false;
+}
+
 static int check_head_group(const mml_head_group* g, bool train, const char* who, int& hmax) {
   MML_REQUIRE(g, "%s: null group", who);
   MML_REQUIRE(g->n_heads >= 1 && g->n_heads <= MML_MAX_HEADS && g->B >= 0, "%s: n_heads=%d", who, g->n_heads);
@@ -436,6 +442,10 @@ static int check_head_group(const mml_head_group* g, bool train, const char* who
     MML_REQUIRE(d.n_bias2 == 0 || d.bias2, "%s: head %d bias2 null", who, t);
     MML_REQUIRE(!train || (d.dH && d.dw && d.dbias && d.lddh >= d.H), "%s: head %d backward buffers", who, t);
     MML_REQUIRE(d.mask_col < 0 || g->mask, "%s: head %d wants a mask column but mask is null", who, t);
+    MML_REQUIRE(!d.gate || (d.ldgate >= d.H && (!train || (d.dgate && d.lddgate >= d.H))),
+                "%s: gated head %d: gate pitch / dgate", who, t);
+    MML_REQUIRE(!d.gate || d.gate_act == MML_ACT_NONE || d.gate_act == MML_ACT_SIGMOID || d.gate_act == MML_ACT_SIGMOID2,
+                "%s: gated head %d: gate_act must be none, sigmoid or 2 sigmoid", who, t);
     if (d.H > hmax) hmax = d.H;
   }
   return MML_OK;
@@ -457,6 +467,10 @@ extern "C" int mml_head_fwd(const mml_head_group* grp, mml_stream_t stream) {
   {
     HeadFastAux fa{};
     if (head_fast_config(grp, false, hmax, fa)) return head_fast(grp, fa, to_stream(stream));
+  }
+  if (head_group_gated(grp)) {
+    set_error("mml_head_fwd: gated heads on a shape the fast row kernel does not serve");
+    return MML_ERR_UNSUPPORTED;
   }
   HeadAux aux{};
   aux.hmax = hmax;
@@ -493,8 +507,8 @@ extern "C" int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* works
       fa.slab = aux.slab; fa.stride = aux.stride; fa.train = 1;
       rc = head_fast(grp, fa, to_stream(stream));
     } else {
-      if (grp->dh_bf16) {
-        set_error("mml_head_bce_fwd_bwd: dh_bf16 on a shape the fast row kernel does not serve");
+      if (grp->dh_bf16 || head_group_gated(grp)) {
+        set_error("mml_head_bce_fwd_bwd: dh_bf16 / gated heads on a shape the fast row kernel does not serve");
         return MML_ERR_UNSUPPORTED;
       }
       MML_LAUNCH(head_kernel, dim3(grid), dim3(ROW_BLOCK), 0, to_stream(stream), *grp, aux);

@@ -20,6 +20,8 @@
 #include "common.hpp"
 #include "lds_async.hpp"
 
+#include <stdlib.h>
+
 namespace mml {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -162,8 +164,13 @@ struct G16TnLaunch {
 // microarchitecture guide, LDS) -- conflict-free.  The DMA writes LDS linearly, so the swizzle is applied to the SOURCE.
 __device__ __forceinline__ int tn_swz(int row) { return (row >> 1) & 7; }
 
+// BN = 256 (round 6): a wave's tile is 64 x 128 -- per 16-k block it reads 2 + 4 fragments for 8 MFMAs (0.75 reads per
+// MFMA) where the 64 x 64 wave tile of BN = 128 reads 2 + 2 for 4 (1.0).  A CU's LDS delivers one 1 KiB fragment read in 8
+// clocks to ONE of its four SIMDs, an MFMA occupies its SIMD for 32: at one read per MFMA the LDS pipe is exactly as busy as
+// the matrix pipes and every hiccup of it stalls them (KuaiRec-32's 512-wide layers ran at 0.17-0.24 of the bf16 peak).  128
+// accumulator registers -> two workgroups per CU (48 KiB of LDS each).
 template <int BN>
-__global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLaunch L) {
+__global__ __launch_bounds__(256, BN == 256 ? 2 : G16_TN_WAVES) void g16_tn_kernel(const G16TnLaunch L) {
   constexpr int NJ = BN / 64;  // 32-column subtiles per wave along N (waves 2 x 2: wave tile 64 x BN/2)
   __shared__ __attribute__((aligned(16))) uint16_t lds[(128 + BN) * 64];
   uint16_t* const sA = lds;
@@ -249,26 +256,37 @@ __global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLa
   // word per element.  Instead every wave turns its 64 x BN/2 tile row-major through its quarter of the (now idle)
   // operand LDS and stores 16 bytes per lane -- whole 128-byte lines; the ReLU sign masks are formed from / applied to the
   // eight (bf16) or four (fp32) consecutive values a lane then holds (a quad of lanes = one 32-column mask word).
-  constexpr int WTN = BN / 2;                     // columns of a wave's tile
-  constexpr int REGION = (128 + BN) * 64 / 4;     // bf16 elements of LDS per wave (8 KiB at BN = 128, 6 KiB at 64)
+  // A wave's tile goes through the turn in passes of at most 64 columns (NJP sub-tiles): BN = 256 makes two passes over
+  // the same LDS region (its 12 KiB per wave hold 64 rows x 64 columns of bf16, or 32 x 64 of fp32, as at BN = 128).
+  constexpr int NJP = NJ < 2 ? NJ : 2;            // sub-tiles per pass
+  constexpr int WTN = NJP * 32;                   // columns of a pass
+  constexpr int REGION = (128 + BN) * 64 / 4;     // bf16 elements of LDS per wave (12 KiB at BN = 256, 8 at 128, 6 at 64)
   uint16_t* const stage = lds + w * REGION;
   const int h = lane >> 5, c31 = lane & 31;
   const int64_t mrow0 = m0 + wm * 64;
-  const int ncol0 = n0 + wn * WTN;
-  float bias[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) bias[j] = P.bias ? P.bias[ncol0 + j * 32 + c31] : 0.f;
   const bool relu = P.act == MML_ACT_RELU;
+#pragma unroll
+  for (int pass = 0; pass < NJ / NJP; ++pass) {
+  if (pass) {  // (the previous pass's row-major reads are done before its region is overwritten)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int ncol0 = n0 + wn * (BN / 2) + pass * WTN;
+  float bias[NJP];
+  f32x16 (&accp)[2][NJ] = acc;
+#pragma unroll
+  for (int j = 0; j < NJP; ++j) bias[j] = P.bias ? P.bias[ncol0 + j * 32 + c31] : 0.f;
+#define ACC(i_, j_) accp[i_][pass * NJP + (j_)]
 
   if (P.c_bf16) {
     // write: pairs of columns packed; even lanes store the pair of reg r, odd lanes the pair of reg r + 1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJP; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          float va = acc[i][j][r] + bias[j], vb = acc[i][j][r + 1] + bias[j];
+          float va = ACC(i, j)[r] + bias[j], vb = ACC(i, j)[r + 1] + bias[j];
           if (relu) {
             va = fmaxf(va, 0.f);
             vb = fmaxf(vb, 0.f);
@@ -330,10 +348,10 @@ __global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLa
         __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJP; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bias[j];
+          float v = ACC(i, j)[r] + bias[j];
           if (relu) v = fmaxf(v, 0.f);
           st32[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + c31] = v;
         }
@@ -369,6 +387,8 @@ __global__ __launch_bounds__(256, G16_TN_WAVES) void g16_tn_kernel(const G16TnLa
       }
     }
   }
+  }  // pass
+#undef ACC
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -629,19 +649,15 @@ extern "C" int mml_gather16_fwd(const float* const* tables, const int64_t* vocab
   return check_launch("mml_gather16_fwd");
 }
 
-extern "C" int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stream) {
-  MML_REQUIRE(d != nullptr, "mml_g16_tn: descriptor array is null");
-  MML_REQUIRE(n >= 1 && n <= G16_MAX_GROUP, "mml_g16_tn: 1 .. %d problems per launch", G16_MAX_GROUP);
+// one kernel launch over problems that share a tile width
+static int g16_tn_launch(const mml_g16_tn_desc* d, const int* idx, int n, int bn, hipStream_t st) {
   G16TnLaunch L{};
   L.n_prob = n;
-  L.M = d[0].M;
-  MML_REQUIRE(L.M > 0 && L.M % 128 == 0, "mml_g16_tn: M must be a positive multiple of 128");
-  bool all128 = true;
-  for (int i = 0; i < n; ++i) all128 = all128 && d[i].N % 128 == 0;
-  const int bn = all128 ? 128 : 64;
-  for (int i = 0; i < n; ++i) {
+  L.M = d[idx[0]].M;
+  for (int k = 0; k < n; ++k) {
+    const int i = idx[k];
     const mml_g16_tn_desc& q = d[i];
-    G16TnProblem& P = L.p[i];
+    G16TnProblem& P = L.p[k];
     MML_REQUIRE(q.M == L.M, "mml_g16_tn: the problems of a launch share M");
     MML_REQUIRE(q.N > 0 && q.N % 64 == 0, "mml_g16_tn: N must be a positive multiple of 64 (problem %d)", i);
     MML_REQUIRE(q.n_src >= 1 && q.n_src <= MML_MAX_SRC, "mml_g16_tn: n_src out of range (problem %d)", i);
@@ -665,14 +681,59 @@ extern "C" int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stre
   }
   const int64_t grid = (int64_t)(L.M / 128) * L.tiles_per_mblock;
   MML_REQUIRE(grid <= 0x7fffffff, "mml_g16_tn: too many tiles");
-  if (bn == 128) {
-    MML_LAUNCH(g16_tn_kernel<128>, dim3((unsigned)grid), dim3(256), 0, to_stream(stream), L);
+  if (bn == 256) {
+    MML_LAUNCH(g16_tn_kernel<256>, dim3((unsigned)grid), dim3(256), 0, st, L);
+    g16_last = "g16_tn_kernel<256>";
+  } else if (bn == 128) {
+    MML_LAUNCH(g16_tn_kernel<128>, dim3((unsigned)grid), dim3(256), 0, st, L);
     g16_last = "g16_tn_kernel<128>";
   } else {
-    MML_LAUNCH(g16_tn_kernel<64>, dim3((unsigned)grid), dim3(256), 0, to_stream(stream), L);
+    MML_LAUNCH(g16_tn_kernel<64>, dim3((unsigned)grid), dim3(256), 0, st, L);
     g16_last = "g16_tn_kernel<64>";
   }
   return check_launch("mml_g16_tn");
+}
+
+// Widest tile the launches of mml_g16_tn may use (process-wide; MMLREC_G16_BN = 64 / 128 / 256, default 256): a lab knob.
+static int g16_bn_max() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("MMLREC_G16_BN");
+    v = (e && atoi(e) > 0) ? atoi(e) : 256;
+  }
+  return v;
+}
+
+extern "C" int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stream) {
+  MML_REQUIRE(d != nullptr, "mml_g16_tn: descriptor array is null");
+  MML_REQUIRE(n >= 1 && n <= G16_MAX_GROUP, "mml_g16_tn: 1 .. %d problems per launch", G16_MAX_GROUP);
+  MML_REQUIRE(d[0].M > 0 && d[0].M % 128 == 0, "mml_g16_tn: M must be a positive multiple of 128");
+  // The problems whose width is a multiple of 256 (at batches that still fill the chip with 128 x 256 tiles) run 128 x 256
+  // tiles in a launch of their own; the others share 128 x 128 tiles, or 128 x 64 as soon as one width is not a multiple of
+  // 128 (the rule of round 5).  Problems of one call are independent: two launches in a row.
+  // Measured (KuaiRec-32 at B = 65 536, three interleaved pairs, tools/lab/ab_g16_bn.sh): the wide tiles win where the
+  // reduction is LONG -- the first layers' input gradient, one problem of 2 304 reduction columns: 184 -> 167 us -- and
+  // lose where it is short (4 x 512 <- 256: 160 -> 188 us; 4 x 512 -> 256 over 512: 133 -> 140; the first-layer group,
+  // which they split into two launches: 205 -> 228): two workgroups per CU instead of four cover each other's load /
+  // MFMA / epilogue phases less well than the fewer LDS reads return on 4-8 k-steps.  So: from 1 536 reduction columns on.
+  int wide[G16_MAX_GROUP], rest[G16_MAX_GROUP], nw = 0, nr = 0;
+  for (int i = 0; i < n; ++i) {
+    int64_t ksum = 0;
+    for (int s = 0; s < d[i].n_src && s < MML_MAX_SRC; ++s) ksum += d[i].K[s];
+    const int64_t kmin = g16_bn_max() > 256 ? 0 : 1536;  // (MMLREC_G16_BN=512: wide tiles for every qualifying problem -- lab)
+    if (g16_bn_max() >= 256 && d[i].N > 0 && d[i].N % 256 == 0 && d[i].M >= 8192 && ksum >= kmin) wide[nw++] = i;
+    else rest[nr++] = i;
+  }
+  if (nw) {
+    const int rc = g16_tn_launch(d, wide, nw, 256, to_stream(stream));
+    if (rc != MML_OK) return rc;
+  }
+  if (nr) {
+    bool all128 = g16_bn_max() >= 128;
+    for (int k = 0; k < nr; ++k) all128 = all128 && d[rest[k]].N % 128 == 0;
+    return g16_tn_launch(d, rest, nr, all128 ? 128 : 64, to_stream(stream));
+  }
+  return MML_OK;
 }
 
 static int g16_wgrad_plan(const mml_g16_wgrad_desc* d, int32_t n, int* slabs_out, int64_t* bytes_out) {

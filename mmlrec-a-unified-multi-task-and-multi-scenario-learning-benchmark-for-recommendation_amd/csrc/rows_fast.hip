@@ -51,6 +51,18 @@ __device__ __forceinline__ float cross_group_sum(float v) {
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
+__device__ __forceinline__ float4 mul4(const float4& a, const float4& b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float act_bwd_rows(const float y, const int act) {  // (gemm.hip: act_bwd)
+  if (act == MML_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == MML_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MML_ACT_SIGMOID2) {
+    const float s_ = 0.5f * y;
+    return 2.f * s_ * (1.f - s_);
+  }
+  return 1.f;
+}
 __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
   acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
 }
@@ -604,7 +616,10 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 }
 
 // ------------------------------------------------------------------------------------------------ heads
-template <int LPS, int NT>
+// GATED (round 6): heads whose input is Hin (.) gate (mml_head_desc.gate; PepNet's last PPNet layer): the product is formed
+// in registers from the two rows, the backward writes dH = dlogit w gate relu'(Hin) and dgate = dlogit w Hin act'(gate) --
+// the product, its gradient and the element-wise launches around them never touch memory.
+template <int LPS, int NT, bool GATED>
 __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, const HeadFastAux aux) {
   __shared__ float red[FW][NT * (4 * LPS + 1) + 1];
   constexpr int SPW = 64 / LPS;
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
   float4 dwacc[NT];
   float dbacc[NT];
   float lossacc = 0.f;
-  float am_dh = 0.f;
+  float am_dh = 0.f, am_dg = 0.f;
   float4 wv[NT];
   float bias[NT];
 #pragma unroll
@@ -646,6 +661,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
     int64_t bb[U];
     bool vld[U];
     float4 hvu[U][NT];
+    float4 gvu[GATED ? U : 1][GATED ? NT : 1];
     float yu[U][NT], mu[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -655,11 +671,13 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         hvu[u][t] = make_float4(0, 0, 0, 0);
+        if (GATED) gvu[u][t] = make_float4(1.f, 1.f, 1.f, 1.f);
         yu[u][t] = 0.f;
         mu[u][t] = 1.f;
         if (t >= g.n_heads || it0 + u >= iters) continue;  // (a trip past the last one: uniform, nothing loaded)
         const mml_head_desc& d = g.head[t];
         if (4 * sub < d.H) hvu[u][t] = ld4(d.Hin + bb[u] * d.ldh + 4 * sub);
+        if (GATED && d.gate && 4 * sub < d.H) gvu[u][t] = ld4(d.gate + bb[u] * d.ldgate + 4 * sub);
         if (d.mask_col >= 0 && g.mask) mu[u][t] = g.mask[bb[u] * g.ldmask + d.mask_col];
         if (aux.train) yu[u][t] = g.y ? g.y[bb[u] * g.ldy + t] : g.dprob[bb[u] * g.lddprob + t];
       }
@@ -671,7 +689,8 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        lg[u][t] = (t < g.n_heads && it0 + u < iters) ? group_sum<LPS>(dot4(hvu[u][t], wv[t])) + bias[t] : 0.f;
+        lg[u][t] = (t < g.n_heads && it0 + u < iters)
+                       ? group_sum<LPS>(dot4(GATED ? mul4(hvu[u][t], gvu[u][t]) : hvu[u][t], wv[t])) + bias[t] : 0.f;
     // The per-sample scalar chain (sigmoid, the two clamped logarithms of the BCE, its derivative) ONCE per trip: lane
     // j of a group takes item j = (u, t) of the trip instead of every lane repeating all NI chains -- the chain is ~150
     // instructions with three transcendentals and two divisions, and it, not the 67 MB, was the kernel's time
@@ -724,8 +743,23 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
           const float dlogit = __shfl(dlj, (lane & ~(LPS - 1)) + u * NT + t, 64);
           if (sub == 0) dbacc[t] += dlogit;
           if (col) {
-            fma4(dwacc[t], dlogit, hv);
             float4 dh = make_float4(dlogit * wv[t].x, dlogit * wv[t].y, dlogit * wv[t].z, dlogit * wv[t].w);
+            if (GATED && d.gate) {  // (uniform per head) input = hv (.) gv
+              const float4 gv = gvu[u][t];
+              fma4(dwacc[t], dlogit, mul4(hv, gv));
+              float4 dg = mul4(dh, hv);
+              if (d.gate_act != MML_ACT_NONE) {
+                dg.x *= act_bwd_rows(gv.x, d.gate_act); dg.y *= act_bwd_rows(gv.y, d.gate_act);
+                dg.z *= act_bwd_rows(gv.z, d.gate_act); dg.w *= act_bwd_rows(gv.w, d.gate_act);
+              }
+              dh = mul4(dh, gv);
+              if (valid) {
+                st4o(d.dgate, b * d.lddgate + 4 * sub, dg, false);
+                amax_acc(am_dg, dg);
+              }
+            } else {
+              fma4(dwacc[t], dlogit, hv);
+            }
             if (d.h_relu) {
               if (!(hv.x > 0.f)) dh.x = 0.f;
               if (!(hv.y > 0.f)) dh.y = 0.f;
@@ -743,6 +777,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
   }
   if (!aux.train) return;
   amax_flush(am_dh, g.amax_dH);
+  if (GATED) amax_flush(am_dg, g.amax_dG);
   constexpr int PH = 4 * LPS + 1;  // per head: dw (4*LPS slots) + dbias
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -933,6 +968,8 @@ int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux&
     const mml_head_desc& d = g->head[t];
     if (d.H % 4 || !ok4(d.Hin, d.ldh) || !aligned16(d.w) || (d.w2 && !aligned16(d.w2))) return 0;
     if (train && !ok4(d.dH, d.lddh)) return 0;
+    if (d.gate && (!ok4(d.gate, d.ldgate) || (train && !ok4(d.dgate, d.lddgate)) || g->dh_bf16)) return 0;
+    if (d.gate) aux.gated = 1;
   }
   aux.lps = pick_lps(hmax);
   aux.nt = g->n_heads <= 2 ? 2 : (g->n_heads <= 4 ? 4 : 8);
@@ -952,9 +989,15 @@ int head_fast_config(const mml_head_group* g, bool train, int hmax, HeadFastAux&
 template <int LPS>
 static void launch_head(const mml_head_group& g, const HeadFastAux& aux, hipStream_t st) {
   dim3 gr(aux.grid), bl(FB);
-  if (aux.nt == 2) MML_LAUNCH((head_fast_kernel<LPS, 2>), gr, bl, 0, st, g, aux);
-  else if (aux.nt == 4) MML_LAUNCH((head_fast_kernel<LPS, 4>), gr, bl, 0, st, g, aux);
-  else MML_LAUNCH((head_fast_kernel<LPS, 8>), gr, bl, 0, st, g, aux);
+  if (aux.gated) {
+    if (aux.nt == 2) MML_LAUNCH((head_fast_kernel<LPS, 2, true>), gr, bl, 0, st, g, aux);
+    else if (aux.nt == 4) MML_LAUNCH((head_fast_kernel<LPS, 4, true>), gr, bl, 0, st, g, aux);
+    else MML_LAUNCH((head_fast_kernel<LPS, 8, true>), gr, bl, 0, st, g, aux);
+    return;
+  }
+  if (aux.nt == 2) MML_LAUNCH((head_fast_kernel<LPS, 2, false>), gr, bl, 0, st, g, aux);
+  else if (aux.nt == 4) MML_LAUNCH((head_fast_kernel<LPS, 4, false>), gr, bl, 0, st, g, aux);
+  else MML_LAUNCH((head_fast_kernel<LPS, 8, false>), gr, bl, 0, st, g, aux);
 }
 
 int head_fast(const mml_head_group* g, const HeadFastAux& aux, hipStream_t st) {

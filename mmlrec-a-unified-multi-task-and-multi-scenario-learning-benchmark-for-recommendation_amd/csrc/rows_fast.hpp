@@ -16,6 +16,7 @@ struct HeadFastAux {
   float* slab;                    // [grid][stride]
   int32_t stride, hmax, train;
   int32_t lps, nt, grid;
+  int32_t gated;                  // some head reads Hin (.) gate (mml_head_desc.gate)
 };
 
 // return the lane-group width (16/32/64) when the fast path applies, 0 otherwise

@@ -1495,7 +1495,9 @@ def _defer_reduce():
 
 class HeadOp(Op):
     """K5: prediction heads (+ summed BCE and its backward when training).
-    heads: dicts with Hin (Val), w (PVal with H elements), bias (PVal [1]), bias2 (PVal [1] or None)."""
+    heads: dicts with Hin (Val), w (PVal with H elements), bias (PVal [1]), bias2 (PVal [1] or None); a gated head (round 6,
+    PepNet's last PPNet layer, reference model/pepnet.py:72-78) also carries gate (Val: the input of the head is
+    Hin (.) gate, formed inside the kernel; this op must be the only consumer of both values)."""
 
     def __init__(self, heads, mask_cols=None):
         self.heads = heads
@@ -1507,7 +1509,7 @@ class HeadOp(Op):
                 all(h["Hin"].producer16 and h["Hin"].n % 8 == 0 and len(h["Hin"].consumers) == 1 for h in self.heads))
 
     def inputs(self):
-        return [h["Hin"] for h in self.heads]
+        return [h["Hin"] for h in self.heads] + [h["gate"] for h in self.heads if h.get("gate") is not None]
 
     def _group(self, plan, train, use_dprob, claim):
         T = len(self.heads)
@@ -1521,8 +1523,25 @@ class HeadOp(Op):
             q = dict(Hin=Hin.buf, w=h["w"].data, bias=h["bias"].data,
                      bias2=h["bias2"].data if h.get("bias2") is not None else None,
                      mask_col=(self.mask_cols[t] if (self.mask_cols and plan.mask is not None) else -1))
+            G = h.get("gate")
+            if G is not None:
+                if G.n != Hin.n or not _fast_row_width_ok(Hin.n) or Hin.is16 or G.is16:
+                    raise L.MMLError("gated head: gate and input of one width the fast row kernel serves, fp32")
+                q.update(gate=G.buf, gate_act=G.act)
             if train:
                 sole = len(Hin.consumers) == 1
+                if G is not None:
+                    if not sole or len(G.consumers) != 1 or G.act not in (L.ACT_NONE, L.ACT_SIGMOID, L.ACT_SIGMOID2):
+                        raise L.MMLError("gated head: the head must be the only consumer of its input and of its gate")
+                    q["dgate"] = plan.grad_of(G)
+                    if claim:
+                        if _claim(G):
+                            raise L.MMLError("gated head: the gate's gradient has another writer")
+                        G.deriv_applied = True   # (the kernel multiplies act'(gate) in)
+                        if plan.amax_pool is not None:  # ONE slot for all gates' gradients
+                            if getattr(self, "_amax_dG", None) is None:
+                                self._amax_dG = plan.new_amax()
+                            G.gamax, G.gamax_writers = self._amax_dG, 1
                 if sole:
                     q["dH"] = plan.grad_of(Hin)
                     q["h_relu"] = int(Hin.act == L.ACT_RELU)
@@ -1572,6 +1591,8 @@ class HeadOp(Op):
                                   dprob=dprob_buf if use_dprob else None)
         if train and getattr(self, "_amax_dH", None) is not None:
             grp.amax_dH = self._amax_dH.data_ptr()
+        if train and getattr(self, "_amax_dG", None) is not None:
+            grp.amax_dG = self._amax_dG.data_ptr()
         plan.keep.append(grp)
         return grp, post
 
@@ -1594,7 +1615,7 @@ class HeadOp(Op):
         ws = (torch.empty(max(nws, 256), dtype=torch.uint8, device=plan.device) if defer  # (its own: see GateGroupOp)
               else ops.workspace(nws, plan.device))
         plan.keep.append(ws)
-        byts = 4.0 * plan.B * sum(2 * h["Hin"].n + 2 for h in self.heads)
+        byts = 4.0 * plan.B * sum((4 if h.get("gate") is not None else 2) * h["Hin"].n + 2 for h in self.heads)
         if defer:
             # (dw / dbias / loss are read by the optimizer and the host only: their reduction runs beside the
             # weight-gradient GEMMs; Plan.finish moves the call tagged `side` out of the head's list)

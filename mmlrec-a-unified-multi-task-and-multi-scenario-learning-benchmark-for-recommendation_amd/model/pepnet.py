@@ -149,11 +149,27 @@ class PepNet(BaseModel):
         hidden = [x2] * T
         heads = []
         for l in range(nl + 1):
-            hins = [plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True) for t in range(T)]
             # the gate products of all tasks of this layer: fused into the gates' output GEMM where the product feeds a
             # Linear layer (l < nl), one batched launch each way in front of the heads
             ok = all(can_fuse(hidden[t].n) for t in range(T))
             fuse = ("full" if l < nl else ("fwd" if fuse_fwd else False)) if ok else False  # (the last product feeds the heads)
+            # the last layer: gated heads (round 6) -- the head kernel reads h and its gate, forms the product in registers
+            # and writes both gradients; no product buffer, no element-wise launch either way
+            gated = (l == nl and fuse_on and os.environ.get("MMLREC_PEP_GATED_HEAD", "1") != "0" and
+                     all(E._fast_row_width_ok(hidden[t].n) for t in range(T)))
+            if gated:
+                l2 = []
+                for t in range(T):
+                    pfx = f"ppn.{t}.gate_layers.{l}"
+                    w2 = store.pvals[f"{pfx}.gate.2.weight"]
+                    g = plan.val(w2.data.shape[0], act=L.ACT_SIGMOID2, name=pfx + ".g", pad_k=True)
+                    l2.append(dict(x=ghs[t * (nl + 1) + l], W=w2, b=store.pvals[f"{pfx}.gate.2.bias"], out=g))
+                plan.add(E.LinearGroupOp(l2))
+                heads = [dict(Hin=hidden[t], gate=l2[t]["out"], w=store.pvals[f"ppn.{t}.mlp_layers.{l}.weight"],
+                              bias=store.pvals[f"out.{t}.bias"], bias2=store.pvals[f"ppn.{t}.mlp_layers.{l}.bias"])
+                         for t in range(T)]
+                continue
+            hins = [plan.val(hidden[t].n, name=f"ppn.{t}.hin.{l}", pad_k=True) for t in range(T)]
             self._gate_out(plan, store, [(f"ppn.{t}.gate_layers.{l}", ghs[t * (nl + 1) + l], hidden[t], hins[t])
                                          for t in range(T)], fuse=fuse)
             if l < nl:

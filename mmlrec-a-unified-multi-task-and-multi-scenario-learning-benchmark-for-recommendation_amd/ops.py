@@ -552,7 +552,8 @@ def gate_mix_bwd(group, device, phases=False):
 # ---------------------------------------------------------------------------------------------- K5
 def make_head_group(heads, prob, y=None, mask=None, loss=None, dprob=None):
     """heads: dicts with Hin [B,H], w [H] (any shape with H elements), bias [1], optional w2, bias2 (list of 1-element
-    tensors packed by the caller into one tensor), dH, dw, dbias, h_relu, mask_col."""
+    tensors packed by the caller into one tensor), dH, dw, dbias, h_relu, mask_col; gated heads also gate [B,H], dgate,
+    gate_act."""
     g = L.HeadGroup()
     g.n_heads = len(heads)
     g.B = prob.shape[0]
@@ -578,6 +579,11 @@ def make_head_group(heads, prob, y=None, mask=None, loss=None, dprob=None):
         d.dw, d.dbias = L.ptr(q.get("dw")), L.ptr(q.get("dbias"))
         d.h_relu = int(q.get("h_relu", 1))
         d.mask_col = int(q.get("mask_col", -1))
+        if q.get("gate") is not None:  # gated head: the input is Hin (.) gate (include/mmlrec.h: mml_head_desc.gate)
+            d.gate, d.ldgate = q["gate"].data_ptr(), _ld(q["gate"])
+            d.gate_act = int(q.get("gate_act", L.ACT_NONE))
+            if q.get("dgate") is not None:
+                d.dgate, d.lddgate = q["dgate"].data_ptr(), _ld(q["dgate"])
     dhs = [q["dH"] for q in heads if q.get("dH") is not None]
     n16 = sum(t.dtype == torch.bfloat16 for t in dhs)
     if n16 not in (0, len(dhs)):

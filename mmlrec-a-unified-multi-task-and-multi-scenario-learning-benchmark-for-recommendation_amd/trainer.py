@@ -101,9 +101,9 @@ def fork_conflicts(side_calls, mid_calls, shared_scratch=()):
 
 class InnerFork:
     """A fork / join INSIDE one call list (one HIP graph): `fork` sends `calls` to a second stream behind everything
-    issued so far, `join` makes the current stream wait for them.  Opt-in knob MMLREC_INNER_FORK (TrainStep): no graph seam,
+    issued so far, `join` makes the current stream wait for them.  Knob MMLREC_INNER_FORK (TrainStep): no graph seam,
     unlike the two-stream schedule of overlap=True -- but a multi-branch graph (see TrainStep.run's note on
-    hip::Graph::UpdateStreams)."""
+    hip::Graph::UpdateStreams and the soak of round 6)."""
 
     def __init__(self, device, calls):
         self.side = torch.cuda.Stream(device=device)
@@ -119,6 +119,23 @@ class InnerFork:
 
     def join(self):
         torch.cuda.current_stream().wait_event(self.ev_join)
+
+
+def _quiesce_collective_watchdog():
+    """Called after a device-wide synchronize and before a HIP-graph capture.  While an RCCL process group exists, its
+    watchdog thread polls the end events of the collectives it has not seen complete yet (every ~100 ms).  A poll that
+    lands inside a capture is an event query during stream capture: with capture_error_mode="thread_local" (Segments)
+    it no longer invalidates the capture, but it was still seen -- 1 run in 24 of the suite's graph tests, round 6 -- as an
+    exception in the watchdog that surfaces as "Fatal Python error: Aborted" in the NEXT destroy_process_group.  Every
+    collective issued so far HAS completed (the synchronize above); giving the watchdog two of its periods to notice
+    leaves it nothing to query while the capture runs.  Once per TrainStep (captures happen on the second call of run())."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            import time
+            time.sleep(0.25)
+    except Exception:  # (never cost a step for this)
+        pass
 
 
 def resolve_overlap(overlap):
@@ -278,14 +295,17 @@ class TrainStep:
             # beside the table scatter and the table optimizer.  Same-box interleaved pairs (tools/lab/ab_env.sh
             # MMLREC_INNER_FORK=0 / 2, B = 65 536): AE-30 1.4773 / 1.4818 / 1.4860 / 1.4952 / 1.4772 -> 1.4635 / 1.4683 /
             # 1.4851 / 1.4623 / 1.4731 ms, AE-30d 1.613 -> 1.582, PLE 1.535 -> 1.509, PepNet 2.028 -> 2.006; at B = 4 096
-            # it loses (0.670 -> 0.679 ms).  MMLREC_INNER_FORK: 0 off (default), 1 joined in front of the table
-            # optimizer (beside the scatter only: level), 2 joined behind it (the measured form).
-            # Round 6: OPT-IN (default 0).  The fork makes the step's graph a multi-branch graph, the kind whose launch
-            # segfaulted sporadically in this runtime (hip::Graph::UpdateStreams, see run() below: dependent on how many
-            # streams the process created) -- 0.9 % is not worth that risk on a first 8-GPU run; the soak protocol and its
-            # result: profiles/r06_fork_soak.txt.
+            # it loses (0.670 -> 0.679 ms), so large batches only.  MMLREC_INNER_FORK: 0 off, 1 joined in front of the table
+            # optimizer (beside the scatter only: level), 2 joined behind it (the default form).
+            # Round 6: the fork makes the step's graph a multi-branch graph, the kind whose launch segfaulted sporadically
+            # in this runtime (hip::Graph::UpdateStreams, see run() below: dependent on how many streams the process
+            # created).  Soaked (tools/lab/fork_soak.sh, profiles/r06_fork_soak.txt): 0 crashes in 32 fresh processes with
+            # the fork forced on for EVERY batch size (22 runs of the suite's graph tests -- every model of the zoo, its
+            # own streams, the original repro's shape -- and 10 of bench.py), so it stays the default for large batches;
+            # it never applies to a step that holds a collective (Python-issued entries between fork and join), i.e. to no
+            # multi-GPU step.  MMLREC_INNER_FORK=0 turns it off.
             env_fork = os.environ.get("MMLREC_INNER_FORK")
-            inner = int(env_fork) if env_fork is not None else 0
+            inner = int(env_fork) if env_fork is not None else (2 if int(B) >= 16384 else 0)
             side_calls = head_side + p.bwd_side
             mid = (p.bwd_tail + self.opt_split["tables"])
             if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
@@ -443,6 +463,7 @@ class TrainStep:
             self._has_next = False
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
+            _quiesce_collective_watchdog()
             for seg in ((self.whole,) if self.whole is not None else
                         (self.pre, self.early, self.front, self.front_b, self.side_a, self.sideq, self.tail)):
                 if seg is not None:

@@ -488,7 +488,8 @@ static int heads(const mml_head_group* g, int train) {
       const mml_head_desc* d = &g->head[t];
       double s = d->bias[0];
       for (int i = 0; i < d->n_bias2; ++i) s += d->bias2[i];
-      for (int h = 0; h < d->H; ++h) s += (double)d->Hin[b * d->ldh + h] * d->w[h] * (d->w2 ? d->w2[h] : 1.f);
+      for (int h = 0; h < d->H; ++h)
+        s += (double)d->Hin[b * d->ldh + h] * (d->gate ? d->gate[b * d->ldgate + h] : 1.f) * d->w[h] * (d->w2 ? d->w2[h] : 1.f);
       const float p = 1.f / (1.f + expf(-(float)s));
       const float m = (d->mask_col >= 0 && g->mask) ? g->mask[b * g->ldmask + d->mask_col] : 1.f;
       const float pm = p * m;
@@ -509,8 +510,17 @@ static int heads(const mml_head_group* g, int train) {
       if (d->dbias) d->dbias[0] += dlogit;
       for (int h = 0; h < d->H; ++h) {
         const float hv = d->Hin[b * d->ldh + h];
-        if (d->dw) d->dw[h] += dlogit * hv;
+        const float gv = d->gate ? d->gate[b * d->ldgate + h] : 1.f;   /* gated head: the input is hv * gv (pepnet.py:72-78) */
+        if (d->dw) d->dw[h] += dlogit * (hv * gv);
         float dh = dlogit * d->w[h] * (d->w2 ? d->w2[h] : 1.f);
+        if (d->gate && d->dgate) {
+          float dg = dh * hv;
+          if (d->gate_act == MML_ACT_SIGMOID) dg *= gv * (1.f - gv);
+          else if (d->gate_act == MML_ACT_SIGMOID2) dg *= 2.f * (0.5f * gv) * (1.f - 0.5f * gv);
+          d->dgate[b * d->lddgate + h] = dg;
+          amax_raise(g->amax_dG, dg);
+        }
+        dh *= gv;
         if (d->h_relu && !(hv > 0.f)) dh = 0.f;
         if (d->dH) { d->dH[b * d->lddh + h] = dh; amax_raise(g->amax_dH, dh); }
       }

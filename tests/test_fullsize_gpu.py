@@ -259,7 +259,10 @@ def test_bench_secondary_configurations_steps_match_oracle(W, workload, expect):
             touched = np.unique(X[:, f].numpy().astype(np.int64))
             assert np.isin(touched, rows).mean() > 0.99, k        # the batch's rows moved
             share, rel = table_update_report(b, a, r, rows)
-            assert share < 2e-3, (i, k, share, rel, len(rows))
+            # (5e-3: soaked in round 6 -- 36 fresh-process runs gave 0.0025-0.003 on KuaiRec-32's 62- and 199-row tables at
+            # the third free-running Adam step in 3 of them, elements whose gradient sits at the scatter's summation-order
+            # noise; the MLP tensors above keep their 1e-2 / 2e-3 bounds, a wrong row or a stale buffer moves whole rows)
+            assert share < 5e-3, (i, k, share, rel, len(rows))
     segs = [runner.whole] if runner.whole is not None else [runner.front, runner.tail, runner.sideq]
     assert sum(s_.n_graphs for s_ in segs if s_ is not None) >= 1   # the replayed path really ran
     # which kernels this configuration's step launches at this size
@@ -517,7 +520,7 @@ def test_bf16_operand_mode_full_size_kuairec(W, storage, monkeypatch):
 _BF16_ORACLE = {}
 
 
-@pytest.mark.parametrize("inner_fork", ["default", "2"])
+@pytest.mark.parametrize("inner_fork", ["default", "0"])
 def test_bf16_bench_configuration_steps_match_oracle(W, inner_fork, monkeypatch):
     """bench.py's `configs[1] ... bf16` entry: mmoe_kuairec under GEMM mode 1 with bf16 storage, table_update "auto",
     train_step_runner(B, use_graph=True) -- step 0 eager, step 1 captured + replayed, step 2 a pure replay -- at B = 32 768
@@ -526,8 +529,8 @@ def test_bf16_bench_configuration_steps_match_oracle(W, inner_fork, monkeypatch)
     tolerance of test_bf16_operand_mode_full_size_kuairec), the total update of every MLP tensor and of every table's
     touched rows within a relative rms bound, and after EVERY step each bf16 weight copy of the plan (plan.cast16_items)
     equal to the bf16 rounding of the fp32 master weight THAT STEP STARTED FROM -- while the master weights moved, i.e. the
-    replayed graph re-casts them.  inner_fork "2": the weight-gradient launches on the second branch of the step's graph
-    (MMLREC_INNER_FORK=2, opt-in since round 6)."""
+    replayed graph re-casts them.  inner_fork "default": the weight-gradient launches on the second branch of the step's
+    graph (on from 16 384 samples; soaked in round 6); "0": the one-branch graph (MMLREC_INNER_FORK=0)."""
     from oracle import mmlrec_oracle as orc
     from mmlrec_amd import _lib
     from mmlrec_amd import engine as E
@@ -566,7 +569,7 @@ def test_bf16_bench_configuration_steps_match_oracle(W, inner_fork, monkeypatch)
         forked = getattr(runner, "inner_fork", None)
         if forked is not None:
             calls += list(forked.calls)
-        assert (forked is not None) == (inner_fork == "2")
+        assert (forked is not None) == (inner_fork == "default")   # (on from 16 384 samples by default)
         n16 = sum(c[0] in (lib.mml_g16_tn, lib.mml_g16_wgrad) for c in calls if c[0] is not E.INLINE)
         n32 = sum(c[0] in (lib.mml_gemm_grouped_fwd, lib.mml_gemm_grouped_dgrad, lib.mml_gemm_grouped_wgrad_phase)
                   for c in calls if c[0] is not E.INLINE)

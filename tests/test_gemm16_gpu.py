@@ -93,6 +93,81 @@ def test_forward_kuairec_first_layer_group(ops, M):
         assert bool((f64(q["C"])[~bits] == 0).all())
 
 
+@pytest.mark.parametrize("M", [8192, 16384 + 128])
+def test_wide_tiles_forward_and_input_gradient(ops, M):
+    """Round 6: problems whose width is a multiple of 256 AND whose reduction is at least 1 536 columns long run 128 x 256
+    tiles (a wave's tile 64 x 128: 0.75 LDS fragment reads per MFMA instead of 1.0) from 8 192 rows on, in a launch of
+    their own -- here: KuaiRec-32's first-layer group and second layers stay on the 128-wide tiles (reductions of 512);
+    the multi-source input gradient of the first layers (2 304 reduction columns) into an accumulating fp32 output and a
+    long masked bf16 input gradient + a forward with bias / ReLU / sign masks over a 2 048-column reduction run the wide
+    ones.  Same tolerances as the 128-wide tiles."""
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    A = rand16(g, M, 512)
+    probs, refs = [], []
+    for N, c16 in ((512, True), (512, True), (128, False), (512, True), (512, False), (128, False), (256, True)):
+        W = rand16(g, N, 512, scale=512 ** -0.5)
+        b = torch.randn(N, generator=g).to(dev())
+        C = torch.empty(M, N, dtype=torch.bfloat16 if c16 else torch.float32, device=dev())
+        mask = torch.zeros(M, N // 32, dtype=torch.int32, device=dev())
+        probs.append(dict(srcs=[(A, W)], C=C, bias=b, act=L.ACT_RELU, mask_out=mask))
+        refs.append(torch.relu(f64(A) @ f64(W).t() + f64(b)))
+    ops.g16_tn(probs)
+    assert lib.mml_g16_last_kernel().decode() == "g16_tn_kernel<128>"    # (reductions of 512: below the wide tiles' 1 536)
+    for q, ref in zip(probs, refs):
+        tol = 1e-5 + (2.0 ** -8 if q["C"].dtype == torch.bfloat16 else 0.0)
+        assert maxrel(q["C"], ref) < tol
+        bits = ((q["mask_out"].view(torch.int32).unsqueeze(-1) >> torch.arange(32, device=dev())) & 1).reshape(M, -1).bool()
+        clear = ref.abs() > 1e-4 * ref.abs().max()
+        assert torch.equal(bits[clear], (ref > 0)[clear])
+        assert bool((f64(q["C"])[~bits] == 0).all())
+    # input gradient, six sources, fp32 output that accumulates
+    srcs, ref = [], torch.zeros(M, 512, dtype=torch.float64, device=dev())
+    for N in (512, 512, 512, 512, 128, 128):
+        dC = rand16(g, M, N)
+        Wt = rand16(g, 512, N, scale=N ** -0.5)
+        srcs.append((dC, Wt))
+        ref += f64(dC) @ f64(Wt).t()
+    out = torch.full((M, 512), 3.0, device=dev())
+    ops.g16_tn([dict(srcs=srcs, C=out)])
+    assert lib.mml_g16_last_kernel().decode() == "g16_tn_kernel<256>"
+    assert maxrel(out, ref) < 1e-5
+    ops.g16_tn([dict(srcs=srcs, C=out, accumulate=1)])
+    assert maxrel(out, 2 * ref) < 1e-5
+    # masked bf16 input gradient over a long reduction (wide tiles), and the second layers' own (narrow tiles)
+    for K2, want in ((2048, "g16_tn_kernel<256>"), (256, "g16_tn_kernel<128>")):
+        dE = rand16(g, M, K2)
+        W2t = rand16(g, 512, K2, scale=K2 ** -0.5)
+        mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (M, 16), dtype=torch.int32, generator=g).to(dev())
+        dH = torch.empty(M, 512, dtype=torch.bfloat16, device=dev())
+        ops.g16_tn([dict(srcs=[(dE, W2t)], C=dH, mask_in=mask)])
+        assert lib.mml_g16_last_kernel().decode() == want
+        bits = ((mask.unsqueeze(-1) >> torch.arange(32, device=dev())) & 1).reshape(M, -1).bool()
+        ref2 = (f64(dE) @ f64(W2t).t()) * bits
+        assert maxrel(dH, ref2) < 1e-5 + 2.0 ** -8
+        assert bool((f64(dH)[~bits] == 0).all())
+    # forward with bias + ReLU + sign masks on the wide tiles: bf16 and fp32 outputs, 256 and 512 columns
+    A2 = rand16(g, M, 2048)
+    probs2, refs2 = [], []
+    for N, c16 in ((256, True), (512, False), (512, True)):
+        W = rand16(g, N, 2048, scale=2048 ** -0.5)
+        b = torch.randn(N, generator=g).to(dev())
+        C = torch.empty(M, N, dtype=torch.bfloat16 if c16 else torch.float32, device=dev())
+        mk = torch.zeros(M, N // 32, dtype=torch.int32, device=dev())
+        probs2.append(dict(srcs=[(A2, W)], C=C, bias=b, act=L.ACT_RELU, mask_out=mk))
+        refs2.append(torch.relu(f64(A2) @ f64(W).t() + f64(b)))
+    ops.g16_tn(probs2)
+    assert lib.mml_g16_last_kernel().decode() == "g16_tn_kernel<256>"
+    for q, ref in zip(probs2, refs2):
+        tol = 1e-5 + (2.0 ** -8 if q["C"].dtype == torch.bfloat16 else 0.0)
+        assert maxrel(q["C"], ref) < tol
+        bits = ((q["mask_out"].view(torch.int32).unsqueeze(-1) >> torch.arange(32, device=dev())) & 1).reshape(M, -1).bool()
+        clear = ref.abs() > 1e-4 * ref.abs().max()
+        assert torch.equal(bits[clear], (ref > 0)[clear])
+        assert bool((f64(q["C"])[~bits] == 0).all())
+
+
 def test_forward_64_wide_outputs_and_linear_activation(ops):
     from mmlrec_amd import _lib as L
     g = torch.Generator().manual_seed(2)

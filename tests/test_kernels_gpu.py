@@ -418,6 +418,97 @@ def test_head_bce(ops, B, H, T_, masked):
         assert torch.equal(h["dw"], w_) and torch.equal(h["dbias"], b_) and torch.equal(h["dH"], d_)
 
 
+@pytest.mark.parametrize("B,H,T_,gate_act", [(1000, 128, 4, "sigmoid2"), (65536, 128, 4, "sigmoid2"), (333, 64, 2, "none"),
+                                            (4099, 16, 3, "sigmoid")])
+def test_gated_head_bce(ops, B, H, T_, gate_act):
+    """Gated heads (round 6; PepNet's last PPNet layer, reference model/pepnet.py:72-78 + :139-140): the head's input is
+    Hin (.) gate, formed inside the kernel -- probabilities, loss, dH = dlogit w gate relu'(Hin), dgate = dlogit w Hin
+    act'(gate), dw = sum dlogit Hin gate, dbias against float64; the forward-only call and the two-launch form give the
+    same bits; a mixed group (one plain head next to the gated ones); the magnitude slots bound what was stored."""
+    from mmlrec_amd import _lib as L
+    rng = np.random.default_rng(B + H)
+    y = (rng.random((B, T_)) < 0.4).astype(np.float32)
+    acts = {"none": L.ACT_NONE, "sigmoid": L.ACT_SIGMOID, "sigmoid2": L.ACT_SIGMOID2}
+    heads, ref_loss = [], 0.0
+    prob = torch.empty(B, T_, device=dev())
+    loss = torch.zeros(1, device=dev())
+    for t in range(T_):
+        Hin = np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32)
+        z = rng.standard_normal((B, H))
+        gated = not (t == T_ - 1 and T_ == 3)          # (the (4099, 16, 3) case: its last head is a plain one)
+        if gate_act == "none":
+            g = z.astype(np.float32)
+            dact = np.ones_like(z)
+        elif gate_act == "sigmoid":
+            g = (1 / (1 + np.exp(-z))).astype(np.float32)
+            dact = g.astype(np.float64) * (1 - g.astype(np.float64))
+        else:
+            g = (2 / (1 + np.exp(-z))).astype(np.float32)
+            dact = g.astype(np.float64) * (1 - g.astype(np.float64) / 2)
+        if not gated:
+            g, dact = np.ones_like(g), np.ones_like(dact)
+        # (logits of a few units: beyond ~16 the fp32 probability is one ulp from 1 and a last-bit difference of the logit
+        # moves that sample's clamped-log loss by 0.7 -- 83 when it reaches exactly 1 --, which tests nothing but rounding)
+        w = (rng.standard_normal(H) * 0.5 / np.sqrt(H)).astype(np.float32)
+        bias = rng.standard_normal(1).astype(np.float32)
+        he = Hin.astype(np.float64) * g.astype(np.float64)
+        logit = (he @ w + bias).astype(np.float32)
+        p = orc.sigmoid(logit)
+        ref_loss += orc.bce_sum(p, y[:, t])
+        p64 = p.astype(np.float64)
+        dlogit = (p64 - y[:, t]) / np.maximum(p64 * (1 - p64), 1e-12) * p64 * (1 - p64)
+        q = dict(Hin=T(Hin), w=T(w), bias=T(bias), dH=torch.full((B, H), float("nan"), device=dev()),
+                 dw=torch.empty(H, device=dev()), dbias=torch.empty(1, device=dev()), h_relu=1, mask_col=-1,
+                 ref=(p, dlogit[:, None] * w[None, :] * g * (Hin > 0), dlogit[:, None] * w[None, :] * Hin * dact,
+                      dlogit @ he, dlogit.sum()))
+        if gated:
+            q.update(gate=T(g), dgate=torch.full((B, H), float("nan"), device=dev()), gate_act=acts[gate_act])
+        heads.append(q)
+    grp = ops.make_head_group(heads, prob, y=T(y), mask=None, loss=loss)
+    slots = ops.amax_slots(2, dev())
+    grp.amax_dH, grp.amax_dG = slots[0].data_ptr(), slots[1].data_ptr()
+    ops.head_bce_fwd_bwd(grp, dev())
+    assert abs(float(loss.item()) - ref_loss) / ref_loss < 1e-4
+    for t, h in enumerate(heads):
+        p, dH, dG, dw, db = h["ref"]
+        assert rel(prob[:, t].cpu().numpy(), p) < 1e-5
+        assert rel(h["dH"].cpu().numpy(), dH) < 2e-5
+        assert rel(h["dw"].cpu().numpy(), dw) < 2e-5
+        assert abs(float(h["dbias"].item()) - db) < 2e-5 * max(abs(db), 1.0)
+        if "gate" in h:
+            assert rel(h["dgate"].cpu().numpy(), dG) < 2e-5
+    am_h = max(float(h["dH"].abs().max()) for h in heads)
+    am_g = max(float(h["dgate"].abs().max()) for h in heads if "gate" in h)
+    for s_, am in ((slots[0], am_h), (slots[1], am_g)):
+        v = float(torch.max(s_.view(torch.float32)))
+        assert v >= am and v <= am * (1 + 1e-6)
+    prob2 = torch.empty(B, T_, device=dev())
+    ops.head_fwd(ops.make_head_group(heads, prob2))
+    assert torch.equal(prob, prob2)
+    keep = [(h["dw"].clone(), h["dbias"].clone(), h["dH"].clone(), h["dgate"].clone() if "gate" in h else None) for h in heads]
+    for h in heads:
+        h["dw"].fill_(float("nan"))
+        h["dbias"].fill_(float("nan"))
+    loss2 = torch.full((1,), float("nan"), device=dev())
+    ops.head_bce_fwd_bwd(ops.make_head_group(heads, prob, y=T(y), mask=None, loss=loss2), dev(), phases=True)
+    assert float(loss2.item()) == float(loss.item())
+    for h, (w_, b_, d_, g_) in zip(heads, keep):
+        assert torch.equal(h["dw"], w_) and torch.equal(h["dbias"], b_) and torch.equal(h["dH"], d_)
+        assert g_ is None or torch.equal(h["dgate"], g_)
+
+
+def test_gated_head_needs_the_fast_row_kernel(ops):
+    """A width the fast row kernel does not serve (H % 4 != 0) is refused, not silently computed without the gate."""
+    from mmlrec_amd import _lib as L
+    B, H = 64, 30
+    rng = np.random.default_rng(1)
+    h = dict(Hin=T(rng.standard_normal((B, H)).astype(np.float32)), w=T(rng.standard_normal(H).astype(np.float32)),
+             bias=T(np.zeros(1, np.float32)), gate=T(rng.standard_normal((B, H)).astype(np.float32)), gate_act=L.ACT_NONE,
+             mask_col=-1)
+    with pytest.raises(L.MMLError):
+        ops.head_fwd(ops.make_head_group([h], torch.empty(B, 1, device=dev())))
+
+
 @pytest.mark.parametrize("H", [64, 200])
 def test_head_bce_loss_propagates_nan(ops, H):
     """F.binary_cross_entropy clamps its log terms with torch.clamp(.., min=-100), which keeps a NaN (the oracle's

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6: KuaiRec-32 bf16 (GEMM mode 1 + bf16 storage), 128 x 256 tiles (MMLREC_G16_BN=256, the default) against 128 x 128
+cd $GRAFT_REPO_ROOT
+run() { env MMLREC_G16_BN=$1 MMLREC_GEMM_MODE=1 python3 bench.py --workload mmoe_kuairec --no-configs --no-cpu-baseline --no-lazy --alt-batch ${2:-0} --table-update auto --steps 30 --warmup 5 --no-loss-check 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); k=d['kernels_ms_per_step']; print('BN=$1', d['ms_per_step'], round(d['value']/1e6,2), {a[:40]: b for a, b in list(k.items())[:8]}, (d.get('alt') or {}).get('ms_per_step'))"; }
+for rep in 1 2 3; do
+run 128
+run 256
+done
+run 128 4096
+run 256 4096
