@@ -412,3 +412,56 @@ def test_bf16_storage_family_on_the_cpu_library(cpu):
     grp = L.GateGroup()
     grp.n_experts, grp.n_gates, grp.H, grp.B, grp.out_bf16 = 1, 1, 4, 0, 1
     assert lib.mml_gate_mix_fwd(C.byref(grp), None) == -3
+
+
+@pytest.mark.parametrize("B,H,T_,gate_act", [(333, 64, 2, "none"), (1000, 128, 4, "sigmoid2"), (77, 16, 3, "sigmoid")])
+def test_cpu_library_gated_heads(cpu, B, H, T_, gate_act):
+    """Gated heads of include/mmlrec.h (mml_head_desc.gate, round 6; reference model/pepnet.py:72-78: the last PPNet layer
+    reads h (.) 2 sigmoid(gate)) through the CPU restatement with the package's descriptor structs: probabilities, loss, dH,
+    dgate, dw, dbias against float64 -- the same numpy reference tests/test_kernels_gpu.py::test_gated_head_bce holds the
+    HIP kernel to."""
+    lib, L = cpu
+    from oracle import mmlrec_oracle as orc
+    rng = np.random.default_rng(B + H)
+    acts = {"none": L.ACT_NONE, "sigmoid": L.ACT_SIGMOID, "sigmoid2": L.ACT_SIGMOID2}
+    y = (rng.random((B, T_)) < 0.4).astype(np.float32)
+    prob = np.zeros((B, T_), np.float32)
+    loss = np.zeros(1, np.float32)
+    hg = L.HeadGroup()
+    hg.n_heads, hg.B, hg.prob, hg.ldprob, hg.y, hg.ldy, hg.loss = T_, B, prob.ctypes.data, T_, y.ctypes.data, T_, loss.ctypes.data
+    keep, ref_loss = [], 0.0
+    for t in range(T_):
+        Hin = np.maximum(rng.standard_normal((B, H)), 0).astype(np.float32)
+        z = rng.standard_normal((B, H))
+        if gate_act == "none":
+            g, dact = z.astype(np.float32), np.ones_like(z)
+        elif gate_act == "sigmoid":
+            g = (1 / (1 + np.exp(-z))).astype(np.float32)
+            dact = g.astype(np.float64) * (1 - g.astype(np.float64))
+        else:
+            g = (2 / (1 + np.exp(-z))).astype(np.float32)
+            dact = g.astype(np.float64) * (1 - g.astype(np.float64) / 2)
+        w = (rng.standard_normal(H) * 0.5 / np.sqrt(H)).astype(np.float32)
+        bias = rng.standard_normal(1).astype(np.float32)
+        he = Hin.astype(np.float64) * g.astype(np.float64)
+        logit = (he @ w + bias).astype(np.float32)
+        p = orc.sigmoid(logit)
+        ref_loss += orc.bce_sum(p, y[:, t])
+        p64 = p.astype(np.float64)
+        dlogit = (p64 - y[:, t]) / np.maximum(p64 * (1 - p64), 1e-12) * p64 * (1 - p64)
+        dH, dG = np.full((B, H), np.nan, np.float32), np.full((B, H), np.nan, np.float32)
+        dw, db = np.zeros(H, np.float32), np.zeros(1, np.float32)
+        d = hg.head[t]
+        d.Hin, d.ldh, d.H, d.w, d.bias = Hin.ctypes.data, H, H, w.ctypes.data, bias.ctypes.data
+        d.dH, d.lddh, d.dw, d.dbias, d.h_relu, d.mask_col = dH.ctypes.data, H, dw.ctypes.data, db.ctypes.data, 1, -1
+        d.gate, d.ldgate, d.dgate, d.lddgate, d.gate_act = g.ctypes.data, H, dG.ctypes.data, H, acts[gate_act]
+        keep.append((Hin, g, w, bias, dH, dG, dw, db, p, dlogit[:, None] * w[None, :] * g * (Hin > 0),
+                     dlogit[:, None] * w[None, :] * Hin * dact, dlogit @ he, dlogit.sum()))
+    assert lib.mml_head_bce_fwd_bwd(C.byref(hg), None, 0, None) == 0
+
+    def rel(a, b):
+        return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+    assert abs(float(loss[0]) - ref_loss) / ref_loss < 1e-4
+    for t, (Hin, g, w, bias, dH, dG, dw, db, p, rH, rG, rw, rb) in enumerate(keep):
+        assert rel(prob[:, t], p) < 1e-5 and rel(dH, rH) < 2e-5 and rel(dG, rG) < 2e-5 and rel(dw, rw) < 2e-5
+        assert abs(float(db[0]) - rb) < 2e-5 * max(abs(rb), 1.0)

@@ -464,7 +464,8 @@ def test_gated_head_bce(ops, B, H, T_, gate_act):
         if gated:
             q.update(gate=T(g), dgate=torch.full((B, H), float("nan"), device=dev()), gate_act=acts[gate_act])
         heads.append(q)
-    grp = ops.make_head_group(heads, prob, y=T(y), mask=None, loss=loss)
+    yt = T(y)   # (the group holds raw pointers: the label tensor must outlive the launch)
+    grp = ops.make_head_group(heads, prob, y=yt, mask=None, loss=loss)
     slots = ops.amax_slots(2, dev())
     grp.amax_dH, grp.amax_dG = slots[0].data_ptr(), slots[1].data_ptr()
     ops.head_bce_fwd_bwd(grp, dev())
