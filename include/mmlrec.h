@@ -43,7 +43,7 @@ extern "C" {
 #define MML_MAX_HEADS 8     /* prediction heads per head launch */
 #define MML_MAX_OPT_TENSORS 32
 #define MML_AMAX_WORDS 8    /* words of one operand-magnitude slot (see "operand magnitudes" at the GEMM family) */
-#define MML_MAX_AMAX 16     /* tensors per mml_amax_batch launch */
+#define MML_MAX_AMAX 64     /* tensors per mml_amax_batch launch (16 until round 6: PepNet's 42 stable weights took three launches) */
 
 typedef void* mml_stream_t; /* hipStream_t */
 

@@ -1273,7 +1273,17 @@ class LinearGroupOp(Op):
                     raise L.MMLError("a fused gate product must feed exactly one Linear group (<= MAX_SRC layers)")
                 h, g = gate
                 gd = dict(h=h.buf, g=g.buf)
+                # h shared by several products and able to take its gradient in parts (MulBatchOp(fwd_fused)): this
+                # problem writes a buffer of its own -- no accumulation, no order between the sharing problems
+                parts = getattr(h, "grad_parts", None)
+                use_part = (parts is not None and h.act == L.ACT_NONE and len(parts) < 8 and
+                            h.buf.stride(0) == h.n and os.environ.get("MMLREC_GRAD_PARTS", "1") != "0")
                 for key, v, nc in (("h", h, 1), ("g", g, 0)):
+                    if key == "h" and use_part:
+                        part = plan.empty(plan.B, h.n)
+                        parts.append(part)
+                        gd.update(dh=part, act_h=L.ACT_NONE, acc_h=0, amax_dh=None)
+                        continue
                     gv = plan.grad_of(v)
                     acc = _claim(v)
                     fold = (not acc and v.act != L.ACT_NONE and not v.deriv_applied and len(v.consumers) == nc)
@@ -1294,8 +1304,10 @@ class LinearGroupOp(Op):
                     gp = [(None, None)] * len(ch)
                 # products that share a factor (the gated input feeds every task's first product) write the SAME
                 # gradient buffer, the first overwriting, the others adding: they must not run in one launch
-                wi = max(gate_wave.get(id(h), -1), gate_wave.get(id(g), -1)) + 1
-                gate_wave[id(h)] = gate_wave[id(g)] = wi
+                wi = max(-1 if use_part else gate_wave.get(id(h), -1), gate_wave.get(id(g), -1)) + 1
+                gate_wave[id(g)] = wi
+                if not use_part:
+                    gate_wave[id(h)] = wi
                 while len(waves) <= wi:
                     waves.append([])
                 waves[wi].append(dict(dA=gd["dh"], gate=gd, Y=None, act=L.ACT_NONE, mask=None, accumulate=0,
@@ -2094,6 +2106,13 @@ class MulBatchOp(Op):
         # True: the products themselves leave the epilogue of the GEMM that produces b (LinearGroupOp problems with mul /
         # prod and prod_bwd = "ext": K7 forward); this op only contributes the backward
         self.fwd_fused = bool(fwd_fused)
+        if self.fwd_fused and len(items) <= 8:
+            # A product whose forward left a GEMM's epilogue and that several gate-mode input-gradient problems read as
+            # their factor h (PepNet's gated input: every task's first product) may receive its gradient as PARTS, one
+            # buffer per reader, summed by this op's backward launch inside its sums of products -- instead of one buffer
+            # the readers add to one after the other (four launches in a row for Amazon-8's four tasks)
+            for _, _, o in items:
+                o.grad_parts = []
 
     def inputs(self):
         return [v for a, b, _ in self.items for v in (a, b)]
@@ -2132,13 +2151,16 @@ class MulBatchOp(Op):
     def bwd_calls(self, plan):
         targets = {}  # id(operand) -> [operand, flat numel, [(dout, other factor)]]
         for (a, b, o), n in zip(self.items, self.flat):
-            if o.grad is None:
+            douts = list(getattr(o, "grad_parts", None) or [])
+            if o.grad is not None:
+                douts.append(o.grad)
+            if not douts:
                 continue
-            if o.grad.stride(0) != o.buf.stride(0):
+            if any(d_.stride(0) != o.buf.stride(0) for d_ in douts):
                 raise L.MMLError("MulBatchOp: value / gradient pitch mismatch")
             for v, other in ((a, b), (b, a)):
                 if v.needs_grad:
-                    targets.setdefault(id(v), [v, n, []])[2].append((o.grad, other.buf))
+                    targets.setdefault(id(v), [v, n, []])[2].extend((d_, other.buf) for d_ in douts)
         rows, nbytes = [], 0.0
         for v, n, terms in targets.values():
             g = plan.grad_of(v)

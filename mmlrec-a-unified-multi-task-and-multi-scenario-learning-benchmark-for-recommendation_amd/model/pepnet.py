@@ -118,13 +118,16 @@ class PepNet(BaseModel):
         # products lose (0.58 -> 0.28 ms) the GEMMs give back -- their epilogues load the extra operands (the LDS-DMA
         # pipeline drains at every tile) and the gate mode only fits 128 x 64 tiles.  Fusing the forward alone is a loss
         # (2.58 ms: the activation derivatives no longer fold into a single consumer).
-        # Round 6: ON from 8 192 samples, where the weight-stationary kernel (csrc/gemm_ws.hip) serves these layers: its
-        # turn stores 16 bytes per lane row-major, so the extra operands of the product (forward) and of the gate mode
+        # Round 6: ON.  From 8 192 samples the weight-stationary kernel (csrc/gemm_ws.hip) serves these layers: its turn
+        # stores 16 bytes per lane row-major, so the extra operands of the product (forward) and of the gate mode
         # (backward) are read and written in the same whole-line pieces as the outputs, with no pipeline to drain; the
-        # forward of the two products no Linear layer reads (the gated input, the products in front of the heads) rides
-        # in its gate GEMM's epilogue as well ("fwd").  Below 8 192 the tile kernel would serve them: off (see above).
+        # forward of the gated input rides in its gate GEMM's epilogue as well ("fwd": its backward stays one element-wise
+        # launch that also sums the four tasks' gradient parts), and the products in front of the heads are formed inside
+        # the head kernel (gated heads).
+        # Measured (same box, tools/lab/pep_parts.sh): B = 65 536 1.976 -> 1.757 ms, 8 192 0.592 -> 0.574, 4 096 0.480 -> 0.472
+        # (there the tile kernel's K7 epilogue and the gated heads carry it): on at every batch, MMLREC_PEP_FUSE=0 = off.
         env = os.environ.get("MMLREC_PEP_FUSE")
-        fuse_on = plan.device.type == "cuda" and (env == "1" or (env is None and plan.B >= 8192))
+        fuse_on = plan.device.type == "cuda" and env != "0"
         fuse_fwd = fuse_on and os.environ.get("MMLREC_PEP_FUSE_FWD", "1") != "0"
 
         def can_fuse(n):
