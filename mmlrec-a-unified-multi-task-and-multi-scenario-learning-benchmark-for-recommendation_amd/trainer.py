@@ -91,7 +91,9 @@ def fork_conflicts(side_calls, mid_calls, shared_scratch=()):
             if c[0] is E.PY or c[0] is E.INLINE:
                 continue
             for a in c[1]:
-                if isinstance(a, int) and not isinstance(a, bool) and a >= (1 << 16):
+                # (device addresses on this platform are 47-bit values far above 2^32; sizes, pitches and counts -- a
+                # batch of 65 536 rows is 0x10000 in BOTH lists -- stay below)
+                if isinstance(a, int) and not isinstance(a, bool) and a >= (1 << 32):
                     out.add(a)
         return out
     a, b = ptrs(side_calls), ptrs(mid_calls)
@@ -308,13 +310,14 @@ class TrainStep:
             inner = int(env_fork) if env_fork is not None else (2 if int(B) >= 16384 else 0)
             side_calls = head_side + p.bwd_side
             mid = (p.bwd_tail + self.opt_split["tables"])
+            self.fork_refused = []
             if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
                     not any(c[0] is E.PY for c in mid)):  # (fork and join must land in ONE graph)
                 from . import ops as _ops
                 bad = fork_conflicts(side_calls, mid, [w.data_ptr() for w in _ops._workspaces.values()])
-                if bad:
-                    raise RuntimeError("inner fork: the two branches of the step share device buffers: " +
-                                       ", ".join(hex(x) for x in bad))
+                self.fork_refused = bad  # (a step whose branches share a buffer simply runs unforked)
+            if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
+                    not any(c[0] is E.PY for c in mid) and not self.fork_refused):
                 self.inner_fork = InnerFork(self.store.device, side_calls)
                 fk = [(E.INLINE, self.inner_fork.fork, ())]
                 jn = [(E.INLINE, self.inner_fork.join, ())]

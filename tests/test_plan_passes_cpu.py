@@ -227,3 +227,4 @@ def test_fork_conflicts_sees_shared_scratch_and_common_pointers():
     mid2 = mid + [(f, (0x7f0000100000, 8))]
     assert trainer.fork_conflicts(side, mid2) == [0x7f0000100000]                                     # a common pointer
     assert trainer.fork_conflicts([(f, (64, 1, True))], [(f, (64, 1))]) == []                         # small integers are sizes
+    assert trainer.fork_conflicts([(f, (0x10000, 1 << 24))], [(f, (0x10000, 1 << 24))]) == []         # ... a batch of 65 536 rows too
