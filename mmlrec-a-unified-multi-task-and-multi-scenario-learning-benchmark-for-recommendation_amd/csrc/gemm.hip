@@ -1965,6 +1965,7 @@ int mml_gemm_panel_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st
 // fits the LDS (second expert layers, towers, and their input gradients)
 int mml_gemm_ws_try_fwd(const mml_gemm_fwd_desc* d, int32_t n, hipStream_t st);
 int mml_gemm_ws_try_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, hipStream_t st);
+namespace mml { const char* mml_gemm_ws_last_symbol(); }
 
 extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_stream_t stream) {
   MML_REQUIRE(n >= 0 && (n == 0 || d), "mml_gemm_grouped_fwd: bad descriptor array");
@@ -1976,7 +1977,7 @@ extern "C" int mml_gemm_grouped_fwd(const mml_gemm_fwd_desc* d, int32_t n, mml_s
     }
     rc = mml_gemm_ws_try_fwd(d, n, to_stream(stream));
     if (rc != MML_ERR_UNSUPPORTED) {
-      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_ws_kernel");
+      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", mml::mml_gemm_ws_last_symbol());
       return rc;
     }
   }
@@ -2059,7 +2060,7 @@ extern "C" int mml_gemm_grouped_dgrad(const mml_gemm_dgrad_desc* d, int32_t n, m
     }
     rc = mml_gemm_ws_try_dgrad(d, n, to_stream(stream));
     if (rc != MML_ERR_UNSUPPORTED) {
-      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_ws_kernel");
+      if (rc == MML_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", mml::mml_gemm_ws_last_symbol());
       return rc;
     }
   }

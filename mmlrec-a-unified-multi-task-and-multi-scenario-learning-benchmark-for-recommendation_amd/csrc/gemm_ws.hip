@@ -411,9 +411,15 @@ static int ws_cus() {
   return cus;
 }
 
+// symbol of the calling thread's most recent weight-stationary launch, as rocprofv3 prints it (mml_gemm_last_kernel)
+static thread_local char g_ws_last[64] = "gemm_ws_kernel";
+const char* mml_gemm_ws_last_symbol() { return g_ws_last; }
+
 template <int MODE>
 static int ws_launch(const WsLaunch& L, const int nout, const bool masks, const int dgroup, const bool k7, hipStream_t st) {
   const dim3 g((unsigned)(L.wg_per_prob * L.n_prob)), b(512);
+  snprintf(g_ws_last, sizeof(g_ws_last), "gemm_ws_kernel<%d, %d, %s, %d, %s>", nout / 32, MODE, (masks && !k7) ? "true" : "false",
+           dgroup, k7 ? "true" : "false");
 #define WS_GO2(NS_, D_)                                                                 \
   do {                                                                                  \
     if (k7) MML_LAUNCH((gemm_ws_kernel<NS_, MODE, false, D_, true>), g, b, 0, st, L);   \

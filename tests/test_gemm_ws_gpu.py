@@ -83,7 +83,7 @@ def test_ws_fwd_matches_float64_and_the_tile_kernel(env, M, K, N, nprob, kn, mas
     lib.mml_gemm_set_mode(4)
     probs = fwd_launch(torch, L, ops, M, K, N, nprob, kn=kn, seed=M + K)
     name_w, out_w = run_fwd(torch, ops, lib, probs, True, masks)
-    assert name_w == "gemm_ws_kernel", name_w
+    assert name_w.startswith("gemm_ws_kernel"), name_w
     name_t, out_t = run_fwd(torch, ops, lib, probs, False, masks)
     assert "gemm_pipe_kernel" in name_t, name_t
     for p, (C, mk, am), (Ct, mkt, amt) in zip(probs, out_w, out_t):
@@ -109,7 +109,7 @@ def test_ws_fwd_linear_layers_and_scales(env):
     for scale in (3e-9, 1.0, 2e20):
         probs = fwd_launch(torch, L, ops, 8192 + 33, 128, 128, 2, acts=[L.ACT_NONE, L.ACT_RELU], seed=3, scale=scale)
         name, out = run_fwd(torch, ops, lib, probs, True, False)
-        assert name == "gemm_ws_kernel"
+        assert name.startswith("gemm_ws_kernel")
         for p, (C, _, am) in zip(probs, out):
             z = p["A"].double() @ p["W"].double().t()
             if p["bias"] is not None:
@@ -132,7 +132,7 @@ def test_ws_fwd_mixed_widths_and_gate_activations(env):
     acts = [L.ACT_RELU, L.ACT_SIGMOID2, L.ACT_SIGMOID, L.ACT_NONE, L.ACT_SIGMOID2, L.ACT_RELU, L.ACT_RELU]
     probs = fwd_launch(torch, L, ops, M, Ks, Ns, 7, acts=acts, seed=21)
     name_w, out_w = run_fwd(torch, ops, lib, probs, True, False)
-    assert name_w == "gemm_ws_kernel", name_w
+    assert name_w.startswith("gemm_ws_kernel"), name_w
     name_t, out_t = run_fwd(torch, ops, lib, probs, False, False)
     assert "gemm_pipe_kernel" in name_t
     for p, (C, _, am), (Ct, _, _) in zip(probs, out_w, out_t):
@@ -156,7 +156,7 @@ def test_launches_the_ws_kernel_does_not_serve_fall_back(env):
                           (8192, 256, 256, None), (8192, 128, 192, None)):
         probs = fwd_launch(torch, L, ops, M, K, N, 1, acts=acts)
         name, out = run_fwd(torch, ops, lib, probs, True, False)
-        assert name != "gemm_ws_kernel", (M, K, N, name)
+        assert not name.startswith("gemm_ws_kernel"), (M, K, N, name)
         z = probs[0]["A"].double() @ probs[0]["W"].double().t() + probs[0]["bias"].double()
         ref = torch.relu(z)
         assert float((out[0][0].double() - ref).abs().max() / ref.abs().max()) < RTOL
@@ -218,7 +218,7 @@ def test_ws_dgrad_matches_float64_and_the_tile_kernel(env, M, Nred, K, nprob, kn
     lib.mml_gemm_set_mode(4)
     probs = dgrad_launch(torch, L, ops, M, Nred, K, nprob, kn=kn, relu=relu, seed=M + K)
     name_w, olds, out_w = run_dgrad(torch, ops, lib, probs, True, acc)
-    assert name_w == "gemm_ws_kernel", name_w
+    assert name_w.startswith("gemm_ws_kernel"), name_w
     name_t, _, out_t = run_dgrad(torch, ops, lib, probs, False, acc)
     assert "gemm_pipe_kernel" in name_t, name_t
     for p, old, (dA, am), (dAt, amt) in zip(probs, olds, out_w, out_t):
@@ -242,15 +242,15 @@ def test_dgrad_launches_the_ws_kernel_does_not_serve_fall_back(env):
     probs = dgrad_launch(torch, L, ops, 8192, 128, 256, 2, seed=5)
     two = [dict(probs[0], srcs=probs[0]["srcs"] + probs[1]["srcs"])]
     name, _, out = run_dgrad(torch, ops, lib, two, True, False)
-    assert name != "gemm_ws_kernel"
+    assert not name.startswith("gemm_ws_kernel")
     v = sum(s[0].double() @ s[1].double() for s in two[0]["srcs"]) * (two[0]["Y"] > 0).double()
     assert float((out[0][0].double() - v).abs().max() / v.abs().max()) < RTOL
     noy = [dict(probs[0], mask=None)]
     name, _, out = run_dgrad(torch, ops, lib, noy, True, False)
-    assert name != "gemm_ws_kernel"
+    assert not name.startswith("gemm_ws_kernel")
     probs = dgrad_launch(torch, L, ops, 8192, 64, 192, 1, seed=6)
     name, _, _ = run_dgrad(torch, ops, lib, probs, True, False)
-    assert name != "gemm_ws_kernel"
+    assert not name.startswith("gemm_ws_kernel")
 
 
 def test_ws_kernels_are_repeatable_on_a_full_chip(env):
@@ -261,7 +261,7 @@ def test_ws_kernels_are_repeatable_on_a_full_chip(env):
     _, ref = run_fwd(torch, ops, lib, probs, False, True)
     for rep in range(20):
         name, out = run_fwd(torch, ops, lib, probs, True, True)
-        assert name == "gemm_ws_kernel"
+        assert name.startswith("gemm_ws_kernel")
         for i, ((C, mk, am), (Ct, mkt, amt)) in enumerate(zip(out, ref)):
             assert torch.equal(C, Ct), (rep, i, int((C != Ct).sum()))
             assert torch.equal(mk, mkt), (rep, i)
@@ -270,7 +270,7 @@ def test_ws_kernels_are_repeatable_on_a_full_chip(env):
     _, _, dref = run_dgrad(torch, ops, lib, dprobs, False, False)
     for rep in range(20):
         name, _, out = run_dgrad(torch, ops, lib, dprobs, True, False)
-        assert name == "gemm_ws_kernel"
+        assert name.startswith("gemm_ws_kernel")
         for i, ((dA, am), (dAt, amt)) in enumerate(zip(out, dref)):
             assert torch.equal(dA, dAt), (rep, i, int((dA != dAt).sum()))
 
@@ -300,7 +300,7 @@ def test_ws_fwd_with_gate_product(env, M, K, N, nprob):
             p["prod"] = torch.full((M, N), float("nan"), device=dev)
             p["amax_prod"].zero_()
         name, out = run_fwd(torch, ops, lib, probs, ws, False)
-        assert (name == "gemm_ws_kernel") == ws, name
+        assert name.startswith("gemm_ws_kernel") == ws, name
         res[ws] = [(C, p["prod"].clone(), am, p["amax_prod"].clone()) for p, (C, _, am) in zip(probs, out)]
     for p, (C, prod, am, am2), (Ct, prodt, amt, am2t) in zip(probs, res[True], res[False]):
         z = p["A"].double() @ p["W"].double().t() + (p["bias"].double() if p["bias"] is not None else 0.0)
@@ -353,7 +353,7 @@ def test_ws_dgrad_gate_mode(env, M, Nred, K, nprob, act_h, acc_h, acc_g):
         L.check(lib.mml_pep_gate_bwd(arr, len(launch), ops._stream()), "mml_pep_gate_bwd")
         torch.cuda.synchronize()
         name = lib.mml_gemm_last_kernel().decode()
-        assert (name == "gemm_ws_kernel") == ws, name
+        assert name.startswith("gemm_ws_kernel") == ws, name
         res[ws] = [(q["dh"].clone(), q["dg"].clone(), q["slots"].clone()) for q in gates]
     for p, q, (dh, dg, sl), (dht, dgt, slt) in zip(probs, gates, res[True], res[False]):
         dC, W = p["srcs"][0][:2]

@@ -114,7 +114,7 @@ def test_star_linear_fwd(env, mode, M, K, Ns):
     L.check(lib.mml_star_linear_fwd(arr, len(probs), ops._stream()), "mml_star_linear_fwd")
     torch.cuda.synchronize()
     name = lib.mml_gemm_last_kernel().decode()
-    assert "gemm_pipe_kernel" in name or name == "gemm_ws_kernel", name  # (8 269 x 256 -> 128: the weight-stationary kernel)
+    assert "gemm_pipe_kernel" in name or name.startswith("gemm_ws_kernel"), name  # (8 269 x 256 -> 128: the weight-stationary kernel)
     outs = [p["C"].clone() for p in probs]
     for p, C in zip(probs, outs):
         ref = torch.relu(A.double() @ p["W"].double() + p["bias"].double())
