@@ -429,8 +429,17 @@ __device__ __forceinline__ bf16x8 nt_fragment(const uint16_t* tile, int ms, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 3) void g16_nt_kernel(const G16NtLaunch L) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 64 * 128];
+// KW = 256 (round 6): the workgroup's tile is 128 (N) x 256 (K), a wave's 64 x 128 -- per 16-row sub-step it reads 2 + 4
+// fragments for 8 MFMAs (0.75 fragment reads per MFMA) where the 64 x 64 wave tile of KW = 128 reads 2 + 2 for 4 (1.0: the
+// LDS pipe exactly as busy as the matrix pipes, see g16_tn_kernel<256>).  The weight gradient's reduction is the batch --
+// hundreds of steps per workgroup -- so the lower occupancy (128 accumulator registers: two workgroups per CU) costs no
+// prologue / epilogue overlap here.  The A tile is two 64 x 128 images (one per k-half of the tile, the layout nt_fragment
+// reads); wave (wn, wk) takes image wk.
+template <int KW>
+__global__ __launch_bounds__(256, KW == 256 ? 2 : 3) void g16_nt_kernel(const G16NtLaunch L) {
+  constexpr int NIMG = KW / 128;   // A images
+  constexpr int NJ = KW / 64;      // 32-column sub-tiles of a wave along K
+  __shared__ __attribute__((aligned(16))) uint16_t lds[(1 + NIMG) * 64 * 128];
   uint16_t* const sC = lds;
   uint16_t* const sA = lds + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -443,18 +452,18 @@ __global__ __launch_bounds__(256, 3) void g16_nt_kernel(const G16NtLaunch L) {
   while (t >= L.p[pi].ntiles * L.p[pi].ktiles) t -= L.p[pi].ntiles * L.p[pi].ktiles, ++pi;  // (uniform)
   const G16NtProblem& P = L.p[pi];
   const int nt = t / P.ktiles, kt = t - nt * P.ktiles;
-  const int n0 = nt * 128, k0 = kt * 128;
+  const int n0 = nt * 128, k0 = kt * KW;
   const int per = (L.steps + L.slabs - 1) / L.slabs;
   const int s_begin = slab * per, s_end = min(L.steps, s_begin + per);
   const bool want_bias = P.ws_bias != nullptr && kt == 0;  // (uniform)
 
-  f32x16 acc[2][2], accb[2];
+  f32x16 acc[2][NJ], accb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
@@ -463,31 +472,36 @@ __global__ __launch_bounds__(256, 3) void g16_nt_kernel(const G16NtLaunch L) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones_v[e] = (lane & 31) == 0 ? (short)0x3F80 : (short)0;
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_v);
+  // this wave's A image and first chunk inside it
+  const uint16_t* const myA = sA + (NIMG == 2 ? wk : 0) * 64 * 128;
+  const int chunkA0 = NIMG == 2 ? 0 : wk * 8;
 
   const int lrow = lane >> 4, lpos = lane & 15;
   for (int st = s_begin; st < s_end; ++st) {
     const int64_t m0 = (int64_t)st * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // each operand: 64 rows of 256 bytes, 4 DMA instructions of 4 rows per wave
+    for (int i = 0; i < 4; ++i) {  // each image: 64 rows of 256 bytes, 4 DMA instructions of 4 rows per wave
       const int row = (w * 4 + i) * 4 + lrow;
       const int ch = lpos ^ nt_swz(row);
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(P.dC + (m0 + row) * P.lddc + n0 + (ch << 3)),
                                        reinterpret_cast<float*>(sC + (w * 4 + i) * 4 * 128), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(P.A + (m0 + row) * P.lda + k0 + (ch << 3)),
-                                       reinterpret_cast<float*>(sA + (w * 4 + i) * 4 * 128), 16, 0, 0);
+#pragma unroll
+      for (int im = 0; im < NIMG; ++im)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(P.A + (m0 + row) * P.lda + k0 + im * 128 + (ch << 3)),
+                                         reinterpret_cast<float*>(sA + im * 64 * 128 + (w * 4 + i) * 4 * 128), 16, 0, 0);
     }
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      bf16x8 a[2], b[2];
+      bf16x8 a[2], b[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = nt_fragment(sC, sub * 16, wn * 8 + i * 4, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = nt_fragment(sA, sub * 16, wk * 8 + j * 4, lane);
+      for (int j = 0; j < NJ; ++j) b[j] = nt_fragment(myA, sub * 16, chunkA0 + j * 4, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       if (want_bias && wk == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
@@ -501,11 +515,11 @@ __global__ __launch_bounds__(256, 3) void g16_nt_kernel(const G16NtLaunch L) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int k = k0 + wk * 64 + j * 32 + c31;
+        const int k = k0 + wk * (KW / 2) + j * 32 + c31;
         ws[(int64_t)n * P.K + k] = acc[i][j][r];
       }
   if (want_bias && wk == 0 && c31 == 0) {
@@ -736,6 +750,20 @@ extern "C" int mml_g16_tn(const mml_g16_tn_desc* d, int32_t n, mml_stream_t stre
   return MML_OK;
 }
 
+// 128 x 256 tiles (g16_nt_kernel<256>) for a launch whose problems all have K % 256 == 0 (MMLREC_G16_NT_KW=128 keeps the
+// narrow tiles: lab knob, read once)
+static bool g16_nt_wide(const mml_g16_wgrad_desc* d, int32_t n) {
+  static int kw = 0;
+  if (kw == 0) {
+    const char* e = getenv("MMLREC_G16_NT_KW");
+    kw = (e && atoi(e) > 0) ? atoi(e) : 256;
+  }
+  if (kw < 256 || d[0].M < 8192) return false;
+  for (int i = 0; i < n; ++i)
+    if (d[i].K % 256 != 0) return false;
+  return true;
+}
+
 static int g16_wgrad_plan(const mml_g16_wgrad_desc* d, int32_t n, int* slabs_out, int64_t* bytes_out) {
   MML_REQUIRE(d != nullptr, "mml_g16_wgrad: descriptor array is null");
   MML_REQUIRE(n >= 1 && n <= G16_MAX_GROUP, "mml_g16_wgrad: 1 .. %d problems per launch", G16_MAX_GROUP);
@@ -752,6 +780,7 @@ static int g16_wgrad_plan(const mml_g16_wgrad_desc* d, int32_t n, int* slabs_out
     tiles += (int64_t)(q.N / 128) * (q.K / 128);
     elems += (int64_t)q.N * q.K + q.N;
   }
+  if (g16_nt_wide(d, n)) tiles /= 2;  // (K % 256 == 0 for every problem: exact)
   const int steps = d[0].M / 64;
   // slabs: enough workgroups for two per CU, at least four 64-row steps each, at most 32 (the partial tiles are
   // written and read back: 64 KiB per tile and slab)
@@ -781,6 +810,7 @@ extern "C" int mml_g16_wgrad(const mml_g16_wgrad_desc* d, int32_t n, void* works
   MML_REQUIRE(phase >= 0 && phase <= 2, "mml_g16_wgrad: phase must be 0, 1 or 2");
   G16NtLaunch L{};
   G16RedLaunch R{};
+  const bool wide = g16_nt_wide(d, n);
   L.n_prob = R.n_prob = n;
   L.steps = d[0].M / 64;
   L.slabs = R.slabs = slabs;
@@ -790,7 +820,7 @@ extern "C" int mml_g16_wgrad(const mml_g16_wgrad_desc* d, int32_t n, void* works
     const mml_g16_wgrad_desc& q = d[i];
     G16NtProblem& P = L.p[i];
     P.dC = q.dC; P.A = q.A; P.lddc = q.lddc; P.lda = q.lda; P.N = q.N; P.K = q.K;
-    P.ntiles = q.N / 128; P.ktiles = q.K / 128;
+    P.ntiles = q.N / 128; P.ktiles = q.K / (wide ? 256 : 128);
     P.ws = ws;
     ws += (int64_t)slabs * q.N * q.K;
     P.ws_bias = q.dbias ? ws : nullptr;
@@ -803,8 +833,13 @@ extern "C" int mml_g16_wgrad(const mml_g16_wgrad_desc* d, int32_t n, void* works
     maxred = blocks > maxred ? blocks : maxred;
   }
   if (phase != 2) {
-    MML_LAUNCH(g16_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, to_stream(stream), L);
-    g16_last = "g16_nt_kernel";
+    if (wide) {
+      MML_LAUNCH(g16_nt_kernel<256>, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, to_stream(stream), L);
+      g16_last = "g16_nt_kernel<256>";
+    } else {
+      MML_LAUNCH(g16_nt_kernel<128>, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, to_stream(stream), L);
+      g16_last = "g16_nt_kernel<128>";
+    }
     const int rc = check_launch("mml_g16_wgrad");
     if (rc != MML_OK) return rc;
   }

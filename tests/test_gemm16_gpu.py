@@ -215,12 +215,16 @@ def test_input_gradient_multi_source_mask_and_accumulate(ops):
     assert bool((f64(dH)[~bits] == 0).all())
 
 
-@pytest.mark.parametrize("M,phases", [(256, False), (65536, True), (8192 + 64, False)])
-def test_weight_gradient_with_bias_gradient(ops, M, phases):
+@pytest.mark.parametrize("M,phases,extra", [(256, False, None), (65536, True, None), (8192 + 64, False, None),
+                                            (8192 + 64, False, (128, 384)), (16384, True, (256, 128))])
+def test_weight_gradient_with_bias_gradient(ops, M, phases, extra):
     """dW = dC^T A and dbias = column sums of dC over the batch, for the KuaiRec layer shapes in one launch; the batch
-    reduction runs through the transposing LDS reads (ds_read_b64_tr_b16).  M = 8 256: slabs of unequal length."""
+    reduction runs through the transposing LDS reads (ds_read_b64_tr_b16).  M = 8 256: slabs of unequal length.  Round 6:
+    launches whose problems all have K % 256 == 0 run 128 x 256 tiles from 8 192 rows on (g16_nt_kernel<256>); one problem
+    with K = 384 or 128 keeps the whole launch on the 128 x 128 tiles."""
+    from mmlrec_amd import _lib as L_
     g = torch.Generator().manual_seed(5)
-    shapes = [(512, 512), (128, 512), (256, 512), (128, 256)]
+    shapes = [(512, 512), (128, 512), (256, 512), (128, 256)] + ([extra] if extra else [])
     probs, refs = [], []
     for N, K in shapes:
         dC = rand16(g, M, N)
@@ -230,7 +234,9 @@ def test_weight_gradient_with_bias_gradient(ops, M, phases):
         probs.append(dict(dC=dC, A=A, dW=dW, dbias=db))
         refs.append((f64(dC).t() @ f64(A), f64(dC).sum(0)))
     ops.g16_wgrad(probs, phases=phases)
-    from mmlrec_amd import _lib as L
+    if not phases:
+        want = "g16_nt_kernel<256>" if (M >= 8192 and extra is None) else "g16_nt_kernel<128>"
+        assert L_.load().mml_g16_last_kernel().decode() in (want, "g16_reduce_kernel"), L_.load().mml_g16_last_kernel()
     for q, (rw, rb) in zip(probs, refs):
         assert maxrel(q["dW"], rw) < 2e-5, (tuple(rw.shape), maxrel(q["dW"], rw))
         assert maxrel(q["dbias"], rb) < 2e-5
