@@ -1276,7 +1276,9 @@ class LinearGroupOp(Op):
                 # h shared by several products and able to take its gradient in parts (MulBatchOp(fwd_fused)): this
                 # problem writes a buffer of its own -- no accumulation, no order between the sharing problems
                 parts = getattr(h, "grad_parts", None)
-                use_part = (parts is not None and h.act == L.ACT_NONE and len(parts) < 8 and
+                # (at most seven: the summing launch takes eight terms per target -- parts + the plain gradient buffer a
+                # further reader would add to)
+                use_part = (parts is not None and h.act == L.ACT_NONE and len(parts) < 7 and
                             h.buf.stride(0) == h.n and os.environ.get("MMLREC_GRAD_PARTS", "1") != "0")
                 for key, v, nc in (("h", h, 1), ("g", g, 0)):
                     if key == "h" and use_part:
