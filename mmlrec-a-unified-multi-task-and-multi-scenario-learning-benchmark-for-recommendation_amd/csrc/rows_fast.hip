@@ -619,6 +619,11 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 // GATED (round 6): heads whose input is Hin (.) gate (mml_head_desc.gate; PepNet's last PPNet layer): the product is formed
 // in registers from the two rows, the backward writes dH = dlogit w gate relu'(Hin) and dgate = dlogit w Hin act'(gate) --
 // the product, its gradient and the element-wise launches around them never touch memory.
+// samples per lane group and trip (see the loop below).  Round 6: four for up to four plain heads as well (STAR's four heads:
+// 90 -> 84 us at B = 65 536, 206 VGPRs at two workgroups per CU); gated heads hold two rows per sample and head: two.
+#ifndef MML_HEAD_U
+#define MML_HEAD_U (NT <= 2 ? 4 : ((NT <= 4 && !GATED) ? 4 : 2))
+#endif
 template <int LPS, int NT, bool GATED>
 __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, const HeadFastAux aux) {
   __shared__ float red[FW][NT * (4 * LPS + 1) + 1];
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(FB) void head_fast_kernel(const mml_head_group g, c
   // first logit is formed.  One sample per trip (until round 5) left a wave with two 16-byte loads in flight in front of
   // a chain of DPP sums, exp, log and log1p: 28 us for 67 MB at B = 65 536 (2.3 TB/s).  The samples of a lane group
   // are visited in the same order as before: the partial sums of dw / dbias / loss are the same bits.
-  constexpr int U = NT <= 2 ? 4 : 2;
+  constexpr int U = MML_HEAD_U;
   for (int64_t it0 = 0; it0 < iters; it0 += U) {
     int64_t bb[U];
     bool vld[U];
