@@ -571,6 +571,7 @@ int mml_head_bce_fwd_bwd_phase(const mml_head_group* grp, void* workspace, int64
  * order of the partial sums is fixed either way).  At most 40 result tensors per call. */
 #define MML_ROWS_REDUCE_HEAD 0
 #define MML_ROWS_REDUCE_GATE 1
+#define MML_ROWS_REDUCE_TOWER_HEAD 2   /* group = const mml_tower_head_group* (K5') */
 typedef struct {
   int32_t kind; /* MML_ROWS_REDUCE_HEAD: group = const mml_head_group*; MML_ROWS_REDUCE_GATE: const mml_gate_group* */
   int32_t pad_;
@@ -579,6 +580,64 @@ typedef struct {
   int64_t workspace_bytes;
 } mml_rows_reduce_item;
 int mml_rows_reduce_batch(const mml_rows_reduce_item* items, int32_t n, mml_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5' (round 6)  the top of the network in ONE launch: last tower layer (Linear(K -> N) + ReLU) -> head (Linear(N -> 1,
+ * no bias) + PredictionLayer bias + sigmoid) -> optional domain-mask product -> summed BCE -> backward of all of it down to
+ * dL/d(tower input).  Replaces, for every task t, tower_dnn[t] (its last layer), tower_dnn_final_layer[t], out[t] and the
+ * loss terms of model/mmoe.py:93-108, model/utils.py:146-161, :242-248, model/basemodel.py:294-296 -- i.e. one
+ * mml_gemm_grouped_fwd, one mml_head_bce_fwd_bwd and one mml_gemm_grouped_dgrad launch.  The tower outputs stay in
+ * registers; written: prob, dH = dL/d(tower pre-activation) (the tower's weight gradient reads it), dA = dL/d(tower input)
+ * (overwritten), and the head's dw / dhbias and the loss through per-workgroup partial sums (phase 2: fixed order).
+ * Arithmetic: the two-plane fp16 products of the GEMM family (the tower weight's pre-cut planes in BOTH layouts,
+ * mml_gemm_planes_cut; the input's magnitude slot; dH is scaled per 32-row block by its own largest magnitude), the head
+ * kernel's expressions for probability, clamped-log BCE and its derivative.  Training only (y required).
+ * Served shapes: mml_tower_head_serves (all tasks of one (N, K) in {(64, 128), (64, 64)}, 16-byte aligned rows).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* A;               /* [M, K] tower input                                                     */
+  int64_t lda;
+  const uint32_t* amax_a;       /* magnitude slot of A                                                    */
+  const uint32_t* w_planes_fwd; /* planes of the tower weight W [N, K], MML_PLANES_ROWS, pitch ldpf words */
+  const uint32_t* w_planes_bwd; /* planes of the same W, MML_PLANES_COLS, pitch ldpb words                */
+  int64_t ldpf, ldpb;
+  const int32_t* kexp_fwd;      /* exponents the two images were cut with                                 */
+  const int32_t* kexp_bwd;
+  const float* bias1;           /* [N] tower bias or NULL                                                 */
+  const float* w;               /* [N] head weight                                                        */
+  const float* hbias;           /* [1] PredictionLayer bias                                               */
+  const float* hbias2;          /* [n_hbias2] further bias terms summed in, or NULL                       */
+  float* dH;                    /* [M, N]                                                                 */
+  float* dA;                    /* [M, K]                                                                 */
+  int64_t lddh, ldda;
+  float* dw;                    /* [N] head weight gradient                                               */
+  float* dhbias;                /* [1]                                                                    */
+  uint32_t* amax_dH;            /* optional magnitude slots raised with what was stored, or NULL          */
+  uint32_t* amax_dA;
+  int32_t K, N, n_hbias2;
+  int32_t mask_col;             /* column of `mask` multiplied into the probability, or -1                */
+  int32_t head;                 /* column of prob / y this task uses                                      */
+  int32_t pad_;
+} mml_tower_head_desc;
+typedef struct {
+  int32_t n;                    /* tasks                                                                  */
+  int32_t pad_;
+  int64_t M;
+  float* prob;                  /* [M, ldprob]                                                            */
+  int64_t ldprob;
+  const float* y;               /* [M, ldy] labels                                                        */
+  int64_t ldy;
+  const float* mask;            /* [M, ldmask] domain mask or NULL                                        */
+  int64_t ldmask;
+  float* loss;                  /* [1] sum of BCE over tasks and samples (overwritten), or NULL           */
+  mml_tower_head_desc t[MML_MAX_HEADS];
+} mml_tower_head_group;
+int mml_tower_head_serves(const mml_tower_head_group* grp);            /* 1 / 0, no error text                   */
+int64_t mml_tower_head_workspace_bytes(const mml_tower_head_group* grp);
+/* phase 1: the launch; 2: the reduction of the partial sums; 0: both */
+int mml_tower_head_fwd_bwd(const mml_tower_head_group* grp, void* workspace, int64_t workspace_bytes, int32_t phase,
+                           mml_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * K3'  bf16-STORAGE GEMM family (round 5; csrc/gemm16.hip) -- BASELINE.json configs[1] ("MMoE ... KuaiRec-shaped ...

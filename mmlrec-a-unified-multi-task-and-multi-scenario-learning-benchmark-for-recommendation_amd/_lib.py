@@ -77,7 +77,7 @@ class RowsReduceItem(C.Structure):
     _fields_ = [("kind", i32), ("pad_", i32), ("group", fp), ("workspace", fp), ("workspace_bytes", i64)]
 
 
-ROWS_REDUCE_HEAD, ROWS_REDUCE_GATE = 0, 1
+ROWS_REDUCE_HEAD, ROWS_REDUCE_GATE, ROWS_REDUCE_TOWER_HEAD = 0, 1, 2
 MAX_REDUCE_SEGS = 40  # csrc/reduce.hpp: segments of one reduction launch
 GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16, GATE_E_BF16 = 1, 2, 4, 8
 
@@ -106,6 +106,19 @@ class HeadGroup(C.Structure):
     _fields_ = [("n_heads", i32), ("dh_bf16", i32), ("B", i64), ("prob", fp), ("ldprob", i64), ("y", fp),
                 ("ldy", i64), ("mask", fp), ("ldmask", i64), ("loss", fp), ("dprob", fp), ("lddprob", i64),
                 ("head", HeadDesc * MAX_HEADS), ("amax_dH", fp), ("amax_dG", fp)]
+
+
+class TowerHeadDesc(C.Structure):
+    _fields_ = [("A", fp), ("lda", i64), ("amax_a", fp), ("w_planes_fwd", fp), ("w_planes_bwd", fp), ("ldpf", i64),
+                ("ldpb", i64), ("kexp_fwd", fp), ("kexp_bwd", fp), ("bias1", fp), ("w", fp), ("hbias", fp),
+                ("hbias2", fp), ("dH", fp), ("dA", fp), ("lddh", i64), ("ldda", i64), ("dw", fp), ("dhbias", fp),
+                ("amax_dH", fp), ("amax_dA", fp), ("K", i32), ("N", i32), ("n_hbias2", i32), ("mask_col", i32),
+                ("head", i32), ("pad_", i32)]
+
+
+class TowerHeadGroup(C.Structure):
+    _fields_ = [("n", i32), ("pad_", i32), ("M", i64), ("prob", fp), ("ldprob", i64), ("y", fp), ("ldy", i64),
+                ("mask", fp), ("ldmask", i64), ("loss", fp), ("t", TowerHeadDesc * MAX_HEADS)]
 
 
 class OptTensor(C.Structure):
@@ -172,6 +185,9 @@ _SIGS = {
     "mml_gemm_set_ws": (C.c_int, [i32]),
     "mml_gemm_set_nt": (C.c_int, [i32]),
     "mml_gemm_nt_serves": (C.c_int, [_PP(GemmWgradDesc)]),
+    "mml_tower_head_serves": (C.c_int, [_PP(TowerHeadGroup)]),
+    "mml_tower_head_workspace_bytes": (i64, [_PP(TowerHeadGroup)]),
+    "mml_tower_head_fwd_bwd": (C.c_int, [_PP(TowerHeadGroup), fp, i64, i32, fp]),
     "mml_gemm_last_kernel": (C.c_char_p, []),
     "mml_gather_last_kernel": (C.c_char_p, []),
     "mml_gemm_set_wgrad_lds_pad": (C.c_int, [i32]),

@@ -553,6 +553,8 @@ extern "C" int mml_rows_reduce_batch(const mml_rows_reduce_item* items, int32_t 
       rc = mml_head_bce_fwd_bwd_phase(static_cast<const mml_head_group*>(it.group), it.workspace, it.workspace_bytes, 2, stream);
     else if (it.kind == MML_ROWS_REDUCE_GATE)
       rc = mml_gate_mix_bwd_phase(static_cast<const mml_gate_group*>(it.group), it.workspace, it.workspace_bytes, 2, stream);
+    else if (it.kind == MML_ROWS_REDUCE_TOWER_HEAD)
+      rc = mml_tower_head_fwd_bwd(static_cast<const mml_tower_head_group*>(it.group), it.workspace, it.workspace_bytes, 2, stream);
     else {
       set_error("mml_rows_reduce_batch: item %d: kind %d", i, it.kind);
       rc = MML_ERR_ARG;

@@ -690,13 +690,107 @@ class Plan:
         self.bwd_side = [c for pair in zip(merged, reduces) for c in pair] + rest
         return True
 
+    def fuse_tower_head(self):
+        """K5' (csrc/tower_head.hip): the last tower layer of every task, the heads + summed BCE and the towers' input gradient
+        -- three launches of the recorded step -- as ONE launch (+ its share of the batched reduction), when the recorded
+        lists hold exactly that pattern: a forward launch of T Linear + ReLU problems whose outputs are the T heads' inputs and
+        nothing else's, the deferred head launch, and an input-gradient launch of T single-source problems over the heads'
+        dH.  Rewrites fwd / head_train / head_side / bwd of THIS plan (a TrainStep's own: the forward-only and the dL/dprob
+        lists of a model's cached plans are never touched).  MMLREC_TOWER_HEAD=0: off."""
+        lib = L.load()
+        if (os.environ.get("MMLREC_TOWER_HEAD", "1") == "0" or self.amax_pool is None or self.bf16 or
+                self.device.type != "cuda"):
+            return False
+        fh, ff, fd = lib.mml_head_bce_fwd_bwd_phase, lib.mml_gemm_grouped_fwd, lib.mml_gemm_grouped_dgrad
+        if len(self.head_train) != 1 or len(self.head_side) != 1:
+            return False
+        hc, hs = self.head_train[0], self.head_side[0]
+        if hc[0] is not fh or hs[0] is not fh or hc[1][3] != 1 or hs[1][3] != 2:
+            return False
+        grp = hc[1][0]._obj
+        T = int(grp.n_heads)
+        if grp.dh_bf16 or grp.dprob or not grp.y or not grp.prob or T < 1:
+            return False
+        heads = [grp.head[t] for t in range(T)]
+        if any(h.gate or h.w2 or not h.dH or not h.h_relu or not h.dw or not h.dbias for h in heads):
+            return False
+        hin = {int(h.Hin): t for t, h in enumerate(heads)}
+        dh = {int(h.dH): t for t, h in enumerate(heads)}
+        if len(hin) != T or len(dh) != T:
+            return False
+        # the forward launch that writes the heads' inputs
+        fi = None
+        for i in range(len(self.fwd) - 1, -1, -1):
+            c = self.fwd[i]
+            if c[0] is ff and c[1][1] == T and all(int(c[1][0][k].C or 0) in hin for k in range(T)):
+                fi = i
+                break
+        if fi is None:
+            return False
+        fdesc = self.fwd[fi][1][0]
+        # the input-gradient launch over the heads' dH
+        di = None
+        for i, c in enumerate(self.bwd):
+            if c[0] is fd and c[1][1] == T and all(c[1][0][k].n_src == 1 and int(c[1][0][k].dC[0] or 0) in dh for k in range(T)):
+                di = i
+                break
+        if di is None:
+            return False
+        ddesc = self.bwd[di][1][0]
+        by_t_f = {hin[int(fdesc[k].C)]: fdesc[k] for k in range(T)}
+        by_t_d = {dh[int(ddesc[k].dC[0])]: ddesc[k] for k in range(T)}
+        if len(by_t_f) != T or len(by_t_d) != T:
+            return False
+        g = L.TowerHeadGroup()
+        g.n, g.M = T, int(grp.B)
+        g.prob, g.ldprob, g.y, g.ldy, g.mask, g.ldmask, g.loss = grp.prob, grp.ldprob, grp.y, grp.ldy, grp.mask, grp.ldmask, grp.loss
+        for t in range(T):
+            f, d, h = by_t_f[t], by_t_d[t], heads[t]
+            if (f.act != L.ACT_RELU or f.w_kn or f.mul or not f.w_planes or not f.w_kexp or not f.amax_a or f.M != g.M or
+                    f.N != h.H or int(f.ldc) != int(h.ldh)):
+                return False
+            if (d.gate_h or d.Y or d.relu_mask or d.act != L.ACT_NONE or d.accumulate or d.w_kn[0] or not d.w_planes[0] or
+                    not d.w_kexp[0] or not d.dA or d.K != f.K or d.N[0] != f.N or int(d.W[0] or 0) != int(f.W or 0) or
+                    int(d.lddc[0]) != int(h.lddh)):
+                return False
+            q = g.t[t]
+            q.A, q.lda, q.amax_a, q.K, q.N = f.A, f.lda, f.amax_a, f.K, f.N
+            q.w_planes_fwd, q.ldpf, q.kexp_fwd = f.w_planes, f.ldw, f.w_kexp
+            q.w_planes_bwd, q.ldpb, q.kexp_bwd = d.w_planes[0], d.ldw[0], d.w_kexp[0]
+            q.bias1, q.w, q.hbias, q.hbias2, q.n_hbias2 = f.bias, h.w, h.bias, h.bias2, h.n_bias2
+            q.dH, q.lddh, q.dA, q.ldda, q.dw, q.dhbias = h.dH, h.lddh, d.dA, d.ldda, h.dw, h.dbias
+            q.amax_dH, q.amax_dA = grp.amax_dH, d.amax_out
+            q.mask_col, q.head = h.mask_col, t
+        if not lib.mml_tower_head_serves(C.byref(g)):
+            return False
+        nws = int(lib.mml_tower_head_workspace_bytes(C.byref(g)))
+        ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=self.device)
+        self.keep += [g, ws]
+        K, N = int(g.t[0].K), int(g.t[0].N)
+        byts = 4.0 * g.M * T * (2 * K + N + 3)
+        fused = (lib.mml_tower_head_fwd_bwd, (C.byref(g), ws.data_ptr(), ws.numel(), 1),
+                 dict(kernel="tower_head_kernel", bytes=byts, hbm_bytes=byts))
+        red = (lib.mml_tower_head_fwd_bwd, (C.byref(g), ws.data_ptr(), ws.numel(), 2),
+               dict(kernel="slab_reduce", bytes=float(nws), side=True, rank=1, ready=0))
+        del self.fwd[fi]
+        del self.bwd[di]
+        for c in list(self.bwd_side) + list(self.head_side):  # (`ready` counts entries of the backward chain)
+            m = c[-1] if isinstance(c[-1], dict) else None
+            if m is not None and m.get("ready", 0) > di:
+                m["ready"] -= 1
+        self.head_train = [fused]
+        self.head_side = [red]
+        self.tower_head = g
+        return True
+
     def merge_row_reduces(self, lib=None):
         """The deferred reductions of the head / gate kernels' partial sums (`head_side`, and the gate groups' entries of
         `bwd_side`: only the optimizer and the host read their results) as ONE launch in front of the weight gradients
         (as few as the launch's segment capacity allows)."""
         lib = lib or L.load()  # (tests/test_plan_passes_cpu.py passes stand-ins: only the functions' identity is used)
         fh, fg = lib.mml_head_bce_fwd_bwd_phase, lib.mml_gate_mix_bwd_phase
-        is_red = lambda c: c[0] in (fh, fg) and c[1][3] == 2  # noqa: E731
+        ft = getattr(lib, "mml_tower_head_fwd_bwd", None)  # (K5': Plan.fuse_tower_head)
+        is_red = lambda c: c[0] in (fh, fg, ft) and c[0] is not None and c[1][3] == 2  # noqa: E731
         picked = [c for c in list(self.head_side) + list(self.bwd_side) if is_red(c)]
         if len(picked) < 2:
             return False
@@ -707,6 +801,8 @@ class Plan:
             g = c[1][0]._obj
             if c[0] is fh:
                 return 2 * int(g.n_heads) + (1 if g.loss else 0)
+            if c[0] is ft:
+                return 2 * int(g.n) + (1 if g.loss else 0)
             return sum(1 for k in range(int(g.n_gates)) if g.gate[k].active)
 
         # one launch takes at most MAX_REDUCE_SEGS segments (csrc/reduce.hpp): a deep PLE (7 tasks x 4 levels: 15 + 8 + 8 +
@@ -730,7 +826,8 @@ class Plan:
             items = (L.RowsReduceItem * len(ch))()
             for it, c in zip(items, ch):
                 grp, ws, nbytes, _ = c[1]
-                it.kind = L.ROWS_REDUCE_HEAD if c[0] is fh else L.ROWS_REDUCE_GATE
+                it.kind = (L.ROWS_REDUCE_HEAD if c[0] is fh else
+                           (L.ROWS_REDUCE_TOWER_HEAD if c[0] is ft else L.ROWS_REDUCE_GATE))
                 it.group = C.addressof(grp._obj)  # (the ops pass C.byref(group); the group itself lives in plan.keep)
                 it.workspace, it.workspace_bytes = ws, nbytes
             self.keep.append(items)

@@ -592,6 +592,48 @@ def make_head_group(heads, prob, y=None, mask=None, loss=None, dprob=None):
     return g
 
 
+def make_tower_head_group(tasks, prob, y, mask=None, loss=None):
+    """K5' (include/mmlrec.h): tasks = dicts with A [M, K], amax_a, planes_fwd / kexp_fwd (MML_PLANES_ROWS image of the tower
+    weight [N, K]), planes_bwd / kexp_bwd (MML_PLANES_COLS), bias1 [N] or None, w [N], hbias [1], hbias2 or None, dH [M, N],
+    dA [M, K], dw [N], dhbias [1], optional amax_dH / amax_dA, mask_col, head (column of prob / y)."""
+    g = L.TowerHeadGroup()
+    g.n, g.M = len(tasks), prob.shape[0]
+    g.prob, g.ldprob = prob.data_ptr(), _ld(prob)
+    g.y, g.ldy = y.data_ptr(), _ld(y)
+    if mask is not None:
+        g.mask, g.ldmask = mask.data_ptr(), _ld(mask)
+    g.loss = L.ptr(loss)
+    for t, q in enumerate(tasks):
+        d = g.t[t]
+        A = q["A"]
+        d.A, d.lda, d.K = A.data_ptr(), _ld(A), A.shape[1]
+        d.N = q["dH"].shape[1]
+        d.amax_a = q["amax_a"].data_ptr()
+        d.w_planes_fwd, d.ldpf, d.kexp_fwd = q["planes_fwd"].data_ptr(), _ld(q["planes_fwd"]), q["kexp_fwd"].data_ptr()
+        d.w_planes_bwd, d.ldpb, d.kexp_bwd = q["planes_bwd"].data_ptr(), _ld(q["planes_bwd"]), q["kexp_bwd"].data_ptr()
+        d.bias1 = L.ptr(q.get("bias1"))
+        d.w, d.hbias = q["w"].data_ptr(), q["hbias"].data_ptr()
+        b2 = q.get("hbias2")
+        d.hbias2, d.n_hbias2 = L.ptr(b2), (0 if b2 is None else b2.numel())
+        d.dH, d.lddh = q["dH"].data_ptr(), _ld(q["dH"])
+        d.dA, d.ldda = q["dA"].data_ptr(), _ld(q["dA"])
+        d.dw, d.dhbias = q["dw"].data_ptr(), q["dhbias"].data_ptr()
+        d.amax_dH, d.amax_dA = L.ptr(q.get("amax_dH")), L.ptr(q.get("amax_dA"))
+        d.mask_col, d.head = int(q.get("mask_col", -1)), int(q.get("head", t))
+    return g
+
+
+def tower_head_fwd_bwd(group, device, phases=False):
+    lib = L.load()
+    n = int(lib.mml_tower_head_workspace_bytes(C.byref(group)))
+    if n < 0:
+        L.check(-1, "mml_tower_head_workspace_bytes")
+    ws = torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+    for ph in ((1, 2) if phases else (0,)):
+        L.check(lib.mml_tower_head_fwd_bwd(C.byref(group), ws.data_ptr(), ws.numel(), ph, _stream()), "mml_tower_head_fwd_bwd")
+    return ws
+
+
 def head_fwd(group):
     lib = L.load()
     L.check(lib.mml_head_fwd(C.byref(group), _stream()), "mml_head_fwd")

@@ -215,6 +215,9 @@ class TrainStep:
         finally:
             _E._DEFER = None
         if one_list:
+            # the top of the network -- last tower layer, heads + BCE, the towers' input gradient -- as one launch where
+            # the recorded lists hold that pattern (csrc/tower_head.hip; before the reductions are merged: it brings its own)
+            self.tower_head_fused = self.plan.fuse_tower_head()
             self.plan.merge_row_reduces()
         self.grad_marks = getattr(self.plan.ops[0], "grad_marks", None) is not None
         # every weight-gradient GEMM of the step in one launch: at small batches (a layer's launch does not fill the chip)

@@ -335,6 +335,14 @@ def test_bench_configuration_steps_match_oracle(W, table_update, streams):
     losses_ref, params, Xs = _bench_oracle(W, cfg, names, vocab, dense, before, nsteps)
     runner = model.train_step_runner(B, use_graph=True, overlap=(streams == 2), split_dense=False)  # bench.py's call
     assert runner.use_graph and runner.overlap == (streams == 2) and (runner.whole is not None) == (streams == 1)
+    if streams == 1:
+        # round 6: the top of the network (last tower layer + heads + BCE + the towers' input gradient) is ONE launch of
+        # the one-stream step (csrc/tower_head.hip; Plan.fuse_tower_head) -- and the three launches it replaces are gone
+        from mmlrec_amd import _lib
+        lib_ = _lib.load()
+        calls = [c for part in runner.whole.parts if part[0] == "c" for c in part[1]]
+        assert runner.tower_head_fused and sum(c[0] is lib_.mml_tower_head_fwd_bwd for c in calls) == 1
+        assert not any(c[0] is lib_.mml_head_bce_fwd_bwd_phase for c in calls)
     for i in range(nsteps):
         X, y = W.synth_batch(vocab, 0, B, T, seed=1 + i)
         runner.plan.X.copy_(X.to(dev()))

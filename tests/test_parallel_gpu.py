@@ -303,6 +303,13 @@ def test_bench_two_ranks_control_flow():
     want = exp["keys_MB"] + 2 * exp["rows_MB_each_way"]   # (+ 2 x 4 bytes of counts; the four batches differ by a few %)
     assert abs(cps["all_to_all"]["MB_sent"] - want) < 0.1 * want, (cps, exp)
     assert abs(cps["all_to_all"]["MB_received"] - want) < 0.1 * want, (cps, exp)
+    # round 6: the run checks ITSELF -- a preflight line on stderr before anything is timed (what DESIGN 5's model expects
+    # for this world size) and the verdict of counted against expected in the JSON line
+    pre = [l for l in r.stderr.splitlines() if l.startswith("bench.py preflight: world 2")]
+    assert len(pre) == 1 and '"all_to_all_calls": 4' in pre[0] and "row_sharded" in pre[0], r.stderr[-1500:]
+    chk = cps["check"]
+    assert chk["ok"] is True and chk["all_to_all_calls"] == [4.0, 4] and chk["all_reduce_calls"] == [1.0, 1], chk
+    assert abs(chk["all_to_all_MB_sent"][0] - chk["all_to_all_MB_sent"][1]) <= 0.15 * chk["all_to_all_MB_sent"][1] + 0.01
 
 
 @pytest.mark.timeout(900)
