@@ -384,6 +384,17 @@ static int nt_mode() {
   }
   return g_nt_on;
 }
+// Workgroups per CU.  Two fill the register file (2 x 4 waves x 248 VGPRs): nothing else becomes resident beside them, so a
+// launch forked beside this one (the table scatter, the table optimizer: HBM-bound, idle matrix pipe) waits for it.  One
+// workgroup per CU leaves half of every SIMD's registers and 76 KiB of LDS to the other branch.
+static int g_nt_per_cu = 0;
+static int nt_per_cu() {
+  if (!g_nt_per_cu) {
+    const char* e = getenv("MMLREC_NT_PER_CU");
+    g_nt_per_cu = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  return g_nt_per_cu;
+}
 static int nt_cus() {
   static int n = 0;
   if (!n) {
@@ -435,7 +446,8 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
   }
   if (nt_mode() == 2 && tiles < NT_MIN_TILES) return MML_ERR_UNSUPPORTED;
   const int steps = M / NT_STEP;
-  int64_t slabs = (2 * (int64_t)nt_cus()) / tiles;   // two workgroups per CU (64 KiB of LDS each)
+  const int per_cu = nt_per_cu();
+  int64_t slabs = (per_cu * (int64_t)nt_cus()) / tiles;   // two workgroups per CU (64 KiB of LDS each), or one (see nt_per_cu)
   if (slabs > steps / 8) slabs = steps / 8;           // at least 256 batch rows per slab
   if (slabs > 64) slabs = 64;
   const int64_t fit = workspace_bytes / (elems * 4);  // (the caller sized the workspace for the tile kernel's split)
@@ -467,7 +479,8 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
     maxred = blocks > maxred ? blocks : maxred;
   }
   if (phase != 2) {
-    MML_LAUNCH(gemm_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, st, L);
+    // (one per CU: 20 KiB of unused dynamic LDS on top of the 64 KiB make a second workgroup not fit)
+    MML_LAUNCH(gemm_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), per_cu == 1 ? 20480 : 0, st, L);
     const int rc = check_launch("mml_gemm_grouped_wgrad(nt)");
     if (rc != MML_OK) return rc;
   }

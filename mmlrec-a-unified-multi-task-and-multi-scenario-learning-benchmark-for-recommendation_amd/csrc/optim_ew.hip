@@ -14,6 +14,10 @@ struct OptLaunch {
   int32_t variant;  // streaming form of the vector loop (tuning knob MMLREC_OPT_VARIANT): bit 0 = nontemporal, bit 1 = 2x unroll; bit 2 = capped grid (4 chunks in flight per thread)
   mml_opt_hyper h;
   int64_t chunk0[MML_MAX_OPT_TENSORS + 1];  // flat kernel: first 4-element chunk of tensor i in the concatenation
+  // streaming kernel over MANY tensors (round 6: every table of the model in one marked launch): a 1-D grid whose
+  // workgroups are dealt to the tensors in proportion to their sizes; blk0[i] = first workgroup of tensor i (prop != 0)
+  int32_t blk0[MML_MAX_OPT_TENSORS + 1];
+  int32_t prop;
 };
 
 struct StepConsts {
@@ -82,14 +86,22 @@ __device__ __forceinline__ float reg_grad(float g, float p, float l1, float l2) 
 enum { OPT_PLAIN = 0, OPT_UNROLL2 = 1, OPT_SKIP_U = 2, OPT_MARK_U = 3 };
 template <bool STREAM, int PATH, int U>
 __global__ __launch_bounds__(256) void opt_dense_kernel(const OptLaunch L) {
-  const mml_opt_tensor& T = L.t[blockIdx.y];
+  // (workgroup-uniform: scalar loads and compares)
+  int ti = blockIdx.y, nblk = gridDim.x, lblk = blockIdx.x;
+  if (L.prop) {
+    ti = 0;
+    while (ti + 1 < L.n && (int)blockIdx.x >= L.blk0[ti + 1]) ++ti;
+    nblk = L.blk0[ti + 1] - L.blk0[ti];
+    lblk = (int)blockIdx.x - L.blk0[ti];
+  }
+  const mml_opt_tensor& T = L.t[ti];
   const mml_opt_hyper& h = L.h;
   const StepConsts c = step_consts(h);
   const int64_t n4 = T.n >> 2;
   const bool vec = aligned16(T.param) && aligned16(T.grad) && (!T.state1 || aligned16(T.state1)) &&
                    (!T.state2 || aligned16(T.state2));
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
+  const int64_t tid = (int64_t)lblk * blockDim.x + threadIdx.x;
   float* gw = const_cast<float*>(T.grad);
   const bool reg = T.l1 != 0.f || T.l2 != 0.f;
   if (vec) {
@@ -790,23 +802,43 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
     // through the flat kernel, where every workgroup has the same amount of work.
     int64_t nmax = 0;
     for (int k = 0; k < L.n; ++k) nmax = L.t[k].n > nmax ? L.t[k].n : nmax;
-    if (total >= ((int64_t)1 << 24) && L.n <= 4) {
+    // the loop form (see opt_dense_kernel): decided for the launch, so every tensor of it must qualify
+    bool all_gm = true, all_skip = true, none = true;
+    for (int k = 0; k < L.n; ++k) {
+      all_gm = all_gm && L.t[k].grad_marks && !L.t[k].skip_rows;
+      all_skip = all_skip && L.t[k].skip_rows;
+      none = none && !L.t[k].grad_marks && !L.t[k].skip_rows;
+    }
+    // Round 6: a model's tables in ONE marked streaming launch (AE-30: 4 huge + 26 small; the small ones were a second
+    // launch of the flat kernel, 31-34 us behind the stream): workgroups dealt in proportion to the tensors' sizes.
+    const bool many = L.n > 4 && all_gm;
+    if (total >= ((int64_t)1 << 24) && (L.n <= 4 || many)) {
       int64_t bx = cdiv(cdiv(nmax, 4), 256);
       if (bx > 256 * 8) bx = 256 * 8;
       if (hyper->max_blocks > 0 && bx * L.n > hyper->max_blocks) bx = cdiv(hyper->max_blocks, L.n);
-      // the loop form (see opt_dense_kernel): decided for the launch, so every tensor of it must qualify
-      bool all_gm = true, all_skip = true, none = true;
-      for (int k = 0; k < L.n; ++k) {
-        all_gm = all_gm && L.t[k].grad_marks && !L.t[k].skip_rows;
-        all_skip = all_skip && L.t[k].skip_rows;
-        none = none && !L.t[k].grad_marks && !L.t[k].skip_rows;
+      dim3 grid((unsigned)bx, (unsigned)L.n);
+      if (many) {
+        int64_t tb = 4 * 256 * 8;  // (what the four-tensor launch of the huge tables gets)
+        if (hyper->max_blocks > 0 && tb > hyper->max_blocks) tb = hyper->max_blocks;
+        if (tb < L.n) tb = L.n;
+        int64_t at = 0;
+        for (int k = 0; k < L.n; ++k) {
+          L.blk0[k] = (int32_t)at;
+          int64_t nb = tb * L.t[k].n / total;
+          const int64_t need = cdiv(cdiv(L.t[k].n, 4), 256);
+          if (nb > need) nb = need;
+          if (nb < 1) nb = 1;
+          at += nb;
+        }
+        L.blk0[L.n] = (int32_t)at;
+        L.prop = 1;
+        grid = dim3((unsigned)at, 1);
       }
       static int u_mark = -1;
       if (u_mark < 0) {
         const char* e = getenv("MMLREC_OPT_U");  // lab knob: chunks in flight per thread of the marked form (2, 4, 8)
         u_mark = e ? atoi(e) : 2;
       }
-      const dim3 grid((unsigned)bx, (unsigned)L.n);
       hipStream_t st = to_stream(stream);
       if ((L.variant & 4) && all_gm) {
         if (u_mark == 4) MML_LAUNCH((opt_dense_kernel<true, OPT_MARK_U, 4>), grid, dim3(256), 0, st, L);

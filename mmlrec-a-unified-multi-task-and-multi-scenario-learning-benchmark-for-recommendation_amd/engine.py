@@ -931,7 +931,7 @@ def _opt_dense_symbol(numel, ntensors, form=0):
     """Kernel symbol of a dense optimizer launch (csrc/optim_ew.hip: mml_opt_step_dense's choice).  form: the loop form
     of the streaming kernel -- 0 plain, 1 two chunks per iteration (MMLREC_OPT_VARIANT bit 1), 2 untouched rows of the
     split update under a capped grid, 3 marked gradients under a capped grid."""
-    if not (numel >= (1 << 24) and ntensors <= 4):
+    if not (numel >= (1 << 24) and (ntensors <= 4 or form == 3)):
         return "opt_flat_kernel"
     u = {0: 1, 1: 1, 2: 4, 3: int(os.environ.get("MMLREC_OPT_U", "2"))}[form]
     return "opt_dense_kernel<true, %d, %d>" % (form, u)
@@ -2688,6 +2688,17 @@ class Optimizer:
                     _, base = st.ensure_grad_marks(gop.tables)
                     for f, t in enumerate(gop.tables):
                         marks_of[id(t)] = gm[base[f]:base[f] + t.data.shape[0]]
+                # Round 6, built and measured, NOT the default: every table in ONE marked streaming launch (workgroups dealt
+                # in proportion to the tables' sizes, csrc/optim_ew.hip) instead of the streaming launch of the huge tables
+                # + a flat launch of the small ones (AE-30: 26 tables, 31-34 us).  Two call lists over ONE model replayed in
+                # alternating blocks, both orders (tools/lab/ab_inproc.py --shared, profiles/r06_tail_lab.txt): the single
+                # launch is 13 us per step SLOWER.  MMLREC_OPT_ONE_LAUNCH=1 turns it on.
+                one_launch = (big and small and cap > 0 and len(tabs) <= L.MAX_OPT_TENSORS and not split_dense and
+                              all(id(t) in marks_of for t in tabs) and
+                              os.environ.get("MMLREC_OPT_ONE_LAUNCH", "0") == "1")
+                if one_launch:
+                    big = big + small
+                    groups = [big]
                 for grp in groups:
                     marked = grp is big and all(id(tabs[i]) in marks_of for i in grp)
                     arr = ops.make_opt_tensors([(tabs[i].data, tabs[i].grad) + self.state[tnames[i]] +

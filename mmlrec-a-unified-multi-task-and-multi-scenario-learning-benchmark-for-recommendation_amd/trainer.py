@@ -314,20 +314,24 @@ class TrainStep:
             side_calls = head_side + p.bwd_side
             mid = (p.bwd_tail + self.opt_split["tables"])
             self.fork_refused = []
-            if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
+            mlp_side = os.environ.get("MMLREC_FORK_MLP", "0") == "1" and not ar
+            if mlp_side:  # the MLP optimizer behind the weight gradients on their branch (it needs nothing of the other one)
+                side_calls = side_calls + self.opt_split["mlp"]
+            if (inner in (1, 2, 3) and side_calls and not any(c[0] is E.PY for c in side_calls) and
                     not any(c[0] is E.PY for c in mid)):  # (fork and join must land in ONE graph)
                 from . import ops as _ops
                 bad = fork_conflicts(side_calls, mid, [w.data_ptr() for w in _ops._workspaces.values()])
                 self.fork_refused = bad  # (a step whose branches share a buffer simply runs unforked)
-            if (inner in (1, 2) and side_calls and not any(c[0] is E.PY for c in side_calls) and
+            if (inner in (1, 2, 3) and side_calls and not any(c[0] is E.PY for c in side_calls) and
                     not any(c[0] is E.PY for c in mid) and not self.fork_refused):
                 self.inner_fork = InnerFork(self.store.device, side_calls)
                 fk = [(E.INLINE, self.inner_fork.fork, ())]
                 jn = [(E.INLINE, self.inner_fork.join, ())]
-                mid = (p.bwd_tail + jn + self.opt_split["tables"]) if inner == 1 else \
-                    (p.bwd_tail + self.opt_split["tables"] + jn)
-                self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + fk + mid + ar +
-                                      self.opt_split["mlp"], self.use_graph)
+                mid = (fk + p.bwd_tail + jn + self.opt_split["tables"]) if inner == 1 else \
+                    (fk + p.bwd_tail + self.opt_split["tables"] + jn) if inner == 2 else \
+                    (p.bwd_tail + fk + self.opt_split["tables"] + jn)   # (3: forked behind the scatter)
+                self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + mid + ar +
+                                      ([] if mlp_side else self.opt_split["mlp"]), self.use_graph)
             else:
                 self.whole = Segments(self.opt_split["pre"] + p.fwd + p.head_train + p.bwd + p.bwd_tail +
                                       self.opt_split["tables"] + head_side + p.bwd_side + ar + self.opt_split["mlp"],
@@ -470,6 +474,13 @@ class TrainStep:
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
             _quiesce_collective_watchdog()
+            nd = int(os.environ.get("MMLREC_DUMMY_STREAMS", "0"))  # lab: shift the hardware queue the graph's branch lands on
+            if nd:
+                self._dummy = [torch.cuda.Stream(device=self.store.device) for _ in range(nd)]
+                for s_ in self._dummy:
+                    with torch.cuda.stream(s_):
+                        self.plan.status.add_(0)
+                torch.cuda.synchronize()
             for seg in ((self.whole,) if self.whole is not None else
                         (self.pre, self.early, self.front, self.front_b, self.side_a, self.sideq, self.tail)):
                 if seg is not None:

@@ -665,6 +665,41 @@ def test_optimizer_dense_marked_gradients(ops, kind, E):
         grads_ref[1].zero_()
 
 
+@pytest.mark.parametrize("cap", [0, 1 << 20, 300])
+def test_optimizer_dense_marked_gradients_many_tables_one_launch(ops, cap):
+    """Round 6: every table of a model in ONE marked streaming launch (more than four tensors: a 1-D grid whose workgroups
+    are dealt to the tensors in proportion to their sizes) -- bitwise the per-table plain dense steps, gradients re-zeroed,
+    marks cleared; with and without a workgroup cap (the capped form keeps several chunks in flight per thread)."""
+    rng = np.random.default_rng(21)
+    E = 8
+    vocab = [(1 << 24) // E + 5, 1, 37, 300000, 4097, 64, 250001]
+    F, B = len(vocab), 3000
+    g = torch.Generator(device="cpu").manual_seed(3)
+    tabs = [torch.randn(v, E, generator=g).to(dev()) for v in vocab]
+    ref = [t.clone() for t in tabs]
+    st = [[torch.rand(v, E, generator=g).to(dev()) for v in vocab] for _ in range(2)]
+    st_ref = [[t.clone() for t in s_] for s_ in st]
+    grads = [torch.zeros(v, E, device=dev()) for v in vocab]
+    marks = torch.zeros(ops.marks_bytes(vocab), dtype=torch.uint8, device=dev())
+    base = np.concatenate([[0], np.cumsum([(v + 31) // 32 * 32 for v in vocab])]).tolist()
+    for step in (1, 2, 3):
+        X = np.stack([np.r_[0, vocab[f] - 1, rng.integers(0, vocab[f], B - 2)] for f in range(F)], 1).astype(np.float32)
+        d_out = T(rng.standard_normal((B, F * E)).astype(np.float32))
+        ops.scatter_bwd(grads, T(X), list(range(F)), d_out, marks=marks)
+        grads_ref = [g_.clone() for g_ in grads]              # the SAME accumulators: the comparison is bitwise
+        hyper = ops.make_hyper("adam", 0.01, step=step, zero_grad=True, max_blocks=cap)
+        ops.opt_step_dense([(tabs[f], grads[f], st[0][f], st[1][f], None, None, marks[base[f]:base[f] + vocab[f]])
+                            for f in range(F)], hyper)
+        plain = ops.make_hyper("adam", 0.01, step=step, zero_grad=True)
+        for f in range(F):
+            ops.opt_step_dense([(ref[f], grads_ref[f], st_ref[0][f], st_ref[1][f])], plain)
+        for f in range(F):
+            assert torch.equal(tabs[f], ref[f]), (step, f)
+            assert torch.equal(st[0][f], st_ref[0][f]) and torch.equal(st[1][f], st_ref[1][f]), (step, f)
+            assert float(grads[f].abs().max()) == 0.0
+        assert int(marks.max()) == 0
+
+
 def test_marks_only_needs_the_fold_scatter_and_the_streaming_launch(ops):
     from mmlrec_amd import _lib as L
     vocab, E, B = [100], 6, 64                    # E = 6: not served by the LDS-fold kernel
