@@ -87,18 +87,19 @@ __device__ __forceinline__ int nt_frag_off(int chunk0, int lane, int t) {
 }
 
 // four values -> their two planes (8 bytes each): h = rne16(x s), l = rne16(x s - h); x s is exact (s a power of two).
-// Twelve full-rate VALU instructions (the sequence of lds_async.hpp: f16_cut_hr2 + f16_cut_l -- hipcc forms packed fp32
-// operations from the C expression, which issue at half rate): 4 v_mul, 2 + 2 v_cvt_pk_f16_f32, 4 v_fma_mix_f32 that read
-// the fp16 halves of h directly.
+// Ten VALU instructions: 2 v_pk_mul_f32 (round 6; four v_mul before), 2 + 2 v_cvt_pk_f16_f32, 4 v_fma_mix_f32 that read the
+// fp16 halves of h directly.
 __device__ __forceinline__ void nt_cut4(const float4& x, const float s, uint2& h, uint2& l) {
-  float y0, y1, y2, y3, r0, r1, r2, r3;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float r0, r1, r2, r3;
   uint32_t h0, h1, l0, l1;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x.x), "s"(s));
-  asm("v_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x.y), "s"(s));
-  asm("v_mul_f32 %0, %1, %2" : "=v"(y2) : "v"(x.z), "s"(s));
-  asm("v_mul_f32 %0, %1, %2" : "=v"(y3) : "v"(x.w), "s"(s));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h0) : "v"(y0), "v"(y1));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(y2), "v"(y3));
+  // (the two scalings of a register pair in one packed multiply: a loaded float4 IS two aligned pairs)
+  const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w}, ss = {s, s};
+  f32x2 y01, y23;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y01) : "v"(x01), "s"(ss));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y23) : "v"(x23), "s"(ss));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h0) : "v"(y01.x), "v"(y01.y));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(y23.x), "v"(y23.y));
   asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x.x), "s"(s), "v"(h0));
   asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x.y), "s"(s), "v"(h0));
   asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(x.z), "s"(s), "v"(h1));
@@ -153,8 +154,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
   // (columns beyond the problem: the lane re-reads the problem's first columns -- finite values whose products land in
   //  accumulator columns / rows the epilogue never stores)
   const bool colC = n0 + 4 * c4 < P.N, colA = k0 + 4 * c4 < P.K;
-  const float* const gC = P.dC + (colC ? n0 + 4 * c4 : 0);
-  const float* const gA = P.A + (colA ? k0 + 4 * c4 : 0);
+  // Addresses: a step's row base is workgroup-uniform (scalar registers, scalar arithmetic); what a thread adds -- its row of
+  // the eight-row pass and its 16-byte column -- is ONE 32-bit byte offset per operand, computed here.  (Per-lane 64-bit row
+  // arithmetic cost four VALU instructions per load: 64 of the 352 per trip of two steps, on an issue port the 48 MFMAs share.)
+  const uint32_t tC = (uint32_t)(((int64_t)r8 * P.lddc + (colC ? n0 + 4 * c4 : 0)) * 4);
+  const uint32_t tA = (uint32_t)(((int64_t)r8 * P.lda + (colA ? k0 + 4 * c4 : 0)) * 4);
   // TWO steps of rows in flight (two register sets, the trip below unrolled by two): one step's MFMAs are ~0.7 us, a load's
   // round trip 1-2 us -- with one step ahead the first-layer launch took 258 us, with two 198, with three 201 (and a
   // branch-free body with three sets spills: 508 bytes of scratch).  The body of a step
@@ -164,15 +168,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
   const int last = s_end - 1;
   auto load_step = [&](int st, float4 (&rc)[4], float4 (&ra)[4]) __attribute__((always_inline)) {
     st = st > last ? last : st;
-    const int64_t m0 = (int64_t)st * NT_STEP;
+    const char* const bC = reinterpret_cast<const char*>(P.dC + (int64_t)st * NT_STEP * P.lddc);
+    const char* const bA = reinterpret_cast<const char*>(P.A + (int64_t)st * NT_STEP * P.lda);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int64_t m = m0 + r8 + 8 * p;
-      rc[p] = *reinterpret_cast<const float4*>(gC + m * P.lddc);
-      ra[p] = *reinterpret_cast<const float4*>(gA + m * P.lda);
+      rc[p] = *reinterpret_cast<const float4*>(bC + (int64_t)(8 * p) * P.lddc * 4 + tC);
+      ra[p] = *reinterpret_cast<const float4*>(bA + (int64_t)(8 * p) * P.lda * 4 + tA);
     }
   };
-  auto store_step = [&](uint16_t* stage, const float4 (&rc)[4], const float4 (&ra)[4], const bool count) __attribute__((always_inline)) {
+  auto store_step = [&](uint16_t* stage, const float4 (&rc)[4], const float4 (&ra)[4], const float count) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = r8 + 8 * p;
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
       nt_cut4(ra[p], sA, h, l);
       *reinterpret_cast<uint2*>(stage + 2 * NT_PLANE + off) = h;
       *reinterpret_cast<uint2*>(stage + 3 * NT_PLANE + off) = l;
-      if (count) { bsum.x += rc[p].x; bsum.y += rc[p].y; bsum.z += rc[p].z; bsum.w += rc[p].w; }
+      // (count = 1 for a real step of a workgroup that owns the bias sums, else 0: an fma, no select)
+      bsum.x = fmaf(rc[p].x, count, bsum.x); bsum.y = fmaf(rc[p].y, count, bsum.y);
+      bsum.z = fmaf(rc[p].z, count, bsum.z); bsum.w = fmaf(rc[p].w, count, bsum.w);
     }
   };
   // per-lane offsets of the fragment reads (sub-step 0): [n / k sub-tile][low / high half of the fragment]
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
   if (ns > 0) {
     load_step(s_begin, rc0, ra0);
     load_step(s_begin + 1, rc1, ra1);
-    store_step(lds, rc0, ra0, want_bias);
+    store_step(lds, rc0, ra0, want_bias ? 1.f : 0.f);
   }
   __syncthreads();
   // trip of two steps: set 0 was stored for step q already and takes the rows of step q + 2; set 1 (step q + 1) is cut into
@@ -233,16 +239,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
 #define NT_TRIP(Q, RCL, RAL, RCS, RAS)                                                        \
   {                                                                                           \
     const int q_ = (Q);                                                                       \
-    if (q_ >= ns) break;                                                                      \
     load_step(s_begin + q_ + 2, RCL, RAL);                                                    \
     compute(lds + (q_ & 1) * NT_STAGE);                                                       \
-    store_step(lds + ((q_ + 1) & 1) * NT_STAGE, RCS, RAS, want_bias && q_ + 1 < ns);          \
+    store_step(lds + ((q_ + 1) & 1) * NT_STAGE, RCS, RAS, (want_bias && q_ + 1 < ns) ? 1.f : 0.f); \
     __syncthreads();                                                                          \
   }
-  for (int q = 0; q < ns; q += 2) {
+  // (no exit between the two halves of the pair: with one, the accumulators were copied -- 32 v_mov_b64 per pair -- to meet
+  //  in the same registers on both exits; an odd step count ends with one trip of its own)
+  int q = 0;
+  for (; q + 1 < ns; q += 2) {
     NT_TRIP(q, rc0, ra0, rc1, ra1)
     NT_TRIP(q + 1, rc1, ra1, rc0, ra0)
   }
+  if (q < ns) NT_TRIP(q, rc0, ra0, rc1, ra1)
 #undef NT_TRIP
   // sub-tiles of this wave that lie inside the problem (whole 32-column blocks)
   bool vi[2], vj[2];
