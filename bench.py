@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP runtime defaults of the package (mmlrec_amd/__init__.py: _runtime_defaults), before anything can initialise HIP;
+# child ranks inherit them
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402
 
@@ -742,6 +745,7 @@ def main():
                                              ("one launch after the scatter, gradients read for marked rows only"
                                               if getattr(runner0, "grad_marks", False) else "one launch after the scatter")),
                    "hip_graph": not args.no_graph, "scatter_mode": args.scatter_mode,
+                   "hip_runtime": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                    "streams": 1 if not getattr(runner0, "overlap", True) else (3 if getattr(runner0, "split_dense", False) else 2),
                    "early_fork": int(getattr(runner0, "early_fork", 0) or 0),
                    "tables": "single GPU" if getattr(model, "_parallel", None) is None else

@@ -6,4 +6,29 @@ Import name: `mmlrec_amd` (see ../mmlrec_amd.py; the directory name itself is no
 """
 __version__ = "0.1.0"
 
+import os as _os
+import sys as _sys
+
+
+def _runtime_defaults():
+    """HIP runtime settings the kernels are measured with, applied unless the environment already decides them.  They are
+    read when the HIP runtime initialises (the first HIP call of the process), so this import has to come before it.
+
+    HIP_FORCE_DEV_KERNARG=1: kernel-argument blocks in device memory instead of host memory.  The launches of this library
+    pass their descriptors BY VALUE (include/mmlrec.h: 1-3 KB per launch -- 16 GEMM problems, 32 optimizer tensors) and
+    every workgroup of every launch reads them with scalar loads: from host memory that is a trip over the host link per
+    cold line.  Round 6, five interleaved pairs of fresh bench.py processes at B = 65 536: 1.499 / 1.503 / 1.554 / 1.514 /
+    1.564 ms -> 1.423 / 1.433 / 1.497 / 1.437 / 1.507 ms per step (-4 to -5 %); B = 4 096: level (0.723 / 0.727).
+    profiles/r06_ab_dev_kernarg.txt."""
+    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    t = _sys.modules.get("torch")
+    try:
+        late = t is not None and t.cuda.is_available() and t.cuda.is_initialized()
+    except Exception:
+        late = False
+    return {"HIP_FORCE_DEV_KERNARG": _os.environ.get("HIP_FORCE_DEV_KERNARG"), "set_before_hip_init": not late}
+
+
+runtime = _runtime_defaults()
+
 from . import _lib  # noqa: F401  (ctypes signatures; the library itself is loaded on first use)

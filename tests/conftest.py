@@ -33,6 +33,9 @@ def _host_threads(cap=16):
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(_host_threads()))
 
+# the package's HIP runtime defaults (mmlrec_amd/__init__.py), before a test module's `import torch` can initialise HIP
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402
 
