@@ -79,6 +79,7 @@ class RowsReduceItem(C.Structure):
 
 ROWS_REDUCE_HEAD, ROWS_REDUCE_GATE, ROWS_REDUCE_TOWER_HEAD = 0, 1, 2
 MAX_REDUCE_SEGS = 40  # csrc/reduce.hpp: segments of one reduction launch
+NT_MAX_GROUP = 48     # csrc/gemm_nt.hip: weight-gradient problems one gemm_nt_kernel launch takes
 GATE_MIX_BF16, GATE_DE_BF16, GATE_DG_BF16, GATE_E_BF16 = 1, 2, 4, 8
 
 

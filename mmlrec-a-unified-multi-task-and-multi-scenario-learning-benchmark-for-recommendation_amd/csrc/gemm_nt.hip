@@ -31,7 +31,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
-constexpr int NT_MAX_GROUP = 16;  // (= MML_MAX_GROUP: the merged weight-gradient launch of a whole step)
+// Problems per launch.  Round 6: 3 x MML_MAX_GROUP -- PepNet's 40-odd weight gradients were three launch + reduction pairs
+// (377 us of its 1.67 ms step); the launch descriptor is 3.9 KB of kernel arguments (limit 4 KB), read from device memory.
+constexpr int NT_MAX_GROUP = 48;
 constexpr int NT_STEP = 32;          // batch rows per step
 constexpr int NT_PLANE = NT_STEP * 128;   // fp16 elements of one plane image ([32 rows][128 columns])
 constexpr int NT_STAGE = 4 * NT_PLANE;    // dC h, dC l, A h, A l

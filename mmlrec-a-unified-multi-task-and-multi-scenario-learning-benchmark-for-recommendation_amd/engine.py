@@ -651,9 +651,11 @@ class Plan:
             fits = [d for d, ok in zip(descs, serves) if ok]
             other = [d for d, ok in zip(descs, serves) if not ok]
             chunks = []
+            # (round 6: gemm_nt_kernel takes 48 problems per launch; MMLREC_NT_GROUP=16 restores the launches of round 5)
+            nt_group = min(L.NT_MAX_GROUP, max(1, int(os.environ.get("MMLREC_NT_GROUP", str(L.NT_MAX_GROUP)))))
             for part in (fits, other):
                 if part:
-                    nch = -(-len(part) // L.MAX_GROUP)
+                    nch = -(-len(part) // (nt_group if part is fits else L.MAX_GROUP))
                     per = -(-len(part) // nch)
                     chunks += [part[i:i + per] for i in range(0, len(part), per)]
 

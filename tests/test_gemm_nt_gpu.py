@@ -59,6 +59,9 @@ def check(probs, tol=RTOL):
     (16384, [(256, 304), (64, 304)], True),                # AE-30d: 303 input columns padded to 304
     (16384 + 32 * 5, [(96, 100), (32, 4)], False),         # slabs of unequal length, ragged tiles, a 4-column problem
     (32768, [(512, 512), (128, 512)], True),               # KuaiRec-32 first layers (several tiles each way)
+    # round 6: 48 problems per launch (PepNet's weight gradients were three launches of <= 16)
+    (16384, [(64, 72), (96, 80), (32, 64), (128, 128)] * 12, False),
+    (32768, [(32, 8)] * 41, False),
 ])
 def test_nt_wgrad_matches_float64(env, M, shapes, shared):
     L, ops, lib = env
@@ -133,6 +136,7 @@ def test_nt_wgrad_leaves_other_launches_to_the_tile_kernel(env):
     L, ops, lib = env
     lib.mml_gemm_set_nt(1)
     for M, shapes, amax in ((8192, [(128, 256)], True),          # small batch
+                            (16384, [(32, 16)] * 49, True),      # more than 48 problems in one call
                             (16384 + 16, [(128, 256)], True),    # M % 32
                             (16384, [(100, 48)], True),          # N % 32
                             (16384, [(128, 256)], False)):       # no magnitudes
