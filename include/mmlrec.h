@@ -771,6 +771,10 @@ typedef struct mml_copy2d_desc {
   int64_t rows;
   int32_t cols;
   int32_t accumulate;
+  /* optional operand-magnitude slot (MML_AMAX_WORDS words, mml_amax_batch's format): raised with max |x| of what this item
+   * stores -- the copies that assemble a GEMM operand measure it on the way (PepNet's gate inputs, model/pepnet.py:72,
+   * :139: torch.cat of a detached input and the scene embedding) instead of a pass of mml_amax_batch over the result. */
+  uint32_t* amax_out;
 } mml_copy2d_desc;
 int mml_copy2d_batch(const mml_copy2d_desc* d, int32_t n, mml_stream_t stream);
 /* Up to MML_MAX_FIELDS strided column-block copies in ONE launch: for segment s, dst[s][r*ldd[s] + c] (+)= src[s][r*lds[s] + c],

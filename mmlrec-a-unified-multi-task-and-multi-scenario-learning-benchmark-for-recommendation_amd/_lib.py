@@ -129,7 +129,7 @@ class OptTensor(C.Structure):
 
 class Copy2dDesc(C.Structure):
     _fields_ = [("src", fp), ("lds", i64), ("dst", fp), ("ldd", i64), ("rows", i64), ("cols", i32),
-                ("accumulate", i32)]
+                ("accumulate", i32), ("amax_out", fp)]
 
 
 class SumProdDesc(C.Structure):

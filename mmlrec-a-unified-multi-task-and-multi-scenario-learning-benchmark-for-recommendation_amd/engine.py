@@ -488,10 +488,12 @@ class Plan:
         def descs_of(c):
             if c[0] is f1:
                 src, lds, dst, ldd, rows, cols, acc = c[1]
-                return [(src, lds, dst, ldd, rows, cols, acc)]
+                return [(src, lds, dst, ldd, rows, cols, acc, None)]
             arr, n = c[1]
-            return [(arr[k].src, arr[k].lds, arr[k].dst, arr[k].ldd, arr[k].rows, arr[k].cols, arr[k].accumulate)
-                    for k in range(n)]
+            # (the 8th entry: an item's optional magnitude slot, mml_copy2d_desc.amax_out -- stand-in arrays of the CPU
+            #  tests need not have the field)
+            return [(arr[k].src, arr[k].lds, arr[k].dst, arr[k].ldd, arr[k].rows, arr[k].cols, arr[k].accumulate,
+                     getattr(arr[k], "amax_out", None)) for k in range(n)]
 
         def span(ptr, ld, rows, cols):
             return (ptr, ld, rows, cols)
@@ -526,8 +528,10 @@ class Plan:
                 out.append(meta_run[0])
             else:
                 arr = (L.Copy2dDesc * len(run))()
-                for d, (src, lds, dst, ldd, rows, cols, acc) in zip(arr, run):
+                for d, (src, lds, dst, ldd, rows, cols, acc, am) in zip(arr, run):
                     d.src, d.lds, d.dst, d.ldd, d.rows, d.cols, d.accumulate = src, lds, dst, ldd, rows, cols, acc
+                    if am:
+                        d.amax_out = am
                 self.keep.append(arr)
                 meta = dict(kernel="copy2d_batch_kernel",
                             bytes=sum(8.0 * r[4] * r[5] for r in run))
@@ -544,9 +548,9 @@ class Plan:
             if c[0] is f1 or c[0] is fb:
                 ds = descs_of(c)
                 ok = len(run) + len(ds) <= 32
-                for (src, lds, dst, ldd, rows, cols, acc) in ds:
+                for (src, lds, dst, ldd, rows, cols, acc, _am) in ds:
                     rs, ws = span(src, lds, rows, cols), span(dst, ldd, rows, cols)
-                    for (s2, l2, d2, ld2, r2, c2, a2) in run:
+                    for (s2, l2, d2, ld2, r2, c2, a2, _am2) in run:
                         rs2, ws2 = span(s2, l2, r2, c2), span(d2, ld2, r2, c2)
                         if hits(rs, ws2) or hits(ws, rs2) or hits(ws, ws2):
                             ok = False
@@ -1088,12 +1092,16 @@ def _padded_view(buf, kp):
     return buf.as_strided((buf.shape[0], kp), (buf.stride(0), 1), buf.storage_offset())
 
 
-def _copy2d_batch_call(plan, pairs):
-    """One launch copying src[:, :cols] -> dst[:, :cols] for every (src, dst) pair (cols = the narrower of the two)."""
+def _copy2d_batch_call(plan, pairs, amax=None):
+    """One launch copying src[:, :cols] -> dst[:, :cols] for every (src, dst) pair (cols = the narrower of the two);
+    amax: per pair a magnitude slot the copy raises with max |x| of what it stores, or None."""
     arr = (L.Copy2dDesc * len(pairs))()
-    for d, (src, dst) in zip(arr, pairs):
+    for k, (d, (src, dst)) in enumerate(zip(arr, pairs)):
         d.src, d.lds, d.dst, d.ldd = src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)
         d.rows, d.cols, d.accumulate = src.shape[0], min(src.shape[1], dst.shape[1]), 0
+        if amax is not None and amax[k] is not None:
+            d.amax_out = amax[k].data_ptr()
+            plan.keep.append(amax[k])
     plan.keep.append(arr)
     return (L.load().mml_copy2d_batch, (arr, len(pairs)),
             dict(kernel="copy2d_batch_kernel", bytes=8.0 * sum(min(a.numel(), b.numel()) for a, b in pairs)))
@@ -2288,10 +2296,14 @@ class CopyColsOp(Op):
     """dst[:, :] = src[:, :] for column-sliced views; no gradient flows (used for detached concatenations,
     model/pepnet.py:72, :139)."""
 
-    def __init__(self, src, dst):
-        self.src, self.dst = src, dst
+    def __init__(self, src, dst, amax_out=None):
+        self.src, self.dst, self.amax_out = src, dst, amax_out
 
     def fwd_calls(self, plan):
+        if self.amax_out is not None:
+            # round 6: the copy raises the magnitude slot of the operand it assembles (mml_copy2d_desc.amax_out) -- PepNet's
+            # two gate inputs cost a pass of mml_amax_batch each (17-20 us of a 1.67 ms step) right behind their copies
+            return [_copy2d_batch_call(plan, [(self.src, self.dst)], amax=[self.amax_out])]
         return [(L.load().mml_copy2d, (self.src.data_ptr(), ops._ld(self.src), self.dst.data_ptr(), ops._ld(self.dst),
                                        plan.B, self.src.shape[1], 0))]
 

@@ -136,8 +136,16 @@ class PepNet(BaseModel):
         def gate_input(src_val, name):
             # (zero-padded rows: K0 + E is rarely a multiple of the GEMM's 16-wide k-step, e.g. 64 + 8)
             v = plan.val(K0 + Edim, needs_grad=False, name=name, pad_k=True)
-            plan.add(E.CopyColsOp(src_val.buf, v.buf[:, :K0]))
-            plan.add(E.CopyColsOp(scene, v.buf[:, K0:]))
+            # (round 6, built and measured, not the default: with MMLREC_PEP_COPY_AMAX=1 the two copies raise the operand's
+            #  magnitude slot themselves -- mml_copy2d_desc.amax_out; the padding columns are zero -- instead of a magnitude
+            #  pass over the assembled [B, K0 + E] buffer.  Two 17-20 us launches leave the step and the step does not move
+            #  (-3 us, both orders of tools/lab/ab_inproc.py): a copy that ends in 2 048 looks at one slot line costs 25 us
+            #  more, one walked by 256 workgroups streams at a third of the rate.  profiles/r06_ab_pep_copy_amax.txt)
+            slot = plan.new_amax() if os.environ.get("MMLREC_PEP_COPY_AMAX", "0") == "1" else None
+            plan.add(E.CopyColsOp(src_val.buf, v.buf[:, :K0], amax_out=slot))
+            plan.add(E.CopyColsOp(scene, v.buf[:, K0:], amax_out=slot))
+            if slot is not None:
+                v.amax = slot
             return v
 
         # EPNet: the feature gate on the input

@@ -829,6 +829,42 @@ def test_copy2d_batch(ops):
         assert torch.equal(dst, ref)
 
 
+def test_copy2d_batch_raises_the_magnitude_slot_of_what_it_stores(ops):
+    """mml_copy2d_desc.amax_out (round 6): the copies that assemble a GEMM operand measure it on the way -- two column blocks
+    into one buffer raise ONE slot to max |x| of both, an accumulating item registers the SUM it stores, an item without a
+    slot leaves every slot alone, and the slot equals what mml_amax_batch measures on the assembled buffer."""
+    from mmlrec_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    B = 5000
+    a = (torch.randn(B, 64, generator=g) * 3.0).to(dev())
+    b = (torch.randn(B, 8, generator=g) * 0.5).to(dev())
+    b[17, 3] = -77.5                                   # the maximum sits in the narrow block, negative
+    whole = torch.zeros(B, 80, device=dev())           # columns 72..79: padding, stays zero
+    c = torch.randn(300, 40, generator=g).to(dev())
+    acc_dst = torch.full((300, 40), 100.0, device=dev())
+    plain_src, plain_dst = torch.randn(7, 5, generator=g).to(dev()), torch.zeros(7, 5, device=dev())
+    slots = ops.amax_slots(3, dev())
+    arr = (L.Copy2dDesc * 4)()
+    for d, (src, dst, acc, slot) in zip(arr, ((a, whole[:, :64], 0, slots[0]), (b, whole[:, 64:72], 0, slots[0]),
+                                               (c, acc_dst, 1, slots[1]), (plain_src, plain_dst, 0, None))):
+        d.src, d.lds, d.dst, d.ldd = src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)
+        d.rows, d.cols, d.accumulate = src.shape[0], src.shape[1], acc
+        if slot is not None:
+            d.amax_out = slot.data_ptr()
+    assert lib.mml_copy2d_batch(arr, 4, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(whole[:, :64], a) and torch.equal(whole[:, 64:72], b) and float(whole[:, 72:].abs().max()) == 0.0
+    assert torch.equal(plain_dst, plain_src)
+    assert ops.amax_value(slots[0]) == 77.5 == float(whole.abs().max())
+    assert ops.amax_value(slots[1]) == float(acc_dst.abs().max()) and torch.equal(acc_dst, c + 100.0)
+    assert ops.amax_value(slots[2]) == 0.0
+    ref = ops.amax_slots(1, dev())
+    ops.amax_batch([(whole, ref[0])])
+    torch.cuda.synchronize()
+    assert ops.amax_value(ref[0]) == ops.amax_value(slots[0])
+
+
 @pytest.mark.parametrize("widths,rows,accumulate", [
     ([8, 8, 16, 8], 1000, 0),        # every segment a multiple of four floats: 16-byte kernel
     ([8] * 30, 4099, 1),             # the row-exchange shape (30 fields, E = 8), accumulate
