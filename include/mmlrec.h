@@ -442,10 +442,11 @@ int mml_gemm_grouped_wgrad(const mml_gemm_wgrad_desc* descs, int32_t n, void* wo
  * needs its own workspace. */
 int mml_gemm_grouped_wgrad_phase(const mml_gemm_wgrad_desc* descs, int32_t n, void* workspace,
                                  int64_t workspace_bytes, int32_t phase, mml_stream_t stream);
-/* 1 when ONE weight-gradient problem satisfies every per-problem condition of the cut-once weight-gradient kernel (mml_gemm_set_nt, csrc/gemm_nt.hip) (layout, both
- * magnitudes, M, N, K, alignment and row pitches), else 0.  A launch is served when all of its problems are and they share
- * M: a caller that groups problems into launches (engine.Plan.merge_wgrad) asks here, so that its grouping and the
- * library's decision cannot drift apart.  No GPU work, no error text. */
+/* 1 when ONE weight-gradient problem satisfies every per-problem condition of the cut-once weight-gradient kernel
+ * (mml_gemm_set_nt, csrc/gemm_nt.hip: layout, both magnitudes, M, N, K, alignment and row pitches), else 0.  A launch is
+ * served when all of its problems are, they share M and there are at most 48 of them: a caller that groups problems into
+ * launches (engine.Plan.merge_wgrad) asks here, so that its grouping and the library's decision cannot drift apart.  No GPU
+ * work, no error text. */
 int mml_gemm_nt_serves(const mml_gemm_wgrad_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
