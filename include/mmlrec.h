@@ -261,8 +261,10 @@ int mml_gemm_set_ws(int32_t on);
  * their fp16 planes ONCE, stored to LDS as they lie in memory, and the MFMA fragments -- consecutive batch rows of a column
  * -- are read with the transposing LDS read ds_read_b64_tr_b16; partial tiles go to the same workspace, summed in slab order.
  * Same products and fp32 accumulation as the tile kernel, another summation order (not bitwise equal to it; bitwise
- * repeatable).  on = 0 never, 1 (default) every qualifying launch, 2 launches of at least 16 output tiles; environment
- * MMLREC_GEMM_NT sets the same (csrc/gemm_nt.hip holds the numbers: AE-30 step 1.68 -> 1.60 ms on one box). */
+ * repeatable).  on = 0 never, 1 (default) every qualifying launch, 2 launches of at least 16 output tiles, 3 a measured
+ * lab variant (the dC fragments loaded straight from global memory, half the LDS traffic: 19-21 % slower, kept for the
+ * record); environment MMLREC_GEMM_NT sets the same (csrc/gemm_nt.hip holds the numbers: AE-30 step 1.68 -> 1.60 ms on
+ * one box). */
 int mml_gemm_set_nt(int32_t on);
 /* Kernel symbol (as rocprofv3 prints it, without the mml:: prefix) of the calling thread's most recent GEMM launch;
  * "" before the first one.  For profilers / benchmark labels. */

@@ -290,6 +290,182 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtLaunch L) {
   }
 }
 
+// ---- lab variant (round 6, MMLREC_NT_DIRECT=1): the dC fragments straight from global memory ----------------------------------
+// gemm_nt_kernel's LDS carries, per wave and 32-row step, 32 transposing reads (2 cycles each) and 8 16-byte stores (13 cycles
+// each: the store path, not the array, sets their price) against 24 MFMAs -- with eight waves per CU as many LDS cycles as MFMA
+// cycles.  An MFMA A fragment of dC^T is eight consecutive BATCH rows of one column per lane, 32 lanes = 32 consecutive columns:
+// a lane can fetch it itself with eight dword loads whose 32 lanes cover one 128-byte line.  This variant does that for dC (cut
+// in registers, once per wave: the two k-halves of the workgroup cut it twice) and keeps the LDS path for the activation operand
+// only: half the stores, half the fragment reads, 32 KiB of LDS per workgroup -- for 32 dword loads per lane and step on the
+// vector-memory path instead of 4 dwordx4.  Same products, scales and k order as gemm_nt_kernel: its bits, except the bias
+// gradient's summation order.
+// MEASURED (tools/lab/nt_time.py, stand-alone, one box, profiles/r06_nt_direct.txt): AE-30 first layers 180-185 -> 213-220 us,
+// KuaiRec-32 first layers 611-632 -> 754 us, second layers level: with half the LDS traffic the kernel is SLOWER -- the 36
+// vector-memory instructions per lane and step (8 in gemm_nt_kernel) are the new bound, so the LDS was not the only one at its
+// limit.  Kept as mode 3 of mml_gemm_set_nt (tests run it), not a default.
+constexpr int NTD_STAGE = 2 * NT_PLANE;  // A h, A l
+
+__global__ __launch_bounds__(256, 2) void gemm_ntd_kernel(const NtLaunch L) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * NTD_STAGE];  // 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = w >> 1, wk = w & 1;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = id / L.tiles;
+  int t = id - slab * L.tiles;
+  int pi = 0;
+  while (t >= L.p[pi].ntiles * L.p[pi].ktiles) t -= L.p[pi].ntiles * L.p[pi].ktiles, ++pi;  // (uniform)
+  const NtProblem& P = L.p[pi];
+  const int nt = t / P.ktiles, kt = t - nt * P.ktiles;
+  const int n0 = nt * 128, k0 = kt * 128;
+  const int per = (L.steps + L.slabs - 1) / L.slabs;
+  const int s_begin = slab * per, s_end = min(L.steps, s_begin + per);
+  const bool want_bias = P.ws_bias != nullptr && kt == 0;  // (uniform)
+
+  int kC = nt_scale_exp(nt_amax_load(P.amax_dc)), kA = nt_scale_exp(nt_amax_load(P.amax_a));
+  {
+    const int over = kC + kA - 126, under = -126 - (kC + kA);
+    if (over > 0) { kC -= (over + 1) >> 1; kA -= over >> 1; }
+    if (under > 0) { kC += (under + 1) >> 1; kA += under >> 1; }
+  }
+  kC = __builtin_amdgcn_readfirstlane(kC);
+  kA = __builtin_amdgcn_readfirstlane(kA);
+  const float sC = nt_pow2(kC), sA = nt_pow2(kA), inv = nt_pow2(-(kC + kA));
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int c4 = tid & 31, r8 = tid >> 5;
+  const bool colA = k0 + 4 * c4 < P.K;
+  const uint32_t tA = (uint32_t)(((int64_t)r8 * P.lda + (colA ? k0 + 4 * c4 : 0)) * 4);
+  const int hh = lane >> 5, c31 = lane & 31;
+  bool vi[2], vj[2];
+  uint32_t tD[2];  // the lane's byte offset into a step's rows: its half's first row, its column of block i
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    vi[i] = n0 + wn * 64 + i * 32 < P.N;
+    vj[i] = k0 + wk * 64 + i * 32 < P.K;
+    // (a block outside the problem re-reads the problem's first 32 columns: finite values for accumulators nobody stores)
+    tD[i] = (uint32_t)(((int64_t)(8 * hh) * P.lddc + (vi[i] ? n0 + wn * 64 + i * 32 : 0) + c31) * 4);
+  }
+  float bs[2] = {0.f, 0.f};
+
+  float dc0[2][2][8], dc1[2][2][8];  // [sub-step][block][batch row of the fragment]
+  float4 ra0[4], ra1[4];
+  const int last = s_end - 1;
+  auto load_step = [&](int st, float (&dc)[2][2][8], float4 (&ra)[4]) __attribute__((always_inline)) {
+    st = st > last ? last : st;
+    const char* const bC = reinterpret_cast<const char*>(P.dC + (int64_t)st * NT_STEP * P.lddc);
+    const char* const bA = reinterpret_cast<const char*>(P.A + (int64_t)st * NT_STEP * P.lda);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          dc[sub][i][e] = *reinterpret_cast<const float*>(bC + (int64_t)(sub * 16 + e) * P.lddc * 4 + tD[i]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(bA + (int64_t)(8 * p) * P.lda * 4 + tA);
+  };
+  auto store_step = [&](uint16_t* stage, const float4 (&ra)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = r8 + 8 * p;
+      const int off = row * 128 + (((c4 >> 1) ^ nt_swz32(row)) << 3) + 4 * (c4 & 1);
+      uint2 h, l;
+      nt_cut4(ra[p], sA, h, l);
+      *reinterpret_cast<uint2*>(stage + off) = h;
+      *reinterpret_cast<uint2*>(stage + NT_PLANE + off) = l;
+    }
+  };
+  int offA[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) offA[i][t2] = nt_frag_off(wk * 8 + i * 4, lane, t2);
+  auto compute = [&](const uint16_t* cur, const float (&dc)[2][2][8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const uint16_t* const b0 = cur + sub * 16 * 128;
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bh[i] = nt_frag32(b0, offA[i][0], offA[i][1]);
+        bl[i] = nt_frag32(b0 + NT_PLANE, offA[i][0], offA[i][1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 x0 = make_float4(dc[sub][i][0], dc[sub][i][1], dc[sub][i][2], dc[sub][i][3]);
+        const float4 x1 = make_float4(dc[sub][i][4], dc[sub][i][5], dc[sub][i][6], dc[sub][i][7]);
+        uint2 h0, l0, h1, l1;
+        nt_cut4(x0, sC, h0, l0);
+        nt_cut4(x1, sC, h1, l1);
+        const uint4 hv = make_uint4(h0.x, h0.y, h1.x, h1.y), lv = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        ah[i] = __builtin_bit_cast(f16x8, hv);
+        al[i] = __builtin_bit_cast(f16x8, lv);
+        bs[i] += ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
+      }
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int ns = s_end - s_begin;
+  if (ns > 0) {
+    load_step(s_begin, dc0, ra0);
+    load_step(s_begin + 1, dc1, ra1);
+    store_step(lds, ra0);
+  }
+  __syncthreads();
+  // step q: dC from the register set loaded two trips earlier (cut right in front of its MFMAs), the activation fragments from
+  // LDS stage q & 1; the set is refilled for step q + 2 BEHIND the MFMAs that read it
+#define NTD_TRIP(Q, DCQ, RAQ, RAS)                                                            \
+  {                                                                                           \
+    const int q_ = (Q);                                                                       \
+    compute(lds + (q_ & 1) * NTD_STAGE, DCQ);                                                 \
+    store_step(lds + ((q_ + 1) & 1) * NTD_STAGE, RAS);                                        \
+    load_step(s_begin + q_ + 2, DCQ, RAQ);                                                    \
+    __syncthreads();                                                                          \
+  }
+  int q = 0;
+  for (; q + 1 < ns; q += 2) {
+    NTD_TRIP(q, dc0, ra0, ra1)
+    NTD_TRIP(q + 1, dc1, ra1, ra0)
+  }
+  if (q < ns) NTD_TRIP(q, dc0, ra0, ra1)
+#undef NTD_TRIP
+
+  float* const ws = P.ws + (int64_t)slab * P.N * P.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!vi[i] || !vj[j]) continue;
+      const int k = k0 + wk * 64 + j * 32 + c31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (k < P.K) ws[(int64_t)n * P.K + k] = acc[i][j][r] * inv;
+      }
+    }
+  if (want_bias) {  // (uniform) the two halves of a column's rows meet by one exchange; the k-half 0 waves own the sums
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float sum = bs[i] + __shfl_xor(bs[i], 32, 64);
+      if (wk == 0 && hh == 0 && vi[i]) P.ws_bias[(int64_t)slab * P.N + n0 + wn * 64 + i * 32 + c31] = sum;
+    }
+  }
+}
+
 struct NtRedProblem {
   const float* ws;
   const float* ws_bias;
@@ -391,7 +567,7 @@ static int nt_mode() {
   if (g_nt_on < 0) {
     const char* e = getenv("MMLREC_GEMM_NT");
     g_nt_on = e ? atoi(e) : 1;
-    if (g_nt_on < 0 || g_nt_on > 2) g_nt_on = 1;
+    if (g_nt_on < 0 || g_nt_on > 3) g_nt_on = 1;
   }
   return g_nt_on;
 }
@@ -435,7 +611,8 @@ static bool nt_serves(const mml_gemm_wgrad_desc& q) {
 extern "C" int mml_gemm_nt_serves(const mml_gemm_wgrad_desc* desc) { return (desc && nt_serves(*desc)) ? 1 : 0; }
 
 extern "C" int mml_gemm_set_nt(int32_t on) {
-  MML_REQUIRE(on >= 0 && on <= 2, "mml_gemm_set_nt: 0 (off), 1 (every qualifying launch: default) or 2 (launches of >= 16 tiles)");
+  MML_REQUIRE(on >= 0 && on <= 3, "mml_gemm_set_nt: 0 (off), 1 (every qualifying launch: default), 2 (launches of >= 16 tiles) "
+              "or 3 (lab: every qualifying launch on gemm_ntd_kernel)");
   g_nt_on = on;
   return MML_OK;
 }
@@ -490,8 +667,10 @@ int mml_gemm_nt_try_wgrad(const mml_gemm_wgrad_desc* d, int32_t n, void* workspa
     maxred = blocks > maxred ? blocks : maxred;
   }
   if (phase != 2) {
+    // (mode 3: the lab variant gemm_ntd_kernel, dC fragments straight from global memory -- measured 19-21 % slower)
     // (one per CU: 20 KiB of unused dynamic LDS on top of the 64 KiB make a second workgroup not fit)
-    MML_LAUNCH(gemm_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), per_cu == 1 ? 20480 : 0, st, L);
+    if (nt_mode() == 3) MML_LAUNCH(gemm_ntd_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), 0, st, L);
+    else MML_LAUNCH(gemm_nt_kernel, dim3((unsigned)(L.tiles * slabs)), dim3(256), per_cu == 1 ? 20480 : 0, st, L);
     const int rc = check_launch("mml_gemm_grouped_wgrad(nt)");
     if (rc != MML_OK) return rc;
   }

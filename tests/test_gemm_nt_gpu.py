@@ -74,6 +74,31 @@ def test_nt_wgrad_matches_float64(env, M, shapes, shared):
     assert worst < 5e-6, worst   # (measured ~3e-7: fp32-equivalent, not merely inside the 1e-4 contract)
 
 
+@pytest.mark.parametrize("M,shapes,shared", [
+    (65536, [(256, 240)] * 4 + [(64, 240)] * 2, True),
+    (16384 + 32 * 5, [(96, 100), (32, 4)], False),
+    (16384, [(64, 72), (96, 80), (32, 64), (128, 128)] * 12, False),
+])
+def test_nt_wgrad_lab_variant_with_direct_gradient_fragments(env, M, shapes, shared):
+    """mml_gemm_set_nt(3): gemm_ntd_kernel (the dC fragments straight from global memory; measured slower, kept for the record)
+    computes the same products -- the weight gradients are BITWISE those of gemm_nt_kernel, the bias gradients (another
+    summation order) agree to fp32 noise."""
+    L, ops, lib = env
+    out = {}
+    for mode in (1, 3):
+        lib.mml_gemm_set_nt(mode)
+        probs = make(shapes, M, seed=7, shared_A=shared)
+        ops.gemm_wgrad(probs, amax=True)
+        torch.cuda.synchronize()
+        assert lib.mml_gemm_last_kernel().decode() == "gemm_nt_kernel"
+        check(probs)
+        out[mode] = probs
+    lib.mml_gemm_set_nt(1)
+    for a, b in zip(out[1], out[3]):
+        assert torch.equal(a["dW"], b["dW"])
+        assert rel(a["dbias"], b["dbias"].double()) < 1e-5
+
+
 def test_nt_wgrad_against_the_tile_kernel_accumulate_and_phases(env):
     """Same arithmetic as gemm_pipe_kernel (two fp16 planes, three products, fp32 accumulation): the two kernels agree to
     summation order; accumulate adds to what dW / dbias hold; the two-launch form equals the one-call form bit for bit;
