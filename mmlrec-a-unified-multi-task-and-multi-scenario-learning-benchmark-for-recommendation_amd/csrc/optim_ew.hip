@@ -866,14 +866,22 @@ extern "C" int mml_opt_step_dense(const mml_opt_tensor* tensors, int32_t n, cons
       if (hyper->max_blocks > 0 && bx * L.n > hyper->max_blocks) bx = cdiv(hyper->max_blocks, L.n);
       dim3 grid((unsigned)bx, (unsigned)L.n);
       if (many) {
-        int64_t tb = 4 * 256 * 8;  // (what the four-tensor launch of the huge tables gets)
-        if (hyper->max_blocks > 0 && tb > hyper->max_blocks) tb = hyper->max_blocks;
+        // every tensor gets what a launch of its own would give it (one workgroup per 256 chunks, at most 2 048): the huge
+        // tables stream exactly as in their four-tensor launch, the small ones add a few hundred workgroups (the caller
+        // lists them FIRST: they start with the launch instead of trailing it).  Under a workgroup cap: in proportion.
+        int64_t want = 0;
+        for (int k = 0; k < L.n; ++k) {
+          const int64_t need = cdiv(cdiv(L.t[k].n, 4), 256);
+          want += need > 256 * 8 ? 256 * 8 : (need < 1 ? 1 : need);
+        }
+        const bool capped = hyper->max_blocks > 0 && want > hyper->max_blocks;
+        int64_t tb = capped ? hyper->max_blocks : want;
         if (tb < L.n) tb = L.n;
         int64_t at = 0;
         for (int k = 0; k < L.n; ++k) {
           L.blk0[k] = (int32_t)at;
-          int64_t nb = tb * L.t[k].n / total;
           const int64_t need = cdiv(cdiv(L.t[k].n, 4), 256);
+          int64_t nb = capped ? tb * L.t[k].n / total : (need > 256 * 8 ? 256 * 8 : need);
           if (nb > need) nb = need;
           if (nb < 1) nb = 1;
           at += nb;

@@ -2706,12 +2706,13 @@ class Optimizer:
                 # in proportion to the tables' sizes, csrc/optim_ew.hip) instead of the streaming launch of the huge tables
                 # + a flat launch of the small ones (AE-30: 26 tables, 31-34 us).  Two call lists over ONE model replayed in
                 # alternating blocks, both orders (tools/lab/ab_inproc.py --shared, profiles/r06_tail_lab.txt): the single
-                # launch is 13 us per step SLOWER.  MMLREC_OPT_ONE_LAUNCH=1 turns it on.
+                # launch is 13 us per step SLOWER (workgroups dealt in proportion to the sizes) or 8 us slower (every tensor
+                # the grid a launch of its own would get, small tables first: the form kept).  MMLREC_OPT_ONE_LAUNCH=1: on.
                 one_launch = (big and small and cap > 0 and len(tabs) <= L.MAX_OPT_TENSORS and not split_dense and
                               all(id(t) in marks_of for t in tabs) and
                               os.environ.get("MMLREC_OPT_ONE_LAUNCH", "0") == "1")
                 if one_launch:
-                    big = big + small
+                    big = small + big   # (the small tables' workgroups first: they start with the launch)
                     groups = [big]
                 for grp in groups:
                     marked = grp is big and all(id(tabs[i]) in marks_of for i in grp)
