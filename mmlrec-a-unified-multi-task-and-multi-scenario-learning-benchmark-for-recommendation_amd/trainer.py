@@ -474,13 +474,6 @@ class TrainStep:
         if self.use_graph and self.calls == 1:
             torch.cuda.synchronize()
             _quiesce_collective_watchdog()
-            nd = int(os.environ.get("MMLREC_DUMMY_STREAMS", "0"))  # lab: shift the hardware queue the graph's branch lands on
-            if nd:
-                self._dummy = [torch.cuda.Stream(device=self.store.device) for _ in range(nd)]
-                for s_ in self._dummy:
-                    with torch.cuda.stream(s_):
-                        self.plan.status.add_(0)
-                torch.cuda.synchronize()
             for seg in ((self.whole,) if self.whole is not None else
                         (self.pre, self.early, self.front, self.front_b, self.side_a, self.sideq, self.tail)):
                 if seg is not None:

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the MMLREC_DUMMY_STREAMS knob these runs used -- extra streams created in front of the graph capture -- was a lab-only line of
+#  trainer.TrainStep.run and has been removed: the runs measured level)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/coresident3.txt; : > $out
 run() { env $1 python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-lazy --alt-batch 0 --no-configs --no-loss-check "${@:2}" 2>/dev/null | python3 -c "
