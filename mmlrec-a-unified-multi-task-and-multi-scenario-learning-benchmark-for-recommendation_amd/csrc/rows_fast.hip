@@ -48,6 +48,50 @@ __device__ __forceinline__ float cross_group_sum(float v) {
   return v;
 }
 
+// Round 6: EIGHT sums over a lane group at once (MMoE's 4 experts x 2 gates: the logits of the forward, the dmix . E dots
+// of the backward).  Eight butterflies of log2(LPS) exchange-adds each were 48 DPP / LDS-crossbar steps per sample; here every
+// exchange also HALVES what a lane carries -- the partner keeps the other half -- so the first three steps (all DPP) take
+// 4 + 2 + 1 adds and leave lane l with the block-of-eight partial sum of value (l & 7); the remaining steps add ONE value
+// across the 8-lane blocks of the group (row_ror:8, then the crossbar for 32 / 64 lanes).  Result: the total of value
+// (sub & 7) in every lane (each total lives in LPS / 8 lanes).  Partners and the bit that decides which half a lane keeps:
+// row_half_mirror (lane ^ 7) by bit 2, quad_perm [2,3,0,1] (lane ^ 2) by bit 1, quad_perm [1,0,3,2] (lane ^ 1) by bit 0.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));
+}
+template <int LPS>
+__device__ __forceinline__ float pack_sum8(const float (&v)[8], const int lane) {
+  const bool b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  float a[4], c[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = (b2 ? v[4 + j] : v[j]) + dpp_get<0x141>(b2 ? v[j] : v[4 + j]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) c[j] = (b1 ? a[2 + j] : a[j]) + dpp_get<0x4E>(b1 ? a[j] : a[2 + j]);
+  float r = (b0 ? c[1] : c[0]) + dpp_get<0xB1>(b0 ? c[0] : c[1]);
+  if (LPS >= 16) r += dpp_get<0x128>(r);  // row_ror:8 = lane ^ 8 inside a row of 16
+#pragma unroll
+  for (int off = 16; off < LPS; off <<= 1) r += __shfl_xor(r, off, 64);
+  return r;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, dpp_get<0xB1>(v));
+  return fmaxf(v, dpp_get<0x4E>(v));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_get<0xB1>(v);
+  return v + dpp_get<0x4E>(v);
+}
+// (lab knob MMLREC_GATE_PACK=0: the eight separate butterflies of round 5)
+static int gate_pack_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MMLREC_GATE_PACK");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return on;
+}
+
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
@@ -175,8 +219,9 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 // probabilities scattered BY EXPERT INDEX into a per-lane-group LDS row, then every expert row is read once and feeds all
 // gates' mixtures.  (The per-gate kernel above re-reads shared experts for every gate that mixes them: 2x the expert
 // traffic for MMoE, 2.25x for a PLE level -- and the second read misses L2: PMC 296 MB read vs 167 MB algorithmic.)
-template <int LPS, int NE, int NG>
+template <int LPS, int NE, int NG, bool PACK = false>
 __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group g, const GateFastAux aux) {
+  static_assert(!PACK || (NE == 4 && NG == 2), "the packed sums carry eight values: 4 experts x 2 gates");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SPW = 64 / LPS;
   float* coef_all = smem + aux.wg_total;  // [FW*SPW][NG*MML_MAX_EXPERTS]
@@ -226,6 +271,35 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
     for (int gi = 0; gi < NG; ++gi) Gv[gi] = Gvn[gi];
     if (it + 1 < iters) request(it + 1);
     __builtin_amdgcn_wave_barrier();  // coef zeroed before the scattered writes below
+    if constexpr (PACK) {
+      // all eight logits' partial dots, ONE packed reduction; lane l then owns the logit of gate (l >> 2) & 1, expert slot
+      // l & 3: its softmax is a max and a sum over the lane's quad and ONE expf per lane (every lane computed all eight before)
+      float d8[8];
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        const mml_gate_desc& d = g.gate[gi < g.n_gates ? gi : 0];
+        const float* W = smem + aux.wg_off[gi < g.n_gates ? gi : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = gi < g.n_gates && e < d.ne && 4 * sub < d.Gd;
+          d8[gi * 4 + e] = on ? dot4(Gv[gi], ld4(W + e * d.Gd + 4 * sub)) : 0.f;
+        }
+      }
+      const float logit = pack_sum8<LPS>(d8, lane);
+      const int gl = (sub >> 2) & 1, el = sub & 3;
+      const bool has = gl < g.n_gates;
+      const mml_gate_desc& dl_ = g.gate[has ? gl : 0];  // (per-lane choice between the two gates: selects, no branch)
+      const bool live = has && el < dl_.ne;
+      const float xl = live ? logit : -INFINITY;
+      const float m = quad_max(xl);
+      const float ex = live ? expf(xl - m) : 0.f;
+      const float den = quad_sum(ex);
+      const float pr = ex * (1.f / den);
+      if (sub < 8 && live) {
+        if (valid) dl_.P[b * dl_.ldp + el] = pr;
+        coef[gl * MML_MAX_EXPERTS + emap[gl * NE + el]] = pr;
+      }
+    } else {
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       if (gi >= g.n_gates) continue;
@@ -258,6 +332,7 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
         if (valid) d.P[b * d.ldp + sub] = mine;
         coef[gi * MML_MAX_EXPERTS + emap[gi * NE + sub]] = mine;
       }
+    }
     }
     __builtin_amdgcn_wave_barrier();
     if (hcol) {
@@ -895,7 +970,11 @@ static void launch_gate_fwd(const mml_gate_group& g, const GateFastAux& aux, hip
   const size_t lds1 = ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)aux.ng * aux.ne) * 4;
   if (forced != 0 && g.n_experts <= aux.ne && aux.ne * aux.ng <= 32 && lds1 <= 60 * 1024) {
 #define MML_GF(NE_, NG_) MML_LAUNCH((gate_fwd_once_kernel<LPS, NE_, NG_>), gr, bl, lds1, st, g, aux)
-    if (aux.ne == 4 && aux.ng == 2) { MML_GF(4, 2); return; }
+    if (aux.ne == 4 && aux.ng == 2) {
+      if (gate_pack_on()) MML_LAUNCH((gate_fwd_once_kernel<LPS, 4, 2, true>), gr, bl, lds1, st, g, aux);
+      else MML_GF(4, 2);
+      return;
+    }
     if (aux.ne == 4 && aux.ng == 3) { MML_GF(4, 3); return; }
     if (aux.ne == 4 && aux.ng == 4) { MML_GF(4, 4); return; }
     if (aux.ne == 4 && aux.ng == 8) { MML_GF(4, 8); return; }

@@ -317,6 +317,12 @@ def _gate_setup(rng, B, H, nexp, gate_sets, Gd):
     (1000, 128, 4, [[0, 1, 2, 3], [0, 1, 2, 3]], 64),                        # MMoE
     (515, 32, 8, [[0, 1, 2, 6, 7], [3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7]], 16),  # PLE CGC
     (70, 300, 3, [[2, 0]], 100),                                             # odd sizes
+    # round 6 (packed sums of the 4 experts x 2 gates kernels): KuaiRec's widths (one sample per wave), one gate only,
+    # three experts in another order, a second gate over a subset, 16-lane groups
+    (300, 256, 4, [[0, 1, 2, 3], [0, 1, 2, 3]], 128),
+    (257, 64, 3, [[2, 0, 1]], 32),
+    (129, 128, 4, [[0, 1, 2, 3], [3, 1]], 64),
+    (1000, 64, 4, [[0, 1, 2, 3], [0, 1, 2, 3]], 16),
 ])
 def test_gate_mix_fwd_bwd(ops, B, H, nexp, gate_sets, Gd):
     rng = np.random.default_rng(7)
