@@ -491,7 +491,9 @@ typedef struct {
    * dE, bit 2 = every dG -- the tensors that only GEMMs read are written as their operands (round to nearest even);
    * bit 3 = every expert output E ARRIVES as bf16 (lde in bf16 elements; written that way by the layer that produced it:
    * mml_g16_tn_desc.c_bf16) and is widened exactly; everything else the kernels read stays fp32.  Only the fast row
-   * kernels honour it: other shapes return MML_ERR_UNSUPPORTED when a bit is set. */
+   * kernels honour it: other shapes return MML_ERR_UNSUPPORTED when a bit is set.  With bit 3, 4 experts x <= 2 gates,
+   * 128 < H <= 256, H % 8 == 0 and gate inputs of at most 128 columns the kernels run eight row columns per lane on
+   * 32-lane groups (16-byte accesses to the bf16 rows, two samples per wave and trip: round 6). */
   int32_t out_bf16;
   int32_t pad_;
 } mml_gate_group;

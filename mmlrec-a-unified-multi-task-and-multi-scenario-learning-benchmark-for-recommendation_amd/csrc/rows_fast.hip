@@ -219,9 +219,13 @@ __global__ __launch_bounds__(FB) void gate_fwd_fast_kernel(const mml_gate_group 
 // probabilities scattered BY EXPERT INDEX into a per-lane-group LDS row, then every expert row is read once and feeds all
 // gates' mixtures.  (The per-gate kernel above re-reads shared experts for every gate that mixes them: 2x the expert
 // traffic for MMoE, 2.25x for a PLE level -- and the second read misses L2: PMC 296 MB read vs 167 MB algorithmic.)
-template <int LPS, int NE, int NG, bool PACK = false>
+// HV = 2 (round 6): bf16 expert rows of up to 256 columns on 32-lane groups, EIGHT columns per lane -- one 16-byte load per
+// expert row and lane instead of an 8-byte one (the vector-memory path serves 8-byte accesses at 0.54-0.70 of the 16-byte
+// rate) and two samples per wave and trip instead of one; the gate inputs (<= 128 columns) keep four columns per lane.
+template <int LPS, int NE, int NG, bool PACK = false, int HV = 1>
 __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group g, const GateFastAux aux) {
   static_assert(!PACK || (NE == 4 && NG == 2), "the packed sums carry eight values: 4 experts x 2 gates");
+  static_assert(HV == 1 || HV == 2, "one or two 16-byte pieces of a row per lane");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SPW = 64 / LPS;
   float* coef_all = smem + aux.wg_total;  // [FW*SPW][NG*MML_MAX_EXPERTS]
@@ -241,18 +245,26 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
   float* coef = coef_all + (wave * SPW + grp) * NG * MML_MAX_EXPERTS;
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
-  const bool hcol = 4 * sub < g.H;
+  const bool hcol = 4 * HV * sub < g.H;
   float am_mix = 0.f;
   // The rows of trip it + 1 are requested before trip it is worked on (round 5): a trip is a chain of a global load, two
   // LDS round trips, the softmax and the stores -- 11 us per trip at B = 65 536 with six workgroups per CU, and a wave had
   // nothing in flight while it worked through it.
-  float4 Evn[NE], Gvn[NG];
+  float4 Evn[NE][HV], Gvn[NG];
   auto request = [&](const int64_t it) __attribute__((always_inline)) {
     int64_t b = it * stride + ((int64_t)blockIdx.x * FW + wave) * SPW + grp;
     if (b >= g.B) b = g.B - 1;
 #pragma unroll
-    for (int x = 0; x < NE; ++x)
-      Evn[x] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+    for (int x = 0; x < NE; ++x) {
+      if constexpr (HV == 2) {  // (bf16 rows: eight values = one 16-byte load, widened exactly)
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (hcol && x < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[x]) + b * g.lde[x] + 8 * sub);
+        Evn[x][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+        Evn[x][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+      } else {
+        Evn[x][0] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi)
       Gvn[gi] = (gi < g.n_gates && 4 * sub < g.gate[gi].Gd) ? ld4(g.gate[gi].G + b * g.gate[gi].ldg + 4 * sub)
@@ -264,9 +276,11 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
     const bool valid = b < g.B;
     if (!valid) b = g.B - 1;
     for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
-    float4 Ev[NE], Gv[NG];
+    float4 Ev[NE][HV], Gv[NG];
 #pragma unroll
-    for (int x = 0; x < NE; ++x) Ev[x] = Evn[x];
+    for (int x = 0; x < NE; ++x)
+#pragma unroll
+      for (int h = 0; h < HV; ++h) Ev[x][h] = Evn[x][h];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) Gv[gi] = Gvn[gi];
     if (it + 1 < iters) request(it + 1);
@@ -339,12 +353,36 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         if (gi >= g.n_gates) continue;
-        float4 acc = make_float4(0, 0, 0, 0);
+        float4 acc[HV];
 #pragma unroll
-        for (int x = 0; x < NE; ++x) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], Ev[x]);
+        for (int h = 0; h < HV; ++h) acc[h] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < NE; ++x) {
+          const float cf = coef[gi * MML_MAX_EXPERTS + x];
+#pragma unroll
+          for (int h = 0; h < HV; ++h) fma4(acc[h], cf, Ev[x][h]);
+        }
         if (valid) {
-          st4o(g.gate[gi].mix, b * g.gate[gi].ldmix + 4 * sub, acc, (g.out_bf16 & MML_GATE_MIX_BF16) != 0);
-          amax_acc(am_mix, acc);
+          const bool m16 = (g.out_bf16 & MML_GATE_MIX_BF16) != 0;
+          if constexpr (HV == 2) {
+            if (m16) {  // eight bf16 values: one 16-byte store
+              typedef float f2 __attribute__((ext_vector_type(2)));
+              typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+              const f2 p0 = {acc[0].x, acc[0].y}, p1 = {acc[0].z, acc[0].w}, p2 = {acc[1].x, acc[1].y}, p3 = {acc[1].z, acc[1].w};
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.gate[gi].mix) + b * g.gate[gi].ldmix + 8 * sub) =
+                  make_uint4(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, b2)));
+            } else {
+              st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 8 * sub, acc[0]);
+              st4(g.gate[gi].mix + b * g.gate[gi].ldmix + 8 * sub + 4, acc[1]);
+            }
+          } else {
+            st4o(g.gate[gi].mix, b * g.gate[gi].ldmix + 4 * sub, acc[0], m16);
+          }
+#pragma unroll
+          for (int h = 0; h < HV; ++h) amax_acc(am_mix, acc[h]);
         }
       }
     }
@@ -356,8 +394,12 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
 // ------------------------------------------------------------------------------------------------ gate backward
 // MODE 0: any expert lists; 1: every gate mixes experts 0..ne-1 in order (MMoE); 2: any membership, but at most NE
 // experts in the group -- every expert row is loaded ONCE per sample and serves all gates (PLE levels)
-template <int LPS, int NE, int NG, int MODE>
+// HV = 2 (round 6, MODE 1 only): bf16 expert rows of up to 256 columns on 32-lane groups, eight row columns per lane -- see
+// gate_fwd_once_kernel; the upstream gradient rows (fp32) are two 16-byte loads per lane, dE leaves as one 16-byte store of
+// eight bf16 values (or two fp32 stores), the gate-input side (<= 128 columns) keeps four columns per lane.
+template <int LPS, int NE, int NG, int MODE, int HV = 1>
 __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group g, const GateFastAux aux) {
+  static_assert(HV == 1 || (HV == 2 && MODE == 1), "eight columns per lane: the MMoE form only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SPW = 64 / LPS;
   float* Wsm = smem;                                   // [wg_total] gate weights
@@ -390,7 +432,7 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
   float* coef = coef_all + (wave * SPW + grp) * NG * MML_MAX_EXPERTS;
   const int64_t stride = (int64_t)gridDim.x * FW * SPW;
   const int64_t iters = (g.B + stride - 1) / stride;
-  const bool hcol = 4 * sub < g.H;
+  const bool hcol = 4 * HV * sub < g.H;
 
   float* myred = red + (wave * SPW + grp) * aux.wg_total;
   float am_dg = 0.f, am_de = 0.f;  // operand magnitudes of everything this lane stores (mml_gate_group.amax_dG / amax_dE)
@@ -413,20 +455,33 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
     for (int i = sub; i < NG * MML_MAX_EXPERTS; i += LPS) coef[i] = 0.f;
     // every load of the sample first (a store between two loads would serialise their latencies): upstream
     // gradients, expert rows, softmax probabilities, gate inputs
-    float4 dmv[NG], Gv[NG], Ev[NE];
+    float4 dmv[NG][HV], Gv[NG], Ev[NE][HV];
     float pv[NG][NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) Ev[e] = (hcol && e < g.n_experts) ? ld4i(g.E[e], b * g.lde[e] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+    for (int e = 0; e < NE; ++e) {
+      if constexpr (HV == 2) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (hcol && e < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[e]) + b * g.lde[e] + 8 * sub);
+        Ev[e][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+        Ev[e][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+      } else {
+        Ev[e][0] = (hcol && e < g.n_experts) ? ld4i(g.E[e], b * g.lde[e] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-      dmv[gi] = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < HV; ++h) dmv[gi][h] = make_float4(0, 0, 0, 0);
       Gv[gi] = make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < NE; ++e) pv[gi][e] = 0.f;
       if (gi >= g.n_gates) continue;
       const mml_gate_desc& d = g.gate[gi];
       if (!d.active) continue;
-      if (hcol) dmv[gi] = ld4(d.dmix + b * d.lddmix + 4 * sub);
+      if (hcol) {
+#pragma unroll
+        for (int h = 0; h < HV; ++h) dmv[gi][h] = ld4(d.dmix + b * d.lddmix + 4 * HV * sub + 4 * h);
+      }
       if (4 * sub < d.Gd) Gv[gi] = ld4(d.G + b * d.ldg + 4 * sub);
 #pragma unroll
       for (int e = 0; e < NE; ++e)
@@ -443,7 +498,11 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
       for (int e = 0; e < NE; ++e) {
         dl[e] = 0.f;
         if (e < d.ne) {
-          const float part = hcol ? dot4(dmv[gi], Ev[e]) : 0.f;
+          float part = 0.f;
+          if (hcol) {
+#pragma unroll
+            for (int h = 0; h < HV; ++h) part += dot4(dmv[gi][h], Ev[e][h]);
+          }
           dl[e] = group_sum<LPS>(part);
           dot += pv[gi][e] * dl[e];
           if (sub == 0) coef[gi * MML_MAX_EXPERTS + e] = pv[gi][e];
@@ -480,18 +539,45 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 #pragma unroll
       for (int x = 0; x < NE; ++x) {
         if (x >= g.n_experts) continue;
-        float4 acc = make_float4(0, 0, 0, 0);
+        float4 acc[HV];
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) fma4(acc, coef[gi * MML_MAX_EXPERTS + x], dmv[gi]);
+        for (int h = 0; h < HV; ++h) acc[h] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+          const float cf = coef[gi * MML_MAX_EXPERTS + x];
+#pragma unroll
+          for (int h = 0; h < HV; ++h) fma4(acc[h], cf, dmv[gi][h]);
+        }
         if (g.e_relu) {
-          if (!(Ev[x].x > 0.f)) acc.x = 0.f;
-          if (!(Ev[x].y > 0.f)) acc.y = 0.f;
-          if (!(Ev[x].z > 0.f)) acc.z = 0.f;
-          if (!(Ev[x].w > 0.f)) acc.w = 0.f;
+#pragma unroll
+          for (int h = 0; h < HV; ++h) {
+            if (!(Ev[x][h].x > 0.f)) acc[h].x = 0.f;
+            if (!(Ev[x][h].y > 0.f)) acc[h].y = 0.f;
+            if (!(Ev[x][h].z > 0.f)) acc[h].z = 0.f;
+            if (!(Ev[x][h].w > 0.f)) acc[h].w = 0.f;
+          }
         }
         if (valid) {
-          st4o(g.dE[x], b * g.ldde[x] + 4 * sub, acc, (g.out_bf16 & MML_GATE_DE_BF16) != 0);
-          amax_acc(am_de, acc);
+          const bool e16 = (g.out_bf16 & MML_GATE_DE_BF16) != 0;
+          if constexpr (HV == 2) {
+            if (e16) {
+              typedef float f2 __attribute__((ext_vector_type(2)));
+              typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+              const f2 p0 = {acc[0].x, acc[0].y}, p1 = {acc[0].z, acc[0].w}, p2 = {acc[1].x, acc[1].y}, p3 = {acc[1].z, acc[1].w};
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.dE[x]) + b * g.ldde[x] + 8 * sub) =
+                  make_uint4(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, b2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, b2)));
+            } else {
+              st4(g.dE[x] + b * g.ldde[x] + 8 * sub, acc[0]);
+              st4(g.dE[x] + b * g.ldde[x] + 8 * sub + 4, acc[1]);
+            }
+          } else {
+            st4o(g.dE[x], b * g.ldde[x] + 4 * sub, acc[0], e16);
+          }
+#pragma unroll
+          for (int h = 0; h < HV; ++h) amax_acc(am_de, acc[h]);
         }
       }
     }
@@ -908,6 +994,20 @@ int fast_row_grid(int64_t B, int lps, int per_cu = 4) {
 
 static bool ok4(const void* p, int64_t ld) { return aligned16(p) && (ld % 4 == 0); }
 
+// does the load-once forward take this group on lane groups of `lps` lanes?  (MMLREC_GATE_FWD_MODE=0: per-gate kernel
+// everywhere, a measurement knob)
+static size_t gate_fwd_once_lds(const GateFastAux& aux, int lps) {
+  return ((size_t)aux.wg_total + (size_t)FW * (64 / lps) * aux.ng * MML_MAX_EXPERTS + (size_t)aux.ng * aux.ne) * 4;
+}
+static bool gate_fwd_once_ok(const mml_gate_group& g, const GateFastAux& aux, int lps) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("MMLREC_GATE_FWD_MODE");
+    forced = e ? atoi(e) : -1;
+  }
+  return forced != 0 && g.n_experts <= aux.ne && aux.ne * aux.ng <= 32 && gate_fwd_once_lds(aux, lps) <= 60 * 1024;
+}
+
 int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
   if (g->H % 4 || g->H > 256) return 0;
   int width = g->H, nemax = 0, off = 0;
@@ -936,6 +1036,31 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
   aux.lps = pick_lps(width);
   aux.ne = nemax <= 4 ? 4 : (nemax <= 8 ? 8 : 16);
   aux.ng = g->n_gates <= 2 ? 2 : (g->n_gates == 3 ? 3 : (g->n_gates <= 4 ? 4 : 8));  // 3: a PLE level at T = 2
+  aux.hv = 1;
+  // forward, bf16 expert rows wider than 128 columns under gate inputs of at most 128 (KuaiRec-32 in the bf16-storage mode):
+  // 32-lane groups with eight row columns per lane (gate_fwd_once_kernel<.., HV = 2>; MMLREC_GATE_HV=0: one sample per wave)
+  static int bwd_forced = -2;
+  if (bwd_forced == -2) {
+    const char* e = getenv("MMLREC_GATE_BWD_MODE");
+    bwd_forced = e ? atoi(e) : -1;
+  }
+  if ((g->out_bf16 & MML_GATE_E_BF16) && g->H > 128 && g->H % 8 == 0 && aux.ne == 4 && aux.ng == 2 && gate_pack_on() &&
+      (!bwd || (aux.ident && bwd_forced == -1))) {
+    static int hv_on = -1;
+    if (hv_on < 0) {
+      const char* e = getenv("MMLREC_GATE_HV");
+      hv_on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    bool ok = hv_on != 0 && g->n_experts <= 4 && (bwd || gate_fwd_once_ok(*g, aux, 32));  // (only these kernels have the form)
+    for (int x = 0; x < g->n_experts && ok; ++x)
+      ok = g->lde[x] % 8 == 0 && (!bwd || g->ldde[x] % ((g->out_bf16 & MML_GATE_DE_BF16) ? 8 : 4) == 0);
+    for (int i = 0; i < g->n_gates && ok; ++i)
+      ok = g->gate[i].Gd <= 128 && (bwd || g->gate[i].ldmix % ((g->out_bf16 & MML_GATE_MIX_BF16) ? 8 : 4) == 0);
+    if (ok) {
+      aux.lps = 32;
+      aux.hv = 2;
+    }
+  }
   if (bwd && aux.ne * aux.ng > 32) return 0;  // register budget (upstream gradients, coefficients)
   static int fwd_per_cu = -1;
   if (fwd_per_cu < 0) {
@@ -961,16 +1086,16 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
 template <int LPS>
 static void launch_gate_fwd(const mml_gate_group& g, const GateFastAux& aux, hipStream_t st) {
   dim3 gr(aux.grid), bl(FB);
-  static int forced = -2;  // MMLREC_GATE_FWD_MODE=0: per-gate kernel everywhere (measurement knob)
-  if (forced == -2) {
-    const char* e = getenv("MMLREC_GATE_FWD_MODE");
-    forced = e ? atoi(e) : -1;
-  }
-  const int spw = 64 / LPS;
-  const size_t lds1 = ((size_t)aux.wg_total + (size_t)FW * spw * aux.ng * MML_MAX_EXPERTS + (size_t)aux.ng * aux.ne) * 4;
-  if (forced != 0 && g.n_experts <= aux.ne && aux.ne * aux.ng <= 32 && lds1 <= 60 * 1024) {
+  const size_t lds1 = gate_fwd_once_lds(aux, LPS);
+  if (gate_fwd_once_ok(g, aux, LPS)) {
 #define MML_GF(NE_, NG_) MML_LAUNCH((gate_fwd_once_kernel<LPS, NE_, NG_>), gr, bl, lds1, st, g, aux)
     if (aux.ne == 4 && aux.ng == 2) {
+      if constexpr (LPS == 32) {
+        if (aux.hv == 2) {
+          MML_LAUNCH((gate_fwd_once_kernel<32, 4, 2, true, 2>), gr, bl, lds1, st, g, aux);
+          return;
+        }
+      }
       if (gate_pack_on()) MML_LAUNCH((gate_fwd_once_kernel<LPS, 4, 2, true>), gr, bl, lds1, st, g, aux);
       else MML_GF(4, 2);
       return;
@@ -1021,7 +1146,10 @@ static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipS
     else if (g.n_experts <= NE_ && NE_ * NG_ <= 32 && forced != 0) MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 2>), gr, bl, lds, st, g, aux); \
     else MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 0>), gr, bl, lds, st, g, aux);   \
   } while (0)
-  if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
+  if (aux.hv == 2) {  // (gate_fast_config: the MMoE form on 32-lane groups)
+    if constexpr (LPS == 32) MML_LAUNCH((gate_bwd_fast_kernel<32, 4, 2, 1, 2>), gr, bl, lds, st, g, aux);
+    else return 1;
+  } else if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
   else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
   else if (aux.ne == 4 && aux.ng == 8) MML_GB(4, 8);
   else if (aux.ne == 8 && aux.ng == 2) MML_GB(8, 2);

@@ -9,6 +9,8 @@ struct GateFastAux {
   int32_t wg_total;
   int32_t lps, ne, ng, grid;
   int32_t ident;                  // every gate mixes experts 0..ne-1 in order (MMoE): backward reuses its expert-row loads
+  int32_t hv;                     // 16-byte pieces of an expert / mixture row per lane: 1, or 2 (bf16 rows of 129..256 columns
+                                  // on 32-lane groups -- two samples per wave and trip, 16-byte accesses; forward only)
   float* slab;                    // backward: [grid][wg_total] per-workgroup dWg partials
 };
 

@@ -52,11 +52,16 @@ class MMOE(BaseModel):
         # bf16-storage path: the expert outputs are read by the gate kernels only, which widen bf16 exactly
         # (mml_gate_group.out_bf16 bit 3) -- half the bytes of the largest tensor three kernels move
         H_, G_ = self.expert_dnn_hidden_units[-1], (self.gate_dnn_hidden_units[-1] if hasattr(self, "gate_dnn") else 0)
-        # Measured (KuaiRec-32, B = 65 536, same box): the second layers' forward 136 -> 121 us, but the gate kernels -- one
-        # 16-byte load per lane and expert -- fall to 8-byte loads: backward 161 -> 191, forward 90 -> 98; a net loss, so
-        # the experts stay fp32 unless MMLREC_BF16_EXPERTS=1.
+        # Round 5 (KuaiRec-32, B = 65 536, same box): the second layers' forward 136 -> 121 us, but the gate kernels -- one
+        # 16-byte load per lane and expert -- fell to 8-byte loads: backward 161 -> 191, forward 90 -> 98; a net loss.
+        # Round 6: the MMoE gate kernels have a form with EIGHT row columns per lane on 32-lane groups (csrc/rows_fast.hip,
+        # HV = 2: 16-byte loads of bf16 rows, two samples per wave and trip) for 129..256-wide experts under gate inputs
+        # of at most 128 columns, 4 experts x 2 tasks: there the experts are bf16 by default (MMLREC_BF16_EXPERTS=0 / 1
+        # forces either way).
         import os
-        e16 = (plan.bf16 and os.environ.get("MMLREC_BF16_EXPERTS", "0") == "1" and hasattr(self, "gate_dnn") and
+        hv_form = 128 < H_ <= 256 and H_ % 8 == 0 and 0 < G_ <= 128 and Ne <= 4 and T <= 2
+        env16 = os.environ.get("MMLREC_BF16_EXPERTS")
+        e16 = (plan.bf16 and (env16 == "1" or (env16 is None and hv_form)) and hasattr(self, "gate_dnn") and
                E._fast_row_width_ok(H_) and E._fast_row_width_ok(G_) and H_ % 8 == 0 and Ne * max(T, 2) <= 32)
         stacks = [self.expert_dnn[e].layer_problems(plan, store, f"expert_dnn.{e}", x0, last16=e16) for e in range(Ne)]
         if hasattr(self, "gate_dnn"):

@@ -275,6 +275,48 @@ def test_bad_arguments_are_rejected(ops):
                             dW=torch.zeros(64, 128, device=dev()))])                     # N % 128
 
 
+@pytest.mark.parametrize("B,H,Gd", [(333, 200, 72), (4099, 256, 128), (64, 136, 128)])
+def test_gate_kernels_with_eight_columns_per_lane_against_float64(ops, B, H, Gd):
+    """Round 6: bf16 expert rows of 129..256 columns under gate inputs of at most 128 (4 experts x 2 gates: KuaiRec-32's MMoE
+    in the bf16-storage mode) run on 32-lane groups with EIGHT row columns per lane (csrc/rows_fast.hip, HV = 2: 16-byte
+    loads of bf16 rows, two samples per wave and trip), forward and backward -- against float64 on the same (bf16-exact)
+    expert values, ragged batches and row widths that end inside a lane's eight columns."""
+    g = torch.Generator().manual_seed(8)
+    Ne, T = 4, 2
+    E16 = [torch.randn(B, H, generator=g).relu().to(torch.bfloat16).to(dev()) for _ in range(Ne)]
+    Gs = [torch.randn(B, Gd, generator=g).relu().to(dev()) for _ in range(T)]
+    Wg = [(torch.randn(Ne, Gd, generator=g) * 0.1).to(dev()) for _ in range(T)]
+    dmix = [torch.randn(B, H, generator=g).to(dev()) for _ in range(T)]
+    for out_dtype in (torch.bfloat16, torch.float32):
+        gates = [dict(G=Gs[t], Wg=Wg[t], P=torch.empty(B, Ne, device=dev()),
+                      mix=torch.empty(B, H, dtype=out_dtype, device=dev()), expert=list(range(Ne))) for t in range(T)]
+        ops.gate_mix_fwd(ops.make_gate_group(E16, gates, B, H))
+        dE = [torch.empty(B, H, dtype=out_dtype, device=dev()) for _ in range(Ne)]
+        for t in range(T):
+            gates[t].update(dmix=dmix[t], dG=torch.empty(B, Gd, device=dev()), dWg=torch.empty(Ne, Gd, device=dev()),
+                            g_relu=1, active=1)
+        ops.gate_mix_bwd(ops.make_gate_group(E16, gates, B, H, d_experts=dE, e_relu=True), dev())
+        torch.cuda.synchronize()
+        Ed = torch.stack([e.double() for e in E16], 1)                         # [B, Ne, H]
+        dE_ref = torch.zeros_like(Ed)
+        tol = 2.0 ** -7 if out_dtype == torch.bfloat16 else 2e-5
+        for t in range(T):
+            p = torch.softmax(Gs[t].double() @ Wg[t].double().t(), 1)          # [B, Ne]
+            mix = (p[:, :, None] * Ed).sum(1)
+            assert float((gates[t]["P"].double() - p).abs().max()) < 1e-5
+            assert float((gates[t]["mix"].double() - mix).abs().max()) <= tol * float(mix.abs().max())
+            dl = (dmix[t].double()[:, None, :] * Ed).sum(2)                    # [B, Ne]
+            dlogit = p * (dl - (p * dl).sum(1, keepdim=True))
+            dG = (dlogit @ Wg[t].double()) * (Gs[t] > 0)
+            assert float((gates[t]["dG"].double() - dG).abs().max()) <= 2e-5 * float(dG.abs().max())
+            dW = dlogit.t() @ Gs[t].double()
+            assert float((gates[t]["dWg"].double() - dW).abs().max()) <= 2e-5 * float(dW.abs().max())
+            dE_ref += p[:, :, None] * dmix[t].double()[:, None, :]
+        dE_ref = dE_ref * (Ed > 0)
+        for x in range(Ne):
+            assert float((dE[x].double() - dE_ref[:, x]).abs().max()) <= tol * float(dE_ref.abs().max())
+
+
 def test_row_kernels_write_bf16_operands(ops):
     """mml_gate_group.out_bf16 / mml_head_group.dh_bf16: the tensors only GEMMs read (mix; dE, dG; dH) leave the fast row
     kernels as bf16 -- exactly the fp32 results rounded to nearest even."""
@@ -304,10 +346,16 @@ def test_row_kernels_write_bf16_operands(ops):
     m16b, e16b, g16b, w16b = run(torch.bfloat16)
     E = [e.float() for e in E]
     m32b, e32b, g32b, w32b = run(torch.float32)
+    # (round 6: 256-wide bf16 expert rows run on 32-lane groups with eight columns per lane -- two samples per wave and
+    #  trip, 16-byte loads -- the fp32 rows of the comparison run on 64-lane groups: the same sums in another order, so
+    #  the rounded results agree to one bf16 step, and exactly almost everywhere)
     for a, b in zip(m32b + e32b + g32b, m16b + e16b + g16b):
-        assert torch.equal(a.to(torch.bfloat16), b)
+        ref = a.to(torch.bfloat16)
+        same = float((ref == b).float().mean())
+        dev_ = float(((ref.float() - b.float()).abs() / (a.abs() * 2.0 ** -7 + 1e-6 * float(a.abs().max()))).max())
+        assert same > 0.995 and dev_ <= 1.0, (same, dev_)
     for a, b in zip(w32b, w16b):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
     E = E_keep
     for a, b in zip(m32 + e32 + g32, m16 + e16 + g16):
         assert b.dtype == torch.bfloat16 and torch.equal(a.to(torch.bfloat16), b)

@@ -741,10 +741,18 @@ def test_bf16_storage_path_equals_operand_rounding_kuairec():
     dev = torch.device("cuda:0")
     res = {}
     old = os.environ.get("MMLREC_BF16_STORAGE")
+    old_e = os.environ.get("MMLREC_BF16_EXPERTS")
     try:
         lib.mml_gemm_set_mode(1)
-        for storage in ("1", "0"):
-            os.environ["MMLREC_BF16_STORAGE"] = storage
+        # (round 6: this model's expert outputs -- read by the gate kernels, not by a GEMM -- are bf16 buffers too by
+        #  default, one more rounding than "operands rounded at the GEMMs": the equivalence is stated with fp32 expert
+        #  outputs, MMLREC_BF16_EXPERTS=0, and the default is held against it below)
+        for storage in ("1", "0", "e16"):
+            os.environ["MMLREC_BF16_STORAGE"] = "1" if storage == "e16" else storage
+            if storage == "e16":
+                os.environ.pop("MMLREC_BF16_EXPERTS", None)
+            else:
+                os.environ["MMLREC_BF16_EXPERTS"] = "0"
             model, cfg, vocab, dense = W.build_model("mmoe_kuairec", dev, vocab_scale=0.05, seed=0, table_update="dense_exact")
             g = torch.Generator().manual_seed(3)
             with torch.no_grad():
@@ -763,7 +771,9 @@ def test_bf16_storage_path_equals_operand_rounding_kuairec():
             torch.cuda.synchronize()
             calls = list(step.plan.fwd) + list(step.plan.bwd) + list(step.plan.bwd_side)
             n16 = sum(c[0] in (lib.mml_g16_tn, lib.mml_g16_wgrad) for c in calls)
-            assert (n16 >= 9) == (storage == "1"), (storage, n16)
+            assert (n16 >= 9) == (storage != "0"), (storage, n16)
+            experts16 = all(v.is16 for v in step.plan.layer_outputs["expert_outputs"])
+            assert experts16 == (storage == "e16"), (storage, experts16)
             st = model._store()
             grads = {k: pv.grad.detach().float().cpu().numpy().copy() for k, pv in st.pvals.items() if pv.grad is not None}
             out = dict(loss=float(step.plan.loss.item()), prob=step.plan.prob.cpu().numpy().copy(), grads=grads)
@@ -785,6 +795,10 @@ def test_bf16_storage_path_equals_operand_rounding_kuairec():
             os.environ.pop("MMLREC_BF16_STORAGE", None)
         else:
             os.environ["MMLREC_BF16_STORAGE"] = old
+        if old_e is None:
+            os.environ.pop("MMLREC_BF16_EXPERTS", None)
+        else:
+            os.environ["MMLREC_BF16_EXPERTS"] = old_e
     a, b = res["1"], res["0"]
     assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(b["loss"]), (a["loss"], b["loss"])
     assert np.abs(a["prob"] - b["prob"]).max() < 1e-4
@@ -801,3 +815,15 @@ def test_bf16_storage_path_equals_operand_rounding_kuairec():
     for k in a["auto_grads"]:
         if k in a["grads"]:
             assert rms_rel(a["auto_grads"][k], a["grads"][k]) < 6e-3, k
+    # the default of the bf16-storage mode (expert outputs stored as bf16, read by the eight-columns-per-lane gate kernels):
+    # one bf16 rounding of the expert outputs away from the path above
+    c = res["e16"]
+    assert abs(c["loss"] - a["loss"]) <= 1e-4 * abs(a["loss"]), (c["loss"], a["loss"])
+    assert np.abs(c["prob"] - a["prob"]).max() < 1e-3
+    assert abs(c["auto_loss"] - c["loss"]) <= 1e-5 * abs(c["loss"])
+    table_e = {k: round(float(rms_rel(c["grads"][k], a["grads"][k])), 5) for k in a["grads"]}
+    print("bf16 expert outputs vs fp32 expert outputs (both bf16 storage), relative rms per gradient:", table_e)
+    # (measured 0.5-2.5 % -- the gates' gradients, differences of nearly equal dot products, the most -- where either
+    #  variant is several % from the fp32 gradients at this batch size: tools/lab/diag_bf16_modes.py)
+    for k in a["grads"]:
+        assert table_e[k] < 5e-2, (k, table_e)
