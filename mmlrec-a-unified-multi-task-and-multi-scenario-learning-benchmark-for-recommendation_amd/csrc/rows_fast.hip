@@ -256,11 +256,17 @@ __global__ __launch_bounds__(FB) void gate_fwd_once_kernel(const mml_gate_group 
     if (b >= g.B) b = g.B - 1;
 #pragma unroll
     for (int x = 0; x < NE; ++x) {
-      if constexpr (HV == 2) {  // (bf16 rows: eight values = one 16-byte load, widened exactly)
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (hcol && x < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[x]) + b * g.lde[x] + 8 * sub);
-        Evn[x][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
-        Evn[x][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+      if constexpr (HV == 2) {
+        if (g.out_bf16 & MML_GATE_E_BF16) {  // (launch-uniform) bf16 rows: eight values = one 16-byte load, widened exactly
+          uint4 q = make_uint4(0, 0, 0, 0);
+          if (hcol && x < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[x]) + b * g.lde[x] + 8 * sub);
+          Evn[x][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+          Evn[x][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+        } else {                             // fp32 rows: two 16-byte loads
+          const bool on = hcol && x < g.n_experts;
+          Evn[x][0] = on ? ld4(g.E[x] + b * g.lde[x] + 8 * sub) : make_float4(0, 0, 0, 0);
+          Evn[x][1] = on ? ld4(g.E[x] + b * g.lde[x] + 8 * sub + 4) : make_float4(0, 0, 0, 0);
+        }
       } else {
         Evn[x][0] = (hcol && x < g.n_experts) ? ld4i(g.E[x], b * g.lde[x] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
       }
@@ -460,10 +466,16 @@ __global__ __launch_bounds__(FB) void gate_bwd_fast_kernel(const mml_gate_group 
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       if constexpr (HV == 2) {
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (hcol && e < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[e]) + b * g.lde[e] + 8 * sub);
-        Ev[e][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
-        Ev[e][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+        if (g.out_bf16 & MML_GATE_E_BF16) {
+          uint4 q = make_uint4(0, 0, 0, 0);
+          if (hcol && e < g.n_experts) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.E[e]) + b * g.lde[e] + 8 * sub);
+          Ev[e][0] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+          Ev[e][1] = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+        } else {
+          const bool on = hcol && e < g.n_experts;
+          Ev[e][0] = on ? ld4(g.E[e] + b * g.lde[e] + 8 * sub) : make_float4(0, 0, 0, 0);
+          Ev[e][1] = on ? ld4(g.E[e] + b * g.lde[e] + 8 * sub + 4) : make_float4(0, 0, 0, 0);
+        }
       } else {
         Ev[e][0] = (hcol && e < g.n_experts) ? ld4i(g.E[e], b * g.lde[e] + 4 * sub, (g.out_bf16 & MML_GATE_E_BF16) != 0) : make_float4(0, 0, 0, 0);
       }
@@ -1044,20 +1056,30 @@ int gate_fast_config(const mml_gate_group* g, bool bwd, GateFastAux& aux) {
     const char* e = getenv("MMLREC_GATE_BWD_MODE");
     bwd_forced = e ? atoi(e) : -1;
   }
-  if ((g->out_bf16 & MML_GATE_E_BF16) && g->H > 128 && g->H % 8 == 0 && aux.ne == 4 && aux.ng == 2 && gate_pack_on() &&
+  // (lab, MMLREC_GATE_HV=2: the same form on 16-lane groups for fp32 rows of 65..128 columns under gate inputs of at most 64 --
+  //  AE-30's MMoE: four samples per wave and trip)
+  static int hv16 = -1;
+  if (hv16 < 0) {
+    const char* e = getenv("MMLREC_GATE_HV");
+    hv16 = (e && atoi(e) == 2) ? 1 : 0;
+  }
+  const bool wide16 = (g->out_bf16 & MML_GATE_E_BF16) && g->H > 128;
+  const bool narrow32 = hv16 && !(g->out_bf16 & MML_GATE_E_BF16) && g->H > 64 && g->H <= 128;
+  if ((wide16 || narrow32) && g->H % 8 == 0 && aux.ne == 4 && aux.ng == 2 && gate_pack_on() &&
       (!bwd || (aux.ident && bwd_forced == -1))) {
+    const int lps_hv = wide16 ? 32 : 16, gd_max = wide16 ? 128 : 64;
     static int hv_on = -1;
     if (hv_on < 0) {
       const char* e = getenv("MMLREC_GATE_HV");
       hv_on = (e && atoi(e) == 0) ? 0 : 1;
     }
-    bool ok = hv_on != 0 && g->n_experts <= 4 && (bwd || gate_fwd_once_ok(*g, aux, 32));  // (only these kernels have the form)
+    bool ok = hv_on != 0 && g->n_experts <= 4 && (bwd || gate_fwd_once_ok(*g, aux, lps_hv));  // (only these kernels have the form)
     for (int x = 0; x < g->n_experts && ok; ++x)
       ok = g->lde[x] % 8 == 0 && (!bwd || g->ldde[x] % ((g->out_bf16 & MML_GATE_DE_BF16) ? 8 : 4) == 0);
     for (int i = 0; i < g->n_gates && ok; ++i)
-      ok = g->gate[i].Gd <= 128 && (bwd || g->gate[i].ldmix % ((g->out_bf16 & MML_GATE_MIX_BF16) ? 8 : 4) == 0);
+      ok = g->gate[i].Gd <= gd_max && (bwd || g->gate[i].ldmix % ((g->out_bf16 & MML_GATE_MIX_BF16) ? 8 : 4) == 0);
     if (ok) {
-      aux.lps = 32;
+      aux.lps = lps_hv;
       aux.hv = 2;
     }
   }
@@ -1090,9 +1112,9 @@ static void launch_gate_fwd(const mml_gate_group& g, const GateFastAux& aux, hip
   if (gate_fwd_once_ok(g, aux, LPS)) {
 #define MML_GF(NE_, NG_) MML_LAUNCH((gate_fwd_once_kernel<LPS, NE_, NG_>), gr, bl, lds1, st, g, aux)
     if (aux.ne == 4 && aux.ng == 2) {
-      if constexpr (LPS == 32) {
+      if constexpr (LPS == 32 || LPS == 16) {
         if (aux.hv == 2) {
-          MML_LAUNCH((gate_fwd_once_kernel<32, 4, 2, true, 2>), gr, bl, lds1, st, g, aux);
+          MML_LAUNCH((gate_fwd_once_kernel<LPS, 4, 2, true, 2>), gr, bl, lds1, st, g, aux);
           return;
         }
       }
@@ -1147,7 +1169,7 @@ static int launch_gate_bwd(const mml_gate_group& g, const GateFastAux& aux, hipS
     else MML_LAUNCH((gate_bwd_fast_kernel<LPS, NE_, NG_, 0>), gr, bl, lds, st, g, aux);   \
   } while (0)
   if (aux.hv == 2) {  // (gate_fast_config: the MMoE form on 32-lane groups)
-    if constexpr (LPS == 32) MML_LAUNCH((gate_bwd_fast_kernel<32, 4, 2, 1, 2>), gr, bl, lds, st, g, aux);
+    if constexpr (LPS == 32 || LPS == 16) MML_LAUNCH((gate_bwd_fast_kernel<LPS, 4, 2, 1, 2>), gr, bl, lds, st, g, aux);
     else return 1;
   } else if (aux.ne == 4 && aux.ng == 2) MML_GB(4, 2);
   else if (aux.ne == 4 && aux.ng == 4) MML_GB(4, 4);
