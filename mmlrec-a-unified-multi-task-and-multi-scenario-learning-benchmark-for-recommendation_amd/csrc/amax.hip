@@ -86,6 +86,11 @@ extern "C" int mml_amax_batch(const mml_amax_desc* d, int32_t n, mml_stream_t st
       // (warm caches, eager launch included; tools/lab/bench_amax.py).  Since the workgroups look at the slot before the
       // atomic (amax_flush<true>) the count no longer matters: 20 us at 256, 2 048 and 4 096.
       if (nb > cap) nb = cap;
+      // Round 6: tensors of at most 32 MB (PepNet's [65 536, 80] gate inputs, 21 MB) on at most 256 workgroups: their pass is
+      // its fixed costs -- launch, one look at / atomic on the slot's line per workgroup -- not bandwidth: 17-18 -> 12-13 us
+      // per launch (amax_kernel 35 -> 25 us per PepNet step; 128 the same, 512 30 us).
+      static const bool cap_env = getenv("MMLREC_AMAX_BLOCKS") != nullptr;
+      if (!cap_env && q.rows * (int64_t)q.cols <= ((int64_t)8 << 20) && nb > 256) nb = 256;
       L.blk0[L.n] = total;
       L.t[L.n++] = q;
       total += (int)nb;
