@@ -647,7 +647,9 @@ int mml_tower_head_fwd_bwd(const mml_tower_head_group* grp, void* workspace, int
 /* ------------------------------------------------------------------------------------------------
  * K3'  bf16-STORAGE GEMM family (round 5; csrc/gemm16.hip) -- BASELINE.json configs[1] ("MMoE ... KuaiRec-shaped ...
  * bf16"): the DNN layers of model/utils.py:146-161 with activations and their gradients STORED as bf16 wherever
- * producer and consumers are GEMMs.  Arithmetic: one v_mfma_f32_32x32x16_bf16 per 16-k block, fp32 accumulation --
+ * producer and consumers are GEMMs (and, round 6, the expert outputs of an MMoE whose gate kernels read bf16 rows
+ * sixteen bytes per lane: mml_gate_group.out_bf16 bit 3 -- one rounding of those outputs more than operand rounding at
+ * the GEMMs).  Arithmetic: one v_mfma_f32_32x32x16_bf16 per 16-k block, fp32 accumulation --
  * exactly the products of mml_gemm_set_mode(1) (operands rounded to bf16, there in registers, here when they are
  * stored), with half the activation traffic and no conversion work in the kernels: bf16 tiles go HBM -> LDS by DMA and
  * LDS -> MFMA fragments as they are (ds_read_b128; the batch-reduction of the weight gradient through the transposing
