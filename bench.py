@@ -105,14 +105,22 @@ def spawn_ranks(args):
     if ndev is not None and ndev < args.gpus and not share:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for attempt in range(3):
+        # (the port is probed free here and bound by the launcher a moment later: if something else on the host took it in
+        #  between -- EADDRINUSE, seen once in ~30 runs of the test suite -- the launcher dies at once and the launch is
+        #  repeated on another port)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t_launch = time.time()
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # (stderr streams: the preflight line, progress)
+        # (a launcher that cannot bind its port dies within seconds, before any rank exists)
+        if r.returncode == 0 or time.time() - t_launch > 30.0 or '"metric"' in r.stdout:
+            break
     lines = r.stdout.splitlines()
     js = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
     for ln in lines:
